@@ -1,0 +1,729 @@
+/*
+ * dust_oracle.c - CPU ORACLE (test infrastructure, NOT product code; see dust_oracle.h).
+ *
+ * Plain scalar C restatement of the reference's per-tick SVGD-MPC algorithm.  Citations are file:line into
+ * lubaroli/dust.  Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/build.py).
+ * -ffp-contract=off matters: torch-CPU elementwise ops round after every operation, and the rollout is chaotic
+ * (pendulum) / discontinuous (occupancy grid), so the order and rounding of each fp32 operation is followed.
+ */
+#include "dust_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI_F ((float)3.14159265358979323846)
+#define LN2_F 0.69314718055994530942f /* softplus(0): gpytorch RBFKernel lengthscale, never changed (svmpc.py:78 typo) */
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ---- Python/torch mixed scalar-tensor arithmetic, as the interpreter evaluates pendulum.py:93-96 ----
+ * kind 0: Python float (double);  kind 1/2: fp32 tensor element. */
+typedef struct {
+  int t;
+  double d;
+  float f;
+} val;
+static inline float tof(val v) { return v.t ? v.f : (float)v.d; }
+static inline val v_py(double d) { val v = {0, d, 0.f}; return v; }
+static inline val v_t(float f) { val v = {1, 0.0, f}; return v; }
+static inline val v_mul(val a, val b) {
+  if (!a.t && !b.t) return v_py(a.d * b.d);
+  return v_t(tof(a) * tof(b));
+}
+static inline val v_div(val a, val b) {
+  if (!a.t && !b.t) return v_py(a.d / b.d);
+  if (a.t && !b.t) return v_t(a.f / (float)b.d);
+  if (!a.t && b.t) return v_t((1.0f / b.f) * (float)a.d); /* Tensor.__rtruediv__ = reciprocal() * other */
+  return v_t(a.f / b.f);
+}
+static inline val v_sq(val a) { return a.t ? v_t(a.f * a.f) : v_py(a.d * a.d); }
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static inline val get_param(const orc_cfg *c, orc_param p, const float *prow) {
+  if (p.is_tensor == 1 && prow) {
+    float v = prow[p.col];
+    if (c->params_log_space) v = expf(v);
+    return v_t(v);
+  }
+  if (p.is_tensor == 2) return v_t((float)p.value);
+  return v_py(p.value);
+}
+
+/* obstacle_map.py:64-93 */
+static inline float collision(const orc_cfg *c, float px, float py) {
+  float inv = (float)(1.0 / c->cell_size);
+  float fx = floorf(px * inv + c->off_x);
+  float fy = floorf(py * inv + c->off_y);
+  /* .type(LongTensor): x86 cvttss2si gives INT64_MIN for NaN / out-of-range, which then clamps to 0 */
+  int64_t ix = (fx >= -9.2e18f && fx <= 9.2e18f) ? (int64_t)fx : INT64_MIN;
+  int64_t iy = (fy >= -9.2e18f && fy <= 9.2e18f) ? (int64_t)fy : INT64_MIN;
+  if (ix < 0) ix = 0;
+  if (ix > c->nx - 1) ix = c->nx - 1;
+  if (iy < 0) iy = 0;
+  if (iy > c->ny - 1) iy = c->ny - 1;
+  return c->grid[ix * c->ny + iy];
+}
+
+void orc_get_collisions(const orc_cfg *c, int n, const float *xy, float *out) {
+  for (int i = 0; i < n; ++i) out[i] = collision(c, xy[2 * i], xy[2 * i + 1]);
+}
+
+/* PendulumModel.step pendulum.py:61-100 */
+static inline void pendulum_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
+  val g = get_param(c, c->g, prow), m = get_param(c, c->mass, prow), l = get_param(c, c->length, prow);
+  float dt = (float)c->dt;
+  float u = clampf(a[0], -(float)c->max_torque, (float)c->max_torque);
+  float s = sinf(x[0] + PI_F);
+  val cg = v_div(v_mul(v_py(-3.0), g), v_mul(v_py(2.0), l)); /* -3 * g / (2 * length) */
+  val cu = v_div(v_py(3.0), v_mul(m, v_sq(l)));              /* 3.0 / (m * length ** 2) */
+  float t1 = tof(cg) * s;
+  float t2 = tof(cu) * u;
+  float thd = x[1] + dt * (t1 + t2);
+  thd = clampf(thd, -(float)c->max_speed_pend, (float)c->max_speed_pend);
+  out[0] = x[0] + thd * dt;
+  out[1] = thd;
+}
+
+/* Particle.step particle.py:117-166 (deterministic=True; control noise 145-148 not modelled) */
+static inline void particle_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
+  val m = get_param(c, c->pmass, prow);
+  float mf = tof(m);
+  float dt = (float)c->dt;
+  float ax = clampf(a[0] / mf, -c->max_acc, c->max_acc);
+  float ay = clampf(a[1] / mf, -c->max_acc, c->max_acc);
+  float xd[4] = {x[2], x[3], ax, ay};
+  if (c->can_crash && c->with_obstacle) {
+    float om = 1.0f - collision(c, x[0], x[1]);
+    for (int k = 0; k < 4; ++k) out[k] = x[k] + (xd[k] * dt) * om;
+  } else {
+    for (int k = 0; k < 4; ++k) out[k] = x[k] + xd[k] * dt;
+  }
+  out[2] = clampf(out[2], -c->max_speed, c->max_speed);
+  out[3] = clampf(out[3], -c->max_speed, c->max_speed);
+}
+
+static inline void model_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
+  if (c->model == ORC_MODEL_PENDULUM)
+    pendulum_step(c, x, a, prow, out);
+  else
+    particle_step(c, x, a, prow, out);
+}
+
+void orc_model_step(const orc_cfg *c, int n, const float *states, const float *actions, int action_rows,
+                    const float *params, float *next) {
+  for (int i = 0; i < n; ++i) {
+    const float *a = actions + (size_t)(action_rows == 1 ? 0 : i) * c->da;
+    model_step(c, states + (size_t)i * c->ds, a, params ? params + (size_t)i * c->P : NULL, next + (size_t)i * c->ds);
+  }
+}
+
+/* demo/pendulum_example.py:21-28 ; particle.py:170-225 */
+static inline float inst_cost(const orc_cfg *c, const float *x, const float *a) {
+  if (c->model == ORC_MODEL_PENDULUM) {
+    float cm = cosf(x[0]) - 1.0f;
+    float t1 = (float)c->w_cos * (cm * cm);
+    float t2 = (float)c->w_vel * (x[1] * x[1]);
+    return t1 + t2;
+  }
+  double sc = 0.0, cc = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    float d = x[k] - c->target[k];
+    sc += (double)((d * d) * c->w_state[k]);
+  }
+  for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * c->w_ctrl[k]);
+  float ob = c->with_obstacle ? c->w_obs * collision(c, x[0], x[1]) : 0.0f;
+  return ((float)sc + (float)cc) + ob;
+}
+static inline float term_cost(const orc_cfg *c, const float *x) {
+  if (c->model == ORC_MODEL_PENDULUM) return inst_cost(c, x, NULL);
+  double sc = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    float d = x[k] - c->target[k];
+    sc += (double)((d * d) * c->w_term[k]);
+  }
+  float ob = c->with_obstacle ? c->w_obs * collision(c, x[0], x[1]) : 0.0f;
+  return (float)sc + ob;
+}
+
+/* likelihoods.py:85-90: Independent(MVN(theta, Sigma_a)).rsample([S]) = theta + L eps */
+void orc_sample_actions(const orc_cfg *c, const float *theta, const float *eps, const float *chol_a, float *actions) {
+  const int D = c->H * c->da;
+  for (int s = 0; s < c->S; ++s)
+    for (int n = 0; n < c->N; ++n)
+      for (int j = 0; j < D; ++j) {
+        size_t i = ((size_t)s * c->N + n) * D + j;
+        actions[i] = theta[(size_t)n * D + j] + chol_a[j % c->da] * eps[i];
+      }
+}
+
+/* disco.py:139-209 (rollout), 294-346 (cost) */
+void orc_rollout_cost(const orc_cfg *c, const float *state, const float *actions, const float *params, float a_reg,
+                      const float *a_mat, const float *a_seq, const float *a_pre_diag, float *states_out, float *costs) {
+  const int N = c->N, S = c->S, M = c->M, H = c->H, da = c->da, ds = c->ds;
+  const long SN = (long)S * N;
+#pragma omp parallel for schedule(static)
+  for (long sn = 0; sn < SN; ++sn) {
+    const int s = (int)(sn / N), n = (int)(sn % N);
+    const float *act = actions + (size_t)sn * H * da;
+    double acc_m = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const long r = (long)m * SN + sn;
+      const float *prow = NULL;
+      if (params) prow = params + (size_t)(c->params_interleave ? (r % M) : m) * c->P;
+      float x[8], xn[8];
+      for (int k = 0; k < ds; ++k) x[k] = state[k];
+      float *so = states_out ? states_out + (size_t)r * (H + 1) * ds : NULL;
+      if (so)
+        for (int k = 0; k < ds; ++k) so[k] = x[k];
+      double tot = 0.0;
+      for (int t = 0; t < H; ++t) {
+        tot += (double)inst_cost(c, x, act + (size_t)t * da); /* cost of the state BEFORE the action (disco.py:306) */
+        model_step(c, x, act + (size_t)t * da, prow, xn);
+        for (int k = 0; k < ds; ++k) x[k] = xn[k];
+        if (so)
+          for (int k = 0; k < ds; ++k) so[(size_t)(t + 1) * ds + k] = x[k];
+      }
+      float traj = (float)tot + term_cost(c, x);
+      acc_m += (double)traj;
+    }
+    float cost = (float)(acc_m / M);
+    if (a_reg != 0.0f) { /* disco.py:338-346: only the diagonal of the [S,N,N] tensordot survives */
+      double cc = 0.0;
+      for (int t = 0; t < H; ++t)
+        for (int d = 0; d < da; ++d) {
+          float e = act[t * da + d] - a_seq[t * da + d];
+          cc += (double)(-e) * (double)(a_mat[((size_t)n * H + t) * da + d] * a_pre_diag[d]);
+        }
+      cost = cost + a_reg * (float)cc;
+    }
+    costs[(size_t)s * N + n] = cost;
+  }
+}
+
+static double lse(const double *v, int n) {
+  double m = -INFINITY;
+  for (int i = 0; i < n; ++i)
+    if (v[i] > m) m = v[i];
+  if (!(m > -INFINITY)) return m;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += exp(v[i] - m);
+  return m + log(s);
+}
+
+/* disco.py:380-393 */
+void orc_disco_weights(const orc_cfg *c, const float *costs, const float *actions, const float *eps_base,
+                       int base_per_policy, float temp, float *omega, float *a_mat, float *a_mix) {
+  const int N = c->N, S = c->S, D = c->H * c->da;
+  float beta = INFINITY;
+  for (long i = 0; i < (long)S * N; ++i)
+    if (costs[i] < beta) beta = costs[i];
+  double *eta = (double *)malloc(sizeof(double) * N);
+  double *col = (double *)malloc(sizeof(double) * S);
+  for (int n = 0; n < N; ++n) {
+    for (int s = 0; s < S; ++s) col[s] = (double)((-1.0f * (costs[(size_t)s * N + n] - beta)) / temp);
+    eta[n] = lse(col, S);
+    for (int s = 0; s < S; ++s) {
+      float w = (float)exp(col[s] - eta[n]);
+      if (omega) omega[(size_t)s * N + n] = w;
+      col[s] = w;
+    }
+    if (a_mat)
+      for (int j = 0; j < D; ++j) {
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) acc += col[s] * (double)(actions[((size_t)s * N + n) * D + j] -
+                                   eps_base[base_per_policy ? (size_t)n * D + j : (size_t)j]);
+        a_mat[(size_t)n * D + j] += (float)acc;
+      }
+  }
+  double z = lse(eta, N);
+  if (a_mix)
+    for (int n = 0; n < N; ++n) a_mix[n] = (float)exp(eta[n] - z);
+  free(eta);
+  free(col);
+}
+
+/* torch.distributions.Categorical(probs=w) + MixtureSameFamily.log_prob's log_softmax(logits):
+ * probs are normalised, clamped to [eps, 1-eps] (probs_to_logits), logged, then log_softmax'ed. */
+void orc_log_mix(int n, const float *weights, float *logmix) {
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += weights[i];
+  float fs = (float)sum;
+  double *lg = (double *)malloc(sizeof(double) * n);
+  for (int i = 0; i < n; ++i) {
+    float p = weights[i] / fs;
+    p = clampf(p, FLT_EPSILON, 1.0f - FLT_EPSILON);
+    lg[i] = (double)logf(p);
+  }
+  double z = lse(lg, n);
+  for (int i = 0; i < n; ++i) logmix[i] = (float)(lg[i] - z);
+  free(lg);
+}
+
+/* svmpc.py:38-56 */
+void orc_score(const orc_cfg *c, const float *theta, const float *mu, const float *logmix, const float *sigma_p,
+               const float *costs, const float *actions, float alpha, const float *sigma_a, float *grad_lik,
+               float *grad_pri, float *score) {
+  const int N = c->N, S = c->S, D = c->H * c->da, da = c->da;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; ++i) {
+    double *lg = (double *)malloc(sizeof(double) * (N > S ? N : S));
+    /* prior score: grad_x log sum_k pi_k N(x; mu_k, diag sigma_p^2) = sum_k r_ik (mu_k - x)/sigma_p^2 (svmpc.py:41) */
+    for (int k = 0; k < N; ++k) {
+      double q = 0.0;
+      for (int j = 0; j < D; ++j) {
+        double z = ((double)theta[(size_t)i * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
+        q += z * z;
+      }
+      lg[k] = (double)logmix[k] - 0.5 * q;
+    }
+    double z = lse(lg, N);
+    for (int j = 0; j < D; ++j) {
+      double acc = 0.0, sp = (double)sigma_p[j % da];
+      for (int k = 0; k < N; ++k)
+        acc += exp(lg[k] - z) * ((double)mu[(size_t)k * D + j] - (double)theta[(size_t)i * D + j]) / (sp * sp);
+      if (grad_pri) grad_pri[(size_t)i * D + j] = (float)acc;
+      if (score) score[(size_t)i * D + j] = (float)acc;
+    }
+    /* likelihood score: sum_s softmax_s(-alpha c)(a - x)/sigma^2 (svmpc.py:47-54) */
+    if (costs) {
+      for (int s = 0; s < S; ++s) lg[s] = (double)(-costs[(size_t)s * N + i] * alpha);
+      double zz = lse(lg, S);
+      for (int j = 0; j < D; ++j) {
+        float sa = sigma_a[j % da];
+        float s2 = sa * sa;
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) {
+          float dlp = (actions[((size_t)s * N + i) * D + j] - theta[(size_t)i * D + j]) / s2;
+          acc += (double)(float)exp(lg[s] - zz) * (double)dlp;
+        }
+        if (grad_lik) grad_lik[(size_t)i * D + j] = (float)acc;
+        if (score) score[(size_t)i * D + j] = (float)acc + score[(size_t)i * D + j];
+      }
+    }
+    free(lg);
+  }
+}
+
+/* svmpc.py:76-83 with gpytorch RBFKernel semantics (lengthscale ln 2). */
+void orc_phi_k1(int N, int D, const float *theta, const float *score, int variant, float *phi, float *gram) {
+  float *K = (float *)malloc(sizeof(float) * (size_t)N * N);
+  const double ell = (double)LN2_F;
+  if (variant == 0) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        double q = 0.0;
+        for (int d = 0; d < D; ++d) {
+          double z = ((double)theta[(size_t)i * D + d] - (double)theta[(size_t)j * D + d]) / ell;
+          q += z * z;
+        }
+        K[(size_t)i * N + j] = (float)exp(-0.5 * q);
+      }
+  } else { /* fp32 mean-centred matmul trick + clamp_min(0), as gpytorch's sq_dist computes it */
+    float *xs = (float *)malloc(sizeof(float) * (size_t)N * D);
+    float *nrm = (float *)malloc(sizeof(float) * N);
+    for (int d = 0; d < D; ++d) {
+      double m = 0.0;
+      for (int i = 0; i < N; ++i) m += (double)(theta[(size_t)i * D + d] / LN2_F);
+      float mean = (float)(m / N);
+      for (int i = 0; i < N; ++i) xs[(size_t)i * D + d] = theta[(size_t)i * D + d] / LN2_F - mean;
+    }
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) s += (double)(xs[(size_t)i * D + d] * xs[(size_t)i * D + d]);
+      nrm[i] = (float)s;
+    }
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) acc += (-2.0f * xs[(size_t)i * D + d]) * xs[(size_t)j * D + d];
+        acc += nrm[i];
+        acc += nrm[j];
+        if (acc < 0.0f) acc = 0.0f;
+        K[(size_t)i * N + j] = expf(acc / -2.0f);
+      }
+    free(xs);
+    free(nrm);
+  }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; ++i)
+    for (int d = 0; d < D; ++d) {
+      double gk = 0.0, ks = 0.0;
+      for (int j = 0; j < N; ++j) {
+        double k = (double)K[(size_t)i * N + j];
+        gk += -k * ((double)theta[(size_t)i * D + d] - (double)theta[(size_t)j * D + d]) / (ell * ell);
+        ks += k * (double)score[(size_t)j * D + d];
+      }
+      phi[(size_t)i * D + d] = (float)(gk + ks / N); /* grad_k is NOT divided by N (svmpc.py:83) */
+    }
+  if (gram) memcpy(gram, K, sizeof(float) * (size_t)N * N);
+  free(K);
+}
+
+/* IMQ: k = (1 + |x-y|^2/ell^2)^(-1/2); same phi structure as the K1 branch (first-argument gradient, not /N).
+ * New feature named by BASELINE.json; NO reference implementation exists => parity unpinned by construction. */
+void orc_phi_imq(int N, int D, const float *theta, const float *score, float ell, float *phi) {
+  const double l2 = (double)ell * (double)ell;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < N; ++i) {
+    double *acc = (double *)calloc((size_t)D, sizeof(double));
+    for (int j = 0; j < N; ++j) {
+      double q = 0.0;
+      for (int d = 0; d < D; ++d) {
+        double z = (double)theta[(size_t)i * D + d] - (double)theta[(size_t)j * D + d];
+        q += z * z;
+      }
+      double base = 1.0 + q / l2;
+      double k = 1.0 / sqrt(base);
+      double dk = -k / base / l2; /* d k / d x_i = dk * (x_i - x_j) */
+      for (int d = 0; d < D; ++d)
+        acc[d] += dk * ((double)theta[(size_t)i * D + d] - (double)theta[(size_t)j * D + d]) +
+                  k * (double)score[(size_t)j * D + d] / N;
+    }
+    for (int d = 0; d < D; ++d) phi[(size_t)i * D + d] = (float)acc[d];
+    free(acc);
+  }
+}
+
+static int cmp_float(const void *a, const void *b) {
+  float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+
+/* svmpc.py:64-74 -> composite_kernels.py:33-64 -> base_kernels.py:53-108 */
+void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, const float *theta, const float *score, float *phi,
+                float *h_out) {
+  const int D = H * da;
+  const int G = indep ? D : H;      /* number of independent kernels */
+  const int gd = indep ? 1 : da;    /* dims per kernel */
+  float *pw = (float *)malloc(sizeof(float) * (size_t)N * N);
+  float *srt = (float *)malloc(sizeof(float) * (size_t)N * N);
+  for (int gI = 0; gI < G; ++gI) {
+    const int c0 = gI * gd;
+    /* compute_bandwidth base_kernels.py:59-63: -2 XY + XX.diag + YY.diag, all fp32 */
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        float xy = 0.f, xx = 0.f, yy = 0.f;
+        for (int q = 0; q < gd; ++q) {
+          float a = theta[(size_t)i * D + c0 + q], b = theta[(size_t)j * D + c0 + q];
+          xy += a * b;
+          xx += a * a;
+          yy += b * b;
+        }
+        pw[(size_t)i * N + j] = (-2.0f * xy + xx) + yy;
+      }
+    memcpy(srt, pw, sizeof(float) * (size_t)N * N);
+    qsort(srt, (size_t)N * N, sizeof(float), cmp_float);
+    float h = srt[((size_t)N * N - 1) / 2]; /* torch.median: lower middle */
+    h = h / (float)log((double)N + 1.0);
+    h = bw_scale * h;
+    if (h < 1e-5f) h = 1e-5f;
+    if (h_out) h_out[gI] = h;
+    for (int i = 0; i < N; ++i)
+      for (int q = 0; q < gd; ++q) {
+        double g1 = 0.0, g2 = 0.0;
+        for (int j = 0; j < N; ++j) {
+          float k = expf(-pw[(size_t)i * N + j] / h);
+          float dk = ((k * (theta[(size_t)i * D + c0 + q] - theta[(size_t)j * D + c0 + q])) * 2.0f) / h;
+          g1 += (double)(k * score[(size_t)j * D + c0 + q]);
+          g2 += (double)dk;
+        }
+        phi[(size_t)i * D + c0 + q] = (float)(g1 / N) + (float)(g2 / N);
+      }
+  }
+  free(pw);
+  free(srt);
+}
+
+void orc_sgd(int n, float lr, const float *phi, float *theta) {
+  for (int i = 0; i < n; ++i) theta[i] = fmaf(lr, phi[i], theta[i]); /* add_(grad, alpha=-lr) is a vec fmadd */
+}
+
+/* svmpc.py:128-200 */
+void orc_forward(const orc_cfg *c, int lik_kind, float alpha, const float *costs, float *theta, float *mu,
+                 float *mix_weights, const float *sigma_p, int weighted_prior, int roll_strategy, float *log_l,
+                 float *log_p, float *p_weights, int *i_star, float *a_seq) {
+  const int N = c->N, S = c->S, H = c->H, da = c->da, D = H * da;
+  float *logmix = (float *)malloc(sizeof(float) * N);
+  double *lw = (double *)malloc(sizeof(double) * N);
+  double *tmp = (double *)malloc(sizeof(double) * (N > S ? N : S));
+  orc_log_mix(N, mix_weights, logmix);
+  double logdet = 0.0;
+  for (int d = 0; d < da; ++d) logdet += log((double)sigma_p[d]);
+  for (int n = 0; n < N; ++n) {
+    double ll;
+    if (lik_kind == ORC_LIK_EXP_UTILITY) { /* likelihoods.py:127-135 */
+      for (int s = 0; s < S; ++s) tmp[s] = (double)(-alpha * costs[(size_t)s * N + n]);
+      ll = (double)((float)lse(tmp, S) - logf((float)S));
+    } else { /* likelihoods.py:113-119 */
+      double m = 0.0;
+      for (int s = 0; s < S; ++s) m += costs[(size_t)s * N + n];
+      ll = (double)(-alpha * (float)(m / S));
+    }
+    for (int k = 0; k < N; ++k) {
+      double q = 0.0;
+      for (int j = 0; j < D; ++j) {
+        double z = ((double)theta[(size_t)n * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
+        q += z * z;
+      }
+      tmp[k] = (double)logmix[k] - 0.5 * q - H * logdet - 0.5 * D * log(2.0 * M_PI);
+    }
+    double lp = lse(tmp, N);
+    if (log_l) log_l[n] = (float)ll;
+    if (log_p) log_p[n] = (float)lp;
+    lw[n] = (double)((float)ll + (float)lp);
+  }
+  double z = lse(lw, N);
+  int best = 0;
+  for (int n = 0; n < N; ++n) {
+    p_weights[n] = (float)exp(lw[n] - z);
+    if (p_weights[n] > p_weights[best]) best = n;
+  }
+  if (i_star) *i_star = best;
+  for (int j = 0; j < D; ++j) a_seq[j] = theta[(size_t)best * D + j];
+  /* roll svmpc.py:142-158 */
+  for (int n = 0; n < N; ++n) {
+    float *th = theta + (size_t)n * D;
+    double mean[8] = {0};
+    for (int t = 0; t < H; ++t)
+      for (int d = 0; d < da; ++d) mean[d] += th[t * da + d];
+    for (int t = 0; t + 1 < H; ++t)
+      for (int d = 0; d < da; ++d) th[t * da + d] = th[(t + 1) * da + d];
+    if (roll_strategy == ORC_ROLL_MEAN)
+      for (int d = 0; d < da; ++d) th[(H - 1) * da + d] = (float)(mean[d] / H);
+    /* "repeat": the last row already equals the old last row */
+  }
+  /* update_prior svmpc.py:160-170 */
+  memcpy(mu, theta, sizeof(float) * (size_t)N * D);
+  for (int n = 0; n < N; ++n) mix_weights[n] = weighted_prior ? p_weights[n] : 1.0f;
+  free(logmix);
+  free(lw);
+  free(tmp);
+}
+
+/* disco.py:396-417 */
+void orc_disco_step(int N, int H, int da, int strategy, int steps, const float *min_a, const float *max_a,
+                    const float *ext, float *a_mat, const float *a_mix, float *a_seq, float *next_actions) {
+  const int D = H * da;
+  if (strategy == 0) {
+    int best = 0;
+    for (int n = 1; n < N; ++n)
+      if (a_mix[n] > a_mix[best]) best = n;
+    for (int j = 0; j < D; ++j) a_seq[j] = a_mat[(size_t)best * D + j];
+  } else if (strategy == 1) {
+    for (int j = 0; j < D; ++j) {
+      double acc = 0.0;
+      for (int n = 0; n < N; ++n) acc += (double)a_mat[(size_t)n * D + j] * (double)a_mix[n];
+      a_seq[j] = (float)acc;
+    }
+  } else {
+    for (int j = 0; j < D; ++j) a_seq[j] = ext[j];
+  }
+  for (int j = 0; j < D; ++j) a_seq[j] = clampf(a_seq[j], min_a[j % da], max_a[j % da]);
+  if (strategy == 0) { /* quirk: a_mat[argmax] is a VIEW, so the in-place clamp_ (disco.py:410) also clamps that a_mat row */
+    int best = 0;
+    for (int n = 1; n < N; ++n)
+      if (a_mix[n] > a_mix[best]) best = n;
+    for (int j = 0; j < D; ++j) a_mat[(size_t)best * D + j] = a_seq[j];
+  }
+  for (int j = 0; j < steps * da; ++j) next_actions[j] = a_seq[j];
+  for (int t = 0; t < H; ++t)
+    for (int d = 0; d < da; ++d) a_seq[t * da + d] = (t + steps < H) ? a_seq[(t + steps) * da + d] : 0.0f;
+  for (int n = 0; n < N; ++n)
+    for (int t = 0; t < H; ++t)
+      for (int d = 0; d < da; ++d)
+        a_mat[((size_t)n * H + t) * da + d] = (t + steps < H) ? a_mat[((size_t)n * H + t + steps) * da + d] : 0.0f;
+}
+
+/* ------------------------------------------------------------------ MPF (dynamics-side SVGD) */
+void orc_gmm_log_prob(int n, int K, int P, const float *x, const float *means, float bw, float *out) {
+  double *lg = (double *)malloc(sizeof(double) * K);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < K; ++k) {
+      double q = 0.0;
+      for (int p = 0; p < P; ++p) {
+        double z = ((double)x[(size_t)i * P + p] - (double)means[(size_t)k * P + p]) / (double)bw;
+        q += z * z;
+      }
+      lg[k] = -log((double)K) - 0.5 * q - P * log((double)bw) - 0.5 * P * log(2.0 * M_PI);
+    }
+    out[i] = (float)lse(lg, K);
+  }
+  free(lg);
+}
+
+/* d obs / d params of one model step, analytic (what autograd returns at mpf.py:50 through model.step) */
+static void step_jacobian(const orc_cfg *c, const float *x, const float *a, const float *prow_raw, int log_space,
+                          double *J /* [ds][P] */) {
+  const int P = c->P;
+  for (int i = 0; i < c->ds * P; ++i) J[i] = 0.0;
+  double pv[4];
+  for (int p = 0; p < P; ++p) pv[p] = log_space ? exp((double)prow_raw[p]) : (double)prow_raw[p];
+  if (c->model == ORC_MODEL_PENDULUM) {
+    double g = c->g.is_tensor == 1 ? pv[c->g.col] : c->g.value;
+    double m = c->mass.is_tensor == 1 ? pv[c->mass.col] : c->mass.value;
+    double l = c->length.is_tensor == 1 ? pv[c->length.col] : c->length.value;
+    double dt = c->dt;
+    double u = clampf(a[0], -(float)c->max_torque, (float)c->max_torque);
+    double s = sin((double)x[0] + M_PI);
+    double thd = (double)x[1] + dt * (-3.0 * g / (2.0 * l) * s + 3.0 / (m * l * l) * u);
+    int live = (thd >= -c->max_speed_pend && thd <= c->max_speed_pend);
+    if (!live) return;
+    double dthd[3]; /* d/dg, d/dm, d/dl */
+    dthd[0] = dt * (-3.0 / (2.0 * l) * s);
+    dthd[1] = dt * (-3.0 / (m * m * l * l) * u);
+    dthd[2] = dt * (3.0 * g / (2.0 * l * l) * s - 6.0 / (m * l * l * l) * u);
+    const orc_param *ps[3] = {&c->g, &c->mass, &c->length};
+    for (int q = 0; q < 3; ++q)
+      if (ps[q]->is_tensor == 1) {
+        int col = ps[q]->col;
+        double chain = log_space ? pv[col] : 1.0;
+        J[1 * P + col] += dthd[q] * chain;
+        J[0 * P + col] += dthd[q] * dt * chain;
+      }
+  } else {
+    if (c->pmass.is_tensor != 1) return;
+    int col = c->pmass.col;
+    double m = pv[col], dt = c->dt;
+    double om = 1.0;
+    if (c->can_crash && c->with_obstacle) om = 1.0 - (double)collision(c, x[0], x[1]);
+    for (int k = 0; k < 2; ++k) {
+      double acc = (double)a[k] / m;
+      int live_a = (acc >= -c->max_acc && acc <= c->max_acc);
+      double accc = acc < -c->max_acc ? -c->max_acc : (acc > c->max_acc ? c->max_acc : acc);
+      double v = (double)x[2 + k] + accc * dt * om;
+      int live_v = (v >= -c->max_speed && v <= c->max_speed);
+      if (live_a && live_v) J[(2 + k) * P + col] = dt * om * (-(double)a[k] / (m * m)) * (log_space ? m : 1.0);
+    }
+  }
+}
+
+void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_means, float prior_bw,
+                 const float *past_obs, const float *past_action, const float *obs, float obs_std, int log_space,
+                 float bw, float *phi) {
+  const int P = c->P, ds = c->ds;
+  double *score = (double *)malloc(sizeof(double) * (size_t)Mp * P);
+  double *lg = (double *)malloc(sizeof(double) * Mp);
+  orc_cfg cc = *c;
+  cc.params_log_space = log_space;
+  for (int i = 0; i < Mp; ++i) {
+    /* prior score, mpf.py:45 */
+    for (int k = 0; k < Mp; ++k) {
+      double q = 0.0;
+      for (int p = 0; p < P; ++p) {
+        double z = ((double)x[(size_t)i * P + p] - (double)prior_means[(size_t)k * P + p]) / (double)prior_bw;
+        q += z * z;
+      }
+      lg[k] = -0.5 * q;
+    }
+    double z = lse(lg, Mp);
+    for (int p = 0; p < P; ++p) {
+      double acc = 0.0;
+      for (int k = 0; k < Mp; ++k)
+        acc += exp(lg[k] - z) * ((double)prior_means[(size_t)k * P + p] - (double)x[(size_t)i * P + p]) /
+               ((double)prior_bw * (double)prior_bw);
+      score[(size_t)i * P + p] = acc;
+    }
+    /* likelihood score, mpf.py:46-50 + likelihoods.py:30-49 */
+    float pred[8];
+    double J[8 * 4];
+    model_step(&cc, past_obs, past_action, x + (size_t)i * P, pred);
+    step_jacobian(&cc, past_obs, past_action, x + (size_t)i * P, log_space, J);
+    for (int p = 0; p < P; ++p) {
+      double acc = 0.0;
+      for (int k = 0; k < ds; ++k) acc += J[k * P + p] * ((double)obs[k] - (double)pred[k]);
+      score[(size_t)i * P + p] += acc / ((double)obs_std * (double)obs_std);
+    }
+  }
+  /* kernel, svgd.py:92-99 ; phi, mpf.py:52-56.  squared_distance (svgd.py:28-39) is the fp32 addmm form
+   * clamp(|b|^2 - 2 a.b + |a|^2, 0); its rounding is part of the reference's result (d^2/bw^2 amplifies it), so it is
+   * followed here: dot as an fma chain (bit-exact vs torch.addmm on the golden inputs), then the two adds. */
+  float bw2 = (float)((double)bw * (double)bw);
+  float *nrm = (float *)malloc(sizeof(float) * Mp);
+  for (int i = 0; i < Mp; ++i) {
+    float a = 0.f;
+    for (int r = 0; r < P; ++r) a = a + x[(size_t)i * P + r] * x[(size_t)i * P + r];
+    nrm[i] = a;
+  }
+  for (int i = 0; i < Mp; ++i)
+    for (int p = 0; p < P; ++p) {
+      double gk = 0.0, ks = 0.0;
+      for (int j = 0; j < Mp; ++j) {
+        float dot = x[(size_t)i * P] * x[(size_t)j * P];
+        for (int r = 1; r < P; ++r) dot = fmaf(x[(size_t)i * P + r], x[(size_t)j * P + r], dot);
+        float q = (nrm[j] + (-2.0f * dot)) + nrm[i];
+        if (q < 0.f) q = 0.f;
+        double k = (double)expf(((-q) / bw2) / 2.0f);
+        gk += -k * ((double)x[(size_t)i * P + p] - (double)x[(size_t)j * P + p]) / ((double)bw * (double)bw);
+        ks += k * score[(size_t)j * P + p];
+      }
+      phi[(size_t)i * P + p] = (float)(gk + ks / Mp);
+    }
+  free(nrm);
+  free(score);
+  free(lg);
+}
+
+void orc_mpf_optimize(const orc_cfg *c, int Mp, float *x, float *prior_means, float *prior_bw, const float *past_obs,
+                      const float *past_action, const float *obs, float obs_std, int log_space, float bw, float lr,
+                      int n_steps, float *grad_norms) {
+  const int P = c->P;
+  float *phi = (float *)malloc(sizeof(float) * (size_t)Mp * P);
+  for (int it = 0; it < n_steps; ++it) {
+    /* quirk: MPF.update_prior (mpf.py:26-38) hands `self.x` itself to MultivariateNormal(loc=...), which aliases its
+     * storage; SGD then updates x in place, so the prior means are always the CURRENT particles. */
+    orc_mpf_phi(c, Mp, x, x, *prior_bw, past_obs, past_action, obs, obs_std, log_space, bw, phi);
+    double nn = 0.0;
+    for (int i = 0; i < Mp * P; ++i) nn += (double)phi[i] * (double)phi[i];
+    if (grad_norms) grad_norms[it] = (float)sqrt(nn);
+    orc_sgd(Mp * P, lr, phi, x);
+  }
+  memcpy(prior_means, x, sizeof(float) * (size_t)Mp * P); /* update_prior mpf.py:26-38,85 */
+  *prior_bw = bw;
+  free(phi);
+}
+
+/* ------------------------------------------------------------------ whole tick (cpu_baseline timing only) */
+void orc_tick_k1(const orc_cfg *c, const float *state, float *theta, float *mu, float *mix_weights, const float *sigma_p,
+                 const float *sigma_a, const float *eps, int n_iters, float alpha, float lr, float *a_mat, float *a_seq_out,
+                 float *p_weights, float *costs_out) {
+  const int N = c->N, S = c->S, D = c->H * c->da;
+  const size_t SND = (size_t)S * N * D;
+  float *actions = (float *)malloc(sizeof(float) * SND);
+  float *costs = (float *)malloc(sizeof(float) * (size_t)S * N);
+  float *score = (float *)malloc(sizeof(float) * (size_t)N * D);
+  float *phi = (float *)malloc(sizeof(float) * (size_t)N * D);
+  float *logmix = (float *)malloc(sizeof(float) * N);
+  float *zero_seq = (float *)calloc((size_t)D, sizeof(float));
+  orc_log_mix(N, mix_weights, logmix);
+  for (int it = 0; it < n_iters; ++it) {
+    orc_sample_actions(c, theta, eps + (size_t)it * SND, sigma_a, actions);
+    orc_rollout_cost(c, state, actions, NULL, 0.0f, NULL, NULL, NULL, NULL, costs);
+    orc_disco_weights(c, costs, actions, zero_seq, 0, 1.0f / alpha, NULL, a_mat, NULL);
+    orc_score(c, theta, mu, logmix, sigma_p, costs, actions, alpha, sigma_a, NULL, NULL, score);
+    orc_phi_k1(N, D, theta, score, 0, phi, NULL);
+    orc_sgd(N * D, lr, phi, theta);
+  }
+  int istar;
+  orc_forward(c, ORC_LIK_EXP_UTILITY, alpha, costs, theta, mu, mix_weights, sigma_p, 0, ORC_ROLL_REPEAT, NULL, NULL,
+              p_weights, &istar, a_seq_out);
+  if (costs_out) memcpy(costs_out, costs, sizeof(float) * (size_t)S * N);
+  free(actions);
+  free(costs);
+  free(score);
+  free(phi);
+  free(logmix);
+  free(zero_seq);
+}

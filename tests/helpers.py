@@ -1,0 +1,29 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+
+
+def relerr(a, b, floor=0.0):
+    """max |a-b| / (max|b| + floor): tensor-level relative error, the form SURVEY section 3 quotes."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + floor + 1e-300))
+
+
+def elem_relerr(a, b, atol=0.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + atol + 1e-300)).max())
+
+
+def scenario_kwargs(g):
+    """Oracle/ctx constructor kwargs for a golden SVMPC scenario (tests/golden/make_golden.py:run_svmpc)."""
+    kind = str(g["model_kind"])
+    kw = dict(model=kind, N=int(g["N"]), S=int(g["S"]), M=int(g["M"]), H=int(g["H"]))
+    if kind == "pendulum":
+        if "params" in g:
+            kw["uncertain_params"] = ("length", "mass")
+    else:
+        kw["uncertain_params"] = ("mass",)
+        kw["mass"] = 2.0
+        kw["mass_0dim"] = True
+        kw["params_log_space"] = bool(int(g["params_log_space"]))
+        kw["params_scalar_event"] = bool(int(g["params_scalar_event"]))
+    return kw
