@@ -1,0 +1,388 @@
+"""Thin object wrapper over the C ABI (one `Context` = one dust_ctx = one controller + its SVMPC state on one GPU).
+
+All array arguments are numpy (or anything np.asarray accepts, torch CPU tensors included); results are numpy fp32.
+No arithmetic of the hot path happens here - only shape checks and pointer plumbing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None:
+        a = np.ascontiguousarray(a.reshape(shape))
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(L.FP)
+
+
+def _vp(a):
+    return None if a is None else C.cast(a.ctypes.data_as(L.FP), L.VP)
+
+
+def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, params_scalar_event=False,
+                params_log_space=False, kernel="K1", likelihood="ExponentiatedUtility", optimizer="SGD", lr=1.0,
+                alpha=1.0, temperature=None, ctrl_penalty=1.0, sigma_a=1.0, sigma_p=1.0, chol_a=None, a_pre=None,
+                weighted_prior=False, roll_strategy="repeat", bw_scale=1.0, imq_ell=1.0, seed=0, device=0,
+                shard_offset=0, shard_size=0, dt=None, g=9.8, mass=1.0, length=1.0, mass_0dim=False, w_cos=50.0, w_vel=1.0,
+                max_speed=5.0, max_accel=10.0, can_crash=True, with_obstacle=True, cell_size=0.1,
+                target=(9.0, 9.0, 0.0, 0.0), w_state=(0.5, 0.5, 0.25, 0.25), w_term=(1e3, 1e3, 0.1, 0.1), w_ctrl=(0.2, 0.2),
+                w_obs=1e6, min_a=None, max_a=None, adam=(0.9, 0.999, 1e-8), sampling=None, **_ignored):
+    c = L.Config()
+    c.abi_version = L.ABI_VERSION
+    c.device = device
+    pend = model == "pendulum"
+    c.model = L.MODEL_PENDULUM if pend else L.MODEL_PARTICLE
+    c.cost = L.COST_PENDULUM_QUADCOS if pend else L.COST_PARTICLE_DEFAULT
+    c.n_policies, c.n_samples, c.n_params, c.horizon = N, S, M, H
+    c.dim_a, c.dim_s = (1, 2) if pend else (2, 4)
+    up = list(uncertain_params) if uncertain_params else []
+    use_params = bool(up) if sampling is None else bool(sampling)
+    c.dim_p = len(up) if use_params else 0
+    c.shard_offset, c.shard_size = shard_offset, shard_size
+    c.kernel = {"K1": L.KERNEL_K1_RBF, "K2": L.KERNEL_K2_IIDMP, "K2shared": L.KERNEL_K2_SHARED, "IMQ": L.KERNEL_IMQ}[kernel]
+    c.likelihood = L.LIK_EXP_UTILITY if likelihood == "ExponentiatedUtility" else L.LIK_EXPECTED_COST
+    c.optimizer = L.OPT_SGD if optimizer == "SGD" else L.OPT_ADAM
+    c.roll_strategy = {"repeat": L.ROLL_REPEAT, "mean": L.ROLL_MEAN}[roll_strategy]
+    c.weighted_prior = int(weighted_prior)
+    c.params_log_space = int(params_log_space)
+    c.params_interleave = int(params_scalar_event)
+    c.alpha = alpha
+    c.temperature = (1.0 / alpha) if temperature is None else temperature
+    c.a_reg = np.float32(c.temperature * (1.0 - ctrl_penalty))
+    c.lr = lr
+    c.adam_beta1, c.adam_beta2, c.adam_eps = adam
+    sa = np.broadcast_to(np.asarray(sigma_a, np.float32), (c.dim_a,))
+    sp = np.broadcast_to(np.asarray(sigma_p, np.float32), (c.dim_a,))
+    ch = sa if chol_a is None else np.broadcast_to(np.asarray(chol_a, np.float32), (c.dim_a,))
+    ap = (1.0 / (sa.astype(np.float32) ** 2)) if a_pre is None else np.broadcast_to(np.asarray(a_pre, np.float32), (c.dim_a,))
+    for d in range(c.dim_a):
+        c.sigma_a[d], c.sigma_p[d], c.chol_a[d], c.a_pre[d] = sa[d], sp[d], ch[d], ap[d]
+    c.bw_scale, c.imq_ell = bw_scale, imq_ell
+    lo = np.broadcast_to(np.asarray((-2.0 if pend else -max_accel) if min_a is None else min_a, np.float32), (c.dim_a,))
+    hi = np.broadcast_to(np.asarray((2.0 if pend else max_accel) if max_a is None else max_a, np.float32), (c.dim_a,))
+    for d in range(c.dim_a):
+        c.min_a[d], c.max_a[d] = lo[d], hi[d]
+    c.seed = seed
+    c.dt = (0.05 if pend else 0.015) if dt is None else dt
+
+    def par(name, value):
+        if use_params and name in up:
+            return L.Param(L.PARAM_SAMPLED, up.index(name), float(value))
+        return L.Param(L.PARAM_TENSOR0D if (mass_0dim and name == "mass") else L.PARAM_PYFLOAT, 0, float(value))
+
+    c.g, c.mass, c.length = par("g", g), par("mass", mass), par("length", length)
+    c.max_torque, c.max_speed_pend, c.w_cos, c.w_vel = 2.0, 8.0, w_cos, w_vel
+    c.max_speed, c.max_accel = max_speed, max_accel
+    c.can_crash, c.with_obstacle = int(can_crash), int(with_obstacle and not pend)
+    c.cell_size = cell_size
+    c.target[:] = list(target)
+    c.w_state[:] = list(w_state)
+    c.w_term[:] = list(w_term)
+    c.w_ctrl[:] = list(w_ctrl)
+    c.w_obs = w_obs
+    return c
+
+
+class Context:
+    def __init__(self, cfg=None, grid=None, _handle=None, **kw):
+        self._h = None
+        lib = L.load()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            self.cfg = cfg if cfg is not None else make_config(**kw)
+            h = L.VP()
+            L.check(lib.dust_create(C.byref(self.cfg), C.byref(h)))
+            self._h = h
+        got = L.Config()
+        L.check(lib.dust_get_config(self._h, C.byref(got)))
+        self.cfg = got
+        self.N, self.S, self.M, self.H = got.n_policies, got.n_samples, got.n_params, got.horizon
+        self.da, self.ds, self.P = got.dim_a, got.dim_s, got.dim_p
+        self.D = self.H * self.da
+        if grid is not None:
+            self.set_grid(grid)
+
+    # ---- lifecycle
+    def close(self):
+        if self._h is not None:
+            L.load().dust_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clone(self):
+        h = L.VP()
+        L.check(L.load().dust_clone(self._h, C.byref(h)))
+        return Context(_handle=h)
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
+    def sync(self):
+        L.check(L.load().dust_sync(self._h))
+
+    def set_grid(self, grid, off=None):
+        g = _f(grid)
+        nx, ny = g.shape
+        ox, oy = (int(nx / 2), int(ny / 2)) if off is None else off
+        L.check(L.load().dust_set_grid(self._h, _p(g), nx, ny, float(ox), float(oy)))
+
+    def set_model_param(self, name, value, kind=-1):
+        L.check(L.load().dust_set_model_param(self._h, name.encode(), float(value), kind))
+
+    # ---- state
+    def _get(self, fn, shape):
+        out = np.empty(shape, np.float32)
+        L.check(fn(self._h, _p(out)))
+        return out
+
+    def set_theta(self, theta):
+        L.check(L.load().dust_set_theta(self._h, _p(_f(theta, (self.N, self.H, self.da)))))
+
+    def get_theta(self):
+        return self._get(L.load().dust_get_theta, (self.N, self.H, self.da))
+
+    def set_prior(self, means, weights=None):
+        w = None if weights is None else _f(weights, (self.N,))
+        L.check(L.load().dust_set_prior(self._h, _p(_f(means, (self.N, self.H, self.da))), _p(w)))
+
+    def get_prior(self):
+        means = np.empty((self.N, self.H, self.da), np.float32)
+        probs = np.empty(self.N, np.float32)
+        L.check(L.load().dust_get_prior(self._h, _p(means), _p(probs)))
+        return means, probs
+
+    def set_a_mat(self, a):
+        L.check(L.load().dust_set_a_mat(self._h, _p(_f(a, (self.N, self.H, self.da)))))
+
+    def get_a_mat(self):
+        return self._get(L.load().dust_get_a_mat, (self.N, self.H, self.da))
+
+    def get_a_mix(self):
+        return self._get(L.load().dust_get_a_mix, (self.N,))
+
+    def set_a_seq(self, a):
+        L.check(L.load().dust_set_a_seq(self._h, _p(_f(a, (self.H, self.da)))))
+
+    def get_a_seq(self):
+        return self._get(L.load().dust_get_a_seq, (self.H, self.da))
+
+    # ---- a1-a6
+    def _params(self, params, sets=1):
+        if self.P == 0:
+            return None
+        if params is None:
+            raise ValueError("params_sampling is on: pass the sampled dynamics parameters")
+        return _f(params, (sets, self.M, self.P))
+
+    def disco_forward(self, state, actions=None, params=None, want_states=False, want_actions=False, want_omega=True,
+                      around_a_mat=False):
+        st = _f(state, (self.ds,))
+        act = None if actions is None else _f(actions, (self.S, self.N, self.H, self.da))
+        pr = self._params(params)
+        costs = np.empty((self.S, self.N), np.float32)
+        states = np.empty((self.M, self.S, self.N, self.H + 1, self.ds), np.float32) if want_states else None
+        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if (want_actions or actions is None) else None
+        omega = np.empty((self.S, self.N), np.float32) if want_omega else None
+        flags = L.EPS_AROUND_A_MAT if around_a_mat else 0
+        L.check(L.load().dust_disco_forward(self._h, _p(st), _vp(act), _p(pr), flags, _p(costs), _p(states), _p(aout), _p(omega)))
+        return costs, states, (aout if aout is not None else act), omega
+
+    def disco_step(self, strategy="argmax", steps=1, ext_actions=None):
+        sid = {"argmax": L.STEP_ARGMAX, "average": L.STEP_AVERAGE, "external": L.STEP_EXTERNAL}.get(strategy, -1)
+        ext = None if ext_actions is None else _f(ext_actions, (self.H, self.da))
+        out = np.empty((steps, self.da), np.float32)
+        L.check(L.load().dust_disco_step(self._h, sid, steps, _p(ext), _p(out)))
+        return out
+
+    def likelihood_sample(self, state, eps=None, params=None, want_actions=False, store_states=False):
+        st = _f(state, (self.ds,))
+        e = None if eps is None else _f(eps, (self.S, self.N, self.H, self.da))
+        pr = self._params(params)
+        costs = np.empty((self.S, self.N), np.float32)
+        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if want_actions else None
+        L.check(L.load().dust_likelihood_sample(self._h, _p(st), _vp(e), _p(pr), L.STORE_STATES if store_states else 0, _p(costs), _p(aout)))
+        return (costs, aout) if want_actions else costs
+
+    def likelihood_log_prob(self):
+        return self._get(L.load().dust_likelihood_log_prob, (self.N,))
+
+    # ---- a7-a12
+    def svmpc_phi(self, costs=None, actions=None):
+        c = None if costs is None else _f(costs, (self.S, self.N))
+        a = None if actions is None else _f(actions, (self.S, self.N, self.H, self.da))
+        phi, gl, gp = (np.empty((self.N, self.H, self.da), np.float32) for _ in range(3))
+        L.check(L.load().dust_svmpc_phi(self._h, _p(c), _p(a), _p(phi), _p(gl), _p(gp)))
+        return phi, gl, gp
+
+    def svmpc_optimize(self, state, n_steps, eps=None, params=None):
+        st = _f(state, (self.ds,))
+        e = None if eps is None else _f(eps, (n_steps, self.S, self.N, self.H, self.da))
+        pr = self._params(params, n_steps)
+        L.check(L.load().dust_svmpc_optimize(self._h, _p(st), n_steps, _vp(e), _p(pr), 0))
+
+    def svmpc_optimize_dev(self, state, n_steps, eps_dev_ptr, params=None):
+        st = _f(state, (self.ds,))
+        pr = self._params(params, n_steps)
+        L.check(L.load().dust_svmpc_optimize(self._h, _p(st), n_steps, L.VP(eps_dev_ptr) if eps_dev_ptr else None, _p(pr),
+                                             L.PTR_DEVICE))
+
+    def svmpc_forward(self):
+        a_seq = np.empty((self.H, self.da), np.float32)
+        pw = np.empty(self.N, np.float32)
+        L.check(L.load().dust_svmpc_forward(self._h, _p(a_seq), _p(pw)))
+        return a_seq, pw
+
+    def svmpc_tick(self, state, n_steps, eps=None, params=None, eps_dev_ptr=None, want_outputs=True):
+        st = _f(state, (self.ds,))
+        pr = self._params(params, n_steps)
+        a_seq = np.empty((self.H, self.da), np.float32) if want_outputs else None
+        pw = np.empty(self.N, np.float32) if want_outputs else None
+        if eps_dev_ptr:
+            e, flags = L.VP(eps_dev_ptr), L.PTR_DEVICE
+        else:
+            e = None if eps is None else _vp(_f(eps, (n_steps, self.S, self.N, self.H, self.da)))
+            flags = 0
+        L.check(L.load().dust_svmpc_tick(self._h, _p(st), n_steps, e, _p(pr), flags, _p(a_seq), _p(pw)))
+        return a_seq, pw
+
+    def get_costs(self):
+        return self._get(L.load().dust_get_costs, (self.S, self.N))
+
+    def get_score(self):
+        return self._get(L.load().dust_get_score, (self.N, self.H, self.da))
+
+    def get_phi(self):
+        return self._get(L.load().dust_get_phi, (self.N, self.H, self.da))
+
+    def get_log_weights(self):
+        ll, lp = np.empty(self.N, np.float32), np.empty(self.N, np.float32)
+        L.check(L.load().dust_get_log_weights(self._h, _p(ll), _p(lp)))
+        return ll, lp
+
+    def get_bandwidths(self):
+        G = self.H if self.cfg.kernel == L.KERNEL_K2_SHARED else self.D
+        return self._get(L.load().dust_get_bandwidths, (G,))
+
+    # ---- timing
+    def profile(self, on=True):
+        L.check(L.load().dust_profile_enable(self._h, int(on)))
+        L.check(L.load().dust_profile_reset(self._h))
+
+    def profile_get(self):
+        out = {}
+        for k in range(L.K_COUNT):
+            ms, n = C.c_double(0), C.c_int64(0)
+            L.check(L.load().dust_profile_get(self._h, k, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[L.load().dust_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def rollout_bytes(self, store_states=False):
+        b = C.c_double(0)
+        L.check(L.load().dust_rollout_algorithmic_bytes(self._h, L.STORE_STATES if store_states else 0, C.byref(b)))
+        return b.value
+
+    def device_noise(self, n_floats, seed=1):
+        p = L.VP()
+        L.check(L.load().dust_device_noise_alloc(self._h, n_floats, seed, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        L.check(L.load().dust_device_free(self._h, L.VP(ptr)))
+
+
+class MpfContext:
+    def __init__(self, init_particles, initial_obs, model="pendulum", uncertain_params=("length", "mass"), log_space=False,
+                 obs_std=0.1, lr=1e-3, bw_scale=1.0, init_bw=0.1, device=0, grid=None, _handle=None, **model_kw):
+        lib = L.load()
+        x = _f(init_particles)
+        self.Mp, self.P = x.shape
+        if _handle is not None:
+            self._h = _handle
+            return
+        c = L.MpfConfig()
+        c.abi_version, c.device, c.n_particles, c.dim_p = L.ABI_VERSION, device, self.Mp, self.P
+        c.model_cfg = make_config(model=model, uncertain_params=uncertain_params, params_log_space=log_space, device=device, **model_kw)
+        c.dim_s, c.dim_a, c.model = c.model_cfg.dim_s, c.model_cfg.dim_a, c.model_cfg.model
+        c.log_space, c.obs_std, c.lr, c.bw_scale, c.init_bw = int(log_space), obs_std, lr, bw_scale, init_bw
+        self.ds, self.da = c.dim_s, c.dim_a
+        h = L.VP()
+        L.check(lib.dust_mpf_create(C.byref(c), _p(x), _p(_f(initial_obs, (c.dim_s,))), C.byref(h)))
+        self._h = h
+        if grid is not None:
+            g = _f(grid)
+            L.check(lib.dust_mpf_set_grid(self._h, _p(g), g.shape[0], g.shape[1], float(int(g.shape[0] / 2)), float(int(g.shape[1] / 2))))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            L.load().dust_mpf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clone(self):
+        h = L.VP()
+        L.check(L.load().dust_mpf_clone(self._h, C.byref(h)))
+        m = MpfContext.__new__(MpfContext)
+        m._h, m.Mp, m.P, m.ds, m.da = h, self.Mp, self.P, self.ds, self.da
+        return m
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
+    def condition(self, action, new_obs):
+        a = None if action is None else _f(action).reshape(-1)
+        L.check(L.load().dust_mpf_condition(self._h, _p(a), _p(_f(new_obs, (self.ds,)))))
+
+    def phi(self, bw):
+        out = np.empty((self.Mp, self.P), np.float32)
+        L.check(L.load().dust_mpf_phi(self._h, float(bw), _p(out)))
+        return out
+
+    def optimize(self, action, new_obs, bw, n_steps):
+        a = None if action is None else _f(action).reshape(-1)
+        o = None if new_obs is None else _f(new_obs, (self.ds,))
+        gn = np.empty(max(n_steps, 1), np.float32)
+        L.check(L.load().dust_mpf_optimize(self._h, _p(a), _p(o), float(bw), n_steps, _p(gn)))
+        return gn[:n_steps]
+
+    def get_particles(self):
+        out = np.empty((self.Mp, self.P), np.float32)
+        L.check(L.load().dust_mpf_get_particles(self._h, _p(out)))
+        return out
+
+    def set_particles(self, x):
+        L.check(L.load().dust_mpf_set_particles(self._h, _p(_f(x, (self.Mp, self.P)))))
+
+    def get_prior(self):
+        means = np.empty((self.Mp, self.P), np.float32)
+        bw = C.c_float(0)
+        L.check(L.load().dust_mpf_get_prior(self._h, _p(means), C.cast(C.byref(bw), L.FP)))
+        return means, bw.value
+
+    def prior_sample(self, n, seed=0):
+        out = np.empty((n, self.P), np.float32)
+        L.check(L.load().dust_mpf_prior_sample(self._h, n, seed, _p(out)))
+        return out
+
+    def prior_log_prob(self, x):
+        x = _f(x, (-1, self.P))
+        out = np.empty(x.shape[0], np.float32)
+        L.check(L.load().dust_mpf_prior_log_prob(self._h, x.shape[0], _p(x), _p(out)))
+        return out

@@ -1,0 +1,241 @@
+// common.hpp - shared host/device declarations for libdust_amd (gfx950 / CDNA4 only).
+//
+// Build flags matter: -ffp-contract=off.  The rollout follows the reference's fp32 operation order exactly (each torch
+// CPU elementwise op rounds once; the pendulum is chaotic and the particle map is discontinuous), so the compiler must
+// not fuse a*b+c on its own.  Kernels that WANT fused multiply-adds (pairwise passes) call fmaf() explicitly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dust_amd.h"
+
+#define DUST_WAVE 64
+
+namespace dust {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-side model description (by-value kernel argument; lives in SGPRs / constant cache).
+struct DevParam {
+  int kind;  // dust_param_kind
+  int col;
+  double value;
+};
+
+struct DevModel {
+  int model;
+  int P;
+  int log_space;
+  int interleave;
+  double dt;
+  // pendulum: dust/models/pendulum.py:61-100
+  DevParam g, mass, length;
+  float max_torque, max_speed_pend, w_cos, w_vel;
+  // particle: dust/models/particle.py:117-225, dust/utils/obstacle_map.py:64-93
+  float max_speed, max_acc;
+  int can_crash, with_obstacle;
+  float inv_cell, off_x, off_y;
+  int nx, ny;
+  const uint32_t *grid_bits;  // bit-packed [nx][ny] occupancy (nx*ny bits, row-major), 6 KB for the demo map
+  float target[4], w_state[4], w_term[4], w_ctrl[2], w_obs;
+};
+
+// Python-float vs fp32-tensor arithmetic, as the interpreter evaluates pendulum.py:93-96.
+struct Val {
+  int t;
+  double d;
+  float f;
+};
+__device__ __forceinline__ float tof(Val v) { return v.t ? v.f : (float)v.d; }
+__device__ __forceinline__ Val v_py(double d) { return Val{0, d, 0.f}; }
+__device__ __forceinline__ Val v_t(float f) { return Val{1, 0.0, f}; }
+__device__ __forceinline__ Val v_mul(Val a, Val b) {
+  if (!a.t && !b.t) return v_py(a.d * b.d);
+  return v_t(tof(a) * tof(b));
+}
+__device__ __forceinline__ Val v_div(Val a, Val b) {
+  if (!a.t && !b.t) return v_py(a.d / b.d);
+  if (a.t && !b.t) return v_t(a.f / (float)b.d);
+  if (!a.t && b.t) return v_t((1.0f / b.f) * (float)a.d);  // Tensor.__rtruediv__ = reciprocal() * other
+  return v_t(a.f / b.f);
+}
+__device__ __forceinline__ Val v_sq(Val a) { return a.t ? v_t(a.f * a.f) : v_py(a.d * a.d); }
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__device__ __forceinline__ Val load_param(const DevModel &dm, const DevParam &p, const float *prow) {
+  if (p.kind == DUST_PARAM_SAMPLED && prow) {
+    float v = prow[p.col];
+    if (dm.log_space) v = expf(v);
+    return v_t(v);
+  }
+  if (p.kind == DUST_PARAM_TENSOR0D) return v_t((float)p.value);
+  return v_py(p.value);
+}
+
+// Per-rollout constants derived from the (sampled) model parameters.
+struct Coef {
+  float c0, c1;  // pendulum: -3g/(2l), 3/(m l^2) ; particle: mass, unused
+};
+
+__device__ __forceinline__ Coef make_coef(const DevModel &dm, const float *prow) {
+  Coef c;
+  if (dm.model == DUST_MODEL_PENDULUM) {
+    Val g = load_param(dm, dm.g, prow), m = load_param(dm, dm.mass, prow), l = load_param(dm, dm.length, prow);
+    c.c0 = tof(v_div(v_mul(v_py(-3.0), g), v_mul(v_py(2.0), l)));
+    c.c1 = tof(v_div(v_py(3.0), v_mul(m, v_sq(l))));
+  } else {
+    c.c0 = tof(load_param(dm, dm.mass, prow));
+    c.c1 = 0.f;
+  }
+  return c;
+}
+
+// ObstacleMap.get_collisions obstacle_map.py:64-93: floor(x * (1/cell) + offset) -> int64 -> clamp -> gather
+__device__ __forceinline__ float collision(const DevModel &dm, float px, float py) {
+  float fx = floorf(px * dm.inv_cell + dm.off_x);
+  float fy = floorf(py * dm.inv_cell + dm.off_y);
+  // float -> int64 of NaN/out-of-range is INT64_MIN on the reference's x86 host, which then clamps to 0
+  int ix = (fx >= 0.f && fx <= 9.2e18f) ? (fx > (float)(dm.nx - 1) ? dm.nx - 1 : (int)fx) : 0;
+  int iy = (fy >= 0.f && fy <= 9.2e18f) ? (fy > (float)(dm.ny - 1) ? dm.ny - 1 : (int)fy) : 0;
+  int bit = ix * dm.ny + iy;
+  return (float)((dm.grid_bits[bit >> 5] >> (bit & 31)) & 1u);
+}
+
+#define PI_F 3.14159274101257324f /* (float)math.pi */
+
+template <int MODEL>
+__device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, float *x, const float *a) {
+  const float dt = (float)dm.dt;
+  if (MODEL == DUST_MODEL_PENDULUM) {
+    float u = clampf(a[0], -dm.max_torque, dm.max_torque);
+    float s = sinf(x[0] + PI_F);
+    float t1 = c.c0 * s;
+    float t2 = c.c1 * u;
+    float thd = x[1] + dt * (t1 + t2);
+    thd = clampf(thd, -dm.max_speed_pend, dm.max_speed_pend);
+    x[0] = x[0] + thd * dt;
+    x[1] = thd;
+  } else {
+    float ax = clampf(a[0] / c.c0, -dm.max_acc, dm.max_acc);
+    float ay = clampf(a[1] / c.c0, -dm.max_acc, dm.max_acc);
+    float xd[4] = {x[2], x[3], ax, ay};
+    if (dm.can_crash && dm.with_obstacle) {
+      float om = 1.0f - collision(dm, x[0], x[1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = x[k] + (xd[k] * dt) * om;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = x[k] + xd[k] * dt;
+    }
+    x[2] = clampf(x[2], -dm.max_speed, dm.max_speed);
+    x[3] = clampf(x[3], -dm.max_speed, dm.max_speed);
+  }
+}
+
+template <int MODEL>
+__device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, const float *a) {
+  if (MODEL == DUST_MODEL_PENDULUM) {
+    float cm = cosf(x[0]) - 1.0f;
+    float t1 = dm.w_cos * (cm * cm);
+    float t2 = dm.w_vel * (x[1] * x[1]);
+    return t1 + t2;
+  } else {
+    double sc = 0.0, cc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = x[k] - dm.target[k];
+      sc += (double)((d * d) * dm.w_state[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
+    float ob = dm.with_obstacle ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
+    return ((float)sc + (float)cc) + ob;
+  }
+}
+
+template <int MODEL>
+__device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
+  if (MODEL == DUST_MODEL_PENDULUM) {
+    return inst_cost<MODEL>(dm, x, nullptr);
+  } else {
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = x[k] - dm.target[k];
+      sc += (double)((d * d) * dm.w_term[k]);
+    }
+    float ob = dm.with_obstacle ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
+    return (float)sc + ob;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave / block reductions (64-lane wavefronts; DPP via __shfl_xor).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide reductions through a small LDS scratch (>= 16 floats). All threads get the result.
+enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
+template <int OP>
+__device__ __forceinline__ float block_reduce(float v, float *scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = OP == RED_SUM ? wave_sum(v) : (OP == RED_MAX ? wave_max(v) : wave_min(v));
+  __syncthreads();  // scratch may still be read from a previous reduction
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int w = 1; w < nw; ++w) r = OP == RED_SUM ? r + scratch[w] : (OP == RED_MAX ? fmaxf(r, scratch[w]) : fminf(r, scratch[w]));
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011) + Box-Muller.  Used only when the caller supplies no noise.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[4]) {
+  uint32_t r[4];
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1] + 0.5f) * k;
+  float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3] + 0.5f) * k;
+  u0 = fminf(fmaxf(u0, 1e-12f), 1.0f);
+  u2 = fminf(fmaxf(u2, 1e-12f), 1.0f);
+  float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+  float sa, ca, sb, cb;
+  __sincosf(6.283185307179586f * u1, &sa, &ca);
+  __sincosf(6.283185307179586f * u3, &sb, &cb);
+  z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
+}
+
+}  // namespace dust

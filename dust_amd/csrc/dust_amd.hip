@@ -1,0 +1,1069 @@
+// dust_amd.hip - C ABI of libdust_amd.so (see include/dust_amd.h).  Host-side orchestration of the HIP kernels in
+// rollout.hpp / stein.hpp / bandwidth.hpp / forward.hpp / mpf.hpp.  gfx950 (MI355X) only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bandwidth.hpp"
+#include "common.hpp"
+#include "forward.hpp"
+#include "rollout.hpp"
+#include "stein.hpp"
+
+using namespace dust;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(x)                                                                                       \
+  do {                                                                                                   \
+    hipError_t e_ = (x);                                                                                 \
+    if (e_ != hipSuccess) return fail(DUST_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(x)               \
+  do {                       \
+    int s_ = (x);            \
+    if (s_ != DUST_OK) return s_; \
+  } while (0)
+
+extern "C" const char *dust_last_error(void) { return g_err.c_str(); }
+extern "C" int dust_abi_version(void) { return DUST_ABI_VERSION; }
+extern "C" int dust_device_count(int *count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(DUST_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return DUST_OK;
+}
+
+static const char *k_names[DUST_K_COUNT] = {"rollout_kernel", "pairwise_kernel<PRIOR>", "pairwise_kernel<STEIN>", "update_kernel",
+                                            "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", ""};
+extern "C" const char *dust_kernel_name(int id) { return (id >= 0 && id < DUST_K_COUNT) ? k_names[id] : ""; }
+
+struct dust_ctx {
+  dust_config cfg;
+  int N, S, M, H, da, ds, P, D, n0, nloc;
+  hipStream_t stream;
+  bool own_stream;
+  // particles / prior / controller state
+  float *theta, *thetaT, *mu, *muT, *logmix, *mixw;
+  bool mu_aliased;  // reference quirk: after update_prior the GMM means alias theta's storage (svgd.py:87, svmpc.py:160-170)
+  float *a_mat, *a_seq, *a_mix, *eta;
+  // per-iteration products
+  float *costsT, *omegaT, *grad_lik, *grad_pri, *score, *phi, *logl, *logp, *lw, *pw, *a_seq_out, *bw;
+  int *istar;
+  float *adam_m, *adam_v;
+  int adam_step;
+  // staging
+  float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage;
+  size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap;
+  uint32_t *grid_bits;
+  int nx, ny;
+  float off_x, off_y;
+  uint32_t tick, iter;
+  bool have_sample, actions_valid;
+  // profiling
+  bool prof;
+  hipEvent_t ev0, ev1;
+  double prof_ms[DUST_K_COUNT];
+  int64_t prof_n[DUST_K_COUNT];
+};
+
+static DevParam dev_param(const dust_param &p) { return DevParam{p.kind, p.column, p.value}; }
+
+static DevModel make_dev_model(const dust_ctx *c) {
+  const dust_config &g = c->cfg;
+  DevModel m;
+  memset(&m, 0, sizeof m);
+  m.model = g.model;
+  m.P = c->P;
+  m.log_space = g.params_log_space;
+  m.interleave = g.params_interleave;
+  m.dt = g.dt;
+  m.g = dev_param(g.g);
+  m.mass = dev_param(g.mass);
+  m.length = dev_param(g.length);
+  m.max_torque = (float)g.max_torque;
+  m.max_speed_pend = (float)g.max_speed_pend;
+  m.w_cos = (float)g.w_cos;
+  m.w_vel = (float)g.w_vel;
+  m.max_speed = g.max_speed;
+  m.max_acc = g.max_accel;
+  m.can_crash = g.can_crash;
+  m.with_obstacle = g.with_obstacle && c->grid_bits != nullptr;
+  m.inv_cell = (float)(1.0 / g.cell_size);
+  m.off_x = c->off_x;
+  m.off_y = c->off_y;
+  m.nx = c->nx;
+  m.ny = c->ny;
+  m.grid_bits = c->grid_bits;
+  for (int k = 0; k < 4; ++k) {
+    m.target[k] = g.target[k];
+    m.w_state[k] = g.w_state[k];
+    m.w_term[k] = g.w_term[k];
+  }
+  m.w_ctrl[0] = g.w_ctrl[0];
+  m.w_ctrl[1] = g.w_ctrl[1];
+  m.w_obs = g.w_obs;
+  return m;
+}
+
+template <class T>
+static int dalloc(T **p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+  return DUST_OK;
+}
+static int ensure(float **p, size_t *cap, size_t n) {
+  if (*cap >= n) return DUST_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  TRY(dalloc(p, n));
+  *cap = n;
+  return DUST_OK;
+}
+
+struct Prof {
+  dust_ctx *c;
+  int id;
+  Prof(dust_ctx *c_, int id_) : c(c_), id(id_) {
+    if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  ~Prof() {
+    if (c->prof) {
+      (void)hipEventRecord(c->ev1, c->stream);
+      (void)hipEventSynchronize(c->ev1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      c->prof_ms[id] += ms;
+      c->prof_n[id] += 1;
+    }
+  }
+};
+
+static int validate(const dust_config *g) {
+  if (!g) return fail(DUST_ERR_INVALID, "null config");
+  if (g->abi_version != DUST_ABI_VERSION) return fail(DUST_ERR_INVALID, "ABI version mismatch: got %d want %d", g->abi_version, DUST_ABI_VERSION);
+  if (g->n_policies < 1 || g->n_samples < 1 || g->n_params < 1 || g->horizon < 1) return fail(DUST_ERR_INVALID, "sizes must be positive");
+  if (g->model == DUST_MODEL_PENDULUM) {
+    if (g->dim_a != 1 || g->dim_s != 2) return fail(DUST_ERR_INVALID, "PendulumModel has dim_a=1, dim_s=2");
+    if (g->cost != DUST_COST_PENDULUM_QUADCOS) return fail(DUST_ERR_UNSUPPORTED, "pendulum model needs the quad-cos cost family");
+  } else if (g->model == DUST_MODEL_PARTICLE) {
+    if (g->dim_a != 2 || g->dim_s != 4) return fail(DUST_ERR_INVALID, "Particle (acceleration control) has dim_a=2, dim_s=4");
+    if (g->cost != DUST_COST_PARTICLE_DEFAULT) return fail(DUST_ERR_UNSUPPORTED, "particle model needs Particle.default_*_cost");
+  } else {
+    return fail(DUST_ERR_UNSUPPORTED, "unknown model id %d", g->model);
+  }
+  const int D = g->horizon * g->dim_a;
+  if (D > 256) return fail(DUST_ERR_UNSUPPORTED, "H*da = %d > 256 not supported by the kernels", D);
+  if (g->dim_p < 0 || g->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p out of range");
+  if (g->kernel < 0 || g->kernel > DUST_KERNEL_IMQ) return fail(DUST_ERR_INVALID, "bad kernel id");
+  if (g->optimizer != DUST_OPT_SGD && g->optimizer != DUST_OPT_ADAM) return fail(DUST_ERR_UNSUPPORTED, "optimizer must be SGD or Adam");
+  if (g->shard_size < 0 || g->shard_offset < 0 || g->shard_offset + g->shard_size > g->n_policies)
+    return fail(DUST_ERR_INVALID, "bad shard [%d,+%d) of %d", g->shard_offset, g->shard_size, g->n_policies);
+  for (int d = 0; d < g->dim_a; ++d)
+    if (!(g->chol_a[d] > 0.f) || !(g->sigma_a[d] > 0.f) || !(g->sigma_p[d] > 0.f))
+      return fail(DUST_ERR_INVALID, "covariance diagonals must be positive (only diagonal a_cov / prior covariances are supported)");
+  if (!(g->temperature > 0.f)) return fail(DUST_ERR_INVALID, "temperature must be > 0");
+  return DUST_OK;
+}
+
+static void free_all(dust_ctx *c) {
+  float **fp[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
+                  &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
+                  &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
+                  &c->state_dev, &c->tmp, &c->costs_stage};
+  for (auto p : fp)
+    if (*p) (void)hipFree(*p);
+  if (c->istar) (void)hipFree(c->istar);
+  if (c->grid_bits) (void)hipFree(c->grid_bits);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+extern "C" void dust_destroy(dust_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipStreamSynchronize(c->stream);
+  free_all(c);
+  delete c;
+}
+
+static int create_impl(const dust_config *cfg, dust_ctx **out) {
+  TRY(validate(cfg));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(DUST_ERR_NO_DEVICE, "no HIP device: libdust_amd has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(DUST_ERR_NO_DEVICE, "device %d of %d", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+  dust_ctx *c = new (std::nothrow) dust_ctx();
+  if (!c) return fail(DUST_ERR_HIP, "out of host memory");
+  memset((void *)c, 0, sizeof *c);
+  c->cfg = *cfg;
+  c->N = cfg->n_policies;
+  c->S = cfg->n_samples;
+  c->M = cfg->n_params;
+  c->H = cfg->horizon;
+  c->da = cfg->dim_a;
+  c->ds = cfg->dim_s;
+  c->P = cfg->dim_p > 0 ? cfg->dim_p : 1;
+  c->D = c->H * c->da;
+  c->n0 = cfg->shard_offset;
+  c->nloc = cfg->shard_size > 0 ? cfg->shard_size : c->N;
+  *out = c;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  const size_t ND = (size_t)c->N * c->D, SN = (size_t)c->S * c->N;
+  float **nd[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->a_mat, &c->grad_lik, &c->grad_pri, &c->score, &c->phi};
+  for (auto p : nd) {
+    TRY(dalloc(p, ND));
+    HIP_TRY(hipMemsetAsync(*p, 0, ND * sizeof(float), c->stream));
+  }
+  float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw, &c->pw};
+  for (auto p : nn) {
+    TRY(dalloc(p, (size_t)c->N));
+    HIP_TRY(hipMemsetAsync(*p, 0, c->N * sizeof(float), c->stream));
+  }
+  TRY(dalloc(&c->a_seq, (size_t)c->D));
+  TRY(dalloc(&c->a_seq_out, (size_t)c->D));
+  TRY(dalloc(&c->bw, (size_t)c->D));
+  HIP_TRY(hipMemsetAsync(c->a_seq, 0, c->D * sizeof(float), c->stream));
+  TRY(dalloc(&c->costsT, SN));
+  TRY(dalloc(&c->omegaT, SN));
+  TRY(dalloc(&c->tmp, SN));
+  c->tmp_cap = SN;
+  TRY(dalloc(&c->costs_stage, SN));
+  TRY(dalloc(&c->state_dev, (size_t)8));
+  TRY(dalloc(&c->istar, (size_t)1));
+  if (cfg->optimizer == DUST_OPT_ADAM) {
+    TRY(dalloc(&c->adam_m, ND));
+    TRY(dalloc(&c->adam_v, ND));
+    HIP_TRY(hipMemsetAsync(c->adam_m, 0, ND * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->adam_v, 0, ND * sizeof(float), c->stream));
+  }
+  // a_mix starts as ones (disco.py:110); uniform prior weights until set_prior
+  std::vector<float> ones((size_t)c->N, 1.0f);
+  HIP_TRY(hipMemcpyAsync(c->a_mix, ones.data(), c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mixw, ones.data(), c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  logmix_kernel<<<1, 1024, 0, c->stream>>>(c->mixw, c->logmix, c->N);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
+  if (!out) return fail(DUST_ERR_INVALID, "null out");
+  *out = nullptr;
+  int s = create_impl(cfg, out);
+  if (s != DUST_OK && *out) {
+    std::string keep = g_err;
+    free_all(*out);
+    delete *out;
+    *out = nullptr;
+    g_err = keep;
+  }
+  return s;
+}
+
+extern "C" int dust_sync(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_get_config(const dust_ctx *c, dust_config *out) {
+  if (!c || !out) return fail(DUST_ERR_INVALID, "null argument");
+  *out = c->cfg;
+  return DUST_OK;
+}
+
+extern "C" int dust_set_stream(dust_ctx *c, void *s) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream) HIP_TRY(hipStreamDestroy(c->stream));
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return DUST_OK;
+}
+
+static int d2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return DUST_OK;
+}
+static int h2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the caller owns (and may free/reuse) the host buffer
+  return DUST_OK;
+}
+static int d2h(dust_ctx *c, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
+  if (!src || !out) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(dust_create(&src->cfg, out));
+  dust_ctx *c = *out;
+  HIP_TRY(hipStreamSynchronize(src->stream));
+  const size_t ND = (size_t)c->N * c->D * sizeof(float), Nb = c->N * sizeof(float), SN = (size_t)c->S * c->N * sizeof(float);
+  struct {
+    float *dst;
+    const float *s;
+    size_t b;
+  } cp[] = {{c->theta, src->theta, ND}, {c->thetaT, src->thetaT, ND}, {c->mu, src->mu, ND}, {c->muT, src->muT, ND},
+            {c->a_mat, src->a_mat, ND}, {c->grad_lik, src->grad_lik, ND}, {c->score, src->score, ND}, {c->phi, src->phi, ND},
+            {c->logmix, src->logmix, Nb}, {c->mixw, src->mixw, Nb}, {c->a_mix, src->a_mix, Nb}, {c->eta, src->eta, Nb},
+            {c->logl, src->logl, Nb}, {c->a_seq, src->a_seq, c->D * sizeof(float)}, {c->costsT, src->costsT, SN}};
+  for (auto &e : cp) TRY(d2d(c, e.dst, e.s, e.b));
+  if (src->adam_m) {
+    TRY(d2d(c, c->adam_m, src->adam_m, ND));
+    TRY(d2d(c, c->adam_v, src->adam_v, ND));
+  }
+  c->adam_step = src->adam_step;
+  c->mu_aliased = src->mu_aliased;
+  c->tick = src->tick;
+  c->iter = src->iter;
+  c->have_sample = src->have_sample;
+  if (src->grid_bits) {
+    const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
+    TRY(dalloc(&c->grid_bits, words));
+    TRY(d2d(c, c->grid_bits, src->grid_bits, words * 4));
+    c->nx = src->nx;
+    c->ny = src->ny;
+    c->off_x = src->off_x;
+    c->off_y = src->off_y;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value, int kind) {
+  if (!c || !name) return fail(DUST_ERR_INVALID, "null argument");
+  dust_param *p = nullptr;
+  if (!strcmp(name, "g")) p = &c->cfg.g;
+  else if (!strcmp(name, "mass")) p = &c->cfg.mass;
+  else if (!strcmp(name, "length")) p = &c->cfg.length;
+  else return fail(DUST_ERR_INVALID, "unknown model parameter '%s'", name);
+  p->value = value;
+  if (kind >= 0 && p->kind != DUST_PARAM_SAMPLED) p->kind = kind;
+  return DUST_OK;
+}
+
+extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
+  if (!c || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
+  const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
+  std::vector<uint32_t> bits(words, 0u);
+  for (size_t i = 0; i < cells; ++i) {
+    if (grid[i] == 1.0f) bits[i >> 5] |= 1u << (i & 31);
+    else if (grid[i] != 0.0f) return fail(DUST_ERR_UNSUPPORTED, "occupancy grid must be binary (ObstacleMap writes 0/1)");
+  }
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->grid_bits) HIP_TRY(hipFree(c->grid_bits));
+  c->grid_bits = nullptr;
+  TRY(dalloc(&c->grid_bits, words));
+  TRY(h2d(c, c->grid_bits, bits.data(), words * 4));
+  c->nx = nx;
+  c->ny = ny;
+  c->off_x = off_x;
+  c->off_y = off_y;
+  return DUST_OK;
+}
+
+static int launch_transpose(dust_ctx *c, const float *src, float *dst, int N, int D) {
+  const int n = N * D;
+  transpose_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(src, dst, N, D);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
+  if (!c || !theta) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(h2d(c, c->theta, theta, (size_t)c->N * c->D * sizeof(float)));
+  TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+  if (c->adam_m) {
+    HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
+    c->adam_step = 0;
+  }
+  return DUST_OK;
+}
+extern "C" int dust_get_theta(dust_ctx *c, float *theta) {
+  if (!c || !theta) return fail(DUST_ERR_INVALID, "null argument");
+  return d2h(c, theta, c->theta, (size_t)c->N * c->D * sizeof(float));
+}
+extern "C" int dust_set_prior(dust_ctx *c, const float *means, const float *w) {
+  if (!c || !means) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(h2d(c, c->mu, means, (size_t)c->N * c->D * sizeof(float)));
+  TRY(launch_transpose(c, c->mu, c->muT, c->N, c->D));
+  c->mu_aliased = false;
+  if (w) {
+    for (int i = 0; i < c->N; ++i)
+      if (!(w[i] >= 0.f)) return fail(DUST_ERR_INVALID, "mixture weights must be >= 0 (torch.distributions.Categorical)");
+    TRY(h2d(c, c->mixw, w, c->N * sizeof(float)));
+  } else {
+    std::vector<float> ones((size_t)c->N, 1.0f);
+    TRY(h2d(c, c->mixw, ones.data(), c->N * sizeof(float)));
+  }
+  logmix_kernel<<<1, 1024, 0, c->stream>>>(c->mixw, c->logmix, c->N);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+extern "C" int dust_get_prior(dust_ctx *c, float *means, float *probs) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (means) TRY(d2h(c, means, c->mu_aliased ? c->theta : c->mu, (size_t)c->N * c->D * sizeof(float)));
+  if (probs) {
+    std::vector<float> w((size_t)c->N);
+    TRY(d2h(c, w.data(), c->mixw, c->N * sizeof(float)));
+    double s = 0;
+    for (float v : w) s += v;
+    for (int i = 0; i < c->N; ++i) probs[i] = w[i] / (float)s;
+  }
+  return DUST_OK;
+}
+extern "C" int dust_set_a_mat(dust_ctx *c, const float *a) {
+  if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  return h2d(c, c->a_mat, a, (size_t)c->N * c->D * sizeof(float));
+}
+extern "C" int dust_get_a_mat(dust_ctx *c, float *a) {
+  if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  return d2h(c, a, c->a_mat, (size_t)c->N * c->D * sizeof(float));
+}
+extern "C" int dust_get_a_mix(dust_ctx *c, float *a) {
+  if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->have_sample) {
+    amix_kernel<<<1, 1024, 0, c->stream>>>(c->eta, c->a_mix, c->N);
+    HIP_TRY(hipGetLastError());
+  }
+  return d2h(c, a, c->a_mix, c->N * sizeof(float));
+}
+extern "C" int dust_set_a_seq(dust_ctx *c, const float *a) {
+  if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  return h2d(c, c->a_seq, a, c->D * sizeof(float));
+}
+extern "C" int dust_get_a_seq(dust_ctx *c, float *a) {
+  if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  return d2h(c, a, c->a_seq, c->D * sizeof(float));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel A
+struct SampleOpts {
+  int noise_mode;
+  const float *noise_dev;  // device pointer [S][N][D] (eps or actions) or nullptr
+  const float *base;       // theta or a_mat
+  int eps_base_mode;
+  int update_a_mat;
+  const float *costs_in;   // device [S][N]: skip the rollouts and use these costs (stage-wise phi)
+  bool want_actions, want_states, want_omega;
+};
+
+static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
+  RolloutArgs a;
+  memset(&a, 0, sizeof a);
+  a.dm = make_dev_model(c);
+  if (c->cfg.model == DUST_MODEL_PARTICLE && c->cfg.with_obstacle && !c->grid_bits)
+    return fail(DUST_ERR_STATE, "with_obstacle is set but no occupancy grid was supplied (dust_set_grid)");
+  a.N_total = c->N;
+  a.n0 = c->n0;
+  a.S = c->S;
+  a.M = c->M;
+  a.H = c->H;
+  a.da = c->da;
+  a.ds = c->ds;
+  a.D = c->D;
+  a.noise_mode = o.noise_mode;
+  a.lik = c->cfg.likelihood;
+  a.eps_base_mode = o.eps_base_mode;
+  a.update_a_mat = o.update_a_mat;
+  a.alpha = c->cfg.alpha;
+  a.temp = c->cfg.temperature;
+  a.a_reg = c->cfg.a_reg;
+  for (int d = 0; d < 4; ++d) {
+    a.chol_a[d] = c->cfg.chol_a[d];
+    a.sigma_a[d] = c->cfg.sigma_a[d];
+    a.a_pre[d] = c->cfg.a_pre[d];
+  }
+  a.state = c->state_dev;
+  a.theta = o.base;
+  a.noise = o.noise_dev;
+  a.params = (c->cfg.dim_p > 0 && c->params_dev) ? c->params_dev : nullptr;
+  a.a_seq = c->a_seq;
+  a.a_mat = c->a_mat;
+  a.costsT = c->costsT;
+  a.costs_in = o.costs_in;
+  a.grad_lik = c->grad_lik;
+  a.logl = c->logl;
+  a.eta = c->eta;
+  a.omegaT = o.want_omega ? c->omegaT : nullptr;
+  if (o.want_actions) {
+    TRY(ensure(&c->actions, &c->actions_cap, (size_t)c->S * c->N * c->D));
+    a.actions_out = c->actions;
+  }
+  if (o.want_states) {
+    TRY(ensure(&c->states, &c->states_cap, (size_t)c->M * c->S * c->N * (c->H + 1) * c->ds));
+    a.states_out = c->states;
+  }
+  a.seed = c->cfg.seed;
+  a.tick = c->tick;
+  a.iter = c->iter;
+  int nt = ((std::max(c->S, c->D) + 63) / 64) * 64;
+  nt = std::min(std::max(nt, 64), 256);
+  const size_t lds = rollout_lds_bytes(c->S, c->D, nt);
+  if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "S*D action tile (%zu B) exceeds the 160 KiB LDS of a CU", lds);
+  Prof p(c, DUST_K_ROLLOUT);
+  if (c->cfg.model == DUST_MODEL_PENDULUM) {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PENDULUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rollout_kernel<DUST_MODEL_PENDULUM><<<c->nloc, nt, lds, c->stream>>>(a);
+  } else {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PARTICLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rollout_kernel<DUST_MODEL_PARTICLE><<<c->nloc, nt, lds, c->stream>>>(a);
+  }
+  HIP_TRY(hipGetLastError());
+  c->actions_valid = o.want_actions;
+  return DUST_OK;
+}
+
+static int upload_state_params(dust_ctx *c, const float *state, const float *params, int n_sets) {
+  if (state) TRY(h2d(c, c->state_dev, state, c->ds * sizeof(float)));
+  if (c->cfg.dim_p > 0 && c->M >= 1) {
+    if (params) {
+      TRY(ensure(&c->params_dev, &c->params_cap, (size_t)n_sets * c->M * c->P));
+      TRY(h2d(c, c->params_dev, params, (size_t)n_sets * c->M * c->P * sizeof(float)));
+    }
+  }
+  return DUST_OK;
+}
+
+static int stage_noise(dust_ctx *c, const float *src, int flags, const float **dev) {
+  const size_t n = (size_t)c->S * c->N * c->D;
+  if (!src) {
+    *dev = nullptr;
+    return DUST_OK;
+  }
+  if (flags & DUST_PTR_DEVICE) {
+    *dev = src;
+    return DUST_OK;
+  }
+  TRY(ensure(&c->noise_stage, &c->noise_cap, n));
+  TRY(h2d(c, c->noise_stage, src, n * sizeof(float)));
+  *dev = c->noise_stage;
+  return DUST_OK;
+}
+
+static int copy_out_SN(dust_ctx *c, const float *srcT, float *host) {  // device [N][S] -> host [S][N]
+  const int n = c->N * c->S;
+  transpose2_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(srcT, c->tmp, c->N, c->S);
+  HIP_TRY(hipGetLastError());
+  return d2h(c, host, c->tmp, (size_t)n * sizeof(float));
+}
+
+extern "C" int dust_get_costs(dust_ctx *c, float *costs) {
+  if (!c || !costs) return fail(DUST_ERR_INVALID, "null argument");
+  if (!c->have_sample) return fail(DUST_ERR_STATE, "no likelihood sample yet");
+  return copy_out_SN(c, c->costsT, costs);
+}
+extern "C" int dust_get_actions(dust_ctx *c, float *actions) {
+  if (!c || !actions) return fail(DUST_ERR_INVALID, "null argument");
+  if (!c->actions_valid) return fail(DUST_ERR_STATE, "the last sample did not keep its actions (pass actions_out)");
+  return d2h(c, actions, c->actions, (size_t)c->S * c->N * c->D * sizeof(float));
+}
+extern "C" int dust_get_score(dust_ctx *c, float *s) {
+  if (!c || !s) return fail(DUST_ERR_INVALID, "null argument");
+  return d2h(c, s, c->score, (size_t)c->N * c->D * sizeof(float));
+}
+extern "C" int dust_get_phi(dust_ctx *c, float *s) {
+  if (!c || !s) return fail(DUST_ERR_INVALID, "null argument");
+  return d2h(c, s, c->phi, (size_t)c->N * c->D * sizeof(float));
+}
+extern "C" int dust_get_log_weights(dust_ctx *c, float *ll, float *lp) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (ll) TRY(d2h(c, ll, c->logl, c->N * sizeof(float)));
+  if (lp) TRY(d2h(c, lp, c->logp, c->N * sizeof(float)));
+  return DUST_OK;
+}
+extern "C" int dust_get_bandwidths(dust_ctx *c, float *h) {
+  if (!c || !h) return fail(DUST_ERR_INVALID, "null argument");
+  const int G = c->cfg.kernel == DUST_KERNEL_K2_SHARED ? c->H : c->D;
+  return d2h(c, h, c->bw, G * sizeof(float));
+}
+extern "C" int dust_likelihood_log_prob(dust_ctx *c, float *ll) {
+  if (!c || !ll) return fail(DUST_ERR_INVALID, "null argument");
+  if (!c->have_sample) return fail(DUST_ERR_STATE, "no likelihood sample yet");
+  return d2h(c, ll, c->logl, c->N * sizeof(float));
+}
+
+extern "C" int dust_disco_forward(dust_ctx *c, const float *state, const float *actions, const float *params, int flags,
+                                  float *costs, float *states, float *actions_out, float *omega) {
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, 1));
+  const float *nd = nullptr;
+  TRY(stage_noise(c, actions, flags, &nd));
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  const bool internal = (actions == nullptr);
+  const bool around_a_mat = internal || (flags & DUST_EPS_AROUND_A_MAT);
+  o.noise_mode = internal ? NOISE_PHILOX : NOISE_ACTIONS;
+  o.noise_dev = nd;
+  o.base = around_a_mat ? c->a_mat : c->theta;
+  o.eps_base_mode = around_a_mat ? 1 : 0;
+  o.update_a_mat = 1;
+  o.want_actions = actions_out != nullptr;
+  o.want_states = states != nullptr;
+  o.want_omega = omega != nullptr;
+  TRY(launch_rollout(c, o));
+  c->have_sample = true;
+  c->iter++;
+  if (costs) TRY(copy_out_SN(c, c->costsT, costs));
+  if (omega) TRY(copy_out_SN(c, c->omegaT, omega));
+  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
+  if (states) TRY(d2h(c, states, c->states, (size_t)c->M * c->S * c->N * (c->H + 1) * c->ds * sizeof(float)));
+  return DUST_OK;
+}
+
+extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const float *eps, const float *params, int flags,
+                                      float *costs, float *actions_out) {
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, 1));
+  const float *nd = nullptr;
+  TRY(stage_noise(c, eps, flags, &nd));
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = eps ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = nd;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  o.want_actions = actions_out != nullptr;
+  o.want_states = (flags & DUST_STORE_STATES) != 0;
+  TRY(launch_rollout(c, o));
+  c->have_sample = true;
+  c->iter++;
+  if (costs) TRY(copy_out_SN(c, c->costsT, costs));
+  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
+  return DUST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise passes
+static void pick_tile(const dust_ctx *c, int *TI, int *JC, int *nt) {
+  *TI = (c->nloc >= 4096) ? 8 : 4;
+  *JC = std::min(c->N, 2048);
+  *nt = 256;
+}
+
+template <int MODE>
+static int launch_pair(dust_ctx *c, const PairArgs &a, int TI, int nt) {
+  const int blocks = (a.n_local + TI - 1) / TI;
+  const size_t lds = pairwise_lds_bytes(TI, a.D, a.JC, nt);
+  if (TI == 4) {
+    pairwise_kernel<MODE, 4><<<blocks, nt, lds, c->stream>>>(a);
+  } else {
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pairwise_kernel<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    pairwise_kernel<MODE, 8><<<blocks, nt, lds, c->stream>>>(a);
+  }
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+static int launch_prior(dust_ctx *c, bool want_grad, bool want_logp) {
+  PairArgs a;
+  memset(&a, 0, sizeof a);
+  int TI, nt;
+  pick_tile(c, &TI, &a.JC, &nt);
+  a.N = c->N;
+  a.D = c->D;
+  a.da = c->da;
+  a.H = c->H;
+  a.i0 = c->n0;
+  a.n_local = c->nloc;
+  a.X = c->theta;
+  a.YT = c->mu_aliased ? c->thetaT : c->muT;
+  a.Y = c->mu_aliased ? c->theta : c->mu;
+  a.logmix = c->logmix;
+  double logdet = 0;
+  for (int d = 0; d < c->da; ++d) {
+    a.inv_s[d] = 1.0f / c->cfg.sigma_p[d];
+    a.inv_s2[d] = 1.0f / (c->cfg.sigma_p[d] * c->cfg.sigma_p[d]);
+    logdet += log((double)c->cfg.sigma_p[d]);
+  }
+  a.log_norm = (float)(-c->H * logdet - 0.5 * c->D * log(2.0 * M_PI));
+  a.inv_n = 1.0f / c->N;
+  a.out = want_grad ? c->grad_pri : nullptr;
+  a.add = c->grad_lik;
+  a.out2 = want_grad ? c->score : nullptr;
+  a.logp = want_logp ? c->logp : nullptr;
+  Prof p(c, DUST_K_PRIOR_SCORE);
+  return launch_pair<PAIR_PRIOR>(c, a, TI, nt);
+}
+
+static int launch_stein(dust_ctx *c) {
+  if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
+    Prof p(c, DUST_K_BANDWIDTH);
+    K2Args k;
+    memset(&k, 0, sizeof k);
+    k.N = c->N;
+    k.H = c->H;
+    k.da = c->da;
+    k.D = c->D;
+    k.shared = c->cfg.kernel == DUST_KERNEL_K2_SHARED;
+    k.i0 = c->n0;
+    k.n_local = c->nloc;
+    k.bw_scale = c->cfg.bw_scale;
+    k.theta = c->theta;
+    k.thetaT = c->thetaT;
+    k.score = c->score;
+    k.h = c->bw;
+    k.phi = c->phi;
+    return launch_k2(c->stream, k);
+  }
+  PairArgs a;
+  memset(&a, 0, sizeof a);
+  int TI, nt;
+  pick_tile(c, &TI, &a.JC, &nt);
+  a.N = c->N;
+  a.D = c->D;
+  a.da = c->da;
+  a.H = c->H;
+  a.i0 = c->n0;
+  a.n_local = c->nloc;
+  a.X = c->theta;
+  a.YT = c->thetaT;
+  a.Y = c->theta;
+  a.V = c->score;
+  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;  // softplus(0) = ln 2 (svmpc.py:78 typo keeps it)
+  for (int d = 0; d < 4; ++d) {
+    a.inv_s[d] = 1.0f / ell;
+    a.inv_s2[d] = 1.0f / (ell * ell);
+  }
+  a.inv_n = 1.0f / c->N;
+  a.out = c->phi;
+  Prof p(c, DUST_K_STEIN);
+  if (c->cfg.kernel == DUST_KERNEL_IMQ) return launch_pair<PAIR_IMQ>(c, a, TI, nt);
+  return launch_pair<PAIR_K1>(c, a, TI, nt);
+}
+
+static int launch_update(dust_ctx *c) {
+  UpdateArgs u;
+  memset(&u, 0, sizeof u);
+  u.N = c->N;
+  u.D = c->D;
+  u.i0 = c->n0;
+  u.n_local = c->nloc;
+  u.optimizer = c->cfg.optimizer;
+  u.lr = c->cfg.lr;
+  u.beta1 = c->cfg.adam_beta1;
+  u.beta2 = c->cfg.adam_beta2;
+  u.eps = c->cfg.adam_eps;
+  u.step = ++c->adam_step;
+  u.phi = c->phi;
+  u.theta = c->theta;
+  u.thetaT = c->thetaT;
+  u.adam_m = c->adam_m;
+  u.adam_v = c->adam_v;
+  const int n = c->nloc * c->D;
+  Prof p(c, DUST_K_UPDATE);
+  update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *actions, float *phi, float *grad_lik, float *grad_pri) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if ((costs == nullptr) != (actions == nullptr)) return fail(DUST_ERR_INVALID, "pass both costs and actions, or neither");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (costs) {
+    // a user-supplied log_p returned (costs, actions): only the weights / score reductions of kernel A run
+    const float *nd = nullptr;
+    TRY(stage_noise(c, actions, 0, &nd));
+    TRY(h2d(c, c->costs_stage, costs, (size_t)c->S * c->N * sizeof(float)));
+    SampleOpts o;
+    memset(&o, 0, sizeof o);
+    o.noise_mode = NOISE_ACTIONS;
+    o.noise_dev = nd;
+    o.base = c->theta;
+    o.costs_in = c->costs_stage;
+    TRY(launch_rollout(c, o));
+  } else if (!c->have_sample) {
+    return fail(DUST_ERR_STATE, "phi without costs/actions needs a prior dust_likelihood_sample");
+  }
+  TRY(launch_prior(c, true, false));
+  TRY(launch_stein(c));
+  if (phi) TRY(d2h(c, phi, c->phi, (size_t)c->N * c->D * sizeof(float)));
+  if (grad_lik) TRY(d2h(c, grad_lik, c->grad_lik, (size_t)c->N * c->D * sizeof(float)));
+  if (grad_pri) TRY(d2h(c, grad_pri, c->grad_pri, (size_t)c->N * c->D * sizeof(float)));
+  return DUST_OK;
+}
+
+static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = noise_dev ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = noise_dev;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  float *save = c->params_dev;
+  if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
+  int s = launch_rollout(c, o);
+  c->params_dev = save;
+  TRY(s);
+  c->have_sample = true;
+  TRY(launch_prior(c, true, false));
+  TRY(launch_stein(c));
+  TRY(launch_update(c));
+  c->iter++;
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_optimize(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags) {
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (n_steps < 0) return fail(DUST_ERR_INVALID, "n_steps < 0");
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: drive it with dust_svmpc_local_score / dust_svmpc_apply_phi");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, n_steps));
+  const size_t slice = (size_t)c->S * c->N * c->D;
+  for (int k = 0; k < n_steps; ++k) {
+    const float *nd = nullptr;
+    if (eps) {
+      if (flags & DUST_PTR_DEVICE) nd = eps + (size_t)k * slice;
+      else TRY(stage_noise(c, eps + (size_t)k * slice, 0, &nd));
+    }
+    TRY(step_device(c, nd, k));
+  }
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_step(dust_ctx *c, const float *state, const float *eps, const float *params, int flags) {
+  return dust_svmpc_optimize(c, state, 1, eps, params, flags);
+}
+
+static int forward_device(dust_ctx *c) {
+  if (!c->have_sample) return fail(DUST_ERR_STATE, "forward(fast_pred=True) needs the costs of a previous optimize step");
+  TRY(launch_prior(c, false, true));
+  Prof p(c, DUST_K_FORWARD);
+  logw_kernel<<<(c->nloc + 255) / 256, 256, 0, c->stream>>>(c->logl, c->logp, c->lw, c->n0, c->nloc);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+static int forward_finish_device(dust_ctx *c) {
+  Prof p(c, DUST_K_FORWARD);
+  FinalizeArgs f;
+  memset(&f, 0, sizeof f);
+  f.N = c->N;
+  f.D = c->D;
+  f.logl = c->logl;
+  f.logp = c->logp;
+  f.lw = c->lw;
+  f.pw = c->pw;
+  f.istar = c->istar;
+  f.theta = c->theta;
+  f.a_seq_out = c->a_seq_out;
+  f.logmix = c->logmix;
+  f.mixw = c->mixw;
+  f.weighted_prior = c->cfg.weighted_prior;
+  finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
+  HIP_TRY(hipGetLastError());
+  const int n = c->nloc * c->da;
+  roll_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->theta, c->thetaT, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
+  HIP_TRY(hipGetLastError());
+  c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
+  c->tick++;
+  c->iter = 0;
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: use dust_svmpc_forward_local / _finish");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(forward_device(c));
+  TRY(forward_finish_device(c));
+  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
+  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags,
+                               float *a_seq, float *p_weights) {
+  TRY(dust_svmpc_optimize(c, state, n_steps, eps, params, flags));
+  TRY(forward_device(c));
+  TRY(forward_finish_device(c));
+  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
+  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  return DUST_OK;
+}
+
+extern "C" int dust_disco_step(dust_ctx *c, int strategy, int steps, const float *ext, float *next) {
+  if (!c || !next) return fail(DUST_ERR_INVALID, "null argument");
+  if (strategy < 0 || strategy > 2 || (strategy == DUST_STEP_EXTERNAL && !ext)) return fail(DUST_ERR_INVALID, "Invalid value for strategy.");
+  if (steps < 1 || steps > c->H) return fail(DUST_ERR_INVALID, "steps out of range");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->have_sample) {
+    amix_kernel<<<1, 1024, 0, c->stream>>>(c->eta, c->a_mix, c->N);
+    HIP_TRY(hipGetLastError());
+  }
+  StepArgs s;
+  memset(&s, 0, sizeof s);
+  s.N = c->N;
+  s.H = c->H;
+  s.da = c->da;
+  s.strategy = strategy;
+  s.steps = steps;
+  for (int d = 0; d < 4; ++d) {
+    s.min_a[d] = c->cfg.min_a[d];
+    s.max_a[d] = c->cfg.max_a[d];
+  }
+  s.a_mix = c->a_mix;
+  if (ext) {
+    TRY(h2d(c, c->a_seq_out, ext, c->D * sizeof(float)));
+    s.ext = c->a_seq_out;
+  }
+  s.a_mat = c->a_mat;
+  s.a_seq = c->a_seq;
+  s.next = c->tmp;
+  disco_step_kernel<<<1, 1024, c->D * sizeof(float), c->stream>>>(s);
+  HIP_TRY(hipGetLastError());
+  const int n = c->N * c->da;
+  amat_roll_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->a_mat, c->N, c->H, c->da, steps);
+  HIP_TRY(hipGetLastError());
+  return d2h(c, next, c->tmp, (size_t)steps * c->da * sizeof(float));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU split of one SVGD iteration around the RCCL all-gather of [theta | score]
+extern "C" int dust_gather_buffers(dust_ctx *c, void **theta_all, void **score_all, size_t *shard_bytes) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (theta_all) *theta_all = c->theta;
+  if (score_all) *score_all = c->score;
+  if (shard_bytes) *shard_bytes = (size_t)c->nloc * c->D * sizeof(float);
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_local_score(dust_ctx *c, const float *state, const float *eps, const float *params, int flags) {
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, 1));
+  const float *nd = nullptr;
+  TRY(stage_noise(c, eps, flags, &nd));
+  // theta rows of the other shards were refreshed by the caller's all-gather: rebuild the transposed copy
+  if (c->nloc != c->N) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = nd ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = nd;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  TRY(launch_rollout(c, o));
+  c->have_sample = true;
+  TRY(launch_prior(c, true, false));
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_apply_phi(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(launch_stein(c));
+  TRY(launch_update(c));
+  c->iter++;
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_forward_local(dust_ctx *c, void **log_w_all, size_t *shard_bytes) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->nloc != c->N) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+  TRY(forward_device(c));
+  if (log_w_all) *log_w_all = c->lw;
+  if (shard_bytes) *shard_bytes = (size_t)c->nloc * sizeof(float);
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_weights) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(forward_finish_device(c));
+  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
+  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  return DUST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int dust_profile_enable(dust_ctx *c, int on) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  c->prof = on != 0;
+  return DUST_OK;
+}
+extern "C" int dust_profile_reset(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  memset(c->prof_ms, 0, sizeof c->prof_ms);
+  memset(c->prof_n, 0, sizeof c->prof_n);
+  return DUST_OK;
+}
+extern "C" int dust_profile_get(dust_ctx *c, int id, double *ms, int64_t *n) {
+  if (!c || id < 0 || id >= DUST_K_COUNT) return fail(DUST_ERR_INVALID, "bad argument");
+  if (ms) *ms = c->prof_ms[id];
+  if (n) *n = c->prof_n[id];
+  return DUST_OK;
+}
+extern "C" int dust_rollout_algorithmic_bytes(const dust_ctx *c, int flags, double *bytes) {
+  if (!c || !bytes) return fail(DUST_ERR_INVALID, "null argument");
+  // B_roll = 4 [S N D (eps in) + N D (theta in) + M P (params) + S N (costs out)] (+ states when stored)
+  double b = 4.0 * ((double)c->S * c->nloc * c->D + (double)c->nloc * c->D + (double)c->M * c->P + (double)c->S * c->nloc);
+  b += 4.0 * (double)c->nloc * c->D;  // grad_lik out
+  if (flags & DUST_STORE_STATES) b += 4.0 * (double)c->M * c->S * c->nloc * (c->H + 1) * c->ds;
+  *bytes = b;
+  return DUST_OK;
+}
+
+__global__ void noise_fill_kernel(float *dst, size_t n, uint64_t seed) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= n) return;
+  float z[4];
+  philox_normal4(seed, (uint32_t)i4, (uint32_t)(i4 >> 32), 0x5eedu, 0xd057u, z);
+  for (int q = 0; q < 4; ++q)
+    if (i4 * 4 + q < n) dst[i4 * 4 + q] = z[q];
+}
+extern "C" int dust_device_noise_alloc(dust_ctx *c, size_t n, uint64_t seed, void **dptr) {
+  if (!c || !dptr) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  float *p = nullptr;
+  TRY(dalloc(&p, n));
+  const size_t n4 = (n + 3) / 4;
+  noise_fill_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, c->stream>>>(p, n, seed);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *dptr = p;
+  return DUST_OK;
+}
+extern "C" int dust_device_free(dust_ctx *c, void *p) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (p) HIP_TRY(hipFree(p));
+  return DUST_OK;
+}
+
+#include "mpf.hpp"

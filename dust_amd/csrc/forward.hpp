@@ -1,0 +1,238 @@
+// forward.hpp - tick epilogue: particle weights, argmax, roll, prior refresh; a_mix; MultiDISCO.step.
+//
+// Replaces (reference file:line): SVMPC.get_weights svmpc.py:128-140, SVMPC.forward svmpc.py:172-200, SVMPC.roll
+// svmpc.py:142-158, SVMPC.update_prior svmpc.py:160-170 (+ get_gmm svgd.py:84-89 and the Categorical/
+// MixtureSameFamily log-weight construction in torch.distributions), a_mix disco.py:393, MultiDISCO.step disco.py:396-417.
+#pragma once
+#include "common.hpp"
+
+namespace dust {
+
+struct FinalizeArgs {
+  int N, D;
+  const float *logl, *logp;  // [N]
+  float *lw;                 // [N] log_l + log_p (gathered across shards by the caller when sharded)
+  float *pw;                 // [N] out: particle weights
+  int *istar;                // out
+  const float *theta;        // [N][D]
+  float *a_seq_out;          // [D] out: theta[i*]
+  float *logmix;             // [N] out: new prior log mixture weights
+  float *mixw;               // [N] out: new prior mixture weights as given to get_gmm (ones or p)
+  int weighted_prior;
+};
+
+// lw = logl + logp for the local shard (separate tiny kernel so a sharded caller can all-gather lw in between)
+__global__ void logw_kernel(const float *logl, const float *logp, float *lw, int i0, int n_local) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_local) lw[i0 + i] = logl[i0 + i] + logp[i0 + i];
+}
+
+// single workgroup: softmax over N, first-index argmax, a_seq, new mixture log-weights
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
+  __shared__ float red[32];
+  __shared__ int redi[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float m = -INFINITY;
+  for (int i = tid; i < a.N; i += nt) m = fmaxf(m, a.lw[i]);
+  m = block_reduce<RED_MAX>(m, red);
+  float z = 0.f;
+  for (int i = tid; i < a.N; i += nt) z += expf(a.lw[i] - m);
+  z = block_reduce<RED_SUM>(z, red);
+  const float lz = m + logf(z);
+  // p = exp(log_w - logsumexp(log_w)) ; argmax = first index of the maximum (torch.argmax on CPU)
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  float psum = 0.f;
+  for (int i = tid; i < a.N; i += nt) {
+    const float p = expf(a.lw[i] - lz);
+    a.pw[i] = p;
+    psum += p;
+    if (p > best) {
+      best = p;
+      bi = i;
+    }
+  }
+  // block argmax with lowest-index tie break
+  const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    red[wid] = best;
+    redi[wid] = bi;
+  }
+  __syncthreads();
+  best = red[0];
+  bi = redi[0];
+  for (int w = 1; w < nw; ++w)
+    if (red[w] > best || (red[w] == best && redi[w] < bi)) {
+      best = red[w];
+      bi = redi[w];
+    }
+  if (tid == 0) *a.istar = bi;
+  for (int d = tid; d < a.D; d += nt) a.a_seq_out[d] = a.theta[(size_t)bi * a.D + d];
+  // new prior mixture: Categorical(probs = w / sum w) -> logits = log(clamp(probs, eps, 1 - eps)) -> log_softmax
+  psum = block_reduce<RED_SUM>(psum, red);
+  const float wsum = a.weighted_prior ? psum : (float)a.N;
+  float lm = -INFINITY;
+  for (int i = tid; i < a.N; i += nt) {
+    const float w = a.weighted_prior ? a.pw[i] : 1.0f;
+    a.mixw[i] = w;
+    float p = w / wsum;
+    p = fminf(fmaxf(p, 1.1920929e-07f), 1.0f - 1.1920929e-07f);
+    const float l = logf(p);
+    a.logmix[i] = l;
+    lm = fmaxf(lm, l);
+  }
+  lm = block_reduce<RED_MAX>(lm, red);
+  float zs = 0.f;
+  for (int i = tid; i < a.N; i += nt) zs += expf(a.logmix[i] - lm);
+  zs = block_reduce<RED_SUM>(zs, red);
+  const float lzz = lm + logf(zs);
+  for (int i = tid; i < a.N; i += nt) a.logmix[i] = a.logmix[i] - lzz;
+}
+
+// mixture log-weights from user-supplied weights (set_prior): same construction as above
+__global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *logmix, int N) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float s = 0.f;
+  for (int i = tid; i < N; i += nt) s += w[i];
+  s = block_reduce<RED_SUM>(s, red);
+  float lm = -INFINITY;
+  for (int i = tid; i < N; i += nt) {
+    float p = w[i] / s;
+    p = fminf(fmaxf(p, 1.1920929e-07f), 1.0f - 1.1920929e-07f);
+    const float l = logf(p);
+    logmix[i] = l;
+    lm = fmaxf(lm, l);
+  }
+  lm = block_reduce<RED_MAX>(lm, red);
+  float zs = 0.f;
+  for (int i = tid; i < N; i += nt) zs += expf(logmix[i] - lm);
+  zs = block_reduce<RED_SUM>(zs, red);
+  const float lzz = lm + logf(zs);
+  for (int i = tid; i < N; i += nt) logmix[i] = logmix[i] - lzz;
+}
+
+// SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy. One thread per (i, d_a).
+__global__ void roll_kernel(float *theta, float *thetaT, int N, int H, int da, int strategy, int i0, int n_local) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_local * da) return;
+  const int i = i0 + idx / da, c = idx % da;
+  const int D = H * da;
+  float *th = theta + (size_t)i * D;
+  float mean = 0.f;
+  if (strategy == DUST_ROLL_MEAN) {
+    double acc = 0.0;
+    for (int t = 0; t < H; ++t) acc += (double)th[t * da + c];
+    mean = (float)(acc / H);
+  }
+  float last = th[(H - 1) * da + c];
+  for (int t = 0; t + 1 < H; ++t) {
+    const float v = th[(t + 1) * da + c];
+    th[t * da + c] = v;
+    thetaT[(size_t)(t * da + c) * N + i] = v;
+  }
+  if (strategy == DUST_ROLL_MEAN) last = mean;
+  th[(H - 1) * da + c] = last;
+  thetaT[(size_t)((H - 1) * da + c) * N + i] = last;
+}
+
+// a_mix = softmax_n(eta) disco.py:393 (single workgroup)
+__global__ __launch_bounds__(1024) void amix_kernel(const float *eta, float *a_mix, int N) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float m = -INFINITY;
+  for (int i = tid; i < N; i += nt) m = fmaxf(m, eta[i]);
+  m = block_reduce<RED_MAX>(m, red);
+  float z = 0.f;
+  for (int i = tid; i < N; i += nt) z += expf(eta[i] - m);
+  z = block_reduce<RED_SUM>(z, red);
+  const float lz = m + logf(z);
+  for (int i = tid; i < N; i += nt) a_mix[i] = expf(eta[i] - lz);
+}
+
+// MultiDISCO.step disco.py:396-417 (single workgroup; N*D is small)
+struct StepArgs {
+  int N, H, da, strategy, steps;
+  float min_a[4], max_a[4];
+  const float *a_mix;
+  const float *ext;  // [D] for strategy external
+  float *a_mat;      // [N][D]
+  float *a_seq;      // [D]
+  float *next;       // [steps][da]
+};
+__global__ __launch_bounds__(1024) void disco_step_kernel(const StepArgs a) {
+  __shared__ float red[32];
+  __shared__ int redi[32];
+  __shared__ int s_best;
+  extern __shared__ float seq[];  // [D]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int D = a.H * a.da;
+  if (a.strategy == DUST_STEP_ARGMAX) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < a.N; i += nt)
+      if (a.a_mix[i] > best) {
+        best = a.a_mix[i];
+        bi = i;
+      }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if ((tid & 63) == 0) {
+      red[tid >> 6] = best;
+      redi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < (nt + 63) / 64; ++w)
+        if (red[w] > best || (red[w] == best && redi[w] < bi)) {
+          best = red[w];
+          bi = redi[w];
+        }
+      s_best = bi;
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += nt) {
+      const float v = clampf(a.a_mat[(size_t)s_best * D + j], a.min_a[j % a.da], a.max_a[j % a.da]);
+      seq[j] = v;
+      a.a_mat[(size_t)s_best * D + j] = v;  // quirk: a_mat[argmax] is a view, the in-place clamp_ reaches a_mat too
+    }
+  } else if (a.strategy == DUST_STEP_AVERAGE) {
+    for (int j = tid; j < D; j += nt) {
+      double acc = 0.0;
+      for (int n = 0; n < a.N; ++n) acc += (double)a.a_mat[(size_t)n * D + j] * (double)a.a_mix[n];
+      seq[j] = clampf((float)acc, a.min_a[j % a.da], a.max_a[j % a.da]);
+    }
+  } else {
+    for (int j = tid; j < D; j += nt) seq[j] = clampf(a.ext[j], a.min_a[j % a.da], a.max_a[j % a.da]);
+  }
+  __syncthreads();
+  for (int j = tid; j < a.steps * a.da; j += nt) a.next[j] = seq[j];
+  const int sh = a.steps * a.da;
+  for (int j = tid; j < D; j += nt) a.a_seq[j] = (j + sh < D) ? seq[j + sh] : 0.f;
+}
+
+// a_mat.roll(-steps, dims=1) with zero fill (disco.py:415-416): one thread per (n, control dim), sequential in t
+__global__ void amat_roll_kernel(float *a_mat, int N, int H, int da, int steps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * da) return;
+  const int n = idx / da, c = idx % da;
+  float *row = a_mat + (size_t)n * H * da;
+  for (int t = 0; t < H; ++t) row[t * da + c] = (t + steps < H) ? row[(t + steps) * da + c] : 0.f;
+}
+
+}  // namespace dust

@@ -1,0 +1,432 @@
+// mpf.hpp - dynamics-parameter SVGD filter ("MPF"), included at the end of dust_amd.hip.
+//
+// Replaces (reference file:line): MPF.phi / step / optimize / update_prior mpf.py:26-86, GaussianLikelihood.sample /
+// log_prob / condition likelihoods.py:30-64, default_kernel + squared_distance svgd.py:28-39, 92-99, and the autograd
+// calls at mpf.py:45 and mpf.py:50 (closed forms: GMM responsibilities; J^T (y - f(x)) / sigma_o^2 with the analytic
+// Jacobian of one model step w.r.t. the uncertain parameters).
+//
+// The problem is tiny (M_p <= 1024 particles x P <= 4 parameters, n_steps ~ 20 dependent SVGD steps), i.e. pure launch
+// latency on a GPU: ALL n_steps run inside ONE single-workgroup kernel with the particles, scores and squared norms in
+// LDS and one lane per particle; the only HBM traffic is the final particle write-back and the gradient norms.
+//
+// Reference quirk kept: MPF.update_prior hands `self.x` itself to MultivariateNormal(loc=...), which aliases the
+// particle storage, and SGD updates x in place - so the prior means are always the CURRENT particles (mpf.py:26-38).
+#pragma once
+
+namespace dust {
+
+struct MpfArgs {
+  DevModel dm;
+  int Mp, P, ds, da, n_steps, log_space, have_past;
+  float prior_bw, bw, lr, obs_std;
+  float past_obs[4], past_action[2], obs[4];
+  float *x;           // [Mp][P] in/out
+  float *grad_norms;  // [n_steps] or nullptr
+  float *phi_out;     // [Mp][P] or nullptr (phi of the first step, when n_steps == 0 semantics are wanted use n_steps=1, lr=0)
+};
+
+// d(next state)/d(params) of one model step, as autograd returns it through model.step (incl. clamp masks)
+__device__ inline void step_jacobian(const DevModel &dm, const float *x, const float *a, const float *prow, double *J /*[ds][P]*/,
+                                     int ds) {
+  const int P = dm.P;
+  for (int i = 0; i < ds * P; ++i) J[i] = 0.0;
+  double pv[4];
+  for (int p = 0; p < P; ++p) pv[p] = dm.log_space ? exp((double)prow[p]) : (double)prow[p];
+  if (dm.model == DUST_MODEL_PENDULUM) {
+    const double g = dm.g.kind == DUST_PARAM_SAMPLED ? pv[dm.g.col] : dm.g.value;
+    const double m = dm.mass.kind == DUST_PARAM_SAMPLED ? pv[dm.mass.col] : dm.mass.value;
+    const double l = dm.length.kind == DUST_PARAM_SAMPLED ? pv[dm.length.col] : dm.length.value;
+    const double dt = dm.dt;
+    const double u = clampf(a[0], -dm.max_torque, dm.max_torque);
+    const double s = sin((double)x[0] + M_PI);
+    const double thd = (double)x[1] + dt * (-3.0 * g / (2.0 * l) * s + 3.0 / (m * l * l) * u);
+    if (!(thd >= -dm.max_speed_pend && thd <= dm.max_speed_pend)) return;
+    const double dthd[3] = {dt * (-3.0 / (2.0 * l) * s), dt * (-3.0 / (m * m * l * l) * u),
+                            dt * (3.0 * g / (2.0 * l * l) * s - 6.0 / (m * l * l * l) * u)};
+    const DevParam *ps[3] = {&dm.g, &dm.mass, &dm.length};
+    for (int q = 0; q < 3; ++q)
+      if (ps[q]->kind == DUST_PARAM_SAMPLED) {
+        const int col = ps[q]->col;
+        const double chain = dm.log_space ? pv[col] : 1.0;
+        J[1 * P + col] += dthd[q] * chain;
+        J[0 * P + col] += dthd[q] * dt * chain;
+      }
+  } else {
+    if (dm.mass.kind != DUST_PARAM_SAMPLED) return;
+    const int col = dm.mass.col;
+    const double m = pv[col], dt = dm.dt;
+    double om = 1.0;
+    if (dm.can_crash && dm.with_obstacle) om = 1.0 - (double)collision(dm, x[0], x[1]);
+    for (int k = 0; k < 2; ++k) {
+      const double acc = (double)a[k] / m;
+      const bool live_a = acc >= -dm.max_acc && acc <= dm.max_acc;
+      const double accc = acc < -dm.max_acc ? -dm.max_acc : (acc > dm.max_acc ? dm.max_acc : acc);
+      const double v = (double)x[2 + k] + accc * dt * om;
+      const bool live_v = v >= -dm.max_speed && v <= dm.max_speed;
+      if (live_a && live_v) J[(2 + k) * P + col] = dt * om * (-(double)a[k] / (m * m)) * (dm.log_space ? m : 1.0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, Mp = a.Mp, P = a.P;
+  float *xs = sm;             // [Mp][P]
+  float *sc = xs + Mp * P;    // [Mp][P] scores
+  float *nrm = sc + Mp * P;   // [Mp] squared norms
+  float *red = nrm + Mp;      // [32]
+  const bool on = tid < Mp;
+  if (on)
+    for (int p = 0; p < P; ++p) xs[tid * P + p] = a.x[tid * P + p];
+  __syncthreads();
+  const float bw2 = (float)((double)a.bw * (double)a.bw);
+  for (int it = 0; it < a.n_steps; ++it) {
+    float xi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      for (int p = 0; p < P; ++p) xi[p] = xs[tid * P + p];
+      // prior score (mpf.py:45): means alias the current particles, covariance prior_bw^2 I, uniform mixture
+      double mx = -INFINITY;
+      for (int k = 0; k < Mp; ++k) {
+        double q = 0.0;
+        for (int p = 0; p < P; ++p) {
+          const double z = ((double)xi[p] - (double)xs[k * P + p]) / (double)a.prior_bw;
+          q += z * z;
+        }
+        mx = fmax(mx, -0.5 * q);
+      }
+      double zs = 0.0, acc[4] = {0, 0, 0, 0};
+      for (int k = 0; k < Mp; ++k) {
+        double q = 0.0;
+        for (int p = 0; p < P; ++p) {
+          const double z = ((double)xi[p] - (double)xs[k * P + p]) / (double)a.prior_bw;
+          q += z * z;
+        }
+        const double w = exp(-0.5 * q - mx);
+        zs += w;
+        for (int p = 0; p < P; ++p) acc[p] += w * ((double)xs[k * P + p] - (double)xi[p]);
+      }
+      double s[4];
+      for (int p = 0; p < P; ++p) s[p] = acc[p] / zs / ((double)a.prior_bw * (double)a.prior_bw);
+      // likelihood score (mpf.py:46-50, likelihoods.py:30-49)
+      float pred[4];
+      for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
+      const Coef cf = make_coef(a.dm, xi);
+      if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
+      else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+      double J[16];
+      step_jacobian(a.dm, a.past_obs, a.past_action, xi, J, a.ds);
+      for (int p = 0; p < P; ++p) {
+        double g = 0.0;
+        for (int k = 0; k < a.ds; ++k) g += J[k * P + p] * ((double)a.obs[k] - (double)pred[k]);
+        s[p] += g / ((double)a.obs_std * (double)a.obs_std);
+        sc[tid * P + p] = (float)s[p];
+      }
+      float nn = 0.f;
+      for (int p = 0; p < P; ++p) nn = nn + xi[p] * xi[p];
+      nrm[tid] = nn;
+    }
+    __syncthreads();
+    // kernel + phi (svgd.py:92-99, mpf.py:52-56).  squared_distance's fp32 addmm rounding is followed: it is part of the
+    // reference's result (d^2 / bw^2 amplifies it) - dot as an fma chain, then |b|^2 - 2 a.b, then + |a|^2, clamp 0.
+    float ph[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
+      for (int j = 0; j < Mp; ++j) {
+        float dot = xi[0] * xs[j * P];
+        for (int r = 1; r < P; ++r) dot = fmaf(xi[r], xs[j * P + r], dot);
+        float q = (nrm[j] + (-2.0f * dot)) + nrm[tid];
+        q = fmaxf(q, 0.f);
+        const double k = (double)expf(((-q) / bw2) / 2.0f);
+        for (int p = 0; p < P; ++p) {
+          gk[p] += -k * ((double)xi[p] - (double)xs[j * P + p]) / ((double)a.bw * (double)a.bw);
+          ks[p] += k * (double)sc[j * P + p];
+        }
+      }
+      for (int p = 0; p < P; ++p) ph[p] = (float)(gk[p] + ks[p] / Mp);
+    }
+    float n2 = 0.f;
+    for (int p = 0; p < P; ++p) n2 += ph[p] * ph[p];
+    n2 = block_reduce<RED_SUM>(n2, red);
+    if (tid == 0 && a.grad_norms) a.grad_norms[it] = sqrtf(n2);
+    if (on && it == 0 && a.phi_out)
+      for (int p = 0; p < P; ++p) a.phi_out[tid * P + p] = ph[p];
+    __syncthreads();
+    if (on)
+      for (int p = 0; p < P; ++p) xs[tid * P + p] = fmaf(a.lr, ph[p], xi[p]);
+    __syncthreads();
+  }
+  if (on)
+    for (int p = 0; p < P; ++p) a.x[tid * P + p] = xs[tid * P + p];
+}
+
+__global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, int K, int P, float bw, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mx = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    double q = 0.0;
+    for (int p = 0; p < P; ++p) {
+      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw;
+      q += z * z;
+    }
+    mx = fmax(mx, -0.5 * q);
+  }
+  double zs = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double q = 0.0;
+    for (int p = 0; p < P; ++p) {
+      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw;
+      q += z * z;
+    }
+    zs += exp(-0.5 * q - mx);
+  }
+  out[i] = (float)(mx + log(zs) - log((double)K) - P * log((double)bw) - 0.5 * P * log(2.0 * M_PI));
+}
+
+// mpf.prior.sample([n]): categorical over the M_p components (uniform), then N(mean, bw^2 I)
+__global__ void mpf_sample_kernel(const float *means, int K, int P, float bw, uint64_t seed, int n, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)i, 0x6d7066u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const int k = (int)(((unsigned long long)r[0] * (unsigned long long)K) >> 32);
+  float z[4];
+  philox_normal4(seed, (uint32_t)i, 0x6d7067u, 1u, 0u, z);
+  for (int p = 0; p < P; ++p) out[i * P + p] = means[k * P + p] + bw * z[p];
+}
+
+}  // namespace dust
+
+struct dust_mpf {
+  dust_mpf_config cfg;
+  int Mp, P;
+  hipStream_t stream;
+  float *x, *gn, *phi, *tmp;
+  size_t tmp_cap;
+  uint32_t *grid_bits;
+  int nx, ny;
+  float off_x, off_y;
+  float prior_bw;
+  float loc[4], past_obs[4], past_action[2];
+  bool have_past;
+};
+
+static DevModel mpf_dev_model(const dust_mpf *m) {
+  dust_ctx fake;
+  memset((void *)&fake, 0, sizeof fake);
+  fake.cfg = m->cfg.model_cfg;
+  fake.cfg.params_log_space = m->cfg.log_space;
+  fake.P = m->P;
+  fake.grid_bits = m->grid_bits;
+  fake.nx = m->nx;
+  fake.ny = m->ny;
+  fake.off_x = m->off_x;
+  fake.off_y = m->off_y;
+  return make_dev_model(&fake);
+}
+
+extern "C" void dust_mpf_destroy(dust_mpf *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->cfg.device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  float *fp[] = {m->x, m->gn, m->phi, m->tmp};
+  for (float *p : fp)
+    if (p) (void)hipFree(p);
+  if (m->grid_bits) (void)hipFree(m->grid_bits);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int dust_mpf_create(const dust_mpf_config *cfg, const float *init_particles, const float *initial_obs, dust_mpf **out) {
+  if (!cfg || !init_particles || !initial_obs || !out) return fail(DUST_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != DUST_ABI_VERSION) return fail(DUST_ERR_INVALID, "ABI version mismatch");
+  if (cfg->n_particles < 1 || cfg->n_particles > 1024) return fail(DUST_ERR_UNSUPPORTED, "MPF supports 1..1024 particles (one workgroup)");
+  if (cfg->dim_p < 1 || cfg->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p must be 1..4");
+  if (!(cfg->init_bw > 0.f)) return fail(DUST_ERR_INVALID, "init_bw must be > 0 (the host layer evaluates bw_silverman)");
+  if (!(cfg->obs_std > 0.f)) return fail(DUST_ERR_INVALID, "obs_std must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DUST_ERR_NO_DEVICE, "no HIP device: libdust_amd has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(DUST_ERR_NO_DEVICE, "device %d of %d", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+  dust_mpf *m = new (std::nothrow) dust_mpf();
+  if (!m) return fail(DUST_ERR_HIP, "out of host memory");
+  memset((void *)m, 0, sizeof *m);
+  m->cfg = *cfg;
+  m->Mp = cfg->n_particles;
+  m->P = cfg->dim_p;
+  *out = m;
+  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  TRY(dalloc(&m->x, (size_t)m->Mp * m->P));
+  TRY(dalloc(&m->phi, (size_t)m->Mp * m->P));
+  TRY(dalloc(&m->gn, (size_t)4096));
+  HIP_TRY(hipMemcpyAsync(m->x, init_particles, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->prior_bw = cfg->init_bw;
+  for (int k = 0; k < cfg->dim_s && k < 4; ++k) m->loc[k] = initial_obs[k];
+  m->have_past = false;
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_set_grid(dust_mpf *m, const float *grid, int nx, int ny, float off_x, float off_y) {
+  if (!m || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
+  const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
+  std::vector<uint32_t> bits(words, 0u);
+  for (size_t i = 0; i < cells; ++i) {
+    if (grid[i] == 1.0f) bits[i >> 5] |= 1u << (i & 31);
+    else if (grid[i] != 0.0f) return fail(DUST_ERR_UNSUPPORTED, "occupancy grid must be binary");
+  }
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  if (m->grid_bits) HIP_TRY(hipFree(m->grid_bits));
+  m->grid_bits = nullptr;
+  TRY(dalloc(&m->grid_bits, words));
+  HIP_TRY(hipMemcpyAsync(m->grid_bits, bits.data(), words * 4, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->nx = nx;
+  m->ny = ny;
+  m->off_x = off_x;
+  m->off_y = off_y;
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
+  if (!src || !out) return fail(DUST_ERR_INVALID, "null argument");
+  std::vector<float> x((size_t)src->Mp * src->P);
+  HIP_TRY(hipSetDevice(src->cfg.device));
+  HIP_TRY(hipMemcpy(x.data(), src->x, x.size() * sizeof(float), hipMemcpyDeviceToHost));
+  TRY(dust_mpf_create(&src->cfg, x.data(), src->loc, out));
+  dust_mpf *m = *out;
+  m->prior_bw = src->prior_bw;
+  memcpy(m->loc, src->loc, sizeof m->loc);
+  memcpy(m->past_obs, src->past_obs, sizeof m->past_obs);
+  memcpy(m->past_action, src->past_action, sizeof m->past_action);
+  m->have_past = src->have_past;
+  if (src->grid_bits) {
+    const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
+    TRY(dalloc(&m->grid_bits, words));
+    HIP_TRY(hipMemcpy(m->grid_bits, src->grid_bits, words * 4, hipMemcpyDeviceToDevice));
+    m->nx = src->nx;
+    m->ny = src->ny;
+    m->off_x = src->off_x;
+    m->off_y = src->off_y;
+  }
+  return DUST_OK;
+}
+
+static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev) {
+  if (m->cfg.model_cfg.model == DUST_MODEL_PARTICLE && m->cfg.model_cfg.with_obstacle && m->cfg.model_cfg.can_crash && !m->grid_bits)
+    return fail(DUST_ERR_STATE, "Particle model with obstacles: call dust_mpf_set_grid first");
+  MpfArgs a;
+  memset(&a, 0, sizeof a);
+  a.dm = mpf_dev_model(m);
+  a.Mp = m->Mp;
+  a.P = m->P;
+  a.ds = m->cfg.dim_s;
+  a.da = m->cfg.dim_a;
+  a.n_steps = n_steps;
+  a.log_space = m->cfg.log_space;
+  a.prior_bw = m->prior_bw;
+  a.bw = bw;
+  a.lr = lr;
+  a.obs_std = m->cfg.obs_std;
+  for (int k = 0; k < 4; ++k) {
+    a.past_obs[k] = m->past_obs[k];
+    a.obs[k] = m->loc[k];
+  }
+  a.past_action[0] = m->past_action[0];
+  a.past_action[1] = m->past_action[1];
+  a.x = m->x;
+  a.grad_norms = gn_dev;
+  a.phi_out = phi_dev;
+  const int nt = ((m->Mp + 63) / 64) * 64;
+  const size_t lds = sizeof(float) * ((size_t)2 * m->Mp * m->P + m->Mp + 32);
+  mpf_optimize_kernel<<<1, nt, lds, m->stream>>>(a);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *new_obs, float bw, int n_steps, float *grad_norms) {
+  if (!m) return fail(DUST_ERR_INVALID, "null mpf");
+  if (n_steps < 0 || n_steps > 4096) return fail(DUST_ERR_INVALID, "n_steps out of range");
+  if (!(bw > 0.f)) return fail(DUST_ERR_INVALID, "bw must be > 0 (the host layer evaluates silvermans_rule when bw is None)");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  if (new_obs) {  // GaussianLikelihood.condition likelihoods.py:51-64
+    if (!action) return fail(DUST_ERR_INVALID, "condition() needs the action that produced new_obs");
+    memcpy(m->past_obs, m->loc, sizeof m->past_obs);
+    for (int k = 0; k < m->cfg.dim_s && k < 4; ++k) m->loc[k] = new_obs[k];
+    for (int k = 0; k < 2; ++k) m->past_action[k] = k < m->cfg.dim_a ? action[k] : 0.f;
+    m->have_past = true;
+  }
+  if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
+  TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr));
+  m->prior_bw = bw;  // update_prior(bw) mpf.py:85
+  if (grad_norms && n_steps > 0) {
+    HIP_TRY(hipMemcpyAsync(grad_norms, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_phi(dust_mpf *m, float bw, float *phi) {
+  if (!m || !phi) return fail(DUST_ERR_INVALID, "null argument");
+  if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  TRY(mpf_launch(m, bw, 0.0f, 1, nullptr, m->phi));  // lr = 0: particles unchanged
+  HIP_TRY(hipMemcpyAsync(phi, m->phi, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+
+// GaussianLikelihood.condition without an optimisation (used by the host mirror's condition())
+extern "C" int dust_mpf_condition(dust_mpf *m, const float *action, const float *new_obs) {
+  if (!m || !new_obs) return fail(DUST_ERR_INVALID, "null argument");
+  memcpy(m->past_obs, m->loc, sizeof m->past_obs);
+  for (int k = 0; k < m->cfg.dim_s && k < 4; ++k) m->loc[k] = new_obs[k];
+  if (action) {
+    for (int k = 0; k < 2; ++k) m->past_action[k] = k < m->cfg.dim_a ? action[k] : 0.f;
+    m->have_past = true;
+  }
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_get_particles(dust_mpf *m, float *x) {
+  if (!m || !x) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  HIP_TRY(hipMemcpyAsync(x, m->x, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+extern "C" int dust_mpf_set_particles(dust_mpf *m, const float *x) {
+  if (!m || !x) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  HIP_TRY(hipMemcpyAsync(m->x, x, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+extern "C" int dust_mpf_get_prior(dust_mpf *m, float *means, float *bw) {
+  if (!m) return fail(DUST_ERR_INVALID, "null mpf");
+  if (means) TRY(dust_mpf_get_particles(m, means));
+  if (bw) *bw = m->prior_bw;
+  return DUST_OK;
+}
+extern "C" int dust_mpf_prior_sample(dust_mpf *m, int n, uint64_t seed, float *samples) {
+  if (!m || !samples || n < 1) return fail(DUST_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  TRY(ensure(&m->tmp, &m->tmp_cap, (size_t)n * m->P));
+  mpf_sample_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->x, m->Mp, m->P, m->prior_bw, seed, n, m->tmp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(samples, m->tmp, (size_t)n * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+extern "C" int dust_mpf_prior_log_prob(dust_mpf *m, int n, const float *x, float *log_prob) {
+  if (!m || !x || !log_prob || n < 1) return fail(DUST_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  TRY(ensure(&m->tmp, &m->tmp_cap, (size_t)n * (m->P + 1)));
+  HIP_TRY(hipMemcpyAsync(m->tmp, x, (size_t)n * m->P * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  mpf_log_prob_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->tmp, m->x, n, m->Mp, m->P, m->prior_bw, m->tmp + (size_t)n * m->P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(log_prob, m->tmp + (size_t)n * m->P, n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}

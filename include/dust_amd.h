@@ -1,0 +1,224 @@
+/*
+ * dust_amd.h - C ABI of libdust_amd.so: the MI355X-native (HIP, gfx950) SVGD-MPC inner loop.
+ *
+ * Drop-in boundary for the one hot path of lubaroli/dust.  The reference is pure Python and
+ * has no FFI of its own; each entry point below replaces one reference METHOD (cited file:line into lubaroli/dust) and
+ * is what a ctypes binding on the reference side would call (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *  - plain C, opaque handles, `int` status (0 = DUST_OK), no exceptions, no callbacks; dust_last_error() gives text;
+ *  - all arrays are fp32, C-contiguous, in the reference's own layouts (e.g. actions [S][N][H][da]);
+ *  - pointers are HOST pointers unless the call has a `flags` argument carrying DUST_PTR_DEVICE, in which case the
+ *    bulk noise/action arrays are device pointers already resident in HBM (benchmarks, fused pipelines);
+ *  - one HIP stream per context; a context is not thread-safe; every call returns after its results are on the host
+ *    (calls with no host outputs are asynchronous on the context's stream; dust_sync() waits);
+ *  - there is NO CPU fallback: without a usable HIP device dust_create fails with DUST_ERR_NO_DEVICE.
+ *
+ * Symbols: N = n_policies (Stein particles), S = n_samples (action samples per policy), M = n_params (dynamics
+ * samples), H = horizon, da/ds = action/state dims, D = H*da, P = number of uncertain model parameters.
+ */
+#ifndef DUST_AMD_H
+#define DUST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUST_ABI_VERSION 1
+
+enum dust_status {
+  DUST_OK = 0,
+  DUST_ERR_INVALID = 1,     /* bad argument / shape (the reference raises ValueError / AssertionError) */
+  DUST_ERR_UNSUPPORTED = 2, /* a configuration outside the HIP kernels' families (the reference would run Python) */
+  DUST_ERR_NO_DEVICE = 3,
+  DUST_ERR_HIP = 4,
+  DUST_ERR_STATE = 5 /* call order (e.g. phi before any likelihood sample) */
+};
+
+enum dust_model { DUST_MODEL_PENDULUM = 0, DUST_MODEL_PARTICLE = 1 };
+/* cost families: pendulum demo cost (demo/pendulum_example.py:21-28), Particle.default_*_cost (particle.py:170-225) */
+enum dust_cost { DUST_COST_PENDULUM_QUADCOS = 0, DUST_COST_PARTICLE_DEFAULT = 1 };
+/* K1: gpytorch RBFKernel semantics, lengthscale ln 2 (svmpc.py:76-83); K2: iid_mp(RBF) per-dimension median bandwidth
+ * (svmpc.py:64-74, composite_kernels.py:33-64); K2_SHARED: indep_controls=False; IMQ: new, no reference. */
+enum dust_kernel { DUST_KERNEL_K1_RBF = 0, DUST_KERNEL_K2_IIDMP = 1, DUST_KERNEL_K2_SHARED = 2, DUST_KERNEL_IMQ = 3 };
+enum dust_likelihood { DUST_LIK_EXP_UTILITY = 0, DUST_LIK_EXPECTED_COST = 1 }; /* likelihoods.py:122-135 / 106-119 */
+enum dust_optimizer { DUST_OPT_SGD = 0, DUST_OPT_ADAM = 1 };                   /* svgd.py:115, demos use SGD */
+enum dust_roll { DUST_ROLL_REPEAT = 0, DUST_ROLL_MEAN = 1 };                    /* svmpc.py:142-158 */
+enum dust_step_strategy { DUST_STEP_ARGMAX = 0, DUST_STEP_AVERAGE = 1, DUST_STEP_EXTERNAL = 2 }; /* disco.py:396-417 */
+/* how a model parameter enters the arithmetic: a Python float (double), a 0-dim fp32 tensor, or a sampled column */
+enum dust_param_kind { DUST_PARAM_PYFLOAT = 0, DUST_PARAM_SAMPLED = 1, DUST_PARAM_TENSOR0D = 2 };
+/* DUST_EPS_AROUND_A_MAT: the external actions were drawn around a_mat (MultiDISCO's own sampling, disco.py:155-160) */
+enum dust_flags { DUST_PTR_DEVICE = 1, DUST_STORE_STATES = 2, DUST_EPS_AROUND_A_MAT = 4 };
+
+typedef struct dust_param {
+  int32_t kind;   /* dust_param_kind */
+  int32_t column; /* column of `params` when kind == DUST_PARAM_SAMPLED */
+  double value;   /* default value otherwise */
+} dust_param;
+
+typedef struct dust_config {
+  int32_t abi_version; /* DUST_ABI_VERSION */
+  int32_t device;      /* HIP device ordinal */
+  /* sizes: MultiDISCO(n_policies, action_samples, params_samples, hz_len) disco.py:16-137 */
+  int32_t n_policies;       /* N, total over all shards */
+  int32_t n_samples;        /* S */
+  int32_t n_params;         /* M (1 when params_sampling is off) */
+  int32_t horizon;          /* H */
+  int32_t dim_a, dim_s, dim_p;
+  /* data-parallel shard of the policy index owned by this context: [shard_offset, shard_offset + shard_size) */
+  int32_t shard_offset, shard_size; /* shard_size 0 = all */
+  int32_t model, cost, kernel, likelihood, optimizer, roll_strategy;
+  int32_t weighted_prior;    /* SVMPC(weighted_prior=) svmpc.py:21 */
+  int32_t params_log_space;  /* MultiDISCO(params_log_space=) disco.py:173 */
+  int32_t params_interleave; /* scalar-event params_dist quirk, disco.py:177-179: rollout r uses params[r % M] */
+  float alpha;               /* likelihood alpha */
+  float temperature;         /* MultiDISCO temperature */
+  float a_reg;               /* temperature * (1 - ctrl_penalty) disco.py:90 */
+  float lr, adam_beta1, adam_beta2, adam_eps;
+  float chol_a[4];  /* diagonal of cholesky(a_cov): policy-noise scale (likelihoods.py:85-90) */
+  float sigma_a[4]; /* sqrt(diag(a_dist.covariance_matrix)) as svmpc.py:107-111 computes it */
+  float a_pre[4];   /* diagonal of inverse(a_cov) disco.py:98 */
+  float sigma_p[4]; /* sqrt of the prior component covariance diagonal (svgd.py:84-89) */
+  float bw_scale;   /* RBF(bw_scale=) base_kernels.py:44 */
+  float imq_ell;
+  float min_a[4], max_a[4]; /* action_space bounds, disco.py:408-410 */
+  uint64_t seed;            /* device Philox stream for internally drawn noise */
+  /* model: dust/models/pendulum.py, dust/models/particle.py */
+  double dt;
+  dust_param g, mass, length; /* pendulum; `mass` is also the particle mass */
+  double max_torque, max_speed_pend;
+  double w_cos, w_vel;        /* pendulum cost weights */
+  float max_speed, max_accel; /* particle */
+  int32_t can_crash, with_obstacle;
+  double cell_size;
+  float target[4], w_state[4], w_term[4], w_ctrl[2], w_obs;
+} dust_config;
+
+typedef struct dust_ctx dust_ctx;
+typedef struct dust_mpf dust_mpf;
+
+const char *dust_last_error(void);
+int dust_abi_version(void);
+int dust_device_count(int *count);
+
+/* lifecycle.  dust_clone is what copy.deepcopy(controller/svmpc) maps to (simulations.py:62, particle_example.py:166-175) */
+int dust_create(const dust_config *cfg, dust_ctx **out);
+int dust_clone(const dust_ctx *src, dust_ctx **out);
+void dust_destroy(dust_ctx *ctx);
+int dust_sync(dust_ctx *ctx);
+int dust_get_config(const dust_ctx *ctx, dust_config *out);
+/* model.params_dict[...] = v after construction (particle_example.py:178-179) */
+int dust_set_model_param(dust_ctx *ctx, const char *name, double value, int kind);
+/* ObstacleMap occupancy grid [nx][ny] (obstacle_map.py:13-43); offsets are the map centre in cells */
+int dust_set_grid(dust_ctx *ctx, const float *grid, int nx, int ny, float off_x, float off_y);
+
+/* particle / prior / controller state (all [N][H][da] or [N]) */
+int dust_set_theta(dust_ctx *ctx, const float *theta);                                /* SVMPC.theta svmpc.py:25 */
+int dust_get_theta(dust_ctx *ctx, float *theta);
+int dust_set_prior(dust_ctx *ctx, const float *means, const float *mix_weights);      /* get_gmm svgd.py:84-89 */
+int dust_get_prior(dust_ctx *ctx, float *means, float *mix_probs);
+int dust_set_a_mat(dust_ctx *ctx, const float *a_mat);                                /* MultiDISCO.a_mat disco.py:101-109 */
+int dust_get_a_mat(dust_ctx *ctx, float *a_mat);
+int dust_get_a_mix(dust_ctx *ctx, float *a_mix);                                      /* disco.py:393 */
+int dust_set_a_seq(dust_ctx *ctx, const float *a_seq);                                /* BaseController.a_seq base.py:34-37 */
+int dust_get_a_seq(dust_ctx *ctx, float *a_seq);
+
+/* MultiDISCO.forward(state, model, params_dist, ext_actions) disco.py:348-394.
+ * actions [S][N][H][da] (NULL: drawn on device as a_mat + L z, disco.py:155-160); params [M][P] raw samples or NULL.
+ * outputs may be NULL: costs [S][N], states [M][S][N][H+1][ds], actions_out [S][N][H][da], omega [S][N].
+ * Side effects as in the reference: a_mat += sum_s omega eps, a_mix refreshed. */
+int dust_disco_forward(dust_ctx *ctx, const float *state, const float *actions, const float *params, int flags,
+                       float *costs, float *states, float *actions_out, float *omega);
+/* MultiDISCO.step(strategy, steps, ext_actions) disco.py:396-417 -> next_actions [steps][da] */
+int dust_disco_step(dust_ctx *ctx, int strategy, int steps, const float *ext_actions, float *next_actions);
+
+/* CostLikelihood.sample(theta, state, params_dist) likelihoods.py:81-101: actions = theta + L eps, then forward.
+ * eps [S][N][H][da] standard-normal draws (NULL: device Philox).  costs [S][N], actions_out optional. */
+int dust_likelihood_sample(dust_ctx *ctx, const float *state, const float *eps, const float *params, int flags,
+                           float *costs, float *actions_out);
+/* likelihood.log_prob(costs) likelihoods.py:113-135 on the last sampled costs -> [N] */
+int dust_likelihood_log_prob(dust_ctx *ctx, float *log_l);
+
+/* SVMPC.phi(log_p, bw, sigma) svmpc.py:32-85 with the costs/actions a user-supplied log_p returned
+ * (costs [S][N], actions [S][N][H][da]); NULL/NULL = use the last likelihood sample held on the device.
+ * outputs optional: phi, grad_lik, grad_pri each [N][H][da]. */
+int dust_svmpc_phi(dust_ctx *ctx, const float *costs, const float *actions, float *phi, float *grad_lik, float *grad_pri);
+/* SVMPC.step(state, params_dist, bw, sigma) svmpc.py:87-95: sample, phi, optimiser step on theta */
+int dust_svmpc_step(dust_ctx *ctx, const float *state, const float *eps, const float *params, int flags);
+/* SVMPC.optimize(state, params_dist, n_steps) svmpc.py:97-126. eps [n_steps][S][N][H][da] or NULL, params [n_steps][M][P] or NULL */
+int dust_svmpc_optimize(dust_ctx *ctx, const float *state, int n_steps, const float *eps, const float *params, int flags);
+/* SVMPC.forward(state, params_dist, fast_pred=True) svmpc.py:172-200: weights, argmax, roll, prior refresh.
+ * a_seq [H][da], p_weights [N] (either may be NULL) */
+int dust_svmpc_forward(dust_ctx *ctx, float *a_seq, float *p_weights);
+/* one whole control tick = optimize(n_steps) + forward(), enqueued without host round trips (replayed as a hipGraph) */
+int dust_svmpc_tick(dust_ctx *ctx, const float *state, int n_steps, const float *eps, const float *params, int flags,
+                    float *a_seq, float *p_weights);
+
+/* stage outputs of the last call, for parity tests ([S][N] / [N][H][da] / [N]) */
+int dust_get_costs(dust_ctx *ctx, float *costs);
+int dust_get_actions(dust_ctx *ctx, float *actions);
+int dust_get_score(dust_ctx *ctx, float *score);
+int dust_get_phi(dust_ctx *ctx, float *phi);
+int dust_get_log_weights(dust_ctx *ctx, float *log_l, float *log_p);
+int dust_get_bandwidths(dust_ctx *ctx, float *h); /* K2: [H*da] or [H] */
+
+/* multi-GPU: the pairwise stages read every shard's theta/score from context-owned gather buffers ([N][D] each).
+ * The caller all-gathers them in place with RCCL between dust_svmpc_local_score and dust_svmpc_apply_phi. */
+int dust_gather_buffers(dust_ctx *ctx, void **theta_all, void **score_all, size_t *shard_bytes);
+int dust_svmpc_local_score(dust_ctx *ctx, const float *state, const float *eps, const float *params, int flags);
+int dust_svmpc_apply_phi(dust_ctx *ctx);
+int dust_svmpc_forward_local(dust_ctx *ctx, void **log_w_all, size_t *shard_bytes);
+int dust_svmpc_forward_finish(dust_ctx *ctx, float *a_seq, float *p_weights);
+/* run the context's kernels on an external HIP stream (hipStream_t), e.g. torch's current stream */
+int dust_set_stream(dust_ctx *ctx, void *hip_stream);
+
+/* timing / roofline support: HIP-event timing of each kernel family on the context's stream */
+enum dust_kernel_id {
+  DUST_K_ROLLOUT = 0, DUST_K_PRIOR_SCORE = 1, DUST_K_STEIN = 2, DUST_K_UPDATE = 3, DUST_K_FORWARD = 4, DUST_K_BANDWIDTH = 5,
+  DUST_K_MPF = 6, DUST_K_COUNT = 8
+};
+int dust_profile_enable(dust_ctx *ctx, int on);
+int dust_profile_get(dust_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+int dust_profile_reset(dust_ctx *ctx);
+const char *dust_kernel_name(int kernel_id);
+/* algorithmic bytes one launch of the rollout kernel moves (SURVEY.md section 8d B_roll) */
+int dust_rollout_algorithmic_bytes(const dust_ctx *ctx, int flags, double *bytes);
+/* device scratch for benchmarks: allocate/fill standard-normal noise in HBM with the context's Philox stream */
+int dust_device_noise_alloc(dust_ctx *ctx, size_t n_floats, uint64_t seed, void **dptr);
+int dust_device_free(dust_ctx *ctx, void *dptr);
+
+/* ---- MPF: dynamics-parameter SVGD filter (mpf.py:13-86, likelihoods.py:12-64, svgd.py:92-99) ---- */
+typedef struct dust_mpf_config {
+  int32_t abi_version, device;
+  int32_t n_particles; /* M_p */
+  int32_t dim_p, dim_s, dim_a;
+  int32_t model;
+  int32_t log_space;   /* GaussianLikelihood(log_space=) */
+  float obs_std, lr, bw_scale;
+  float init_bw;       /* MPF(bw=): bandwidth of the initial prior; <= 0: bw_silverman of the particles (svgd.py:55-81) */
+  dust_config model_cfg; /* only the model fields are read */
+} dust_mpf_config;
+int dust_mpf_create(const dust_mpf_config *cfg, const float *init_particles, const float *initial_obs, dust_mpf **out);
+int dust_mpf_clone(const dust_mpf *src, dust_mpf **out);
+void dust_mpf_destroy(dust_mpf *mpf);
+/* MPF.optimize(action, new_obs, bw, n_steps) mpf.py:64-86 -> grad_norms [n_steps] */
+int dust_mpf_optimize(dust_mpf *mpf, const float *action, const float *new_obs, float bw, int n_steps, float *grad_norms);
+int dust_mpf_phi(dust_mpf *mpf, float bw, float *phi); /* MPF.phi mpf.py:40-57 */
+/* GaussianLikelihood.condition(action, new_obs) likelihoods.py:51-64 */
+int dust_mpf_condition(dust_mpf *mpf, const float *action, const float *new_obs);
+/* occupancy grid for the Particle model's crash mask inside the one-step prediction */
+int dust_mpf_set_grid(dust_mpf *mpf, const float *grid, int nx, int ny, float off_x, float off_y);
+int dust_mpf_get_particles(dust_mpf *mpf, float *x);
+int dust_mpf_set_particles(dust_mpf *mpf, const float *x);
+int dust_mpf_get_prior(dust_mpf *mpf, float *means, float *bw);
+/* mpf.prior.sample([n]) / .log_prob(x): the controller draws its dynamics samples here (disco.py:171-172) */
+int dust_mpf_prior_sample(dust_mpf *mpf, int n, uint64_t seed, float *samples);
+int dust_mpf_prior_log_prob(dust_mpf *mpf, int n, const float *x, float *log_prob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
