@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdust_amd.so")
+LIB_PATH = os.environ.get("DUST_AMD_LIB", os.path.join(_HERE, "libdust_amd.so"))  # override: diagnostic builds only
 
 ABI_VERSION = 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)

@@ -12,6 +12,19 @@
 
 #define DUST_WAVE 64
 
+// In-kernel phase stamps (s_memtime) exist only in the diagnostic build (-DDUST_STAMPS, tools/kprof.py); the product
+// build compiles them to nothing.
+#ifdef DUST_STAMPS
+#define DUST_STAMP(p, k)                                                                             \
+  do {                                                                                               \
+    if ((p) && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) (p)[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DUST_STAMP(p, k) \
+  do {                   \
+  } while (0)
+#endif
+
 namespace dust {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -104,12 +117,55 @@ __device__ __forceinline__ float collision(const DevModel &dm, float px, float p
 
 #define PI_F 3.14159274101257324f /* (float)math.pi */
 
+// sin / cos for the rollout: 3-term Cody-Waite reduction by pi/2 (exact for |x| < 1e5) + degree-7/8 minimax polynomials
+// on [-pi/4, pi/4], <= 1.5 ulp - the same class as the reference's vectorised torch kernels (Sleef u10).  ocml's
+// sinf/cosf cost ~10x more instructions (Payne-Hanek path compiled in); huge arguments fall back to them.
+__device__ __forceinline__ float trig_reduce(float x, int *q) {
+  const float k = rintf(x * 0.636619747f);
+  *q = (int)k;
+  float r = fmaf(k, -1.57079601e+00f, x);
+  r = fmaf(k, -3.13916473e-07f, r);
+  r = fmaf(k, -5.39030253e-15f, r);
+  return r;
+}
+__device__ __forceinline__ float poly_sin(float r) {
+  const float s = r * r;
+  float p = 2.86567956e-6f;
+  p = fmaf(p, s, -1.98559923e-4f);
+  p = fmaf(p, s, 8.33338592e-3f);
+  p = fmaf(p, s, -1.66666672e-1f);
+  const float t = r * s;
+  return fmaf(p, t, r);
+}
+__device__ __forceinline__ float poly_cos(float r) {
+  const float s = r * r;
+  float p = 2.44677067e-5f;
+  p = fmaf(p, s, -1.38877297e-3f);
+  p = fmaf(p, s, 4.16666567e-2f);
+  p = fmaf(p, s, -5.00000000e-1f);
+  return fmaf(p, s, 1.0f);
+}
+__device__ __forceinline__ float fast_sinf(float x) {
+  if (!(fabsf(x) < 1.0e5f)) return sinf(x);
+  int q;
+  const float r = trig_reduce(x, &q);
+  const float v = (q & 1) ? poly_cos(r) : poly_sin(r);
+  return (q & 2) ? -v : v;
+}
+__device__ __forceinline__ float fast_cosf(float x) {
+  if (!(fabsf(x) < 1.0e5f)) return cosf(x);
+  int q;
+  const float r = trig_reduce(x, &q);
+  const float v = (q & 1) ? poly_sin(r) : poly_cos(r);
+  return ((q + 1) & 2) ? -v : v;
+}
+
 template <int MODEL>
 __device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, float *x, const float *a) {
   const float dt = (float)dm.dt;
   if (MODEL == DUST_MODEL_PENDULUM) {
     float u = clampf(a[0], -dm.max_torque, dm.max_torque);
-    float s = sinf(x[0] + PI_F);
+    float s = fast_sinf(x[0] + PI_F);
     float t1 = c.c0 * s;
     float t2 = c.c1 * u;
     float thd = x[1] + dt * (t1 + t2);
@@ -136,7 +192,7 @@ __device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, fl
 template <int MODEL>
 __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, const float *a) {
   if (MODEL == DUST_MODEL_PENDULUM) {
-    float cm = cosf(x[0]) - 1.0f;
+    float cm = fast_cosf(x[0]) - 1.0f;
     float t1 = dm.w_cos * (cm * cm);
     float t2 = dm.w_vel * (x[1] * x[1]);
     return t1 + t2;

@@ -71,14 +71,17 @@ struct dust_ctx {
   int *istar;
   float *adam_m, *adam_v;
   int adam_step;
+  float *pA, *pB, *pM, *pL;  // slice partials of the tiled pairwise passes
+  size_t pA_cap, pB_cap, pM_cap, pL_cap;
   // staging
-  float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage;
-  size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap;
+  float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
+  size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
   uint32_t *grid_bits;
   int nx, ny;
   float off_x, off_y;
   uint32_t tick, iter;
   bool have_sample, actions_valid;
+  unsigned long long *stamps_dev;  // diagnostic build only: [DUST_K_COUNT][16]
   // profiling
   bool prof;
   hipEvent_t ev0, ev1;
@@ -174,7 +177,7 @@ static int validate(const dust_config *g) {
     return fail(DUST_ERR_UNSUPPORTED, "unknown model id %d", g->model);
   }
   const int D = g->horizon * g->dim_a;
-  if (D > 256) return fail(DUST_ERR_UNSUPPORTED, "H*da = %d > 256 not supported by the kernels", D);
+  if (D > 128) return fail(DUST_ERR_UNSUPPORTED, "H*da = %d > 128 not supported by the kernels", D);
   if (g->dim_p < 0 || g->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p out of range");
   if (g->kernel < 0 || g->kernel > DUST_KERNEL_IMQ) return fail(DUST_ERR_INVALID, "bad kernel id");
   if (g->optimizer != DUST_OPT_SGD && g->optimizer != DUST_OPT_ADAM) return fail(DUST_ERR_UNSUPPORTED, "optimizer must be SGD or Adam");
@@ -191,7 +194,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
                   &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->istar) (void)hipFree(c->istar);
@@ -403,7 +406,6 @@ extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
   if (!c || !theta) return fail(DUST_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(h2d(c, c->theta, theta, (size_t)c->N * c->D * sizeof(float)));
-  TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
   if (c->adam_m) {
     HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
@@ -419,7 +421,6 @@ extern "C" int dust_set_prior(dust_ctx *c, const float *means, const float *w) {
   if (!c || !means) return fail(DUST_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(h2d(c, c->mu, means, (size_t)c->N * c->D * sizeof(float)));
-  TRY(launch_transpose(c, c->mu, c->muT, c->N, c->D));
   c->mu_aliased = false;
   if (w) {
     for (int i = 0; i < c->N; ++i)
@@ -480,7 +481,37 @@ struct SampleOpts {
   int update_a_mat;
   const float *costs_in;   // device [S][N]: skip the rollouts and use these costs (stage-wise phi)
   bool want_actions, want_states, want_omega;
+  int merge_prior;         // a prior pass ran just before: fold its partials into grad_pri / score
 };
+
+// geometry of the tiled pairwise launches: i-tiles of PAIR_TI queries x JS key slices, >= ~512 workgroups when possible
+static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
+  *tiles = (c->nloc + PAIR_TI - 1) / PAIR_TI;
+  const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
+  int js = (512 + *tiles - 1) / *tiles;
+  js = std::max(1, std::min(js, chunks));
+  const int cps = (chunks + js - 1) / js;  // chunks per slice
+  *slice = cps * PAIR_JC;
+  *JS = (c->N + *slice - 1) / *slice;
+}
+
+static PriorMerge prior_merge_args(const dust_ctx *c) {
+  PriorMerge pm;
+  memset(&pm, 0, sizeof pm);
+  int tiles, slice;
+  pair_geometry(c, &tiles, &pm.JS, &slice);
+  pm.n_local = c->nloc;
+  pm.pA = c->pA;
+  pm.pM = c->pM;
+  pm.pL = c->pL;
+  double logdet = 0;
+  for (int d = 0; d < c->da; ++d) {
+    pm.inv_s2[d] = 1.0f / (c->cfg.sigma_p[d] * c->cfg.sigma_p[d]);
+    logdet += log((double)c->cfg.sigma_p[d]);
+  }
+  pm.log_norm = (float)(-c->H * logdet - 0.5 * c->D * log(2.0 * M_PI));
+  return pm;
+}
 
 static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
   RolloutArgs a;
@@ -493,9 +524,14 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
   a.S = c->S;
   a.M = c->M;
   a.H = c->H;
-  a.da = c->da;
-  a.ds = c->ds;
   a.D = c->D;
+  a.magicD = (uint32_t)((1ull << 32) / (uint64_t)c->D) + 1u;
+  a.merge_prior = o.merge_prior;
+  if (o.merge_prior) {
+    a.pm = prior_merge_args(c);
+    a.grad_pri = c->grad_pri;
+    a.score = c->score;
+  }
   a.noise_mode = o.noise_mode;
   a.lik = c->cfg.likelihood;
   a.eps_base_mode = o.eps_base_mode;
@@ -531,10 +567,16 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
   a.seed = c->cfg.seed;
   a.tick = c->tick;
   a.iter = c->iter;
+  a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_ROLLOUT : nullptr;
   int nt = ((std::max(c->S, c->D) + 63) / 64) * 64;
   nt = std::min(std::max(nt, 64), 256);
-  const size_t lds = rollout_lds_bytes(c->S, c->D, nt);
-  if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "S*D action tile (%zu B) exceeds the 160 KiB LDS of a CU", lds);
+  size_t lds = rollout_lds_bytes(c->S, c->D, nt, true);
+  if (lds > 96 * 1024) {  // keep >= 1 workgroup per CU resident with room to spare; larger tiles go to an HBM slab
+    TRY(ensure(&c->tile_scratch, &c->tile_cap, (size_t)c->nloc * c->S * (c->D | 1)));
+    a.tile_scratch = c->tile_scratch;
+    lds = rollout_lds_bytes(c->S, c->D, nt, false);
+    if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "n_samples too large for one workgroup (%zu B of LDS)", lds);
+  }
   Prof p(c, DUST_K_ROLLOUT);
   if (c->cfg.model == DUST_MODEL_PENDULUM) {
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PENDULUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -672,32 +714,45 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pairwise passes
-static void pick_tile(const dust_ctx *c, int *TI, int *JC, int *nt) {
-  *TI = (c->nloc >= 4096) ? 8 : 4;
-  *JC = std::min(c->N, 2048);
-  *nt = 256;
-}
+// pairwise passes (tiled: PAIR_TI queries x key slices; partials combined by the next kernel in the chain)
+static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }
 
 template <int MODE>
-static int launch_pair(dust_ctx *c, const PairArgs &a, int TI, int nt) {
-  const int blocks = (a.n_local + TI - 1) / TI;
-  const size_t lds = pairwise_lds_bytes(TI, a.D, a.JC, nt);
-  if (TI == 4) {
-    pairwise_kernel<MODE, 4><<<blocks, nt, lds, c->stream>>>(a);
-  } else {
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pairwise_kernel<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    pairwise_kernel<MODE, 8><<<blocks, nt, lds, c->stream>>>(a);
-  }
+static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
+  const int cpt = cpt_for(a.D);
+  const size_t lds = pairwise_lds_bytes(MODE, cpt);
+  dim3 grid(tiles, a.JS);
+#define DUST_LAUNCH_PAIR(CPT)                                                                                                    \
+  do {                                                                                                                            \
+    if (lds > 64 * 1024)                                                                                                          \
+      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_kernel<MODE, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    pairwise_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(a);                                                             \
+  } while (0)
+  if (cpt == 4) DUST_LAUNCH_PAIR(4);
+  else if (cpt == 8) DUST_LAUNCH_PAIR(8);
+  else if (cpt == 12) DUST_LAUNCH_PAIR(12);
+  else DUST_LAUNCH_PAIR(16);
+#undef DUST_LAUNCH_PAIR
   HIP_TRY(hipGetLastError());
   return DUST_OK;
 }
 
-static int launch_prior(dust_ctx *c, bool want_grad, bool want_logp) {
+static int ensure_partials(dust_ctx *c, int JS) {
+  const size_t nd = (size_t)JS * c->nloc * c->D, nn = (size_t)JS * c->nloc;
+  TRY(ensure(&c->pA, &c->pA_cap, nd));
+  TRY(ensure(&c->pB, &c->pB_cap, nd));
+  TRY(ensure(&c->pM, &c->pM_cap, nn));
+  TRY(ensure(&c->pL, &c->pL_cap, nn));
+  return DUST_OK;
+}
+
+// prior pass: writes slice partials (pA, pM, pL); combined by rollout_kernel (merge_prior) or prior_finish_kernel
+static int launch_prior(dust_ctx *c) {
   PairArgs a;
   memset(&a, 0, sizeof a);
-  int TI, nt;
-  pick_tile(c, &TI, &a.JC, &nt);
+  int tiles;
+  pair_geometry(c, &tiles, &a.JS, &a.slice);
+  TRY(ensure_partials(c, a.JS));
   a.N = c->N;
   a.D = c->D;
   a.da = c->da;
@@ -705,90 +760,124 @@ static int launch_prior(dust_ctx *c, bool want_grad, bool want_logp) {
   a.i0 = c->n0;
   a.n_local = c->nloc;
   a.X = c->theta;
-  a.YT = c->mu_aliased ? c->thetaT : c->muT;
   a.Y = c->mu_aliased ? c->theta : c->mu;
   a.logmix = c->logmix;
-  double logdet = 0;
-  for (int d = 0; d < c->da; ++d) {
-    a.inv_s[d] = 1.0f / c->cfg.sigma_p[d];
-    a.inv_s2[d] = 1.0f / (c->cfg.sigma_p[d] * c->cfg.sigma_p[d]);
-    logdet += log((double)c->cfg.sigma_p[d]);
-  }
-  a.log_norm = (float)(-c->H * logdet - 0.5 * c->D * log(2.0 * M_PI));
-  a.inv_n = 1.0f / c->N;
-  a.out = want_grad ? c->grad_pri : nullptr;
-  a.add = c->grad_lik;
-  a.out2 = want_grad ? c->score : nullptr;
-  a.logp = want_logp ? c->logp : nullptr;
+  a.magicD = (uint32_t)((1ull << 32) / (uint64_t)c->D) + 1u;
+  for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / c->cfg.sigma_p[d < c->da ? d : 0];
+  a.pA = c->pA;
+  a.pM = c->pM;
+  a.pL = c->pL;
+  a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_PRIOR_SCORE : nullptr;
   Prof p(c, DUST_K_PRIOR_SCORE);
-  return launch_pair<PAIR_PRIOR>(c, a, TI, nt);
+  return launch_pair<PAIR_PRIOR>(c, a, tiles);
 }
 
-static int launch_stein(dust_ctx *c) {
-  if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
-    Prof p(c, DUST_K_BANDWIDTH);
-    K2Args k;
-    memset(&k, 0, sizeof k);
-    k.N = c->N;
-    k.H = c->H;
-    k.da = c->da;
-    k.D = c->D;
-    k.shared = c->cfg.kernel == DUST_KERNEL_K2_SHARED;
-    k.i0 = c->n0;
-    k.n_local = c->nloc;
-    k.bw_scale = c->cfg.bw_scale;
-    k.theta = c->theta;
-    k.thetaT = c->thetaT;
-    k.score = c->score;
-    k.h = c->bw;
-    k.phi = c->phi;
-    return launch_k2(c->stream, k);
-  }
-  PairArgs a;
-  memset(&a, 0, sizeof a);
-  int TI, nt;
-  pick_tile(c, &TI, &a.JC, &nt);
-  a.N = c->N;
-  a.D = c->D;
-  a.da = c->da;
-  a.H = c->H;
-  a.i0 = c->n0;
-  a.n_local = c->nloc;
-  a.X = c->theta;
-  a.YT = c->thetaT;
-  a.Y = c->theta;
-  a.V = c->score;
-  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;  // softplus(0) = ln 2 (svmpc.py:78 typo keeps it)
-  for (int d = 0; d < 4; ++d) {
-    a.inv_s[d] = 1.0f / ell;
-    a.inv_s2[d] = 1.0f / (ell * ell);
-  }
-  a.inv_n = 1.0f / c->N;
-  a.out = c->phi;
-  Prof p(c, DUST_K_STEIN);
-  if (c->cfg.kernel == DUST_KERNEL_IMQ) return launch_pair<PAIR_IMQ>(c, a, TI, nt);
-  return launch_pair<PAIR_K1>(c, a, TI, nt);
+static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp) {
+  PriorFinishArgs f;
+  memset(&f, 0, sizeof f);
+  f.pm = prior_merge_args(c);
+  f.D = c->D;
+  f.da = c->da;
+  f.i0 = c->n0;
+  f.n_local = c->nloc;
+  f.grad_lik = c->grad_lik;
+  f.grad_pri = want_grad ? c->grad_pri : nullptr;
+  f.score = want_grad ? c->score : nullptr;
+  f.logp = want_logp ? c->logp : nullptr;
+  const int n = c->nloc * c->D;
+  Prof p(c, DUST_K_PRIOR_SCORE);
+  prior_finish_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(f);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
 }
 
-static int launch_update(dust_ctx *c) {
+static UpdateArgs update_args(dust_ctx *c, int apply) {
   UpdateArgs u;
   memset(&u, 0, sizeof u);
+  int tiles, slice;
+  pair_geometry(c, &tiles, &u.JS, &slice);
   u.N = c->N;
   u.D = c->D;
   u.i0 = c->n0;
   u.n_local = c->nloc;
   u.optimizer = c->cfg.optimizer;
+  u.apply = apply;
   u.lr = c->cfg.lr;
   u.beta1 = c->cfg.adam_beta1;
   u.beta2 = c->cfg.adam_beta2;
   u.eps = c->cfg.adam_eps;
-  u.step = ++c->adam_step;
+  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;  // softplus(0) = ln 2 (svmpc.py:78 typo keeps it)
+  u.inv_l2 = 1.0f / (ell * ell);
+  u.inv_n = 1.0f / c->N;
+  u.pA = c->pA;
+  u.pB = c->pB;
   u.phi = c->phi;
   u.theta = c->theta;
-  u.thetaT = c->thetaT;
   u.adam_m = c->adam_m;
   u.adam_v = c->adam_v;
+  return u;
+}
+
+// Stein pass (+ optimiser step when apply != 0).  K1 / IMQ: tiled partials -> update_kernel; K2: bandwidths + phi, then update.
+static int launch_stein_update(dust_ctx *c, int apply) {
   const int n = c->nloc * c->D;
+  if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
+    {
+      Prof p(c, DUST_K_BANDWIDTH);
+      TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+      K2Args k;
+      memset(&k, 0, sizeof k);
+      k.N = c->N;
+      k.H = c->H;
+      k.da = c->da;
+      k.D = c->D;
+      k.shared = c->cfg.kernel == DUST_KERNEL_K2_SHARED;
+      k.i0 = c->n0;
+      k.n_local = c->nloc;
+      k.bw_scale = c->cfg.bw_scale;
+      k.theta = c->theta;
+      k.thetaT = c->thetaT;
+      k.score = c->score;
+      k.h = c->bw;
+      k.phi = c->phi;
+      TRY(launch_k2(c->stream, k));
+    }
+    if (apply) {
+      UpdateArgs u = update_args(c, 1);
+      u.step = ++c->adam_step;
+      Prof p(c, DUST_K_UPDATE);
+      update_from_phi_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
+      HIP_TRY(hipGetLastError());
+    }
+    return DUST_OK;
+  }
+  {
+    PairArgs a;
+    memset(&a, 0, sizeof a);
+    int tiles;
+    pair_geometry(c, &tiles, &a.JS, &a.slice);
+    TRY(ensure_partials(c, a.JS));
+    a.N = c->N;
+    a.D = c->D;
+    a.da = c->da;
+    a.H = c->H;
+    a.i0 = c->n0;
+    a.n_local = c->nloc;
+    a.X = c->theta;
+    a.Y = c->theta;
+    a.V = c->score;
+    a.magicD = (uint32_t)((1ull << 32) / (uint64_t)c->D) + 1u;
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / ell;
+    a.pA = c->pA;
+    a.pB = c->pB;
+    a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_STEIN : nullptr;
+    Prof p(c, DUST_K_STEIN);
+    if (c->cfg.kernel == DUST_KERNEL_IMQ) TRY(launch_pair<PAIR_IMQ>(c, a, tiles));
+    else TRY(launch_pair<PAIR_K1>(c, a, tiles));
+  }
+  UpdateArgs u = update_args(c, apply);
+  if (apply) u.step = ++c->adam_step;
   Prof p(c, DUST_K_UPDATE);
   update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
   HIP_TRY(hipGetLastError());
@@ -799,6 +888,7 @@ extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *acti
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if ((costs == nullptr) != (actions == nullptr)) return fail(DUST_ERR_INVALID, "pass both costs and actions, or neither");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(launch_prior(c));
   if (costs) {
     // a user-supplied log_p returned (costs, actions): only the weights / score reductions of kernel A run
     const float *nd = nullptr;
@@ -810,34 +900,41 @@ extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *acti
     o.noise_dev = nd;
     o.base = c->theta;
     o.costs_in = c->costs_stage;
+    o.merge_prior = 1;
     TRY(launch_rollout(c, o));
-  } else if (!c->have_sample) {
-    return fail(DUST_ERR_STATE, "phi without costs/actions needs a prior dust_likelihood_sample");
+  } else {
+    if (!c->have_sample) return fail(DUST_ERR_STATE, "phi without costs/actions needs a prior dust_likelihood_sample");
+    TRY(launch_prior_finish(c, true, false));
   }
-  TRY(launch_prior(c, true, false));
-  TRY(launch_stein(c));
+  TRY(launch_stein_update(c, 0));
   if (phi) TRY(d2h(c, phi, c->phi, (size_t)c->N * c->D * sizeof(float)));
   if (grad_lik) TRY(d2h(c, grad_lik, c->grad_lik, (size_t)c->N * c->D * sizeof(float)));
   if (grad_pri) TRY(d2h(c, grad_pri, c->grad_pri, (size_t)c->N * c->D * sizeof(float)));
   return DUST_OK;
 }
 
-static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
+// local half of one SVGD iteration: prior partials -> rollout (+ merge) -> score rows of this shard
+static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set) {
+  TRY(launch_prior(c));
   SampleOpts o;
   memset(&o, 0, sizeof o);
   o.noise_mode = noise_dev ? NOISE_EPS : NOISE_PHILOX;
   o.noise_dev = noise_dev;
   o.base = c->theta;
   o.update_a_mat = 1;
+  o.merge_prior = 1;
   float *save = c->params_dev;
   if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
   int s = launch_rollout(c, o);
   c->params_dev = save;
   TRY(s);
   c->have_sample = true;
-  TRY(launch_prior(c, true, false));
-  TRY(launch_stein(c));
-  TRY(launch_update(c));
+  return DUST_OK;
+}
+
+static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
+  TRY(local_score_device(c, noise_dev, param_set));
+  TRY(launch_stein_update(c, 1));
   c->iter++;
   return DUST_OK;
 }
@@ -867,7 +964,8 @@ extern "C" int dust_svmpc_step(dust_ctx *c, const float *state, const float *eps
 
 static int forward_device(dust_ctx *c) {
   if (!c->have_sample) return fail(DUST_ERR_STATE, "forward(fast_pred=True) needs the costs of a previous optimize step");
-  TRY(launch_prior(c, false, true));
+  TRY(launch_prior(c));
+  TRY(launch_prior_finish(c, false, true));
   Prof p(c, DUST_K_FORWARD);
   logw_kernel<<<(c->nloc + 255) / 256, 256, 0, c->stream>>>(c->logl, c->logp, c->lw, c->n0, c->nloc);
   HIP_TRY(hipGetLastError());
@@ -893,7 +991,7 @@ static int forward_finish_device(dust_ctx *c) {
   finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
   HIP_TRY(hipGetLastError());
   const int n = c->nloc * c->da;
-  roll_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->theta, c->thetaT, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
+  roll_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
   HIP_TRY(hipGetLastError());
   c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
   c->tick++;
@@ -973,31 +1071,18 @@ extern "C" int dust_svmpc_local_score(dust_ctx *c, const float *state, const flo
   TRY(upload_state_params(c, state, params, 1));
   const float *nd = nullptr;
   TRY(stage_noise(c, eps, flags, &nd));
-  // theta rows of the other shards were refreshed by the caller's all-gather: rebuild the transposed copy
-  if (c->nloc != c->N) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
-  SampleOpts o;
-  memset(&o, 0, sizeof o);
-  o.noise_mode = nd ? NOISE_EPS : NOISE_PHILOX;
-  o.noise_dev = nd;
-  o.base = c->theta;
-  o.update_a_mat = 1;
-  TRY(launch_rollout(c, o));
-  c->have_sample = true;
-  TRY(launch_prior(c, true, false));
-  return DUST_OK;
+  return local_score_device(c, nd, 0);
 }
 extern "C" int dust_svmpc_apply_phi(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
-  TRY(launch_stein(c));
-  TRY(launch_update(c));
+  TRY(launch_stein_update(c, 1));
   c->iter++;
   return DUST_OK;
 }
 extern "C" int dust_svmpc_forward_local(dust_ctx *c, void **log_w_all, size_t *shard_bytes) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
-  if (c->nloc != c->N) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
   TRY(forward_device(c));
   if (log_w_all) *log_w_all = c->lw;
   if (shard_bytes) *shard_bytes = (size_t)c->nloc * sizeof(float);
@@ -1065,5 +1150,19 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
   if (p) HIP_TRY(hipFree(p));
   return DUST_OK;
 }
+
+#ifdef DUST_STAMPS
+// diagnostic build only (not part of include/dust_amd.h): s_memtime phase stamps of block 0 of the last launch of a kernel
+extern "C" int dust_debug_stamps(dust_ctx *c, int kernel_id, unsigned long long *out16) {
+  if (!c->stamps_dev) {
+    HIP_TRY(hipMalloc((void **)&c->stamps_dev, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->stamps_dev, 0, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
+    return DUST_OK;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out16, c->stamps_dev + 16 * kernel_id, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+#endif
 
 #include "mpf.hpp"

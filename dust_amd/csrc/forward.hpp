@@ -122,7 +122,7 @@ __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *log
 }
 
 // SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy. One thread per (i, d_a).
-__global__ void roll_kernel(float *theta, float *thetaT, int N, int H, int da, int strategy, int i0, int n_local) {
+__global__ void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_local * da) return;
   const int i = i0 + idx / da, c = idx % da;
@@ -135,14 +135,9 @@ __global__ void roll_kernel(float *theta, float *thetaT, int N, int H, int da, i
     mean = (float)(acc / H);
   }
   float last = th[(H - 1) * da + c];
-  for (int t = 0; t + 1 < H; ++t) {
-    const float v = th[(t + 1) * da + c];
-    th[t * da + c] = v;
-    thetaT[(size_t)(t * da + c) * N + i] = v;
-  }
+  for (int t = 0; t + 1 < H; ++t) th[t * da + c] = th[(t + 1) * da + c];
   if (strategy == DUST_ROLL_MEAN) last = mean;
   th[(H - 1) * da + c] = last;
-  thetaT[(size_t)((H - 1) * da + c) * N + i] = last;
 }
 
 // a_mix = softmax_n(eta) disco.py:393 (single workgroup)

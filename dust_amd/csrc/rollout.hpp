@@ -1,18 +1,24 @@
 // rollout.hpp - kernel A: policy-noise sampling + batched rollouts + trajectory costs + softmax weights +
-// likelihood score + MPPI side update, one workgroup per Stein particle n.
+// likelihood score + MPPI side update (+ combine of the prior-score partials), one workgroup per Stein particle n.
 //
 // Replaces (reference file:line): CostLikelihood.sample likelihoods.py:81-101, MultiDISCO._rollout disco.py:139-209,
 // PendulumModel.step pendulum.py:61-100 / Particle.step particle.py:117-166, MultiDISCO._compute_cost disco.py:294-346,
-// MultiDISCO.forward disco.py:380-393 (omega, a_mat, eta) and the likelihood half of SVMPC.phi svmpc.py:44-54.
+// MultiDISCO.forward disco.py:380-393 (omega, a_mat, eta) and the likelihood half of SVMPC.phi svmpc.py:44-56.
 //
 // Layout / mapping (MI355X): a workgroup owns particle n and its S action samples.  The S x D action tile
-// (a[s][j] = theta[n][j] + L eps[s][n][j]) is staged ONCE in LDS with coalesced loads of the S contiguous D-float
-// rows of eps (row stride N*D floats in HBM); every later use - H-step rollout (lane = sample s, the M dynamics samples
-// looped in registers), weighted reductions over s for grad_lik and the a_mat update - reads LDS, never HBM again.
-// Row stride in LDS is D|1 dwords so lane-strided reads are bank-conflict free.  Costs are written as costsT[n][s]
-// (coalesced); the host-facing [S][N] view is produced on demand.
+// (a[s][j] = theta[n][j] + L eps[s][n][j]) is staged ONCE in LDS; every later use - H-step rollout (lane = sample s, the
+// M dynamics samples looped in registers), weighted reductions over s for grad_lik and the a_mat update - reads LDS,
+// never HBM again.  Row stride in LDS is D|1 dwords so lane-strided reads are bank-conflict free.
+//   * caller-supplied noise: the S contiguous D-float rows of eps (row stride N*D floats in HBM) are fetched with
+//     coalesced loads, 8 in flight per lane before the first LDS write (the kernel is latency-, not bandwidth-bound);
+//   * no noise supplied: each lane fills ITS OWN tile row from a Philox counter stream and rolls it out straight away -
+//     eps never exists in HBM and no workgroup barrier separates sampling from the rollout.
+// Costs are written as costsT[n][s] (coalesced); the host-facing [S][N] view is produced on demand.
+// At N*S = 131072 rollouts a launch is only 2 waves per SIMD, so the kernel is instruction-issue bound: the pendulum
+// step is specialised (one argument reduction serves sin(theta+pi) and cos(theta), see pendulum_trig).
 #pragma once
 #include "common.hpp"
+#include "stein.hpp"
 
 namespace dust {
 
@@ -20,13 +26,16 @@ enum { NOISE_EPS = 0, NOISE_ACTIONS = 1, NOISE_PHILOX = 2 };
 
 struct RolloutArgs {
   DevModel dm;
-  int N_total, n0, S, M, H, da, ds, D;
+  int N_total, n0, S, M, H, D;
   int noise_mode;
   int lik;           // dust_likelihood
   int eps_base_mode; // 0: eps = a - a_seq (ext actions, disco.py:161-164); 1: eps = a - a_mat[n] (internal noise, 155-160)
   int update_a_mat;
+  int merge_prior;   // combine the prior-pass partials and write grad_pri / score = grad_lik + grad_pri
+  uint32_t magicD;   // floor(2^32 / D) + 1: exact division of tile indices by D
   float alpha, temp, a_reg;
   float chol_a[4], sigma_a[4], a_pre[4];
+  PriorMerge pm;
   const float *state;   // [ds]
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
   const float *noise;   // eps or actions [S][N_total][D] (device), or nullptr for Philox
@@ -36,94 +45,160 @@ struct RolloutArgs {
   float *costsT;        // [N_total][S]
   const float *costs_in; // [S][N_total] or nullptr: stage-wise mode (SVMPC.phi with a user log_p): skip the rollouts
   float *grad_lik;      // [N_total][D]
+  float *grad_pri;      // [N_total][D] (merge_prior)
+  float *score;         // [N_total][D] (merge_prior)
   float *logl;          // [N_total]   likelihood.log_prob per particle
   float *eta;           // [N_total]   logsumexp_s(-c/temp)  (a_mix = softmax_n(eta), beta cancels)
   float *omegaT;        // [N_total][S] or nullptr
   float *actions_out;   // [S][N_total][D] or nullptr
   float *states_out;    // [M][S][N_total][H+1][ds] or nullptr
+  float *tile_scratch;  // [n_local][S][D|1] HBM slab for action tiles too large for LDS, else nullptr
   uint64_t seed;
   uint32_t tick, iter;
+  unsigned long long *stamps;  // diagnostic build only
 };
+
+// sin(fl(theta + pi_f)) and cos(theta) from ONE Cody-Waite reduction of theta.  fl(theta + pi_f) = theta + pi + e with
+// e = (pi_f - pi) - err, err the rounding error of the fp32 add recovered exactly by TwoSum; then
+// sin(theta + pi + e) = -(sin theta cos e + cos theta sin e) = -(sin theta + e cos theta) up to e^2 < 1e-13.
+__device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
+  int q;
+  const float r = trig_reduce(th, &q);
+  const float ps = poly_sin(r), pc = poly_cos(r);
+  float sn = (q & 1) ? pc : ps;
+  float cs = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -sn : sn;
+  cs = ((q + 1) & 2) ? -cs : cs;
+  const float tp = th + PI_F;
+  const float bb = tp - th;
+  const float err = (th - (tp - bb)) + (PI_F - bb);  // exact: th + PI_F = tp + err
+  const float e = 8.742278000372485e-8f - err;       // pi_f - pi
+  *sin_tp = -fmaf(e, cs, sn);
+  *cos_th = cs;
+}
 
 template <int MODEL>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
+  constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
+  constexpr int DA = MODEL == DUST_MODEL_PENDULUM ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n = a.n0 + blockIdx.x;
-  const int S = a.S, D = a.D, H = a.H, da = a.da, N = a.N_total;
+  const int S = a.S, D = a.D, H = a.H, N = a.N_total;
   const int Dp = D | 1;
-  float *tile = lds;                 // [S][Dp] actions
-  float *cst = tile + (size_t)S * Dp;  // [S] costs -> weights
-  float *omg = cst + S;              // [S] omega
-  float *red = omg + S;              // [32] reduction scratch
-  float *part = red + 32;            // [nt] partial sums for the weighted reductions (2 x nt)
+  // the S x D action tile lives in LDS; when it would not fit (huge S*D) it spills to a per-workgroup HBM scratch slab
+  float *tile = a.tile_scratch ? a.tile_scratch + (size_t)blockIdx.x * S * Dp : lds;  // [S][Dp] actions
+  float *cst = a.tile_scratch ? lds : lds + (size_t)S * Dp;                            // [S] costs -> weights
+  float *omg = cst + S;    // [S] omega
+  float *red = omg + S;    // [64] reduction scratch
+  float *part = red + 64;  // [2][nt] partial sums for the weighted reductions
 
+  DUST_STAMP(a.stamps, 0);
   // ---- 1. stage the action tile (a1: actions = theta + L eps) ----
-  const float *th = a.theta + (size_t)n * D;
-  if (a.noise_mode == NOISE_PHILOX) {
-    const int D4 = (D + 3) >> 2;
-    for (int idx = tid; idx < S * D4; idx += nt) {
-      const int s = idx / D4, j4 = idx - s * D4;
-      float z[4];
-      philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), a.iter, a.tick, z);
+  // theta row of this particle -> LDS once (every later use is an LDS broadcast / lane read, not a global load)
+  float *th = part + 2 * nt;  // [D]
+  if (tid < D) th[tid] = a.theta[(size_t)n * D + tid];
+  float x0[DS];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int j = j4 * 4 + q;
-        if (j < D) tile[s * Dp + j] = th[j] + a.chol_a[j % da] * z[q];
+  for (int k = 0; k < DS; ++k) x0[k] = a.state[k];
+  __syncthreads();
+  if (a.noise_mode != NOISE_PHILOX) {
+    const int total = S * D;
+    for (int base = 0; base < total; base += 16 * nt) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight per lane
+        const int idx = base + u * nt + tid;
+        const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
+        v[u] = idx < total ? a.noise[((size_t)s * N + n) * D + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = base + u * nt + tid;
+        const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
+        if (idx < total) tile[s * Dp + j] = a.noise_mode == NOISE_EPS ? th[j] + a.chol_a[j % DA] * v[u] : v[u];
       }
     }
-  } else {
-    for (int idx = tid; idx < S * D; idx += nt) {
-      const int s = idx / D, j = idx - s * D;
-      const float e = a.noise[((size_t)s * N + n) * D + j];
-      tile[s * Dp + j] = a.noise_mode == NOISE_EPS ? th[j] + a.chol_a[j % da] * e : e;
-    }
-  }
-  __syncthreads();
-  if (a.actions_out) {
-    for (int idx = tid; idx < S * D; idx += nt) {
-      const int s = idx / D, j = idx - s * D;
-      a.actions_out[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
-    }
+    __syncthreads();
   }
 
+  DUST_STAMP(a.stamps, 1);
   // ---- 2. rollouts: lane = sample s, dynamics samples m looped in registers (a2-a5) ----
   const long SN = (long)S * N;
-  if (a.costs_in) {
-    for (int s = tid; s < S; s += nt) cst[s] = a.costs_in[(size_t)s * N + n];
-  } else
+  // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
+  const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out &&
+                         (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   for (int s = tid; s < S; s += nt) {
-    const float *act = tile + s * Dp;
+    float *act = tile + s * Dp;
+    if (a.noise_mode == NOISE_PHILOX) {  // this lane's own row: no barrier needed before it is consumed below
+      for (int j4 = 0; j4 * 4 < D; ++j4) {
+        float z[4];
+        philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), a.iter, a.tick, z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j4 * 4 + q;
+          if (j < D) act[j] = th[j] + a.chol_a[j % DA] * z[q];
+        }
+      }
+    }
+    if (a.costs_in) {
+      cst[s] = a.costs_in[(size_t)s * N + n];
+      continue;
+    }
     double acc_m = 0.0;
     for (int m = 0; m < a.M; ++m) {
       const long r = (long)m * SN + (long)s * N + n;
       const float *prow = a.params ? a.params + (size_t)(a.dm.interleave ? (int)(r % a.M) : m) * a.dm.P : nullptr;
       const Coef cf = make_coef(a.dm, prow);
-      float x[4];
+      float x[DS];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = k < a.ds ? a.state[k] : 0.f;
-      float *so = a.states_out ? a.states_out + (size_t)r * (H + 1) * a.ds : nullptr;
-      if (so)
-        for (int k = 0; k < a.ds; ++k) so[k] = x[k];
+      for (int k = 0; k < DS; ++k) x[k] = x0[k];
       double tot = 0.0;
-      for (int t = 0; t < H; ++t) {
-        float at[2];
-        at[0] = act[t * da];
-        at[1] = da > 1 ? act[t * da + 1] : 0.f;
-        tot += (double)inst_cost<MODEL>(a.dm, x, at);  // cost of the state BEFORE the action (disco.py:306)
-        model_step<MODEL>(a.dm, cf, x, at);
-        if (so)
-          for (int k = 0; k < a.ds; ++k) so[(size_t)(t + 1) * a.ds + k] = x[k];
+      float traj;
+      if (fast_trig) {
+        // PendulumModel.step + demo cost, same fp32 operation order as model_step / inst_cost
+        const float dt = (float)a.dm.dt;
+        float sn, cs;
+        for (int t = 0; t < H; ++t) {
+          pendulum_trig(x[0], &sn, &cs);
+          const float cm = cs - 1.0f;
+          tot += (double)(a.dm.w_cos * (cm * cm) + a.dm.w_vel * (x[1] * x[1]));
+          const float u = clampf(act[t], -a.dm.max_torque, a.dm.max_torque);
+          float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
+          thd = clampf(thd, -a.dm.max_speed_pend, a.dm.max_speed_pend);
+          x[0] = x[0] + thd * dt;
+          x[1] = thd;
+        }
+        pendulum_trig(x[0], &sn, &cs);
+        const float cm = cs - 1.0f;
+        traj = (float)tot + (a.dm.w_cos * (cm * cm) + a.dm.w_vel * (x[1] * x[1]));
+      } else {
+        float *so = a.states_out ? a.states_out + (size_t)r * (H + 1) * DS : nullptr;
+        if (so) {
+#pragma unroll
+          for (int k = 0; k < DS; ++k) so[k] = x[k];
+        }
+        for (int t = 0; t < H; ++t) {
+          float at[DA];
+#pragma unroll
+          for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
+          tot += (double)inst_cost<MODEL>(a.dm, x, at);  // cost of the state BEFORE the action (disco.py:306)
+          model_step<MODEL>(a.dm, cf, x, at);
+          if (so) {
+#pragma unroll
+            for (int k = 0; k < DS; ++k) so[(size_t)(t + 1) * DS + k] = x[k];
+          }
+        }
+        traj = (float)tot + term_cost<MODEL>(a.dm, x);
       }
-      const float traj = (float)tot + term_cost<MODEL>(a.dm, x);
       acc_m += (double)traj;
     }
-    float cost = (float)(acc_m / a.M);
+    float cost = a.M == 1 ? (float)acc_m : (float)(acc_m / a.M);
     if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
       double cc = 0.0;
       for (int j = 0; j < D; ++j) {
         const float e = act[j] - a.a_seq[j];
-        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % da]);
+        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % DA]);
       }
       cost = cost + a.a_reg * (float)cc;
     }
@@ -131,15 +206,36 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
     a.costsT[(size_t)n * S + s] = cost;
   }
   __syncthreads();
+  if (a.actions_out) {
+    for (int idx = tid; idx < S * D; idx += nt) {
+      const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
+      a.actions_out[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
+    }
+  }
 
+  DUST_STAMP(a.stamps, 2);
   // ---- 3. softmax over samples: likelihood weights w (alpha) and MPPI weights omega (1/temp) ----
   float cmin = INFINITY, csum = 0.f;
   for (int s = tid; s < S; s += nt) {
     cmin = fminf(cmin, cst[s]);
     csum += cst[s];
   }
-  cmin = block_reduce<RED_MIN>(cmin, red);
-  csum = block_reduce<RED_SUM>(csum, red);
+  {
+    const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
+    cmin = wave_min(cmin);
+    csum = wave_sum(csum);
+    if (lane == 0) {
+      red[wid] = cmin;
+      red[8 + wid] = csum;
+    }
+    __syncthreads();
+    cmin = red[0];
+    csum = red[8];
+    for (int w = 1; w < nw; ++w) {
+      cmin = fminf(cmin, red[w]);
+      csum += red[8 + w];
+    }
+  }
   float zw = 0.f, zo = 0.f;
   for (int s = tid; s < S; s += nt) {
     const float c = cst[s];
@@ -151,8 +247,22 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
     cst[s] = ew;
     zw += ew;
   }
-  zw = block_reduce<RED_SUM>(zw, red);
-  zo = block_reduce<RED_SUM>(zo, red);
+  {
+    const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
+    zw = wave_sum(zw);
+    zo = wave_sum(zo);
+    if (lane == 0) {
+      red[16 + wid] = zw;
+      red[24 + wid] = zo;
+    }
+    __syncthreads();
+    zw = red[16];
+    zo = red[24];
+    for (int w = 1; w < nw; ++w) {
+      zw += red[16 + w];
+      zo += red[24 + w];
+    }
+  }
   for (int s = tid; s < S; s += nt) {
     cst[s] = cst[s] / zw;
     omg[s] = omg[s] / zo;
@@ -167,34 +277,77 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   }
   __syncthreads();
 
+  DUST_STAMP(a.stamps, 3);
   // ---- 4. weighted reductions over s: grad_lik (svmpc.py:52-54) and a_mat += sum_s omega eps (disco.py:387-392) ----
   const int Q = nt / D > 0 ? nt / D : 1;
   float g = 0.f, am = 0.f;
-  const int j = tid % D, q = tid / D;
+  const int q = (int)__umulhi((uint32_t)tid, a.magicD), j = tid - q * D;
+  // prior partials of this row: issue the (independent) loads now, consume them after the reduction below
+  float pmM[16], pmL[16], pmA[16];
+  const bool merger = a.merge_prior && tid < D;
+  const int JS = a.pm.JS;
+  if (merger) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool ok = u < JS;
+      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + blockIdx.x;
+      pmM[u] = ok ? a.pm.pM[rowi] : -INFINITY;
+      pmL[u] = ok ? a.pm.pL[rowi] : 0.f;
+      pmA[u] = ok ? a.pm.pA[rowi * D + tid] : 0.f;
+    }
+  }
   if (q < Q) {
     const float thj = th[j];
-    const float s2 = a.sigma_a[j % da] * a.sigma_a[j % da];
+    const float is2 = 1.0f / (a.sigma_a[j % DA] * a.sigma_a[j % DA]);  // (a - x) / sigma^2 as a multiply: <= 1 ulp apart
     const float base = a.eps_base_mode ? thj : a.a_seq[j];
+#pragma unroll 8
     for (int s = q; s < S; s += Q) {
       const float av = tile[s * Dp + j];
-      g = fmaf(cst[s], (av - thj) / s2, g);
+      g = fmaf(cst[s], (av - thj) * is2, g);
       am = fmaf(omg[s], av - base, am);
     }
   }
   part[tid] = g;
   part[nt + tid] = am;
   __syncthreads();
-  for (int jj = tid; jj < D; jj += nt) {
+  DUST_STAMP(a.stamps, 4);
+  if (tid < D) {
     float gs = 0.f, as = 0.f;
     for (int qq = 0; qq < Q; ++qq) {
-      gs += part[qq * D + jj];
-      as += part[nt + qq * D + jj];
+      gs += part[qq * D + tid];
+      as += part[nt + qq * D + tid];
     }
-    a.grad_lik[(size_t)n * D + jj] = gs;
-    if (a.update_a_mat) a.a_mat[(size_t)n * D + jj] += as;
+    const size_t o = (size_t)n * D + tid;
+    a.grad_lik[o] = gs;
+    if (a.update_a_mat) a.a_mat[o] += as;
+    if (a.merge_prior) {  // prior half of the score (svmpc.py:38-41,56) from the pairwise kernel's slice partials
+      float gp;
+      if (JS <= 16) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m = fmaxf(m, pmM[u]);
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float w = (pmM[u] == -INFINITY) ? 0.f : expf(pmM[u] - m);
+          l = fmaf(pmL[u], w, l);
+          acc = fmaf(pmA[u], w, acc);
+        }
+        gp = (acc / l) * a.pm.inv_s2[tid % DA];
+      } else {
+        float m, l;
+        prior_merge_row(a.pm, blockIdx.x, &m, &l);
+        gp = prior_merge_col(a.pm, blockIdx.x, D, tid, DA, m, l);
+      }
+      a.grad_pri[o] = gp;
+      a.score[o] = gs + gp;
+    }
   }
+  DUST_STAMP(a.stamps, 5);
 }
 
-static inline size_t rollout_lds_bytes(int S, int D, int nt) { return sizeof(float) * ((size_t)S * (D | 1) + 2 * (size_t)S + 32 + 2 * (size_t)nt); }
+static inline size_t rollout_lds_bytes(int S, int D, int nt, bool tile_in_lds) {
+  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 64 + 2 * (size_t)nt + (size_t)D);
+}
 
 }  // namespace dust

@@ -5,198 +5,296 @@
 // svmpc.py:128-140, the K1 kernel branch svmpc.py:76-83 (gpytorch RBFKernel semantics, lengthscale ln 2), the new IMQ
 // kernel, and SVMPC.step's optimiser update svmpc.py:87-95.
 //
-// Mapping (MI355X): a workgroup owns TI query particles i and streams all N "key" particles j in chunks of JC:
-//   pass A  lane = j : d2[t][j] = sum_d ((x_i[t][d] - YT[d][j]) / s_d)^2 from the TRANSPOSED copy YT[D][N] (coalesced
-//           256-B wave loads; x_i broadcast from LDS), kernel value / softmax logit into LDS kv[TI][JC];
-//   pass B  lane = (d, q): acc[t] += kv[t][j] * V[j][d] from the ROW-MAJOR copy V[N][D] (contiguous D-float rows),
-//           j interleaved over the Q = blockDim/D lane groups so LDS reads of kv broadcast / stay conflict free.
-// Nothing N x N is ever written to HBM (the reference materialises [N,N,H,da]).  Differences (x_i - x_j) are formed
-// before multiplying by the kernel value, so collapsed particle sets do not cancel catastrophically.
+// Mapping (MI355X).  The pairwise work is cut into 2-D tiles so that a launch has >= 256 workgroups even at N = 1024
+// and every CU reads only ITS tile of the particle set (not all of it): workgroup (it, js) owns TI = 32 query particles
+// and the js-th slice of the key particles, streamed through LDS in chunks of JC = 64 rows (coalesced loads of
+// contiguous row-major rows, 8 in flight per lane; two workgroups per CU hide each other's LDS / exp latency).  Per chunk:
+//   pass A  lane = key j, the wave walks 8 queries: d2 = sum_d ((x_i[d] - y_j[d]) / s_d)^2 with y_j in registers and
+//           x_i[d] LDS-broadcast (b128); kernel value / softmax logit -> LDS kv[TI][JC+1];
+//   pass B  lane = (query i, column group): acc[i][c] += kv[i][j] * V[j][c], a [32 x 64] . [64 x D] product out of
+//           LDS with b128 reads, differences (x_i - y_j) formed BEFORE the multiply (collapsed particle sets must not
+//           cancel catastrophically).
+// Each workgroup writes a partial row block; the js partials are combined by the NEXT kernel in the chain (prior ->
+// rollout_kernel, Stein -> update_kernel) in a fixed order, so results are bitwise reproducible (no float atomics).
+// Nothing N x N ever reaches HBM (the reference materialises [N,N,H,da] through autograd).
 #pragma once
 #include "common.hpp"
 
 namespace dust {
 
 enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2 };
+enum { PAIR_TI = 32, PAIR_JC = 64, PAIR_NT = 256 };
 
 struct PairArgs {
   int N, D, da, H;
   int i0, n_local;     // query rows [i0, i0 + n_local)
-  int JC;              // j-chunk held in LDS
+  int JS;              // number of key slices (gridDim.y)
+  int slice;           // keys per slice (multiple of PAIR_JC except possibly the last)
+  uint32_t magicD;     // floor(2^32 / D) + 1
   const float *X;      // [N][D] queries (theta)
-  const float *YT;     // [D][N] keys, transposed (mu^T for the prior, theta^T for Stein)
-  const float *Y;      // [N][D] keys, row-major
-  const float *V;      // [N][D] second value array (score) for Stein; unused for the prior
+  const float *Y;      // [N][D] keys (mu for the prior, theta for Stein), row-major
+  const float *V;      // [N][D] score (Stein only)
   const float *logmix; // [N] prior mixture log-weights
-  float inv_s[4];      // 1/sigma_p[d % da]  (prior)  or 1/ell (Stein)
-  float inv_s2[4];
-  float log_norm;      // -H*sum(log sigma_p) - D/2 log(2 pi)
-  float inv_n;         // 1/N
-  float *out;          // prior: grad_pri [N][D] ; Stein: phi [N][D]
-  const float *add;    // prior: grad_lik to add -> score written to out2
-  float *out2;         // prior: score [N][D]
-  float *logp;         // prior: log p(x_i) [N] (nullptr to skip)
+  float inv_s[4];      // 1/sigma_p[d % da] (prior) or 1/ell (Stein)
+  // partial outputs, indexed [js][i_local]
+  float *pA;           // [JS][n_local][D]  prior: sum_k p (mu - x)      Stein: sum_j k s_j
+  float *pB;           // [JS][n_local][D]                               Stein: sum_j k' (x_i - x_j)
+  float *pM;           // [JS][n_local]     prior: slice max of the logits
+  float *pL;           // [JS][n_local]     prior: sum exp(logit - max)
+  unsigned long long *stamps;  // diagnostic build only
 };
 
-template <int MODE, int TI>
-__global__ __launch_bounds__(256) void pairwise_kernel(const PairArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int N = a.N, D = a.D, da = a.da, JC = a.JC;
-  float *xi = lds;                 // [TI][D]
-  float *kv = xi + TI * D;         // [TI][JC]
-  float *red = kv + TI * JC;       // [32]
-  float *mrun = red + 32;          // [TI] running max (prior)
-  float *part = mrun + TI;         // [TI][nt] + [TI][nt] partial sums
-  const int ib = a.i0 + blockIdx.x * TI;
-
-  for (int idx = tid; idx < TI * D; idx += nt) {
-    const int t = idx / D, d = idx - t * D;
-    const int i = ib + t;
-    xi[idx] = (i < a.i0 + a.n_local) ? a.X[(size_t)i * D + d] : 0.f;
-  }
-  if (tid < TI) mrun[tid] = -INFINITY;
+// rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP.
+// The source range is one contiguous run of nrows*D floats: coalesced dword loads, 8 in flight per lane.
+template <int TR, int DP, int LS, int NT>
+__device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0, int nrows, int D, uint32_t magicD, float *dst) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < TR * DP; idx += NT) dst[(idx / DP) * LS + (idx % DP)] = 0.f;
   __syncthreads();
-
-  const int Q = nt / D > 0 ? nt / D : 1;
-  const int d = tid % D, q = tid / D;
-  const bool active = q < Q;
-  float accA[TI], accB[TI], accC[TI];  // prior: A = sum p (mu - x), C = sum p ; Stein: A = sum k s, B = sum k' (x_i - x_j), C unused
+  const int total = nrows * D;
+  const float *base = src + (size_t)r0 * D;
+  for (int b = 0; b < total; b += 8 * NT) {
+    float v[8];
 #pragma unroll
-  for (int t = 0; t < TI; ++t) accA[t] = accB[t] = accC[t] = 0.f;
-  float xid[TI];
-#pragma unroll
-  for (int t = 0; t < TI; ++t) xid[t] = active ? xi[t * D + d] : 0.f;
-
-  for (int j0 = 0; j0 < N; j0 += JC) {
-    const int jc = min(JC, N - j0);
-    // ---- pass A: kernel values / logits for this chunk ----
-    float lmax[TI];
-#pragma unroll
-    for (int t = 0; t < TI; ++t) lmax[t] = -INFINITY;
-    for (int jj = tid; jj < jc; jj += nt) {
-      const int j = j0 + jj;
-      float d2[TI];
-#pragma unroll
-      for (int t = 0; t < TI; ++t) d2[t] = 0.f;
-      for (int dd = 0; dd < D; ++dd) {
-        const float y = a.YT[(size_t)dd * N + j];
-        const float is = a.inv_s[dd % da];
-#pragma unroll
-        for (int t = 0; t < TI; ++t) {
-          const float z = (xi[t * D + dd] - y) * is;
-          d2[t] = fmaf(z, z, d2[t]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < TI; ++t) {
-        float v;
-        if (MODE == PAIR_PRIOR) {
-          v = a.logmix[j] - 0.5f * d2[t];
-          lmax[t] = fmaxf(lmax[t], v);
-        } else if (MODE == PAIR_K1) {
-          v = expf(-0.5f * d2[t]);
-        } else {
-          v = d2[t];  // IMQ: keep the scaled squared distance; both k and k' are formed in pass B
-        }
-        kv[t * JC + jj] = v;
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int idx = b + u * NT + tid;
+      v[u] = idx < total ? base[idx] : 0.f;
     }
-    if (MODE == PAIR_PRIOR) {
-      // online softmax across chunks: rescale the running sums when the max moves
 #pragma unroll
-      for (int t = 0; t < TI; ++t) {
-        const float cm = block_reduce<RED_MAX>(lmax[t], red);
-        const float mo = mrun[t];
-        const float mn = fmaxf(mo, cm);
-        const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
-        accA[t] *= sc;
-        accC[t] *= sc;
-        __syncthreads();
-        if (tid == 0) mrun[t] = mn;
-      }
-      __syncthreads();
-      for (int idx = tid; idx < TI * jc; idx += nt) {
-        const int t = idx / jc, jj = idx - t * jc;
-        kv[t * JC + jj] = expf(kv[t * JC + jj] - mrun[t]);
-      }
-    }
-    __syncthreads();
-    // ---- pass B: accumulate over the chunk ----
-    if (active) {
-      for (int jj = q; jj < jc; jj += Q) {
-        const int j = j0 + jj;
-        const float y = a.Y[(size_t)j * D + d];
-        if (MODE == PAIR_PRIOR) {
-#pragma unroll
-          for (int t = 0; t < TI; ++t) {
-            const float p = kv[t * JC + jj];
-            accA[t] = fmaf(p, y - xid[t], accA[t]);
-            accC[t] += p;
-          }
-        } else {
-          const float sv = a.V[(size_t)j * D + d];
-#pragma unroll
-          for (int t = 0; t < TI; ++t) {
-            float k, kp;
-            if (MODE == PAIR_K1) {
-              k = kv[t * JC + jj];
-              kp = -k;  // d k / d x_i = -k (x_i - x_j)/ell^2
-            } else {
-              const float base = 1.0f + kv[t * JC + jj];
-              k = rsqrtf(base);
-              kp = -k / base;
-            }
-            accA[t] = fmaf(k, sv, accA[t]);
-            accB[t] = fmaf(kp, xid[t] - y, accB[t]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- cross-group reduction and epilogue ----
-#pragma unroll
-  for (int t = 0; t < TI; ++t) {
-    part[t * nt + tid] = accA[t];
-    part[(TI + t) * nt + tid] = (MODE == PAIR_PRIOR) ? accC[t] : accB[t];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < TI * D; idx += nt) {
-    const int t = idx / D, dd = idx - t * D;
-    const int i = ib + t;
-    if (i >= a.i0 + a.n_local) continue;
-    float sa = 0.f, sb = 0.f;
-    for (int qq = 0; qq < Q; ++qq) {
-      sa += part[t * nt + qq * D + dd];
-      sb += part[(TI + t) * nt + qq * D + dd];
-    }
-    if (MODE == PAIR_PRIOR) {
-      const float gp = (sa / sb) * a.inv_s2[dd % da];
-      if (a.out) a.out[(size_t)i * D + dd] = gp;
-      if (a.out2) a.out2[(size_t)i * D + dd] = a.add[(size_t)i * D + dd] + gp;
-      if (a.logp && dd == 0) a.logp[i] = (mrun[t] + logf(sb)) + a.log_norm;
-    } else {
-      a.out[(size_t)i * D + dd] = sb * a.inv_s2[0] + sa * a.inv_n;  // grad_k (not /N) + K score / N  (svmpc.py:83)
+    for (int u = 0; u < 8; ++u) {
+      const int idx = b + u * NT + tid;
+      const int r = (int)__umulhi((uint32_t)idx, magicD), d = idx - r * D;
+      if (idx < total) dst[r * LS + d] = v[u];
     }
   }
 }
 
-static inline size_t pairwise_lds_bytes(int TI, int D, int JC, int nt) {
-  return sizeof(float) * ((size_t)TI * D + (size_t)TI * JC + 32 + TI + 2 * (size_t)TI * nt);
+template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
+__global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) {
+  constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
+  constexpr int DP = 8 * CPT;  // padded row length in LDS (multiple of 4 -> b128 reads)
+  constexpr int YS = DP + 4;
+  constexpr int QG = NT / JC;      // query groups in pass A (4)
+  constexpr int QPG = TI / QG;     // queries per group (8)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Xs = lds;                  // [TI][DP]
+  float *Ys = Xs + TI * DP;         // [JC][YS]
+  float *Vs = Ys + JC * YS;         // [JC][YS]   (Stein)
+  float *kv = Vs + (MODE == PAIR_PRIOR ? 0 : JC * YS);  // [TI][JC + 1]
+  float *mrow = kv + TI * (JC + 1); // [TI] running max
+  const int tid = threadIdx.x;
+  const int D = a.D, da = a.da, N = a.N;
+  const int ib = a.i0 + blockIdx.x * TI;  // first query (global index)
+  const int js = blockIdx.y;
+  const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
+
+  DUST_STAMP(a.stamps, 0);
+  // ---- query tile -> LDS (zero padded) ----
+  load_rows<TI, DP, DP, NT>(a.X, ib, min(TI, a.i0 + a.n_local - ib), D, a.magicD, Xs);
+  if (tid < TI) mrow[tid] = -INFINITY;
+
+  // pass-B ownership: query iB, columns [cB, cB + CPT)
+  const int iB = tid >> 3, cB = (tid & 7) * CPT;
+  float accA[CPT], accB[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) accA[c] = accB[c] = 0.f;
+  float accL = 0.f;  // prior: sum of weights (same in the 8 lanes of a query)
+  __syncthreads();
+  float xB[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) xB[c] = Xs[iB * DP + cB + c];
+  float isc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) isc[q] = a.inv_s[q];
+
+  for (int j0 = jbeg; j0 < jend; j0 += JC) {
+    const int jc = min(JC, jend - j0);
+    DUST_STAMP(a.stamps, 1);
+    // ---- key chunk -> LDS: rows j0..j0+jc-1 are contiguous in HBM ----
+    load_rows<JC, DP, YS, NT>(a.Y, j0, jc, D, a.magicD, Ys);
+    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT>(a.V, j0, jc, D, a.magicD, Vs);
+    __syncthreads();
+    DUST_STAMP(a.stamps, 2);
+    // ---- pass A: lane = key j, QPG queries per lane, 4 independent accumulators per query ----
+    {
+      const int j = tid & (JC - 1), ig = tid / JC;
+      const float lm = (MODE == PAIR_PRIOR && j < jc) ? a.logmix[j0 + j] : 0.f;
+      float d2[QPG];
+#pragma unroll
+      for (int ii = 0; ii < QPG; ++ii) d2[ii] = 0.f;
+#pragma unroll
+      for (int d = 0; d < DP; d += 4) {
+        const float4 yv = *reinterpret_cast<const float4 *>(&Ys[j * YS + d]);
+        const float s0 = isc[d % da], s1 = isc[(d + 1) % da], s2 = isc[(d + 2) % da], s3 = isc[(d + 3) % da];
+#pragma unroll
+        for (int ii = 0; ii < QPG; ++ii) {
+          const float4 xv = *reinterpret_cast<const float4 *>(&Xs[(ig * QPG + ii) * DP + d]);  // wave-uniform: LDS broadcast
+          const float z0 = (xv.x - yv.x) * s0, z1 = (xv.y - yv.y) * s1, z2 = (xv.z - yv.z) * s2, z3 = (xv.w - yv.w) * s3;
+          d2[ii] = fmaf(z0, z0, d2[ii]);
+          d2[ii] = fmaf(z1, z1, d2[ii]);
+          d2[ii] = fmaf(z2, z2, d2[ii]);
+          d2[ii] = fmaf(z3, z3, d2[ii]);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < QPG; ++ii) {
+        float v;
+        if (MODE == PAIR_PRIOR) v = (j < jc) ? lm - 0.5f * d2[ii] : -INFINITY;
+        else if (MODE == PAIR_K1) v = (j < jc) ? expf(-0.5f * d2[ii]) : 0.f;
+        else v = (j < jc) ? d2[ii] : INFINITY;  // IMQ: k and k' are formed in pass B (inf -> k = 0)
+        kv[(ig * QPG + ii) * (JC + 1) + j] = v;
+      }
+    }
+    __syncthreads();
+    if (MODE == PAIR_PRIOR) {
+      // online softmax over key chunks: row max (8 lanes per query), rescale, exponentiate in place
+      float m = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < JC / 8; ++q) m = fmaxf(m, kv[iB * (JC + 1) + (tid & 7) + 8 * q]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      m = fmaxf(m, __shfl_xor(m, 4, 64));
+      const float mo = mrow[iB];
+      const float mn = fmaxf(mo, m);
+      const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) accA[c] *= sc;
+      accL *= sc;
+      __syncthreads();
+      if ((tid & 7) == 0) mrow[iB] = mn;
+#pragma unroll
+      for (int q = 0; q < JC / 8; ++q) {
+        const int jj = (tid & 7) + 8 * q;
+        const float l = kv[iB * (JC + 1) + jj];
+        kv[iB * (JC + 1) + jj] = (mn == -INFINITY) ? 0.f : expf(l - mn);
+      }
+      __syncthreads();
+    }
+    DUST_STAMP(a.stamps, 3);
+    // ---- pass B: lane = (query, 8 column groups) ----
+#pragma unroll 8
+    for (int jj = 0; jj < JC; ++jj) {
+      const float kq = kv[iB * (JC + 1) + jj];
+      float k = kq, kp = 0.f;
+      if (MODE == PAIR_K1) kp = -kq;  // d k / d x_i = -k (x_i - x_j) / ell^2
+      if (MODE == PAIR_IMQ) {
+        const float base = 1.0f + kq;
+        k = rsqrtf(base);  // inf -> 0
+        kp = (kq == INFINITY) ? 0.f : -k / base;
+      }
+#pragma unroll
+      for (int c = 0; c < CPT; c += 4) {
+        const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jj * YS + cB + c]);
+        if (MODE == PAIR_PRIOR) {
+          accA[c] = fmaf(k, yv.x - xB[c], accA[c]);
+          accA[c + 1] = fmaf(k, yv.y - xB[c + 1], accA[c + 1]);
+          accA[c + 2] = fmaf(k, yv.z - xB[c + 2], accA[c + 2]);
+          accA[c + 3] = fmaf(k, yv.w - xB[c + 3], accA[c + 3]);
+        } else {
+          const float4 sv = *reinterpret_cast<const float4 *>(&Vs[jj * YS + cB + c]);
+          accA[c] = fmaf(k, sv.x, accA[c]);
+          accA[c + 1] = fmaf(k, sv.y, accA[c + 1]);
+          accA[c + 2] = fmaf(k, sv.z, accA[c + 2]);
+          accA[c + 3] = fmaf(k, sv.w, accA[c + 3]);
+          accB[c] = fmaf(kp, xB[c] - yv.x, accB[c]);
+          accB[c + 1] = fmaf(kp, xB[c + 1] - yv.y, accB[c + 1]);
+          accB[c + 2] = fmaf(kp, xB[c + 2] - yv.z, accB[c + 2]);
+          accB[c + 3] = fmaf(kp, xB[c + 3] - yv.w, accB[c + 3]);
+        }
+      }
+      if (MODE == PAIR_PRIOR) accL += k;
+    }
+    __syncthreads();
+  }
+
+  DUST_STAMP(a.stamps, 4);
+  // ---- partial outputs ----
+  const int il = blockIdx.x * TI + iB;  // local row
+  if (il < a.n_local) {
+    const size_t row = ((size_t)js * a.n_local + il) * D;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+      if (cB + c < D) {
+        a.pA[row + cB + c] = accA[c];
+        if (MODE != PAIR_PRIOR) a.pB[row + cB + c] = accB[c];
+      }
+    if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
+      a.pM[(size_t)js * a.n_local + il] = mrow[iB];
+      a.pL[(size_t)js * a.n_local + il] = accL;
+    }
+  }
+  DUST_STAMP(a.stamps, 5);
+}
+
+static inline size_t pairwise_lds_bytes(int mode, int CPT) {
+  const int DP = 8 * CPT;
+  return sizeof(float) * ((size_t)PAIR_TI * DP + (size_t)(mode == PAIR_PRIOR ? 1 : 2) * PAIR_JC * (DP + 4) + (size_t)PAIR_TI * (PAIR_JC + 1) + PAIR_TI);
+}
+
+// Combine the JS slice partials of the prior pass for one row (fixed order -> reproducible): returns grad_pri[d] for the
+// columns the caller owns and log p(x_i).  Used by rollout_kernel (score) and logp_merge_kernel (forward).
+struct PriorMerge {
+  int JS, n_local;
+  const float *pA, *pM, *pL;
+  float inv_s2[4];
+  float log_norm;  // -H sum(log sigma_p) - D/2 log(2 pi)
+};
+__device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, float *m_out, float *l_out) {
+  float m = -INFINITY;
+  for (int q = 0; q < pm.JS; ++q) m = fmaxf(m, pm.pM[(size_t)q * pm.n_local + il]);
+  float l = 0.f;
+  for (int q = 0; q < pm.JS; ++q) {
+    const float mq = pm.pM[(size_t)q * pm.n_local + il];
+    l += (mq == -INFINITY) ? 0.f : pm.pL[(size_t)q * pm.n_local + il] * expf(mq - m);
+  }
+  *m_out = m;
+  *l_out = l;
+}
+__device__ __forceinline__ float prior_merge_col(const PriorMerge &pm, int il, int D, int d, int da, float m, float l) {
+  float acc = 0.f;
+  for (int q = 0; q < pm.JS; ++q) {
+    const float mq = pm.pM[(size_t)q * pm.n_local + il];
+    if (mq != -INFINITY) acc = fmaf(pm.pA[((size_t)q * pm.n_local + il) * D + d], expf(mq - m), acc);
+  }
+  return (acc / l) * pm.inv_s2[d % da];
+}
+
+// score = grad_lik + grad_pri and/or log p, when no rollout kernel follows the prior pass (stage-wise API, forward)
+struct PriorFinishArgs {
+  PriorMerge pm;
+  int D, da, i0, n_local;
+  const float *grad_lik;  // [N][D] or nullptr
+  float *grad_pri;        // [N][D] or nullptr
+  float *score;           // [N][D] or nullptr
+  float *logp;            // [N] or nullptr
+};
+__global__ void prior_finish_kernel(const PriorFinishArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_local * a.D) return;
+  const int il = idx / a.D, d = idx - il * a.D;
+  float m, l;
+  prior_merge_row(a.pm, il, &m, &l);
+  const size_t o = (size_t)(a.i0 + il) * a.D + d;
+  if (a.grad_pri || a.score) {
+    const float gp = prior_merge_col(a.pm, il, a.D, d, a.da, m, l);
+    if (a.grad_pri) a.grad_pri[o] = gp;
+    if (a.score) a.score[o] = a.grad_lik[o] + gp;
+  }
+  if (a.logp && d == 0) a.logp[a.i0 + il] = (m + logf(l)) + a.pm.log_norm;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Optimiser update (svmpc.py:87-95: theta.grad = -phi; optimizer.step()).  Writes the row-major and the transposed copy.
+// Stein partial combine + optimiser update (svmpc.py:83 phi = grad_k + K score / N ; svmpc.py:87-95 theta.grad = -phi;
+// optimizer.step()).  Writes phi, theta in place (row-major) - each element is touched by exactly one lane.
 struct UpdateArgs {
-  int N, D, i0, n_local;
-  int optimizer;
+  int N, D, i0, n_local, JS;
+  int optimizer, apply;  // apply = 0: only materialise phi (stage-wise SVMPC.phi)
   float lr, beta1, beta2, eps;
+  float inv_l2, inv_n;
   int step;  // Adam step count (1-based)
-  const float *phi;
-  float *theta;   // [N][D] in place (each element touched by exactly one thread)
-  float *thetaT;  // [D][N]
+  const float *pA, *pB;  // [JS][n_local][D]
+  float *phi;     // [N][D]
+  float *theta;   // [N][D]
   float *adam_m, *adam_v;
 };
 
@@ -204,10 +302,18 @@ __global__ void update_kernel(const UpdateArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.n_local * a.D) return;
   const int il = idx / a.D, d = idx - il * a.D;
-  const int i = a.i0 + il;
-  const size_t o = (size_t)i * a.D + d;
+  const size_t o = (size_t)(a.i0 + il) * a.D + d;
+  float sa = 0.f, sb = 0.f;
+  for (int q = 0; q < a.JS; ++q) {
+    const size_t p = ((size_t)q * a.n_local + il) * a.D + d;
+    sa += a.pA[p];
+    sb += a.pB[p];
+  }
+  const float phi = sb * a.inv_l2 + sa * a.inv_n;
+  a.phi[o] = phi;
+  if (!a.apply) return;
   float th = a.theta[o];
-  const float g = -a.phi[o];
+  const float g = -phi;
   if (a.optimizer == DUST_OPT_SGD) {
     th = fmaf(-a.lr, g, th);  // torch SGD: p.add_(grad, alpha=-lr), a vectorised fmadd
   } else {  // torch.optim.Adam (no weight decay, no amsgrad)
@@ -221,10 +327,32 @@ __global__ void update_kernel(const UpdateArgs a) {
     th = th - (a.lr / bc1) * (m / denom);
   }
   a.theta[o] = th;
-  a.thetaT[(size_t)d * a.N + i] = th;
 }
 
-// row-major [N][D] -> transposed [D][N]
+// optimiser update from an already materialised phi (K2 branch, which writes phi directly)
+__global__ void update_from_phi_kernel(const UpdateArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_local * a.D) return;
+  const int il = idx / a.D, d = idx - il * a.D;
+  const size_t o = (size_t)(a.i0 + il) * a.D + d;
+  float th = a.theta[o];
+  const float g = -a.phi[o];
+  if (a.optimizer == DUST_OPT_SGD) {
+    th = fmaf(-a.lr, g, th);
+  } else {
+    float m = a.adam_m[o], v = a.adam_v[o];
+    m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
+    v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+    a.adam_m[o] = m;
+    a.adam_v[o] = v;
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step), bc2 = 1.f - powf(a.beta2, (float)a.step);
+    const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
+    th = th - (a.lr / bc1) * (m / denom);
+  }
+  a.theta[o] = th;
+}
+
+// row-major [N][D] -> transposed [D][N] (K2's per-dimension kernels read the transposed copy)
 __global__ void transpose_kernel(const float *src, float *dst, int N, int D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * D) return;
@@ -232,7 +360,7 @@ __global__ void transpose_kernel(const float *src, float *dst, int N, int D) {
   dst[(size_t)d * N + i] = src[idx];
 }
 
-// [N][S] -> [S][N] (and back) for the host-facing cost / weight layouts
+// [R][C] -> [C][R] for the host-facing cost / weight layouts
 __global__ void transpose2_kernel(const float *src, float *dst, int R, int C) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * C) return;

@@ -50,7 +50,12 @@ def test_rollout_costs_vs_reference(golden, name):
             assert np.array_equal(actions, g["actions"][t, k]), "a1 must be bit-exact"
             assert relerr(costs, g["costs"][t, k]) < TOL, (name, t, k)
             assert relerr(c.get_a_mat(), g["omega_amat"][t, k]) < 1e-4  # omega = softmax of O(1e3) logits (see module doc)
-            assert relerr(c.get_a_mix(), g["a_mix"][t, k], floor=1e-30) < 2e-3
+            # a_mix = softmax_n(logsumexp_s(-c/temp)): one fp32 ulp of a cost moves a logit by ulp(c)/temp, so the check is
+            # meaningful only while that is small (Particle costs are O(1e7): ulp = 2-4, i.e. factors of e^2 in the
+            # reference's own result)
+            ulp_logit = float(np.spacing(np.float32(np.abs(g["costs"][t, k]).max()))) / float(g["temperature"])
+            if ulp_logit < 1e-3:
+                assert relerr(c.get_a_mix(), g["a_mix"][t, k], floor=1e-30) < 2e-3
             if k == 0:
                 _, states, _, _ = c.disco_forward(g["state"][t, k], g["actions"][t, k], params, want_states=True)
                 assert relerr(states, g["states_iter0"][t]) < TOL
@@ -103,7 +108,7 @@ def test_tick_chain_vs_oracle_and_reference(golden, name):
         if srt[-1] > 1.5 * srt[-2]:
             assert int(np.argmax(pw)) == int(np.argmax(ref_pw))
             assert np.abs(a_seq - g["tick_a_seq"][t]).max() / scale < 2e-3
-        assert abs(float(pw.sum()) - 1.0) < 1e-5
+        assert abs(float(pw.sum()) - 1.0) < 5e-4  # log-weights are O(1e3): one fp32 ulp there is 1e-4 relative on a weight
         # re-synchronise with the reference before the next tick so the comparison stays stage-local
         c.set_theta(g["tick_theta_rolled"][t])
 
@@ -120,7 +125,9 @@ def test_forward_vs_reference(golden, name):
         # put the device in the state the reference was in before forward(): theta, prior, last costs
         c.set_theta(g["theta0"] if K == 1 and t == 0 else (g["theta_after"][t, K - 2] if K > 1 else g["tick_theta_rolled"][t - 1]))
         params = g["params"][t, K - 1] if "params" in g else None
-        c.set_a_mat(g["a_mat0"])
+        # a_mat as it stood before the last iteration (it enters the costs when ctrl_penalty != 1)
+        a_prev = g["omega_amat"][t, K - 2] if K > 1 else (g["a_mat0"] if t == 0 else g["omega_amat"][t - 1, K - 1])
+        c.set_a_mat(a_prev)
         c.likelihood_sample(g["state"][t, K - 1], g["eps"][t, K - 1], params)
         c.set_theta(th)
         c.set_prior(mu, mix)
