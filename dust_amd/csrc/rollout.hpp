@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
       float v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight per lane
-        const int idx = base + u * nt + tid;
+        // clamp instead of predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
+        const int idx = min(base + u * nt + tid, total - 1);
         const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-        v[u] = idx < total ? a.noise[((size_t)s * N + n) * D + j] : 0.f;
+        v[u] = a.noise[((size_t)s * N + n) * D + j];
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -291,9 +292,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
     for (int u = 0; u < 16; ++u) {
       const bool ok = u < JS;
       const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + blockIdx.x;
-      pmM[u] = ok ? a.pm.pM[rowi] : -INFINITY;
-      pmL[u] = ok ? a.pm.pL[rowi] : 0.f;
-      pmA[u] = ok ? a.pm.pA[rowi * D + tid] : 0.f;
+      const float tm = a.pm.pM[rowi], tl = a.pm.pL[rowi], ta = a.pm.pA[rowi * D + tid];  // unconditional loads
+      pmM[u] = ok ? tm : -INFINITY;
+      pmL[u] = ok ? tl : 0.f;
+      pmA[u] = ok ? ta : 0.f;
     }
   }
   if (q < Q) {

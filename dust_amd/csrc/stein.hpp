@@ -53,12 +53,13 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0,
   __syncthreads();
   const int total = nrows * D;
   const float *base = src + (size_t)r0 * D;
-  for (int b = 0; b < total; b += 8 * NT) {
+  for (int b = 0; b < total; b += 8 * NT) {  // total >= 1: every workgroup owns at least one row
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int idx = b + u * NT + tid;
-      v[u] = idx < total ? base[idx] : 0.f;
+      // clamp, do not predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
+      const int idx = min(b + u * NT + tid, total - 1);
+      v[u] = base[idx];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

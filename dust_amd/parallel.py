@@ -3,13 +3,17 @@
 The policy index n is data-parallel: rank g owns N/G Stein particles with all their S*M rollouts,
 costs, softmax weights, likelihood score, a_mat rows, optimiser update and roll - no communication.  The pairwise stages
 need every particle, so per SVGD iteration the ranks all-gather, IN PLACE in the context-owned [N][D] buffers,
-  (1) theta  (after the optimiser update; the prior means alias theta from the second tick on, so the prior pass needs it),
-  (2) score  (after the local score, before the Gram / phi kernel - the exchange BASELINE.json's north_star names),
-and once per tick the N log-weights.  xGMI is a point-to-point mesh and these messages are a few hundred KB at most, so
-the collectives are latency-bound; they are issued on the context's stream so no host synchronisation is needed.
+  (1) score  (after the local score, before the Gram / phi kernel - the exchange BASELINE.json's north_star names),
+  (2) theta  (after the optimiser update: from the second tick on the prior means alias theta, so the next prior pass and
+              the next Gram pass both need every shard's new particles),
+and once per tick the N log-weights (then the rolled theta).  xGMI is a point-to-point mesh and these messages are a few
+hundred KB at most, so the collectives are latency-bound; they are issued on the stream the kernels run on, so no host
+synchronisation is needed between kernels and collectives.
 
-`backend` is anything with the small collective interface below (torch.distributed for RCCL/gloo); the device pointers
-are wrapped as torch tensors through __cuda_array_interface__ without copying.
+Structure: a *shard* object (DeviceShard for the HIP library; tests inject a CPU stand-in) exposes the four local phases
+and its three gather buffers as torch tensors; `tick()` is the fixed phase/collective order; `comm` performs the in-place
+all-gather (TorchComm over torch.distributed - RCCL on GPUs, gloo in the CPU tests - or LocalComm, which runs several
+shards inside one process by copying slices, used to check sharded == unsharded on a single GPU).
 """
 import ctypes as C
 
@@ -26,67 +30,149 @@ class _DevBuf:
 
 def shard_bounds(n_total, rank, world):
     """Contiguous equal shards of the particle index (N must divide evenly, as the in-place all-gather requires)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank %d of %d" % (rank, world))
     if n_total % world:
         raise ValueError("n_particles (%d) must be divisible by the number of GPUs (%d)" % (n_total, world))
     n_loc = n_total // world
     return rank * n_loc, n_loc
 
 
-class ShardedSVMPC:
-    def __init__(self, common_cfg, rank, world, dist):
+class DeviceShard:
+    """One rank's slice of the problem on one GPU: a sharded dust_ctx plus torch views of its gather buffers."""
+
+    def __init__(self, common_cfg, rank, world, device_index=None, use_torch_stream=True):
         import torch
 
-        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.torch = torch
         off, n_loc = shard_bounds(common_cfg["N"], rank, world)
-        self.off, self.n_loc = off, n_loc
-        self.ctx = Context(**dict(common_cfg, shard_offset=off, shard_size=n_loc))
+        self.rank, self.world, self.off, self.n_loc = rank, world, off, n_loc
+        cfg = dict(common_cfg, shard_offset=off, shard_size=n_loc)
+        if device_index is not None:
+            cfg["device"] = device_index
+        self.ctx = Context(**cfg)
         lib = L.load()
-        L.check(lib.dust_set_stream(self.ctx._h, L.VP(torch.cuda.current_stream().cuda_stream)))
+        dev = torch.device("cuda", cfg.get("device", 0))
+        if use_torch_stream:
+            with torch.cuda.device(dev):
+                L.check(lib.dust_set_stream(self.ctx._h, L.VP(torch.cuda.current_stream().cuda_stream)))
         th, sc, nb = L.VP(), L.VP(), C.c_size_t(0)
         L.check(lib.dust_gather_buffers(self.ctx._h, C.byref(th), C.byref(sc), C.byref(nb)))
         nd = self.ctx.N * self.ctx.D
-        dev = torch.device("cuda", torch.cuda.current_device())
         self.theta_all = torch.as_tensor(_DevBuf(th.value, nd), device=dev)
         self.score_all = torch.as_tensor(_DevBuf(sc.value, nd), device=dev)
-        lw, nb2 = L.VP(), C.c_size_t(0)
+        self.lw_all = None
         self._lw_ptr = None
-        self._shard = n_loc * self.ctx.D
+        self.shard_elems = n_loc * self.ctx.D
+        self.N, self.D = self.ctx.N, self.ctx.D
 
-    def _gather(self, full, shard_elems):
-        lo = self.rank * shard_elems
-        self.dist.all_gather_into_tensor(full, full[lo:lo + shard_elems])
-
-    def set_state(self, theta, mu, a_mat=None):
+    def set_state(self, theta, mu, a_mat=None, mix=None):
         self.ctx.set_theta(theta)
-        self.ctx.set_prior(mu)
+        self.ctx.set_prior(mu, mix)
         self.ctx.set_a_mat(theta if a_mat is None else a_mat)
 
-    def tick(self, state, n_iters, eps=None):
-        lib, h = L.load(), self.ctx._h
+    # -- the four local phases (each only enqueues kernels)
+    def local_score(self, state, eps=None, params=None):
+        lib = L.load()
         st = np.ascontiguousarray(np.asarray(state, np.float32).reshape(-1))
-        stp = st.ctypes.data_as(L.FP)
-        for k in range(n_iters):
-            e = None
-            if eps is not None:
-                ek = np.ascontiguousarray(eps[k], dtype=np.float32)
-                e = C.cast(ek.ctypes.data_as(L.FP), L.VP)
-            L.check(lib.dust_svmpc_local_score(h, stp, e, None, 0))
-            self._gather(self.score_all, self._shard)
-            L.check(lib.dust_svmpc_apply_phi(h))
-            self._gather(self.theta_all, self._shard)
+        e = None
+        if eps is not None:
+            ek = np.ascontiguousarray(eps, dtype=np.float32)
+            e = C.cast(ek.ctypes.data_as(L.FP), L.VP)
+        p = None
+        if params is not None:
+            pk = np.ascontiguousarray(params, dtype=np.float32)
+            p = pk.ctypes.data_as(L.FP)
+        L.check(lib.dust_svmpc_local_score(self.ctx._h, st.ctypes.data_as(L.FP), e, p, 0))
+
+    def apply_phi(self):
+        L.check(L.load().dust_svmpc_apply_phi(self.ctx._h))
+
+    def forward_local(self):
         lw, nb = L.VP(), C.c_size_t(0)
-        L.check(lib.dust_svmpc_forward_local(h, C.byref(lw), C.byref(nb)))
+        L.check(L.load().dust_svmpc_forward_local(self.ctx._h, C.byref(lw), C.byref(nb)))
         if self._lw_ptr != lw.value:
             self._lw_ptr = lw.value
             self.lw_all = self.torch.as_tensor(_DevBuf(lw.value, self.ctx.N), device=self.theta_all.device)
-        self._gather(self.lw_all, self.n_loc)
-        L.check(lib.dust_svmpc_forward_finish(h, None, None))
-        self._gather(self.theta_all, self._shard)  # rolled rows of the other shards
 
-    def outputs(self):
+    def forward_finish(self, want_outputs=False):
+        if not want_outputs:
+            L.check(L.load().dust_svmpc_forward_finish(self.ctx._h, None, None))
+            return None, None
         a_seq = np.empty((self.ctx.H, self.ctx.da), np.float32)
         pw = np.empty(self.ctx.N, np.float32)
+        L.check(L.load().dust_svmpc_forward_finish(self.ctx._h, a_seq.ctypes.data_as(L.FP), pw.ctypes.data_as(L.FP)))
         return a_seq, pw
 
     def sync(self):
-        self.torch.cuda.current_stream().synchronize()
+        self.ctx.sync()
+        self.torch.cuda.synchronize(self.theta_all.device)
+
+
+class TorchComm:
+    """In-place all-gather over torch.distributed ("nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
+
+    def __init__(self, dist, rank):
+        self.dist, self.rank = dist, rank
+
+    def all_gather_inplace(self, shards, name, shard_elems):
+        (sh,) = shards
+        full = getattr(sh, name)
+        lo = self.rank * shard_elems
+        if full.is_cuda:
+            self.dist.all_gather_into_tensor(full, full[lo:lo + shard_elems])
+        else:  # gloo has no all_gather_into_tensor for a view of the output: gather to a list of views
+            world = self.dist.get_world_size()
+            parts = [full[r * shard_elems:(r + 1) * shard_elems] for r in range(world)]
+            self.dist.all_gather(parts, full[lo:lo + shard_elems].clone())
+
+
+class LocalComm:
+    """Several shards inside ONE process: the all-gather is a set of slice copies (single-GPU equivalence tests)."""
+
+    def all_gather_inplace(self, shards, name, shard_elems):
+        for src in shards:
+            lo = src.rank * shard_elems
+            piece = getattr(src, name)[lo:lo + shard_elems]
+            for dst in shards:
+                if dst is not src:
+                    getattr(dst, name)[lo:lo + shard_elems].copy_(piece)
+
+
+def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False):
+    """One control tick = n_iters SVGD iterations + forward, for the shard(s) this process drives.
+
+    `shards` is a 1-tuple under torch.distributed (one rank per process) or all shards under LocalComm.
+    eps[k] / params[k] are the per-iteration noise [S][N][H][da] / dynamics samples (None: device Philox / no sampling).
+    """
+    for k in range(n_iters):
+        for sh in shards:
+            sh.local_score(state, None if eps is None else eps[k], None if params is None else params[k])
+        comm.all_gather_inplace(shards, "score_all", shards[0].shard_elems)
+        for sh in shards:
+            sh.apply_phi()
+        comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)
+    for sh in shards:
+        sh.forward_local()
+    comm.all_gather_inplace(shards, "lw_all", shards[0].n_loc)
+    outs = [sh.forward_finish(want_outputs) for sh in shards]
+    comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)  # rolled rows of the other shards
+    return outs[0]
+
+
+class ShardedSVMPC:
+    """Convenience wrapper: one rank of a torch.distributed job."""
+
+    def __init__(self, common_cfg, rank, world, dist):
+        self.shard = DeviceShard(common_cfg, rank, world, device_index=common_cfg.get("device", 0))
+        self.comm = TorchComm(dist, rank)
+        self.ctx = self.shard.ctx
+
+    def set_state(self, theta, mu, a_mat=None):
+        self.shard.set_state(theta, mu, a_mat)
+
+    def tick(self, state, n_iters, eps=None, want_outputs=False):
+        return tick((self.shard,), self.comm, state, n_iters, eps, None, want_outputs)
+
+    def sync(self):
+        self.shard.sync()

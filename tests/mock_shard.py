@@ -1,0 +1,74 @@
+"""CPU stand-in for dust_amd.parallel.DeviceShard (TEST INFRASTRUCTURE): same four phases and gather buffers, the
+arithmetic done by the CPU oracle.  Lets the N>1 orchestration (phase order, in-place all-gathers, shard bounds) run under
+gloo with world_size 2 in a container that has no GPU."""
+import numpy as np
+import torch
+
+import oracle
+from dust_amd.parallel import shard_bounds
+from oracle import Oracle
+
+
+class MockShard:
+    def __init__(self, cfg, rank, world):
+        self.cfg, self.rank, self.world = cfg, rank, world
+        self.N, self.S, self.H = cfg["N"], cfg["S"], cfg["H"]
+        self.off, self.n_loc = shard_bounds(self.N, rank, world)
+        self.o = Oracle(model="pendulum", N=self.N, S=self.S, M=1, H=self.H)
+        self.D = self.H
+        self.shard_elems = self.n_loc * self.D
+        self.theta_all = torch.zeros(self.N * self.D)
+        self.score_all = torch.zeros(self.N * self.D)
+        self.lw_all = torch.zeros(self.N)
+        self.sig = np.array([cfg["sigma_a"]], np.float32)
+        self.sp = np.array([cfg["sigma_p"]], np.float32)
+        self.aliased = False
+        self.a_seq = None
+        self.pw = None
+
+    def _rows(self, full):
+        return full[self.off * self.D:(self.off + self.n_loc) * self.D]
+
+    def set_state(self, theta, mu, a_mat=None, mix=None):
+        self.theta_all[:] = torch.from_numpy(np.asarray(theta, np.float32).reshape(-1))
+        self.mu = np.asarray(mu, np.float32).reshape(self.N, self.H, 1).copy()
+        self.mix = np.ones(self.N, np.float32)
+
+    def _theta(self):
+        return self.theta_all.numpy().reshape(self.N, self.H, 1)
+
+    def local_score(self, state, eps=None, params=None):
+        th = self._theta()
+        mu = th if self.aliased else self.mu
+        actions = self.o.sample_actions(th, eps, self.sig)
+        self.costs = self.o.rollout_cost(state, actions)
+        _, _, sc = self.o.score(th, mu, self.mix, self.sp, self.costs, actions, self.cfg["alpha"], self.sig)
+        self._rows(self.score_all)[:] = torch.from_numpy(sc.reshape(-1))[self.off * self.D:(self.off + self.n_loc) * self.D]
+
+    def apply_phi(self):
+        th = self._theta()
+        phi = self.o.phi_k1(th, self.score_all.numpy().reshape(self.N, self.H, 1))
+        new = Oracle.sgd(th, phi, self.cfg["lr"]).reshape(-1)
+        self._rows(self.theta_all)[:] = torch.from_numpy(new)[self.off * self.D:(self.off + self.n_loc) * self.D]
+
+    def forward_local(self):
+        th = self._theta()
+        mu = th if self.aliased else self.mu
+        r = self.o.forward(self.costs, th, mu, self.mix, self.sp, self.cfg["alpha"])
+        lw = r["log_l"] + r["log_p"]
+        self.lw_all[self.off:self.off + self.n_loc] = torch.from_numpy(lw[self.off:self.off + self.n_loc])
+
+    def forward_finish(self, want_outputs=False):
+        lw = self.lw_all.numpy().astype(np.float64)
+        p = np.exp(lw - lw.max())
+        p /= p.sum()
+        th = self._theta().copy()
+        best = int(np.argmax(p))
+        a_seq = th[best].copy()
+        rolled = np.concatenate([th[:, 1:], th[:, -1:]], axis=1).reshape(-1)
+        self._rows(self.theta_all)[:] = torch.from_numpy(rolled)[self.off * self.D:(self.off + self.n_loc) * self.D]
+        self.aliased = True
+        return (a_seq, p.astype(np.float32)) if want_outputs else (None, None)
+
+    def sync(self):
+        pass

@@ -267,3 +267,30 @@ def test_seeded_vs_oracle(model, N, S, M, H):
         assert relerr(phi, ref_phi) < TOL, kernel
         if kernel == "K2":
             assert relerr(c.get_bandwidths(), o.phi_k2(theta, sc)[1]) < TOL
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_equals_unsharded(golden, world):
+    """Particle sharding (the multi-GPU path) on ONE GPU: `world` sharded contexts in one process, the RCCL all-gathers
+    replaced by slice copies (LocalComm).  Every shard must end with the same particles as the unsharded context."""
+    from dust_amd import Context
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    g = golden("pend_k1")
+    kw = ctx_kwargs(g)
+    T, K = g["eps"].shape[:2]
+    ref = Context(**kw)
+    ref.set_theta(g["theta0"]); ref.set_prior(g["mu0"]); ref.set_a_mat(g["a_mat0"])
+    shards = tuple(DeviceShard(kw, r, world) for r in range(world))
+    for s in shards:
+        s.set_state(g["theta0"], g["mu0"], g["a_mat0"])
+    for t in range(T):
+        ref.svmpc_optimize(g["state"][t, 0], K, g["eps"][t])
+        ra, rp = ref.svmpc_forward()
+        a_seq, pw = tick(shards, LocalComm(), g["state"][t, 0], K, g["eps"][t], None, want_outputs=True)
+        for s in shards:
+            s.sync()
+        rt = ref.get_theta()
+        for s in shards:
+            assert relerr(s.ctx.get_theta(), rt) < 1e-6, (world, t, s.rank)
+        assert relerr(pw, rp) < 1e-5 and np.array_equal(a_seq, ra)

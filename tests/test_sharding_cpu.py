@@ -1,0 +1,96 @@
+"""N>1 path on CPU: shard bounds, and the sharded tick (dust_amd.parallel.tick) under gloo with world_size 2, with the
+oracle-backed MockShard standing in for the GPU shard.  The sharded result must equal the unsharded one."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dust_amd.parallel import LocalComm, TorchComm, shard_bounds, tick
+
+CFG = dict(N=8, S=6, H=5, sigma_a=2.0, sigma_p=2.0, alpha=1.0, lr=0.5)
+
+
+def _inputs():
+    rng = np.random.default_rng(3)
+    mu = rng.standard_normal((CFG["N"], CFG["H"], 1)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal(mu.shape)).astype(np.float32)
+    eps = rng.standard_normal((2, 2, CFG["S"], CFG["N"], CFG["H"], 1)).astype(np.float32)
+    return mu, theta, eps, np.array([3.0, 0.0], np.float32)
+
+
+def test_shard_bounds():
+    assert shard_bounds(1024, 0, 8) == (0, 128)
+    assert shard_bounds(1024, 7, 8) == (896, 128)
+    assert sorted(sum(([o + i for i in range(n)] for o, n in (shard_bounds(64, r, 4) for r in range(4))), [])) == list(range(64))
+    with pytest.raises(ValueError):
+        shard_bounds(10, 0, 4)
+    with pytest.raises(ValueError):
+        shard_bounds(8, 4, 4)
+
+
+def _run_unsharded():
+    from mock_shard import MockShard
+
+    mu, theta, eps, state = _inputs()
+    sh = MockShard(CFG, 0, 1)
+    sh.set_state(theta, mu)
+    outs = []
+    for t in range(2):
+        outs.append(tick((sh,), LocalComm(), state, 2, eps[t], None, want_outputs=True))
+    return sh.theta_all.numpy().copy(), outs
+
+
+def test_local_comm_two_shards_equal_unsharded():
+    from mock_shard import MockShard
+
+    mu, theta, eps, state = _inputs()
+    ref_theta, ref_outs = _run_unsharded()
+    shards = tuple(MockShard(CFG, r, 2) for r in range(2))
+    for s in shards:
+        s.set_state(theta, mu)
+    for t in range(2):
+        a_seq, pw = tick(shards, LocalComm(), state, 2, eps[t], None, want_outputs=True)
+        assert np.allclose(a_seq, ref_outs[t][0], atol=1e-6) and np.allclose(pw, ref_outs[t][1], atol=1e-6)
+    for s in shards:
+        assert np.allclose(s.theta_all.numpy(), ref_theta, atol=1e-6)
+
+
+def _worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mock_shard import MockShard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mu, theta, eps, state = _inputs()
+    sh = MockShard(CFG, rank, world)
+    sh.set_state(theta, mu)
+    comm = TorchComm(dist, rank)
+    outs = []
+    for t in range(2):
+        outs.append(tick((sh,), comm, state, 2, eps[t], None, want_outputs=True))
+    q.put((rank, sh.theta_all.numpy().copy(), outs[-1][1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_equals_unsharded():
+    ref_theta, ref_outs = _run_unsharded()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, theta, pw in got:
+        assert np.allclose(theta, ref_theta, atol=1e-6), rank
+        assert np.allclose(pw, ref_outs[-1][1], atol=1e-6), rank
