@@ -1,0 +1,146 @@
+"""The reference's class API (MultiDISCO / SVMPC / likelihoods / MPF / get_gmm) on top of the C ABI, replaying golden
+scenarios through the SAME call sequence the reference's simulation loop uses (simulations.py:104-138)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import relerr
+from test_host_mirror_cpu import PARTICLE_ENV
+from test_oracle_golden import k1_tolerance
+
+pytestmark = pytest.mark.gpu
+
+
+def inst_cost(states, controls=None, n_pol=1, debug=None):  # the demo's own, un-tagged cost functions
+    theta, theta_d = states.chunk(2, dim=1)
+    return 50.0 * (theta.cos() - 1) ** 2 + 1.0 * theta_d ** 2
+
+
+def term_cost(states, n_pol=1, debug=None):
+    return inst_cost(states).squeeze()
+
+
+def build_pendulum(g, kernel):
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import SVMPC, ExponentiatedUtility, get_gmm
+    from dust_amd.models import PendulumModel
+
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    model = PendulumModel()
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=float(g["temperature"]),
+                      a_cov=float(g["sigma_a"]) ** 2 * torch.eye(1), inst_cost_fn=inst_cost, term_cost_fn=term_cost, params_sampling=None)
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), float(g["sigma_p"]) ** 2 * torch.eye(1))
+    lik = ExponentiatedUtility(alpha=float(g["alpha"]), n_samples=S, controller=ctrl, model=model)
+    sv = SVMPC(init_particles=torch.tensor(g["theta0"]), prior=prior, likelihood=lik, kernel=kernel, n_particles=N, bw_scale=1.0,
+               n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]))
+    return model, ctrl, lik, sv
+
+
+@pytest.mark.parametrize("name,kernel_name", [("pend_k1", "rbf"), ("pend_k2", "message_passing")])
+def test_simulation_loop_call_sequence(golden, name, kernel_name):
+    from dust_amd.kernels import RBF, RBFKernel, iid_mp
+
+    g = golden(name)
+    kernel = RBFKernel() if kernel_name == "rbf" else iid_mp(base_kernel=RBF(bandwidth=-1), ctrl_dim=1, indep_controls=True)
+    model, ctrl, lik, sv = build_pendulum(g, kernel)
+    T, K = g["eps"].shape[:2]
+    for t in range(T):
+        state = torch.tensor(g["state"][t, 0]).unsqueeze(0)
+        sv.optimize(state, None, n_steps=K, eps=g["eps"][t])           # sim_svmpc.optimize(state, dyn_dist)
+        scale = np.abs(g["theta_after"][t, K - 1]).max()
+        assert np.abs(sv.theta.numpy() - g["theta_after"][t, K - 1]).max() / scale < 2e-3
+        a_seq, p_w = sv.forward(state, None)                           # sim_svmpc.forward(state, dyn_dist)
+        assert a_seq.shape == (int(g["H"]), 1) and abs(float(p_w.sum()) - 1) < 5e-4
+        assert int(p_w.argmax()) == int(np.argmax(g["tick_p_weights"][t]))
+        sv.theta = torch.tensor(g["tick_theta_rolled"][t])             # re-sync with the reference (stage-local checks)
+    assert ctrl.a_mat.shape == (int(g["N"]), int(g["H"]), 1)
+
+
+def test_phi_hook_and_likelihood_api(golden):
+    from dust_amd.kernels import RBFKernel
+
+    g = golden("pend_k1")
+    model, ctrl, lik, sv = build_pendulum(g, RBFKernel())
+    state = torch.tensor(g["state"][0, 0])
+    costs, actions = lik.sample(torch.tensor(g["theta0"]), state, None, eps=g["eps"][0, 0])
+    assert np.array_equal(actions.numpy(), g["actions"][0, 0])
+    assert relerr(costs.numpy(), g["costs"][0, 0]) < 1e-5
+    assert relerr(lik.log_prob(costs).numpy(), lik.log_prob(torch.tensor(g["costs"][0, 0])).numpy()) < 1e-5
+
+    def log_p(theta):  # the reference's phi() takes exactly such a callable (svmpc.py:88-90)
+        return None, torch.tensor(g["costs"][0, 0]), torch.tensor(g["actions"][0, 0])
+
+    phi = sv.phi(log_p, None, None)
+    assert relerr(phi.numpy(), g["phi"][0, 0]) < k1_tolerance(g["theta0"])
+
+
+def test_deepcopy_isolates_device_state(golden):
+    from dust_amd.kernels import RBFKernel
+
+    g = golden("pend_k1")
+    model, ctrl, lik, sv = build_pendulum(g, RBFKernel())
+    state = torch.tensor(g["state"][0, 0])
+    sv.optimize(state, None, n_steps=1, eps=g["eps"][0, :1])
+    sv2 = copy.deepcopy(sv)                                            # simulations.py:62,78 / particle_example.py:166-175
+    assert sv2.likelihood.controller is not ctrl and sv2.likelihood.controller._ctx is not ctrl._ctx
+    t_before = sv.theta.clone()
+    sv2.optimize(state, None, n_steps=1, eps=g["eps"][0, 1:2])
+    assert torch.equal(sv.theta, t_before) and not torch.equal(sv2.theta, t_before)
+    sv.optimize(state, None, n_steps=1, eps=g["eps"][0, 1:2])
+    assert torch.equal(sv.theta, sv2.theta)                            # same inputs -> bitwise same result (no atomics)
+
+
+def test_multidisco_forward_and_step(golden):
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.models import PendulumModel
+
+    g = golden("disco_mppi")
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    model = PendulumModel()
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=0.7, ctrl_penalty=0.4, a_cov=1.5 ** 2 * torch.eye(1),
+                      inst_cost_fn=inst_cost, term_cost_fn=term_cost, params_sampling=None)
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    costs, states, actions, omega, plp = ctrl.forward(torch.tensor(g["state"]), model)  # own (Philox) noise
+    assert costs.shape == (S, N) and states.shape == (1, S, N, H + 1, 2) and actions.shape == (1, S, N, H, 1) and plp is None
+    assert torch.allclose(omega.sum(0), torch.ones(N), atol=1e-5)
+    a = ctrl.step(strategy="average")
+    assert a.shape == (1, 1) and float(a.abs().max()) <= 2.0
+    with pytest.raises(ValueError):
+        ctrl.step(strategy="nonsense")
+    with pytest.raises(NotImplementedError):
+        MultiDISCO(model.observation_space, model.action_space, H, N, S, inst_cost_fn=lambda s, c=None, **k: s.sum(1, keepdim=True),
+                   term_cost_fn=term_cost, params_sampling=None).forward(torch.tensor(g["state"]), model)
+
+
+def test_particle_dual_inference_loop(golden):
+    """particle_example.py:150-207 call sequence with MPF coupled in: controller draws its dynamics samples from mpf.prior."""
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import MPF, SVMPC, ExponentiatedUtility, GaussianLikelihood, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import Particle
+
+    torch.manual_seed(0)
+    N, H, S, M = 8, 12, 16, 4
+    model = Particle(**PARTICLE_ENV, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    system = Particle(**PARTICLE_ENV, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=1.0, a_cov=25.0 * torch.eye(2), params_sampling=True,
+                      params_samples=M, params_log_space=True, inst_cost_fn=model.default_inst_cost, term_cost_fn=model.default_term_cost)
+    prior = get_gmm(torch.randn(N, H, 2), torch.ones(N), 25.0 * torch.eye(2))
+    lik = ExponentiatedUtility(1.0, controller=ctrl, model=model, n_samples=S)
+    sv = SVMPC(init_particles=prior.sample([N]), prior=prior, likelihood=lik, kernel=RBFKernel(), n_particles=N, n_steps=1,
+               optimizer_class=torch.optim.SGD, lr=100.0, weighted_prior=True)
+    state = torch.tensor([-9.0, -9.0, 0.0, 0.0])
+    x0 = torch.distributions.Normal(2.0, 0.1).sample([16, 1]).clamp(min=1e-6).log()
+    mpf = MPF(init_particles=x0, likelihood=GaussianLikelihood(state, 0.1, model, log_space=True), optimizer_class=torch.optim.SGD, lr=0.01,
+              bw=0.1, bw_scale=1.0)
+    for step in range(3):
+        sv.optimize(state, mpf.prior)
+        a_seq, _ = sv.forward(state, mpf.prior)
+        action = a_seq[0]
+        state = system.step(state, action)
+        grads, bw = mpf.optimize(action, state, bw=0.5, n_steps=5)
+        assert grads.shape == (5,) and torch.isfinite(grads).all() and torch.isfinite(sv.theta).all()
+    assert mpf.x.shape == (16, 1) and mpf.prior.sample([4]).shape == (4, 1)
