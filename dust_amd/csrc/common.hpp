@@ -264,11 +264,13 @@ __device__ __forceinline__ float block_reduce(float v, float *scratch) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG (Salmon et al. 2011) + Box-Muller.  Used only when the caller supplies no noise.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t out[4]) {
+// Philox4x32 counter RNG (Salmon et al., SC'11) + Box-Muller.  Used only when the caller supplies no noise.
+// 7 rounds: the smallest round count the paper reports as Crush-resistant (10 is its conservative default); the rollout
+// kernel is instruction-issue bound and the integer multiplies are quarter rate, so rounds are not free here.
+template <int ROUNDS>
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -278,20 +280,25 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  philox4x32<10>(c0, c1, c2, c3, k0, k1, out);
+}
 
+// four standard normals from one Philox block.  u in (0,1) from the top 24 bits; radius and angle with the hardware
+// transcendentals (v_log_f32 is log2, v_sin/v_cos take revolutions): sqrt(-2 ln u0) cos(2 pi u1), ... (relative error
+// ~1e-6: statistical noise generation, never compared bitwise).
 __device__ __forceinline__ void philox_normal4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[4]) {
   uint32_t r[4];
-  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  const float k = 2.3283064365386963e-10f;  // 2^-32
-  float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1] + 0.5f) * k;
-  float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3] + 0.5f) * k;
-  u0 = fminf(fmaxf(u0, 1e-12f), 1.0f);
-  u2 = fminf(fmaxf(u2, 1e-12f), 1.0f);
-  float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
-  float sa, ca, sb, cb;
-  __sincosf(6.283185307179586f * u1, &sa, &ca);
-  __sincosf(6.283185307179586f * u3, &sb, &cb);
-  z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
+  philox4x32<7>(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float k = 5.9604644775390625e-08f, h = 2.98023223876953125e-08f;  // 2^-24, 2^-25
+  const float u0 = fmaf((float)(r[0] >> 8), k, h), u1 = fmaf((float)(r[1] >> 8), k, h);
+  const float u2 = fmaf((float)(r[2] >> 8), k, h), u3 = fmaf((float)(r[3] >> 8), k, h);
+  const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));  // -2 ln 2 * log2 u
+  const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  z[0] = ra * __builtin_amdgcn_cosf(u1);
+  z[1] = ra * __builtin_amdgcn_sinf(u1);
+  z[2] = rb * __builtin_amdgcn_cosf(u3);
+  z[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 
 }  // namespace dust

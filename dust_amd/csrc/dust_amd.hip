@@ -62,6 +62,9 @@ struct dust_ctx {
   int N, S, M, H, da, ds, P, D, n0, nloc;
   hipStream_t stream;
   bool own_stream;
+  hipStream_t stream2;  // side stream: the prior pass runs beside the rollout kernel (both only read theta)
+  hipEvent_t ev_fork, ev_join;
+  hipStream_t pair_stream;  // stream the next pairwise launch goes to (stream or stream2)
   // particles / prior / controller state
   float *theta, *thetaT, *mu, *muT, *logmix, *mixw;
   bool mu_aliased;  // reference quirk: after update_prior the GMM means alias theta's storage (svgd.py:87, svmpc.py:160-170)
@@ -201,6 +204,9 @@ static void free_all(dust_ctx *c) {
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -236,6 +242,10 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   *out = c;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->own_stream = true;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->pair_stream = c->stream;
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   const size_t ND = (size_t)c->N * c->D, SN = (size_t)c->S * c->N;
@@ -307,6 +317,7 @@ extern "C" int dust_set_stream(dust_ctx *c, void *s) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->own_stream) HIP_TRY(hipStreamDestroy(c->stream));
   c->stream = (hipStream_t)s;
+  c->pair_stream = c->stream;
   c->own_stream = false;
   return DUST_OK;
 }
@@ -726,7 +737,7 @@ static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
   do {                                                                                                                            \
     if (lds > 64 * 1024)                                                                                                          \
       HIP_TRY(hipFuncSetAttribute((const void *)pairwise_kernel<MODE, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    pairwise_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(a);                                                             \
+    pairwise_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->pair_stream>>>(a);                                                             \
   } while (0)
   if (cpt == 4) DUST_LAUNCH_PAIR(4);
   else if (cpt == 8) DUST_LAUNCH_PAIR(8);
@@ -915,20 +926,39 @@ extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *acti
 
 // local half of one SVGD iteration: prior partials -> rollout (+ merge) -> score rows of this shard
 static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set) {
-  TRY(launch_prior(c));
+  // The prior pass and the rollout kernel both only READ theta: fork the prior pass onto the side stream, run the
+  // rollout kernel on the main stream, join, then combine (prior_finish: score = grad_lik + grad_pri).  With per-kernel
+  // event timing on (dust_profile_enable) everything stays on one stream so the timings remain attributable.
+  // Measured on MI355X (round 1): the cross-stream event waits cost more than the overlap gains at cfg2 sizes
+  // (2 695 vs 3 010 ticks/s), so the fork/join form is opt-in and the default folds the combine into rollout_kernel.
+  static const bool env_on = getenv("DUST_OVERLAP") != nullptr;
+  const bool overlap = !c->prof && env_on;
+  if (overlap) {
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    c->pair_stream = c->stream2;
+  }
+  int sp = launch_prior(c);
+  c->pair_stream = c->stream;
+  TRY(sp);
+  if (overlap) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
   SampleOpts o;
   memset(&o, 0, sizeof o);
   o.noise_mode = noise_dev ? NOISE_EPS : NOISE_PHILOX;
   o.noise_dev = noise_dev;
   o.base = c->theta;
   o.update_a_mat = 1;
-  o.merge_prior = 1;
+  o.merge_prior = overlap ? 0 : 1;
   float *save = c->params_dev;
   if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
   int s = launch_rollout(c, o);
   c->params_dev = save;
   TRY(s);
   c->have_sample = true;
+  if (overlap) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    TRY(launch_prior_finish(c, true, false));
+  }
   return DUST_OK;
 }
 
@@ -965,6 +995,7 @@ extern "C" int dust_svmpc_step(dust_ctx *c, const float *state, const float *eps
 static int forward_device(dust_ctx *c) {
   if (!c->have_sample) return fail(DUST_ERR_STATE, "forward(fast_pred=True) needs the costs of a previous optimize step");
   TRY(launch_prior(c));
+  if (c->nloc == c->N) return DUST_OK;  // unsharded: finalize_kernel combines the partials itself
   TRY(launch_prior_finish(c, false, true));
   Prof p(c, DUST_K_FORWARD);
   logw_kernel<<<(c->nloc + 255) / 256, 256, 0, c->stream>>>(c->logl, c->logp, c->lw, c->n0, c->nloc);
@@ -988,10 +1019,14 @@ static int forward_finish_device(dust_ctx *c) {
   f.logmix = c->logmix;
   f.mixw = c->mixw;
   f.weighted_prior = c->cfg.weighted_prior;
+  if (c->nloc == c->N) {
+    f.merge_logp = 1;
+    f.logp_out = c->logp;
+    f.pm = prior_merge_args(c);
+  }
   finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
   HIP_TRY(hipGetLastError());
-  const int n = c->nloc * c->da;
-  roll_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
+  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
   HIP_TRY(hipGetLastError());
   c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
   c->tick++;

@@ -5,6 +5,7 @@
 // MixtureSameFamily log-weight construction in torch.distributions), a_mix disco.py:393, MultiDISCO.step disco.py:396-417.
 #pragma once
 #include "common.hpp"
+#include "stein.hpp"
 
 namespace dust {
 
@@ -19,6 +20,9 @@ struct FinalizeArgs {
   float *logmix;             // [N] out: new prior log mixture weights
   float *mixw;               // [N] out: new prior mixture weights as given to get_gmm (ones or p)
   int weighted_prior;
+  int merge_logp;            // unsharded path: combine the prior-pass partials here (log p, then lw = logl + logp)
+  float *logp_out;           // [N]
+  PriorMerge pm;
 };
 
 // lw = logl + logp for the local shard (separate tiny kernel so a sharded caller can all-gather lw in between)
@@ -32,6 +36,16 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
   __shared__ float red[32];
   __shared__ int redi[32];
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (a.merge_logp) {  // prior.log_prob(theta) from the slice partials (svmpc.py:137), then log_w = log_l + log_p (:138)
+    for (int i = tid; i < a.N; i += nt) {
+      float pmx, pl;
+      prior_merge_row(a.pm, i, &pmx, &pl);
+      const float lp = (pmx + logf(pl)) + a.pm.log_norm;
+      a.logp_out[i] = lp;
+      a.lw[i] = a.logl[i] + lp;
+    }
+    __syncthreads();
+  }
   float m = -INFINITY;
   for (int i = tid; i < a.N; i += nt) m = fmaxf(m, a.lw[i]);
   m = block_reduce<RED_MAX>(m, red);
@@ -121,23 +135,24 @@ __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *log
   for (int i = tid; i < N; i += nt) logmix[i] = logmix[i] - lzz;
 }
 
-// SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy. One thread per (i, d_a).
-__global__ void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_local * da) return;
-  const int i = i0 + idx / da, c = idx % da;
-  const int D = H * da;
+// SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy.  One workgroup per particle,
+// lane = element: every element is read into a register, the workgroup syncs, then the shifted value is written.
+__global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local) {
+  __shared__ float red[32];
+  const int i = i0 + blockIdx.x;
+  const int D = H * da, j = threadIdx.x;
   float *th = theta + (size_t)i * D;
-  float mean = 0.f;
-  if (strategy == DUST_ROLL_MEAN) {
-    double acc = 0.0;
-    for (int t = 0; t < H; ++t) acc += (double)th[t * da + c];
-    mean = (float)(acc / H);
+  const float own = j < D ? th[j] : 0.f;
+  const float nxt = (j + da < D) ? th[j + da] : own;  // "repeat": the last row keeps its value
+  float out = nxt;
+  if (strategy == DUST_ROLL_MEAN) {  // mean over the horizon of each control dimension (svmpc.py:151-153)
+    for (int c = 0; c < da; ++c) {
+      const float s = block_reduce<RED_SUM>((j < D && j % da == c) ? own : 0.f, red);
+      if (j + da >= D && j < D && j % da == c) out = s / (float)H;
+    }
   }
-  float last = th[(H - 1) * da + c];
-  for (int t = 0; t + 1 < H; ++t) th[t * da + c] = th[(t + 1) * da + c];
-  if (strategy == DUST_ROLL_MEAN) last = mean;
-  th[(H - 1) * da + c] = last;
+  __syncthreads();
+  if (j < D) th[j] = out;
 }
 
 // a_mix = softmax_n(eta) disco.py:393 (single workgroup)

@@ -44,43 +44,44 @@ struct PairArgs {
   unsigned long long *stamps;  // diagnostic build only
 };
 
-// rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP.
-// The source range is one contiguous run of nrows*D floats: coalesced dword loads, 8 in flight per lane.
-template <int TR, int DP, int LS, int NT>
-__device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0, int nrows, int D, uint32_t magicD, float *dst) {
+typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)
+
+// rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP, each column
+// multiplied by colscale[d % da].  The source range is one contiguous run of nrows*D floats: coalesced dword loads, 8 in
+// flight per lane (clamped, never predicated: a conditional load makes hipcc branch and wait vmcnt(0) per element).
+template <int TR, int DP, int LS, int NT, bool SCALE>
+__device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0, int nrows, int D, int da, uint32_t magicD,
+                                          const float *colscale, float *dst) {
   const int tid = threadIdx.x;
   for (int idx = tid; idx < TR * DP; idx += NT) dst[(idx / DP) * LS + (idx % DP)] = 0.f;
   __syncthreads();
-  const int total = nrows * D;
+  const int total = nrows * D;  // >= 1: every workgroup owns at least one row
   const float *base = src + (size_t)r0 * D;
-  for (int b = 0; b < total; b += 8 * NT) {  // total >= 1: every workgroup owns at least one row
+  for (int b = 0; b < total; b += 8 * NT) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      // clamp, do not predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
-      const int idx = min(b + u * NT + tid, total - 1);
-      v[u] = base[idx];
-    }
+    for (int u = 0; u < 8; ++u) v[u] = base[min(b + u * NT + tid, total - 1)];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = b + u * NT + tid;
       const int r = (int)__umulhi((uint32_t)idx, magicD), d = idx - r * D;
-      if (idx < total) dst[r * LS + d] = v[u];
+      const int cd = da == 1 ? 0 : (da == 2 ? (d & 1) : d % da);  // no runtime modulo on the common control dims
+      if (idx < total) dst[r * LS + d] = SCALE ? v[u] * colscale[cd] : v[u];
     }
   }
 }
 
 template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
-__global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) {
+__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(const PairArgs a) {
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
   constexpr int DP = 8 * CPT;  // padded row length in LDS (multiple of 4 -> b128 reads)
   constexpr int YS = DP + 4;
   constexpr int QG = NT / JC;      // query groups in pass A (4)
   constexpr int QPG = TI / QG;     // queries per group (8)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Xs = lds;                  // [TI][DP]
-  float *Ys = Xs + TI * DP;         // [JC][YS]
-  float *Vs = Ys + JC * YS;         // [JC][YS]   (Stein)
+  float *Xs = lds;                  // [TI][DP]   queries, pre-scaled by 1/s_d
+  float *Ys = Xs + TI * DP;         // [JC][YS]   keys, pre-scaled by 1/s_d
+  float *Vs = Ys + JC * YS;         // [JC][YS]   score (Stein), unscaled
   float *kv = Vs + (MODE == PAIR_PRIOR ? 0 : JC * YS);  // [TI][JC + 1]
   float *mrow = kv + TI * (JC + 1); // [TI] running max
   const int tid = threadIdx.x;
@@ -90,60 +91,58 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) 
   const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
 
   DUST_STAMP(a.stamps, 0);
-  // ---- query tile -> LDS (zero padded) ----
-  load_rows<TI, DP, DP, NT>(a.X, ib, min(TI, a.i0 + a.n_local - ib), D, a.magicD, Xs);
+  // ---- query tile -> LDS (zero padded, scaled) ----
+  load_rows<TI, DP, DP, NT, true>(a.X, ib, min(TI, a.i0 + a.n_local - ib), D, da, a.magicD, a.inv_s, Xs);
   if (tid < TI) mrow[tid] = -INFINITY;
 
   // pass-B ownership: query iB, columns [cB, cB + CPT)
   const int iB = tid >> 3, cB = (tid & 7) * CPT;
-  float accA[CPT], accB[CPT];
+  v2f accA[CPT / 2], accB[CPT / 2];
 #pragma unroll
-  for (int c = 0; c < CPT; ++c) accA[c] = accB[c] = 0.f;
+  for (int c = 0; c < CPT / 2; ++c) accA[c] = accB[c] = v2f{0.f, 0.f};
   float accL = 0.f;  // prior: sum of weights (same in the 8 lanes of a query)
   __syncthreads();
-  float xB[CPT];
+  v2f xB[CPT / 2];
 #pragma unroll
-  for (int c = 0; c < CPT; ++c) xB[c] = Xs[iB * DP + cB + c];
-  float isc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) isc[q] = a.inv_s[q];
+  for (int c = 0; c < CPT / 2; ++c) xB[c] = *reinterpret_cast<const v2f *>(&Xs[iB * DP + cB + 2 * c]);
 
   for (int j0 = jbeg; j0 < jend; j0 += JC) {
     const int jc = min(JC, jend - j0);
     DUST_STAMP(a.stamps, 1);
     // ---- key chunk -> LDS: rows j0..j0+jc-1 are contiguous in HBM ----
-    load_rows<JC, DP, YS, NT>(a.Y, j0, jc, D, a.magicD, Ys);
-    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT>(a.V, j0, jc, D, a.magicD, Vs);
+    const int jA = tid & (JC - 1), igA = tid / JC;
+    const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
+    load_rows<JC, DP, YS, NT, true>(a.Y, j0, jc, D, da, a.magicD, a.inv_s, Ys);
+    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, j0, jc, D, da, a.magicD, a.inv_s, Vs);
     __syncthreads();
     DUST_STAMP(a.stamps, 2);
-    // ---- pass A: lane = key j, QPG queries per lane, 4 independent accumulators per query ----
+    // ---- pass A: lane = key j, QPG queries per lane; packed math: 2 dims per v_pk_add / v_pk_fma ----
     {
-      const int j = tid & (JC - 1), ig = tid / JC;
-      const float lm = (MODE == PAIR_PRIOR && j < jc) ? a.logmix[j0 + j] : 0.f;
-      float d2[QPG];
+      // packed math: 2 dims per v_pk_add / v_pk_fma.  (The Gram value uses the bare v_exp_f32: inlining ocml expf eight
+      // times here made hipcc (ROCm 7.2) allocate 256 VGPRs + scratch and pass A ran 2-8x slower.)
+      v2f d2[QPG];
 #pragma unroll
-      for (int ii = 0; ii < QPG; ++ii) d2[ii] = 0.f;
+      for (int ii = 0; ii < QPG; ++ii) d2[ii] = v2f{0.f, 0.f};
 #pragma unroll
       for (int d = 0; d < DP; d += 4) {
-        const float4 yv = *reinterpret_cast<const float4 *>(&Ys[j * YS + d]);
-        const float s0 = isc[d % da], s1 = isc[(d + 1) % da], s2 = isc[(d + 2) % da], s3 = isc[(d + 3) % da];
+        const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jA * YS + d]);
+        const v2f y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
 #pragma unroll
         for (int ii = 0; ii < QPG; ++ii) {
-          const float4 xv = *reinterpret_cast<const float4 *>(&Xs[(ig * QPG + ii) * DP + d]);  // wave-uniform: LDS broadcast
-          const float z0 = (xv.x - yv.x) * s0, z1 = (xv.y - yv.y) * s1, z2 = (xv.z - yv.z) * s2, z3 = (xv.w - yv.w) * s3;
-          d2[ii] = fmaf(z0, z0, d2[ii]);
-          d2[ii] = fmaf(z1, z1, d2[ii]);
-          d2[ii] = fmaf(z2, z2, d2[ii]);
-          d2[ii] = fmaf(z3, z3, d2[ii]);
+          const float4 xv = *reinterpret_cast<const float4 *>(&Xs[(igA * QPG + ii) * DP + d]);  // wave-uniform: LDS broadcast
+          const v2f z01 = v2f{xv.x, xv.y} - y01, z23 = v2f{xv.z, xv.w} - y23;
+          d2[ii] = __builtin_elementwise_fma(z01, z01, d2[ii]);
+          d2[ii] = __builtin_elementwise_fma(z23, z23, d2[ii]);
         }
       }
 #pragma unroll
       for (int ii = 0; ii < QPG; ++ii) {
+        const float dd = d2[ii].x + d2[ii].y;
         float v;
-        if (MODE == PAIR_PRIOR) v = (j < jc) ? lm - 0.5f * d2[ii] : -INFINITY;
-        else if (MODE == PAIR_K1) v = (j < jc) ? expf(-0.5f * d2[ii]) : 0.f;
-        else v = (j < jc) ? d2[ii] : INFINITY;  // IMQ: k and k' are formed in pass B (inf -> k = 0)
-        kv[(ig * QPG + ii) * (JC + 1) + j] = v;
+        if (MODE == PAIR_PRIOR) v = (jA < jc) ? lm - 0.5f * dd : -INFINITY;
+        else if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;  // exp(-dd/2) = 2^(-dd/(2 ln 2)); bare v_exp_f32, rel. error ~|x| 2^-24
+        else v = (jA < jc) ? dd : INFINITY;  // IMQ: k and k' are formed in pass B (inf -> k = 0)
+        kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
       }
     }
     __syncthreads();
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) 
       const float mn = fmaxf(mo, m);
       const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) accA[c] *= sc;
+      for (int c = 0; c < CPT / 2; ++c) accA[c] *= sc;
       accL *= sc;
       __syncthreads();
       if ((tid & 7) == 0) mrow[iB] = mn;
@@ -172,8 +171,8 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) 
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 3);
-    // ---- pass B: lane = (query, 8 column groups) ----
-#pragma unroll 8
+    // ---- pass B: lane = (query, 8 column groups); packed math ----
+#pragma unroll 4
     for (int jj = 0; jj < JC; ++jj) {
       const float kq = kv[iB * (JC + 1) + jj];
       float k = kq, kp = 0.f;
@@ -183,24 +182,20 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) 
         k = rsqrtf(base);  // inf -> 0
         kp = (kq == INFINITY) ? 0.f : -k / base;
       }
+      const v2f kk = {k, k}, kpp = {kp, kp};
 #pragma unroll
       for (int c = 0; c < CPT; c += 4) {
         const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jj * YS + cB + c]);
+        const v2f y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
         if (MODE == PAIR_PRIOR) {
-          accA[c] = fmaf(k, yv.x - xB[c], accA[c]);
-          accA[c + 1] = fmaf(k, yv.y - xB[c + 1], accA[c + 1]);
-          accA[c + 2] = fmaf(k, yv.z - xB[c + 2], accA[c + 2]);
-          accA[c + 3] = fmaf(k, yv.w - xB[c + 3], accA[c + 3]);
+          accA[c / 2] = __builtin_elementwise_fma(kk, y01 - xB[c / 2], accA[c / 2]);
+          accA[c / 2 + 1] = __builtin_elementwise_fma(kk, y23 - xB[c / 2 + 1], accA[c / 2 + 1]);
         } else {
           const float4 sv = *reinterpret_cast<const float4 *>(&Vs[jj * YS + cB + c]);
-          accA[c] = fmaf(k, sv.x, accA[c]);
-          accA[c + 1] = fmaf(k, sv.y, accA[c + 1]);
-          accA[c + 2] = fmaf(k, sv.z, accA[c + 2]);
-          accA[c + 3] = fmaf(k, sv.w, accA[c + 3]);
-          accB[c] = fmaf(kp, xB[c] - yv.x, accB[c]);
-          accB[c + 1] = fmaf(kp, xB[c + 1] - yv.y, accB[c + 1]);
-          accB[c + 2] = fmaf(kp, xB[c + 2] - yv.z, accB[c + 2]);
-          accB[c + 3] = fmaf(kp, xB[c + 3] - yv.w, accB[c + 3]);
+          accA[c / 2] = __builtin_elementwise_fma(kk, v2f{sv.x, sv.y}, accA[c / 2]);
+          accA[c / 2 + 1] = __builtin_elementwise_fma(kk, v2f{sv.z, sv.w}, accA[c / 2 + 1]);
+          accB[c / 2] = __builtin_elementwise_fma(kpp, xB[c / 2] - y01, accB[c / 2]);
+          accB[c / 2 + 1] = __builtin_elementwise_fma(kpp, xB[c / 2 + 1] - y23, accB[c / 2 + 1]);
         }
       }
       if (MODE == PAIR_PRIOR) accL += k;
@@ -209,15 +204,17 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_kernel(const PairArgs a) 
   }
 
   DUST_STAMP(a.stamps, 4);
-  // ---- partial outputs ----
+  // ---- partial outputs (differences were accumulated in scaled coordinates: undo the 1/s_d) ----
   const int il = blockIdx.x * TI + iB;  // local row
   if (il < a.n_local) {
     const size_t row = ((size_t)js * a.n_local + il) * D;
 #pragma unroll
     for (int c = 0; c < CPT; ++c)
       if (cB + c < D) {
-        a.pA[row + cB + c] = accA[c];
-        if (MODE != PAIR_PRIOR) a.pB[row + cB + c] = accB[c];
+        const float un = 1.0f / a.inv_s[(cB + c) % da];
+        const float va = (c & 1) ? accA[c / 2].y : accA[c / 2].x, vb = (c & 1) ? accB[c / 2].y : accB[c / 2].x;
+        a.pA[row + cB + c] = (MODE == PAIR_PRIOR) ? va * un : va;
+        if (MODE != PAIR_PRIOR) a.pB[row + cB + c] = vb * un;
       }
     if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
       a.pM[(size_t)js * a.n_local + il] = mrow[iB];
@@ -240,22 +237,42 @@ struct PriorMerge {
   float inv_s2[4];
   float log_norm;  // -H sum(log sigma_p) - D/2 log(2 pi)
 };
+// loads are issued in batches of 8 with clamped (never predicated) indices so they overlap instead of serialising
 __device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, float *m_out, float *l_out) {
-  float m = -INFINITY;
-  for (int q = 0; q < pm.JS; ++q) m = fmaxf(m, pm.pM[(size_t)q * pm.n_local + il]);
-  float l = 0.f;
-  for (int q = 0; q < pm.JS; ++q) {
-    const float mq = pm.pM[(size_t)q * pm.n_local + il];
-    l += (mq == -INFINITY) ? 0.f : pm.pL[(size_t)q * pm.n_local + il] * expf(mq - m);
+  float m = -INFINITY, l = 0.f;
+  for (int q0 = 0; q0 < pm.JS; q0 += 8) {
+    float mq[8], lq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t r = (size_t)min(q0 + u, pm.JS - 1) * pm.n_local + il;
+      mq[u] = pm.pM[r];
+      lq[u] = pm.pL[r];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (q0 + u < pm.JS && mq[u] != -INFINITY) {  // online combine (fixed order)
+        const float mn = fmaxf(m, mq[u]);
+        l = l * ((m == -INFINITY) ? 0.f : expf(m - mn)) + lq[u] * expf(mq[u] - mn);
+        m = mn;
+      }
+    }
   }
   *m_out = m;
   *l_out = l;
 }
 __device__ __forceinline__ float prior_merge_col(const PriorMerge &pm, int il, int D, int d, int da, float m, float l) {
   float acc = 0.f;
-  for (int q = 0; q < pm.JS; ++q) {
-    const float mq = pm.pM[(size_t)q * pm.n_local + il];
-    if (mq != -INFINITY) acc = fmaf(pm.pA[((size_t)q * pm.n_local + il) * D + d], expf(mq - m), acc);
+  for (int q0 = 0; q0 < pm.JS; q0 += 8) {
+    float mq[8], aq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t r = (size_t)min(q0 + u, pm.JS - 1) * pm.n_local + il;
+      mq[u] = pm.pM[r];
+      aq[u] = pm.pA[r * D + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u < pm.JS && mq[u] != -INFINITY) acc = fmaf(aq[u], expf(mq[u] - m), acc);
   }
   return (acc / l) * pm.inv_s2[d % da];
 }
@@ -305,10 +322,20 @@ __global__ void update_kernel(const UpdateArgs a) {
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   float sa = 0.f, sb = 0.f;
-  for (int q = 0; q < a.JS; ++q) {
-    const size_t p = ((size_t)q * a.n_local + il) * a.D + d;
-    sa += a.pA[p];
-    sb += a.pB[p];
+  for (int q0 = 0; q0 < a.JS; q0 += 8) {  // 16 independent loads in flight, fixed summation order
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t p = ((size_t)min(q0 + u, a.JS - 1) * a.n_local + il) * a.D + d;
+      va[u] = a.pA[p];
+      vb[u] = a.pB[p];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u < a.JS) {
+        sa += va[u];
+        sb += vb[u];
+      }
   }
   const float phi = sb * a.inv_l2 + sa * a.inv_n;
   a.phi[o] = phi;
