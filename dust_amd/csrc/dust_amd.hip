@@ -14,6 +14,7 @@
 #include "bandwidth.hpp"
 #include "common.hpp"
 #include "forward.hpp"
+#include "fused.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -73,7 +74,6 @@ struct dust_ctx {
   float *costsT, *omegaT, *grad_lik, *grad_pri, *score, *phi, *logl, *logp, *lw, *pw, *a_seq_out, *bw;
   int *istar;
   float *adam_m, *adam_v;
-  int adam_step;
   float *pA, *pB, *pM, *pL;  // slice partials of the tiled pairwise passes
   size_t pA_cap, pB_cap, pM_cap, pL_cap;
   // staging
@@ -82,7 +82,20 @@ struct dust_ctx {
   uint32_t *grid_bits;
   int nx, ny;
   float off_x, off_y;
-  uint32_t tick, iter;
+  uint32_t *ctr_dev;  // device counters {tick, iter, adam_step, pad}
+  unsigned int *fused_cnt;  // [tiles + 1]: per-tile arrival counters of the fused launch, last word = spin-timeout flag
+  int fused_tiles;
+  bool fused_dirty;   // a fused launch ran and no update kernel has re-armed the counters yet
+  float *state_pin;   // pinned host ring [RING][4] feeding state_dev by async copies (no host sync per tick)
+  hipEvent_t ring_ev[16];
+  int ring_pos;
+  // hipGraph replay of a whole tick (dust_svmpc_tick)
+  hipGraph_t graph;
+  hipGraphExec_t graph_exec;
+  int graph_steps;
+  const void *graph_eps;
+  int graph_seen;     // consecutive eager ticks with the same shape (capture on the 2nd)
+  bool capturing;
   bool have_sample, actions_valid;
   unsigned long long *stamps_dev;  // diagnostic build only: [DUST_K_COUNT][16]
   // profiling
@@ -129,6 +142,34 @@ static DevModel make_dev_model(const dust_ctx *c) {
   m.w_ctrl[1] = g.w_ctrl[1];
   m.w_obs = g.w_obs;
   return m;
+}
+
+// Host evaluation of the model coefficients when no parameter is sampled (same Python-float / fp32-tensor rules as the
+// device make_coef in common.hpp; pendulum.py:93-96, particle.py:152).
+struct HVal {
+  int t;
+  double d;
+  float f;
+};
+static float h_tof(HVal v) { return v.t ? v.f : (float)v.d; }
+static HVal h_val(const dust_param &p) { return p.kind == DUST_PARAM_TENSOR0D ? HVal{1, 0.0, (float)p.value} : HVal{0, p.value, 0.f}; }
+static HVal h_mul(HVal a, HVal b) { return (!a.t && !b.t) ? HVal{0, a.d * b.d, 0.f} : HVal{1, 0.0, h_tof(a) * h_tof(b)}; }
+static HVal h_div(HVal a, HVal b) {
+  if (!a.t && !b.t) return HVal{0, a.d / b.d, 0.f};
+  if (a.t && !b.t) return HVal{1, 0.0, a.f / (float)b.d};
+  if (!a.t && b.t) return HVal{1, 0.0, (1.0f / b.f) * (float)a.d};
+  return HVal{1, 0.0, a.f / b.f};
+}
+static void host_coef(const dust_config &g, float out[2]) {
+  if (g.model == DUST_MODEL_PENDULUM) {
+    const HVal gg = h_val(g.g), m = h_val(g.mass), l = h_val(g.length);
+    const HVal l2 = l.t ? HVal{1, 0.0, l.f * l.f} : HVal{0, l.d * l.d, 0.f};
+    out[0] = h_tof(h_div(h_mul(HVal{0, -3.0, 0.f}, gg), h_mul(HVal{0, 2.0, 0.f}, l)));
+    out[1] = h_tof(h_div(HVal{0, 3.0, 0.f}, h_mul(m, l2)));
+  } else {
+    out[0] = h_tof(h_val(g.mass));
+    out[1] = 0.f;
+  }
 }
 
 template <class T>
@@ -184,6 +225,7 @@ static int validate(const dust_config *g) {
   if (g->dim_p < 0 || g->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p out of range");
   if (g->kernel < 0 || g->kernel > DUST_KERNEL_IMQ) return fail(DUST_ERR_INVALID, "bad kernel id");
   if (g->optimizer != DUST_OPT_SGD && g->optimizer != DUST_OPT_ADAM) return fail(DUST_ERR_UNSUPPORTED, "optimizer must be SGD or Adam");
+  if (g->n_policies > 16384) return fail(DUST_ERR_UNSUPPORTED, "n_policies > 16384 (finalize_kernel keeps all particles of the tick epilogue in one workgroup)");
   if (g->shard_size < 0 || g->shard_offset < 0 || g->shard_offset + g->shard_size > g->n_policies)
     return fail(DUST_ERR_INVALID, "bad shard [%d,+%d) of %d", g->shard_offset, g->shard_size, g->n_policies);
   for (int d = 0; d < g->dim_a; ++d)
@@ -200,6 +242,13 @@ static void free_all(dust_ctx *c) {
                   &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->ctr_dev) (void)hipFree(c->ctr_dev);
+  if (c->fused_cnt) (void)hipFree(c->fused_cnt);
+  if (c->state_pin) (void)hipHostFree(c->state_pin);
+  for (auto &e : c->ring_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -270,6 +319,10 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   TRY(dalloc(&c->costs_stage, SN));
   TRY(dalloc(&c->state_dev, (size_t)8));
   TRY(dalloc(&c->istar, (size_t)1));
+  TRY(dalloc(&c->ctr_dev, (size_t)4));
+  HIP_TRY(hipMemsetAsync(c->ctr_dev, 0, 4 * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipHostMalloc((void **)&c->state_pin, 16 * 4 * sizeof(float), hipHostMallocDefault));
+  for (auto &e : c->ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (cfg->optimizer == DUST_OPT_ADAM) {
     TRY(dalloc(&c->adam_m, ND));
     TRY(dalloc(&c->adam_v, ND));
@@ -300,9 +353,16 @@ extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
   return s;
 }
 
+static void graph_drop(dust_ctx *c);
+
 extern "C" int dust_sync(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->fused_cnt) {  // bounded spin of the fused launch's in-kernel hand-off: report instead of hanging
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->fused_cnt + c->fused_tiles, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(DUST_ERR_HIP, "fused prior+rollout launch: hand-off spin timed out (results of that tick are invalid)");
+  }
   return DUST_OK;
 }
 
@@ -314,6 +374,7 @@ extern "C" int dust_get_config(const dust_ctx *c, dust_config *out) {
 
 extern "C" int dust_set_stream(dust_ctx *c, void *s) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->graph_exec) graph_drop(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->own_stream) HIP_TRY(hipStreamDestroy(c->stream));
   c->stream = (hipStream_t)s;
@@ -356,10 +417,8 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
     TRY(d2d(c, c->adam_m, src->adam_m, ND));
     TRY(d2d(c, c->adam_v, src->adam_v, ND));
   }
-  c->adam_step = src->adam_step;
+  TRY(d2d(c, c->ctr_dev, src->ctr_dev, 4 * sizeof(uint32_t)));
   c->mu_aliased = src->mu_aliased;
-  c->tick = src->tick;
-  c->iter = src->iter;
   c->have_sample = src->have_sample;
   if (src->grid_bits) {
     const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
@@ -376,6 +435,7 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
 
 extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value, int kind) {
   if (!c || !name) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->graph_exec) graph_drop(c);
   dust_param *p = nullptr;
   if (!strcmp(name, "g")) p = &c->cfg.g;
   else if (!strcmp(name, "mass")) p = &c->cfg.mass;
@@ -388,6 +448,7 @@ extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value,
 
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
   if (!c || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
+  if (c->graph_exec) graph_drop(c);
   const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
   std::vector<uint32_t> bits(words, 0u);
   for (size_t i = 0; i < cells; ++i) {
@@ -420,7 +481,7 @@ extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
   if (c->adam_m) {
     HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
-    c->adam_step = 0;
+    HIP_TRY(hipMemsetAsync(c->ctr_dev + 2, 0, sizeof(uint32_t), c->stream));
   }
   return DUST_OK;
 }
@@ -430,6 +491,7 @@ extern "C" int dust_get_theta(dust_ctx *c, float *theta) {
 }
 extern "C" int dust_set_prior(dust_ctx *c, const float *means, const float *w) {
   if (!c || !means) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->graph_exec) graph_drop(c);
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(h2d(c, c->mu, means, (size_t)c->N * c->D * sizeof(float)));
   c->mu_aliased = false;
@@ -493,6 +555,7 @@ struct SampleOpts {
   const float *costs_in;   // device [S][N]: skip the rollouts and use these costs (stage-wise phi)
   bool want_actions, want_states, want_omega;
   int merge_prior;         // a prior pass ran just before: fold its partials into grad_pri / score
+  int bump_adam;           // an optimiser step follows this sample
 };
 
 // geometry of the tiled pairwise launches: i-tiles of PAIR_TI queries x JS key slices, >= ~512 workgroups when possible
@@ -524,8 +587,7 @@ static PriorMerge prior_merge_args(const dust_ctx *c) {
   return pm;
 }
 
-static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
-  RolloutArgs a;
+static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *nt_out, size_t *lds_out) {
   memset(&a, 0, sizeof a);
   a.dm = make_dev_model(c);
   if (c->cfg.model == DUST_MODEL_PARTICLE && c->cfg.with_obstacle && !c->grid_bits)
@@ -576,24 +638,38 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
     a.states_out = c->states;
   }
   a.seed = c->cfg.seed;
-  a.tick = c->tick;
-  a.iter = c->iter;
+  a.ctr = c->ctr_dev;
+  a.bump_adam = o.bump_adam;
+  if (a.params == nullptr) {
+    a.coef_given = 1;
+    host_coef(c->cfg, a.coef_host);
+  }
   a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_ROLLOUT : nullptr;
   int nt = ((std::max(c->S, c->D) + 63) / 64) * 64;
   nt = std::min(std::max(nt, 64), 256);
-  size_t lds = rollout_lds_bytes(c->S, c->D, nt, true);
+  size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true);
   if (lds > 96 * 1024) {  // keep >= 1 workgroup per CU resident with room to spare; larger tiles go to an HBM slab
     TRY(ensure(&c->tile_scratch, &c->tile_cap, (size_t)c->nloc * c->S * (c->D | 1)));
     a.tile_scratch = c->tile_scratch;
-    lds = rollout_lds_bytes(c->S, c->D, nt, false);
+    lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false);
     if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "n_samples too large for one workgroup (%zu B of LDS)", lds);
   }
+  *nt_out = nt;
+  *lds_out = lds;
+  return DUST_OK;
+}
+
+static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
+  RolloutArgs a;
+  int nt;
+  size_t lds;
+  TRY(rollout_args(c, o, a, &nt, &lds));
   Prof p(c, DUST_K_ROLLOUT);
   if (c->cfg.model == DUST_MODEL_PENDULUM) {
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PENDULUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024 && !c->capturing) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PENDULUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     rollout_kernel<DUST_MODEL_PENDULUM><<<c->nloc, nt, lds, c->stream>>>(a);
   } else {
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PARTICLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024 && !c->capturing) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PARTICLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     rollout_kernel<DUST_MODEL_PARTICLE><<<c->nloc, nt, lds, c->stream>>>(a);
   }
   HIP_TRY(hipGetLastError());
@@ -602,7 +678,16 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
 }
 
 static int upload_state_params(dust_ctx *c, const float *state, const float *params, int n_sets) {
-  if (state) TRY(h2d(c, c->state_dev, state, c->ds * sizeof(float)));
+  if (state) {
+    // 16-byte state through a pinned ring: the copy is asynchronous and the host never waits for the previous tick
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % 16;
+    HIP_TRY(hipEventSynchronize(c->ring_ev[slot]));  // the copy that last used this slot (16 ticks ago) has long finished
+    float *pin = c->state_pin + 4 * slot;
+    for (int k = 0; k < 4; ++k) pin[k] = k < c->ds ? state[k] : 0.f;
+    HIP_TRY(hipMemcpyAsync(c->state_dev, pin, 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ring_ev[slot], c->stream));
+  }
   if (c->cfg.dim_p > 0 && c->M >= 1) {
     if (params) {
       TRY(ensure(&c->params_dev, &c->params_cap, (size_t)n_sets * c->M * c->P));
@@ -692,7 +777,8 @@ extern "C" int dust_disco_forward(dust_ctx *c, const float *state, const float *
   o.want_omega = omega != nullptr;
   TRY(launch_rollout(c, o));
   c->have_sample = true;
-  c->iter++;
+  bump_iter_kernel<<<1, 1, 0, c->stream>>>(c->ctr_dev);
+  HIP_TRY(hipGetLastError());
   if (costs) TRY(copy_out_SN(c, c->costsT, costs));
   if (omega) TRY(copy_out_SN(c, c->omegaT, omega));
   if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
@@ -718,7 +804,8 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
   o.want_states = (flags & DUST_STORE_STATES) != 0;
   TRY(launch_rollout(c, o));
   c->have_sample = true;
-  c->iter++;
+  bump_iter_kernel<<<1, 1, 0, c->stream>>>(c->ctr_dev);
+  HIP_TRY(hipGetLastError());
   if (costs) TRY(copy_out_SN(c, c->costsT, costs));
   if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
   return DUST_OK;
@@ -735,7 +822,7 @@ static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
   dim3 grid(tiles, a.JS);
 #define DUST_LAUNCH_PAIR(CPT)                                                                                                    \
   do {                                                                                                                            \
-    if (lds > 64 * 1024)                                                                                                          \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                         \
       HIP_TRY(hipFuncSetAttribute((const void *)pairwise_kernel<MODE, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     pairwise_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->pair_stream>>>(a);                                                             \
   } while (0)
@@ -758,11 +845,9 @@ static int ensure_partials(dust_ctx *c, int JS) {
 }
 
 // prior pass: writes slice partials (pA, pM, pL); combined by rollout_kernel (merge_prior) or prior_finish_kernel
-static int launch_prior(dust_ctx *c) {
-  PairArgs a;
+static int prior_args(dust_ctx *c, PairArgs &a, int *tiles) {
   memset(&a, 0, sizeof a);
-  int tiles;
-  pair_geometry(c, &tiles, &a.JS, &a.slice);
+  pair_geometry(c, tiles, &a.JS, &a.slice);
   TRY(ensure_partials(c, a.JS));
   a.N = c->N;
   a.D = c->D;
@@ -779,8 +864,77 @@ static int launch_prior(dust_ctx *c) {
   a.pM = c->pM;
   a.pL = c->pL;
   a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_PRIOR_SCORE : nullptr;
+  return DUST_OK;
+}
+
+static int launch_prior(dust_ctx *c) {
+  PairArgs a;
+  int tiles;
+  TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
   return launch_pair<PAIR_PRIOR>(c, a, tiles);
+}
+
+// Fused prior pass + rollout kernel (fused.hpp).  Returns DUST_OK with *done = false when the shape does not qualify.
+static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
+  *done = false;
+  static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
+  if (off || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in) return DUST_OK;
+  FusedArgs f;
+  memset(&f, 0, sizeof f);
+  int nt;
+  size_t lds_r;
+  TRY(prior_args(c, f.pa, &f.tiles));  // first: it sizes the partial buffers that rollout_args' combine descriptor points to
+  if (f.pa.JS > 16) return DUST_OK;    // rollout_body's in-register combine holds 16 slices
+  SampleOpts oo = o;
+  oo.merge_prior = 1;
+  TRY(rollout_args(c, oo, f.ra, &nt, &lds_r));
+  if (f.ra.tile_scratch || (PAIR_NT % nt) != 0) return DUST_OK;
+  f.sub_nt = nt;
+  f.per_block = PAIR_NT / nt;
+  if (c->nloc % f.per_block || PAIR_TI % f.per_block) return DUST_OK;
+  const int cpt = cpt_for(c->D);
+  const size_t lds_p = pairwise_lds_bytes(PAIR_PRIOR, cpt);
+  f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
+  const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
+  if (lds > 72 * 1024) return DUST_OK;  // keep >= 2 workgroups per CU co-resident
+  if (!c->fused_cnt || c->fused_tiles != f.tiles) {
+    if (c->capturing) return DUST_OK;
+    if (c->fused_cnt) HIP_TRY(hipFree(c->fused_cnt));
+    c->fused_cnt = nullptr;
+    TRY(dalloc(&c->fused_cnt, (size_t)f.tiles + 1));
+    c->fused_tiles = f.tiles;
+    c->fused_dirty = true;
+  }
+  if (c->fused_dirty)  // previous fused launch was not followed by an update kernel (which re-arms the counters)
+    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, ((size_t)f.tiles + 1) * sizeof(unsigned int), c->stream));
+  f.n_pair_blocks = f.tiles * f.pa.JS;
+  f.cnt = c->fused_cnt;
+  f.timeout_flag = c->fused_cnt + f.tiles;
+  const int grid = f.n_pair_blocks + c->nloc / f.per_block;
+#define DUST_LAUNCH_FUSED(MODEL, CPT)                                                                                                  \
+  do {                                                                                                                                  \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                               \
+      HIP_TRY(hipFuncSetAttribute((const void *)fused_prior_rollout_kernel<MODEL, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    fused_prior_rollout_kernel<MODEL, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f);                                                      \
+  } while (0)
+  if (c->cfg.model == DUST_MODEL_PENDULUM) {
+    if (cpt == 4) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 4);
+    else if (cpt == 8) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 8);
+    else if (cpt == 12) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 12);
+    else DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 16);
+  } else {
+    if (cpt == 4) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 4);
+    else if (cpt == 8) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 8);
+    else if (cpt == 12) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 12);
+    else DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 16);
+  }
+#undef DUST_LAUNCH_FUSED
+  HIP_TRY(hipGetLastError());
+  c->fused_dirty = true;
+  c->actions_valid = false;
+  *done = true;
+  return DUST_OK;
 }
 
 static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp) {
@@ -826,6 +980,9 @@ static UpdateArgs update_args(dust_ctx *c, int apply) {
   u.theta = c->theta;
   u.adam_m = c->adam_m;
   u.adam_v = c->adam_v;
+  u.ctr = c->ctr_dev;
+  u.fused_cnt = c->fused_cnt;
+  u.fused_tiles = c->fused_cnt ? c->fused_tiles : 0;
   return u;
 }
 
@@ -855,10 +1012,10 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     }
     if (apply) {
       UpdateArgs u = update_args(c, 1);
-      u.step = ++c->adam_step;
       Prof p(c, DUST_K_UPDATE);
       update_from_phi_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
       HIP_TRY(hipGetLastError());
+      c->fused_dirty = false;
     }
     return DUST_OK;
   }
@@ -888,10 +1045,10 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     else TRY(launch_pair<PAIR_K1>(c, a, tiles));
   }
   UpdateArgs u = update_args(c, apply);
-  if (apply) u.step = ++c->adam_step;
   Prof p(c, DUST_K_UPDATE);
   update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
   HIP_TRY(hipGetLastError());
+  c->fused_dirty = false;
   return DUST_OK;
 }
 
@@ -933,6 +1090,25 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
   // (2 695 vs 3 010 ticks/s), so the fork/join form is opt-in and the default folds the combine into rollout_kernel.
   static const bool env_on = getenv("DUST_OVERLAP") != nullptr;
   const bool overlap = !c->prof && env_on;
+  if (!overlap) {
+    SampleOpts of;
+    memset(&of, 0, sizeof of);
+    of.noise_mode = noise_dev ? NOISE_EPS : NOISE_PHILOX;
+    of.noise_dev = noise_dev;
+    of.base = c->theta;
+    of.update_a_mat = 1;
+    of.bump_adam = 1;
+    float *sv = c->params_dev;
+    if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
+    bool done = false;
+    int sf = launch_fused(c, of, &done);
+    c->params_dev = sv;
+    TRY(sf);
+    if (done) {
+      c->have_sample = true;
+      return DUST_OK;
+    }
+  }
   if (overlap) {
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -948,6 +1124,7 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
   o.noise_dev = noise_dev;
   o.base = c->theta;
   o.update_a_mat = 1;
+  o.bump_adam = 1;
   o.merge_prior = overlap ? 0 : 1;
   float *save = c->params_dev;
   if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
@@ -965,7 +1142,6 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
 static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
   TRY(local_score_device(c, noise_dev, param_set));
   TRY(launch_stein_update(c, 1));
-  c->iter++;
   return DUST_OK;
 }
 
@@ -1026,11 +1202,9 @@ static int forward_finish_device(dust_ctx *c) {
   }
   finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
   HIP_TRY(hipGetLastError());
-  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc);
+  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc, c->ctr_dev);
   HIP_TRY(hipGetLastError());
   c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
-  c->tick++;
-  c->iter = 0;
   return DUST_OK;
 }
 
@@ -1045,11 +1219,79 @@ extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
   return DUST_OK;
 }
 
+static void graph_drop(dust_ctx *c) {
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  c->graph_exec = nullptr;
+  c->graph = nullptr;
+  c->graph_seen = 0;
+}
+
+// One whole control tick.  The kernel chain of a tick is static once the context is warm (same kernels, same pointers:
+// state, counters and dynamics samples live in device buffers that are refreshed by copies outside the graph), so from
+// the third tick of a given shape on it is replayed as ONE hipGraph launch instead of ~22 kernel launches.
 extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags,
                                float *a_seq, float *p_weights) {
-  TRY(dust_svmpc_optimize(c, state, n_steps, eps, params, flags));
-  TRY(forward_device(c));
-  TRY(forward_finish_device(c));
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
+  const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
+                         c->mu_aliased && c->own_stream;
+  if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps) {
+    if (c->graph_exec) graph_drop(c);
+    c->graph_steps = n_steps;
+    c->graph_eps = (const void *)eps;
+    c->graph_seen = 0;
+  }
+  if (graphable && c->graph_exec) {
+    if (n_steps < 0) return fail(DUST_ERR_INVALID, "n_steps < 0");
+    if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(upload_state_params(c, state, params, n_steps));
+    HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+  } else if (graphable && c->graph_seen >= 1) {
+    // warm (every lazily sized buffer exists): capture this tick, then launch the capture
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+    TRY(upload_state_params(c, state, params, n_steps));
+    c->capturing = true;
+    hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    int st = DUST_OK;
+    if (e == hipSuccess) {
+      const size_t slice = (size_t)c->S * c->N * c->D;
+      for (int k = 0; k < n_steps && st == DUST_OK; ++k) st = step_device(c, eps ? eps + (size_t)k * slice : nullptr, k);
+      if (st == DUST_OK) st = forward_device(c);
+      if (st == DUST_OK) st = forward_finish_device(c);
+      hipGraph_t g = nullptr;
+      hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+      if (st == DUST_OK && e2 == hipSuccess && g) {
+        c->graph = g;
+        if (hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) != hipSuccess) {
+          (void)hipGraphDestroy(c->graph);
+          c->graph = nullptr;
+          c->graph_exec = nullptr;
+        }
+      } else if (g) {
+        (void)hipGraphDestroy(g);
+      }
+    }
+    c->capturing = false;
+    TRY(st);
+    if (c->graph_exec) {
+      HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    } else {  // capture unavailable: run the tick eagerly (nothing was executed during the failed capture)
+      (void)hipGetLastError();
+      c->graph_seen = -1000000;  // do not retry every tick
+      const size_t slice = (size_t)c->S * c->N * c->D;
+      for (int k = 0; k < n_steps; ++k) TRY(step_device(c, eps ? eps + (size_t)k * slice : nullptr, k));
+      TRY(forward_device(c));
+      TRY(forward_finish_device(c));
+    }
+  } else {
+    TRY(dust_svmpc_optimize(c, state, n_steps, eps, params, flags));
+    TRY(forward_device(c));
+    TRY(forward_finish_device(c));
+    if (graphable) c->graph_seen++;
+  }
   if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
   if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
   return DUST_OK;
@@ -1112,7 +1354,6 @@ extern "C" int dust_svmpc_apply_phi(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(launch_stein_update(c, 1));
-  c->iter++;
   return DUST_OK;
 }
 extern "C" int dust_svmpc_forward_local(dust_ctx *c, void **log_w_all, size_t *shard_bytes) {
@@ -1135,6 +1376,7 @@ extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_wei
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int dust_profile_enable(dust_ctx *c, int on) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->graph_exec) graph_drop(c);
   c->prof = on != 0;
   return DUST_OK;
 }

@@ -31,35 +31,63 @@ __global__ void logw_kernel(const float *logl, const float *logp, float *lw, int
   if (i < n_local) lw[i0 + i] = logl[i0 + i] + logp[i0 + i];
 }
 
-// single workgroup: softmax over N, first-index argmax, a_seq, new mixture log-weights
+// block-wide reduction of TWO values at once (one barrier pair instead of two)
+__device__ __forceinline__ void block_reduce2(float &mx, float &sm, float *scratch /* >= 32 */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  mx = wave_max(mx);
+  sm = wave_sum(sm);
+  __syncthreads();
+  if (lane == 0) {
+    scratch[wid] = mx;
+    scratch[16 + wid] = sm;
+  }
+  __syncthreads();
+  mx = scratch[0];
+  sm = scratch[16];
+  for (int w = 1; w < nw; ++w) {
+    mx = fmaxf(mx, scratch[w]);
+    sm += scratch[16 + w];
+  }
+}
+
+// single workgroup: softmax over N, first-index argmax, a_seq, new mixture log-weights.  Each lane keeps its particles'
+// values in registers between the passes (N <= 8 * 1024 on that path), so global memory is read once and written once.
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
   __shared__ float red[32];
   __shared__ int redi[32];
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (a.merge_logp) {  // prior.log_prob(theta) from the slice partials (svmpc.py:137), then log_w = log_l + log_p (:138)
-    for (int i = tid; i < a.N; i += nt) {
+  constexpr int R = 16;  // N <= 16384 particles (validated at create)
+  float lwr[R];  // requires N <= R * blockDim (the host checks)
+  // pass 1: log-weights (merging the prior-pass partials when unsharded) and their max
+  float m = -INFINITY;
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i >= a.N) continue;
+    float lw;
+    if (a.merge_logp) {  // prior.log_prob(theta) from the slice partials (svmpc.py:137), then log_w = log_l + log_p (:138)
       float pmx, pl;
       prior_merge_row(a.pm, i, &pmx, &pl);
       const float lp = (pmx + logf(pl)) + a.pm.log_norm;
       a.logp_out[i] = lp;
-      a.lw[i] = a.logl[i] + lp;
+      lw = a.logl[i] + lp;
+      a.lw[i] = lw;
+    } else {
+      lw = a.lw[i];
     }
-    __syncthreads();
+    lwr[r] = lw;
+    m = fmaxf(m, lw);
   }
-  float m = -INFINITY;
-  for (int i = tid; i < a.N; i += nt) m = fmaxf(m, a.lw[i]);
   m = block_reduce<RED_MAX>(m, red);
   float z = 0.f;
-  for (int i = tid; i < a.N; i += nt) z += expf(a.lw[i] - m);
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i < a.N) z += expf(lwr[r] - m); }
   z = block_reduce<RED_SUM>(z, red);
   const float lz = m + logf(z);
   // p = exp(log_w - logsumexp(log_w)) ; argmax = first index of the maximum (torch.argmax on CPU)
   float best = -INFINITY;
   int bi = 0x7fffffff;
   float psum = 0.f;
-  for (int i = tid; i < a.N; i += nt) {
-    const float p = expf(a.lw[i] - lz);
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i >= a.N) continue;
+    const float p = expf(lwr[r] - lz);
     a.pw[i] = p;
+    lwr[r] = p;
     psum += p;
     if (p > best) {
       best = p;
@@ -92,24 +120,35 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
   if (tid == 0) *a.istar = bi;
   for (int d = tid; d < a.D; d += nt) a.a_seq_out[d] = a.theta[(size_t)bi * a.D + d];
   // new prior mixture: Categorical(probs = w / sum w) -> logits = log(clamp(probs, eps, 1 - eps)) -> log_softmax
+  if (!a.weighted_prior) {  // uniform: every logit is log(1/N) and the log_softmax of a constant vector is -log N exactly
+    const float l = logf(fminf(fmaxf(1.0f / (float)a.N, 1.1920929e-07f), 1.0f - 1.1920929e-07f));
+    float zs = 0.f;
+    for (int i = tid; i < a.N; i += nt) zs += 1.0f;  // exp(l - l)
+    zs = block_reduce<RED_SUM>(zs, red);
+    const float lzz = l + logf(zs);
+    for (int i = tid; i < a.N; i += nt) {
+      a.mixw[i] = 1.0f;
+      a.logmix[i] = l - lzz;
+    }
+    return;
+  }
   psum = block_reduce<RED_SUM>(psum, red);
-  const float wsum = a.weighted_prior ? psum : (float)a.N;
   float lm = -INFINITY;
-  for (int i = tid; i < a.N; i += nt) {
-    const float w = a.weighted_prior ? a.pw[i] : 1.0f;
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i >= a.N) continue;
+    const float w = lwr[r];
     a.mixw[i] = w;
-    float p = w / wsum;
+    float p = w / psum;
     p = fminf(fmaxf(p, 1.1920929e-07f), 1.0f - 1.1920929e-07f);
     const float l = logf(p);
-    a.logmix[i] = l;
+    lwr[r] = l;
     lm = fmaxf(lm, l);
   }
   lm = block_reduce<RED_MAX>(lm, red);
   float zs = 0.f;
-  for (int i = tid; i < a.N; i += nt) zs += expf(a.logmix[i] - lm);
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i < a.N) zs += expf(lwr[r] - lm); }
   zs = block_reduce<RED_SUM>(zs, red);
   const float lzz = lm + logf(zs);
-  for (int i = tid; i < a.N; i += nt) a.logmix[i] = a.logmix[i] - lzz;
+  _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i < a.N) a.logmix[i] = lwr[r] - lzz; }
 }
 
 // mixture log-weights from user-supplied weights (set_prior): same construction as above
@@ -137,8 +176,12 @@ __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *log
 
 // SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy.  One workgroup per particle,
 // lane = element: every element is read into a register, the workgroup syncs, then the shifted value is written.
-__global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local) {
+__global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local, uint32_t *ctr) {
   __shared__ float red[32];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // next tick: new Philox sub-stream
+    ctr[0] += 1u;
+    ctr[1] = 0u;
+  }
   const int i = i0 + blockIdx.x;
   const int D = H * da, j = threadIdx.x;
   float *th = theta + (size_t)i * D;
@@ -244,5 +287,8 @@ __global__ void amat_roll_kernel(float *a_mat, int N, int H, int da, int steps) 
   float *row = a_mat + (size_t)n * H * da;
   for (int t = 0; t < H; ++t) row[t * da + c] = (t + steps < H) ? row[(t + steps) * da + c] : 0.f;
 }
+
+// advance the Philox position after a stand-alone sample (no optimiser step / roll follows)
+__global__ void bump_iter_kernel(uint32_t *ctr) { ctr[1] += 1u; }
 
 }  // namespace dust

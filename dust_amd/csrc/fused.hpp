@@ -1,0 +1,51 @@
+// fused.hpp - one launch for the two halves of the score that only READ theta: the prior pass (pairwise_body<PRIOR>)
+// and the rollout / likelihood-score kernel (rollout_body).
+//
+// Why: at cfg2 sizes (N = 1024, S = 128) the rollout kernel is 2 waves per SIMD and instruction-issue / latency bound
+// (~25 % of the issue slots), and the prior pass is another 2 waves per SIMD of the same kind; run back to back they cost
+// 20.6 + 12.2 us.  Two streams (eager or inside a hipGraph) were SLOWER than back-to-back on this stack (2 970 vs
+// 3 660 ticks/s: cross-queue dependencies cost more than the overlap gains), so the overlap is done inside one launch:
+// workgroups [0, n_pair) run the prior tiles, workgroups [n_pair, ...) run the rollouts (256 / nt particles each).
+//
+// Hand-off inside the launch (the rollout role needs the prior partials of its particle only at its very end): per
+// query tile a counter in HBM, zeroed by the update kernel of the previous iteration.  Producer = cdna_hip_programming.md
+// Guideline 16, write-through form: partials stored with sc1 (agent-scope relaxed atomic stores) -> every wave
+// s_waitcnt vmcnt(0) -> barrier -> lane 0 relaxed agent atomic add.  Consumer (rollout_body): ONE lane polls relaxed with
+// s_sleep, barrier, then EVERY load of the partials is an sc1 load.  No L2 write-back / L1 invalidate fences: the
+// release+acquire fence form measured 30 % SLOWER than two separate launches (512 workgroups each flushing an XCD L2).  Results do not depend on placement or timing; the
+// prior workgroups have the LOWER block indices and never wait on anything, so the rollout workgroups can only wait on
+// work that has already been dispatched (and the spin is bounded).
+#pragma once
+#include "rollout.hpp"
+#include "stein.hpp"
+
+namespace dust {
+
+struct FusedArgs {
+  PairArgs pa;
+  RolloutArgs ra;
+  int tiles, n_pair_blocks;
+  int sub_nt, per_block;     // rollout role: lanes per particle, particles per 256-lane workgroup
+  int lds_roll_floats;       // LDS floats per particle sub-block
+  unsigned int *cnt;         // [tiles] arrival counters
+  unsigned int *timeout_flag;
+};
+
+template <int MODEL, int CPT>
+__global__ __launch_bounds__(PAIR_NT, 2) void fused_prior_rollout_kernel(const FusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < f.n_pair_blocks) {
+    const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
+    pairwise_body<PAIR_PRIOR, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores ...
+    __syncthreads();                                    // ... before the one lane that signals for the workgroup
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const int b = (int)blockIdx.x - f.n_pair_blocks;
+    const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
+    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag};
+    rollout_body<MODEL>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+  }
+}
+
+}  // namespace dust

@@ -36,7 +36,11 @@ struct RolloutArgs {
   float alpha, temp, a_reg;
   float chol_a[4], sigma_a[4], a_pre[4];
   PriorMerge pm;
-  const float *state;   // [ds]
+  const float *state;   // [ds] (device; refreshed by an async copy from a pinned ring before each tick)
+  uint32_t *ctr;        // device counters {tick, iter, adam_step}: the Philox stream position (static under hipGraph replay)
+  int bump_adam;        // an optimiser step follows: advance adam_step (read by update_kernel, never by this kernel)
+  int coef_given;       // no sampled parameters: the model coefficients were evaluated once on the host
+  float coef_host[2];
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
   const float *noise;   // eps or actions [S][N_total][D] (device), or nullptr for Philox
   const float *params;  // [M][P] raw samples or nullptr
@@ -54,7 +58,6 @@ struct RolloutArgs {
   float *states_out;    // [M][S][N_total][H+1][ds] or nullptr
   float *tile_scratch;  // [n_local][S][D|1] HBM slab for action tiles too large for LDS, else nullptr
   uint64_t seed;
-  uint32_t tick, iter;
   unsigned long long *stamps;  // diagnostic build only
 };
 
@@ -77,17 +80,26 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   *cos_th = cs;
 }
 
+// In-launch hand-off from the prior-pass workgroups of a fused launch (fused.hpp): per query tile, a monotonic arrival
+// counter; `target` arrivals mean every key slice of that tile has published its partials.
+struct FusedWait {
+  const unsigned int *cnt;  // [tiles]
+  unsigned int target;
+  unsigned int *timeout_flag;
+};
+
+// `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
+// wide (every sub-block of a workgroup runs the same control flow), reductions are sub-block local.
 template <int MODEL>
-__global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
+__device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, const int tid, const int nt, const int nl,
+                                             const FusedWait *fw) {
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
   constexpr int DA = MODEL == DUST_MODEL_PENDULUM ? 1 : 2;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int n = a.n0 + blockIdx.x;
+  const int n = a.n0 + nl;
   const int S = a.S, D = a.D, H = a.H, N = a.N_total;
   const int Dp = D | 1;
   // the S x D action tile lives in LDS; when it would not fit (huge S*D) it spills to a per-workgroup HBM scratch slab
-  float *tile = a.tile_scratch ? a.tile_scratch + (size_t)blockIdx.x * S * Dp : lds;  // [S][Dp] actions
+  float *tile = a.tile_scratch ? a.tile_scratch + (size_t)nl * S * Dp : lds;  // [S][Dp] actions
   float *cst = a.tile_scratch ? lds : lds + (size_t)S * Dp;                            // [S] costs -> weights
   float *omg = cst + S;    // [S] omega
   float *red = omg + S;    // [64] reduction scratch
@@ -101,6 +113,18 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   float x0[DS];
 #pragma unroll
   for (int k = 0; k < DS; ++k) x0[k] = a.state[k];
+  // per-dynamics-sample coefficients once per workgroup (the Python-float / fp32-tensor emulation is long and branchy)
+  float *coefs = th + D;  // [M][2]
+  for (int m = tid; m < a.M; m += nt) {
+    if (a.coef_given) {
+      coefs[2 * m] = a.coef_host[0];
+      coefs[2 * m + 1] = a.coef_host[1];
+    } else {
+      const Coef c = make_coef(a.dm, a.params ? a.params + (size_t)m * a.dm.P : nullptr);
+      coefs[2 * m] = c.c0;
+      coefs[2 * m + 1] = c.c1;
+    }
+  }
   __syncthreads();
   if (a.noise_mode != NOISE_PHILOX) {
     const int total = S * D;
@@ -126,6 +150,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   DUST_STAMP(a.stamps, 1);
   // ---- 2. rollouts: lane = sample s, dynamics samples m looped in registers (a2-a5) ----
   const long SN = (long)S * N;
+  const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
   const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out &&
                          (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
@@ -134,7 +159,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
     if (a.noise_mode == NOISE_PHILOX) {  // this lane's own row: no barrier needed before it is consumed below
       for (int j4 = 0; j4 * 4 < D; ++j4) {
         float z[4];
-        philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), a.iter, a.tick, z);
+        philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int j = j4 * 4 + q;
@@ -149,8 +174,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
     double acc_m = 0.0;
     for (int m = 0; m < a.M; ++m) {
       const long r = (long)m * SN + (long)s * N + n;
-      const float *prow = a.params ? a.params + (size_t)(a.dm.interleave ? (int)(r % a.M) : m) * a.dm.P : nullptr;
-      const Coef cf = make_coef(a.dm, prow);
+      const int pidx = a.dm.interleave ? (int)(r % a.M) : m;
+      Coef cf;
+      cf.c0 = coefs[2 * pidx];
+      cf.c1 = coefs[2 * pidx + 1];
       float x[DS];
 #pragma unroll
       for (int k = 0; k < DS; ++k) x[k] = x0[k];
@@ -283,6 +310,23 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   const int Q = nt / D > 0 ? nt / D : 1;
   float g = 0.f, am = 0.f;
   const int q = (int)__umulhi((uint32_t)tid, a.magicD), j = tid - q * D;
+  if (fw) {
+    // fused launch: the prior-pass workgroups of this launch publish the partials of query tile nl/32 with an agent-scope
+    // release + counter add; poll relaxed from ONE lane, acquire once, then the barrier admits the other lanes
+    // (cdna_hip_programming.md Guideline 16, counter form).  The spin is bounded.
+    if (threadIdx.x == 0) {
+      const unsigned int *cp = fw->cnt + (nl / PAIR_TI);
+      unsigned int spins = 0;
+      while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw->target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 24)) {
+          *fw->timeout_flag = 1u;
+          break;
+        }
+      }
+    }
+    __syncthreads();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
+  }
   // prior partials of this row: issue the (independent) loads now, consume them after the reduction below
   float pmM[16], pmL[16], pmA[16];
   const bool merger = a.merge_prior && tid < D;
@@ -291,8 +335,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const bool ok = u < JS;
-      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + blockIdx.x;
-      const float tm = a.pm.pM[rowi], tl = a.pm.pL[rowi], ta = a.pm.pA[rowi * D + tid];  // unconditional loads
+      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + nl;
+      float tm, tl, ta;  // unconditional loads
+      if (fw) {
+        tm = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tl = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ta = __hip_atomic_load(a.pm.pA + rowi * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        tm = a.pm.pM[rowi];
+        tl = a.pm.pL[rowi];
+        ta = a.pm.pA[rowi * D + tid];
+      }
       pmM[u] = ok ? tm : -INFINITY;
       pmL[u] = ok ? tl : 0.f;
       pmA[u] = ok ? ta : 0.f;
@@ -338,18 +391,25 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
         gp = (acc / l) * a.pm.inv_s2[tid % DA];
       } else {
         float m, l;
-        prior_merge_row(a.pm, blockIdx.x, &m, &l);
-        gp = prior_merge_col(a.pm, blockIdx.x, D, tid, DA, m, l);
+        prior_merge_row(a.pm, nl, &m, &l);
+        gp = prior_merge_col(a.pm, nl, D, tid, DA, m, l);
       }
       a.grad_pri[o] = gp;
       a.score[o] = gs + gp;
     }
   }
+  if (a.bump_adam && nl == 0 && tid == 0) a.ctr[2] += 1u;
   DUST_STAMP(a.stamps, 5);
 }
 
-static inline size_t rollout_lds_bytes(int S, int D, int nt, bool tile_in_lds) {
-  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 64 + 2 * (size_t)nt + (size_t)D);
+template <int MODEL>
+__global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rollout_body<MODEL>(a, lds, threadIdx.x, blockDim.x, blockIdx.x, nullptr);
+}
+
+static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
+  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 64 + 2 * (size_t)nt + (size_t)D + 2 * (size_t)M);
 }
 
 }  // namespace dust

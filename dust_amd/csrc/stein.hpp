@@ -46,39 +46,49 @@ struct PairArgs {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)
 
-// rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP, each column
-// multiplied by colscale[d % da].  The source range is one contiguous run of nrows*D floats: coalesced dword loads, 8 in
-// flight per lane (clamped, never predicated: a conditional load makes hipcc branch and wait vmcnt(0) per element).
+// Tile staging: rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP,
+// each column multiplied by colscale[d % da].  The source range is one contiguous run of nrows*D floats: coalesced dword
+// loads in batches of 8 per lane, clamped and never predicated (a conditional load makes hipcc branch and wait vmcnt(0)
+// per element).  Issue and commit are separate so a caller can put several tiles' loads in flight before the first wait.
+template <int NT>
+__device__ __forceinline__ void rows_issue(const float *__restrict__ base, int total, int b, float v[8]) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = base[min(b + u * NT + (int)threadIdx.x, total - 1)];
+}
+template <int LS, int NT, bool SCALE>
+__device__ __forceinline__ void rows_commit(const float v[8], int total, int b, int D, int da, uint32_t magicD, const float *colscale,
+                                            float *dst) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = b + u * NT + (int)threadIdx.x;
+    const int r = (int)__umulhi((uint32_t)idx, magicD), d = idx - r * D;
+    const int cd = da == 1 ? 0 : (da == 2 ? (d & 1) : d % da);  // no runtime modulo on the common control dims
+    if (idx < total) dst[r * LS + d] = SCALE ? v[u] * colscale[cd] : v[u];
+  }
+}
+template <int TR, int DP, int LS, int NT>
+__device__ __forceinline__ void rows_zero(float *dst) {
+  for (int idx = threadIdx.x; idx < TR * DP; idx += NT) dst[(idx / DP) * LS + (idx % DP)] = 0.f;
+}
 template <int TR, int DP, int LS, int NT, bool SCALE>
 __device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0, int nrows, int D, int da, uint32_t magicD,
-                                          const float *colscale, float *dst) {
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < TR * DP; idx += NT) dst[(idx / DP) * LS + (idx % DP)] = 0.f;
-  __syncthreads();
+                                          const float *colscale, float *dst, int first_batch = 0) {
   const int total = nrows * D;  // >= 1: every workgroup owns at least one row
   const float *base = src + (size_t)r0 * D;
-  for (int b = 0; b < total; b += 8 * NT) {
+  for (int b = first_batch * 8 * NT; b < total; b += 8 * NT) {
     float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[min(b + u * NT + tid, total - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = b + u * NT + tid;
-      const int r = (int)__umulhi((uint32_t)idx, magicD), d = idx - r * D;
-      const int cd = da == 1 ? 0 : (da == 2 ? (d & 1) : d % da);  // no runtime modulo on the common control dims
-      if (idx < total) dst[r * LS + d] = SCALE ? v[u] * colscale[cd] : v[u];
-    }
+    rows_issue<NT>(base, total, b, v);
+    rows_commit<LS, NT, SCALE>(v, total, b, D, da, magicD, colscale, dst);
   }
 }
 
 template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
-__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(const PairArgs a) {
+__device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, const int tile_x, const int js, const bool write_through = false) {
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
   constexpr int DP = 8 * CPT;  // padded row length in LDS (multiple of 4 -> b128 reads)
   constexpr int YS = DP + 4;
   constexpr int QG = NT / JC;      // query groups in pass A (4)
   constexpr int QPG = TI / QG;     // queries per group (8)
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Xs = lds;                  // [TI][DP]   queries, pre-scaled by 1/s_d
   float *Ys = Xs + TI * DP;         // [JC][YS]   keys, pre-scaled by 1/s_d
   float *Vs = Ys + JC * YS;         // [JC][YS]   score (Stein), unscaled
@@ -86,14 +96,29 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(c
   float *mrow = kv + TI * (JC + 1); // [TI] running max
   const int tid = threadIdx.x;
   const int D = a.D, da = a.da, N = a.N;
-  const int ib = a.i0 + blockIdx.x * TI;  // first query (global index)
-  const int js = blockIdx.y;
+  const int ib = a.i0 + tile_x * TI;  // first query (global index)
   const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
 
   DUST_STAMP(a.stamps, 0);
-  // ---- query tile -> LDS (zero padded, scaled) ----
-  load_rows<TI, DP, DP, NT, true>(a.X, ib, min(TI, a.i0 + a.n_local - ib), D, da, a.magicD, a.inv_s, Xs);
-  if (tid < TI) mrow[tid] = -INFINITY;
+  // ---- query tile + first key chunk -> LDS: all first-batch loads are in flight before the first wait ----
+  const int nq = min(TI, a.i0 + a.n_local - ib), jc0 = min(JC, jend - jbeg);
+  {
+    float vx[8], vy[8], vv[8];
+    rows_issue<NT>(a.X + (size_t)ib * D, nq * D, 0, vx);
+    rows_issue<NT>(a.Y + (size_t)jbeg * D, jc0 * D, 0, vy);
+    if (MODE != PAIR_PRIOR) rows_issue<NT>(a.V + (size_t)jbeg * D, jc0 * D, 0, vv);
+    rows_zero<TI, DP, DP, NT>(Xs);
+    rows_zero<JC, DP, YS, NT>(Ys);
+    if (MODE != PAIR_PRIOR) rows_zero<JC, DP, YS, NT>(Vs);
+    if (tid < TI) mrow[tid] = -INFINITY;
+    __syncthreads();
+    rows_commit<DP, NT, true>(vx, nq * D, 0, D, da, a.magicD, a.inv_s, Xs);
+    rows_commit<YS, NT, true>(vy, jc0 * D, 0, D, da, a.magicD, a.inv_s, Ys);
+    if (MODE != PAIR_PRIOR) rows_commit<YS, NT, false>(vv, jc0 * D, 0, D, da, a.magicD, a.inv_s, Vs);
+    load_rows<TI, DP, DP, NT, true>(a.X, ib, nq, D, da, a.magicD, a.inv_s, Xs, 1);  // remaining batches (large D only)
+    load_rows<JC, DP, YS, NT, true>(a.Y, jbeg, jc0, D, da, a.magicD, a.inv_s, Ys, 1);
+    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, jbeg, jc0, D, da, a.magicD, a.inv_s, Vs, 1);
+  }
 
   // pass-B ownership: query iB, columns [cB, cB + CPT)
   const int iB = tid >> 3, cB = (tid & 7) * CPT;
@@ -112,9 +137,14 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(c
     // ---- key chunk -> LDS: rows j0..j0+jc-1 are contiguous in HBM ----
     const int jA = tid & (JC - 1), igA = tid / JC;
     const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
-    load_rows<JC, DP, YS, NT, true>(a.Y, j0, jc, D, da, a.magicD, a.inv_s, Ys);
-    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, j0, jc, D, da, a.magicD, a.inv_s, Vs);
-    __syncthreads();
+    if (j0 != jbeg) {  // later chunks of a long slice (the first one was staged with the query tile)
+      rows_zero<JC, DP, YS, NT>(Ys);
+      if (MODE != PAIR_PRIOR) rows_zero<JC, DP, YS, NT>(Vs);
+      __syncthreads();
+      load_rows<JC, DP, YS, NT, true>(a.Y, j0, jc, D, da, a.magicD, a.inv_s, Ys);
+      if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, j0, jc, D, da, a.magicD, a.inv_s, Vs);
+      __syncthreads();
+    }
     DUST_STAMP(a.stamps, 2);
     // ---- pass A: lane = key j, QPG queries per lane; packed math: 2 dims per v_pk_add / v_pk_fma ----
     {
@@ -205,7 +235,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(c
 
   DUST_STAMP(a.stamps, 4);
   // ---- partial outputs (differences were accumulated in scaled coordinates: undo the 1/s_d) ----
-  const int il = blockIdx.x * TI + iB;  // local row
+  const int il = tile_x * TI + iB;  // local row
   if (il < a.n_local) {
     const size_t row = ((size_t)js * a.n_local + il) * D;
 #pragma unroll
@@ -213,15 +243,30 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(c
       if (cB + c < D) {
         const float un = 1.0f / a.inv_s[(cB + c) % da];
         const float va = (c & 1) ? accA[c / 2].y : accA[c / 2].x, vb = (c & 1) ? accB[c / 2].y : accB[c / 2].x;
-        a.pA[row + cB + c] = (MODE == PAIR_PRIOR) ? va * un : va;
+        const float oa = (MODE == PAIR_PRIOR) ? va * un : va;
+        // write_through: sc1 stores (agent-scope relaxed atomics) so an in-launch consumer on another CU can read them
+        // with sc1 loads after the arrival counter, with no release / acquire fence (Guideline 16, R1 form)
+        if (write_through) __hip_atomic_store(a.pA + row + cB + c, oa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.pA[row + cB + c] = oa;
         if (MODE != PAIR_PRIOR) a.pB[row + cB + c] = vb * un;
       }
     if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
-      a.pM[(size_t)js * a.n_local + il] = mrow[iB];
-      a.pL[(size_t)js * a.n_local + il] = accL;
+      if (write_through) {
+        __hip_atomic_store(a.pM + (size_t)js * a.n_local + il, mrow[iB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.pL + (size_t)js * a.n_local + il, accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.pM[(size_t)js * a.n_local + il] = mrow[iB];
+        a.pL[(size_t)js * a.n_local + il] = accL;
+      }
     }
   }
   DUST_STAMP(a.stamps, 5);
+}
+
+template <int MODE, int CPT>
+__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(const PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  pairwise_body<MODE, CPT>(a, lds, blockIdx.x, blockIdx.y);
 }
 
 static inline size_t pairwise_lds_bytes(int mode, int CPT) {
@@ -309,7 +354,9 @@ struct UpdateArgs {
   int optimizer, apply;  // apply = 0: only materialise phi (stage-wise SVMPC.phi)
   float lr, beta1, beta2, eps;
   float inv_l2, inv_n;
-  int step;  // Adam step count (1-based)
+  uint32_t *ctr;  // device counters {tick, iter, adam_step}; this kernel advances iter after use
+  unsigned int *fused_cnt;  // [fused_tiles] hand-off counters of the fused prior+rollout launch: re-armed (zeroed) here
+  int fused_tiles;
   const float *pA, *pB;  // [JS][n_local][D]
   float *phi;     // [N][D]
   float *theta;   // [N][D]
@@ -318,7 +365,12 @@ struct UpdateArgs {
 
 __global__ void update_kernel(const UpdateArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < a.fused_tiles) a.fused_cnt[idx] = 0u;
   if (idx >= a.n_local * a.D) return;
+  // counters: this kernel READS adam_step (bumped by the rollout kernel of the same iteration) and ADVANCES iter (read
+  // only by rollout kernels) - no launch both reads and writes the same counter
+  const float adam_t = (float)a.ctr[2];
+  if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   float sa = 0.f, sb = 0.f;
@@ -350,7 +402,7 @@ __global__ void update_kernel(const UpdateArgs a) {
     v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
     a.adam_m[o] = m;
     a.adam_v[o] = v;
-    const float bc1 = 1.f - powf(a.beta1, (float)a.step), bc2 = 1.f - powf(a.beta2, (float)a.step);
+    const float bc1 = 1.f - powf(a.beta1, adam_t), bc2 = 1.f - powf(a.beta2, adam_t);
     const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
     th = th - (a.lr / bc1) * (m / denom);
   }
@@ -360,7 +412,10 @@ __global__ void update_kernel(const UpdateArgs a) {
 // optimiser update from an already materialised phi (K2 branch, which writes phi directly)
 __global__ void update_from_phi_kernel(const UpdateArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < a.fused_tiles) a.fused_cnt[idx] = 0u;
   if (idx >= a.n_local * a.D) return;
+  const float adam_t = (float)a.ctr[2];
+  if (idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   float th = a.theta[o];
@@ -373,7 +428,7 @@ __global__ void update_from_phi_kernel(const UpdateArgs a) {
     v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
     a.adam_m[o] = m;
     a.adam_v[o] = v;
-    const float bc1 = 1.f - powf(a.beta1, (float)a.step), bc2 = 1.f - powf(a.beta2, (float)a.step);
+    const float bc1 = 1.f - powf(a.beta1, adam_t), bc2 = 1.f - powf(a.beta2, adam_t);
     const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
     th = th - (a.lr / bc1) * (m / denom);
   }
