@@ -264,16 +264,21 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       csum += red[8 + w];
     }
   }
+  // un-normalised weights stay in LDS; the 1/Z factors are applied once to the reduced sums in stage 4.  With
+  // temperature = 1/alpha (every demo) omega and w are the same softmax: one exp and one accumulation are skipped.
+  const bool same_w = (a.alpha * a.temp == 1.0f);
   float zw = 0.f, zo = 0.f;
   for (int s = tid; s < S; s += nt) {
     const float c = cst[s];
-    const float lo = (-1.0f * (c - cmin)) / a.temp;  // disco.py:381 with beta := per-policy min (beta cancels in omega)
-    const float eo = expf(lo);
     const float ew = expf(-c * a.alpha - (-cmin * a.alpha));  // svmpc.py:51 softmax(-costs * alpha)
-    omg[s] = eo;
-    zo += eo;
     cst[s] = ew;
     zw += ew;
+    if (!same_w) {
+      const float lo = (-1.0f * (c - cmin)) / a.temp;  // disco.py:381 with beta := per-policy min (beta cancels in omega)
+      const float eo = expf(lo);
+      omg[s] = eo;
+      zo += eo;
+    }
   }
   {
     const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
@@ -283,19 +288,18 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       red[16 + wid] = zw;
       red[24 + wid] = zo;
     }
-    __syncthreads();
+    __syncthreads();  // also publishes every lane's cst[] / omg[] to the stage-4 readers
     zw = red[16];
     zo = red[24];
     for (int w = 1; w < nw; ++w) {
       zw += red[16 + w];
       zo += red[24 + w];
     }
+    if (same_w) zo = zw;
   }
-  for (int s = tid; s < S; s += nt) {
-    cst[s] = cst[s] / zw;
-    omg[s] = omg[s] / zo;
-    if (a.omegaT) a.omegaT[(size_t)n * S + s] = omg[s];
-  }
+  const float *wom = same_w ? cst : omg;
+  if (a.omegaT)
+    for (int s = tid; s < S; s += nt) a.omegaT[(size_t)n * S + s] = wom[s] / zo;
   if (tid == 0 && !a.costs_in) {
     if (a.lik == DUST_LIK_EXP_UTILITY)  // likelihoods.py:127-135
       a.logl[n] = ((-cmin * a.alpha) + logf(zw)) - logf((float)S);
@@ -303,7 +307,6 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       a.logl[n] = -a.alpha * (csum / (float)S);
     a.eta[n] = (-cmin / a.temp) + logf(zo);
   }
-  __syncthreads();
 
   DUST_STAMP(a.stamps, 3);
   // ---- 4. weighted reductions over s: grad_lik (svmpc.py:52-54) and a_mat += sum_s omega eps (disco.py:387-392) ----
@@ -358,8 +361,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
 #pragma unroll 8
     for (int s = q; s < S; s += Q) {
       const float av = tile[s * Dp + j];
-      g = fmaf(cst[s], (av - thj) * is2, g);
-      am = fmaf(omg[s], av - base, am);
+      const float d = av - thj;
+      g = fmaf(cst[s], d * is2, g);
+      if (!same_w) am = fmaf(omg[s], av - base, am);
+      else if (a.eps_base_mode == 0) am = fmaf(cst[s], av - base, am);  // base = a_seq; with base = theta it is g / is2
     }
   }
   part[tid] = g;
@@ -373,6 +378,9 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       as += part[nt + qq * D + tid];
     }
     const size_t o = (size_t)n * D + tid;
+    gs = gs / zw;
+    if (same_w && a.eps_base_mode) as = gs * (a.sigma_a[tid % DA] * a.sigma_a[tid % DA]);  // sum_s w (a - theta)
+    else as = as / zo;
     a.grad_lik[o] = gs;
     if (a.update_a_mat) a.a_mat[o] += as;
     if (a.merge_prior) {  // prior half of the score (svmpc.py:38-41,56) from the pairwise kernel's slice partials

@@ -285,22 +285,24 @@ struct PriorMerge {
 // loads are issued in batches of 8 with clamped (never predicated) indices so they overlap instead of serialising
 __device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, float *m_out, float *l_out) {
   float m = -INFINITY, l = 0.f;
-  for (int q0 = 0; q0 < pm.JS; q0 += 8) {
-    float mq[8], lq[8];
+  for (int q0 = 0; q0 < pm.JS; q0 += 16) {  // 32 independent loads in flight: one round trip for JS <= 16
+    float mq[16], lq[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const size_t r = (size_t)min(q0 + u, pm.JS - 1) * pm.n_local + il;
       mq[u] = pm.pM[r];
       lq[u] = pm.pL[r];
     }
+    float mc = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (q0 + u < pm.JS && mq[u] != -INFINITY) {  // online combine (fixed order)
-        const float mn = fmaxf(m, mq[u]);
-        l = l * ((m == -INFINITY) ? 0.f : expf(m - mn)) + lq[u] * expf(mq[u] - mn);
-        m = mn;
-      }
-    }
+    for (int u = 0; u < 16; ++u) mc = fmaxf(mc, (q0 + u < pm.JS) ? mq[u] : -INFINITY);
+    const float mn = fmaxf(m, mc);
+    float lc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (q0 + u < pm.JS && mq[u] != -INFINITY) lc += lq[u] * expf(mq[u] - mn);
+    l = ((m == -INFINITY) ? 0.f : l * expf(m - mn)) + lc;
+    m = mn;
   }
   *m_out = m;
   *l_out = l;
