@@ -79,7 +79,8 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if world > 1 or (under_launcher and os.environ.get("DUST_BENCH_FORCE_DIST")):
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
@@ -104,7 +105,7 @@ def main():
     state = np.array([3.0, 0.0], np.float32)
     common = dict(model=w["model"], N=n_tot, S=w["S"], M=1, H=w["H"], kernel=w["kernel"], lr=w["lr"], alpha=w["alpha"],
                   sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
-    if n_gpus == 1:
+    if dist is None:
         ctx = Context(**common)
         ctx.set_theta(theta)
         ctx.set_prior(mu)

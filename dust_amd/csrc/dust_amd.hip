@@ -86,6 +86,9 @@ struct dust_ctx {
   unsigned int *fused_cnt;  // [tiles + 1]: per-tile arrival counters of the fused launch, last word = spin-timeout flag
   int fused_tiles;
   bool fused_dirty;   // a fused launch ran and no update kernel has re-armed the counters yet
+  unsigned int *stein_cnt;  // [tiles + 1]: arrival counters of the Stein+update launch (re-armed by the next rollout launch)
+  int stein_tiles;
+  bool stein_dirty;
   float *state_pin;   // pinned host ring [RING][4] feeding state_dev by async copies (no host sync per tick)
   hipEvent_t ring_ev[16];
   int ring_pos;
@@ -246,6 +249,7 @@ static void free_all(dust_ctx *c) {
   if (c->graph) (void)hipGraphDestroy(c->graph);
   if (c->ctr_dev) (void)hipFree(c->ctr_dev);
   if (c->fused_cnt) (void)hipFree(c->fused_cnt);
+  if (c->stein_cnt) (void)hipFree(c->stein_cnt);
   if (c->state_pin) (void)hipHostFree(c->state_pin);
   for (auto &e : c->ring_ev)
     if (e) (void)hipEventDestroy(e);
@@ -360,8 +364,13 @@ extern "C" int dust_sync(dust_ctx *c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->fused_cnt) {  // bounded spin of the fused launch's in-kernel hand-off: report instead of hanging
     unsigned int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c->fused_cnt + c->fused_tiles, sizeof flag, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(DUST_ERR_HIP, "fused prior+rollout launch: hand-off spin timed out (results of that tick are invalid)");
+  }
+  if (c->stein_cnt) {
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->stein_cnt + (size_t)c->stein_tiles * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(DUST_ERR_HIP, "Stein+update launch: hand-off spin timed out (results of that tick are invalid)");
   }
   return DUST_OK;
 }
@@ -569,12 +578,15 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   *JS = (c->N + *slice - 1) / *slice;
 }
 
+static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }  // pass-B columns per lane
+
 static PriorMerge prior_merge_args(const dust_ctx *c) {
   PriorMerge pm;
   memset(&pm, 0, sizeof pm);
   int tiles, slice;
   pair_geometry(c, &tiles, &pm.JS, &slice);
   pm.n_local = c->nloc;
+  pm.ldp = 8 * cpt_for(c->D);
   pm.pA = c->pA;
   pm.pM = c->pM;
   pm.pL = c->pL;
@@ -640,6 +652,8 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.seed = c->cfg.seed;
   a.ctr = c->ctr_dev;
   a.bump_adam = o.bump_adam;
+  a.rearm = c->stein_cnt;
+  a.rearm_n = c->stein_cnt ? c->stein_tiles : 0;
   if (a.params == nullptr) {
     a.coef_given = 1;
     host_coef(c->cfg, a.coef_host);
@@ -674,6 +688,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
   }
   HIP_TRY(hipGetLastError());
   c->actions_valid = o.want_actions;
+  c->stein_dirty = false;
   return DUST_OK;
 }
 
@@ -813,7 +828,6 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
 
 // ---------------------------------------------------------------------------------------------------------------
 // pairwise passes (tiled: PAIR_TI queries x key slices; partials combined by the next kernel in the chain)
-static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }
 
 template <int MODE>
 static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
@@ -836,7 +850,7 @@ static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
 }
 
 static int ensure_partials(dust_ctx *c, int JS) {
-  const size_t nd = (size_t)JS * c->nloc * c->D, nn = (size_t)JS * c->nloc;
+  const size_t nd = (size_t)JS * c->nloc * 8 * cpt_for(c->D), nn = (size_t)JS * c->nloc;
   TRY(ensure(&c->pA, &c->pA_cap, nd));
   TRY(ensure(&c->pB, &c->pB_cap, nd));
   TRY(ensure(&c->pM, &c->pM_cap, nn));
@@ -902,15 +916,15 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
     if (c->capturing) return DUST_OK;
     if (c->fused_cnt) HIP_TRY(hipFree(c->fused_cnt));
     c->fused_cnt = nullptr;
-    TRY(dalloc(&c->fused_cnt, (size_t)f.tiles + 1));
+    TRY(dalloc(&c->fused_cnt, ((size_t)f.tiles + 1) * CNT_STRIDE));
     c->fused_tiles = f.tiles;
     c->fused_dirty = true;
   }
   if (c->fused_dirty)  // previous fused launch was not followed by an update kernel (which re-arms the counters)
-    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, ((size_t)f.tiles + 1) * sizeof(unsigned int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, ((size_t)f.tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
   f.n_pair_blocks = f.tiles * f.pa.JS;
   f.cnt = c->fused_cnt;
-  f.timeout_flag = c->fused_cnt + f.tiles;
+  f.timeout_flag = c->fused_cnt + (size_t)f.tiles * CNT_STRIDE;
   const int grid = f.n_pair_blocks + c->nloc / f.per_block;
 #define DUST_LAUNCH_FUSED(MODEL, CPT)                                                                                                  \
   do {                                                                                                                                  \
@@ -932,6 +946,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
 #undef DUST_LAUNCH_FUSED
   HIP_TRY(hipGetLastError());
   c->fused_dirty = true;
+  c->stein_dirty = false;
   c->actions_valid = false;
   *done = true;
   return DUST_OK;
@@ -974,6 +989,7 @@ static UpdateArgs update_args(dust_ctx *c, int apply) {
   const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;  // softplus(0) = ln 2 (svmpc.py:78 typo keeps it)
   u.inv_l2 = 1.0f / (ell * ell);
   u.inv_n = 1.0f / c->N;
+  u.ldp = 8 * cpt_for(c->D);
   u.pA = c->pA;
   u.pB = c->pB;
   u.phi = c->phi;
@@ -1040,6 +1056,46 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     a.pA = c->pA;
     a.pB = c->pB;
     a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_STEIN : nullptr;
+    static const bool no_fuse = getenv("DUST_NO_FUSE") != nullptr;  // development switch
+    const int cpt = cpt_for(a.D);
+    const size_t lds = pairwise_lds_bytes(PAIR_K1, cpt);
+    bool fuse = apply && !c->prof && !no_fuse && cpt <= 8;  // D <= 64: >= 2 workgroups per CU co-resident
+    if (fuse && (!c->stein_cnt || c->stein_tiles != tiles)) {
+      if (c->capturing) fuse = false;
+      else {
+        if (c->stein_cnt) HIP_TRY(hipFree(c->stein_cnt));
+        c->stein_cnt = nullptr;
+        TRY(dalloc(&c->stein_cnt, ((size_t)tiles + 1) * CNT_STRIDE));
+        c->stein_tiles = tiles;
+        c->stein_dirty = true;  // the rollout launch that preceded this call did not know the buffer
+      }
+    }
+    if (fuse) {
+      // Stein tiles + update role in ONE launch (fused.hpp): the update launch and its ramp disappear
+      if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+      SteinUpdateArgs f;
+      memset(&f, 0, sizeof f);
+      f.pa = a;
+      f.ua = update_args(c, 1);
+      f.tiles = tiles;
+      f.n_pair_blocks = tiles * a.JS;
+      f.cnt = c->stein_cnt;
+      f.timeout_flag = c->stein_cnt + (size_t)tiles * CNT_STRIDE;
+      const int grid = f.n_pair_blocks + (n + PAIR_NT - 1) / PAIR_NT;
+#define DUST_LAUNCH_SU(MODE, CPT) stein_update_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
+      if (c->cfg.kernel == DUST_KERNEL_IMQ) {
+        if (cpt == 4) DUST_LAUNCH_SU(PAIR_IMQ, 4);
+        else DUST_LAUNCH_SU(PAIR_IMQ, 8);
+      } else {
+        if (cpt == 4) DUST_LAUNCH_SU(PAIR_K1, 4);
+        else DUST_LAUNCH_SU(PAIR_K1, 8);
+      }
+#undef DUST_LAUNCH_SU
+      HIP_TRY(hipGetLastError());
+      c->stein_dirty = true;
+      c->fused_dirty = false;
+      return DUST_OK;
+    }
     Prof p(c, DUST_K_STEIN);
     if (c->cfg.kernel == DUST_KERNEL_IMQ) TRY(launch_pair<PAIR_IMQ>(c, a, tiles));
     else TRY(launch_pair<PAIR_K1>(c, a, tiles));

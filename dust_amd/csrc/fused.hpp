@@ -27,7 +27,7 @@ struct FusedArgs {
   int tiles, n_pair_blocks;
   int sub_nt, per_block;     // rollout role: lanes per particle, particles per 256-lane workgroup
   int lds_roll_floats;       // LDS floats per particle sub-block
-  unsigned int *cnt;         // [tiles] arrival counters
+  unsigned int *cnt;         // [tiles][CNT_STRIDE] arrival counters, one per 128-byte line
   unsigned int *timeout_flag;
 };
 
@@ -39,12 +39,58 @@ __global__ __launch_bounds__(PAIR_NT, 2) void fused_prior_rollout_kernel(const F
     pairwise_body<PAIR_PRIOR, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores ...
     __syncthreads();                                    // ... before the one lane that signals for the workgroup
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     const int b = (int)blockIdx.x - f.n_pair_blocks;
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
     const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag};
     rollout_body<MODEL>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stein pass + optimiser update in one launch.  Workgroups [0, n_pair) run the Stein tiles (pairwise_body<K1|IMQ>) and
+// publish their slice partials write-through + one arrival per (tile, slice); workgroups [n_pair, ...) are the update
+// role: 256 consecutive (particle, dim) elements each, waiting until the (at most two) query tiles they touch have all JS
+// arrivals, then combining the partials in the fixed slice order (bitwise the same result as the two-launch form).
+// The update role has the HIGHER block indices: it only ever waits on work dispatched before it; the spin is bounded.
+// The arrival counters are re-armed by the next rollout launch (RolloutArgs::rearm), as fused_cnt is by the update role.
+struct SteinUpdateArgs {
+  PairArgs pa;
+  UpdateArgs ua;
+  int tiles, n_pair_blocks;
+  unsigned int *cnt;  // [tiles][CNT_STRIDE]: one counter per 128-byte line (pollers of different tiles must not share a line)
+  unsigned int *timeout_flag;
+};
+
+template <int MODE, int CPT>
+__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kernel(const SteinUpdateArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < f.n_pair_blocks) {
+    const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
+    pairwise_body<MODE, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const int b = (int)blockIdx.x - f.n_pair_blocks;
+    const int total = f.ua.n_local * f.ua.D;
+    const int idx = b * PAIR_NT + (int)threadIdx.x;
+    if (threadIdx.x == 0) {
+      const int t0 = (min(b * PAIR_NT, total - 1) / f.ua.D) / PAIR_TI;
+      const int t1 = (min(b * PAIR_NT + PAIR_NT - 1, total - 1) / f.ua.D) / PAIR_TI;
+      unsigned int spins = 0;
+      for (int t = t0; t <= t1; ++t)
+        while (__hip_atomic_load(f.cnt + t * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)f.pa.JS) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) {
+            *f.timeout_flag = 1u;
+            break;
+          }
+        }
+    }
+    __syncthreads();
+    update_body<true>(f.ua, idx);
   }
 }
 

@@ -23,6 +23,7 @@
 namespace dust {
 
 enum { NOISE_EPS = 0, NOISE_ACTIONS = 1, NOISE_PHILOX = 2 };
+enum { CNT_STRIDE = 32 };  // dwords between in-launch arrival counters: one 128-byte line each
 
 struct RolloutArgs {
   DevModel dm;
@@ -39,6 +40,8 @@ struct RolloutArgs {
   const float *state;   // [ds] (device; refreshed by an async copy from a pinned ring before each tick)
   uint32_t *ctr;        // device counters {tick, iter, adam_step}: the Philox stream position (static under hipGraph replay)
   int bump_adam;        // an optimiser step follows: advance adam_step (read by update_kernel, never by this kernel)
+  unsigned int *rearm;  // arrival counters of the Stein+update launch (fused.hpp), zeroed here for its next use, or nullptr
+  int rearm_n;
   int coef_given;       // no sampled parameters: the model coefficients were evaluated once on the host
   float coef_host[2];
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
@@ -83,7 +86,7 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
 // In-launch hand-off from the prior-pass workgroups of a fused launch (fused.hpp): per query tile, a monotonic arrival
 // counter; `target` arrivals mean every key slice of that tile has published its partials.
 struct FusedWait {
-  const unsigned int *cnt;  // [tiles]
+  const unsigned int *cnt;  // [tiles][CNT_STRIDE]
   unsigned int target;
   unsigned int *timeout_flag;
 };
@@ -318,7 +321,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     // release + counter add; poll relaxed from ONE lane, acquire once, then the barrier admits the other lanes
     // (cdna_hip_programming.md Guideline 16, counter form).  The spin is bounded.
     if (threadIdx.x == 0) {
-      const unsigned int *cp = fw->cnt + (nl / PAIR_TI);
+      const unsigned int *cp = fw->cnt + (nl / PAIR_TI) * CNT_STRIDE;
       unsigned int spins = 0;
       while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw->target) {
         __builtin_amdgcn_s_sleep(4);
@@ -343,11 +346,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       if (fw) {
         tm = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tl = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ta = __hip_atomic_load(a.pm.pA + rowi * D + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ta = __hip_atomic_load(a.pm.pA + rowi * a.pm.ldp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         tm = a.pm.pM[rowi];
         tl = a.pm.pL[rowi];
-        ta = a.pm.pA[rowi * D + tid];
+        ta = a.pm.pA[rowi * a.pm.ldp + tid];
       }
       pmM[u] = ok ? tm : -INFINITY;
       pmL[u] = ok ? tl : 0.f;
@@ -407,6 +410,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
   }
   if (a.bump_adam && nl == 0 && tid == 0) a.ctr[2] += 1u;
+  if (a.rearm && nl == 0)
+    for (int t = tid; t < a.rearm_n; t += nt) a.rearm[t * CNT_STRIDE] = 0u;
   DUST_STAMP(a.stamps, 5);
 }
 

@@ -37,13 +37,19 @@ struct PairArgs {
   const float *logmix; // [N] prior mixture log-weights
   float inv_s[4];      // 1/sigma_p[d % da] (prior) or 1/ell (Stein)
   // partial outputs, indexed [js][i_local]
-  float *pA;           // [JS][n_local][D]  prior: sum_k p (mu - x)      Stein: sum_j k s_j
-  float *pB;           // [JS][n_local][D]                               Stein: sum_j k' (x_i - x_j)
+  float *pA;           // [JS][n_local][DP] prior: sum_k p (mu - x)      Stein: sum_j k s_j
+  float *pB;           // [JS][n_local][DP]                              Stein: sum_j k' (x_i - x_j)
   float *pM;           // [JS][n_local]     prior: slice max of the logits
   float *pL;           // [JS][n_local]     prior: sum exp(logit - max)
   unsigned long long *stamps;  // diagnostic build only
 };
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+// 16-byte global store; `wt` = write-through to memory (sc1), readable by sc1 loads from any CU of the device in the same launch
+__device__ __forceinline__ void store16(float *p, v4f v, bool wt) {
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<v4f *>(p) = v;
+}
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)
 
 // Tile staging: rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP,
@@ -237,19 +243,27 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   // ---- partial outputs (differences were accumulated in scaled coordinates: undo the 1/s_d) ----
   const int il = tile_x * TI + iB;  // local row
   if (il < a.n_local) {
-    const size_t row = ((size_t)js * a.n_local + il) * D;
+    // partial rows are padded to DP floats: every lane stores whole 16-byte groups, the 8 lanes of a row one contiguous
+    // DP*4-byte run (pad columns hold zeros).  Full-line stores matter for the write-through form: dword-granular sc1
+    // stores cost a memory transaction each.
+    const size_t row = ((size_t)js * a.n_local + il) * DP;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c)
-      if (cB + c < D) {
-        const float un = 1.0f / a.inv_s[(cB + c) % da];
-        const float va = (c & 1) ? accA[c / 2].y : accA[c / 2].x, vb = (c & 1) ? accB[c / 2].y : accB[c / 2].x;
-        const float oa = (MODE == PAIR_PRIOR) ? va * un : va;
-        // write_through: sc1 stores (agent-scope relaxed atomics) so an in-launch consumer on another CU can read them
-        // with sc1 loads after the arrival counter, with no release / acquire fence (Guideline 16, R1 form)
-        if (write_through) __hip_atomic_store(a.pA + row + cB + c, oa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else a.pA[row + cB + c] = oa;
-        if (MODE != PAIR_PRIOR) a.pB[row + cB + c] = vb * un;
+    for (int c = 0; c < CPT; c += 4) {
+      v4f oa, ob;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = cB + c + k;
+        const float un = 1.0f / a.inv_s[da == 1 ? 0 : (da == 2 ? (col & 1) : col % da)];
+        const float va = ((c + k) & 1) ? accA[(c + k) / 2].y : accA[(c + k) / 2].x;
+        const float vb = ((c + k) & 1) ? accB[(c + k) / 2].y : accB[(c + k) / 2].x;
+        oa[k] = (MODE == PAIR_PRIOR) ? va * un : va;
+        ob[k] = vb * un;
       }
+      // write_through: sc1 stores so an in-launch consumer on another CU can read them with sc1 loads after the arrival
+      // counter, with no release / acquire fence (Guideline 16, R1 form)
+      store16(a.pA + row + cB + c, oa, write_through);
+      if (MODE != PAIR_PRIOR) store16(a.pB + row + cB + c, ob, write_through);
+    }
     if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
       if (write_through) {
         __hip_atomic_store(a.pM + (size_t)js * a.n_local + il, mrow[iB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -278,6 +292,7 @@ static inline size_t pairwise_lds_bytes(int mode, int CPT) {
 // columns the caller owns and log p(x_i).  Used by rollout_kernel (score) and logp_merge_kernel (forward).
 struct PriorMerge {
   int JS, n_local;
+  int ldp;  // row stride of pA (D padded to 8*CPT)
   const float *pA, *pM, *pL;
   float inv_s2[4];
   float log_norm;  // -H sum(log sigma_p) - D/2 log(2 pi)
@@ -315,7 +330,7 @@ __device__ __forceinline__ float prior_merge_col(const PriorMerge &pm, int il, i
     for (int u = 0; u < 8; ++u) {
       const size_t r = (size_t)min(q0 + u, pm.JS - 1) * pm.n_local + il;
       mq[u] = pm.pM[r];
-      aq[u] = pm.pA[r * D + d];
+      aq[u] = pm.pA[r * pm.ldp + d];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -353,21 +368,24 @@ __global__ void prior_finish_kernel(const PriorFinishArgs a) {
 // optimizer.step()).  Writes phi, theta in place (row-major) - each element is touched by exactly one lane.
 struct UpdateArgs {
   int N, D, i0, n_local, JS;
+  int ldp;               // row stride of pA / pB (D padded to 8*CPT)
   int optimizer, apply;  // apply = 0: only materialise phi (stage-wise SVMPC.phi)
   float lr, beta1, beta2, eps;
   float inv_l2, inv_n;
   uint32_t *ctr;  // device counters {tick, iter, adam_step}; this kernel advances iter after use
   unsigned int *fused_cnt;  // [fused_tiles] hand-off counters of the fused prior+rollout launch: re-armed (zeroed) here
   int fused_tiles;
-  const float *pA, *pB;  // [JS][n_local][D]
+  const float *pA, *pB;  // [JS][n_local][ldp]
   float *phi;     // [N][D]
   float *theta;   // [N][D]
   float *adam_m, *adam_v;
 };
 
-__global__ void update_kernel(const UpdateArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < a.fused_tiles) a.fused_cnt[idx] = 0u;
+// `sc1`: the partials were published inside the SAME launch (fused.hpp stein_update_kernel) with write-through stores and
+// must be read with sc1 loads; across a kernel boundary plain loads do.
+template <bool SC1>
+__device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) {
+  if (idx < a.fused_tiles) a.fused_cnt[idx * 32] = 0u;  // CNT_STRIDE (rollout.hpp): one counter per 128-byte line
   if (idx >= a.n_local * a.D) return;
   // counters: this kernel READS adam_step (bumped by the rollout kernel of the same iteration) and ADVANCES iter (read
   // only by rollout kernels) - no launch both reads and writes the same counter
@@ -375,17 +393,23 @@ __global__ void update_kernel(const UpdateArgs a) {
   if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
+  float th = a.apply ? a.theta[o] : 0.f;  // independent of the partials: in flight together with them
   float sa = 0.f, sb = 0.f;
-  for (int q0 = 0; q0 < a.JS; q0 += 8) {  // 16 independent loads in flight, fixed summation order
-    float va[8], vb[8];
+  for (int q0 = 0; q0 < a.JS; q0 += 16) {  // 32 independent loads in flight (one round trip for JS <= 16), fixed summation order
+    float va[16], vb[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const size_t p = ((size_t)min(q0 + u, a.JS - 1) * a.n_local + il) * a.D + d;
-      va[u] = a.pA[p];
-      vb[u] = a.pB[p];
+    for (int u = 0; u < 16; ++u) {
+      const size_t p = ((size_t)min(q0 + u, a.JS - 1) * a.n_local + il) * a.ldp + d;
+      if (SC1) {
+        va[u] = __hip_atomic_load(a.pA + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb[u] = __hip_atomic_load(a.pB + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        va[u] = a.pA[p];
+        vb[u] = a.pB[p];
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 16; ++u)
       if (q0 + u < a.JS) {
         sa += va[u];
         sb += vb[u];
@@ -394,7 +418,6 @@ __global__ void update_kernel(const UpdateArgs a) {
   const float phi = sb * a.inv_l2 + sa * a.inv_n;
   a.phi[o] = phi;
   if (!a.apply) return;
-  float th = a.theta[o];
   const float g = -phi;
   if (a.optimizer == DUST_OPT_SGD) {
     th = fmaf(-a.lr, g, th);  // torch SGD: p.add_(grad, alpha=-lr), a vectorised fmadd
@@ -411,10 +434,12 @@ __global__ void update_kernel(const UpdateArgs a) {
   a.theta[o] = th;
 }
 
+__global__ void update_kernel(const UpdateArgs a) { update_body<false>(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
 // optimiser update from an already materialised phi (K2 branch, which writes phi directly)
 __global__ void update_from_phi_kernel(const UpdateArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < a.fused_tiles) a.fused_cnt[idx] = 0u;
+  if (idx < a.fused_tiles) a.fused_cnt[idx * 32] = 0u;
   if (idx >= a.n_local * a.D) return;
   const float adam_t = (float)a.ctr[2];
   if (idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
