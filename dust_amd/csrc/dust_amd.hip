@@ -225,6 +225,8 @@ static int validate(const dust_config *g) {
   }
   const int D = g->horizon * g->dim_a;
   if (D > 128) return fail(DUST_ERR_UNSUPPORTED, "H*da = %d > 128 not supported by the kernels", D);
+  if ((double)g->n_samples * g->n_policies * D >= 1073741824.0)
+    return fail(DUST_ERR_UNSUPPORTED, "n_samples * n_policies * H * da >= 2^30: the noise tile offsets are 32-bit");
   if (g->dim_p < 0 || g->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p out of range");
   if (g->kernel < 0 || g->kernel > DUST_KERNEL_IMQ) return fail(DUST_ERR_INVALID, "bad kernel id");
   if (g->optimizer != DUST_OPT_SGD && g->optimizer != DUST_OPT_ADAM) return fail(DUST_ERR_UNSUPPORTED, "optimizer must be SGD or Adam");

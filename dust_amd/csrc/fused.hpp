@@ -32,7 +32,7 @@ struct FusedArgs {
 };
 
 template <int MODEL, int CPT>
-__global__ __launch_bounds__(PAIR_NT, 2) void fused_prior_rollout_kernel(const FusedArgs f) {
+__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollout_kernel(const FusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x < f.n_pair_blocks) {
     const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
@@ -41,10 +41,11 @@ __global__ __launch_bounds__(PAIR_NT, 2) void fused_prior_rollout_kernel(const F
     __syncthreads();                                    // ... before the one lane that signals for the workgroup
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    const int b = (int)blockIdx.x - f.n_pair_blocks;
+    const int nb = (int)gridDim.x - f.n_pair_blocks;
+    const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
     const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag};
-    rollout_body<MODEL>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+    rollout_body<MODEL, 12>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
   }
 }
 

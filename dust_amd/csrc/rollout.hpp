@@ -83,6 +83,10 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   *cos_th = cs;
 }
 
+// Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (__syncthreads()
+// drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // In-launch hand-off from the prior-pass workgroups of a fused launch (fused.hpp): per query tile, a monotonic arrival
 // counter; `target` arrivals mean every key slice of that tile has published its partials.
 struct FusedWait {
@@ -93,7 +97,7 @@ struct FusedWait {
 
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
 // wide (every sub-block of a workgroup runs the same control flow), reductions are sub-block local.
-template <int MODEL>
+template <int MODEL, int NB /* staged noise loads in flight per lane: 32 standalone, 16 inside the fused launch (VGPR budget) */>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, const int tid, const int nt, const int nl,
                                              const FusedWait *fw) {
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
@@ -105,8 +109,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   float *tile = a.tile_scratch ? a.tile_scratch + (size_t)nl * S * Dp : lds;  // [S][Dp] actions
   float *cst = a.tile_scratch ? lds : lds + (size_t)S * Dp;                            // [S] costs -> weights
   float *omg = cst + S;    // [S] omega
-  float *red = omg + S;    // [64] reduction scratch
-  float *part = red + 64;  // [2][nt] partial sums for the weighted reductions
+  float *red = omg + S;    // [96] reduction scratch, flags, prior slice words
+  float *part = red + 96;  // [2][nt] partial sums for the weighted reductions
 
   DUST_STAMP(a.stamps, 0);
   // ---- 1. stage the action tile (a1: actions = theta + L eps) ----
@@ -115,8 +119,9 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // red[40]: "some action of this particle is NaN" (the branch-free rollout loop clamps with v_med3_f32, which would
   // swallow a NaN that torch.clamp propagates: such particles take the general loop)
   if (tid == 0) red[40] = 0.f;
-  float thv = 0.f;
+  float thv = 0.f, amv = 0.f;
   if (tid < D) thv = a.theta[(size_t)n * D + tid];
+  if (tid < D && a.update_a_mat) amv = a.a_mat[(size_t)n * D + tid];  // consumed at the very end: no round trip there
   float x0[DS];
 #pragma unroll
   for (int k = 0; k < DS; ++k) x0[k] = a.state[k];
@@ -132,22 +137,36 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       coefs[2 * m + 1] = c.c1;
     }
   }
+  // caller-supplied noise: the first 32 loads of every lane are issued BEFORE the wait on the theta row, so the two
+  // round trips overlap (at S*D <= 32 nt - cfg2 - that is the whole tile: one memory round trip for stage 1)
+  const int total = S * D;
+  float v[NB];
+  const char *nbase = reinterpret_cast<const char *>(a.noise + (size_t)n * D);
+  const uint32_t rowstride = (uint32_t)N * (uint32_t)D;  // S*N*D < 2^30 is checked at configuration time
+  if (a.noise_mode != NOISE_PHILOX) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      // clamp instead of predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
+      const int idx = min(u * nt + tid, total - 1);
+      const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
+      v[u] = *reinterpret_cast<const float *>(nbase + (((uint32_t)s * rowstride + (uint32_t)j) << 2));  // uniform base + 32-bit byte offset: one VGPR per address
+    }
+  }
   if (tid < D) th[tid] = thv;
   __syncthreads();
   if (tid < D && thv != thv) red[40] = 1.f;
   if (a.noise_mode != NOISE_PHILOX) {
-    const int total = S * D;
-    for (int base = 0; base < total; base += 16 * nt) {
-      float v[16];
+    for (int base = 0; base < total; base += NB * nt) {
+      if (base) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight per lane
-        // clamp instead of predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
-        const int idx = min(base + u * nt + tid, total - 1);
-        const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-        v[u] = a.noise[((size_t)s * N + n) * D + j];
+        for (int u = 0; u < NB; ++u) {
+          const int idx = min(base + u * nt + tid, total - 1);
+          const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
+          v[u] = *reinterpret_cast<const float *>(nbase + (((uint32_t)s * rowstride + (uint32_t)j) << 2));
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int idx = base + u * nt + tid;
         const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
         if (idx < total) {
@@ -260,6 +279,53 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
   }
 
+  if (fw) {
+    // fused launch: the prior-pass workgroups of this launch publish the partials of query tile nl/32 with an agent-scope
+    // release + counter add; poll relaxed from ONE lane, acquire once, then the barrier admits the other lanes
+    // (cdna_hip_programming.md Guideline 16, counter form).  The spin is bounded.
+    if (threadIdx.x == 0) {
+      const unsigned int *cp = fw->cnt + (nl / PAIR_TI) * CNT_STRIDE;
+      unsigned int spins = 0;
+      while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw->target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 24)) {
+          *fw->timeout_flag = 1u;
+          break;
+        }
+      }
+    }
+    __syncthreads();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
+  }
+  // prior partials of this row: issue the (independent) loads now, consume them after the reduction below
+  // (the per-slice max / mass words are the same for every column: lanes 0..15 fetch one slice each and hand them to
+  // the other lanes through LDS (red[64..95]) - 2 registers instead of 32 in every lane)
+  float pmA[16], pmM1 = -INFINITY, pmL1 = 0.f;
+  const bool merger = a.merge_prior && tid < D;
+  const int JS = a.pm.JS;
+  if (a.merge_prior && tid < 16) {
+    const size_t rowi = (size_t)min(tid, JS - 1) * a.pm.n_local + nl;
+    float tm, tl;
+    if (fw) {
+      tm = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tl = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      tm = a.pm.pM[rowi];
+      tl = a.pm.pL[rowi];
+    }
+    pmM1 = tid < JS ? tm : -INFINITY;
+    pmL1 = tid < JS ? tl : 0.f;
+  }
+  if (merger) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool ok = u < JS;
+      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + nl;
+      float ta;  // unconditional loads
+      if (fw) ta = __hip_atomic_load(a.pm.pA + rowi * a.pm.ldp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else ta = a.pm.pA[rowi * a.pm.ldp + tid];
+      pmA[u] = ok ? ta : 0.f;
+    }
+  }
   DUST_STAMP(a.stamps, 2);
   // ---- 3. softmax over samples: likelihood weights w (alpha) and MPPI weights omega (1/temp) ----
   float cmin = INFINITY, csum = 0.f;
@@ -275,7 +341,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       red[wid] = cmin;
       red[8 + wid] = csum;
     }
-    __syncthreads();
+    lds_barrier();
     cmin = red[0];
     csum = red[8];
     for (int w = 1; w < nw; ++w) {
@@ -307,7 +373,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       red[16 + wid] = zw;
       red[24 + wid] = zo;
     }
-    __syncthreads();  // also publishes every lane's cst[] / omg[] to the stage-4 readers
+    lds_barrier();  // also publishes every lane's cst[] / omg[] to the stage-4 readers
     zw = red[16];
     zo = red[24];
     for (int w = 1; w < nw; ++w) {
@@ -332,47 +398,6 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const int Q = nt / D > 0 ? nt / D : 1;
   float g = 0.f, am = 0.f;
   const int q = (int)__umulhi((uint32_t)tid, a.magicD), j = tid - q * D;
-  if (fw) {
-    // fused launch: the prior-pass workgroups of this launch publish the partials of query tile nl/32 with an agent-scope
-    // release + counter add; poll relaxed from ONE lane, acquire once, then the barrier admits the other lanes
-    // (cdna_hip_programming.md Guideline 16, counter form).  The spin is bounded.
-    if (threadIdx.x == 0) {
-      const unsigned int *cp = fw->cnt + (nl / PAIR_TI) * CNT_STRIDE;
-      unsigned int spins = 0;
-      while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fw->target) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 24)) {
-          *fw->timeout_flag = 1u;
-          break;
-        }
-      }
-    }
-    __syncthreads();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
-  }
-  // prior partials of this row: issue the (independent) loads now, consume them after the reduction below
-  float pmM[16], pmL[16], pmA[16];
-  const bool merger = a.merge_prior && tid < D;
-  const int JS = a.pm.JS;
-  if (merger) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const bool ok = u < JS;
-      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + nl;
-      float tm, tl, ta;  // unconditional loads
-      if (fw) {
-        tm = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tl = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ta = __hip_atomic_load(a.pm.pA + rowi * a.pm.ldp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        tm = a.pm.pM[rowi];
-        tl = a.pm.pL[rowi];
-        ta = a.pm.pA[rowi * a.pm.ldp + tid];
-      }
-      pmM[u] = ok ? tm : -INFINITY;
-      pmL[u] = ok ? tl : 0.f;
-      pmA[u] = ok ? ta : 0.f;
-    }
-  }
   if (q < Q) {
     const float thj = th[j];
     const float is2 = 1.0f / (a.sigma_a[j % DA] * a.sigma_a[j % DA]);  // (a - x) / sigma^2 as a multiply: <= 1 ulp apart
@@ -388,7 +413,11 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   }
   part[tid] = g;
   part[nt + tid] = am;
-  __syncthreads();
+  if (a.merge_prior && tid < 16) {
+    red[64 + tid] = pmM1;
+    red[80 + tid] = pmL1;
+  }
+  lds_barrier();
   DUST_STAMP(a.stamps, 4);
   if (tid < D) {
     float gs = 0.f, as = 0.f;
@@ -401,18 +430,19 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     if (same_w && a.eps_base_mode) as = gs * (a.sigma_a[tid % DA] * a.sigma_a[tid % DA]);  // sum_s w (a - theta)
     else as = as / zo;
     a.grad_lik[o] = gs;
-    if (a.update_a_mat) a.a_mat[o] += as;
+    if (a.update_a_mat) a.a_mat[o] = amv + as;
     if (a.merge_prior) {  // prior half of the score (svmpc.py:38-41,56) from the pairwise kernel's slice partials
       float gp;
       if (JS <= 16) {
         float m = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) m = fmaxf(m, pmM[u]);
+        for (int u = 0; u < 16; ++u) m = fmaxf(m, red[64 + u]);
         float l = 0.f, acc = 0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          const float w = (pmM[u] == -INFINITY) ? 0.f : expf(pmM[u] - m);
-          l = fmaf(pmL[u], w, l);
+          const float pm_u = red[64 + u];
+          const float w = (pm_u == -INFINITY) ? 0.f : expf(pm_u - m);
+          l = fmaf(red[80 + u], w, l);
           acc = fmaf(pmA[u], w, acc);
         }
         gp = (acc / l) * a.pm.inv_s2[tid % DA];
@@ -431,14 +461,22 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   DUST_STAMP(a.stamps, 5);
 }
 
+// XCD-aware block -> work-item map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own
+// L2): give every XCD one CONTIGUOUS range of particles, so rows that share a 128-byte line (120-byte noise rows, the
+// per-slice pM / pL words of 32 neighbours) are fetched into one L2 once instead of into several (measured with
+// FETCH_SIZE: 2.2x the algorithmic bytes before).  Affinity only: results do not depend on the actual placement.
+__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
+  return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL>(a, lds, threadIdx.x, blockDim.x, blockIdx.x, nullptr);
+  rollout_body<MODEL, 32>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
-  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 64 + 2 * (size_t)nt + (size_t)D + 2 * (size_t)M);
+  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + (size_t)D + 2 * (size_t)M);
 }
 
 }  // namespace dust
