@@ -163,18 +163,19 @@ def main():
         n_slices = 8
         slice_f = w["S"] * n_loc * w["H"]
         ptr = c1.device_noise(n_slices * slice_f, seed=99)
-        c1.profile(True)
-        reps = 25
-        for _ in range(reps):
-            c1.svmpc_optimize_dev(state, n_slices, ptr)
-        c1.sync()
-        ms, n = c1.profile_get()["rollout_kernel"]
-        avg_s = ms / n * 1e-3
+        avg_s = c1.profile_rollout(state, ptr, n_slices, 400) * 1e-3
         bytes_alg = c1.rollout_bytes()
         ach = bytes_alg / avg_s / 1e9
-        roofline = dict(kernel="rollout_kernel<PENDULUM> (external-noise form)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=bytes_alg,
-                        avg_launch_us=avg_s * 1e6, launches=n)
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "round1_rollout_traffic.json")
+        if os.path.exists(tf):  # PMC passes cannot run inside this process: the committed summary of the same kernel / shape
+            with open(tf) as fh:
+                tj = json.load(fh)
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round1_rollout_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        roofline = dict(kernel="dust::rollout_stream_kernel<0> (rollout kernel, HBM-streaming form: caller-supplied eps)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=bytes_alg, avg_launch_us=avg_s * 1e6, launches=400,
+                        timing="one HIP event pair around 400 back-to-back launches on the context's stream")
         c1.device_free(ptr)
         c1.profile(False)
         c1.close()

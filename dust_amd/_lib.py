@@ -116,6 +116,7 @@ SYMBOLS = {
     "dust_profile_enable": (C.c_int, [VP, C.c_int]),
     "dust_profile_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dust_profile_reset": (C.c_int, [VP]),
+    "dust_profile_rollout": (C.c_int, [VP, FP, VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dust_kernel_name": (C.c_char_p, [C.c_int]),
     "dust_rollout_algorithmic_bytes": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double)]),
     "dust_device_noise_alloc": (C.c_int, [VP, C.c_size_t, C.c_uint64, C.POINTER(VP)]),

@@ -289,6 +289,13 @@ class Context:
                 out[L.load().dust_kernel_name(k).decode()] = (ms.value, n.value)
         return out
 
+    def profile_rollout(self, state, eps_dev, n_slices, reps):
+        """Average launch-to-launch time (ms) of the standalone rollout kernel over device-resident eps slices."""
+        ms = C.c_double(0)
+        L.check(L.load().dust_profile_rollout(self._h, _p(np.ascontiguousarray(state, np.float32)), C.c_void_p(eps_dev), int(n_slices),
+                                              int(reps), C.byref(ms)))
+        return ms.value
+
     def rollout_bytes(self, store_states=False):
         b = C.c_double(0)
         L.check(L.load().dust_rollout_algorithmic_bytes(self._h, L.STORE_STATES if store_states else 0, C.byref(b)))

@@ -681,13 +681,21 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
   size_t lds;
   TRY(rollout_args(c, o, a, &nt, &lds));
   Prof p(c, DUST_K_ROLLOUT);
+#define DUST_LAUNCH_ROLLOUT(KERNEL)                                                                                            \
+  do {                                                                                                                          \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                       \
+      HIP_TRY(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+    KERNEL<<<c->nloc, nt, lds, c->stream>>>(a);                                                                                 \
+  } while (0)
+  const bool stream_form = a.noise_mode == NOISE_EPS;
   if (c->cfg.model == DUST_MODEL_PENDULUM) {
-    if (lds > 64 * 1024 && !c->capturing) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PENDULUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rollout_kernel<DUST_MODEL_PENDULUM><<<c->nloc, nt, lds, c->stream>>>(a);
+    if (stream_form) DUST_LAUNCH_ROLLOUT(rollout_stream_kernel<DUST_MODEL_PENDULUM>);
+    else DUST_LAUNCH_ROLLOUT(rollout_kernel<DUST_MODEL_PENDULUM>);
   } else {
-    if (lds > 64 * 1024 && !c->capturing) HIP_TRY(hipFuncSetAttribute((const void *)rollout_kernel<DUST_MODEL_PARTICLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    rollout_kernel<DUST_MODEL_PARTICLE><<<c->nloc, nt, lds, c->stream>>>(a);
+    if (stream_form) DUST_LAUNCH_ROLLOUT(rollout_stream_kernel<DUST_MODEL_PARTICLE>);
+    else DUST_LAUNCH_ROLLOUT(rollout_kernel<DUST_MODEL_PARTICLE>);
   }
+#undef DUST_LAUNCH_ROLLOUT
   HIP_TRY(hipGetLastError());
   c->actions_valid = o.want_actions;
   c->stein_dirty = false;
@@ -1450,6 +1458,52 @@ extern "C" int dust_profile_get(dust_ctx *c, int id, double *ms, int64_t *n) {
   if (n) *n = c->prof_n[id];
   return DUST_OK;
 }
+// Back-to-back launches of the standalone rollout kernel in its HBM-streaming form (device-resident eps, a fresh slice
+// per launch), bracketed by ONE pair of HIP events on the context's stream: the average is the kernel's launch-to-launch
+// duration without per-launch event overhead (bench.py's roofline; compare rocprofv3 --kernel-trace --stats).
+extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float *eps_dev, int n_slices, int reps, double *avg_ms) {
+  if (!c || !state || !eps_dev || !avg_ms || n_slices < 1 || reps < 1) return fail(DUST_ERR_INVALID, "bad argument");
+  if (c->cfg.dim_p > 0) return fail(DUST_ERR_UNSUPPORTED, "dust_profile_rollout: contexts without sampled parameters only");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, nullptr, 0));
+  TRY(launch_prior(c));  // the partials the kernel's combine stage reads
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = NOISE_EPS;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  o.merge_prior = 1;
+  const size_t slice = (size_t)c->S * c->N * c->D;
+  const bool prof = c->prof;
+  c->prof = false;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  int st = DUST_OK;
+  for (int r = 0; r < 3 && st == DUST_OK; ++r) {  // warm-up
+    o.noise_dev = eps_dev + (size_t)(r % n_slices) * slice;
+    st = launch_rollout(c, o);
+  }
+  if (st == DUST_OK) {
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps && st == DUST_OK; ++r) {
+      o.noise_dev = eps_dev + (size_t)(r % n_slices) * slice;
+      st = launch_rollout(c, o);
+    }
+    (void)hipEventRecord(e1, c->stream);
+  }
+  c->prof = prof;
+  if (st == DUST_OK) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = fail(DUST_ERR_HIP, "event timing failed");
+    *avg_ms = (double)ms / reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  c->have_sample = true;
+  return st;
+}
+
 extern "C" int dust_rollout_algorithmic_bytes(const dust_ctx *c, int flags, double *bytes) {
   if (!c || !bytes) return fail(DUST_ERR_INVALID, "null argument");
   // B_roll = 4 [S N D (eps in) + N D (theta in) + M P (params) + S N (costs out)] (+ states when stored)

@@ -475,6 +475,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   rollout_body<MODEL, 32>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
+// Same body under its own symbol for the HBM-streaming form (caller-supplied eps resident in HBM): profiles and PMC
+// passes then attribute it separately from the Philox form.
+template <int MODEL>
+__global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rollout_body<MODEL, 32>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+}
+
 static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
   return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + (size_t)D + 2 * (size_t)M);
 }

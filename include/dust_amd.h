@@ -183,6 +183,9 @@ enum dust_kernel_id {
 int dust_profile_enable(dust_ctx *ctx, int on);
 int dust_profile_get(dust_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int dust_profile_reset(dust_ctx *ctx);
+/* reps back-to-back launches of the standalone rollout kernel over device-resident eps [n_slices][S][N][D] (slice r %
+ * n_slices per launch) between one pair of HIP events on the context's stream; *avg_ms = elapsed / reps. */
+int dust_profile_rollout(dust_ctx *ctx, const float *state, const float *eps_dev, int n_slices, int reps, double *avg_ms);
 const char *dust_kernel_name(int kernel_id);
 /* algorithmic bytes one launch of the rollout kernel moves (SURVEY.md section 8d B_roll) */
 int dust_rollout_algorithmic_bytes(const dust_ctx *ctx, int flags, double *bytes);
