@@ -210,6 +210,45 @@ __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, c
   }
 }
 
+// inst_cost of the state BEFORE the action, then the step: the Particle model looks the same cell up for the obstacle
+// cost and for the crash mask - one lookup serves both.
+template <int MODEL>
+__device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &c, float *x, const float *a) {
+  if (MODEL == DUST_MODEL_PENDULUM) {
+    const float cost = inst_cost<MODEL>(dm, x, a);
+    model_step<MODEL>(dm, c, x, a);
+    return cost;
+  } else {
+    const bool crash = dm.can_crash && dm.with_obstacle;
+    const float coll = (dm.with_obstacle || crash) ? collision(dm, x[0], x[1]) : 0.f;
+    double sc = 0.0, cc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = x[k] - dm.target[k];
+      sc += (double)((d * d) * dm.w_state[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
+    const float ob = dm.with_obstacle ? dm.w_obs * coll : 0.0f;
+    const float cost = ((float)sc + (float)cc) + ob;
+    const float dt = (float)dm.dt;
+    float ax = clampf(a[0] / c.c0, -dm.max_acc, dm.max_acc);
+    float ay = clampf(a[1] / c.c0, -dm.max_acc, dm.max_acc);
+    float xd[4] = {x[2], x[3], ax, ay};
+    if (crash) {
+      float om = 1.0f - coll;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = x[k] + (xd[k] * dt) * om;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = x[k] + xd[k] * dt;
+    }
+    x[2] = clampf(x[2], -dm.max_speed, dm.max_speed);
+    x[3] = clampf(x[3], -dm.max_speed, dm.max_speed);
+    return cost;
+  }
+}
+
 template <int MODEL>
 __device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
   if (MODEL == DUST_MODEL_PENDULUM) {

@@ -371,7 +371,7 @@ extern "C" int dust_sync(dust_ctx *c) {
   }
   if (c->stein_cnt) {
     unsigned int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c->stein_cnt + (size_t)c->stein_tiles * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(DUST_ERR_HIP, "Stein+update launch: hand-off spin timed out (results of that tick are invalid)");
   }
   return DUST_OK;
@@ -655,7 +655,7 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.ctr = c->ctr_dev;
   a.bump_adam = o.bump_adam;
   a.rearm = c->stein_cnt;
-  a.rearm_n = c->stein_cnt ? c->stein_tiles : 0;
+  a.rearm_n = c->stein_cnt ? c->stein_tiles + 1 : 0;  // per-tile lines + the global line
   if (a.params == nullptr) {
     a.coef_given = 1;
     host_coef(c->cfg, a.coef_host);
@@ -663,6 +663,16 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_ROLLOUT : nullptr;
   int nt = ((std::max(c->S, c->D) + 63) / 64) * 64;
   nt = std::min(std::max(nt, 64), 256);
+  a.G = 1;
+  {  // several dynamics samples and few action samples: split the M loop over lane groups (rollout.hpp)
+    const int sub = ((c->S + 63) / 64) * 64;
+    int G = 1;
+    while (2 * G <= c->M && sub * 2 * G <= 256) G *= 2;
+    if (G > 1 && !o.costs_in) {
+      a.G = G;
+      nt = sub * G;  // >= 128 >= D
+    }
+  }
   size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true);
   if (lds > 96 * 1024) {  // keep >= 1 workgroup per CU resident with room to spare; larger tiles go to an HBM slab
     TRY(ensure(&c->tile_scratch, &c->tile_cap, (size_t)c->nloc * c->S * (c->D | 1)));
@@ -1075,14 +1085,14 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       else {
         if (c->stein_cnt) HIP_TRY(hipFree(c->stein_cnt));
         c->stein_cnt = nullptr;
-        TRY(dalloc(&c->stein_cnt, ((size_t)tiles + 1) * CNT_STRIDE));
+        TRY(dalloc(&c->stein_cnt, ((size_t)tiles + 2) * CNT_STRIDE));
         c->stein_tiles = tiles;
         c->stein_dirty = true;  // the rollout launch that preceded this call did not know the buffer
       }
     }
     if (fuse) {
       // Stein tiles + update role in ONE launch (fused.hpp): the update launch and its ramp disappear
-      if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+      if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 2) * CNT_STRIDE * sizeof(unsigned int), c->stream));
       SteinUpdateArgs f;
       memset(&f, 0, sizeof f);
       f.pa = a;
@@ -1090,7 +1100,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       f.tiles = tiles;
       f.n_pair_blocks = tiles * a.JS;
       f.cnt = c->stein_cnt;
-      f.timeout_flag = c->stein_cnt + (size_t)tiles * CNT_STRIDE;
+      f.timeout_flag = c->stein_cnt + ((size_t)tiles + 1) * CNT_STRIDE;
       const int grid = f.n_pair_blocks + (n + PAIR_NT - 1) / PAIR_NT;
 #define DUST_LAUNCH_SU(MODE, CPT) stein_update_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
       if (c->cfg.kernel == DUST_KERNEL_IMQ) {

@@ -51,16 +51,18 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stein pass + optimiser update in one launch.  Workgroups [0, n_pair) run the Stein tiles (pairwise_body<K1|IMQ>) and
-// publish their slice partials write-through + one arrival per (tile, slice); workgroups [n_pair, ...) are the update
-// role: 256 consecutive (particle, dim) elements each, waiting until the (at most two) query tiles they touch have all JS
-// arrivals, then combining the partials in the fixed slice order (bitwise the same result as the two-launch form).
+// publish their slice partials write-through; workgroups [n_pair, ...) are the update role: 256 consecutive (particle,
+// dim) elements each.  theta is BOTH an input of every Stein tile (queries and keys) and the output of the update, so the
+// update role may not start before EVERY Stein workgroup has finished reading: arrivals are counted per query tile (one
+// 128-byte line each, 16 arrivals), the last arrival of a tile bumps one global line (tiles arrivals), and the update
+// role polls that single line.  (A flat counter with tiles*JS arrivals on one line serialises the producers' atomics.)
 // The update role has the HIGHER block indices: it only ever waits on work dispatched before it; the spin is bounded.
-// The arrival counters are re-armed by the next rollout launch (RolloutArgs::rearm), as fused_cnt is by the update role.
+// The counters are re-armed by the next rollout launch (RolloutArgs::rearm), as fused_cnt is by the update role.
 struct SteinUpdateArgs {
   PairArgs pa;
   UpdateArgs ua;
   int tiles, n_pair_blocks;
-  unsigned int *cnt;  // [tiles][CNT_STRIDE]: one counter per 128-byte line (pollers of different tiles must not share a line)
+  unsigned int *cnt;  // [tiles + 1][CNT_STRIDE]: per-tile arrivals, then the global "tiles done" line
   unsigned int *timeout_flag;
 };
 
@@ -72,23 +74,23 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kern
     pairwise_body<MODE, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      const unsigned int prev = __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev + 1u == (unsigned int)f.pa.JS)
+        __hip_atomic_fetch_add(f.cnt + f.tiles * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     const int b = (int)blockIdx.x - f.n_pair_blocks;
-    const int total = f.ua.n_local * f.ua.D;
     const int idx = b * PAIR_NT + (int)threadIdx.x;
     if (threadIdx.x == 0) {
-      const int t0 = (min(b * PAIR_NT, total - 1) / f.ua.D) / PAIR_TI;
-      const int t1 = (min(b * PAIR_NT + PAIR_NT - 1, total - 1) / f.ua.D) / PAIR_TI;
       unsigned int spins = 0;
-      for (int t = t0; t <= t1; ++t)
-        while (__hip_atomic_load(f.cnt + t * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)f.pa.JS) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1u << 24)) {
-            *f.timeout_flag = 1u;
-            break;
-          }
+      while (__hip_atomic_load(f.cnt + f.tiles * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)f.tiles) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1u << 24)) {
+          *f.timeout_flag = 1u;
+          break;
         }
+      }
     }
     __syncthreads();
     update_body<true>(f.ua, idx);

@@ -17,6 +17,8 @@
 // At N*S = 131072 rollouts a launch is only 2 waves per SIMD, so the kernel is instruction-issue bound: the pendulum
 // step is specialised (one argument reduction serves sin(theta+pi) and cos(theta), see pendulum_trig).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "stein.hpp"
 
@@ -29,6 +31,7 @@ struct RolloutArgs {
   DevModel dm;
   int N_total, n0, S, M, H, D;
   int noise_mode;
+  int G;             // dynamics-sample groups: lane = (sample, group), group g rolls out m = g, g+G, ... (G > 1 only when S <= nt/G)
   int lik;           // dust_likelihood
   int eps_base_mode; // 0: eps = a - a_seq (ext actions, disco.py:161-164); 1: eps = a - a_mat[n] (internal noise, 155-160)
   int update_a_mat;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   DUST_STAMP(a.stamps, 0);
   // ---- 1. stage the action tile (a1: actions = theta + L eps) ----
   // theta row of this particle -> LDS once (every later use is an LDS broadcast / lane read, not a global load)
-  float *th = part + 2 * nt;  // [D]
+  float *th = part + 2 * nt + 2;  // [D]
   // red[40]: "some action of this particle is NaN" (the branch-free rollout loop clamps with v_med3_f32, which would
   // swallow a NaN that torch.clamp propagates: such particles take the general loop)
   if (tid == 0) red[40] = 0.f;
@@ -186,10 +189,19 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
   const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out && !a.tile_scratch && red[40] == 0.f &&
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
-  for (int s = tid; s < S; s += nt) {
-    float *act = tile + s * Dp;
-    if (a.noise_mode == NOISE_PHILOX) {  // this lane's own row: no barrier needed before it is consumed below
-      for (int j4 = 0; j4 * 4 < D; ++j4) {
+  // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
+  // M loop is split over G lane groups that share the action tile - 4x the waves per LDS byte at cfg3 (S = 64, M = 64)
+  // (the G == 1 instance is compiled with mg = 0 and G = 1 as constants: block indices, the dynamics-sample index and
+  // with them most of the Philox rounds stay wave-uniform and run on the scalar unit)
+  auto rollouts = [&](auto one_group) {
+  constexpr bool ONE = decltype(one_group)::value;
+  const int G = ONE ? 1 : a.G, sub = ONE ? nt : nt / a.G;
+  const int mg = ONE ? 0 : __builtin_amdgcn_readfirstlane(tid / sub);  // sub is a multiple of 64: a wave belongs to one group
+  const int ts = ONE ? tid : tid - mg * sub;
+  if (a.noise_mode == NOISE_PHILOX) {  // the lanes of a sample fill ITS row (4-element blocks dealt over the groups)
+    for (int s = ts; s < S; s += sub) {
+      float *act = tile + s * Dp;
+      for (int j4 = mg; j4 * 4 < D; j4 += G) {
         float z[4];
         philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);
 #pragma unroll
@@ -199,12 +211,33 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         }
       }
     }
+    if (G > 1) __syncthreads();  // G == 1: every lane consumes only the row it filled itself
+  }
+  // [G][sub] per-group partial sums over m (G > 1); `part` is only 4-byte aligned for odd S: round up (one spare pair of
+  // floats is reserved in rollout_lds_bytes)
+  double *accp = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(part) + 7) & ~(uintptr_t)7);
+  auto finish_cost = [&](const int s, const double acc) {
+    float cost = a.M == 1 ? (float)acc : (float)(acc / a.M);
+    if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
+      const float *act = tile + s * Dp;
+      double cc = 0.0;
+      for (int j = 0; j < D; ++j) {
+        const float e = act[j] - a.a_seq[j];
+        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % DA]);
+      }
+      cost = cost + a.a_reg * (float)cc;
+    }
+    cst[s] = cost;
+    a.costsT[(size_t)n * S + s] = cost;
+  };
+  for (int s = ts; s < S; s += sub) {
+    float *act = tile + s * Dp;
     if (a.costs_in) {
-      cst[s] = a.costs_in[(size_t)s * N + n];
+      if (mg == 0) cst[s] = a.costs_in[(size_t)s * N + n];
       continue;
     }
     double acc_m = 0.0;
-    for (int m = 0; m < a.M; ++m) {
+    for (int m = mg; m < a.M; m += G) {
       const long r = (long)m * SN + (long)s * N + n;
       const int pidx = a.dm.interleave ? (int)(r % a.M) : m;
       Coef cf;
@@ -248,8 +281,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           float at[DA];
 #pragma unroll
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
-          tot += (double)inst_cost<MODEL>(a.dm, x, at);  // cost of the state BEFORE the action (disco.py:306)
-          model_step<MODEL>(a.dm, cf, x, at);
+          tot += (double)step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           if (so) {
 #pragma unroll
             for (int k = 0; k < DS; ++k) so[(size_t)(t + 1) * DS + k] = x[k];
@@ -259,18 +291,23 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       }
       acc_m += (double)traj;
     }
-    float cost = a.M == 1 ? (float)acc_m : (float)(acc_m / a.M);
-    if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
-      double cc = 0.0;
-      for (int j = 0; j < D; ++j) {
-        const float e = act[j] - a.a_seq[j];
-        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % DA]);
-      }
-      cost = cost + a.a_reg * (float)cc;
+    if (G > 1) {  // every lane has at most one sample here: park the group partial, combine after the barrier below
+      accp[mg * sub + ts] = acc_m;
+      continue;
     }
-    cst[s] = cost;
-    a.costsT[(size_t)n * S + s] = cost;
+    finish_cost(s, acc_m);
   }
+  if (G > 1) {  // fixed-order sum of the group partials (the barrier sits outside the sample loop: lanes without a sample reach it too)
+    __syncthreads();
+    if (mg == 0 && ts < S && !a.costs_in) {
+      double acc_m = accp[ts];
+      for (int g = 1; g < G; ++g) acc_m += accp[g * sub + ts];
+      finish_cost(ts, acc_m);
+    }
+  }
+  };
+  if (a.G == 1) rollouts(std::true_type{});
+  else rollouts(std::false_type{});
   __syncthreads();
   if (a.actions_out) {
     for (int idx = tid; idx < S * D; idx += nt) {
@@ -484,7 +521,7 @@ __global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a
 }
 
 static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
-  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + (size_t)D + 2 * (size_t)M);
+  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + 2 + (size_t)D + 2 * (size_t)M);
 }
 
 }  // namespace dust

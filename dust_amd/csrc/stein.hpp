@@ -47,7 +47,10 @@ struct PairArgs {
 typedef float v4f __attribute__((ext_vector_type(4)));
 // 16-byte global store; `wt` = write-through to memory (sc1), readable by sc1 loads from any CU of the device in the same launch
 __device__ __forceinline__ void store16(float *p, v4f v, bool wt) {
-  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  // s_nop AFTER the store: a > 8-byte VMEM store reads its data registers late, and a VALU write of them in the next
+  // instruction needs a wait state that the compiler's hazard recogniser inserts for its own stores but not around
+  // inline asm (without it the register allocator's immediate reuse of v[8:9] zeroed two columns at CPT = 8)
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else *reinterpret_cast<v4f *>(p) = v;
 }
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)

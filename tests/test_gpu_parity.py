@@ -294,3 +294,38 @@ def test_sharded_equals_unsharded(golden, world):
         for s in shards:
             assert relerr(s.ctx.get_theta(), rt) < 1e-6, (world, t, s.rank)
         assert relerr(pw, rp) < 1e-5 and np.array_equal(a_seq, ra)
+
+
+@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 1024, 128, 1, 30), ("pendulum", 512, 64, 1, 12), ("particle", 256, 64, 4, 20)])
+def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H):
+    """The fused launches (prior + rollout, Stein + update) hand partials over INSIDE a launch; the same bodies run as
+    separate kernels when per-kernel profiling is on.  Both must give the same bits, tick after tick: a hand-off that
+    lets a consumer run early (or a producer overwrite an input another workgroup still reads) shows up here."""
+    from dust_amd import Context
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(3)
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    th = (mu + rng.standard_normal((N, H, da))).astype(np.float32)
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    up = None if M == 1 else ("mass",)
+    params = None if M == 1 else (1.0 + 0.1 * rng.standard_normal((3, M, 1))).astype(np.float32)
+    grid = None
+    if model == "particle":
+        from oracle import grid_4x4_map  # data only (the demo's occupancy grid)
+
+        grid = grid_4x4_map()
+    out = []
+    for unfused in (False, True):
+        c = Context(model=model, N=N, S=S, M=M, H=H, kernel="K1", lr=0.5, sigma_a=1.0, sigma_p=1.0, uncertain_params=up, grid=grid, seed=11)
+        c.set_theta(th)
+        c.set_prior(mu)
+        c.set_a_mat(th)
+        c.profile(unfused)
+        for _ in range(4):
+            c.svmpc_tick(state, 3, params=params, want_outputs=False)
+        c.sync()
+        out.append((c.get_theta(), c.get_score(), c.get_a_mat()))
+        c.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
