@@ -86,6 +86,8 @@ struct dust_ctx {
   unsigned int *fused_cnt;  // [tiles + 1]: per-tile arrival counters of the fused launch, last word = spin-timeout flag
   int fused_tiles;
   bool fused_dirty;   // a fused launch ran and no update kernel has re-armed the counters yet
+  float *theta_home, *theta_alt;  // theta ping-pong of the fused Stein+update launch (theta == one of the two)
+  const float *graph_theta;       // theta at the start of the captured tick
   unsigned int *stein_cnt;  // [tiles + 1]: arrival counters of the Stein+update launch (re-armed by the next rollout launch)
   int stein_tiles;
   bool stein_dirty;
@@ -241,7 +243,8 @@ static int validate(const dust_config *g) {
 }
 
 static void free_all(dust_ctx *c) {
-  float **fp[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
+  // {theta, theta_alt} are always the two particle buffers, whichever is current
+  float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
                   &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
                   &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL};
@@ -307,6 +310,8 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   float **nd[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->a_mat, &c->grad_lik, &c->grad_pri, &c->score, &c->phi};
   for (auto p : nd) {
     TRY(dalloc(p, ND));
+  TRY(dalloc(&c->theta_alt, ND));
+  c->theta_home = c->theta;
     HIP_TRY(hipMemsetAsync(*p, 0, ND * sizeof(float), c->stream));
   }
   float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw, &c->pw};
@@ -1014,6 +1019,7 @@ static UpdateArgs update_args(dust_ctx *c, int apply) {
   u.pB = c->pB;
   u.phi = c->phi;
   u.theta = c->theta;
+  u.theta_out = c->theta;
   u.adam_m = c->adam_m;
   u.adam_v = c->adam_v;
   u.ctr = c->ctr_dev;
@@ -1097,6 +1103,11 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       memset(&f, 0, sizeof f);
       f.pa = a;
       f.ua = update_args(c, 1);
+      // unsharded: the update writes the OTHER theta buffer, so its role may start per query tile while other Stein tiles
+      // still read the current one; sharded contexts expose theta's address to the collectives and keep one buffer
+      const bool pingpong = c->nloc == c->N;
+      if (pingpong) f.ua.theta_out = c->theta_alt;
+      f.wait_all = pingpong ? 0 : 1;
       f.tiles = tiles;
       f.n_pair_blocks = tiles * a.JS;
       f.cnt = c->stein_cnt;
@@ -1112,6 +1123,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       }
 #undef DUST_LAUNCH_SU
       HIP_TRY(hipGetLastError());
+      if (pingpong) std::swap(c->theta, c->theta_alt);
       c->stein_dirty = true;
       c->fused_dirty = false;
       return DUST_OK;
@@ -1278,8 +1290,13 @@ static int forward_finish_device(dust_ctx *c) {
   }
   finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
   HIP_TRY(hipGetLastError());
-  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc, c->ctr_dev);
+  // reads the current buffer, writes the home buffer: a tick always ends (and a captured tick always starts) on home
+  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->theta_home, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc, c->ctr_dev);
   HIP_TRY(hipGetLastError());
+  if (c->theta != c->theta_home) {
+    c->theta_alt = c->theta;
+    c->theta = c->theta_home;
+  }
   c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
   return DUST_OK;
 }
@@ -1312,7 +1329,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
   static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
                          c->mu_aliased && c->own_stream;
-  if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps) {
+  if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || (c->graph_exec && c->graph_theta != c->theta)) {
     if (c->graph_exec) graph_drop(c);
     c->graph_steps = n_steps;
     c->graph_eps = (const void *)eps;
@@ -1330,6 +1347,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
     TRY(upload_state_params(c, state, params, n_steps));
     c->capturing = true;
+    c->graph_theta = c->theta;
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
     int st = DUST_OK;
     if (e == hipSuccess) {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *log
 
 // SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy.  One workgroup per particle,
 // lane = element: every element is read into a register, the workgroup syncs, then the shifted value is written.
-__global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, int da, int strategy, int i0, int n_local, uint32_t *ctr) {
+__global__ __launch_bounds__(128) void roll_kernel(const float *theta, float *theta_dst, int N, int H, int da, int strategy, int i0, int n_local, uint32_t *ctr) {
   __shared__ float red[32];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // next tick: new Philox sub-stream
     ctr[0] += 1u;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, i
   }
   const int i = i0 + blockIdx.x;
   const int D = H * da, j = threadIdx.x;
-  float *th = theta + (size_t)i * D;
+  const float *th = theta + (size_t)i * D;
   const float own = j < D ? th[j] : 0.f;
   const float nxt = (j + da < D) ? th[j + da] : own;  // "repeat": the last row keeps its value
   float out = nxt;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(128) void roll_kernel(float *theta, int N, int H, i
     }
   }
   __syncthreads();
-  if (j < D) th[j] = out;
+  if (j < D) theta_dst[(size_t)i * D + j] = out;
 }
 
 // a_mix = softmax_n(eta) disco.py:393 (single workgroup)

@@ -52,16 +52,19 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
 // ---------------------------------------------------------------------------------------------------------------
 // Stein pass + optimiser update in one launch.  Workgroups [0, n_pair) run the Stein tiles (pairwise_body<K1|IMQ>) and
 // publish their slice partials write-through; workgroups [n_pair, ...) are the update role: 256 consecutive (particle,
-// dim) elements each.  theta is BOTH an input of every Stein tile (queries and keys) and the output of the update, so the
-// update role may not start before EVERY Stein workgroup has finished reading: arrivals are counted per query tile (one
-// 128-byte line each, 16 arrivals), the last arrival of a tile bumps one global line (tiles arrivals), and the update
-// role polls that single line.  (A flat counter with tiles*JS arrivals on one line serialises the producers' atomics.)
+// dim) elements each.  theta is BOTH an input of every Stein tile (queries and keys) and the output of the update: updated
+// IN PLACE, the update role may not start before EVERY Stein workgroup has finished reading (arrivals are counted per query
+// tile, one 128-byte line each; the last arrival of a tile bumps one global line and the update role polls that line - a
+// flat counter with tiles*JS arrivals on one line serialises the producers' atomics).  Unsharded contexts ping-pong theta
+// instead (the update writes the other buffer), and the update role of a query tile starts as soon as that tile's JS
+// slices have arrived.
 // The update role has the HIGHER block indices: it only ever waits on work dispatched before it; the spin is bounded.
 // The counters are re-armed by the next rollout launch (RolloutArgs::rearm), as fused_cnt is by the update role.
 struct SteinUpdateArgs {
   PairArgs pa;
   UpdateArgs ua;
   int tiles, n_pair_blocks;
+  int wait_all;       // 1: theta is updated in place, the update role waits for EVERY Stein tile; 0: ping-pong, per query tile
   unsigned int *cnt;  // [tiles + 1][CNT_STRIDE]: per-tile arrivals, then the global "tiles done" line
   unsigned int *timeout_flag;
 };
@@ -84,13 +87,19 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kern
     const int idx = b * PAIR_NT + (int)threadIdx.x;
     if (threadIdx.x == 0) {
       unsigned int spins = 0;
-      while (__hip_atomic_load(f.cnt + f.tiles * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)f.tiles) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1u << 24)) {
-          *f.timeout_flag = 1u;
-          break;
+      const int total = f.ua.n_local * f.ua.D;
+      // in place: the global line (tiles arrivals); ping-pong: the (at most two) query tiles this block's elements belong to
+      const int t0 = f.wait_all ? f.tiles : (min(b * PAIR_NT, total - 1) / f.ua.D) / PAIR_TI;
+      const int t1 = f.wait_all ? f.tiles : (min(b * PAIR_NT + PAIR_NT - 1, total - 1) / f.ua.D) / PAIR_TI;
+      const unsigned int target = f.wait_all ? (unsigned int)f.tiles : (unsigned int)f.pa.JS;
+      for (int t = t0; t <= t1; ++t)
+        while (__hip_atomic_load(f.cnt + t * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) {
+            *f.timeout_flag = 1u;
+            break;
+          }
         }
-      }
     }
     __syncthreads();
     update_body<true>(f.ua, idx);

@@ -380,7 +380,8 @@ struct UpdateArgs {
   int fused_tiles;
   const float *pA, *pB;  // [JS][n_local][ldp]
   float *phi;     // [N][D]
-  float *theta;   // [N][D]
+  float *theta;   // [N][D] current particles
+  float *theta_out;  // [N][D] where the updated particles go (== theta, or the other buffer of the ping-pong)
   float *adam_m, *adam_v;
 };
 
@@ -434,7 +435,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
     const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
     th = th - (a.lr / bc1) * (m / denom);
   }
-  a.theta[o] = th;
+  a.theta_out[o] = th;
 }
 
 __global__ void update_kernel(const UpdateArgs a) { update_body<false>(a, blockIdx.x * blockDim.x + threadIdx.x); }
