@@ -7,7 +7,8 @@
 //
 // The problem is tiny (M_p <= 1024 particles x P <= 4 parameters, n_steps ~ 20 dependent SVGD steps), i.e. pure launch
 // latency on a GPU: ALL n_steps run inside ONE single-workgroup kernel with the particles, scores and squared norms in
-// LDS and one lane per particle; the only HBM traffic is the final particle write-back and the gradient norms.
+// LDS; up to 1024 lanes = (particle, slice of the other particles); the only HBM traffic is the final particle
+// write-back and the gradient norms.
 //
 // Reference quirk kept: MPF.update_prior hands `self.x` itself to MultivariateNormal(loc=...), which aliases the
 // particle storage, and SGD updates x in place - so the prior means are always the CURRENT particles (mpf.py:26-38).
@@ -25,138 +26,192 @@ struct MpfArgs {
   float *phi_out;     // [Mp][P] or nullptr (phi of the first step, when n_steps == 0 semantics are wanted use n_steps=1, lr=0)
 };
 
-// d(next state)/d(params) of one model step, as autograd returns it through model.step (incl. clamp masks)
-__device__ inline void step_jacobian(const DevModel &dm, const float *x, const float *a, const float *prow, double *J /*[ds][P]*/,
-                                     int ds) {
-  const int P = dm.P;
-  for (int i = 0; i < ds * P; ++i) J[i] = 0.0;
-  double pv[4];
+// d(next state)/d(params) of one model step, as autograd returns it through model.step (incl. clamp masks).
+// J is [4][4] (state row, parameter column) and every index below is a compile-time constant or a select: a
+// dynamically indexed local array would live in scratch memory.
+__device__ __forceinline__ double sel4(const double v[4], int c) { return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ void add_col(double J[4][4], int row, int col, double v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (k == row && c == col) J[k][c] += v;
+}
+template <int P>
+__device__ __forceinline__ void step_jacobian(const DevModel &dm, const float *x, const float *a, const float prow[4], double J[4][4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) J[k][c] = 0.0;
+  double pv[4] = {0, 0, 0, 0};
+#pragma unroll
   for (int p = 0; p < P; ++p) pv[p] = dm.log_space ? exp((double)prow[p]) : (double)prow[p];
   if (dm.model == DUST_MODEL_PENDULUM) {
-    const double g = dm.g.kind == DUST_PARAM_SAMPLED ? pv[dm.g.col] : dm.g.value;
-    const double m = dm.mass.kind == DUST_PARAM_SAMPLED ? pv[dm.mass.col] : dm.mass.value;
-    const double l = dm.length.kind == DUST_PARAM_SAMPLED ? pv[dm.length.col] : dm.length.value;
+    const double g = dm.g.kind == DUST_PARAM_SAMPLED ? sel4(pv, dm.g.col) : dm.g.value;
+    const double m = dm.mass.kind == DUST_PARAM_SAMPLED ? sel4(pv, dm.mass.col) : dm.mass.value;
+    const double l = dm.length.kind == DUST_PARAM_SAMPLED ? sel4(pv, dm.length.col) : dm.length.value;
     const double dt = dm.dt;
     const double u = clampf(a[0], -dm.max_torque, dm.max_torque);
     const double s = sin((double)x[0] + M_PI);
     const double thd = (double)x[1] + dt * (-3.0 * g / (2.0 * l) * s + 3.0 / (m * l * l) * u);
     if (!(thd >= -dm.max_speed_pend && thd <= dm.max_speed_pend)) return;
-    const double dthd[3] = {dt * (-3.0 / (2.0 * l) * s), dt * (-3.0 / (m * m * l * l) * u),
-                            dt * (3.0 * g / (2.0 * l * l) * s - 6.0 / (m * l * l * l) * u)};
-    const DevParam *ps[3] = {&dm.g, &dm.mass, &dm.length};
-    for (int q = 0; q < 3; ++q)
-      if (ps[q]->kind == DUST_PARAM_SAMPLED) {
-        const int col = ps[q]->col;
-        const double chain = dm.log_space ? pv[col] : 1.0;
-        J[1 * P + col] += dthd[q] * chain;
-        J[0 * P + col] += dthd[q] * dt * chain;
-      }
+    const double dg = dt * (-3.0 / (2.0 * l) * s), dmass = dt * (-3.0 / (m * m * l * l) * u);
+    const double dl = dt * (3.0 * g / (2.0 * l * l) * s - 6.0 / (m * l * l * l) * u);
+    if (dm.g.kind == DUST_PARAM_SAMPLED) {
+      const double ch = dm.log_space ? sel4(pv, dm.g.col) : 1.0;
+      add_col(J, 1, dm.g.col, dg * ch);
+      add_col(J, 0, dm.g.col, dg * dt * ch);
+    }
+    if (dm.mass.kind == DUST_PARAM_SAMPLED) {
+      const double ch = dm.log_space ? sel4(pv, dm.mass.col) : 1.0;
+      add_col(J, 1, dm.mass.col, dmass * ch);
+      add_col(J, 0, dm.mass.col, dmass * dt * ch);
+    }
+    if (dm.length.kind == DUST_PARAM_SAMPLED) {
+      const double ch = dm.log_space ? sel4(pv, dm.length.col) : 1.0;
+      add_col(J, 1, dm.length.col, dl * ch);
+      add_col(J, 0, dm.length.col, dl * dt * ch);
+    }
   } else {
     if (dm.mass.kind != DUST_PARAM_SAMPLED) return;
     const int col = dm.mass.col;
-    const double m = pv[col], dt = dm.dt;
+    const double m = sel4(pv, col), dt = dm.dt;
     double om = 1.0;
     if (dm.can_crash && dm.with_obstacle) om = 1.0 - (double)collision(dm, x[0], x[1]);
+#pragma unroll
     for (int k = 0; k < 2; ++k) {
       const double acc = (double)a[k] / m;
       const bool live_a = acc >= -dm.max_acc && acc <= dm.max_acc;
       const double accc = acc < -dm.max_acc ? -dm.max_acc : (acc > dm.max_acc ? dm.max_acc : acc);
       const double v = (double)x[2 + k] + accc * dt * om;
       const bool live_v = v >= -dm.max_speed && v <= dm.max_speed;
-      if (live_a && live_v) J[(2 + k) * P + col] = dt * om * (-(double)a[k] / (m * m)) * (dm.log_space ? m : 1.0);
+      if (live_a && live_v) add_col(J, 2 + k, col, dt * om * (-(double)a[k] / (m * m)) * (dm.log_space ? m : 1.0));
     }
   }
 }
 
+// Lane = (particle i, slice r of the other particles): R = blockDim / Mpad slices share the O(M_p) loops of a particle and
+// their partial sums are combined in slice order through LDS (fixed order: reproducible).  No divisions or fp64
+// transcendentals inside the O(M_p^2) loops: reciprocals are hoisted (fp64, error 1e-16), weights use expf.
+// P is a template parameter: with a run-time P the per-lane arrays are indexed dynamically and live in scratch memory
+// (measured: 3 us per inner-loop iteration instead of ~50 ns).
+template <int P>
 __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int tid = threadIdx.x, Mp = a.Mp, P = a.P;
-  float *xs = sm;             // [Mp][P]
+  const int Mp = a.Mp;
+  const int Mpad = (Mp + 63) & ~63, R = blockDim.x / Mpad;
+  const int r = __builtin_amdgcn_readfirstlane((int)threadIdx.x / Mpad), i = (int)threadIdx.x - r * Mpad;
+  double *dbuf = reinterpret_cast<double *>(sm);  // [R][Mpad][2 P] partial sums (prior: zs + acc[P]; Stein: gk[P] + ks[P])
+  float *xs = reinterpret_cast<float *>(dbuf + (size_t)R * Mpad * 2 * P);  // [Mp][P]
   float *sc = xs + Mp * P;    // [Mp][P] scores
   float *nrm = sc + Mp * P;   // [Mp] squared norms
   float *red = nrm + Mp;      // [32]
-  const bool on = tid < Mp;
-  if (on)
-    for (int p = 0; p < P; ++p) xs[tid * P + p] = a.x[tid * P + p];
+  const bool on = i < Mp;
+  const int per = (Mp + R - 1) / R, k0 = r * per, k1 = min(Mp, k0 + per);
+  if (on && r == 0)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = a.x[i * P + p];
   __syncthreads();
   const float bw2 = (float)((double)a.bw * (double)a.bw);
+  const double inv_pbw = 1.0 / (double)a.prior_bw, inv_pbw2 = inv_pbw * inv_pbw;
+  const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw), inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
   for (int it = 0; it < a.n_steps; ++it) {
     float xi[4] = {0.f, 0.f, 0.f, 0.f};
     if (on) {
-      for (int p = 0; p < P; ++p) xi[p] = xs[tid * P + p];
-      // prior score (mpf.py:45): means alias the current particles, covariance prior_bw^2 I, uniform mixture
-      double mx = -INFINITY;
-      for (int k = 0; k < Mp; ++k) {
-        double q = 0.0;
-        for (int p = 0; p < P; ++p) {
-          const double z = ((double)xi[p] - (double)xs[k * P + p]) / (double)a.prior_bw;
-          q += z * z;
-        }
-        mx = fmax(mx, -0.5 * q);
-      }
+      _Pragma("unroll") for (int p = 0; p < P; ++p) xi[p] = xs[i * P + p];
+      // prior score (mpf.py:45): means alias the CURRENT particles (covariance prior_bw^2 I, uniform mixture), so the
+      // i-th logit is exactly 0 and no other is larger: the softmax needs no max pass
       double zs = 0.0, acc[4] = {0, 0, 0, 0};
-      for (int k = 0; k < Mp; ++k) {
+      for (int k = k0; k < k1; ++k) {
         double q = 0.0;
-        for (int p = 0; p < P; ++p) {
-          const double z = ((double)xi[p] - (double)xs[k * P + p]) / (double)a.prior_bw;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          const double z = ((double)xi[p] - (double)xs[k * P + p]) * inv_pbw;
           q += z * z;
         }
-        const double w = exp(-0.5 * q - mx);
+        const double w = (double)expf((float)(-0.5 * q));
         zs += w;
-        for (int p = 0; p < P; ++p) acc[p] += w * ((double)xs[k * P + p] - (double)xi[p]);
+        _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] += w * ((double)xs[k * P + p] - (double)xi[p]);
+      }
+      double *d = dbuf + ((size_t)r * Mpad + i) * 2 * P;
+      d[0] = zs;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) d[1 + p] = acc[p];  // 1 + P <= 2 P slots
+    }
+    __syncthreads();
+    if (on && r == 0) {
+      double zs = 0.0, acc[4] = {0, 0, 0, 0};
+      for (int rr = 0; rr < R; ++rr) {
+        const double *d = dbuf + ((size_t)rr * Mpad + i) * 2 * P;
+        zs += d[0];
+        _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] += d[1 + p];
       }
       double s[4];
-      for (int p = 0; p < P; ++p) s[p] = acc[p] / zs / ((double)a.prior_bw * (double)a.prior_bw);
+      _Pragma("unroll") for (int p = 0; p < P; ++p) s[p] = acc[p] / zs * inv_pbw2;
       // likelihood score (mpf.py:46-50, likelihoods.py:30-49)
       float pred[4];
       for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
       const Coef cf = make_coef(a.dm, xi);
       if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
       else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
-      double J[16];
-      step_jacobian(a.dm, a.past_obs, a.past_action, xi, J, a.ds);
-      for (int p = 0; p < P; ++p) {
+      double J[4][4];
+      step_jacobian<P>(a.dm, a.past_obs, a.past_action, xi, J);
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
         double g = 0.0;
-        for (int k = 0; k < a.ds; ++k) g += J[k * P + p] * ((double)a.obs[k] - (double)pred[k]);
-        s[p] += g / ((double)a.obs_std * (double)a.obs_std);
-        sc[tid * P + p] = (float)s[p];
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)
+          if (k < a.ds) g += J[k][p] * ((double)a.obs[k] - (double)pred[k]);
+        s[p] += g * inv_obs2;
+        sc[i * P + p] = (float)s[p];
       }
       float nn = 0.f;
-      for (int p = 0; p < P; ++p) nn = nn + xi[p] * xi[p];
-      nrm[tid] = nn;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) nn = nn + xi[p] * xi[p];
+      nrm[i] = nn;
     }
     __syncthreads();
     // kernel + phi (svgd.py:92-99, mpf.py:52-56).  squared_distance's fp32 addmm rounding is followed: it is part of the
     // reference's result (d^2 / bw^2 amplifies it) - dot as an fma chain, then |b|^2 - 2 a.b, then + |a|^2, clamp 0.
-    float ph[4] = {0.f, 0.f, 0.f, 0.f};
     if (on) {
       double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
-      for (int j = 0; j < Mp; ++j) {
+      const float ni = nrm[i];
+      for (int j = k0; j < k1; ++j) {
         float dot = xi[0] * xs[j * P];
-        for (int r = 1; r < P; ++r) dot = fmaf(xi[r], xs[j * P + r], dot);
-        float q = (nrm[j] + (-2.0f * dot)) + nrm[tid];
+        _Pragma("unroll") for (int q = 1; q < P; ++q) dot = fmaf(xi[q], xs[j * P + q], dot);
+        float q = (nrm[j] + (-2.0f * dot)) + ni;
         q = fmaxf(q, 0.f);
         const double k = (double)expf(((-q) / bw2) / 2.0f);
-        for (int p = 0; p < P; ++p) {
-          gk[p] += -k * ((double)xi[p] - (double)xs[j * P + p]) / ((double)a.bw * (double)a.bw);
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          gk[p] -= k * ((double)xi[p] - (double)xs[j * P + p]);
           ks[p] += k * (double)sc[j * P + p];
         }
       }
-      for (int p = 0; p < P; ++p) ph[p] = (float)(gk[p] + ks[p] / Mp);
+      double *d = dbuf + ((size_t)r * Mpad + i) * 2 * P;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        d[p] = gk[p];
+        d[P + p] = ks[p];
+      }
+    }
+    __syncthreads();
+    float ph[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on && r == 0) {
+      double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
+      for (int rr = 0; rr < R; ++rr) {
+        const double *d = dbuf + ((size_t)rr * Mpad + i) * 2 * P;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          gk[p] += d[p];
+          ks[p] += d[P + p];
+        }
+      }
+      _Pragma("unroll") for (int p = 0; p < P; ++p) ph[p] = (float)(gk[p] * inv_bw2 + ks[p] / Mp);
     }
     float n2 = 0.f;
-    for (int p = 0; p < P; ++p) n2 += ph[p] * ph[p];
+    _Pragma("unroll") for (int p = 0; p < P; ++p) n2 += ph[p] * ph[p];
     n2 = block_reduce<RED_SUM>(n2, red);
-    if (tid == 0 && a.grad_norms) a.grad_norms[it] = sqrtf(n2);
-    if (on && it == 0 && a.phi_out)
-      for (int p = 0; p < P; ++p) a.phi_out[tid * P + p] = ph[p];
-    __syncthreads();
-    if (on)
-      for (int p = 0; p < P; ++p) xs[tid * P + p] = fmaf(a.lr, ph[p], xi[p]);
+    if (threadIdx.x == 0 && a.grad_norms) a.grad_norms[it] = sqrtf(n2);
+    if (on && r == 0 && it == 0 && a.phi_out)
+      _Pragma("unroll") for (int p = 0; p < P; ++p) a.phi_out[i * P + p] = ph[p];
+    if (on && r == 0)
+      _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = fmaf(a.lr, ph[p], xi[p]);
     __syncthreads();
   }
-  if (on)
-    for (int p = 0; p < P; ++p) a.x[tid * P + p] = xs[tid * P + p];
+  if (on && r == 0)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) a.x[i * P + p] = xs[i * P + p];
 }
 
 __global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, int K, int P, float bw, float *out) {
@@ -338,9 +393,20 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.x = m->x;
   a.grad_norms = gn_dev;
   a.phi_out = phi_dev;
-  const int nt = ((m->Mp + 63) / 64) * 64;
-  const size_t lds = sizeof(float) * ((size_t)2 * m->Mp * m->P + m->Mp + 32);
-  mpf_optimize_kernel<<<1, nt, lds, m->stream>>>(a);
+  const int mpad = ((m->Mp + 63) / 64) * 64;
+  int R = 1;
+  while (mpad * R * 2 <= 1024) R *= 2;
+  const size_t lds = sizeof(double) * (size_t)R * mpad * 2 * m->P + sizeof(float) * ((size_t)2 * m->Mp * m->P + m->Mp + 32);
+#define DUST_LAUNCH_MPF(PP)                                                                                                        \
+  do {                                                                                                                              \
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)mpf_optimize_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    mpf_optimize_kernel<PP><<<1, mpad * R, lds, m->stream>>>(a);                                                                    \
+  } while (0)
+  if (m->P == 1) DUST_LAUNCH_MPF(1);
+  else if (m->P == 2) DUST_LAUNCH_MPF(2);
+  else if (m->P == 3) DUST_LAUNCH_MPF(3);
+  else DUST_LAUNCH_MPF(4);
+#undef DUST_LAUNCH_MPF
   HIP_TRY(hipGetLastError());
   return DUST_OK;
 }
