@@ -42,8 +42,108 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   return r;
 }
 
+enum { K2_NC = 1 };  // candidate thresholds per bisection round (measured at N = 1024: 1 -> 43 us, 2 -> 50, 3 -> 54, 7 -> 77)
+
 // one workgroup per independent scalar dimension c
 __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args a, int npow2) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [npow2]
+  __shared__ unsigned redc[16 * 8];
+  const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
+  for (int i = tid; i < npow2; i += nt) xs[i] = i < N ? a.thetaT[(size_t)c * N + i] : INFINITY;
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += nt) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float u = xs[i], v = xs[ixj];
+          const bool up = (i & k) == 0;
+          if ((u > v) == up) {
+            xs[i] = v;
+            xs[ixj] = u;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
+  const float span = xs[N - 1] - xs[0];
+  unsigned lo = 0u, hi = __float_as_uint(span * span);
+  // Bisection with NC candidate thresholds per round (their counts share one block reduction).  b_v(i) = largest j >= i with
+  // (x_j - x_i)^2 <= v is monotone in v, so every lane keeps a bracket [bl, br] of b for the current [lo, hi] and only
+  // searches inside it: the per-lane searches shrink from log2 N steps to 1-2 as the bisection narrows.
+  // (blockDim >= N is required: one particle per lane - the host launches 1024 lanes and N <= 1024 takes this kernel.)
+  constexpr int NC = K2_NC;
+  const bool has = tid < N;
+  const float xi = has ? xs[tid] : 0.f;
+  int bl = tid, br = N - 1;
+  while (lo < hi) {
+    unsigned mid[NC];
+    int b[NC];
+    unsigned cnt[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      mid[c] = lo + (unsigned)(((unsigned long long)(hi - lo) * (unsigned)(c + 1)) / (unsigned)(NC + 1));
+      const float v = __uint_as_float(mid[c]);
+      int l = (c == 0) ? bl : b[c - 1], r = br;  // candidates ascend: b of the previous one is a lower bound
+      if (has)
+        while (l < r) {
+          const int m = (l + r + 1) >> 1;
+          const float dlt = xs[m] - xi;
+          if (dlt * dlt <= v) l = m;
+          else r = m - 1;
+        }
+      b[c] = l;
+      cnt[c] = has ? (unsigned)(l - tid) : 0u;
+    }
+    // block sums of the NC counters (2 sum + N <= 2 N^2 < 2^32)
+    {
+      const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt[c] += __shfl_xor(cnt[c], o, 64);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) redc[wid * 8 + c] = cnt[c];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        unsigned t = lane < nw ? redc[lane * 8 + c] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        cnt[c] = t;
+      }
+    }
+    // counts are monotone in the threshold
+    unsigned nlo = lo, nhi = hi;
+    int nbl = bl, nbr = br;
+#pragma unroll
+    for (int c = NC - 1; c >= 0; --c) {
+      const bool below = 2ull * cnt[c] + (unsigned long long)N < want;
+      nhi = below ? nhi : mid[c];  // smallest candidate that reaches the rank
+      nbr = below ? nbr : b[c];
+      const bool raise = below && nlo <= mid[c];
+      nlo = raise ? mid[c] + 1u : nlo;  // largest candidate below the rank, + 1
+      nbl = raise ? b[c] : nbl;
+    }
+    lo = nlo;
+    hi = nhi < nlo ? nlo : nhi;
+    bl = nbl;
+    br = nbr;
+  }
+  if (tid == 0) {
+    float h = __uint_as_float(lo);
+    h = h / (float)log((double)N + 1.0);  // base_kernels.py:77
+    h = a.bw_scale * h;
+    a.h[c] = fmaxf(h, 1e-5f);
+  }
+}
+
+// N > 1024 (several particles per lane): plain bisection, a full binary search per particle and round
+__global__ __launch_bounds__(1024) void k2_bandwidth_sorted_big_kernel(const K2Args a, int npow2) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [npow2]
   __shared__ unsigned long long red64[16];
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
@@ -141,34 +241,75 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_pairs_kernel(const K2Args a
 }
 
 // phi_ic = mean_j K^c_ij score_jc + mean_j K^c_ij (x_ic - x_jc) 2/h_c   (svmpc.py:69-73, base_kernels.py:100-101)
-// grid = (ceil(n_local/256), G); lane = particle i; the j loop reads wave-uniform addresses (scalar loads).
+// grid = (ceil(n_local/64), G) x 256 lanes: lane = (particle i of a 64-tile, one of 4 wave-uniform slices of the other
+// particles j).  The j-columns (coordinates and scores of the group's dimension(s)) are staged through LDS in chunks of
+// K2_JT rows and read back as broadcasts; the 4 slice partials are combined in slice order (reproducible).
+// exp(-d2/h): exact fp32 division as the reference, then the bare v_exp_f32 (error ~|x| 2^-24, as in the K1 Gram value);
+// the 2/h factor of the repulsive term is applied once to the sum.
+enum { K2_JT = 2048 };
+template <int GD /* dimensions per kernel group: 1, or d_a (<= 2) when shared */>
 __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
+  __shared__ float xcol[GD][K2_JT], scol[GD][K2_JT];
+  __shared__ float part[4][64][4];
   const int N = a.N, D = a.D, da = a.da;
   const int g = blockIdx.y;
-  const int gd = a.shared ? da : 1;
+  constexpr int gd = GD;
   const int c0 = g * gd;
-  const int il = blockIdx.x * blockDim.x + threadIdx.x;
-  if (il >= a.n_local) return;
-  const int i = a.i0 + il;
+  const int ii = threadIdx.x & 63, js = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int il = blockIdx.x * 64 + ii;
+  const bool on = il < a.n_local;
+  const int i = a.i0 + (on ? il : 0);
   const float h = a.h[g];
-  float xi[4], g1[4], g2[4];
-  for (int q = 0; q < gd; ++q) {
-    xi[q] = a.thetaT[(size_t)(c0 + q) * N + i];
-    g1[q] = g2[q] = 0.f;
-  }
-  for (int j = 0; j < N; ++j) {
-    float d2 = 0.f, df[4];
-    for (int q = 0; q < gd; ++q) {
-      df[q] = xi[q] - a.thetaT[(size_t)(c0 + q) * N + j];
-      d2 = fmaf(df[q], df[q], d2);
+  float xi[2] = {0.f, 0.f}, g1[2] = {0.f, 0.f}, g2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (q < gd) xi[q] = a.thetaT[(size_t)(c0 + q) * N + i];
+  for (int jb = 0; jb < N; jb += K2_JT) {
+    const int jn = min(K2_JT, N - jb);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < gd * jn; idx += 256) {
+      const int q = idx / jn, j = idx - q * jn;
+      xcol[q][j] = a.thetaT[(size_t)(c0 + q) * N + jb + j];
+      scol[q][j] = a.score[(size_t)(jb + j) * D + c0 + q];
     }
-    const float k = expf(-d2 / h);
-    for (int q = 0; q < gd; ++q) {
-      g1[q] = fmaf(k, a.score[(size_t)j * D + c0 + q], g1[q]);
-      g2[q] += ((k * df[q]) * 2.0f) / h;
+    __syncthreads();
+    const int per = (jn + 3) >> 2, j0 = js * per, j1 = min(jn, j0 + per);
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      float d2 = 0.f, df[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (q < gd) {
+          df[q] = xi[q] - xcol[q][j];
+          d2 = fmaf(df[q], df[q], d2);
+        }
+      const float k = __builtin_amdgcn_exp2f((-d2 / h) * 1.44269504088896340736f);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (q < gd) {
+          g1[q] = fmaf(k, scol[q][j], g1[q]);
+          g2[q] = fmaf(k, df[q], g2[q]);
+        }
     }
   }
-  for (int q = 0; q < gd; ++q) a.phi[(size_t)i * D + c0 + q] = g1[q] / (float)N + g2[q] / (float)N;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    part[js][ii][q] = g1[q];
+    part[js][ii][2 + q] = g2[q];
+  }
+  __syncthreads();
+  if (js == 0 && on) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < gd) {
+        float s1 = part[0][ii][q], s2 = part[0][ii][2 + q];
+        for (int r = 1; r < 4; ++r) {
+          s1 += part[r][ii][q];
+          s2 += part[r][ii][2 + q];
+        }
+        a.phi[(size_t)i * D + c0 + q] = s1 / (float)N + ((s2 * 2.0f) / h) / (float)N;
+      }
+  }
 }
 
 static inline int launch_k2(hipStream_t stream, const K2Args &a) {
@@ -178,11 +319,14 @@ static inline int launch_k2(hipStream_t stream, const K2Args &a) {
   } else {
     int np = 1;
     while (np < a.N) np <<= 1;
-    k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
+    if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
+    else k2_bandwidth_sorted_big_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
   }
   if (hipGetLastError() != hipSuccess) return DUST_ERR_HIP;
-  dim3 grid((a.n_local + 255) / 256, G);
-  k2_phi_kernel<<<grid, 256, 0, stream>>>(a);
+  if (a.da > 2) return DUST_ERR_UNSUPPORTED;  // models on the path have d_a <= 2
+  dim3 grid((a.n_local + 63) / 64, G);
+  if (a.shared && a.da == 2) k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
+  else k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
   if (hipGetLastError() != hipSuccess) return DUST_ERR_HIP;
   return DUST_OK;
 }

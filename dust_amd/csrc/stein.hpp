@@ -180,7 +180,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         float v;
         if (MODE == PAIR_PRIOR) v = (jA < jc) ? lm - 0.5f * dd : -INFINITY;
         else if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;  // exp(-dd/2) = 2^(-dd/(2 ln 2)); bare v_exp_f32, rel. error ~|x| 2^-24
-        else v = (jA < jc) ? dd : INFINITY;  // IMQ: k and k' are formed in pass B (inf -> k = 0)
+        else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + dd) : 0.f;  // IMQ: k = (1 + d^2/l^2)^(-1/2) once per pair (bare v_rsq_f32, 1 ulp); k' = -k^3 in pass B
         kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
       }
     }
@@ -216,11 +216,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       const float kq = kv[iB * (JC + 1) + jj];
       float k = kq, kp = 0.f;
       if (MODE == PAIR_K1) kp = -kq;  // d k / d x_i = -k (x_i - x_j) / ell^2
-      if (MODE == PAIR_IMQ) {
-        const float base = 1.0f + kq;
-        k = rsqrtf(base);  // inf -> 0
-        kp = (kq == INFINITY) ? 0.f : -k / base;
-      }
+      if (MODE == PAIR_IMQ) kp = -(kq * kq) * kq;  // d k / d x_i = -(1 + d^2/l^2)^(-3/2) (x_i - x_j) / l^2
       const v2f kk = {k, k}, kpp = {kp, kp};
 #pragma unroll
       for (int c = 0; c < CPT; c += 4) {
