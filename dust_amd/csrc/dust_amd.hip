@@ -1288,11 +1288,27 @@ static int forward_finish_device(dust_ctx *c) {
     f.logp_out = c->logp;
     f.pm = prior_merge_args(c);
   }
-  finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
-  HIP_TRY(hipGetLastError());
-  // reads the current buffer, writes the home buffer: a tick always ends (and a captured tick always starts) on home
-  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(c->theta, c->theta_home, c->N, c->H, c->da, c->cfg.roll_strategy, c->n0, c->nloc, c->ctr_dev);
-  HIP_TRY(hipGetLastError());
+  RollArgs r;
+  memset(&r, 0, sizeof r);
+  r.theta = c->theta;
+  r.theta_dst = c->theta_home;  // a tick always ends (and a captured tick always starts) on the home buffer
+  r.N = c->N;
+  r.H = c->H;
+  r.da = c->da;
+  r.strategy = c->cfg.roll_strategy;
+  r.i0 = c->n0;
+  r.n_local = c->nloc;
+  r.ctr = c->ctr_dev;
+  if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && c->D <= 128 && !c->prof) {
+    // out-of-place roll: independent of finalize (which gathers a_seq from the buffer the roll only reads) -> one launch
+    finalize_roll_kernel<<<1 + (c->nloc + 7) / 8, 1024, 0, c->stream>>>(f, r);
+    HIP_TRY(hipGetLastError());
+  } else {
+    finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
+    HIP_TRY(hipGetLastError());
+    roll_kernel<<<c->nloc, 128, 0, c->stream>>>(r);
+    HIP_TRY(hipGetLastError());
+  }
   if (c->theta != c->theta_home) {
     c->theta_alt = c->theta;
     c->theta = c->theta_home;

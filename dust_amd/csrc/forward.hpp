@@ -52,7 +52,7 @@ __device__ __forceinline__ void block_reduce2(float &mx, float &sm, float *scrat
 
 // single workgroup: softmax over N, first-index argmax, a_seq, new mixture log-weights.  Each lane keeps its particles'
 // values in registers between the passes (N <= 8 * 1024 on that path), so global memory is read once and written once.
-__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
+__device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
   __shared__ float red[32];
   __shared__ int redi[32];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -151,6 +151,8 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
   _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i < a.N) a.logmix[i] = lwr[r] - lzz; }
 }
 
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) { finalize_body(a); }
+
 // mixture log-weights from user-supplied weights (set_prior): same construction as above
 __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *logmix, int N) {
   __shared__ float red[32];
@@ -174,28 +176,54 @@ __global__ __launch_bounds__(1024) void logmix_kernel(const float *w, float *log
   for (int i = tid; i < N; i += nt) logmix[i] = logmix[i] - lzz;
 }
 
-// SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy.  One workgroup per particle,
-// lane = element: every element is read into a register, the workgroup syncs, then the shifted value is written.
-__global__ __launch_bounds__(128) void roll_kernel(const float *theta, float *theta_dst, int N, int H, int da, int strategy, int i0, int n_local, uint32_t *ctr) {
+// SVMPC.roll svmpc.py:142-158 (steps = -1): shift left along H; last row per strategy.  One 128-lane group per particle,
+// lane = element: every element is read into a register, the group syncs, then the shifted value is written.
+struct RollArgs {
+  const float *theta;  // current particles
+  float *theta_dst;    // where the rolled particles go (the home buffer of the ping-pong; may equal theta)
+  int N, H, da, strategy, i0, n_local;
+  uint32_t *ctr;
+};
+
+__global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
   __shared__ float red[32];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // next tick: new Philox sub-stream
-    ctr[0] += 1u;
-    ctr[1] = 0u;
+    a.ctr[0] += 1u;
+    a.ctr[1] = 0u;
   }
-  const int i = i0 + blockIdx.x;
-  const int D = H * da, j = threadIdx.x;
-  const float *th = theta + (size_t)i * D;
+  const int i = a.i0 + blockIdx.x;
+  const int D = a.H * a.da, j = threadIdx.x, da = a.da;
+  const float *th = a.theta + (size_t)i * D;
   const float own = j < D ? th[j] : 0.f;
   const float nxt = (j + da < D) ? th[j + da] : own;  // "repeat": the last row keeps its value
   float out = nxt;
-  if (strategy == DUST_ROLL_MEAN) {  // mean over the horizon of each control dimension (svmpc.py:151-153)
+  if (a.strategy == DUST_ROLL_MEAN) {  // mean over the horizon of each control dimension (svmpc.py:151-153)
     for (int c = 0; c < da; ++c) {
       const float s = block_reduce<RED_SUM>((j < D && j % da == c) ? own : 0.f, red);
-      if (j + da >= D && j < D && j % da == c) out = s / (float)H;
+      if (j + da >= D && j < D && j % da == c) out = s / (float)a.H;
     }
   }
   __syncthreads();
-  if (j < D) theta_dst[(size_t)i * D + j] = out;
+  if (j < D) a.theta_dst[(size_t)i * D + j] = out;
+}
+
+// finalize + roll in ONE launch (1024-lane workgroups: workgroup 0 finalizes, every other one rolls 8 particles).  Only
+// when the roll is out of place ("repeat" strategy, theta != theta_dst): finalize gathers a_seq = theta[i*] from the
+// buffer the roll only reads, so the two are independent and the roll hides under the single-workgroup finalize.
+__global__ __launch_bounds__(1024) void finalize_roll_kernel(const FinalizeArgs f, const RollArgs a) {
+  if (blockIdx.x == 0) {
+    finalize_body(f);
+    if (threadIdx.x == 0) {
+      a.ctr[0] += 1u;
+      a.ctr[1] = 0u;
+    }
+    return;
+  }
+  const int il = ((int)blockIdx.x - 1) * 8 + ((int)threadIdx.x >> 7), j = threadIdx.x & 127;
+  if (il >= a.n_local) return;
+  const int i = a.i0 + il, D = a.H * a.da;
+  const float *th = a.theta + (size_t)i * D;
+  if (j < D) a.theta_dst[(size_t)i * D + j] = (j + a.da < D) ? th[j + a.da] : th[j];
 }
 
 // a_mix = softmax_n(eta) disco.py:393 (single workgroup)
