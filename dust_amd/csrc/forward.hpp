@@ -110,13 +110,16 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
     redi[wid] = bi;
   }
   __syncthreads();
-  best = red[0];
-  bi = redi[0];
-  for (int w = 1; w < nw; ++w)
-    if (red[w] > best || (red[w] == best && redi[w] < bi)) {
-      best = red[w];
-      bi = redi[w];
+  best = lane < nw ? red[lane] : -INFINITY;  // second level in registers (lane w holds wave w's candidate)
+  bi = lane < nw ? redi[lane] : 0x7fffffff;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
     }
+  }
   if (tid == 0) *a.istar = bi;
   for (int d = tid; d < a.D; d += nt) a.a_seq_out[d] = a.theta[(size_t)bi * a.D + d];
   // new prior mixture: Categorical(probs = w / sum w) -> logits = log(clamp(probs, eps, 1 - eps)) -> log_softmax
