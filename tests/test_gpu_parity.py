@@ -329,3 +329,56 @@ def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H):
         c.close()
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,H,ell", [(256, 30, 1.0), (1024, 30, 0.7), (96, 40, 2.5)])
+def test_imq_phi_vs_oracle(N, H, ell):
+    """IMQ kernel k = (1 + |x-y|^2/l^2)^(-1/2) (new with the north star, pinned only by the oracle's closed form)."""
+    from dust_amd import Context
+    from oracle import Oracle
+
+    rng = np.random.default_rng(N)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    theta = (mu + 0.5 * rng.standard_normal((N, H, 1))).astype(np.float32)
+    S = 16
+    costs = (50.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, 1))).astype(np.float32)
+    o = Oracle(model="pendulum", N=N, S=S, M=1, H=H)
+    sg = np.ones(1, np.float32)
+    gl, gp, sc = o.score(theta, mu, np.ones(N), sg, costs, actions, 1.0, sg)
+    c = Context(model="pendulum", N=N, S=S, M=1, H=H, kernel="IMQ", imq_ell=ell, lr=0.5, sigma_a=1.0, sigma_p=1.0)
+    c.set_theta(theta)
+    c.set_prior(mu)
+    c.set_a_mat(theta)
+    phi, dgl, dgp = c.svmpc_phi(costs, actions)
+    assert relerr(dgl, gl) < TOL and relerr(dgp, gp) < TOL
+    assert relerr(phi, o.phi_imq(theta, sc, ell)) < TOL
+    c.close()
+
+
+@pytest.mark.parametrize("N", [1000, 1024, 2048, 3000])
+def test_k2_bandwidth_is_the_exact_order_statistic(N):
+    """h_c = median(pairwise squared distances) / log(N+1) with torch.median's lower-middle rule over all N^2 entries
+    (base_kernels.py:53-77): the GPU selects it by bisection on the float's bit pattern - it must be the exact value, for
+    both bandwidth kernels (N <= 1024 bracketed search, N > 1024 plain)."""
+    from dust_amd import Context
+
+    H = 3
+    rng = np.random.default_rng(N)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    theta = (mu + rng.standard_normal((N, H, 1))).astype(np.float32)
+    theta[: N // 7, 1, 0] = theta[0, 1, 0]  # ties and zero distances in one dimension
+    c = Context(model="pendulum", N=N, S=8, M=1, H=H, kernel="K2", lr=0.0, sigma_a=1.0, sigma_p=1.0)
+    c.set_theta(theta)
+    c.set_prior(mu)
+    c.set_a_mat(theta)
+    c.svmpc_optimize(np.array([3.0, 0.0], np.float32), 1)
+    h = c.get_bandwidths()
+    c.close()
+    X = theta.reshape(N, H)
+    for d in range(H):
+        x = X[:, d]
+        pw = (x[:, None] - x[None, :]) ** 2  # fp32, as the sorted-coordinate kernel forms it
+        v = np.partition(pw.ravel(), (N * N - 1) // 2)[(N * N - 1) // 2]
+        ref = max(np.float32(v) / np.float32(np.log(N + 1.0)), np.float32(1e-5))
+        assert np.float32(h[d]) == np.float32(ref), (d, h[d], ref)
