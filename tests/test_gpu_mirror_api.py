@@ -144,3 +144,48 @@ def test_particle_dual_inference_loop(golden):
         grads, bw = mpf.optimize(action, state, bw=0.5, n_steps=5)
         assert grads.shape == (5,) and torch.isfinite(grads).all() and torch.isfinite(sv.theta).all()
     assert mpf.x.shape == (16, 1) and mpf.prior.sample([4]).shape == (4, 1)
+
+
+def test_closed_loop_drivers():
+    """the reference's closed-loop entry points (simulations.py) on the device backend - the particle
+    episode with the mass-change event and the dynamics filter, and the pendulum simulation's result frame."""
+    import importlib.util
+    import os
+
+    import torch.distributions as dist
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import MPF, GaussianLikelihood, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import PendulumModel
+    from dust_amd.utils.simulations import run_pendulum_simulation
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("particle_example", os.path.join(root, "examples", "particle_example.py"))
+    pe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pe)
+    costs = pe.main(["--steps", "24", "--seed", "1"])
+    assert len(costs) == 1 and np.isfinite(costs[0]) and costs[0] > 0
+
+    torch.manual_seed(0)
+    N, H, S = 4, 10, 32
+    env_model = PendulumModel()
+    prior = get_gmm(torch.randn(N, H, 1), torch.ones(N), 4.0 * torch.eye(1))
+    init_policies = prior.sample([N])
+    dyn_prior = dist.Independent(dist.Uniform(torch.tensor([0.6, 0.6]), torch.tensor([1.3, 1.3])), 1)
+    ctrl = MultiDISCO(env_model.observation_space, env_model.action_space, H, N, S, temperature=1.0, a_cov=4.0 * torch.eye(1),
+                      inst_cost_fn=inst_cost, term_cost_fn=term_cost, params_sampling=True, params_samples=3)
+    init_state = torch.tensor([3.0, 0.0])
+    lik = GaussianLikelihood(initial_obs=init_state, obs_std=0.1, model=PendulumModel(uncertain_params=("length", "mass")), log_space=False)
+    mpf = MPF(init_particles=dyn_prior.sample([16]), likelihood=lik, optimizer_class=torch.optim.SGD, lr=1e-3, bw=0.1)
+    df = run_pendulum_simulation(
+        init_state, init_policies, dict(uncertain_params=("length", "mass")), mpf.prior, [dict(length=0.9, mass=1.1)], ctrl,
+        use_exact_model=False, use_svmpc=True,
+        svmpc_kwargs=dict(init_particles=init_policies, prior=prior, kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1,
+                          optimizer_class=torch.optim.SGD, lr=2.0),
+        lik_kwargs=dict(alpha=1.0, n_samples=S), mpf=mpf, mpf_bw=None, mpf_steps=5, episodes=1, steps=6, warm_up=1)
+    want = {"Cost", "Position", "Speed", "Actions", "Timestep", "Iteration", "DynParticles", "DynBandwidths", "PolParticles", "Weights",
+            "ExpParams", "AvgCumCost"}
+    assert want <= set(df.columns) and len(df) == 6
+    assert np.isfinite(df["Cost"].to_numpy()).all() and np.isfinite(df["Position"].to_numpy()).all()
+    assert abs(sum(df["Weights"].iloc[3]) - 1.0) < 1e-3
