@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "forward.hpp"
 #include "fused.hpp"
+#include "pairwise_big.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -76,6 +77,8 @@ struct dust_ctx {
   float *adam_m, *adam_v;
   float *pA, *pB, *pM, *pL;  // slice partials of the tiled pairwise passes
   size_t pA_cap, pB_cap, pM_cap, pL_cap;
+  float *xpad;               // [N][DPB] zero-padded query rows of the large-N pairwise kernel
+  size_t xpad_cap;
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
   size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
@@ -247,7 +250,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
                   &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->xpad};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -575,8 +578,19 @@ struct SampleOpts {
 };
 
 // geometry of the tiled pairwise launches: i-tiles of PAIR_TI queries x JS key slices, >= ~512 workgroups when possible
+// Large key sets take the register-blocked kernel of pairwise_big.hpp (its tile is TQ = 4096 / DPB queries).
+// Measured (round 1, N = 16384 / 4096, D = 30): Stein 1107 / 82 us vs 1730 / 115 us, prior 1367 / 99 vs 1799 / 119 us; D = 40:
+// 5-15 % faster; D = 80 (DPB = 128, 32-query tiles) the prior pass is slower, so D > 64 keeps the 32 x 64 kernel.  Sharded
+// contexts (few query tiles per rank) keep it too: it allows JS <= 16 and with that the fused launches.
+static int pair_dpb(int D) { return D <= 32 ? 32 : 64; }
+static bool pair_is_big(const dust_ctx *c) {
+  static const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel
+  if (env && atoi(env) == 0) return false;
+  return c->N >= 2048 && c->D <= 64 && c->nloc == c->N;
+}
 static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
-  *tiles = (c->nloc + PAIR_TI - 1) / PAIR_TI;
+  const int ti = pair_is_big(c) ? 4096 / pair_dpb(c->D) : PAIR_TI;
+  *tiles = (c->nloc + ti - 1) / ti;
   const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
   int js = (512 + *tiles - 1) / *tiles;
   js = std::max(1, std::min(js, chunks));
@@ -855,7 +869,11 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
 // pairwise passes (tiled: PAIR_TI queries x key slices; partials combined by the next kernel in the chain)
 
 template <int MODE>
+static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles);
+
+template <int MODE>
 static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
+  if (pair_is_big(c)) return launch_pair_big<MODE>(c, a, tiles);
   const int cpt = cpt_for(a.D);
   const size_t lds = pairwise_lds_bytes(MODE, cpt);
   dim3 grid(tiles, a.JS);
@@ -870,6 +888,37 @@ static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
   else if (cpt == 12) DUST_LAUNCH_PAIR(12);
   else DUST_LAUNCH_PAIR(16);
 #undef DUST_LAUNCH_PAIR
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
+template <int MODE>
+static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
+  const int dpb = pair_dpb(a.D);
+  TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
+  {
+    const int n = c->N * dpb;
+    pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
+    HIP_TRY(hipGetLastError());
+  }
+  PairBigArgs b;
+  memset(&b, 0, sizeof b);
+  b.p = a;
+  b.Xp = c->xpad;
+  b.ldp = 8 * cpt_for(a.D);
+  b.w[0] = a.inv_s[0] * a.inv_s[0];
+  b.w[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.w[0];
+  const size_t lds = pairwise_big_lds_bytes(MODE, dpb);
+  dim3 grid(tiles, a.JS);
+#define DUST_LAUNCH_BIG(DPB)                                                                                                        \
+  do {                                                                                                                               \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                            \
+      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_big_kernel<MODE, DPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    pairwise_big_kernel<MODE, DPB><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                       \
+  } while (0)
+  if (dpb == 32) DUST_LAUNCH_BIG(32);
+  else DUST_LAUNCH_BIG(64);
+#undef DUST_LAUNCH_BIG
   HIP_TRY(hipGetLastError());
   return DUST_OK;
 }
@@ -918,7 +967,7 @@ static int launch_prior(dust_ctx *c) {
 static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
   static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
-  if (off || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in) return DUST_OK;
+  if (off || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
   FusedArgs f;
   memset(&f, 0, sizeof f);
   int nt;
@@ -1085,7 +1134,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     static const bool no_fuse = getenv("DUST_NO_FUSE") != nullptr;  // development switch
     const int cpt = cpt_for(a.D);
     const size_t lds = pairwise_lds_bytes(PAIR_K1, cpt);
-    bool fuse = apply && !c->prof && !no_fuse && cpt <= 8;  // D <= 64: >= 2 workgroups per CU co-resident
+    bool fuse = apply && !c->prof && !no_fuse && cpt <= 8 && !pair_is_big(c);  // D <= 64: >= 2 workgroups per CU co-resident
     if (fuse && (!c->stein_cnt || c->stein_tiles != tiles)) {
       if (c->capturing) fuse = false;
       else {

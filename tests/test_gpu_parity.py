@@ -382,3 +382,43 @@ def test_k2_bandwidth_is_the_exact_order_statistic(N):
         v = np.partition(pw.ravel(), (N * N - 1) // 2)[(N * N - 1) // 2]
         ref = max(np.float32(v) / np.float32(np.log(N + 1.0)), np.float32(1e-5))
         assert np.float32(h[d]) == np.float32(ref), (d, h[d], ref)
+
+
+@pytest.mark.parametrize("model,N,H,kernel", [("pendulum", 2048, 30, "K1"), ("pendulum", 2200, 17, "IMQ"), ("particle", 2048, 20, "K1"),
+                                              ("particle", 2048, 40, "K1"), ("pendulum", 4096, 30, "K1")])
+def test_large_key_set_pairwise_vs_oracle(model, N, H, kernel):
+    """N >= 2048 takes the register-blocked pairwise kernel (pairwise_big.hpp): prior score, log p and phi against the
+    oracle for both padded widths (D = 30 / 17 -> 32, 40 -> 64), D = 80 (which stays on the 32 x 64 kernel), ragged N, and
+    log p through a forward pass."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(N + H)
+    S = 8
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    theta = (mu + 0.4 * rng.standard_normal((N, H, da))).astype(np.float32)
+    costs = (30.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, da))).astype(np.float32)
+    grid = grid_4x4_map() if model == "particle" else None
+    o = Oracle(model=model, N=N, S=S, M=1, H=H, grid=grid)
+    sg = np.full(da, 1.5, np.float32)
+    sp = np.array([1.5, 0.8], np.float32)[:da]
+    gl, gp, sc = o.score(theta, mu, np.ones(N), sp, costs, actions, 1.0, sg)
+    c = Context(model=model, N=N, S=S, M=1, H=H, kernel=kernel, imq_ell=0.9, lr=0.5, sigma_a=sg, sigma_p=sp, grid=grid)
+    c.set_theta(theta)
+    c.set_prior(mu)
+    c.set_a_mat(theta)
+    phi, dgl, dgp = c.svmpc_phi(costs, actions)
+    assert relerr(dgp, gp) < TOL
+    ref = o.phi_k1(theta, sc) if kernel == "K1" else o.phi_imq(theta, sc, 0.9)
+    assert relerr(phi, ref) < (k1_tolerance(theta) if kernel == "K1" else TOL)
+    # log p(theta) of the forward pass (the prior pass without the gradient)
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    c.svmpc_optimize(state, 1)
+    th1 = c.get_theta()
+    c.svmpc_forward()
+    ll, lp = c.get_log_weights()
+    fw = o.forward(c.get_costs(), th1, mu, np.ones(N), sp, 1.0)
+    assert relerr(lp, fw["log_p"]) < 1e-5
+    c.close()

@@ -1,0 +1,37 @@
+"""Per-iteration GPU time of ONE rank's share of the weak-scaled bench (1024 particles per GPU, N = 1024 * G in the joint
+problem), measured on a single GPU without collectives: what each rank computes between the all-gathers."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from dust_amd.parallel import DeviceShard
+
+for G in (1, 2, 4, 8):
+    N = 1024 * G
+    cfg = dict(model="pendulum", N=N, S=128, M=1, H=30, kernel="K1", lr=2.0, sigma_a=2.0, sigma_p=2.0, seed=3)
+    rng = np.random.default_rng(0)
+    mu = rng.standard_normal((N, 30, 1)).astype(np.float32)
+    th = (mu + 2 * rng.standard_normal((N, 30, 1))).astype(np.float32)
+    sh = DeviceShard(cfg, 0, G, use_torch_stream=False)
+    sh.set_state(th, mu)
+    state = np.array([3.0, 0.0], np.float32)
+    for rep in range(2):
+        sh.ctx.sync()
+        t0 = time.perf_counter()
+        iters = 200
+        for _ in range(iters):
+            sh.local_score(state)
+            sh.apply_phi()
+        sh.ctx.sync()
+        el = (time.perf_counter() - t0) / iters
+    sh.ctx.profile(True)
+    for _ in range(20):
+        sh.local_score(state)
+        sh.apply_phi()
+    sh.ctx.sync()
+    pk = {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}
+    print("G=%d N=%d: %.1f us per iteration (local score + Stein/update), unfused kernels: %s" % (G, N, el * 1e6, pk), flush=True)
+    sh.ctx.close()
