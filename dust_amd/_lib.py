@@ -109,6 +109,8 @@ SYMBOLS = {
     "dust_get_bandwidths": (C.c_int, [VP, FP]),
     "dust_gather_buffers": (C.c_int, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(C.c_size_t)]),
     "dust_svmpc_local_score": (C.c_int, [VP, FP, VP, FP, C.c_int]),
+    "dust_svmpc_local_rollout": (C.c_int, [VP, FP, VP, FP, C.c_int]),
+    "dust_svmpc_local_prior_score": (C.c_int, [VP]),
     "dust_svmpc_apply_phi": (C.c_int, [VP]),
     "dust_svmpc_forward_local": (C.c_int, [VP, C.POINTER(VP), C.POINTER(C.c_size_t)]),
     "dust_svmpc_forward_finish": (C.c_int, [VP, FP, FP]),

@@ -1509,6 +1509,33 @@ extern "C" int dust_svmpc_local_score(dust_ctx *c, const float *state, const flo
   TRY(stage_noise(c, eps, flags, &nd));
   return local_score_device(c, nd, 0);
 }
+// The two halves of dust_svmpc_local_score as separate calls, for callers that overlap the all-gather of theta with the
+// rollouts: the rollout / likelihood half reads only the LOCAL particles; the prior half reads every particle (keys).
+extern "C" int dust_svmpc_local_rollout(dust_ctx *c, const float *state, const float *eps, const float *params, int flags) {
+  if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, 1));
+  const float *nd = nullptr;
+  TRY(stage_noise(c, eps, flags, &nd));
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = nd ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = nd;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  o.bump_adam = 1;
+  o.merge_prior = 0;
+  TRY(launch_rollout(c, o));
+  c->have_sample = true;
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_local_prior_score(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (!c->have_sample) return fail(DUST_ERR_STATE, "dust_svmpc_local_prior_score needs a preceding dust_svmpc_local_rollout");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(launch_prior(c));
+  return launch_prior_finish(c, true, false);  // score = grad_lik + grad_pri for the local rows
+}
 extern "C" int dust_svmpc_apply_phi(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));

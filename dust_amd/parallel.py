@@ -5,7 +5,8 @@ costs, softmax weights, likelihood score, a_mat rows, optimiser update and roll 
 need every particle, so per SVGD iteration the ranks all-gather, IN PLACE in the context-owned [N][D] buffers,
   (1) score  (after the local score, before the Gram / phi kernel - the exchange BASELINE.json's north_star names),
   (2) theta  (after the optimiser update: from the second tick on the prior means alias theta, so the next prior pass and
-              the next Gram pass both need every shard's new particles),
+              the next Gram pass both need every shard's new particles; tick(overlap=True) starts it asynchronously and
+              runs the next iteration's rollouts - which read only the rank's own particles - underneath it),
 and once per tick the N log-weights (then the rolled theta).  xGMI is a point-to-point mesh and these messages are a few
 hundred KB at most, so the collectives are latency-bound; they are issued on the stream the kernels run on, so no host
 synchronisation is needed between kernels and collectives.
@@ -72,8 +73,7 @@ class DeviceShard:
         self.ctx.set_a_mat(theta if a_mat is None else a_mat)
 
     # -- the four local phases (each only enqueues kernels)
-    def local_score(self, state, eps=None, params=None):
-        lib = L.load()
+    def _args(self, state, eps, params):
         st = np.ascontiguousarray(np.asarray(state, np.float32).reshape(-1))
         e = None
         if eps is not None:
@@ -83,7 +83,20 @@ class DeviceShard:
         if params is not None:
             pk = np.ascontiguousarray(params, dtype=np.float32)
             p = pk.ctypes.data_as(L.FP)
-        L.check(lib.dust_svmpc_local_score(self.ctx._h, st.ctypes.data_as(L.FP), e, p, 0))
+        return st, e, p, (ek if eps is not None else None, pk if params is not None else None)
+
+    def local_score(self, state, eps=None, params=None):
+        st, e, p, _keep = self._args(state, eps, params)
+        L.check(L.load().dust_svmpc_local_score(self.ctx._h, st.ctypes.data_as(L.FP), e, p, 0))
+
+    def local_rollout(self, state, eps=None, params=None):
+        """Rollout / likelihood half of the local score: reads only this shard's particles."""
+        st, e, p, _keep = self._args(state, eps, params)
+        L.check(L.load().dust_svmpc_local_rollout(self.ctx._h, st.ctypes.data_as(L.FP), e, p, 0))
+
+    def local_prior_score(self):
+        """Prior half (reads every particle): score rows of this shard = grad_lik + grad_pri."""
+        L.check(L.load().dust_svmpc_local_prior_score(self.ctx._h))
 
     def apply_phi(self):
         L.check(L.load().dust_svmpc_apply_phi(self.ctx._h))
@@ -127,8 +140,28 @@ class TorchComm:
             self.dist.all_gather(parts, full[lo:lo + shard_elems].clone())
 
 
+    def all_gather_start(self, shards, name, shard_elems):
+        """Non-blocking form: returns a handle whose wait() makes the caller's stream (host, under gloo) wait for it."""
+        (sh,) = shards
+        full = getattr(sh, name)
+        lo = self.rank * shard_elems
+        if full.is_cuda:
+            return self.dist.all_gather_into_tensor(full, full[lo:lo + shard_elems], async_op=True)
+        self.all_gather_inplace(shards, name, shard_elems)
+        return _Done()
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
 class LocalComm:
     """Several shards inside ONE process: the all-gather is a set of slice copies (single-GPU equivalence tests)."""
+
+    def all_gather_start(self, shards, name, shard_elems):
+        self.all_gather_inplace(shards, name, shard_elems)
+        return _Done()
 
     def all_gather_inplace(self, shards, name, shard_elems):
         for src in shards:
@@ -139,19 +172,39 @@ class LocalComm:
                     getattr(dst, name)[lo:lo + shard_elems].copy_(piece)
 
 
-def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False):
+def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False, overlap=False):
     """One control tick = n_iters SVGD iterations + forward, for the shard(s) this process drives.
 
     `shards` is a 1-tuple under torch.distributed (one rank per process) or all shards under LocalComm.
     eps[k] / params[k] are the per-iteration noise [S][N][H][da] / dynamics samples (None: device Philox / no sampling).
+    overlap=True runs the rollouts (which read only the rank's own particles) while the all-gather of theta is still in
+    flight.  Measured at world size 1 on MI355X the extra host calls cost more than the overlap can give while this driver
+    is host-stepped from Python (1 970 vs 2 820 ticks/s), so it is off by default; the split entry points are what a
+    C-side driver with its own RCCL communicator would use.
     """
-    for k in range(n_iters):
-        for sh in shards:
-            sh.local_score(state, None if eps is None else eps[k], None if params is None else params[k])
-        comm.all_gather_inplace(shards, "score_all", shards[0].shard_elems)
-        for sh in shards:
-            sh.apply_phi()
-        comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)
+    if overlap:
+        pending = None
+        for k in range(n_iters):
+            for sh in shards:
+                sh.local_rollout(state, None if eps is None else eps[k], None if params is None else params[k])
+            if pending is not None:
+                pending.wait()  # theta of every shard has arrived
+            for sh in shards:
+                sh.local_prior_score()
+            comm.all_gather_inplace(shards, "score_all", shards[0].shard_elems)
+            for sh in shards:
+                sh.apply_phi()
+            pending = comm.all_gather_start(shards, "theta_all", shards[0].shard_elems)
+        if pending is not None:
+            pending.wait()
+    else:
+        for k in range(n_iters):
+            for sh in shards:
+                sh.local_score(state, None if eps is None else eps[k], None if params is None else params[k])
+            comm.all_gather_inplace(shards, "score_all", shards[0].shard_elems)
+            for sh in shards:
+                sh.apply_phi()
+            comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)
     for sh in shards:
         sh.forward_local()
     comm.all_gather_inplace(shards, "lw_all", shards[0].n_loc)

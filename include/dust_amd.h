@@ -169,6 +169,11 @@ int dust_get_bandwidths(dust_ctx *ctx, float *h); /* K2: [H*da] or [H] */
  * The caller all-gathers them in place with RCCL between dust_svmpc_local_score and dust_svmpc_apply_phi. */
 int dust_gather_buffers(dust_ctx *ctx, void **theta_all, void **score_all, size_t *shard_bytes);
 int dust_svmpc_local_score(dust_ctx *ctx, const float *state, const float *eps, const float *params, int flags);
+/* dust_svmpc_local_score in two calls, so that the all-gather of theta (issued after dust_svmpc_apply_phi) can run while
+ * the rollouts - which read only this rank's particles - execute: local_rollout (costs, weights, grad_lik, a_mat), then,
+ * once every rank's theta has arrived, local_prior_score (prior pass over all particles; score = grad_lik + grad_pri). */
+int dust_svmpc_local_rollout(dust_ctx *ctx, const float *state, const float *eps, const float *params, int flags);
+int dust_svmpc_local_prior_score(dust_ctx *ctx);
 int dust_svmpc_apply_phi(dust_ctx *ctx);
 int dust_svmpc_forward_local(dust_ctx *ctx, void **log_w_all, size_t *shard_bytes);
 int dust_svmpc_forward_finish(dust_ctx *ctx, float *a_seq, float *p_weights);

@@ -45,6 +45,20 @@ class MockShard:
         _, _, sc = self.o.score(th, mu, self.mix, self.sp, self.costs, actions, self.cfg["alpha"], self.sig)
         self._rows(self.score_all)[:] = torch.from_numpy(sc.reshape(-1))[self.off * self.D:(self.off + self.n_loc) * self.D]
 
+    def local_rollout(self, state, eps=None, params=None):
+        th = self._theta()  # the other shards' rows may still be in flight here: only the local rows are used below
+        self._actions = self.o.sample_actions(th, eps, self.sig)
+        self.costs = self.o.rollout_cost(state, self._actions)
+        self._local_rows = th[self.off:self.off + self.n_loc].copy()
+
+    def local_prior_score(self):
+        th = self._theta()
+        lo, hi = self.off, self.off + self.n_loc
+        assert np.array_equal(th[lo:hi], self._local_rows)  # the all-gather never touches a rank's own rows
+        mu = th if self.aliased else self.mu
+        _, _, sc = self.o.score(th, mu, self.mix, self.sp, self.costs, self._actions, self.cfg["alpha"], self.sig)
+        self._rows(self.score_all)[:] = torch.from_numpy(sc.reshape(-1))[lo * self.D:hi * self.D]
+
     def apply_phi(self):
         th = self._theta()
         phi = self.o.phi_k1(th, self.score_all.numpy().reshape(self.N, self.H, 1))

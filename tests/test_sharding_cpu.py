@@ -43,7 +43,8 @@ def _run_unsharded():
     return sh.theta_all.numpy().copy(), outs
 
 
-def test_local_comm_two_shards_equal_unsharded():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_local_comm_two_shards_equal_unsharded(overlap):
     from mock_shard import MockShard
 
     mu, theta, eps, state = _inputs()
@@ -52,7 +53,7 @@ def test_local_comm_two_shards_equal_unsharded():
     for s in shards:
         s.set_state(theta, mu)
     for t in range(2):
-        a_seq, pw = tick(shards, LocalComm(), state, 2, eps[t], None, want_outputs=True)
+        a_seq, pw = tick(shards, LocalComm(), state, 2, eps[t], None, want_outputs=True, overlap=overlap)
         assert np.allclose(a_seq, ref_outs[t][0], atol=1e-6) and np.allclose(pw, ref_outs[t][1], atol=1e-6)
     for s in shards:
         assert np.allclose(s.theta_all.numpy(), ref_theta, atol=1e-6)
