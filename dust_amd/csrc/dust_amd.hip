@@ -682,6 +682,8 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_ROLLOUT : nullptr;
   int nt = ((std::max(c->S, c->D) + 63) / 64) * 64;
   nt = std::min(std::max(nt, 64), 256);
+  a.lgW = 0;
+  while ((1 << a.lgW) < c->D) ++a.lgW;  // nt = roundup64(max(S, D)) >= 2^lgW for D <= 128
   a.G = 1;
   {  // several dynamics samples and few action samples: split the M loop over lane groups (rollout.hpp)
     const int sub = ((c->S + 63) / 64) * 64;
@@ -717,13 +719,19 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
     KERNEL<<<c->nloc, nt, lds, c->stream>>>(a);                                                                                 \
   } while (0)
   const bool stream_form = a.noise_mode == NOISE_EPS;
-  if (c->cfg.model == DUST_MODEL_PENDULUM) {
-    if (stream_form) DUST_LAUNCH_ROLLOUT(rollout_stream_kernel<DUST_MODEL_PENDULUM>);
-    else DUST_LAUNCH_ROLLOUT(rollout_kernel<DUST_MODEL_PENDULUM>);
-  } else {
-    if (stream_form) DUST_LAUNCH_ROLLOUT(rollout_stream_kernel<DUST_MODEL_PARTICLE>);
-    else DUST_LAUNCH_ROLLOUT(rollout_kernel<DUST_MODEL_PARTICLE>);
-  }
+#define DUST_PICK_ROLLOUT(MODEL)                                                          \
+  do {                                                                                   \
+    if (a.G > 1) {                                                                       \
+      if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, true>));        \
+      else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, true>));                           \
+    } else {                                                                             \
+      if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, false>));       \
+      else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, false>));                          \
+    }                                                                                    \
+  } while (0)
+  if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_ROLLOUT(DUST_MODEL_PENDULUM);
+  else DUST_PICK_ROLLOUT(DUST_MODEL_PARTICLE);
+#undef DUST_PICK_ROLLOUT
 #undef DUST_LAUNCH_ROLLOUT
   HIP_TRY(hipGetLastError());
   c->actions_valid = o.want_actions;
@@ -982,6 +990,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   f.per_block = PAIR_NT / nt;
   if (c->nloc % f.per_block || PAIR_TI % f.per_block) return DUST_OK;
   const int cpt = cpt_for(c->D);
+  if (cpt > 8) return DUST_OK;  // D > 64: separate launches
   const size_t lds_p = pairwise_lds_bytes(PAIR_PRIOR, cpt);
   f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
   const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
@@ -1000,23 +1009,25 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   f.cnt = c->fused_cnt;
   f.timeout_flag = c->fused_cnt + (size_t)f.tiles * CNT_STRIDE;
   const int grid = f.n_pair_blocks + c->nloc / f.per_block;
-#define DUST_LAUNCH_FUSED(MODEL, CPT)                                                                                                  \
+#define DUST_LAUNCH_FUSED2(MODEL, CPT, GR)                                                                                                \
   do {                                                                                                                                  \
     if (lds > 64 * 1024 && !c->capturing)                                                                                               \
-      HIP_TRY(hipFuncSetAttribute((const void *)fused_prior_rollout_kernel<MODEL, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    fused_prior_rollout_kernel<MODEL, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f);                                                      \
+      HIP_TRY(hipFuncSetAttribute((const void *)fused_prior_rollout_kernel<MODEL, CPT, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    fused_prior_rollout_kernel<MODEL, CPT, GR><<<grid, PAIR_NT, lds, c->stream>>>(f);                                                  \
+  } while (0)
+#define DUST_LAUNCH_FUSED(MODEL, CPT)                   \
+  do {                                                   \
+    if (f.ra.G > 1) DUST_LAUNCH_FUSED2(MODEL, CPT, true); \
+    else DUST_LAUNCH_FUSED2(MODEL, CPT, false);           \
   } while (0)
   if (c->cfg.model == DUST_MODEL_PENDULUM) {
     if (cpt == 4) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 4);
-    else if (cpt == 8) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 8);
-    else if (cpt == 12) DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 12);
-    else DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 16);
+    else DUST_LAUNCH_FUSED(DUST_MODEL_PENDULUM, 8);
   } else {
     if (cpt == 4) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 4);
-    else if (cpt == 8) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 8);
-    else if (cpt == 12) DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 12);
-    else DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 16);
+    else DUST_LAUNCH_FUSED(DUST_MODEL_PARTICLE, 8);
   }
+#undef DUST_LAUNCH_FUSED2
 #undef DUST_LAUNCH_FUSED
   HIP_TRY(hipGetLastError());
   c->fused_dirty = true;

@@ -31,6 +31,7 @@ struct RolloutArgs {
   DevModel dm;
   int N_total, n0, S, M, H, D;
   int noise_mode;
+  int lgW;           // log2 of the lanes per action row in the noise staging (2^lgW >= D)
   int G;             // dynamics-sample groups: lane = (sample, group), group g rolls out m = g, g+G, ... (G > 1 only when S <= nt/G)
   int lik;           // dust_likelihood
   int eps_base_mode; // 0: eps = a - a_seq (ext actions, disco.py:161-164); 1: eps = a - a_mat[n] (internal noise, 155-160)
@@ -100,7 +101,8 @@ struct FusedWait {
 
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
 // wide (every sub-block of a workgroup runs the same control flow), reductions are sub-block local.
-template <int MODEL, int NB /* staged noise loads in flight per lane: 32 standalone, 16 inside the fused launch (VGPR budget) */>
+template <int MODEL, int NB /* staged noise loads in flight per lane: 32 standalone, 12 inside the fused launch (VGPR budget) */,
+          bool GROUPS /* lane = (sample, dynamics group): a.G > 1 */>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, const int tid, const int nt, const int nl,
                                              const FusedWait *fw) {
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
@@ -140,46 +142,49 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       coefs[2 * m + 1] = c.c1;
     }
   }
-  // caller-supplied noise: the first 32 loads of every lane are issued BEFORE the wait on the theta row, so the two
-  // round trips overlap (at S*D <= 32 nt - cfg2 - that is the whole tile: one memory round trip for stage 1)
-  const int total = S * D;
+  // caller-supplied noise, row-lane mapping: W = 2^lgW >= D lanes per action row, R = nt / W rows per batch, so a lane keeps
+  // ONE column j (theta_j and the Cholesky factor are per-lane constants, no index division) and walks the rows with a
+  // fixed stride in HBM and in LDS.  The first NB loads of every lane are issued BEFORE the wait on the theta row, so the
+  // two round trips overlap (at S <= NB R - cfg2: 128 rows = 32 batches of 4 - that is the whole tile: one memory round
+  // trip for stage 1).  Offsets are clamped, never predicated (a conditional load makes hipcc branch and wait per element).
   float v[NB];
+  const int lgW = a.lgW, R = nt >> lgW;
+  const int sr = tid >> lgW, sj = tid & ((1 << lgW) - 1);
+  const bool jv = sj < D;
   const char *nbase = reinterpret_cast<const char *>(a.noise + (size_t)n * D);
-  const uint32_t rowstride = (uint32_t)N * (uint32_t)D;  // S*N*D < 2^30 is checked at configuration time
+  const uint32_t rowbytes = ((uint32_t)N * (uint32_t)D) << 2;  // S*N*D < 2^30 is checked at configuration time
+  const uint32_t jbytes = (uint32_t)min(sj, D - 1) << 2;
+  const uint32_t off_last = (uint32_t)(S - 1) * rowbytes + jbytes, off_step = (uint32_t)R * rowbytes;
+  uint32_t off0 = (uint32_t)sr * rowbytes + jbytes;
   if (a.noise_mode != NOISE_PHILOX) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      // clamp instead of predicate: a conditional load makes hipcc branch and wait vmcnt(0) per element
-      const int idx = min(u * nt + tid, total - 1);
-      const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-      v[u] = *reinterpret_cast<const float *>(nbase + (((uint32_t)s * rowstride + (uint32_t)j) << 2));  // uniform base + 32-bit byte offset: one VGPR per address
-    }
+    for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
   }
   if (tid < D) th[tid] = thv;
   __syncthreads();
-  if (tid < D && thv != thv) red[40] = 1.f;
+  bool nanf = tid < D && thv != thv;
   if (a.noise_mode != NOISE_PHILOX) {
-    for (int base = 0; base < total; base += NB * nt) {
-      if (base) {
+    const float thj = a.noise_mode == NOISE_EPS ? th[min(sj, D - 1)] : 0.f;
+    const float lj = a.noise_mode == NOISE_EPS ? a.chol_a[sj % DA] : 1.f;
+    for (int s0 = 0; s0 < S; s0 += NB * R) {
+      if (s0) {
+        off0 += (uint32_t)NB * off_step;
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int idx = min(base + u * nt + tid, total - 1);
-          const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-          v[u] = *reinterpret_cast<const float *>(nbase + (((uint32_t)s * rowstride + (uint32_t)j) << 2));
-        }
+        for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
       }
+      float *trow = tile + (s0 + sr) * Dp + sj;
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const int idx = base + u * nt + tid;
-        const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-        if (idx < total) {
-          const float av = a.noise_mode == NOISE_EPS ? th[j] + a.chol_a[j % DA] * v[u] : v[u];
-          tile[s * Dp + j] = av;
-          if (av != av) red[40] = 1.f;
+        const int srow = s0 + u * R + sr;
+        if (srow < S && jv) {
+          const float av = thj + lj * v[u];  // NOISE_ACTIONS: 0 + 1 * v (exact)
+          trow[u * R * Dp] = av;
+          nanf |= av != av;
         }
       }
     }
   }
+  if (nanf) red[40] = 1.f;
   __syncthreads();
 
   DUST_STAMP(a.stamps, 1);
@@ -191,10 +196,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
   // M loop is split over G lane groups that share the action tile - 4x the waves per LDS byte at cfg3 (S = 64, M = 64)
-  // (the G == 1 instance is compiled with mg = 0 and G = 1 as constants: block indices, the dynamics-sample index and
-  // with them most of the Philox rounds stay wave-uniform and run on the scalar unit)
-  auto rollouts = [&](auto one_group) {
-  constexpr bool ONE = decltype(one_group)::value;
+  // (GROUPS is a template parameter - separate kernels - so that the common G == 1 form keeps mg = 0 / G = 1 as constants:
+  // block indices, the dynamics-sample index and most of the Philox rounds stay wave-uniform, and the argument block is not
+  // kept live across two copies of the loop: with both in one kernel the SGPR spill traffic cost 3.6 us per launch)
+  constexpr bool ONE = !GROUPS;
   const int G = ONE ? 1 : a.G, sub = ONE ? nt : nt / a.G;
   const int mg = ONE ? 0 : __builtin_amdgcn_readfirstlane(tid / sub);  // sub is a multiple of 64: a wave belongs to one group
   const int ts = ONE ? tid : tid - mg * sub;
@@ -305,9 +310,6 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       finish_cost(ts, acc_m);
     }
   }
-  };
-  if (a.G == 1) rollouts(std::true_type{});
-  else rollouts(std::false_type{});
   __syncthreads();
   if (a.actions_out) {
     for (int idx = tid; idx < S * D; idx += nt) {
@@ -506,18 +508,18 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
   return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
 }
 
-template <int MODEL>
+template <int MODEL, bool GROUPS>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 // Same body under its own symbol for the HBM-streaming form (caller-supplied eps resident in HBM): profiles and PMC
 // passes then attribute it separately from the Philox form.
-template <int MODEL>
+template <int MODEL, bool GROUPS>
 __global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
