@@ -82,6 +82,7 @@ SYMBOLS = {
     "dust_sync": (C.c_int, [VP]),
     "dust_get_config": (C.c_int, [VP, C.POINTER(Config)]),
     "dust_set_model_param": (C.c_int, [VP, C.c_char_p, C.c_double, C.c_int]),
+    "dust_set_param_weights": (C.c_int, [VP, FP]),
     "dust_set_grid": (C.c_int, [VP, FP, C.c_int, C.c_int, C.c_float, C.c_float]),
     "dust_set_theta": (C.c_int, [VP, FP]),
     "dust_get_theta": (C.c_int, [VP, FP]),

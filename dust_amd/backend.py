@@ -138,6 +138,10 @@ class Context:
         ox, oy = (int(nx / 2), int(ny / 2)) if off is None else off
         L.check(L.load().dust_set_grid(self._h, _p(g), nx, ny, float(ox), float(oy)))
 
+    def set_param_weights(self, w):
+        """Unscented-transform weights of the n_params dynamics samples (None: plain mean)."""
+        L.check(L.load().dust_set_param_weights(self._h, _p(None if w is None else _f(w, (self.M,)))))
+
     def set_model_param(self, name, value, kind=-1):
         L.check(L.load().dust_set_model_param(self._h, name.encode(), float(value), kind))
 

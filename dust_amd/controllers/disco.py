@@ -12,6 +12,7 @@ import torch
 from .. import _lib as L
 from ..backend import Context
 from ..costs import recognise
+from ..utils.utf import MerweScaledUTF
 
 Empty = torch.Size([])
 
@@ -45,13 +46,17 @@ class MultiDISCO:
             self._a_mat = init_actions.clone()
         self._a_mix = torch.ones(n_policies)
         self._params_log_space = params_log_space
+        self._tf = None
         if params_sampling is False or params_sampling is None or params_sampling == "none":
             self.n_params, self._sampling = 1, False
         elif params_sampling is True:
             self.n_params, self._sampling = params_samples, True
+        elif isinstance(params_sampling, MerweScaledUTF):  # disco.py:124-131: sigma-point rollouts ("DISCO" case)
+            assert self._params_log_space is False, "Distribution must not be on log space if using UTF."
+            self.n_params, self._sampling = 1, True
+            self._tf = params_sampling
         else:
-            raise NotImplementedError("params_sampling=%r (unscented transform) has no HIP kernel; out of scope (SURVEY 2, row 1)"
-                                      % (params_sampling,))
+            raise ValueError("Invalid value for 'params_sampling': {}".format(params_sampling))
         self.n_rollouts = self.n_params * self.n_actions * self.n_pol
         self._ctx = None
         self._ctx_key = None
@@ -63,13 +68,15 @@ class MultiDISCO:
     def _config(self, model, params_dist):
         chol = torch.linalg.cholesky(self.a_dist.covariance_matrix).diag()
         sigma = self.a_dist.covariance_matrix.diag().sqrt()  # svmpc.py:107-111
-        cfg = dict(model=model.family, N=self.n_pol, S=self.n_actions, M=self.n_params, H=self.hz_len,
+        cfg = dict(model=model.family, N=self.n_pol, S=self.n_actions, M=self._tf.pts if self._tf is not None else self.n_params, H=self.hz_len,
                    temperature=float(self.temp), ctrl_penalty=float(self._ctrl_penalty), alpha=1.0 / float(self.temp),
                    chol_a=chol.numpy(), sigma_a=sigma.numpy(), a_pre=self.a_pre.diag().numpy(),
                    min_a=self.min_a.numpy(), max_a=self.max_a.numpy(), device=self._device, seed=self._seed, dt=model.dt,
                    params_log_space=bool(self._params_log_space), sampling=self._sampling)
         if self._sampling:
-            if params_dist is not None:
+            if self._tf is not None:
+                self._scalar_event = False
+            elif params_dist is not None:
                 self._scalar_event = params_dist.event_shape == Empty
             elif getattr(self, "_scalar_event", None) is None:
                 raise ValueError("params_sampling is on but no params_dist was given")
@@ -102,6 +109,8 @@ class MultiDISCO:
         grid = model.obst_map.map.astype(np.float32) if getattr(model, "obst_map", None) is not None else None
         self._ctx = Context(grid=grid, **cfg)
         self._ctx_key = key
+        if self._tf is not None:
+            self._ctx.set_param_weights(self._tf.loc_weights.numpy())
         if state is None:
             self._ctx.set_a_mat(self._a_mat.numpy())
             self._ctx.set_a_seq(self._a_seq.numpy())
@@ -150,9 +159,22 @@ class MultiDISCO:
             self._ctx.set_a_seq(self._a_seq.numpy())
 
     # ------------------------------------------------------------------ disco.py:348-394
+    def _sigma_params(self, params_dist):
+        """Sigma points of the parameter distribution (disco.py:238-251) and their weighted log-probability (288-291)."""
+        try:
+            cov, mean = params_dist.covariance_matrix, params_dist.mean
+        except AttributeError:
+            cov, mean = params_dist.variance.diag(), params_dist.mean
+        sp = self._tf.compute_sigma_points(mean, cov).T.contiguous()  # [pts][P]
+        lp = params_dist.log_prob(sp) @ self._tf.loc_weights
+        return sp.reshape(1, self._tf.pts, -1).numpy(), lp.expand(self.n_actions, self.n_pol)
+
     def _sample_params(self, params_dist, n_sets=1):
         if not self._sampling:
             return None, None
+        if self._tf is not None:
+            sp, lp = self._sigma_params(params_dist)
+            return np.repeat(sp, n_sets, axis=0), lp
         ps, lps = [], []
         for _ in range(n_sets):
             p = params_dist.sample([self.n_params])

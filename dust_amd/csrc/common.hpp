@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dust_amd.h"
 
 #define DUST_WAVE 64
@@ -266,21 +268,34 @@ __device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave / block reductions (64-lane wavefronts; DPP via __shfl_xor).
+// Wave / block reductions (64-lane wavefronts).  __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip,
+// ~100+ cycles per step); these use DPP modifiers instead: two quad permutes, row_half_mirror and row_mirror leave every
+// lane with its 16-lane row's result, row_bcast:15 / row_bcast:31 (gfx9) carry it across the four rows into lane 63, and
+// a v_readlane broadcasts it.  `identity` fills lanes a DPP step does not write (bound_ctrl off keeps `old`).
+template <typename F>
+__device__ __forceinline__ float wave_reduce_dpp(float v, const float identity, F op) {
+  auto dpp = [&](float x, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, x),
+                                                                   decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+  };
+  using I = std::integral_constant<int, 0>;
+  (void)sizeof(I);
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}));   // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}));   // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));  // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}));  // row_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));  // row_bcast:15 -> rows 1, 3
+  v = op(v, dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));  // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce_dpp(v, 0.f, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_dpp(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce_dpp(v, INFINITY, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

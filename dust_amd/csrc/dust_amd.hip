@@ -77,6 +77,7 @@ struct dust_ctx {
   float *adam_m, *adam_v;
   float *pA, *pB, *pM, *pL;  // slice partials of the tiled pairwise passes
   size_t pA_cap, pB_cap, pM_cap, pL_cap;
+  float *mw_dev;             // [M] unscented-transform weights of the dynamics samples (nullptr: mean)
   float *xpad;               // [N][DPB] zero-padded query rows of the large-N pairwise kernel
   size_t xpad_cap;
   // staging
@@ -250,7 +251,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
                   &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->xpad};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->xpad, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -448,6 +449,10 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
     c->off_x = src->off_x;
     c->off_y = src->off_y;
   }
+  if (src->mw_dev) {
+    TRY(dalloc(&c->mw_dev, (size_t)c->M));
+    TRY(d2d(c, c->mw_dev, src->mw_dev, (size_t)c->M * sizeof(float)));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DUST_OK;
 }
@@ -463,6 +468,23 @@ extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value,
   p->value = value;
   if (kind >= 0 && p->kind != DUST_PARAM_SAMPLED) p->kind = kind;
   return DUST_OK;
+}
+
+extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->graph_exec) graph_drop(c);
+  if (!w) {
+    if (c->mw_dev) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipFree(c->mw_dev));
+      c->mw_dev = nullptr;
+    }
+    return DUST_OK;
+  }
+  if (c->cfg.dim_p <= 0) return fail(DUST_ERR_STATE, "parameter weights need sampled parameters (dim_p > 0)");
+  if (!c->mw_dev) TRY(dalloc(&c->mw_dev, (size_t)c->M));
+  return h2d(c, c->mw_dev, w, (size_t)c->M * sizeof(float));
 }
 
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
@@ -654,6 +676,7 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.theta = o.base;
   a.noise = o.noise_dev;
   a.params = (c->cfg.dim_p > 0 && c->params_dev) ? c->params_dev : nullptr;
+  a.mw = c->mw_dev;
   a.a_seq = c->a_seq;
   a.a_mat = c->a_mat;
   a.costsT = c->costsT;
@@ -689,7 +712,7 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
     const int sub = ((c->S + 63) / 64) * 64;
     int G = 1;
     while (2 * G <= c->M && sub * 2 * G <= 256) G *= 2;
-    if (G > 1 && !o.costs_in) {
+    if (G > 1 && !o.costs_in && !c->mw_dev) {
       a.G = G;
       nt = sub * G;  // >= 128 >= D
     }

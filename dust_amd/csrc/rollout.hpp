@@ -51,6 +51,7 @@ struct RolloutArgs {
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
   const float *noise;   // eps or actions [S][N_total][D] (device), or nullptr for Philox
   const float *params;  // [M][P] raw samples or nullptr
+  const float *mw;      // [M] unscented-transform weights (sigma-point rollouts) or nullptr: plain mean over m
   const float *a_seq;   // [D]
   float *a_mat;         // [N_total][D]
   float *costsT;        // [N_total][S]
@@ -192,7 +193,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const long SN = (long)S * N;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
-  const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out && !a.tile_scratch && red[40] == 0.f &&
+  const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out && !a.tile_scratch && red[40] == 0.f && !a.mw &&
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
   // M loop is split over G lane groups that share the action tile - 4x the waves per LDS byte at cfg3 (S = 64, M = 64)
@@ -221,8 +222,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // [G][sub] per-group partial sums over m (G > 1); `part` is only 4-byte aligned for odd S: round up (one spare pair of
   // floats is reserved in rollout_lds_bytes)
   double *accp = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(part) + 7) & ~(uintptr_t)7);
-  auto finish_cost = [&](const int s, const double acc) {
-    float cost = a.M == 1 ? (float)acc : (float)(acc / a.M);
+  auto finish_cost = [&](const int s, const double acc, const bool is_sum = false) {
+    float cost = (a.M == 1 || is_sum) ? (float)acc : (float)(acc / a.M);
     if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
       const float *act = tile + s * Dp;
       double cc = 0.0;
@@ -241,7 +242,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       if (mg == 0) cst[s] = a.costs_in[(size_t)s * N + n];
       continue;
     }
-    double acc_m = 0.0;
+    double acc_m = 0.0, ut_term = 0.0;
     for (int m = mg; m < a.M; m += G) {
       const long r = (long)m * SN + (long)s * N + n;
       const int pidx = a.dm.interleave ? (int)(r % a.M) : m;
@@ -286,11 +287,19 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           float at[DA];
 #pragma unroll
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
-          tot += (double)step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+          const float ci = step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+          // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
+          tot += a.mw ? (double)a.mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
           if (so) {
 #pragma unroll
             for (int k = 0; k < DS; ++k) so[(size_t)(t + 1) * DS + k] = x[k];
           }
+        }
+        if (a.mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
+          ut_term += (double)a.mw[m] * (double)term_cost<MODEL>(a.dm, x);
+          traj = (float)tot;  // unused
+          acc_m += tot;
+          continue;
         }
         traj = (float)tot + term_cost<MODEL>(a.dm, x);
       }
@@ -300,7 +309,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       accp[mg * sub + ts] = acc_m;
       continue;
     }
-    finish_cost(s, acc_m);
+    if (a.mw) finish_cost(s, (double)((float)acc_m + (float)ut_term), true);  // weighted sum over sigma points, not a mean
+    else finish_cost(s, acc_m);
   }
   if (G > 1) {  // fixed-order sum of the group partials (the barrier sits outside the sample loop: lanes without a sample reach it too)
     __syncthreads();

@@ -112,6 +112,11 @@ int dust_sync(dust_ctx *ctx);
 int dust_get_config(const dust_ctx *ctx, dust_config *out);
 /* model.params_dict[...] = v after construction (particle_example.py:178-179) */
 int dust_set_model_param(dust_ctx *ctx, const char *name, double value, int kind);
+/* Unscented-transform rollouts (MultiDISCO(params_sampling=MerweScaledUTF), disco.py:211-292, 312-323): the n_params
+ * dynamics samples passed to forward / optimize are the 2 n + 1 sigma points and the cost of a rollout is their weighted
+ * combination with `w[n_params]` (utf.py loc_weights; the reference's (sigma, step) weight pattern is reproduced) instead
+ * of the mean.  NULL switches back to the mean over sampled parameters. */
+int dust_set_param_weights(dust_ctx *ctx, const float *w);
 /* ObstacleMap occupancy grid [nx][ny] (obstacle_map.py:13-43); offsets are the map centre in cells */
 int dust_set_grid(dust_ctx *ctx, const float *grid, int nx, int ny, float off_x, float off_y);
 

@@ -167,6 +167,18 @@ class Oracle:
                                _p(a_pre), _p(states), _p(costs))
         return (costs, states) if want_states else costs
 
+    def rollout_cost_ut(self, state, actions, sigma_points, loc_weights, a_reg=0.0, a_mat=None, a_seq=None, a_pre_diag=None):
+        """Unscented-transform rollouts (disco.py:211-292, 312-323): sigma_points [M][P], loc_weights [M] (self.c.M = M)."""
+        c = self.c
+        st, act = _f(state), _f(actions)
+        sp, w = _f(sigma_points), _f(loc_weights)
+        assert sp.shape == (c.M, c.P) and w.shape == (c.M,)
+        costs = np.empty((c.S, c.N), np.float32)
+        lib().orc_rollout_cost_ut(C.byref(c), _p(st), _p(act), _p(sp), _p(w), C.c_float(a_reg),
+                                  _p(None if a_mat is None else _f(a_mat)), _p(None if a_seq is None else _f(a_seq)),
+                                  _p(None if a_pre_diag is None else _f(a_pre_diag)), _p(costs))
+        return costs
+
     # -- a6
     def disco_weights(self, costs, actions, eps_base, temp, a_mat):
         c = self.c

@@ -212,6 +212,45 @@ void orc_rollout_cost(const orc_cfg *c, const float *state, const float *actions
   }
 }
 
+/* Unscented-transform rollouts: disco.py:211-292 (_sigma_rollout) + the `_tf` branch of _compute_cost (disco.py:312-323).
+ * params_sp[M][P] are the M = 2 n + 1 sigma points (utf.py:93-123), w[M] the mean weights (utf.py:85-91).
+ * Reference layout kept: the instantaneous costs of one (s, n) form a flat [sigma point][step] block of M*H values and
+ * `inst_costs.view(-1, pts) @ loc_weights` pairs entry i of that block with w[i mod M] - so the weight of (sigma m, step t)
+ * is w[(m H + t) mod M] (it is w[m] only for the terminal costs, whose block is [sigma point] alone). */
+void orc_rollout_cost_ut(const orc_cfg *c, const float *state, const float *actions, const float *params_sp, const float *w,
+                         float a_reg, const float *a_mat, const float *a_seq, const float *a_pre_diag, float *costs) {
+  const int N = c->N, S = c->S, M = c->M, H = c->H, da = c->da, ds = c->ds;
+  const long SN = (long)S * N;
+#pragma omp parallel for schedule(static)
+  for (long sn = 0; sn < SN; ++sn) {
+    const int n = (int)(sn % N);
+    const float *act = actions + (size_t)sn * H * da;
+    double inst_acc = 0.0, term_acc = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const float *prow = params_sp + (size_t)m * c->P;
+      float x[8], xn[8];
+      for (int k = 0; k < ds; ++k) x[k] = state[k];
+      for (int t = 0; t < H; ++t) {
+        inst_acc += (double)w[((long)m * H + t) % M] * (double)inst_cost(c, x, act + (size_t)t * da);
+        model_step(c, x, act + (size_t)t * da, prow, xn);
+        for (int k = 0; k < ds; ++k) x[k] = xn[k];
+      }
+      term_acc += (double)w[m] * (double)term_cost(c, x);
+    }
+    float cost = (float)inst_acc + (float)term_acc;
+    if (a_reg != 0.0f) {
+      double cc = 0.0;
+      for (int t = 0; t < H; ++t)
+        for (int d = 0; d < da; ++d) {
+          float e = act[t * da + d] - a_seq[t * da + d];
+          cc += (double)(-e) * (double)(a_mat[((size_t)n * H + t) * da + d] * a_pre_diag[d]);
+        }
+      cost = cost + a_reg * (float)cc;
+    }
+    costs[sn] = cost;
+  }
+}
+
 static double lse(const double *v, int n) {
   double m = -INFINITY;
   for (int i = 0; i < n; ++i)

@@ -69,6 +69,8 @@ void orc_rollout_cost(const orc_cfg *c, const float *state, const float *actions
 /* a6  MultiDISCO.forward disco.py:380-393: omega, a_mat += sum_s omega eps, a_mix.
  * eps = actions - eps_base: eps_base = a_seq [H*da] for external actions (disco.py:161-164, base_per_policy 0),
  * or the pre-update a_mat [N][H*da] for internally sampled noise (disco.py:155-160, base_per_policy 1). */
+void orc_rollout_cost_ut(const orc_cfg *c, const float *state, const float *actions, const float *params_sp, const float *w,
+                         float a_reg, const float *a_mat, const float *a_seq, const float *a_pre_diag, float *costs);
 void orc_disco_weights(const orc_cfg *c, const float *costs, const float *actions, const float *eps_base,
                        int base_per_policy, float temp, float *omega, float *a_mat, float *a_mix);
 

@@ -189,3 +189,43 @@ def test_closed_loop_drivers():
     assert want <= set(df.columns) and len(df) == 6
     assert np.isfinite(df["Cost"].to_numpy()).all() and np.isfinite(df["Position"].to_numpy()).all()
     assert abs(sum(df["Weights"].iloc[3]) - 1.0) < 1e-3
+
+
+def test_unscented_transform_disco_vs_reference(golden):
+    """SURVEY 8(f).3, the reference's "DISCO" case: MultiDISCO(params_sampling=MerweScaledUTF) - sigma-point rollouts of the
+    dynamics distribution, UT-weighted costs, MPPI update and step("average") - against the reference's own outputs."""
+    import torch.distributions as dist
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.models import PendulumModel
+    from dust_amd.utils.utf import MerweScaledUTF
+
+    g = golden("disco_ut")
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    tf = MerweScaledUTF(n=2, alpha=0.5)
+    dyn = dist.Independent(dist.Uniform(torch.tensor([0.6, 0.7]), torch.tensor([1.3, 1.2])), 1)
+    model = PendulumModel(length=dyn.mean[0], mass=dyn.mean[1], uncertain_params=("length", "mass"))
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=0.8, a_cov=1.2 ** 2 * torch.eye(1),
+                      inst_cost_fn=inst_cost, term_cost_fn=term_cost, params_sampling=tf, params_log_space=False)
+    assert ctrl.n_params == 1  # disco.py:128: the sigma points are internal to the rollouts
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    state = torch.tensor(g["state"])
+    # the reference's recorded draws as external actions: a_mat + L z (disco.py:229-233)
+    costs, states, actions, omega, plp = ctrl.forward(state, model, dyn, ext_actions=torch.tensor(g["actions"]))
+    assert relerr(costs.numpy(), g["costs"]) < 1e-5
+    # costs ~ 1.4e3: one fp32 ulp of a cost (1.2e-4) is 1.5e-4 on exp(-cost / 0.8) - the weights carry that amplification
+    wtol = 8 * float(np.spacing(np.float32(np.abs(g["costs"]).max()))) / 0.8
+    assert relerr(omega.numpy(), g["omega"]) < wtol
+    assert relerr(plp.numpy(), g["params_log_p"]) < 1e-5
+    assert relerr(ctrl.a_mix.numpy(), g["a_mix"]) < wtol
+    # second call, external actions around the updated plan
+    ctrl.a_mat = torch.tensor(g["a_mat1"])
+    costs2, _, _, omega2, _ = ctrl.forward(state, model, dyn, ext_actions=torch.tensor(g["ext_actions"]))
+    assert relerr(costs2.numpy(), g["costs_ext"]) < 1e-5 and relerr(omega2.numpy(), g["omega_ext"]) < wtol
+    # own noise + step("average"): shapes / bounds (the draws differ from torch's)
+    ctrl.forward(state, model, dyn)
+    a = ctrl.step(strategy="average")
+    assert a.shape == (1, 1) and float(a.abs().max()) <= 2.0
+    c2 = copy.deepcopy(ctrl)  # the weights travel with the clone
+    c3, *_ = c2.forward(state, model, dyn, ext_actions=torch.tensor(g["ext_actions"]))
+    assert np.isfinite(c3.numpy()).all()

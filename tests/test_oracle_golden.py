@@ -181,3 +181,21 @@ def test_mpf(golden, name):
     # torch's vectorised exp in mass = exp(x) shows up at ~1e-4 in the first steps' gradient norms; x itself agrees to 1e-5.
     assert relerr(gn2, g["grad_norms2"]) < 2e-4
     assert relerr(Oracle.gmm_log_prob(g["probe"], pm2, bw), g["probe_log_prob"]) < TOL
+
+
+def test_unscented_transform_costs_vs_reference(golden):
+    """sigma-point rollouts.  The oracle's restatement (incl. the reference's (sigma, step) weight pattern,
+    disco.py:314-316) against MultiDISCO(params_sampling=MerweScaledUTF(n=2, alpha=0.5)).forward of the reference."""
+    from dust_amd.utils.utf import MerweScaledUTF
+    from oracle import Oracle
+
+    g = golden("disco_ut")
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    tf = MerweScaledUTF(n=2, alpha=0.5)
+    assert np.allclose(tf.loc_weights.numpy(), g["loc_weights"], rtol=1e-6)
+    sp = tf.compute_sigma_points(g["dyn_mean"], np.diag(g["dyn_var"]))
+    assert np.allclose(sp.numpy(), g["sigma_points"], rtol=1e-6)
+    o = Oracle(model="pendulum", N=N, S=S, M=tf.pts, H=H, uncertain_params=("length", "mass"))
+    spT = np.ascontiguousarray(g["sigma_points"].T)
+    assert relerr(o.rollout_cost_ut(g["state"], g["actions"], spT, g["loc_weights"]), g["costs"]) < 1e-5
+    assert relerr(o.rollout_cost_ut(g["state"], g["ext_actions"], spT, g["loc_weights"]), g["costs_ext"]) < 1e-5
