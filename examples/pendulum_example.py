@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--config", default=None)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--particles", type=int, default=None)
-    ap.add_argument("--case", choices=["dual", "svmpc"], default="dual")
+    ap.add_argument("--case", choices=["dual", "svmpc", "mppi", "disco"], default="dual")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     cfg = copy.deepcopy(DEFAULTS)
@@ -75,6 +75,24 @@ def main():
     dynamics_prior = dist.Independent(dist.Uniform(torch.tensor([0.6, 0.6]), torch.tensor([1.3, 1.3])), 1)
     true_params = dynamics_prior.sample()
 
+    if args.case in ("mppi", "disco"):
+        # the reference's "MPPI Baseline" / "DISCO" cases (pendulum_example.py:217-261): one policy, no SVGD; DISCO rolls the
+        # sigma points of the dynamics prior out (unscented transform, yaml utf block: n = 2, alpha = 0.5)
+        from dust_amd.utils.simulations import run_pendulum_simulation
+        from dust_amd.utils.utf import MerweScaledUTF
+
+        disco = args.case == "disco"
+        controller = MultiDISCO(observation_space=env_model.observation_space, action_space=env_model.action_space, hz_len=H,
+                                n_policies=1, action_samples=S, temperature=1 / alpha, a_cov=e["ctrl_sigma"] ** 2 * torch.eye(e["ctrl_dim"]),
+                                inst_cost_fn=inst_cost, term_cost_fn=term_cost,
+                                params_sampling=MerweScaledUTF(n=2, alpha=0.5) if disco else None, params_log_space=False)
+        t0 = time.perf_counter()
+        df = run_pendulum_simulation(init_state, init_policies[0].unsqueeze(0), dict(uncertain_params=("length", "mass")) if disco else {},
+                                     dynamics_prior, [dict(length=float(true_params[0]), mass=float(true_params[1]))], controller,
+                                     use_exact_model=False, use_svmpc=False, episodes=1, steps=steps, warm_up=sim["warm_up"])
+        el = time.perf_counter() - t0
+        print("%s: %d ticks, avg cost %.2f, %.1f ticks/s incl. host plumbing" % (args.case, steps, float(df["Cost"].mean()), steps / el))
+        return
     kernel = RBFKernel() if e["kernel"] == "rbf" else iid_mp(base_kernel=RBF(bandwidth=-1), ctrl_dim=1, indep_controls=True)
     dual = args.case == "dual"
     controller = MultiDISCO(observation_space=env_model.observation_space, action_space=env_model.action_space, hz_len=H, n_policies=N,
