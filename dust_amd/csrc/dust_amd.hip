@@ -742,18 +742,26 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
     KERNEL<<<c->nloc, nt, lds, c->stream>>>(a);                                                                                 \
   } while (0)
   const bool stream_form = a.noise_mode == NOISE_EPS;
-#define DUST_PICK_ROLLOUT(MODEL)                                                          \
-  do {                                                                                   \
-    if (a.G > 1) {                                                                       \
-      if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, true>));        \
-      else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, true>));                           \
-    } else {                                                                             \
-      if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, false>));       \
-      else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, false>));                          \
-    }                                                                                    \
+  // LEAN instances: the optional features compiled out (rollout.hpp)
+  const bool lean = !a.states_out && !a.actions_out && !a.costs_in && a.a_reg == 0.0f && !a.mw && !a.tile_scratch && !a.omegaT;
+#define DUST_PICK_ROLLOUT3(MODEL, GR, LN)                                            \
+  do {                                                                              \
+    if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, GR, LN>));    \
+    else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, GR, LN>));                       \
+  } while (0)
+#define DUST_PICK_ROLLOUT(MODEL)                                     \
+  do {                                                               \
+    if (a.G > 1) {                                                   \
+      if (lean) DUST_PICK_ROLLOUT3(MODEL, true, true);               \
+      else DUST_PICK_ROLLOUT3(MODEL, true, false);                   \
+    } else {                                                         \
+      if (lean) DUST_PICK_ROLLOUT3(MODEL, false, true);              \
+      else DUST_PICK_ROLLOUT3(MODEL, false, false);                  \
+    }                                                                \
   } while (0)
   if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_ROLLOUT(DUST_MODEL_PENDULUM);
   else DUST_PICK_ROLLOUT(DUST_MODEL_PARTICLE);
+#undef DUST_PICK_ROLLOUT3
 #undef DUST_PICK_ROLLOUT
 #undef DUST_LAUNCH_ROLLOUT
   HIP_TRY(hipGetLastError());
@@ -1009,6 +1017,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   oo.merge_prior = 1;
   TRY(rollout_args(c, oo, f.ra, &nt, &lds_r));
   if (f.ra.tile_scratch || (PAIR_NT % nt) != 0) return DUST_OK;
+  if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // the fused launch carries the LEAN rollout body only
   f.sub_nt = nt;
   f.per_block = PAIR_NT / nt;
   if (c->nloc % f.per_block || PAIR_TI % f.per_block) return DUST_OK;

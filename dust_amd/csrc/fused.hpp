@@ -45,7 +45,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
     const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
     const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag};
-    rollout_body<MODEL, 12, GROUPS>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+    rollout_body<MODEL, 12, GROUPS, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
   }
 }
 

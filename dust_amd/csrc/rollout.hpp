@@ -103,7 +103,8 @@ struct FusedWait {
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
 // wide (every sub-block of a workgroup runs the same control flow), reductions are sub-block local.
 template <int MODEL, int NB /* staged noise loads in flight per lane: 32 standalone, 12 inside the fused launch (VGPR budget) */,
-          bool GROUPS /* lane = (sample, dynamics group): a.G > 1 */>
+          bool GROUPS /* lane = (sample, dynamics group): a.G > 1 */,
+          bool LEAN /* none of: stored states / actions / omega, injected costs, control cost, sigma-point weights, HBM tile */>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, const int tid, const int nt, const int nl,
                                              const FusedWait *fw) {
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
@@ -111,9 +112,18 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const int n = a.n0 + nl;
   const int S = a.S, D = a.D, H = a.H, N = a.N_total;
   const int Dp = D | 1;
+  // Optional features are compiled OUT of the LEAN instances (the host picks them when none is requested): the argument
+  // block no longer has to stay live in SGPRs across the hot loops (the full kernel spills ~1000 scalars to VGPR lanes).
+  float *const f_states = LEAN ? nullptr : a.states_out;
+  float *const f_actions = LEAN ? nullptr : a.actions_out;
+  const float *const f_costs_in = LEAN ? nullptr : a.costs_in;
+  const float f_a_reg = LEAN ? 0.0f : a.a_reg;
+  const float *const f_mw = LEAN ? nullptr : a.mw;
+  float *const f_tile_scratch = LEAN ? nullptr : a.tile_scratch;
+  float *const f_omegaT = LEAN ? nullptr : a.omegaT;
   // the S x D action tile lives in LDS; when it would not fit (huge S*D) it spills to a per-workgroup HBM scratch slab
-  float *tile = a.tile_scratch ? a.tile_scratch + (size_t)nl * S * Dp : lds;  // [S][Dp] actions
-  float *cst = a.tile_scratch ? lds : lds + (size_t)S * Dp;                            // [S] costs -> weights
+  float *tile = f_tile_scratch ? f_tile_scratch + (size_t)nl * S * Dp : lds;  // [S][Dp] actions
+  float *cst = f_tile_scratch ? lds : lds + (size_t)S * Dp;                            // [S] costs -> weights
   float *omg = cst + S;    // [S] omega
   float *red = omg + S;    // [96] reduction scratch, flags, prior slice words
   float *part = red + 96;  // [2][nt] partial sums for the weighted reductions
@@ -193,7 +203,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const long SN = (long)S * N;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
-  const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !a.states_out && !a.tile_scratch && red[40] == 0.f && !a.mw &&
+  const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !f_states && !f_tile_scratch && red[40] == 0.f && !f_mw &&
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
   // M loop is split over G lane groups that share the action tile - 4x the waves per LDS byte at cfg3 (S = 64, M = 64)
@@ -224,22 +234,22 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   double *accp = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(part) + 7) & ~(uintptr_t)7);
   auto finish_cost = [&](const int s, const double acc, const bool is_sum = false) {
     float cost = (a.M == 1 || is_sum) ? (float)acc : (float)(acc / a.M);
-    if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
+    if (f_a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
       const float *act = tile + s * Dp;
       double cc = 0.0;
       for (int j = 0; j < D; ++j) {
         const float e = act[j] - a.a_seq[j];
         cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % DA]);
       }
-      cost = cost + a.a_reg * (float)cc;
+      cost = cost + f_a_reg * (float)cc;
     }
     cst[s] = cost;
     a.costsT[(size_t)n * S + s] = cost;
   };
   for (int s = ts; s < S; s += sub) {
     float *act = tile + s * Dp;
-    if (a.costs_in) {
-      if (mg == 0) cst[s] = a.costs_in[(size_t)s * N + n];
+    if (f_costs_in) {
+      if (mg == 0) cst[s] = f_costs_in[(size_t)s * N + n];
       continue;
     }
     double acc_m = 0.0, ut_term = 0.0;
@@ -278,7 +288,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         q = W * (q * q);
         traj = (float)tot + (q.x + q.y);
       } else {
-        float *so = a.states_out ? a.states_out + (size_t)r * (H + 1) * DS : nullptr;
+        float *so = f_states ? f_states + (size_t)r * (H + 1) * DS : nullptr;
         if (so) {
 #pragma unroll
           for (int k = 0; k < DS; ++k) so[k] = x[k];
@@ -289,14 +299,14 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
           const float ci = step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
-          tot += a.mw ? (double)a.mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
+          tot += f_mw ? (double)f_mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
           if (so) {
 #pragma unroll
             for (int k = 0; k < DS; ++k) so[(size_t)(t + 1) * DS + k] = x[k];
           }
         }
-        if (a.mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
-          ut_term += (double)a.mw[m] * (double)term_cost<MODEL>(a.dm, x);
+        if (f_mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
+          ut_term += (double)f_mw[m] * (double)term_cost<MODEL>(a.dm, x);
           traj = (float)tot;  // unused
           acc_m += tot;
           continue;
@@ -309,22 +319,22 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       accp[mg * sub + ts] = acc_m;
       continue;
     }
-    if (a.mw) finish_cost(s, (double)((float)acc_m + (float)ut_term), true);  // weighted sum over sigma points, not a mean
+    if (f_mw) finish_cost(s, (double)((float)acc_m + (float)ut_term), true);  // weighted sum over sigma points, not a mean
     else finish_cost(s, acc_m);
   }
   if (G > 1) {  // fixed-order sum of the group partials (the barrier sits outside the sample loop: lanes without a sample reach it too)
     __syncthreads();
-    if (mg == 0 && ts < S && !a.costs_in) {
+    if (mg == 0 && ts < S && !f_costs_in) {
       double acc_m = accp[ts];
       for (int g = 1; g < G; ++g) acc_m += accp[g * sub + ts];
       finish_cost(ts, acc_m);
     }
   }
   __syncthreads();
-  if (a.actions_out) {
+  if (f_actions) {
     for (int idx = tid; idx < S * D; idx += nt) {
       const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-      a.actions_out[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
+      f_actions[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
     }
   }
 
@@ -432,9 +442,9 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     if (same_w) zo = zw;
   }
   const float *wom = same_w ? cst : omg;
-  if (a.omegaT)
-    for (int s = tid; s < S; s += nt) a.omegaT[(size_t)n * S + s] = wom[s] / zo;
-  if (tid == 0 && !a.costs_in) {
+  if (f_omegaT)
+    for (int s = tid; s < S; s += nt) f_omegaT[(size_t)n * S + s] = wom[s] / zo;
+  if (tid == 0 && !f_costs_in) {
     if (a.lik == DUST_LIK_EXP_UTILITY)  // likelihoods.py:127-135
       a.logl[n] = ((-cmin * a.alpha) + logf(zw)) - logf((float)S);
     else  // likelihoods.py:113-119
@@ -518,18 +528,18 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
   return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
 }
 
-template <int MODEL, bool GROUPS>
+template <int MODEL, bool GROUPS, bool LEAN>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32, GROUPS>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS, LEAN>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 // Same body under its own symbol for the HBM-streaming form (caller-supplied eps resident in HBM): profiles and PMC
 // passes then attribute it separately from the Philox form.
-template <int MODEL, bool GROUPS>
+template <int MODEL, bool GROUPS, bool LEAN>
 __global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32, GROUPS>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS, LEAN>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
