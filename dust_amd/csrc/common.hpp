@@ -288,6 +288,19 @@ __device__ __forceinline__ float wave_reduce_dpp(float v, const float identity, 
   v = op(v, dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));  // row_bcast:31 -> rows 2, 3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// the same over each 16-lane row only (every lane of a row gets its row's result)
+template <typename F>
+__device__ __forceinline__ float row16_reduce(float v, const float identity, F op) {
+  auto dpp = [&](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, x),
+                                                                   decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   return wave_reduce_dpp(v, 0.f, [](float a, float b) { return a + b; });
 }

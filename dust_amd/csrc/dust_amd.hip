@@ -724,6 +724,10 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
     lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false);
     if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "n_samples too large for one workgroup (%zu B of LDS)", lds);
   }
+  {
+    const int Q = std::max(1, nt / c->D);
+    a.wq_iters = (c->S + Q - 1) / Q;
+  }
   *nt_out = nt;
   *lds_out = lds;
   return DUST_OK;

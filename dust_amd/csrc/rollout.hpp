@@ -31,6 +31,7 @@ struct RolloutArgs {
   DevModel dm;
   int N_total, n0, S, M, H, D;
   int noise_mode;
+  int wq_iters;      // ceil(S / (nt / D)): trip count of the weighted reductions over s
   int lgW;           // log2 of the lanes per action row in the noise staging (2^lgW >= D)
   int G;             // dynamics-sample groups: lane = (sample, group), group g rolls out m = g, g+G, ... (G > 1 only when S <= nt/G)
   int lik;           // dust_likelihood
@@ -460,21 +461,39 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   if (q < Q) {
     const float thj = th[j];
     const float is2 = 1.0f / (a.sigma_a[j % DA] * a.sigma_a[j % DA]);  // (a - x) / sigma^2 as a multiply: <= 1 ulp apart
-    const float base = a.eps_base_mode ? thj : a.a_seq[j];
-#pragma unroll 8
-    for (int s = q; s < S; s += Q) {
-      const float av = tile[s * Dp + j];
-      const float d = av - thj;
-      g = fmaf(cst[s], d * is2, g);
-      if (!same_w) am = fmaf(omg[s], av - base, am);
-      else if (a.eps_base_mode == 0) am = fmaf(cst[s], av - base, am);  // base = a_seq; with base = theta it is g / is2
+    // running pointers and a host-computed, wave-uniform trip count (a.wq_iters = ceil(S / Q)): no index division, no
+    // remainder loop; the mode tests are hoisted out of the loop
+    const float *tp = tile + q * Dp + j, *cp = cst + q;
+    const int tstep = Q * Dp;
+    if (same_w && a.eps_base_mode) {  // SVMPC: omega == w and eps = a - theta: the a_mat sum is g * sigma^2
+#pragma unroll 4
+      for (int it = 0; it < a.wq_iters; ++it) {
+        const bool ok = q + it * Q < S;
+        const float av = ok ? tp[it * tstep] : thj, w = ok ? cp[it * Q] : 0.f;
+        g = fmaf(w, (av - thj) * is2, g);
+      }
+    } else {
+      const float base = a.eps_base_mode ? thj : a.a_seq[j];
+      const float *op = (same_w ? cst : omg) + q;
+#pragma unroll 4
+      for (int it = 0; it < a.wq_iters; ++it) {
+        const bool ok = q + it * Q < S;
+        const float av = ok ? tp[it * tstep] : thj, w = ok ? cp[it * Q] : 0.f, wo = ok ? op[it * Q] : 0.f;
+        g = fmaf(w, (av - thj) * is2, g);
+        am = fmaf(wo, av - base, am);
+      }
     }
   }
   part[tid] = g;
   part[nt + tid] = am;
   if (a.merge_prior && tid < 16) {
-    red[64 + tid] = pmM1;
-    red[80 + tid] = pmL1;
+    // combine weights of the JS <= 16 prior slices, once per particle: lane u holds slice u's (max, mass); 16-lane DPP
+    // reductions give the overall max and the total mass; every column then only needs sum_u pA[u] w_u
+    const float m = row16_reduce(pmM1, -INFINITY, [](float x, float y) { return fmaxf(x, y); });
+    const float w = (pmM1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((pmM1 - m) * 1.44269504088896340736f);
+    const float l = row16_reduce(pmL1 * w, 0.f, [](float x, float y) { return x + y; });
+    red[64 + tid] = w;
+    red[80 + tid] = l;
   }
   lds_barrier();
   DUST_STAMP(a.stamps, 4);
@@ -493,18 +512,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     if (a.merge_prior) {  // prior half of the score (svmpc.py:38-41,56) from the pairwise kernel's slice partials
       float gp;
       if (JS <= 16) {
-        float m = -INFINITY;
+        float acc = 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) m = fmaxf(m, red[64 + u]);
-        float l = 0.f, acc = 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const float pm_u = red[64 + u];
-          const float w = (pm_u == -INFINITY) ? 0.f : expf(pm_u - m);
-          l = fmaf(red[80 + u], w, l);
-          acc = fmaf(pmA[u], w, acc);
-        }
-        gp = (acc / l) * a.pm.inv_s2[tid % DA];
+        for (int u = 0; u < 16; ++u) acc = fmaf(pmA[u], red[64 + u], acc);
+        gp = (acc / red[80]) * a.pm.inv_s2[tid % DA];
       } else {
         float m, l;
         prior_merge_row(a.pm, nl, &m, &l);
