@@ -9,12 +9,14 @@ One "step" = one control tick = SVMPC.optimize(5 iterations) + SVMPC.forward (we
 Policy noise is drawn on the device inside the timed region (Philox, fused into the rollout kernel) - the reference also
 draws its noise inside the tick - so no work is skipped.
 
-N>1 shards the particle index over the ranks (weak scaling: 1024 particles per GPU, N*1024 in the joint problem) with one
-RCCL all-gather of [theta | score] per SVGD iteration before the pairwise kernel step; `value` counts 1024-particle
-shard-ticks per second summed over ranks (= joint ticks/s * N), `joint_ticks_per_s` is the joint rate itself.
+N>1 shards the particle index over the ranks (weak scaling: 1024 particles per GPU, N*1024 in the joint problem) with two
+in-place RCCL all-gathers per SVGD iteration (score before the Stein pass, theta after the update - the prior means alias
+theta); `value` counts 1024-particle shard-ticks per second summed over ranks (= joint ticks/s * N),
+`joint_ticks_per_s` is the joint rate itself.  The pairwise passes are N_loc x N, so per-rank work grows with N by design.
 
 Extra objects in the JSON line (tier contract): `roofline` for the rollout kernel in its HBM-streaming form (external
-noise read from HBM, the variant the parity tests drive), timed with HIP events inside this process; `cpu_baseline` =
+noise read from HBM, the variant the parity tests drive), timed with HIP events inside this process (one event pair around
+400 back-to-back launches on the context's stream; `traffic` from the committed PMC summary under profiles/); `cpu_baseline` =
 the CPU oracle (oracle/dust_oracle.c, a port - the reference is Python and cannot travel) on the host cores.
 """
 import argparse
@@ -201,7 +203,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Pendulum N=%d particles/GPU (%d total), S=128, M=1, H=30, 5 SVGD iters, K1 (gpytorch-RBF) kernel, SGD, "
                                    "device Philox noise inside the tick" % (n_loc, n_tot),
-                       "parallelism": "particles sharded x%d, RCCL all-gather of [theta|score] per SVGD iteration" % n_gpus if n_gpus > 1 else "single GPU"},
+                       "parallelism": "particles sharded x%d, two in-place RCCL all-gathers (score, theta) per SVGD iteration" % n_gpus if n_gpus > 1 else "single GPU"},
             "joint_ticks_per_s": joint,
             "n_particles_total": n_tot,
             "per_kernel": per_kernel,
