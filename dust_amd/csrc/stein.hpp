@@ -91,6 +91,39 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0,
   }
 }
 
+// Row-lane tile staging: W = 2^k >= DP lanes per row, RB = NT / W rows per batch; a lane keeps ONE column (its scale is a
+// per-lane constant, no index division) and walks the rows with a fixed stride in HBM and LDS.  Rows / columns outside the
+// source are written as zeros, so no separate zero-fill pass (and no barrier for it) is needed.  Loads are clamped, never
+// predicated.  issue and commit are separate: several tiles' loads are put in flight before the first wait.
+template <int TR, int DP, int NT>
+struct RowLane {
+  static constexpr int W = DP <= 32 ? 32 : (DP <= 64 ? 64 : 128);
+  static constexpr int RB = NT / W;
+  static constexpr int NB = TR / RB;
+};
+template <int TR, int DP, int NT>
+__device__ __forceinline__ void rowlane_issue(const float *__restrict__ src, int r0, int nrows, int D, float (&v)[RowLane<TR, DP, NT>::NB]) {
+  using RL = RowLane<TR, DP, NT>;
+  const int lr = (int)threadIdx.x / RL::W, lc = min((int)threadIdx.x % RL::W, D - 1);
+  const float *base = src + (size_t)r0 * D + lc;
+#pragma unroll
+  for (int u = 0; u < RL::NB; ++u) v[u] = base[(size_t)min(u * RL::RB + lr, nrows - 1) * D];
+}
+template <int TR, int DP, int LS, int NT, bool SCALE>
+__device__ __forceinline__ void rowlane_commit(const float (&v)[RowLane<TR, DP, NT>::NB], int nrows, int D, int da, const float *colscale,
+                                               float *dst) {
+  using RL = RowLane<TR, DP, NT>;
+  const int lr = (int)threadIdx.x / RL::W, lc = (int)threadIdx.x % RL::W;
+  if (lc >= DP) return;  // W > DP (DP = 96): idle lanes
+  const float sc = SCALE ? colscale[da == 1 ? 0 : (da == 2 ? (lc & 1) : lc % da)] : 1.0f;
+  const bool cv = lc < D;
+#pragma unroll
+  for (int u = 0; u < RL::NB; ++u) {
+    const int r = u * RL::RB + lr;
+    dst[r * LS + lc] = (cv && r < nrows) ? (SCALE ? v[u] * sc : v[u]) : 0.f;
+  }
+}
+
 template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
 __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, const int tile_x, const int js, const bool write_through = false) {
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
@@ -112,21 +145,14 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   // ---- query tile + first key chunk -> LDS: all first-batch loads are in flight before the first wait ----
   const int nq = min(TI, a.i0 + a.n_local - ib), jc0 = min(JC, jend - jbeg);
   {
-    float vx[8], vy[8], vv[8];
-    rows_issue<NT>(a.X + (size_t)ib * D, nq * D, 0, vx);
-    rows_issue<NT>(a.Y + (size_t)jbeg * D, jc0 * D, 0, vy);
-    if (MODE != PAIR_PRIOR) rows_issue<NT>(a.V + (size_t)jbeg * D, jc0 * D, 0, vv);
-    rows_zero<TI, DP, DP, NT>(Xs);
-    rows_zero<JC, DP, YS, NT>(Ys);
-    if (MODE != PAIR_PRIOR) rows_zero<JC, DP, YS, NT>(Vs);
+    float vx[RowLane<TI, DP, NT>::NB], vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
+    rowlane_issue<TI, DP, NT>(a.X, ib, nq, D, vx);
+    rowlane_issue<JC, DP, NT>(a.Y, jbeg, jc0, D, vy);
+    if (MODE != PAIR_PRIOR) rowlane_issue<JC, DP, NT>(a.V, jbeg, jc0, D, vv);
     if (tid < TI) mrow[tid] = -INFINITY;
-    __syncthreads();
-    rows_commit<DP, NT, true>(vx, nq * D, 0, D, da, a.magicD, a.inv_s, Xs);
-    rows_commit<YS, NT, true>(vy, jc0 * D, 0, D, da, a.magicD, a.inv_s, Ys);
-    if (MODE != PAIR_PRIOR) rows_commit<YS, NT, false>(vv, jc0 * D, 0, D, da, a.magicD, a.inv_s, Vs);
-    load_rows<TI, DP, DP, NT, true>(a.X, ib, nq, D, da, a.magicD, a.inv_s, Xs, 1);  // remaining batches (large D only)
-    load_rows<JC, DP, YS, NT, true>(a.Y, jbeg, jc0, D, da, a.magicD, a.inv_s, Ys, 1);
-    if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, jbeg, jc0, D, da, a.magicD, a.inv_s, Vs, 1);
+    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs);
+    rowlane_commit<JC, DP, YS, NT, true>(vy, jc0, D, da, a.inv_s, Ys);
+    if (MODE != PAIR_PRIOR) rowlane_commit<JC, DP, YS, NT, false>(vv, jc0, D, da, a.inv_s, Vs);
   }
 
   // pass-B ownership: query iB, columns [cB, cB + CPT)
@@ -147,11 +173,11 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     const int jA = tid & (JC - 1), igA = tid / JC;
     const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
     if (j0 != jbeg) {  // later chunks of a long slice (the first one was staged with the query tile)
-      rows_zero<JC, DP, YS, NT>(Ys);
-      if (MODE != PAIR_PRIOR) rows_zero<JC, DP, YS, NT>(Vs);
-      __syncthreads();
-      load_rows<JC, DP, YS, NT, true>(a.Y, j0, jc, D, da, a.magicD, a.inv_s, Ys);
-      if (MODE != PAIR_PRIOR) load_rows<JC, DP, YS, NT, false>(a.V, j0, jc, D, da, a.magicD, a.inv_s, Vs);
+      float vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
+      rowlane_issue<JC, DP, NT>(a.Y, j0, jc, D, vy);
+      if (MODE != PAIR_PRIOR) rowlane_issue<JC, DP, NT>(a.V, j0, jc, D, vv);
+      rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys);  // the barrier that ended the previous chunk's pass B
+      if (MODE != PAIR_PRIOR) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);  // protects these writes
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 2);
