@@ -73,13 +73,13 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
   for (int j0 = jbeg; j0 < jend; j0 += JC) {
     const int jc = min(JC, jend - j0);
     // ---- key chunk -> LDS (rows j0 .. j0 + jc - 1 are contiguous in HBM) ----
-    __syncthreads();  // the previous chunk's pass B is done with Ys / Vs / kv
-    rows_zero<JC, DPB, YS, NT>(Ys);
-    if (MODE != PAIR_PRIOR) rows_zero<JC, DPB, YS, NT>(Vs);
+    float vy[RowLane<JC, DPB, NT>::NB], vv[RowLane<JC, DPB, NT>::NB];
+    rowlane_issue<JC, DPB, NT>(a.Y, j0, jc, D, vy);
+    if (MODE != PAIR_PRIOR) rowlane_issue<JC, DPB, NT>(a.V, j0, jc, D, vv);
     const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;
-    __syncthreads();
-    load_rows<JC, DPB, YS, NT, false>(a.Y, j0, jc, D, a.da, a.magicD, a.inv_s, Ys);
-    if (MODE != PAIR_PRIOR) load_rows<JC, DPB, YS, NT, false>(a.V, j0, jc, D, a.da, a.magicD, a.inv_s, Vs);
+    __syncthreads();  // the previous chunk's pass B is done with Ys / Vs / kv
+    rowlane_commit<JC, DPB, YS, NT, false>(vy, jc, D, a.da, a.inv_s, Ys);
+    if (MODE != PAIR_PRIOR) rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, a.da, a.inv_s, Vs);
     __syncthreads();
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
