@@ -7,8 +7,8 @@
 //
 // Mapping (MI355X).  The pairwise work is cut into 2-D tiles so that a launch has >= 256 workgroups even at N = 1024
 // and every CU reads only ITS tile of the particle set (not all of it): workgroup (it, js) owns TI = 32 query particles
-// and the js-th slice of the key particles, streamed through LDS in chunks of JC = 64 rows (coalesced loads of
-// contiguous row-major rows, 8 in flight per lane; two workgroups per CU hide each other's LDS / exp latency).  Per chunk:
+// and the js-th slice of the key particles, streamed through LDS in chunks of JC = 64 rows (row-lane staging: a lane keeps
+// one column and walks the rows, every load of a tile in flight before the first wait).  Per chunk:
 //   pass A  lane = key j, the wave walks 8 queries: d2 = sum_d ((x_i[d] - y_j[d]) / s_d)^2 with y_j in registers and
 //           x_i[d] LDS-broadcast (b128); kernel value / softmax logit -> LDS kv[TI][JC+1];
 //   pass B  lane = (query i, column group): acc[i][c] += kv[i][j] * V[j][c], a [32 x 64] . [64 x D] product out of
@@ -54,42 +54,6 @@ __device__ __forceinline__ void store16(float *p, v4f v, bool wt) {
   else *reinterpret_cast<v4f *>(p) = v;
 }
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)
-
-// Tile staging: rows [r0, r0 + nrows) of a row-major [*][D] array -> LDS tile with row stride LS, zero padded to TR x DP,
-// each column multiplied by colscale[d % da].  The source range is one contiguous run of nrows*D floats: coalesced dword
-// loads in batches of 8 per lane, clamped and never predicated (a conditional load makes hipcc branch and wait vmcnt(0)
-// per element).  Issue and commit are separate so a caller can put several tiles' loads in flight before the first wait.
-template <int NT>
-__device__ __forceinline__ void rows_issue(const float *__restrict__ base, int total, int b, float v[8]) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = base[min(b + u * NT + (int)threadIdx.x, total - 1)];
-}
-template <int LS, int NT, bool SCALE>
-__device__ __forceinline__ void rows_commit(const float v[8], int total, int b, int D, int da, uint32_t magicD, const float *colscale,
-                                            float *dst) {
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int idx = b + u * NT + (int)threadIdx.x;
-    const int r = (int)__umulhi((uint32_t)idx, magicD), d = idx - r * D;
-    const int cd = da == 1 ? 0 : (da == 2 ? (d & 1) : d % da);  // no runtime modulo on the common control dims
-    if (idx < total) dst[r * LS + d] = SCALE ? v[u] * colscale[cd] : v[u];
-  }
-}
-template <int TR, int DP, int LS, int NT>
-__device__ __forceinline__ void rows_zero(float *dst) {
-  for (int idx = threadIdx.x; idx < TR * DP; idx += NT) dst[(idx / DP) * LS + (idx % DP)] = 0.f;
-}
-template <int TR, int DP, int LS, int NT, bool SCALE>
-__device__ __forceinline__ void load_rows(const float *__restrict__ src, int r0, int nrows, int D, int da, uint32_t magicD,
-                                          const float *colscale, float *dst, int first_batch = 0) {
-  const int total = nrows * D;  // >= 1: every workgroup owns at least one row
-  const float *base = src + (size_t)r0 * D;
-  for (int b = first_batch * 8 * NT; b < total; b += 8 * NT) {
-    float v[8];
-    rows_issue<NT>(base, total, b, v);
-    rows_commit<LS, NT, SCALE>(v, total, b, D, da, magicD, colscale, dst);
-  }
-}
 
 // Row-lane tile staging: W = 2^k >= DP lanes per row, RB = NT / W rows per batch; a lane keeps ONE column (its scale is a
 // per-lane constant, no index division) and walks the rows with a fixed stride in HBM and LDS.  Rows / columns outside the
