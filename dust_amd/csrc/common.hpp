@@ -301,6 +301,17 @@ __device__ __forceinline__ float row16_reduce(float v, const float identity, F o
   v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
   return v;
 }
+// max over each aligned group of 8 consecutive lanes (all 8 lanes get it)
+__device__ __forceinline__ float oct_max(float v) {
+  auto dpp = [&](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, x),
+                                                                   decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // lane ^ 1
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // lane ^ 2
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror: the other quad of the 8
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   return wave_reduce_dpp(v, 0.f, [](float a, float b) { return a + b; });
 }

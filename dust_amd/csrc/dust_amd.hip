@@ -91,6 +91,7 @@ struct dust_ctx {
   int fused_tiles;
   bool fused_dirty;   // a fused launch ran and no update kernel has re-armed the counters yet
   float *theta_home, *theta_alt;  // theta ping-pong of the fused Stein+update launch (theta == one of the two)
+  bool theta_pinned;              // dust_gather_buffers handed theta's address out: no ping-pong any more
   const float *graph_theta;       // theta at the start of the captured tick
   unsigned int *stein_cnt;  // [tiles + 1]: arrival counters of the Stein+update launch (re-armed by the next rollout launch)
   int stein_tiles;
@@ -1201,7 +1202,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       f.ua = update_args(c, 1);
       // unsharded: the update writes the OTHER theta buffer, so its role may start per query tile while other Stein tiles
       // still read the current one; sharded contexts expose theta's address to the collectives and keep one buffer
-      const bool pingpong = c->nloc == c->N;
+      const bool pingpong = c->nloc == c->N && !c->theta_pinned;
       if (pingpong) f.ua.theta_out = c->theta_alt;
       f.wait_all = pingpong ? 0 : 1;
       f.tiles = tiles;
@@ -1543,6 +1544,15 @@ extern "C" int dust_disco_step(dust_ctx *c, int strategy, int steps, const float
 // multi-GPU split of one SVGD iteration around the RCCL all-gather of [theta | score]
 extern "C" int dust_gather_buffers(dust_ctx *c, void **theta_all, void **score_all, size_t *shard_bytes) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  // the caller keeps these addresses (in-place collectives): from here on theta stays in ONE buffer (no ping-pong)
+  if (c->theta != c->theta_home) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(d2d(c, c->theta_home, c->theta, (size_t)c->N * c->D * sizeof(float)));
+    c->theta_alt = c->theta;
+    c->theta = c->theta_home;
+  }
+  if (c->graph_exec) graph_drop(c);
+  c->theta_pinned = true;
   if (theta_all) *theta_all = c->theta;
   if (score_all) *score_all = c->score;
   if (shard_bytes) *shard_bytes = (size_t)c->nloc * c->D * sizeof(float);

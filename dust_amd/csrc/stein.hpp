@@ -180,22 +180,23 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       float m = -INFINITY;
 #pragma unroll
       for (int q = 0; q < JC / 8; ++q) m = fmaxf(m, kv[iB * (JC + 1) + (tid & 7) + 8 * q]);
-      m = fmaxf(m, __shfl_xor(m, 1, 64));
-      m = fmaxf(m, __shfl_xor(m, 2, 64));
-      m = fmaxf(m, __shfl_xor(m, 4, 64));
+      m = oct_max(m);  // the 8 lanes of a query are 8 consecutive lanes of one wave: DPP, no LDS crossbar
       const float mo = mrow[iB];
       const float mn = fmaxf(mo, m);
-      const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+      // bare v_exp_f32 (relative error ~|x| 2^-24, as for the K1 Gram value): weights near 1 are exact to 1 ulp and the
+      // ones it perturbs are negligible in the sums
+      const float sc = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
 #pragma unroll
       for (int c = 0; c < CPT / 2; ++c) accA[c] *= sc;
       accL *= sc;
-      __syncthreads();
+      // no barrier here: mrow[iB] and the kv entries below are touched only by the 8 lanes of query iB, which run in
+      // lockstep (every lane has read mrow[iB] before lane 0 of the group overwrites it)
       if ((tid & 7) == 0) mrow[iB] = mn;
 #pragma unroll
       for (int q = 0; q < JC / 8; ++q) {
         const int jj = (tid & 7) + 8 * q;
         const float l = kv[iB * (JC + 1) + jj];
-        kv[iB * (JC + 1) + jj] = (mn == -INFINITY) ? 0.f : expf(l - mn);
+        kv[iB * (JC + 1) + jj] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((l - mn) * 1.44269504088896340736f);
       }
       __syncthreads();
     }
