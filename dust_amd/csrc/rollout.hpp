@@ -93,6 +93,13 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
 // drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// v[j % DA] for a kernel-ARGUMENT array without a per-lane index: a lane-varying index into the argument block becomes a
+// vector memory load (whose in-order vmcnt wait covers every prefetch issued before it); DA is 1 or 2, so a select does.
+template <int DA>
+__device__ __forceinline__ float pick_da(const float (&v)[4], int j) {
+  return DA == 1 ? v[0] : ((j & 1) ? v[1] : v[0]);
+}
+
 // In-launch hand-off from the prior-pass workgroups of a fused launch (fused.hpp): per query tile, a monotonic arrival
 // counter; `target` arrivals mean every key slice of that tile has published its partials.
 struct FusedWait {
@@ -177,7 +184,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   bool nanf = tid < D && thv != thv;
   if (a.noise_mode != NOISE_PHILOX) {
     const float thj = a.noise_mode == NOISE_EPS ? th[min(sj, D - 1)] : 0.f;
-    const float lj = a.noise_mode == NOISE_EPS ? a.chol_a[sj % DA] : 1.f;
+    const float lj = a.noise_mode == NOISE_EPS ? pick_da<DA>(a.chol_a, sj) : 1.f;
     for (int s0 = 0; s0 < S; s0 += NB * R) {
       if (s0) {
         off0 += (uint32_t)NB * off_step;
@@ -224,7 +231,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int j = j4 * 4 + q;
-          if (j < D) act[j] = th[j] + a.chol_a[j % DA] * z[q];
+          if (j < D) act[j] = th[j] + pick_da<DA>(a.chol_a, j) * z[q];
         }
       }
     }
@@ -240,7 +247,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       double cc = 0.0;
       for (int j = 0; j < D; ++j) {
         const float e = act[j] - a.a_seq[j];
-        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j % DA]);
+        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * pick_da<DA>(a.a_pre, j));
       }
       cost = cost + f_a_reg * (float)cc;
     }
@@ -356,36 +363,6 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
     __syncthreads();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
   }
-  // prior partials of this row: issue the (independent) loads now, consume them after the reduction below
-  // (the per-slice max / mass words are the same for every column: lanes 0..15 fetch one slice each and hand them to
-  // the other lanes through LDS (red[64..95]) - 2 registers instead of 32 in every lane)
-  float pmA[16], pmM1 = -INFINITY, pmL1 = 0.f;
-  const bool merger = a.merge_prior && tid < D;
-  const int JS = a.pm.JS;
-  if (a.merge_prior && tid < 16) {
-    const size_t rowi = (size_t)min(tid, JS - 1) * a.pm.n_local + nl;
-    float tm, tl;
-    if (fw) {
-      tm = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tl = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      tm = a.pm.pM[rowi];
-      tl = a.pm.pL[rowi];
-    }
-    pmM1 = tid < JS ? tm : -INFINITY;
-    pmL1 = tid < JS ? tl : 0.f;
-  }
-  if (merger) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const bool ok = u < JS;
-      const size_t rowi = (size_t)(ok ? u : 0) * a.pm.n_local + nl;
-      float ta;  // unconditional loads
-      if (fw) ta = __hip_atomic_load(a.pm.pA + rowi * a.pm.ldp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else ta = a.pm.pA[rowi * a.pm.ldp + tid];
-      pmA[u] = ok ? ta : 0.f;
-    }
-  }
   DUST_STAMP(a.stamps, 2);
   // ---- 3. softmax over samples: likelihood weights w (alpha) and MPPI weights omega (1/temp) ----
   float cmin = INFINITY, csum = 0.f;
@@ -454,33 +431,68 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   }
 
   DUST_STAMP(a.stamps, 3);
+  // prior partials of this row: the (independent) loads are issued HERE - after the softmax, whose wave reductions would
+  // otherwise run into waits on them (in-order vmcnt + register reuse) - and land under the weighted reductions below.
+  // (the per-slice max / mass words are the same for every column: lanes 0..15 fetch one slice each and hand the combine
+  // weights to the other lanes through LDS (red[64..95]) - 2 registers instead of 32 in every lane; slices past JS re-read
+  // slice 0, clamped and never predicated, and are masked at the point of use: a select right after the load would make
+  // the compiler wait for it on the spot)
+  float pmA[16], pmM1 = -INFINITY, pmL1 = 0.f;
+  const bool merger = a.merge_prior && tid < D;
+  const int JS = a.pm.JS;
+  if (a.merge_prior && tid < 16) {
+    const size_t rowi = (size_t)min(tid, JS - 1) * a.pm.n_local + nl;
+    if (fw) {
+      pmM1 = __hip_atomic_load(a.pm.pM + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pmL1 = __hip_atomic_load(a.pm.pL + rowi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      pmM1 = a.pm.pM[rowi];
+      pmL1 = a.pm.pL[rowi];
+    }
+  }
+  if (merger) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const size_t rowi = (size_t)(u < JS ? u : 0) * a.pm.n_local + nl;  // combine weight of slices past JS is 0
+      if (fw) pmA[u] = __hip_atomic_load(a.pm.pA + rowi * a.pm.ldp + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else pmA[u] = a.pm.pA[rowi * a.pm.ldp + tid];
+    }
+  }
   // ---- 4. weighted reductions over s: grad_lik (svmpc.py:52-54) and a_mat += sum_s omega eps (disco.py:387-392) ----
   const int Q = nt / D > 0 ? nt / D : 1;
   float g = 0.f, am = 0.f;
   const int q = (int)__umulhi((uint32_t)tid, a.magicD), j = tid - q * D;
   if (q < Q) {
     const float thj = th[j];
-    const float is2 = 1.0f / (a.sigma_a[j % DA] * a.sigma_a[j % DA]);  // (a - x) / sigma^2 as a multiply: <= 1 ulp apart
+    const float is2 = 1.0f / (pick_da<DA>(a.sigma_a, j) * pick_da<DA>(a.sigma_a, j));  // (a - x) / sigma^2 as a multiply: <= 1 ulp apart
     // running pointers and a host-computed, wave-uniform trip count (a.wq_iters = ceil(S / Q)): no index division, no
     // remainder loop; the mode tests are hoisted out of the loop
-    const float *tp = tile + q * Dp + j, *cp = cst + q;
-    const int tstep = Q * Dp;
+    // (rows past S are clamped to row S-1 and given weight 0: a PREDICATED LDS load makes hipcc branch and wait per element -
+    // this loop ran at 176 cycles per iteration that way)
+    const float *tp = tile + j;
+    int so = q, to = q * Dp;  // running row index / tile offset
+    const int tstep = Q * Dp, tmax = (S - 1) * Dp;
     if (same_w && a.eps_base_mode) {  // SVMPC: omega == w and eps = a - theta: the a_mat sum is g * sigma^2
 #pragma unroll 4
       for (int it = 0; it < a.wq_iters; ++it) {
-        const bool ok = q + it * Q < S;
-        const float av = ok ? tp[it * tstep] : thj, w = ok ? cp[it * Q] : 0.f;
+        const float av = tp[min(to, tmax)], wl = cst[min(so, S - 1)];
+        const float w = so < S ? wl : 0.f;
         g = fmaf(w, (av - thj) * is2, g);
+        so += Q;
+        to += tstep;
       }
     } else {
       const float base = a.eps_base_mode ? thj : a.a_seq[j];
-      const float *op = (same_w ? cst : omg) + q;
+      const float *op = same_w ? cst : omg;
 #pragma unroll 4
       for (int it = 0; it < a.wq_iters; ++it) {
-        const bool ok = q + it * Q < S;
-        const float av = ok ? tp[it * tstep] : thj, w = ok ? cp[it * Q] : 0.f, wo = ok ? op[it * Q] : 0.f;
+        const int sc = min(so, S - 1);
+        const float av = tp[min(to, tmax)], wl = cst[sc], wol = op[sc];
+        const float w = so < S ? wl : 0.f, wo = so < S ? wol : 0.f;
         g = fmaf(w, (av - thj) * is2, g);
         am = fmaf(wo, av - base, am);
+        so += Q;
+        to += tstep;
       }
     }
   }
@@ -489,6 +501,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   if (a.merge_prior && tid < 16) {
     // combine weights of the JS <= 16 prior slices, once per particle: lane u holds slice u's (max, mass); 16-lane DPP
     // reductions give the overall max and the total mass; every column then only needs sum_u pA[u] w_u
+    if (tid >= JS) {  // clamped duplicates of slice JS-1
+      pmM1 = -INFINITY;
+      pmL1 = 0.f;
+    }
     const float m = row16_reduce(pmM1, -INFINITY, [](float x, float y) { return fmaxf(x, y); });
     const float w = (pmM1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((pmM1 - m) * 1.44269504088896340736f);
     const float l = row16_reduce(pmL1 * w, 0.f, [](float x, float y) { return x + y; });
@@ -505,7 +521,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
     const size_t o = (size_t)n * D + tid;
     gs = gs / zw;
-    if (same_w && a.eps_base_mode) as = gs * (a.sigma_a[tid % DA] * a.sigma_a[tid % DA]);  // sum_s w (a - theta)
+    if (same_w && a.eps_base_mode) as = gs * (pick_da<DA>(a.sigma_a, tid) * pick_da<DA>(a.sigma_a, tid));  // sum_s w (a - theta)
     else as = as / zo;
     a.grad_lik[o] = gs;
     if (a.update_a_mat) a.a_mat[o] = amv + as;
@@ -515,7 +531,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         float acc = 0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = fmaf(pmA[u], red[64 + u], acc);
-        gp = (acc / red[80]) * a.pm.inv_s2[tid % DA];
+        gp = (acc / red[80]) * pick_da<DA>(a.pm.inv_s2, tid);
       } else {
         float m, l;
         prior_merge_row(a.pm, nl, &m, &l);
