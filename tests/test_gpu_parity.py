@@ -231,7 +231,9 @@ def test_collisions_and_edges(golden):
     del pts, coll
 
 
-@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 256, 128, 1, 30), ("pendulum", 64, 32, 3, 7), ("particle", 128, 64, 4, 40)])
+@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 256, 128, 1, 30), ("pendulum", 64, 32, 3, 7), ("particle", 128, 64, 4, 40),
+                                           ("pendulum", 100, 40, 1, 7), ("pendulum", 33, 130, 2, 3), ("particle", 48, 96, 2, 9),
+                                           ("pendulum", 70, 200, 1, 33)])
 def test_seeded_vs_oracle(model, N, S, M, H):
     """Seeded inputs at sizes the oracle finishes in seconds: rollout/costs, score, phi (K1 and K2), forward."""
     from dust_amd import Context
@@ -296,7 +298,9 @@ def test_sharded_equals_unsharded(golden, world, overlap):
         assert relerr(pw, rp) < 1e-5 and np.array_equal(a_seq, ra)
 
 
-@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 1024, 128, 1, 30), ("pendulum", 512, 64, 1, 12), ("particle", 256, 64, 4, 20)])
+@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 1024, 128, 1, 30), ("pendulum", 512, 64, 1, 12), ("particle", 256, 64, 4, 20),
+                                           ("pendulum", 100, 40, 1, 7), ("pendulum", 33, 130, 3, 3), ("particle", 64, 96, 2, 9),
+                                           ("pendulum", 96, 256, 1, 33), ("particle", 40, 30, 1, 31)])
 def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H):
     """The fused launches (prior + rollout, Stein + update) hand partials over INSIDE a launch; the same bodies run as
     separate kernels when per-kernel profiling is on.  Both must give the same bits, tick after tick: a hand-off that
