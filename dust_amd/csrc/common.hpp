@@ -301,6 +301,14 @@ __device__ __forceinline__ float row16_reduce(float v, const float identity, F o
   v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
   return v;
 }
+// max over aligned groups of 2 / 4 consecutive lanes
+__device__ __forceinline__ float pair_max(float v) {
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = pair_max(v);
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+}
 // max over each aligned group of 8 consecutive lanes (all 8 lanes get it)
 __device__ __forceinline__ float oct_max(float v) {
   auto dpp = [&](float x, auto ctrl) {

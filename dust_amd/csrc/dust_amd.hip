@@ -603,7 +603,7 @@ struct SampleOpts {
 // geometry of the tiled pairwise launches: i-tiles of PAIR_TI queries x JS key slices, >= ~512 workgroups when possible
 // Large key sets take the register-blocked kernel of pairwise_big.hpp (its tile is TQ = 4096 / DPB queries).
 // Measured (round 1, N = 16384 / 4096, D = 30): Stein 1107 / 82 us vs 1730 / 115 us, prior 1367 / 99 vs 1799 / 119 us; D = 40:
-// 5-15 % faster; D = 80 (DPB = 128, 32-query tiles) the prior pass is slower, so D > 64 keeps the 32 x 64 kernel.  Sharded
+// 5-15 % faster; D = 80 (DPB = 128, 32-query tiles): 1630 / 1394 us vs 1060 / 905 us at N = 8192, so D > 64 keeps the 32 x 64 kernel.  Sharded
 // contexts (few query tiles per rank) keep it too: it allows JS <= 16 and with that the fused launches.
 static int pair_dpb(int D) { return D <= 32 ? 32 : 64; }
 static bool pair_is_big(const dust_ctx *c) {

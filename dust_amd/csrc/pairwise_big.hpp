@@ -125,24 +125,23 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
     }
     __syncthreads();
     if (MODE == PAIR_PRIOR) {
-      // online softmax over key chunks: LQ lanes per query
+      // online softmax over key chunks: LQ consecutive lanes per query (DPP max, bare v_exp_f32 as in the 32 x 64 kernel)
       const int q = tid / LQ, l = tid - q * LQ;
       float m = -INFINITY;
 #pragma unroll
       for (int t = 0; t < JC / LQ; ++t) m = fmaxf(m, kv[q * KS + l + LQ * t]);
-#pragma unroll
-      for (int o = 1; o < LQ; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      m = LQ == 8 ? oct_max(m) : (LQ == 4 ? quad_max(m) : pair_max(m));
       const float mo = mrow[q];
       const float mn = fmaxf(mo, m);
 #pragma unroll
       for (int t = 0; t < JC / LQ; ++t) {
         const int jj = l + LQ * t;
         const float lg = kv[q * KS + jj];
-        kv[q * KS + jj] = (mn == -INFINITY) ? 0.f : expf(lg - mn);
+        kv[q * KS + jj] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((lg - mn) * 1.44269504088896340736f);
       }
-      if (l == 0) {
+      if (l == 0) {  // the LQ lanes of a query run in lockstep: all have read mrow[q] by now
         mrow[q] = mn;
-        scl[q] = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+        scl[q] = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
       }
       __syncthreads();
 #pragma unroll
