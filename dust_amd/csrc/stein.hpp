@@ -125,6 +125,16 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 #pragma unroll
   for (int c = 0; c < CPT / 2; ++c) accA[c] = accB[c] = v2f{0.f, 0.f};
   float accL = 0.f;  // prior: sum of weights (same in the 8 lanes of a query)
+  // Stein modes, D <= 64: the Gram x score product (sum_j k_ij s_j: a [32 x 64].[64 x DP] GEMM per chunk) runs on the matrix
+  // cores - v_mfma_f32_16x16x4_f32, fp32 in and out - computed transposed (D'[col][query]) so that a lane ends up with 4
+  // CONSECUTIVE columns of one query, i.e. one 16-byte store of the partial row.  Wave w owns query half w >> 1 and
+  // TPW = DP / 32 column tiles.  The repulsive term keeps exact differences on the VALU and overlaps with the MFMAs.
+  constexpr bool MFMA_A = MODE != PAIR_PRIOR && CPT <= 8;
+  constexpr int TPW = MFMA_A ? DP / 32 : 1;
+  v4f accM[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;  // MFMA ownership
   __syncthreads();
   v2f xB[CPT / 2];
 #pragma unroll
@@ -202,6 +212,18 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     }
     DUST_STAMP(a.stamps, 3);
     // ---- pass B: lane = (query, 8 column groups); packed math ----
+    if (MFMA_A) {
+      // A[i = col][k = key] = S[key][col] (lane: i = l % 16, k = l / 16), B[k = key][j = query] = K[query][key] (lane:
+      // j = l % 16, k = l / 16), D'[col][query]: lane holds cols 4 (l / 16) + r of query l % 16
+      const float *kb = kv + (mqh * 16 + (ml & 15)) * (JC + 1) + (ml >> 4);
+      const float *sb = Vs + (ml >> 4) * YS + mct0 * 16 + (ml & 15);
+#pragma unroll
+      for (int k4 = 0; k4 < JC / 4; ++k4) {
+        const float bq = kb[4 * k4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) accM[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sb[4 * k4 * YS + 16 * t], bq, accM[t], 0, 0, 0);
+      }
+    }
 #pragma unroll 4
     for (int jj = 0; jj < JC; ++jj) {
       const float kq = kv[iB * (JC + 1) + jj];
@@ -217,9 +239,11 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
           accA[c / 2] = __builtin_elementwise_fma(kk, y01 - xB[c / 2], accA[c / 2]);
           accA[c / 2 + 1] = __builtin_elementwise_fma(kk, y23 - xB[c / 2 + 1], accA[c / 2 + 1]);
         } else {
-          const float4 sv = *reinterpret_cast<const float4 *>(&Vs[jj * YS + cB + c]);
-          accA[c / 2] = __builtin_elementwise_fma(kk, v2f{sv.x, sv.y}, accA[c / 2]);
-          accA[c / 2 + 1] = __builtin_elementwise_fma(kk, v2f{sv.z, sv.w}, accA[c / 2 + 1]);
+          if (!MFMA_A) {
+            const float4 sv = *reinterpret_cast<const float4 *>(&Vs[jj * YS + cB + c]);
+            accA[c / 2] = __builtin_elementwise_fma(kk, v2f{sv.x, sv.y}, accA[c / 2]);
+            accA[c / 2 + 1] = __builtin_elementwise_fma(kk, v2f{sv.z, sv.w}, accA[c / 2 + 1]);
+          }
           accB[c / 2] = __builtin_elementwise_fma(kpp, xB[c / 2] - y01, accB[c / 2]);
           accB[c / 2 + 1] = __builtin_elementwise_fma(kpp, xB[c / 2 + 1] - y23, accB[c / 2 + 1]);
         }
@@ -251,7 +275,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       }
       // write_through: sc1 stores so an in-launch consumer on another CU can read them with sc1 loads after the arrival
       // counter, with no release / acquire fence (Guideline 16, R1 form)
-      store16(a.pA + row + cB + c, oa, write_through);
+      if (!MFMA_A) store16(a.pA + row + cB + c, oa, write_through);
       if (MODE != PAIR_PRIOR) store16(a.pB + row + cB + c, ob, write_through);
     }
     if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
@@ -262,6 +286,14 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         a.pM[(size_t)js * a.n_local + il] = mrow[iB];
         a.pL[(size_t)js * a.n_local + il] = accL;
       }
+    }
+  }
+  if (MFMA_A) {  // Gram x score partial rows from the MFMA accumulators: query = l % 16 of the wave's half, 4 consecutive columns
+    const int ilm = tile_x * TI + mqh * 16 + (ml & 15);
+    if (ilm < a.n_local) {
+      const size_t rowm = ((size_t)js * a.n_local + ilm) * DP;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) store16(a.pA + rowm + (mct0 + t) * 16 + 4 * (ml >> 4), accM[t], write_through);
     }
   }
   DUST_STAMP(a.stamps, 5);
