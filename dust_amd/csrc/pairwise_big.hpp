@@ -58,7 +58,10 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), jA = tid & 63;
   const int qg = tid / LC, cg = tid - qg * LC, c0 = 4 * cg;  // pass-B ownership: queries 4 qg .. 4 qg + 3, columns c0 .. c0 + 3
 
-  v4f xB[4], accA[4], accB[4];
+  constexpr int NCT = DPB / 16, NQW = (TQ / 16) / 4;  // MFMA tiles: NCT column tiles x NQW query tiles per wave (4 in all)
+  v4f xB[4], accA[4], accB[4], accM[NCT * NQW];
+#pragma unroll
+  for (int t = 0; t < NCT * NQW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};
   float accL[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -151,12 +154,26 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
         accL[r] *= sc;
       }
     }
-    // ---- pass B: lane = 4 queries x 4 columns ----
+    // ---- pass B: lane = 4 queries x 4 columns; Stein modes: the Gram x score product on the matrix cores ----
+    if (MODE != PAIR_PRIOR) {
+      // 16 tiles of 16 x 16 per chunk (D'[col][query], transposed as in stein.hpp): wave w owns NQW query tiles x NCT column
+      // tiles; v_mfma_f32_16x16x4_f32 runs beside the VALU repulsion loop below
+#pragma unroll
+      for (int k4 = 0; k4 < JC / 4; ++k4) {
+        float bq[NQW], as[NCT];
+#pragma unroll
+        for (int u = 0; u < NQW; ++u) bq[u] = kv[((wave * NQW + u) * 16 + (jA & 15)) * KS + 4 * k4 + (jA >> 4)];
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) as[t] = Vs[(4 * k4 + (jA >> 4)) * YS + 16 * t + (jA & 15)];
+#pragma unroll
+        for (int u = 0; u < NQW; ++u)
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) accM[u * NCT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[t], bq[u], accM[u * NCT + t], 0, 0, 0);
+      }
+    }
 #pragma unroll 4
     for (int jj = 0; jj < JC; ++jj) {
       const v4f yv = *reinterpret_cast<const v4f *>(&Ys[jj * YS + c0]);
-      v4f sv = {0.f, 0.f, 0.f, 0.f};
-      if (MODE != PAIR_PRIOR) sv = *reinterpret_cast<const v4f *>(&Vs[jj * YS + c0]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float k = kv[(4 * qg + r) * KS + jj];
@@ -165,7 +182,6 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
           accL[r] += k;
         } else {
           const float kp = (MODE == PAIR_K1) ? -k : -(k * k) * k;
-          accA[r] = __builtin_elementwise_fma(v4f{k, k, k, k}, sv, accA[r]);
           accB[r] = __builtin_elementwise_fma(v4f{kp, kp, kp, kp}, xB[r] - yv, accB[r]);
         }
       }
@@ -179,12 +195,23 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
     if (il >= a.n_local) continue;
     if (c0 < b.ldp) {
       const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
-      *reinterpret_cast<v4f *>(a.pA + row + c0) = accA[r];
-      if (MODE != PAIR_PRIOR) *reinterpret_cast<v4f *>(a.pB + row + c0) = accB[r];
+      if (MODE == PAIR_PRIOR) *reinterpret_cast<v4f *>(a.pA + row + c0) = accA[r];
+      else *reinterpret_cast<v4f *>(a.pB + row + c0) = accB[r];
     }
     if (MODE == PAIR_PRIOR && cg == 0) {
       a.pM[(size_t)js * a.n_local + il] = mrow[4 * qg + r];
       a.pL[(size_t)js * a.n_local + il] = accL[r];
+    }
+  }
+  if (MODE != PAIR_PRIOR) {  // Gram x score rows from the MFMA accumulators: query = l % 16 of the tile, columns 16 t + 4 (l / 16) ..
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) {
+      const int il = tile * TQ + (wave * NQW + u) * 16 + (jA & 15);
+      if (il >= a.n_local) continue;
+      const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+        if (16 * t + 4 * (jA >> 4) < b.ldp) *reinterpret_cast<v4f *>(a.pA + row + 16 * t + 4 * (jA >> 4)) = accM[u * NCT + t];
     }
   }
 }
