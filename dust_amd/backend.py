@@ -197,7 +197,7 @@ class Context:
         pr = self._params(params)
         costs = np.empty((self.S, self.N), np.float32)
         states = np.empty((self.M, self.S, self.N, self.H + 1, self.ds), np.float32) if want_states else None
-        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if (want_actions or actions is None) else None
+        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if want_actions else None
         omega = np.empty((self.S, self.N), np.float32) if want_omega else None
         flags = L.EPS_AROUND_A_MAT if around_a_mat else 0
         L.check(L.load().dust_disco_forward(self._h, _p(st), _vp(act), _p(pr), flags, _p(costs), _p(states), _p(aout), _p(omega)))

@@ -47,6 +47,10 @@ class MultiDISCO:
         self._a_mix = torch.ones(n_policies)
         self._params_log_space = params_log_space
         self._tf = None
+        # forward() returns (costs, states, actions, omega, params_log_p) like the reference; states [M,S,N,H+1,ds] and
+        # actions are tens of MB per call at demo sizes.  Callers that ignore them (the closed-loop drivers) set this False:
+        # the rollout kernel then neither stores nor copies them (states / actions come back as None).
+        self.return_rollouts = True
         if params_sampling is False or params_sampling is None or params_sampling == "none":
             self.n_params, self._sampling = 1, False
         elif params_sampling is True:
@@ -187,8 +191,11 @@ class MultiDISCO:
         state = torch.as_tensor(state, dtype=torch.float).reshape(-1)
         params, params_log_p = self._sample_params(params_dist)
         acts = None if ext_actions is None else torch.as_tensor(ext_actions, dtype=torch.float).numpy()
+        want = bool(self.return_rollouts)
         costs, states, actions, omega = ctx.disco_forward(state.numpy(), acts, None if params is None else params[0],
-                                                          want_states=True, want_actions=True)
+                                                          want_states=want, want_actions=want)
+        if not want:
+            return torch.from_numpy(costs), None, None, torch.from_numpy(omega), params_log_p
         actions = torch.from_numpy(actions).unsqueeze(0).expand(self.n_params, -1, -1, -1, -1)
         return torch.from_numpy(costs), torch.from_numpy(states), actions, torch.from_numpy(omega), params_log_p
 

@@ -41,6 +41,7 @@ def run_pendulum_simulation(init_state, init_policies, model_kwargs, dyn_dist, e
         # the controller of this episode: same starting plan as SVMPC's particles, separate storage (simulations.py:60-63)
         sim_ctrl = deepcopy(controller)
         sim_ctrl.a_mat = init_policies.detach().clone()
+        sim_ctrl.return_rollouts = False  # nothing below reads the sampled states / actions (no rendering)
         sim_svmpc = None
         if use_svmpc:
             if svmpc_kwargs is None or lik_kwargs is None:
@@ -107,6 +108,7 @@ def run_particle_episode(init_state, model, dyn_dist, controller, use_svmpc=True
     if render:
         raise NotImplementedError("render: plotting is out of scope for the MI355X build")
     system = deepcopy(model)
+    controller.return_rollouts = False  # the sampled states only feed the (unsupported) renderer
     state = torch.as_tensor(init_state, dtype=torch.float).clone()
     cum_cost = 0
     for step in range(steps):

@@ -172,7 +172,7 @@ def test_disco_mppi(golden):
     # internally drawn noise (Philox): statistically, not bitwise, comparable - actions centred on a_mat with std sigma_a
     c2 = Context(model="pendulum", N=N, S=4096, M=1, H=H, temperature=temp, sigma_a=1.5, alpha=1.0 / temp, seed=7)
     c2.set_a_mat(g["a_mat0"])
-    _, _, act, _ = c2.disco_forward(g["state"], None)
+    _, _, act, _ = c2.disco_forward(g["state"], None, want_actions=True)
     z = (act - g["a_mat0"][None]) / 1.5
     assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
 
