@@ -309,6 +309,16 @@ __device__ __forceinline__ float quad_max(float v) {
   v = pair_max(v);
   return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
 }
+// sum over each aligned group of 8 consecutive lanes
+__device__ __forceinline__ float oct_sum(float v) {
+  auto dpp = [&](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});
+  v += dpp(v, std::integral_constant<int, 0x4E>{});
+  v += dpp(v, std::integral_constant<int, 0x141>{});
+  return v;
+}
 // max over each aligned group of 8 consecutive lanes (all 8 lanes get it)
 __device__ __forceinline__ float oct_max(float v) {
   auto dpp = [&](float x, auto ctrl) {

@@ -999,11 +999,12 @@ static int prior_args(dust_ctx *c, PairArgs &a, int *tiles) {
   return DUST_OK;
 }
 
-static int launch_prior(dust_ctx *c) {
+static int launch_prior(dust_ctx *c, bool logp_only = false) {
   PairArgs a;
   int tiles;
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
+  if (logp_only && !pair_is_big(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
   return launch_pair<PAIR_PRIOR>(c, a, tiles);
 }
 
@@ -1355,7 +1356,7 @@ extern "C" int dust_svmpc_step(dust_ctx *c, const float *state, const float *eps
 
 static int forward_device(dust_ctx *c) {
   if (!c->have_sample) return fail(DUST_ERR_STATE, "forward(fast_pred=True) needs the costs of a previous optimize step");
-  TRY(launch_prior(c));
+  TRY(launch_prior(c, /*logp_only=*/true));
   if (c->nloc == c->N) return DUST_OK;  // unsharded: finalize_kernel combines the partials itself
   TRY(launch_prior_finish(c, false, true));
   Prof p(c, DUST_K_FORWARD);

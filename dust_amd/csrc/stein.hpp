@@ -22,7 +22,7 @@
 
 namespace dust {
 
-enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2 };
+enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2, PAIR_LOGP = 3 };  // LOGP: the prior pass of SVMPC.forward - log p only, no gradient
 enum { PAIR_TI = 32, PAIR_JC = 64, PAIR_NT = 256 };
 
 struct PairArgs {
@@ -91,6 +91,8 @@ __device__ __forceinline__ void rowlane_commit(const float (&v)[RowLane<TR, DP, 
 template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
 __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, const int tile_x, const int js, const bool write_through = false) {
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
+  constexpr bool PRI = MODE == PAIR_PRIOR || MODE == PAIR_LOGP;  // softmax-weighted passes over the prior mixture
+  constexpr bool LOGP = MODE == PAIR_LOGP;                        // ... of which forward needs only the log-density
   constexpr int DP = 8 * CPT;  // padded row length in LDS (multiple of 4 -> b128 reads)
   constexpr int YS = DP + 4;
   constexpr int QG = NT / JC;      // query groups in pass A (4)
@@ -98,7 +100,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   float *Xs = lds;                  // [TI][DP]   queries, pre-scaled by 1/s_d
   float *Ys = Xs + TI * DP;         // [JC][YS]   keys, pre-scaled by 1/s_d
   float *Vs = Ys + JC * YS;         // [JC][YS]   score (Stein), unscaled
-  float *kv = Vs + (MODE == PAIR_PRIOR ? 0 : JC * YS);  // [TI][JC + 1]
+  float *kv = Vs + (PRI ? 0 : JC * YS);  // [TI][JC + 1]
   float *mrow = kv + TI * (JC + 1); // [TI] running max
   const int tid = threadIdx.x;
   const int D = a.D, da = a.da, N = a.N;
@@ -112,11 +114,11 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     float vx[RowLane<TI, DP, NT>::NB], vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
     rowlane_issue<TI, DP, NT>(a.X, ib, nq, D, vx);
     rowlane_issue<JC, DP, NT>(a.Y, jbeg, jc0, D, vy);
-    if (MODE != PAIR_PRIOR) rowlane_issue<JC, DP, NT>(a.V, jbeg, jc0, D, vv);
+    if (!PRI) rowlane_issue<JC, DP, NT>(a.V, jbeg, jc0, D, vv);
     if (tid < TI) mrow[tid] = -INFINITY;
     rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs);
     rowlane_commit<JC, DP, YS, NT, true>(vy, jc0, D, da, a.inv_s, Ys);
-    if (MODE != PAIR_PRIOR) rowlane_commit<JC, DP, YS, NT, false>(vv, jc0, D, da, a.inv_s, Vs);
+    if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc0, D, da, a.inv_s, Vs);
   }
 
   // pass-B ownership: query iB, columns [cB, cB + CPT)
@@ -129,7 +131,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   // cores - v_mfma_f32_16x16x4_f32, fp32 in and out - computed transposed (D'[col][query]) so that a lane ends up with 4
   // CONSECUTIVE columns of one query, i.e. one 16-byte store of the partial row.  Wave w owns query half w >> 1 and
   // TPW = DP / 32 column tiles.  The repulsive term keeps exact differences on the VALU and overlaps with the MFMAs.
-  constexpr bool MFMA_A = MODE != PAIR_PRIOR && CPT <= 8;
+  constexpr bool MFMA_A = !PRI && CPT <= 8;
   constexpr int TPW = MFMA_A ? DP / 32 : 1;
   v4f accM[TPW];
 #pragma unroll
@@ -145,13 +147,13 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     DUST_STAMP(a.stamps, 1);
     // ---- key chunk -> LDS: rows j0..j0+jc-1 are contiguous in HBM ----
     const int jA = tid & (JC - 1), igA = tid / JC;
-    const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
+    const float lm = (PRI) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
     if (j0 != jbeg) {  // later chunks of a long slice (the first one was staged with the query tile)
       float vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
       rowlane_issue<JC, DP, NT>(a.Y, j0, jc, D, vy);
-      if (MODE != PAIR_PRIOR) rowlane_issue<JC, DP, NT>(a.V, j0, jc, D, vv);
+      if (!PRI) rowlane_issue<JC, DP, NT>(a.V, j0, jc, D, vv);
       rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys);  // the barrier that ended the previous chunk's pass B
-      if (MODE != PAIR_PRIOR) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);  // protects these writes
+      if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);  // protects these writes
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 2);
@@ -178,14 +180,14 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       for (int ii = 0; ii < QPG; ++ii) {
         const float dd = d2[ii].x + d2[ii].y;
         float v;
-        if (MODE == PAIR_PRIOR) v = (jA < jc) ? lm - 0.5f * dd : -INFINITY;
+        if (PRI) v = (jA < jc) ? lm - 0.5f * dd : -INFINITY;
         else if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;  // exp(-dd/2) = 2^(-dd/(2 ln 2)); bare v_exp_f32, rel. error ~|x| 2^-24
         else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + dd) : 0.f;  // IMQ: k = (1 + d^2/l^2)^(-1/2) once per pair (bare v_rsq_f32, 1 ulp); k' = -k^3 in pass B
         kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
       }
     }
     __syncthreads();
-    if (MODE == PAIR_PRIOR) {
+    if (PRI) {
       // online softmax over key chunks: row max (8 lanes per query), rescale, exponentiate in place
       float m = -INFINITY;
 #pragma unroll
@@ -202,12 +204,16 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       // no barrier here: mrow[iB] and the kv entries below are touched only by the 8 lanes of query iB, which run in
       // lockstep (every lane has read mrow[iB] before lane 0 of the group overwrites it)
       if ((tid & 7) == 0) mrow[iB] = mn;
+      float rs = 0.f;
 #pragma unroll
       for (int q = 0; q < JC / 8; ++q) {
         const int jj = (tid & 7) + 8 * q;
         const float l = kv[iB * (JC + 1) + jj];
-        kv[iB * (JC + 1) + jj] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((l - mn) * 1.44269504088896340736f);
+        const float e = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((l - mn) * 1.44269504088896340736f);
+        kv[iB * (JC + 1) + jj] = e;
+        if (LOGP) rs += e;
       }
+      if (LOGP) accL += oct_sum(rs);  // mass of this chunk (pass B, which would add it up, is skipped)
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 3);
@@ -225,7 +231,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       }
     }
 #pragma unroll 4
-    for (int jj = 0; jj < JC; ++jj) {
+    for (int jj = 0; jj < (LOGP ? 0 : JC); ++jj) {
       const float kq = kv[iB * (JC + 1) + jj];
       float k = kq, kp = 0.f;
       if (MODE == PAIR_K1) kp = -kq;  // d k / d x_i = -k (x_i - x_j) / ell^2
@@ -235,7 +241,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       for (int c = 0; c < CPT; c += 4) {
         const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jj * YS + cB + c]);
         const v2f y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
-        if (MODE == PAIR_PRIOR) {
+        if (PRI) {
           accA[c / 2] = __builtin_elementwise_fma(kk, y01 - xB[c / 2], accA[c / 2]);
           accA[c / 2 + 1] = __builtin_elementwise_fma(kk, y23 - xB[c / 2 + 1], accA[c / 2 + 1]);
         } else {
@@ -248,7 +254,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
           accB[c / 2 + 1] = __builtin_elementwise_fma(kpp, xB[c / 2 + 1] - y23, accB[c / 2 + 1]);
         }
       }
-      if (MODE == PAIR_PRIOR) accL += k;
+      if (PRI) accL += k;
     }
     __syncthreads();
   }
@@ -270,15 +276,15 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         const float un = 1.0f / a.inv_s[da == 1 ? 0 : (da == 2 ? (col & 1) : col % da)];
         const float va = ((c + k) & 1) ? accA[(c + k) / 2].y : accA[(c + k) / 2].x;
         const float vb = ((c + k) & 1) ? accB[(c + k) / 2].y : accB[(c + k) / 2].x;
-        oa[k] = (MODE == PAIR_PRIOR) ? va * un : va;
+        oa[k] = (PRI) ? va * un : va;
         ob[k] = vb * un;
       }
       // write_through: sc1 stores so an in-launch consumer on another CU can read them with sc1 loads after the arrival
       // counter, with no release / acquire fence (Guideline 16, R1 form)
-      if (!MFMA_A) store16(a.pA + row + cB + c, oa, write_through);
-      if (MODE != PAIR_PRIOR) store16(a.pB + row + cB + c, ob, write_through);
+      if (!MFMA_A && !LOGP) store16(a.pA + row + cB + c, oa, write_through);
+      if (!PRI) store16(a.pB + row + cB + c, ob, write_through);
     }
-    if (MODE == PAIR_PRIOR && (tid & 7) == 0) {
+    if (PRI && (tid & 7) == 0) {
       if (write_through) {
         __hip_atomic_store(a.pM + (size_t)js * a.n_local + il, mrow[iB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.pL + (size_t)js * a.n_local + il, accL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(c
 
 static inline size_t pairwise_lds_bytes(int mode, int CPT) {
   const int DP = 8 * CPT;
-  return sizeof(float) * ((size_t)PAIR_TI * DP + (size_t)(mode == PAIR_PRIOR ? 1 : 2) * PAIR_JC * (DP + 4) + (size_t)PAIR_TI * (PAIR_JC + 1) + PAIR_TI);
+  return sizeof(float) * ((size_t)PAIR_TI * DP + (size_t)((mode == PAIR_PRIOR || mode == PAIR_LOGP) ? 1 : 2) * PAIR_JC * (DP + 4) + (size_t)PAIR_TI * (PAIR_JC + 1) + PAIR_TI);
 }
 
 // Combine the JS slice partials of the prior pass for one row (fixed order -> reproducible): returns grad_pri[d] for the
