@@ -63,11 +63,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
   _Pragma("unroll") for (int r = 0; r < R; ++r) { const int i = tid + r * nt; if (i >= a.N) continue;
     float lw;
     if (a.merge_logp) {  // prior.log_prob(theta) from the slice partials (svmpc.py:137), then log_w = log_l + log_p (:138)
+      const float ll = a.logl[i];  // in flight together with the partials
       float pmx, pl;
       prior_merge_row(a.pm, i, &pmx, &pl);
       const float lp = (pmx + logf(pl)) + a.pm.log_norm;
       a.logp_out[i] = lp;
-      lw = a.logl[i] + lp;
+      lw = ll + lp;
       a.lw[i] = lw;
     } else {
       lw = a.lw[i];
@@ -125,10 +126,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
   // new prior mixture: Categorical(probs = w / sum w) -> logits = log(clamp(probs, eps, 1 - eps)) -> log_softmax
   if (!a.weighted_prior) {  // uniform: every logit is log(1/N) and the log_softmax of a constant vector is -log N exactly
     const float l = logf(fminf(fmaxf(1.0f / (float)a.N, 1.1920929e-07f), 1.0f - 1.1920929e-07f));
-    float zs = 0.f;
-    for (int i = tid; i < a.N; i += nt) zs += 1.0f;  // exp(l - l)
-    zs = block_reduce<RED_SUM>(zs, red);
-    const float lzz = l + logf(zs);
+    const float lzz = l + logf((float)a.N);  // sum_i exp(l - l) = N exactly (N <= 16384): no reduction needed
     for (int i = tid; i < a.N; i += nt) {
       a.mixw[i] = 1.0f;
       a.logmix[i] = l - lzz;
