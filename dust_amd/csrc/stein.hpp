@@ -338,13 +338,17 @@ __device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, fl
     }
     float mc = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) mc = fmaxf(mc, (q0 + u < pm.JS) ? mq[u] : -INFINITY);
+    for (int u = 0; u < 16; ++u) {
+      mq[u] = (q0 + u < pm.JS) ? mq[u] : -INFINITY;  // clamped duplicates carry no mass
+      mc = fmaxf(mc, mq[u]);
+    }
     const float mn = fmaxf(m, mc);
     float lc = 0.f;
+    if (mn != -INFINITY) {  // branch-free inside: exp2(-inf) = 0 drops empty slices (bare v_exp_f32, as in the passes themselves)
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (q0 + u < pm.JS && mq[u] != -INFINITY) lc += lq[u] * expf(mq[u] - mn);
-    l = ((m == -INFINITY) ? 0.f : l * expf(m - mn)) + lc;
+      for (int u = 0; u < 16; ++u) lc = fmaf(lq[u], __builtin_amdgcn_exp2f((mq[u] - mn) * 1.44269504088896340736f), lc);
+      l = l * __builtin_amdgcn_exp2f((m - mn) * 1.44269504088896340736f) + lc;
+    }
     m = mn;
   }
   *m_out = m;
