@@ -77,6 +77,8 @@ struct dust_ctx {
   float *adam_m, *adam_v;
   float *pA, *pB, *pM, *pL;  // slice partials of the tiled pairwise passes
   size_t pA_cap, pB_cap, pM_cap, pL_cap;
+  float *pS;                 // Gram x score partials of the one-launch iteration (pA still holds the prior's while its Stein tiles run)
+  size_t pS_cap;
   float *mw_dev;             // [M] unscented-transform weights of the dynamics samples (nullptr: mean)
   float *xpad;               // [N][DPB] zero-padded query rows of the large-N pairwise kernel
   size_t xpad_cap;
@@ -96,6 +98,9 @@ struct dust_ctx {
   unsigned int *stein_cnt;  // [tiles + 1]: arrival counters of the Stein+update launch (re-armed by the next rollout launch)
   int stein_tiles;
   bool stein_dirty;
+  // one-launch SVGD iteration (fused.hpp svgd_iter_kernel): two sets of [tiles | JS | tiles] counter lines, then the time-out flag
+  unsigned int *iter_cnt;
+  int iter_tiles, iter_js, iter_set;
   float *state_pin;   // pinned host ring [RING][4] feeding state_dev by async copies (no host sync per tick)
   hipEvent_t ring_ev[16];
   int ring_pos;
@@ -252,7 +257,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
                   &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->xpad, &c->mw_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -260,6 +265,7 @@ static void free_all(dust_ctx *c) {
   if (c->ctr_dev) (void)hipFree(c->ctr_dev);
   if (c->fused_cnt) (void)hipFree(c->fused_cnt);
   if (c->stein_cnt) (void)hipFree(c->stein_cnt);
+  if (c->iter_cnt) (void)hipFree(c->iter_cnt);
   if (c->state_pin) (void)hipHostFree(c->state_pin);
   for (auto &e : c->ring_ev)
     if (e) (void)hipEventDestroy(e);
@@ -383,6 +389,11 @@ extern "C" int dust_sync(dust_ctx *c) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(DUST_ERR_HIP, "Stein+update launch: hand-off spin timed out (results of that tick are invalid)");
+  }
+  if (c->iter_cnt) {
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(DUST_ERR_HIP, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid)");
   }
   return DUST_OK;
 }
@@ -1325,7 +1336,119 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
   return DUST_OK;
 }
 
+// One launch per SVGD iteration (fused.hpp svgd_iter_kernel) when every role is eligible; otherwise *done stays false and
+// the caller runs the two-launch form.
+static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool *done) {
+  *done = false;
+  static const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_ITER") != nullptr;  // development switches
+  if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
+  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
+  const int cpt = cpt_for(c->D);
+  if (cpt > 8) return DUST_OK;
+  IterArgs f;
+  memset(&f, 0, sizeof f);
+  TRY(prior_args(c, f.prior, &f.tiles));
+  if (f.prior.JS > 16 || f.prior.slice > PAIR_JC) return DUST_OK;  // single-chunk key slices (stein_split_body)
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = noise_dev ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = noise_dev;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  o.bump_adam = 1;
+  o.merge_prior = 1;
+  int nt;
+  size_t lds_r;
+  float *sv = c->params_dev;
+  if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
+  int sr = rollout_args(c, o, f.ra, &nt, &lds_r);
+  c->params_dev = sv;
+  TRY(sr);
+  if (f.ra.tile_scratch || (PAIR_NT % nt) != 0 || f.ra.G > 1) return DUST_OK;
+  if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // LEAN rollout body only
+  f.ra.rearm = nullptr;
+  f.ra.rearm_n = 0;
+  f.sub_nt = nt;
+  f.per_block = PAIR_NT / nt;
+  if (c->nloc % f.per_block || PAIR_JC % f.per_block) return DUST_OK;
+  const size_t lds_p = pairwise_lds_bytes(PAIR_K1, cpt);  // >= the prior tile's
+  f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
+  const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
+  if (lds > 72 * 1024) return DUST_OK;
+  const int JS = f.prior.JS, lines = 2 * f.tiles + JS;
+  {
+    const size_t nd = (size_t)JS * c->nloc * 8 * cpt;
+    if (c->pS_cap < nd && c->capturing) return DUST_OK;
+    TRY(ensure(&c->pS, &c->pS_cap, nd));
+  }
+  if (!c->iter_cnt || c->iter_tiles != f.tiles || c->iter_js != JS) {
+    if (c->capturing) return DUST_OK;
+    if (c->iter_cnt) HIP_TRY(hipFree(c->iter_cnt));
+    c->iter_cnt = nullptr;
+    TRY(dalloc(&c->iter_cnt, ((size_t)2 * lines + 1) * CNT_STRIDE));
+    HIP_TRY(hipMemsetAsync(c->iter_cnt, 0, ((size_t)2 * lines + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+    c->iter_tiles = f.tiles;
+    c->iter_js = JS;
+    c->iter_set = 0;
+  }
+  // Stein role: same geometry as the prior pass (pair_geometry), keys = queries = theta, values = the score rows
+  f.stein = f.prior;
+  f.stein.Y = c->theta;
+  f.stein.V = c->score;
+  f.stein.logmix = nullptr;
+  {
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    for (int d = 0; d < 4; ++d) f.stein.inv_s[d] = 1.0f / ell;
+  }
+  f.stein.pA = c->pS;  // own buffer: pA holds the prior partials, which the rollout role may still be reading
+  f.stein.pB = c->pB;
+  f.stein.pM = nullptr;
+  f.stein.pL = nullptr;
+  f.stein.stamps = nullptr;
+  f.ua = update_args(c, 1);
+  f.ua.pA = c->pS;
+  f.ua.theta_out = c->theta_alt;
+  f.ua.fused_cnt = nullptr;
+  f.ua.fused_tiles = 0;
+  f.n_pair_blocks = f.tiles * JS;
+  f.n_roll_blocks = c->nloc / f.per_block;
+  unsigned int *set = c->iter_cnt + (size_t)c->iter_set * lines * CNT_STRIDE;
+  f.cnt_prior = set;
+  f.cnt_score = set + (size_t)f.tiles * CNT_STRIDE;
+  f.cnt_stein = set + (size_t)(f.tiles + JS) * CNT_STRIDE;
+  f.zero_base = c->iter_cnt + (size_t)(1 - c->iter_set) * lines * CNT_STRIDE;
+  f.zero_lines = lines;
+  f.timeout_flag = c->iter_cnt + (size_t)2 * lines * CNT_STRIDE;
+  const int n = c->nloc * c->D;
+  const int grid = 2 * f.n_pair_blocks + f.n_roll_blocks + (n + PAIR_NT - 1) / PAIR_NT;
+#define DUST_LAUNCH_ITER(MODEL, MODE, CPT) svgd_iter_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
+#define DUST_PICK_ITER(MODEL)                                       \
+  do {                                                              \
+    if (c->cfg.kernel == DUST_KERNEL_IMQ) {                         \
+      if (cpt == 4) DUST_LAUNCH_ITER(MODEL, PAIR_IMQ, 4);           \
+      else DUST_LAUNCH_ITER(MODEL, PAIR_IMQ, 8);                    \
+    } else {                                                        \
+      if (cpt == 4) DUST_LAUNCH_ITER(MODEL, PAIR_K1, 4);            \
+      else DUST_LAUNCH_ITER(MODEL, PAIR_K1, 8);                     \
+    }                                                               \
+  } while (0)
+  if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_ITER(DUST_MODEL_PENDULUM);
+  else DUST_PICK_ITER(DUST_MODEL_PARTICLE);
+#undef DUST_PICK_ITER
+#undef DUST_LAUNCH_ITER
+  HIP_TRY(hipGetLastError());
+  c->iter_set ^= 1;
+  std::swap(c->theta, c->theta_alt);
+  c->actions_valid = false;
+  c->have_sample = true;
+  *done = true;
+  return DUST_OK;
+}
+
 static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
+  bool done = false;
+  TRY(launch_iter(c, noise_dev, param_set, &done));
+  if (done) return DUST_OK;
   TRY(local_score_device(c, noise_dev, param_set));
   TRY(launch_stein_update(c, 1));
   return DUST_OK;
@@ -1397,6 +1520,10 @@ static int forward_finish_device(dust_ctx *c) {
   r.i0 = c->n0;
   r.n_local = c->nloc;
   r.ctr = c->ctr_dev;
+  if (c->iter_cnt) {
+    r.rearm = c->iter_cnt;
+    r.rearm_lines = 2 * (2 * c->iter_tiles + c->iter_js);
+  }
   if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && c->D <= 128 && !c->prof) {
     // out-of-place roll: independent of finalize (which gathers a_seq from the buffer the roll only reads) -> one launch
     finalize_roll_kernel<<<1 + (c->nloc + 7) / 8, 1024, 0, c->stream>>>(f, r);

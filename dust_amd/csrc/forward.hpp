@@ -184,6 +184,8 @@ struct RollArgs {
   float *theta_dst;    // where the rolled particles go (the home buffer of the ping-pong; may equal theta)
   int N, H, da, strategy, i0, n_local;
   uint32_t *ctr;
+  unsigned int *rearm;  // hand-off counters of the one-launch SVGD iteration (both sets; one 128-byte line each) or nullptr:
+  int rearm_lines;      // zeroed here, so that a tick - and a replayed graph - starts with both sets clean
 };
 
 __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
     a.ctr[0] += 1u;
     a.ctr[1] = 0u;
   }
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < a.rearm_lines; t += blockDim.x) a.rearm[t * 32] = 0u;
   const int i = a.i0 + blockIdx.x;
   const int D = a.H * a.da, j = threadIdx.x, da = a.da;
   const float *th = a.theta + (size_t)i * D;
@@ -220,6 +224,8 @@ __global__ __launch_bounds__(1024) void finalize_roll_kernel(const FinalizeArgs 
     }
     return;
   }
+  if (blockIdx.x == 1)
+    for (int t = threadIdx.x; t < a.rearm_lines; t += 1024) a.rearm[t * 32] = 0u;
   const int il = ((int)blockIdx.x - 1) * 8 + ((int)threadIdx.x >> 7), j = threadIdx.x & 127;
   if (il >= a.n_local) return;
   const int i = a.i0 + il, D = a.H * a.da;

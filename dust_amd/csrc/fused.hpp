@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
     const int nb = (int)gridDim.x - f.n_pair_blocks;
     const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
-    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag};
+    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0};
     rollout_body<MODEL, 12, GROUPS, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
   }
 }
@@ -94,6 +94,77 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kern
       const unsigned int target = f.wait_all ? (unsigned int)f.tiles : (unsigned int)f.pa.JS;
       for (int t = t0; t <= t1; ++t)
         while (__hip_atomic_load(f.cnt + t * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) {
+            *f.timeout_flag = 1u;
+            break;
+          }
+        }
+    }
+    __syncthreads();
+    update_body<true>(f.ua, idx);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launch per SVGD iteration (K1 / IMQ, D <= 64, N < 2048, single-chunk key slices, ping-ponged theta).  Roles by
+// workgroup index, producers before consumers:
+//   [0, P)            prior tiles              -> prior partials   (cnt_prior[tile], JS arrivals)
+//   [P, P + R)        rollouts                 -> score rows       (cnt_score[key slice], `slice` arrivals)
+//   [P + R, 2P + R)   Stein tiles              -> Stein partials   (cnt_stein[tile], JS arrivals)
+//   [2P + R, ...)     optimiser update (256 elements each), writes the OTHER theta buffer
+// Every input of the launch that is written inside it travels write-through (sc1 stores, sc1 loads, one arrival counter per
+// 128-byte line; cdna_hip_programming.md Guideline 16).  What this buys over the two-launch form: the Stein tiles' theta-only
+// work (Gram values, repulsive term) runs underneath the rollouts, and one launch boundary per iteration disappears.
+// A workgroup only ever waits on LOWER-indexed workgroups; the hardware dispatches workgroups in index order per XCD, so the
+// lowest-indexed unfinished workgroup is always resident and never blocked (the grid need not be co-resident); every spin
+// is bounded.  Counters: two sets - the launch uses one and zeroes the other (which the previous launch used).
+struct IterArgs {
+  PairArgs prior, stein;
+  RolloutArgs ra;
+  UpdateArgs ua;
+  int tiles, n_pair_blocks, n_roll_blocks;
+  int sub_nt, per_block, lds_roll_floats;
+  unsigned int *cnt_prior, *cnt_score, *cnt_stein;  // this launch's set
+  unsigned int *zero_base;                          // the other set ...
+  int zero_lines;                                   // ... of this many 128-byte lines
+  unsigned int *timeout_flag;
+};
+
+template <int MODEL, int MODE, int CPT>
+__global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(const IterArgs f) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b0 = (int)blockIdx.x;
+  if (b0 < f.n_pair_blocks) {
+    if (b0 == 0)
+      for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
+    const int tile_x = b0 % f.tiles, js = b0 / f.tiles;
+    pairwise_body<PAIR_PRIOR, CPT>(f.prior, lds, tile_x, js, /*write_through=*/true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_prior + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (b0 < f.n_pair_blocks + f.n_roll_blocks) {
+    const int br = b0 - f.n_pair_blocks;
+    const int b = ((f.n_pair_blocks | f.n_roll_blocks) & 7) ? br : xcd_contiguous(br, f.n_roll_blocks);
+    const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
+    const FusedWait fw{f.cnt_prior, (unsigned int)f.prior.JS, f.timeout_flag, f.cnt_score, f.stein.slice, f.per_block};
+    rollout_body<MODEL, 12, false, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+  } else if (b0 < 2 * f.n_pair_blocks + f.n_roll_blocks) {
+    const int bs = b0 - f.n_pair_blocks - f.n_roll_blocks;
+    const int tile_x = bs % f.tiles, js = bs / f.tiles;
+    stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.timeout_flag);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_stein + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const int b = b0 - 2 * f.n_pair_blocks - f.n_roll_blocks;
+    const int idx = b * PAIR_NT + (int)threadIdx.x;
+    if (threadIdx.x == 0) {
+      unsigned int spins = 0;
+      const int total = f.ua.n_local * f.ua.D;
+      const int t0 = (min(b * PAIR_NT, total - 1) / f.ua.D) / PAIR_TI, t1 = (min(b * PAIR_NT + PAIR_NT - 1, total - 1) / f.ua.D) / PAIR_TI;
+      for (int t = t0; t <= t1; ++t)
+        while (__hip_atomic_load(f.cnt_stein + t * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)f.stein.JS) {
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1u << 24)) {
             *f.timeout_flag = 1u;

@@ -106,6 +106,11 @@ struct FusedWait {
   const unsigned int *cnt;  // [tiles][CNT_STRIDE]
   unsigned int target;
   unsigned int *timeout_flag;
+  // one-launch SVGD iteration (fused.hpp svgd_iter_kernel): the score rows are published to the Stein tiles of the SAME launch -
+  // written through (sc1), then one arrival per workgroup on the counter of the key slice its particles belong to
+  unsigned int *score_cnt;  // [JS][CNT_STRIDE] or nullptr
+  int score_slice;          // keys per slice (a multiple of the particles per workgroup)
+  int score_add;            // particles per workgroup
 };
 
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
@@ -538,13 +543,25 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         gp = prior_merge_col(a.pm, nl, D, tid, DA, m, l);
       }
       a.grad_pri[o] = gp;
-      a.score[o] = gs + gp;
+      if (fw && fw->score_cnt) __hip_atomic_store(a.score + o, gs + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.score[o] = gs + gp;
     }
   }
-  if (a.bump_adam && nl == 0 && tid == 0) a.ctr[2] += 1u;
+  if (a.bump_adam && nl == 0 && tid == 0) {
+    // (one-launch iteration: the update role of the same launch reads adam_step - device-scope RMW, read there with an sc1 load)
+    if (fw && fw->score_cnt) __hip_atomic_fetch_add(a.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.ctr[2] += 1u;
+  }
   if (a.rearm && nl == 0)
     for (int t = tid; t < a.rearm_n; t += nt) a.rearm[t * CNT_STRIDE] = 0u;
   DUST_STAMP(a.stamps, 5);
+  if (fw && fw->score_cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __syncthreads();                                    // ... before the one lane that signals for the workgroup
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(fw->score_cnt + (nl / fw->score_slice) * CNT_STRIDE, (unsigned int)fw->score_add, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // XCD-aware block -> work-item map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own

@@ -305,6 +305,143 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   DUST_STAMP(a.stamps, 5);
 }
 
+// Stein tile of the one-launch SVGD iteration (fused.hpp svgd_iter_kernel): the same arithmetic as pairwise_body<K1|IMQ> on a
+// single key chunk (slice <= PAIR_JC), split at the point where the score is first needed.  Everything that reads only
+// theta - the Gram values (pass A) and the repulsive term sum_j k'_ij (x_i - x_j) - runs BEFORE the wait on the score rows,
+// i.e. underneath the rollouts of the same launch; after the wait only the score tile load, the Gram x score MFMAs and the
+// 16-byte partial stores remain on the critical path.  Accumulation orders are those of pairwise_body (bitwise equal).
+template <int MODE, int CPT>
+__device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, const int tile_x, const int js, const unsigned int *score_cnt,
+                                                 unsigned int *timeout_flag) {
+  static_assert(MODE == PAIR_K1 || MODE == PAIR_IMQ, "Stein modes only");
+  static_assert(CPT <= 8, "the Gram x score product runs on the matrix cores (D <= 64)");
+  constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
+  constexpr int DP = 8 * CPT, YS = DP + 4, QG = NT / JC, QPG = TI / QG, TPW = DP / 32;
+  float *Xs = lds;                   // [TI][DP]  queries / ell
+  float *Ys = Xs + TI * DP;          // [JC][YS]  keys / ell
+  float *Vs = Ys + JC * YS;          // [JC][YS]  score rows
+  float *kv = Vs + JC * YS;          // [TI][JC + 1] Gram values
+  const int tid = threadIdx.x;
+  const int D = a.D, da = a.da, N = a.N;
+  const int ib = a.i0 + tile_x * TI;
+  const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
+  const int nq = min(TI, a.i0 + a.n_local - ib), jc = min(JC, jend - jbeg);
+  {
+    float vx[RowLane<TI, DP, NT>::NB], vy[RowLane<JC, DP, NT>::NB];
+    rowlane_issue<TI, DP, NT>(a.X, ib, nq, D, vx);
+    rowlane_issue<JC, DP, NT>(a.Y, jbeg, jc, D, vy);
+    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs);
+    rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys);
+  }
+  const int iB = tid >> 3, cB = (tid & 7) * CPT;
+  v2f accB[CPT / 2];
+#pragma unroll
+  for (int c = 0; c < CPT / 2; ++c) accB[c] = v2f{0.f, 0.f};
+  const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;
+  __syncthreads();
+  v2f xB[CPT / 2];
+#pragma unroll
+  for (int c = 0; c < CPT / 2; ++c) xB[c] = *reinterpret_cast<const v2f *>(&Xs[iB * DP + cB + 2 * c]);
+  {  // pass A: lane = key, QPG queries per lane (pairwise_body)
+    const int jA = tid & (JC - 1), igA = tid / JC;
+    v2f d2[QPG];
+#pragma unroll
+    for (int ii = 0; ii < QPG; ++ii) d2[ii] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DP; d += 4) {
+      const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jA * YS + d]);
+      const v2f y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
+#pragma unroll
+      for (int ii = 0; ii < QPG; ++ii) {
+        const float4 xv = *reinterpret_cast<const float4 *>(&Xs[(igA * QPG + ii) * DP + d]);
+        const v2f z01 = v2f{xv.x, xv.y} - y01, z23 = v2f{xv.z, xv.w} - y23;
+        d2[ii] = __builtin_elementwise_fma(z01, z01, d2[ii]);
+        d2[ii] = __builtin_elementwise_fma(z23, z23, d2[ii]);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < QPG; ++ii) {
+      const float dd = d2[ii].x + d2[ii].y;
+      float v;
+      if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;
+      else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + dd) : 0.f;
+      kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
+    }
+  }
+  __syncthreads();
+  // repulsive term: lane = (query, 8 column groups)
+#pragma unroll 4
+  for (int jj = 0; jj < JC; ++jj) {
+    const float kq = kv[iB * (JC + 1) + jj];
+    const float kp = MODE == PAIR_K1 ? -kq : -(kq * kq) * kq;
+    const v2f kpp = {kp, kp};
+#pragma unroll
+    for (int c = 0; c < CPT; c += 4) {
+      const float4 yv = *reinterpret_cast<const float4 *>(&Ys[jj * YS + cB + c]);
+      const v2f y01 = {yv.x, yv.y}, y23 = {yv.z, yv.w};
+      accB[c / 2] = __builtin_elementwise_fma(kpp, xB[c / 2] - y01, accB[c / 2]);
+      accB[c / 2 + 1] = __builtin_elementwise_fma(kpp, xB[c / 2 + 1] - y23, accB[c / 2 + 1]);
+    }
+  }
+  const int il = tile_x * TI + iB;
+  if (il < a.n_local) {
+    const size_t row = ((size_t)js * a.n_local + il) * DP;
+#pragma unroll
+    for (int c = 0; c < CPT; c += 4) {
+      v4f ob;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = cB + c + k;
+        const float un = 1.0f / a.inv_s[da == 1 ? 0 : (da == 2 ? (col & 1) : col % da)];
+        ob[k] = (((c + k) & 1) ? accB[(c + k) / 2].y : accB[(c + k) / 2].x) * un;
+      }
+      store16(a.pB + row + cB + c, ob, true);
+    }
+  }
+  // ---- the score rows of this key slice, published by the rollout role of this launch ----
+  if (tid == 0) {
+    const unsigned int target = (unsigned int)(jend - jbeg);
+    unsigned int spins = 0;
+    while (__hip_atomic_load(score_cnt + js * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // 32 = CNT_STRIDE (rollout.hpp)
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 24)) {
+        *timeout_flag = 1u;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  {  // row-lane staging with sc1 loads (the rows were written through by other CUs in this launch)
+    using RL = RowLane<JC, DP, NT>;
+    float vv[RL::NB];
+    const int lr = tid / RL::W, lc = min(tid % RL::W, D - 1);
+    const float *base = a.V + (size_t)jbeg * D + lc;
+#pragma unroll
+    for (int u = 0; u < RL::NB; ++u) vv[u] = __hip_atomic_load(base + (size_t)min(u * RL::RB + lr, jc - 1) * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);
+  }
+  __syncthreads();
+  v4f accM[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  {
+    const float *kb = kv + (mqh * 16 + (ml & 15)) * (JC + 1) + (ml >> 4);
+    const float *sb = Vs + (ml >> 4) * YS + mct0 * 16 + (ml & 15);
+#pragma unroll
+    for (int k4 = 0; k4 < JC / 4; ++k4) {
+      const float bq = kb[4 * k4];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) accM[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sb[4 * k4 * YS + 16 * t], bq, accM[t], 0, 0, 0);
+    }
+  }
+  const int ilm = tile_x * TI + mqh * 16 + (ml & 15);
+  if (ilm < a.n_local) {
+    const size_t rowm = ((size_t)js * a.n_local + ilm) * DP;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) store16(a.pA + rowm + (mct0 + t) * 16 + 4 * (ml >> 4), accM[t], true);
+  }
+}
+
 template <int MODE, int CPT>
 __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void pairwise_kernel(const PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -422,7 +559,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
   if (idx >= a.n_local * a.D) return;
   // counters: this kernel READS adam_step (bumped by the rollout kernel of the same iteration) and ADVANCES iter (read
   // only by rollout kernels) - no launch both reads and writes the same counter
-  const float adam_t = (float)a.ctr[2];
+  const float adam_t = SC1 ? (float)__hip_atomic_load(a.ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (float)a.ctr[2];
   if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;

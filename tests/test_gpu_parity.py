@@ -301,7 +301,8 @@ def test_sharded_equals_unsharded(golden, world, overlap):
 @pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 1024, 128, 1, 30), ("pendulum", 512, 64, 1, 12), ("particle", 256, 64, 4, 20),
                                            ("pendulum", 100, 40, 1, 7), ("pendulum", 33, 130, 3, 3), ("particle", 64, 96, 2, 9),
                                            ("pendulum", 96, 256, 1, 33), ("particle", 40, 30, 1, 31)])
-def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H):
+@pytest.mark.parametrize("kernel,optimizer", [("K1", "SGD"), ("IMQ", "Adam")])
+def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H, kernel, optimizer):
     """The fused launches (prior + rollout, Stein + update) hand partials over INSIDE a launch; the same bodies run as
     separate kernels when per-kernel profiling is on.  Both must give the same bits, tick after tick: a hand-off that
     lets a consumer run early (or a producer overwrite an input another workgroup still reads) shows up here."""
@@ -321,7 +322,8 @@ def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H):
         grid = grid_4x4_map()
     out = []
     for unfused in (False, True):
-        c = Context(model=model, N=N, S=S, M=M, H=H, kernel="K1", lr=0.5, sigma_a=1.0, sigma_p=1.0, uncertain_params=up, grid=grid, seed=11)
+        c = Context(model=model, N=N, S=S, M=M, H=H, kernel=kernel, lr=0.5 if optimizer == "SGD" else 0.05, optimizer=optimizer, sigma_a=1.0,
+                    sigma_p=1.0, uncertain_params=up, grid=grid, seed=11)
         c.set_theta(th)
         c.set_prior(mu)
         c.set_a_mat(th)
