@@ -21,9 +21,17 @@
   do {                                                                                               \
     if ((p) && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) (p)[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// launch timeline of the one-launch SVGD iteration: 4 words per workgroup, the 100 MHz wall clock at its role's boundaries
+#define DUST_TL(p, k)                                                                                                      \
+  do {                                                                                                                      \
+    if ((p) && threadIdx.x == 0) (p)[4 * blockIdx.x + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime();          \
+  } while (0)
 #else
 #define DUST_STAMP(p, k) \
   do {                   \
+  } while (0)
+#define DUST_TL(p, k) \
+  do {                \
   } while (0)
 #endif
 

@@ -113,6 +113,7 @@ struct dust_ctx {
   bool capturing;
   bool have_sample, actions_valid;
   unsigned long long *stamps_dev;  // diagnostic build only: [DUST_K_COUNT][16]
+  unsigned long long *tl_dev;      // diagnostic build only: [8192][4] launch timeline of svgd_iter_kernel
   // profiling
   bool prof;
   hipEvent_t ev0, ev1;
@@ -1419,6 +1420,7 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   f.zero_base = c->iter_cnt + (size_t)(1 - c->iter_set) * lines * CNT_STRIDE;
   f.zero_lines = lines;
   f.timeout_flag = c->iter_cnt + (size_t)2 * lines * CNT_STRIDE;
+  f.tl = c->tl_dev;
   const int n = c->nloc * c->D;
   const int grid = 2 * f.n_pair_blocks + f.n_roll_blocks + (n + PAIR_NT - 1) / PAIR_NT;
 #define DUST_LAUNCH_ITER(MODEL, MODE, CPT) svgd_iter_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
@@ -1851,9 +1853,15 @@ extern "C" int dust_debug_stamps(dust_ctx *c, int kernel_id, unsigned long long 
   if (!c->stamps_dev) {
     HIP_TRY(hipMalloc((void **)&c->stamps_dev, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->stamps_dev, 0, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&c->tl_dev, 8192 * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->tl_dev, 0, 8192 * 4 * sizeof(unsigned long long)));
     return DUST_OK;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (kernel_id < 0) {  // launch timeline of the one-launch iteration: out16 receives -kernel_id workgroups x 4 words
+    HIP_TRY(hipMemcpy(out16, c->tl_dev, (size_t)(-kernel_id) * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return DUST_OK;
+  }
   HIP_TRY(hipMemcpy(out16, c->stamps_dev + 16 * kernel_id, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return DUST_OK;
 }

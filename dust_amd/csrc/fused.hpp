@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
     const int nb = (int)gridDim.x - f.n_pair_blocks;
     const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
-    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0};
+    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0, nullptr};
     rollout_body<MODEL, 12, GROUPS, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
   }
 }
@@ -129,12 +129,14 @@ struct IterArgs {
   unsigned int *zero_base;                          // the other set ...
   int zero_lines;                                   // ... of this many 128-byte lines
   unsigned int *timeout_flag;
+  unsigned long long *tl;                           // diagnostic build only: [grid][4] launch timeline (common.hpp DUST_TL)
 };
 
 template <int MODEL, int MODE, int CPT>
 __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(const IterArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b0 = (int)blockIdx.x;
+  DUST_TL(f.tl, 0);
   if (b0 < f.n_pair_blocks) {
     if (b0 == 0)
       for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
@@ -143,19 +145,22 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_prior + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DUST_TL(f.tl, 3);
   } else if (b0 < f.n_pair_blocks + f.n_roll_blocks) {
     const int br = b0 - f.n_pair_blocks;
     const int b = ((f.n_pair_blocks | f.n_roll_blocks) & 7) ? br : xcd_contiguous(br, f.n_roll_blocks);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
-    const FusedWait fw{f.cnt_prior, (unsigned int)f.prior.JS, f.timeout_flag, f.cnt_score, f.stein.slice, f.per_block};
+    const FusedWait fw{f.cnt_prior, (unsigned int)f.prior.JS, f.timeout_flag, f.cnt_score, f.stein.slice, f.per_block, f.tl};
     rollout_body<MODEL, 12, false, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
+    DUST_TL(f.tl, 3);
   } else if (b0 < 2 * f.n_pair_blocks + f.n_roll_blocks) {
     const int bs = b0 - f.n_pair_blocks - f.n_roll_blocks;
     const int tile_x = bs % f.tiles, js = bs / f.tiles;
-    stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.timeout_flag);
+    stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.timeout_flag, f.tl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_stein + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DUST_TL(f.tl, 3);
   } else {
     const int b = b0 - 2 * f.n_pair_blocks - f.n_roll_blocks;
     const int idx = b * PAIR_NT + (int)threadIdx.x;
@@ -172,8 +177,10 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
           }
         }
     }
+    DUST_TL(f.tl, 1);
     __syncthreads();
     update_body<true>(f.ua, idx);
+    DUST_TL(f.tl, 3);
   }
 }
 

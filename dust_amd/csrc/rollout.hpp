@@ -111,6 +111,7 @@ struct FusedWait {
   unsigned int *score_cnt;  // [JS][CNT_STRIDE] or nullptr
   int score_slice;          // keys per slice (a multiple of the particles per workgroup)
   int score_add;            // particles per workgroup
+  unsigned long long *tl;   // diagnostic build only: launch timeline words
 };
 
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
@@ -351,6 +352,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
   }
 
+  DUST_TL(fw ? fw->tl : nullptr, 1);
   if (fw) {
     // fused launch: the prior-pass workgroups of this launch publish the partials of query tile nl/32 with an agent-scope
     // release + counter add; poll relaxed from ONE lane, acquire once, then the barrier admits the other lanes
@@ -555,6 +557,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   if (a.rearm && nl == 0)
     for (int t = tid; t < a.rearm_n; t += nt) a.rearm[t * CNT_STRIDE] = 0u;
   DUST_STAMP(a.stamps, 5);
+  DUST_TL(fw ? fw->tl : nullptr, 2);
   if (fw && fw->score_cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
     __syncthreads();                                    // ... before the one lane that signals for the workgroup

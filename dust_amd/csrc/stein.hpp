@@ -312,7 +312,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 // 16-byte partial stores remain on the critical path.  Accumulation orders are those of pairwise_body (bitwise equal).
 template <int MODE, int CPT>
 __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, const int tile_x, const int js, const unsigned int *score_cnt,
-                                                 unsigned int *timeout_flag) {
+                                                 unsigned int *timeout_flag, unsigned long long *tl) {
   static_assert(MODE == PAIR_K1 || MODE == PAIR_IMQ, "Stein modes only");
   static_assert(CPT <= 8, "the Gram x score product runs on the matrix cores (D <= 64)");
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
@@ -399,6 +399,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
     }
   }
   // ---- the score rows of this key slice, published by the rollout role of this launch ----
+  DUST_TL(tl, 1);
   if (tid == 0) {
     const unsigned int target = (unsigned int)(jend - jbeg);
     unsigned int spins = 0;
@@ -410,6 +411,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
       }
     }
   }
+  DUST_TL(tl, 2);
   __syncthreads();
   {  // row-lane staging with sc1 loads (the rows were written through by other CUs in this launch)
     using RL = RowLane<JC, DP, NT>;
