@@ -330,8 +330,10 @@ def test_fused_launches_equal_unfused_bitwise(model, N, S, M, H, kernel, optimiz
         c.profile(unfused)
         for _ in range(4):
             c.svmpc_tick(state, 3, params=params, want_outputs=False)
+        a_seq, pw = c.svmpc_tick(state, 3, params=params, want_outputs=True)
+        c.svmpc_tick(state, 2, params=None if params is None else params[:2], want_outputs=False)  # even count: the in-place roll path
         c.sync()
-        out.append((c.get_theta(), c.get_score(), c.get_a_mat()))
+        out.append((c.get_theta(), c.get_score(), c.get_a_mat(), a_seq, pw))
         c.close()
     for a, b in zip(*out):
         assert np.array_equal(a, b)
