@@ -179,6 +179,13 @@ def main():
                         algorithmic_bytes_per_launch=bytes_alg, avg_launch_us=avg_s * 1e6, launches=400,
                         timing="one HIP event pair around 400 back-to-back launches on the context's stream")
         c1.device_free(ptr)
+        # the same kernel over binary16-stored noise (BASELINE.json config 5 "fp16 rollout"): informational, not the roofline line
+        ptr16 = c1.device_noise(n_slices * slice_f, seed=99, f16=True)
+        t16 = c1.profile_rollout(state, ptr16, n_slices, 400, f16=True) * 1e-3
+        b16 = c1.rollout_bytes(eps_f16=True)
+        roofline["f16_storage_variant"] = dict(avg_launch_us=t16 * 1e6, algorithmic_bytes_per_launch=b16, achieved=b16 / t16 / 1e9,
+                                               frac=b16 / t16 / 1e9 / HBM_PEAK_GBS)
+        c1.device_free(ptr16)
         c1.profile(False)
         c1.close()
 

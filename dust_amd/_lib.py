@@ -19,7 +19,7 @@ OPT_SGD, OPT_ADAM = 0, 1
 ROLL_REPEAT, ROLL_MEAN = 0, 1
 STEP_ARGMAX, STEP_AVERAGE, STEP_EXTERNAL = 0, 1, 2
 PARAM_PYFLOAT, PARAM_SAMPLED, PARAM_TENSOR0D = 0, 1, 2
-PTR_DEVICE, STORE_STATES, EPS_AROUND_A_MAT = 1, 2, 4
+PTR_DEVICE, STORE_STATES, EPS_AROUND_A_MAT, EPS_F16, STORE_F16 = 1, 2, 4, 8, 16
 K_ROLLOUT, K_PRIOR_SCORE, K_STEIN, K_UPDATE, K_FORWARD, K_BANDWIDTH, K_MPF, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 
 
@@ -119,10 +119,10 @@ SYMBOLS = {
     "dust_profile_enable": (C.c_int, [VP, C.c_int]),
     "dust_profile_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dust_profile_reset": (C.c_int, [VP]),
-    "dust_profile_rollout": (C.c_int, [VP, FP, VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "dust_profile_rollout": (C.c_int, [VP, FP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dust_kernel_name": (C.c_char_p, [C.c_int]),
     "dust_rollout_algorithmic_bytes": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double)]),
-    "dust_device_noise_alloc": (C.c_int, [VP, C.c_size_t, C.c_uint64, C.POINTER(VP)]),
+    "dust_device_noise_alloc": (C.c_int, [VP, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(VP)]),
     "dust_device_free": (C.c_int, [VP, VP]),
     "dust_mpf_create": (C.c_int, [C.POINTER(MpfConfig), FP, FP, C.POINTER(VP)]),
     "dust_mpf_clone": (C.c_int, [VP, C.POINTER(VP)]),

@@ -17,6 +17,17 @@ def _f(a, shape=None):
     return a
 
 
+def _fh(a, shape):
+    """Bulk noise / action input: a float16 array stays binary16 (storage only, DUST_EPS_F16); anything else becomes fp32.
+    Returns (array or None, flag)."""
+    if a is None:
+        return None, 0
+    a = np.asarray(a)
+    if a.dtype == np.float16:
+        return np.ascontiguousarray(a.reshape(shape)), L.EPS_F16
+    return _f(a, shape), 0
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(L.FP)
 
@@ -191,15 +202,17 @@ class Context:
         return _f(params, (sets, self.M, self.P))
 
     def disco_forward(self, state, actions=None, params=None, want_states=False, want_actions=False, want_omega=True,
-                      around_a_mat=False):
+                      around_a_mat=False, store_f16=False):
+        """`actions` may be a float16 array (binary16 storage, fp32 arithmetic); `store_f16`: states / actions come back as float16."""
         st = _f(state, (self.ds,))
-        act = None if actions is None else _f(actions, (self.S, self.N, self.H, self.da))
+        act, fl = _fh(actions, (self.S, self.N, self.H, self.da))
         pr = self._params(params)
+        odt = np.float16 if store_f16 else np.float32
         costs = np.empty((self.S, self.N), np.float32)
-        states = np.empty((self.M, self.S, self.N, self.H + 1, self.ds), np.float32) if want_states else None
-        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if want_actions else None
+        states = np.empty((self.M, self.S, self.N, self.H + 1, self.ds), odt) if want_states else None
+        aout = np.empty((self.S, self.N, self.H, self.da), odt) if want_actions else None
         omega = np.empty((self.S, self.N), np.float32) if want_omega else None
-        flags = L.EPS_AROUND_A_MAT if around_a_mat else 0
+        flags = (L.EPS_AROUND_A_MAT if around_a_mat else 0) | fl | (L.STORE_F16 if store_f16 else 0)
         L.check(L.load().dust_disco_forward(self._h, _p(st), _vp(act), _p(pr), flags, _p(costs), _p(states), _p(aout), _p(omega)))
         return costs, states, (aout if aout is not None else act), omega
 
@@ -210,13 +223,14 @@ class Context:
         L.check(L.load().dust_disco_step(self._h, sid, steps, _p(ext), _p(out)))
         return out
 
-    def likelihood_sample(self, state, eps=None, params=None, want_actions=False, store_states=False):
+    def likelihood_sample(self, state, eps=None, params=None, want_actions=False, store_states=False, store_f16=False):
         st = _f(state, (self.ds,))
-        e = None if eps is None else _f(eps, (self.S, self.N, self.H, self.da))
+        e, fl = _fh(eps, (self.S, self.N, self.H, self.da))
         pr = self._params(params)
         costs = np.empty((self.S, self.N), np.float32)
-        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if want_actions else None
-        L.check(L.load().dust_likelihood_sample(self._h, _p(st), _vp(e), _p(pr), L.STORE_STATES if store_states else 0, _p(costs), _p(aout)))
+        aout = np.empty((self.S, self.N, self.H, self.da), np.float16 if store_f16 else np.float32) if want_actions else None
+        flags = (L.STORE_STATES if store_states else 0) | fl | (L.STORE_F16 if store_f16 else 0)
+        L.check(L.load().dust_likelihood_sample(self._h, _p(st), _vp(e), _p(pr), flags, _p(costs), _p(aout)))
         return (costs, aout) if want_actions else costs
 
     def likelihood_log_prob(self):
@@ -232,9 +246,9 @@ class Context:
 
     def svmpc_optimize(self, state, n_steps, eps=None, params=None):
         st = _f(state, (self.ds,))
-        e = None if eps is None else _f(eps, (n_steps, self.S, self.N, self.H, self.da))
+        e, fl = _fh(eps, (n_steps, self.S, self.N, self.H, self.da))
         pr = self._params(params, n_steps)
-        L.check(L.load().dust_svmpc_optimize(self._h, _p(st), n_steps, _vp(e), _p(pr), 0))
+        L.check(L.load().dust_svmpc_optimize(self._h, _p(st), n_steps, _vp(e), _p(pr), fl))
 
     def svmpc_optimize_dev(self, state, n_steps, eps_dev_ptr, params=None):
         st = _f(state, (self.ds,))
@@ -256,8 +270,8 @@ class Context:
         if eps_dev_ptr:
             e, flags = L.VP(eps_dev_ptr), L.PTR_DEVICE
         else:
-            e = None if eps is None else _vp(_f(eps, (n_steps, self.S, self.N, self.H, self.da)))
-            flags = 0
+            e, flags = _fh(eps, (n_steps, self.S, self.N, self.H, self.da))
+            e = _vp(e)
         L.check(L.load().dust_svmpc_tick(self._h, _p(st), n_steps, e, _p(pr), flags, _p(a_seq), _p(pw)))
         return a_seq, pw
 
@@ -293,21 +307,22 @@ class Context:
                 out[L.load().dust_kernel_name(k).decode()] = (ms.value, n.value)
         return out
 
-    def profile_rollout(self, state, eps_dev, n_slices, reps):
+    def profile_rollout(self, state, eps_dev, n_slices, reps, f16=False):
         """Average launch-to-launch time (ms) of the standalone rollout kernel over device-resident eps slices."""
         ms = C.c_double(0)
         L.check(L.load().dust_profile_rollout(self._h, _p(np.ascontiguousarray(state, np.float32)), C.c_void_p(eps_dev), int(n_slices),
-                                              int(reps), C.byref(ms)))
+                                              int(reps), L.EPS_F16 if f16 else 0, C.byref(ms)))
         return ms.value
 
-    def rollout_bytes(self, store_states=False):
+    def rollout_bytes(self, store_states=False, eps_f16=False, store_f16=False):
         b = C.c_double(0)
-        L.check(L.load().dust_rollout_algorithmic_bytes(self._h, L.STORE_STATES if store_states else 0, C.byref(b)))
+        fl = (L.STORE_STATES if store_states else 0) | (L.EPS_F16 if eps_f16 else 0) | (L.STORE_F16 if store_f16 else 0)
+        L.check(L.load().dust_rollout_algorithmic_bytes(self._h, fl, C.byref(b)))
         return b.value
 
-    def device_noise(self, n_floats, seed=1):
+    def device_noise(self, n_values, seed=1, f16=False):
         p = L.VP()
-        L.check(L.load().dust_device_noise_alloc(self._h, n_floats, seed, C.byref(p)))
+        L.check(L.load().dust_device_noise_alloc(self._h, n_values, seed, L.EPS_F16 if f16 else 0, C.byref(p)))
         return p.value
 
     def device_free(self, ptr):

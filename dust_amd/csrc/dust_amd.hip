@@ -112,6 +112,9 @@ struct dust_ctx {
   int graph_seen;     // consecutive eager ticks with the same shape (capture on the 2nd)
   bool capturing;
   bool have_sample, actions_valid;
+  bool noise_f16;     // the eps / actions handed to the current call are binary16 (DUST_EPS_F16), set by the API entry points
+  bool actions_f16;   // the kept actions were stored as binary16
+  int graph_flags;
   unsigned long long *stamps_dev;  // diagnostic build only: [DUST_K_COUNT][16]
   unsigned long long *tl_dev;      // diagnostic build only: [8192][4] launch timeline of svgd_iter_kernel
   // profiling
@@ -608,6 +611,7 @@ struct SampleOpts {
   int update_a_mat;
   const float *costs_in;   // device [S][N]: skip the rollouts and use these costs (stage-wise phi)
   bool want_actions, want_states, want_omega;
+  bool store_f16;          // states / actions are stored as binary16 (DUST_STORE_F16)
   int merge_prior;         // a prior pass ran just before: fold its partials into grad_pri / score
   int bump_adam;           // an optimiser step follows this sample
 };
@@ -674,6 +678,8 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
     a.score = c->score;
   }
   a.noise_mode = o.noise_mode;
+  a.noise_f16 = (o.noise_mode != NOISE_PHILOX && c->noise_f16) ? 1 : 0;
+  a.store_f16 = o.store_f16 ? 1 : 0;
   a.lik = c->cfg.likelihood;
   a.eps_base_mode = o.eps_base_mode;
   a.update_a_mat = o.update_a_mat;
@@ -699,11 +705,11 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.eta = c->eta;
   a.omegaT = o.want_omega ? c->omegaT : nullptr;
   if (o.want_actions) {
-    TRY(ensure(&c->actions, &c->actions_cap, (size_t)c->S * c->N * c->D));
+    TRY(ensure(&c->actions, &c->actions_cap, ((size_t)c->S * c->N * c->D + (o.store_f16 ? 1 : 0)) >> (o.store_f16 ? 1 : 0)));
     a.actions_out = c->actions;
   }
   if (o.want_states) {
-    TRY(ensure(&c->states, &c->states_cap, (size_t)c->M * c->S * c->N * (c->H + 1) * c->ds));
+    TRY(ensure(&c->states, &c->states_cap, ((size_t)c->M * c->S * c->N * (c->H + 1) * c->ds) >> (o.store_f16 ? 1 : 0)));
     a.states_out = c->states;
   }
   a.seed = c->cfg.seed;
@@ -783,6 +789,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
 #undef DUST_LAUNCH_ROLLOUT
   HIP_TRY(hipGetLastError());
   c->actions_valid = o.want_actions;
+  c->actions_f16 = o.want_actions && o.store_f16;
   c->stein_dirty = false;
   return DUST_OK;
 }
@@ -811,14 +818,16 @@ static int stage_noise(dust_ctx *c, const float *src, int flags, const float **d
   const size_t n = (size_t)c->S * c->N * c->D;
   if (!src) {
     *dev = nullptr;
+    c->noise_f16 = false;
     return DUST_OK;
   }
+  c->noise_f16 = (flags & DUST_EPS_F16) != 0;
   if (flags & DUST_PTR_DEVICE) {
     *dev = src;
     return DUST_OK;
   }
   TRY(ensure(&c->noise_stage, &c->noise_cap, n));
-  TRY(h2d(c, c->noise_stage, src, n * sizeof(float)));
+  TRY(h2d(c, c->noise_stage, src, n * ((flags & DUST_EPS_F16) ? 2 : sizeof(float))));
   *dev = c->noise_stage;
   return DUST_OK;
 }
@@ -838,6 +847,7 @@ extern "C" int dust_get_costs(dust_ctx *c, float *costs) {
 extern "C" int dust_get_actions(dust_ctx *c, float *actions) {
   if (!c || !actions) return fail(DUST_ERR_INVALID, "null argument");
   if (!c->actions_valid) return fail(DUST_ERR_STATE, "the last sample did not keep its actions (pass actions_out)");
+  if (c->actions_f16) return fail(DUST_ERR_STATE, "the last sample kept its actions as binary16 (DUST_STORE_F16): they were returned by that call");
   return d2h(c, actions, c->actions, (size_t)c->S * c->N * c->D * sizeof(float));
 }
 extern "C" int dust_get_score(dust_ctx *c, float *s) {
@@ -885,14 +895,16 @@ extern "C" int dust_disco_forward(dust_ctx *c, const float *state, const float *
   o.want_actions = actions_out != nullptr;
   o.want_states = states != nullptr;
   o.want_omega = omega != nullptr;
+  o.store_f16 = (flags & DUST_STORE_F16) != 0;
+  const size_t osz = o.store_f16 ? 2 : sizeof(float);
   TRY(launch_rollout(c, o));
   c->have_sample = true;
   bump_iter_kernel<<<1, 1, 0, c->stream>>>(c->ctr_dev);
   HIP_TRY(hipGetLastError());
   if (costs) TRY(copy_out_SN(c, c->costsT, costs));
   if (omega) TRY(copy_out_SN(c, c->omegaT, omega));
-  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
-  if (states) TRY(d2h(c, states, c->states, (size_t)c->M * c->S * c->N * (c->H + 1) * c->ds * sizeof(float)));
+  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * osz));
+  if (states) TRY(d2h(c, states, c->states, (size_t)c->M * c->S * c->N * (c->H + 1) * c->ds * osz));
   return DUST_OK;
 }
 
@@ -912,12 +924,13 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
   o.update_a_mat = 1;
   o.want_actions = actions_out != nullptr;
   o.want_states = (flags & DUST_STORE_STATES) != 0;
+  o.store_f16 = (flags & DUST_STORE_F16) != 0;
   TRY(launch_rollout(c, o));
   c->have_sample = true;
   bump_iter_kernel<<<1, 1, 0, c->stream>>>(c->ctr_dev);
   HIP_TRY(hipGetLastError());
   if (costs) TRY(copy_out_SN(c, c->costsT, costs));
-  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * sizeof(float)));
+  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * (o.store_f16 ? 2 : sizeof(float))));
   return DUST_OK;
 }
 
@@ -1463,13 +1476,12 @@ extern "C" int dust_svmpc_optimize(dust_ctx *c, const float *state, int n_steps,
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: drive it with dust_svmpc_local_score / dust_svmpc_apply_phi");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, params, n_steps));
-  const size_t slice = (size_t)c->S * c->N * c->D;
+  const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats (binary16: S*N*D is even or n_steps is 1)
+  if ((flags & DUST_EPS_F16) && eps && n_steps > 1 && (((size_t)c->S * c->N * c->D) & 1))
+    return fail(DUST_ERR_UNSUPPORTED, "binary16 eps for several steps needs an even S*N*D");
   for (int k = 0; k < n_steps; ++k) {
     const float *nd = nullptr;
-    if (eps) {
-      if (flags & DUST_PTR_DEVICE) nd = eps + (size_t)k * slice;
-      else TRY(stage_noise(c, eps + (size_t)k * slice, 0, &nd));
-    }
+    TRY(stage_noise(c, eps ? eps + (size_t)k * slice : nullptr, flags, &nd));
     TRY(step_device(c, nd, k));
   }
   return DUST_OK;
@@ -1572,10 +1584,12 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
   static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
                          c->mu_aliased && c->own_stream;
-  if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || (c->graph_exec && c->graph_theta != c->theta)) {
+  if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || c->graph_flags != flags ||
+      (c->graph_exec && c->graph_theta != c->theta)) {
     if (c->graph_exec) graph_drop(c);
     c->graph_steps = n_steps;
     c->graph_eps = (const void *)eps;
+    c->graph_flags = flags;
     c->graph_seen = 0;
   }
   if (graphable && c->graph_exec) {
@@ -1594,7 +1608,8 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
     int st = DUST_OK;
     if (e == hipSuccess) {
-      const size_t slice = (size_t)c->S * c->N * c->D;
+      const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
+      c->noise_f16 = eps && (flags & DUST_EPS_F16);
       for (int k = 0; k < n_steps && st == DUST_OK; ++k) st = step_device(c, eps ? eps + (size_t)k * slice : nullptr, k);
       if (st == DUST_OK) st = forward_device(c);
       if (st == DUST_OK) st = forward_finish_device(c);
@@ -1618,7 +1633,8 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     } else {  // capture unavailable: run the tick eagerly (nothing was executed during the failed capture)
       (void)hipGetLastError();
       c->graph_seen = -1000000;  // do not retry every tick
-      const size_t slice = (size_t)c->S * c->N * c->D;
+      const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
+      c->noise_f16 = eps && (flags & DUST_EPS_F16);
       for (int k = 0; k < n_steps; ++k) TRY(step_device(c, eps ? eps + (size_t)k * slice : nullptr, k));
       TRY(forward_device(c));
       TRY(forward_finish_device(c));
@@ -1768,7 +1784,7 @@ extern "C" int dust_profile_get(dust_ctx *c, int id, double *ms, int64_t *n) {
 // Back-to-back launches of the standalone rollout kernel in its HBM-streaming form (device-resident eps, a fresh slice
 // per launch), bracketed by ONE pair of HIP events on the context's stream: the average is the kernel's launch-to-launch
 // duration without per-launch event overhead (bench.py's roofline; compare rocprofv3 --kernel-trace --stats).
-extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float *eps_dev, int n_slices, int reps, double *avg_ms) {
+extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float *eps_dev, int n_slices, int reps, int flags, double *avg_ms) {
   if (!c || !state || !eps_dev || !avg_ms || n_slices < 1 || reps < 1) return fail(DUST_ERR_INVALID, "bad argument");
   if (c->cfg.dim_p > 0) return fail(DUST_ERR_UNSUPPORTED, "dust_profile_rollout: contexts without sampled parameters only");
   HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1780,7 +1796,8 @@ extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float
   o.base = c->theta;
   o.update_a_mat = 1;
   o.merge_prior = 1;
-  const size_t slice = (size_t)c->S * c->N * c->D;
+  const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats
+  c->noise_f16 = (flags & DUST_EPS_F16) != 0;
   const bool prof = c->prof;
   c->prof = false;
   hipEvent_t e0, e1;
@@ -1814,9 +1831,10 @@ extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float
 extern "C" int dust_rollout_algorithmic_bytes(const dust_ctx *c, int flags, double *bytes) {
   if (!c || !bytes) return fail(DUST_ERR_INVALID, "null argument");
   // B_roll = 4 [S N D (eps in) + N D (theta in) + M P (params) + S N (costs out)] (+ states when stored)
-  double b = 4.0 * ((double)c->S * c->nloc * c->D + (double)c->nloc * c->D + (double)c->M * c->P + (double)c->S * c->nloc);
+  double b = ((flags & DUST_EPS_F16) ? 2.0 : 4.0) * (double)c->S * c->nloc * c->D +
+             4.0 * ((double)c->nloc * c->D + (double)c->M * c->P + (double)c->S * c->nloc);
   b += 4.0 * (double)c->nloc * c->D;  // grad_lik out
-  if (flags & DUST_STORE_STATES) b += 4.0 * (double)c->M * c->S * c->nloc * (c->H + 1) * c->ds;
+  if (flags & DUST_STORE_STATES) b += ((flags & DUST_STORE_F16) ? 2.0 : 4.0) * (double)c->M * c->S * c->nloc * (c->H + 1) * c->ds;
   *bytes = b;
   return DUST_OK;
 }
@@ -1829,7 +1847,17 @@ __global__ void noise_fill_kernel(float *dst, size_t n, uint64_t seed) {
   for (int q = 0; q < 4; ++q)
     if (i4 * 4 + q < n) dst[i4 * 4 + q] = z[q];
 }
-extern "C" int dust_device_noise_alloc(dust_ctx *c, size_t n, uint64_t seed, void **dptr) {
+__global__ void narrow_f16_kernel(float *buf, size_t n) {  // in place: value i moves from byte 4i to byte 2i; chunks in order
+  _Float16 *out = reinterpret_cast<_Float16 *>(buf);
+  for (size_t base = 0; base < n; base += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = base + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float v = i < n ? buf[i] : 0.f;
+    __syncthreads();
+    if (i < n) out[i] = (_Float16)v;
+  }
+}
+
+extern "C" int dust_device_noise_alloc(dust_ctx *c, size_t n, uint64_t seed, int flags, void **dptr) {
   if (!c || !dptr) return fail(DUST_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device));
   float *p = nullptr;
@@ -1837,6 +1865,10 @@ extern "C" int dust_device_noise_alloc(dust_ctx *c, size_t n, uint64_t seed, voi
   const size_t n4 = (n + 3) / 4;
   noise_fill_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, c->stream>>>(p, n, seed);
   HIP_TRY(hipGetLastError());
+  if (flags & DUST_EPS_F16) {  // one workgroup walks the buffer front to back: a value's new place was read before it is written
+    narrow_f16_kernel<<<1, 1024, 0, c->stream>>>(p, n);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   *dptr = p;
   return DUST_OK;

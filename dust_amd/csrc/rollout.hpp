@@ -31,6 +31,8 @@ struct RolloutArgs {
   DevModel dm;
   int N_total, n0, S, M, H, D;
   int noise_mode;
+  int noise_f16;     // the caller's eps / actions are IEEE binary16 (storage only: converted on load)
+  int store_f16;     // states_out / actions_out are binary16 buffers
   int wq_iters;      // ceil(S / (nt / D)): trip count of the weighted reductions over s
   int lgW;           // log2 of the lanes per action row in the noise staging (2^lgW >= D)
   int G;             // dynamics-sample groups: lane = (sample, group), group g rolls out m = g, g+G, ... (G > 1 only when S <= nt/G)
@@ -176,15 +178,23 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const int lgW = a.lgW, R = nt >> lgW;
   const int sr = tid >> lgW, sj = tid & ((1 << lgW) - 1);
   const bool jv = sj < D;
-  const char *nbase = reinterpret_cast<const char *>(a.noise + (size_t)n * D);
-  const uint32_t rowbytes = ((uint32_t)N * (uint32_t)D) << 2;  // S*N*D < 2^30 is checked at configuration time
-  const uint32_t jbytes = (uint32_t)min(sj, D - 1) << 2;
+  const int esh = a.noise_f16 ? 1 : 2;  // log2 of the element size in HBM
+  const char *nbase = reinterpret_cast<const char *>(a.noise) + (((size_t)n * D) << esh);
+  const uint32_t rowbytes = ((uint32_t)N * (uint32_t)D) << esh;  // S*N*D < 2^30 is checked at configuration time
+  const uint32_t jbytes = (uint32_t)min(sj, D - 1) << esh;
   const uint32_t off_last = (uint32_t)(S - 1) * rowbytes + jbytes, off_step = (uint32_t)R * rowbytes;
   uint32_t off0 = (uint32_t)sr * rowbytes + jbytes;
-  if (a.noise_mode != NOISE_PHILOX) {
+  // (the element-size test is wave-uniform and sits OUTSIDE the unrolled load sequences)
+  auto issue_loads = [&]() {
+    if (a.noise_f16) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
-  }
+      for (int u = 0; u < NB; ++u) v[u] = (float)*reinterpret_cast<const _Float16 *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
+    }
+  };
+  if (a.noise_mode != NOISE_PHILOX) issue_loads();
   if (tid < D) th[tid] = thv;
   __syncthreads();
   bool nanf = tid < D && thv != thv;
@@ -194,8 +204,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     for (int s0 = 0; s0 < S; s0 += NB * R) {
       if (s0) {
         off0 += (uint32_t)NB * off_step;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float *>(nbase + min(off0 + (uint32_t)u * off_step, off_last));
+        issue_loads();
       }
       float *trow = tile + (s0 + sr) * Dp + sj;
 #pragma unroll
@@ -302,11 +311,15 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         q = W * (q * q);
         traj = (float)tot + (q.x + q.y);
       } else {
-        float *so = f_states ? f_states + (size_t)r * (H + 1) * DS : nullptr;
-        if (so) {
+        float *so = f_states ? f_states + (((size_t)r * (H + 1) * DS) >> (a.store_f16 ? 1 : 0)) : nullptr;  // binary16: half the stride
+        auto put_state = [&](const int row) {
 #pragma unroll
-          for (int k = 0; k < DS; ++k) so[k] = x[k];
-        }
+          for (int k = 0; k < DS; ++k) {
+            if (a.store_f16) reinterpret_cast<_Float16 *>(so)[(size_t)row * DS + k] = (_Float16)x[k];
+            else so[(size_t)row * DS + k] = x[k];
+          }
+        };
+        if (so) put_state(0);
         for (int t = 0; t < H; ++t) {
           float at[DA];
 #pragma unroll
@@ -314,10 +327,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           const float ci = step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
           tot += f_mw ? (double)f_mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
-          if (so) {
-#pragma unroll
-            for (int k = 0; k < DS; ++k) so[(size_t)(t + 1) * DS + k] = x[k];
-          }
+          if (so) put_state(t + 1);
         }
         if (f_mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
           ut_term += (double)f_mw[m] * (double)term_cost<MODEL>(a.dm, x);
@@ -348,7 +358,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   if (f_actions) {
     for (int idx = tid; idx < S * D; idx += nt) {
       const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
-      f_actions[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
+      if (a.store_f16) reinterpret_cast<_Float16 *>(f_actions)[((size_t)s * N + n) * D + j] = (_Float16)tile[s * Dp + j];
+      else f_actions[((size_t)s * N + n) * D + j] = tile[s * Dp + j];
     }
   }
 

@@ -51,7 +51,17 @@ enum dust_step_strategy { DUST_STEP_ARGMAX = 0, DUST_STEP_AVERAGE = 1, DUST_STEP
 /* how a model parameter enters the arithmetic: a Python float (double), a 0-dim fp32 tensor, or a sampled column */
 enum dust_param_kind { DUST_PARAM_PYFLOAT = 0, DUST_PARAM_SAMPLED = 1, DUST_PARAM_TENSOR0D = 2 };
 /* DUST_EPS_AROUND_A_MAT: the external actions were drawn around a_mat (MultiDISCO's own sampling, disco.py:155-160) */
-enum dust_flags { DUST_PTR_DEVICE = 1, DUST_STORE_STATES = 2, DUST_EPS_AROUND_A_MAT = 4 };
+enum dust_flags {
+  DUST_PTR_DEVICE = 1,
+  DUST_STORE_STATES = 2,
+  DUST_EPS_AROUND_A_MAT = 4,
+  /* fp16 STORAGE of the rollout's bulk data, fp32 arithmetic (BASELINE.json config 5 "fp16 rollout / fp32 SVGD"; the reference
+   * itself is fp32 only).  DUST_EPS_F16: the `eps` / `actions` argument points to IEEE binary16 values (same layout, host or
+   * device) - the rollout kernel's HBM read traffic halves.  DUST_STORE_F16: the stored `states` / `actions_out` are binary16
+   * (the caller's output buffers receive binary16 values, half the bytes; 5.5 GB instead of 11 GB of states at config 3). */
+  DUST_EPS_F16 = 8,
+  DUST_STORE_F16 = 16
+};
 
 typedef struct dust_param {
   int32_t kind;   /* dust_param_kind */
@@ -194,13 +204,15 @@ int dust_profile_enable(dust_ctx *ctx, int on);
 int dust_profile_get(dust_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int dust_profile_reset(dust_ctx *ctx);
 /* reps back-to-back launches of the standalone rollout kernel over device-resident eps [n_slices][S][N][D] (slice r %
- * n_slices per launch) between one pair of HIP events on the context's stream; *avg_ms = elapsed / reps. */
-int dust_profile_rollout(dust_ctx *ctx, const float *state, const float *eps_dev, int n_slices, int reps, double *avg_ms);
+ * n_slices per launch) between one pair of HIP events on the context's stream; *avg_ms = elapsed / reps.
+ * flags: DUST_EPS_F16 when eps_dev holds binary16 values. */
+int dust_profile_rollout(dust_ctx *ctx, const float *state, const float *eps_dev, int n_slices, int reps, int flags, double *avg_ms);
 const char *dust_kernel_name(int kernel_id);
 /* algorithmic bytes one launch of the rollout kernel moves (SURVEY.md section 8d B_roll) */
 int dust_rollout_algorithmic_bytes(const dust_ctx *ctx, int flags, double *bytes);
-/* device scratch for benchmarks: allocate/fill standard-normal noise in HBM with the context's Philox stream */
-int dust_device_noise_alloc(dust_ctx *ctx, size_t n_floats, uint64_t seed, void **dptr);
+/* device scratch for benchmarks: allocate/fill standard-normal noise in HBM with the context's Philox stream
+ * (n values; flags: DUST_EPS_F16 -> binary16 values, n * 2 bytes) */
+int dust_device_noise_alloc(dust_ctx *ctx, size_t n_floats, uint64_t seed, int flags, void **dptr);
 int dust_device_free(dust_ctx *ctx, void *dptr);
 
 /* ---- MPF: dynamics-parameter SVGD filter (mpf.py:13-86, likelihoods.py:12-64, svgd.py:92-99) ---- */

@@ -271,6 +271,61 @@ def test_seeded_vs_oracle(model, N, S, M, H):
             assert relerr(c.get_bandwidths(), o.phi_k2(theta, sc)[1]) < TOL
 
 
+@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 64, 128, 1, 30), ("particle", 32, 64, 2, 20), ("pendulum", 33, 40, 3, 7)])
+def test_fp16_storage_mode_vs_oracle(model, N, S, M, H):
+    """BASELINE.json config 5 ("fp16 rollout / fp32 SVGD"): binary16 is a STORAGE format of the rollout's bulk data - the
+    noise / actions the kernel reads (DUST_EPS_F16) and the states / actions it stores (DUST_STORE_F16) - while every
+    operation stays fp32.  So the oracle fed the same binary16-rounded noise must agree to the fp32 tolerance (1e-5 relative),
+    the SVGD step taken from it too, and the stored states are the fp32 states rounded once to binary16."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    rng = np.random.default_rng(5 * N + S)
+    da = 1 if model == "pendulum" else 2
+    sig = 2.0 if model == "pendulum" else 5.0
+    up = None if M == 1 else (("length", "mass") if model == "pendulum" else ("mass",))
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal((N, H, da))).astype(np.float32)
+    eps16 = rng.standard_normal((S, N, H, da)).astype(np.float16)
+    state = np.array([3.0, 0.0] if model == "pendulum" else [-5.2, -7.3, 4.0, 3.0], np.float32)
+    params = None if up is None else rng.uniform(0.6, 1.3, (M, len(up))).astype(np.float32)
+    grid = grid_4x4_map() if model == "particle" else None
+    kw = dict(model=model, N=N, S=S, M=M, H=H, uncertain_params=up)
+    o = Oracle(grid=grid, **kw)
+    sg = np.full(da, sig, np.float32)
+    actions = o.sample_actions(theta, eps16.astype(np.float32), sg)
+    ref_costs, ref_states = o.rollout_cost(state, actions, params, want_states=True)
+    alpha = 1.0 if model == "pendulum" else 1e-4
+    c = Context(grid=grid, kernel="K1", lr=0.5, alpha=alpha, sigma_a=sig, sigma_p=sig, **kw)
+    c.set_theta(theta)
+    c.set_prior(mu)
+    c.set_a_mat(theta)
+    costs, aout = c.likelihood_sample(state, eps16, params, want_actions=True)
+    assert relerr(costs, ref_costs) < TOL and np.array_equal(aout, actions)
+    # binary16 actions in, binary16 states / actions out (MultiDISCO.forward with external actions)
+    act16 = actions.astype(np.float16)
+    costs2, st16, a16, _ = c.disco_forward(state, act16, params, want_states=True, want_actions=True, store_f16=True)
+    ref2, ref_states2 = o.rollout_cost(state, act16.astype(np.float32), params, want_states=True)
+    assert st16.dtype == np.float16 and a16.dtype == np.float16
+    assert relerr(costs2, ref2) < TOL and np.array_equal(a16, act16)
+    ok = np.isfinite(ref_states2) & (np.abs(ref_states2) < 6.0e4)
+    d = np.abs(st16.astype(np.float32) - ref_states2)[ok]
+    # one binary16 rounding (half an ulp, a whole one when the fp32 values straddle a tie) of states that agree to TOL
+    assert np.all(d <= 2.0 ** -10 * np.abs(ref_states2[ok]) + TOL * np.abs(ref_states2[ok]).max())
+    # one SVGD step from binary16 noise == the same step from that noise widened to fp32 on the host
+    c2 = Context(grid=grid, kernel="K1", lr=0.5, alpha=alpha, sigma_a=sig, sigma_p=sig, **kw)
+    for cc in (c, c2):
+        cc.set_theta(theta)
+        cc.set_prior(mu)
+        cc.set_a_mat(theta)
+    pr = None if params is None else params[None]
+    c.svmpc_optimize(state, 1, eps16[None], pr)
+    c2.svmpc_optimize(state, 1, eps16.astype(np.float32)[None], pr)
+    assert np.array_equal(c.get_theta(), c2.get_theta())
+    c.close()
+    c2.close()
+
+
 @pytest.mark.parametrize("world,overlap", [(2, False), (4, False), (2, True), (4, True)])
 def test_sharded_equals_unsharded(golden, world, overlap):
     """Particle sharding (the multi-GPU path) on ONE GPU: `world` sharded contexts in one process, the RCCL all-gathers

@@ -1,4 +1,4 @@
 import sys, os
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
 import kprof
-kprof.run("base")
+kprof.run("external eps", ext=True)
