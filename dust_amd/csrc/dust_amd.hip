@@ -1119,23 +1119,6 @@ static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp) {
   return DUST_OK;
 }
 
-// Scaling of the Stein tiles.  With an isotropic prior covariance the tiles are staged in the PRIOR pass's coordinates
-// (x / sigma_p, bit-identical to the prior pass's tiles, which lets one workgroup serve both passes: fused.hpp) and the Gram
-// value takes rho2 = (sigma_p / ell)^2 times the squared distance; otherwise in x / ell with rho2 = 1.
-static void stein_scaling(const dust_ctx *c, PairArgs &a) {
-  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;  // K1: softplus(0) = ln 2 (svmpc.py:78)
-  bool iso = !pair_is_big(c);
-  for (int d = 1; d < c->da; ++d) iso = iso && c->cfg.sigma_p[d] == c->cfg.sigma_p[0];
-  if (iso) {
-    const float r = c->cfg.sigma_p[0] / ell;
-    for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / c->cfg.sigma_p[0];
-    a.rho2 = r * r;
-  } else {
-    for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / ell;
-    a.rho2 = 1.0f;
-  }
-}
-
 static UpdateArgs update_args(dust_ctx *c, int apply) {
   UpdateArgs u;
   memset(&u, 0, sizeof u);
@@ -1217,7 +1200,8 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     a.Y = c->theta;
     a.V = c->score;
     a.magicD = (uint32_t)((1ull << 32) / (uint64_t)c->D) + 1u;
-    stein_scaling(c, a);
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / ell;
     a.pA = c->pA;
     a.pB = c->pB;
     a.stamps = c->stamps_dev ? c->stamps_dev + 16 * DUST_K_STEIN : nullptr;
@@ -1426,7 +1410,10 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   f.stein.Y = c->theta;
   f.stein.V = c->score;
   f.stein.logmix = nullptr;
-  stein_scaling(c, f.stein);
+  {
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    for (int d = 0; d < 4; ++d) f.stein.inv_s[d] = 1.0f / ell;
+  }
   f.stein.pA = c->pS;  // own buffer: pA holds the prior partials, which the rollout role may still be reading
   f.stein.pB = c->pB;
   f.stein.pM = nullptr;

@@ -35,8 +35,7 @@ struct PairArgs {
   const float *Y;      // [N][D] keys (mu for the prior, theta for Stein), row-major
   const float *V;      // [N][D] score (Stein only)
   const float *logmix; // [N] prior mixture log-weights
-  float inv_s[4];      // per-column scale of the staged tiles: 1/sigma_p[d % da] (prior); Stein: 1/ell, or 1/sigma_p with rho2 below
-  float rho2;          // Stein: the Gram value is k(rho2 * d2) - (sigma_p/ell)^2 when the tiles are staged in the prior's coordinates, else 1
+  float inv_s[4];      // 1/sigma_p[d % da] (prior) or 1/ell (Stein)
   // partial outputs, indexed [js][i_local]
   float *pA;           // [JS][n_local][DP] prior: sum_k p (mu - x)      Stein: sum_j k s_j
   float *pB;           // [JS][n_local][DP]                              Stein: sum_j k' (x_i - x_j)
@@ -182,8 +181,8 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         const float dd = d2[ii].x + d2[ii].y;
         float v;
         if (PRI) v = (jA < jc) ? lm - 0.5f * dd : -INFINITY;
-        else if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * (a.rho2 * dd)) : 0.f;  // exp(-dd/2) = 2^(-dd/(2 ln 2)); bare v_exp_f32, rel. error ~|x| 2^-24
-        else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + a.rho2 * dd) : 0.f;  // IMQ: k = (1 + d^2/l^2)^(-1/2) once per pair (bare v_rsq_f32, 1 ulp); k' = -k^3 in pass B
+        else if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;  // exp(-dd/2) = 2^(-dd/(2 ln 2)); bare v_exp_f32, rel. error ~|x| 2^-24
+        else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + dd) : 0.f;  // IMQ: k = (1 + d^2/l^2)^(-1/2) once per pair (bare v_rsq_f32, 1 ulp); k' = -k^3 in pass B
         kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
       }
     }
@@ -364,8 +363,8 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
     for (int ii = 0; ii < QPG; ++ii) {
       const float dd = d2[ii].x + d2[ii].y;
       float v;
-      if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * (a.rho2 * dd)) : 0.f;
-      else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + a.rho2 * dd) : 0.f;
+      if (MODE == PAIR_K1) v = (jA < jc) ? __builtin_amdgcn_exp2f(-0.72134752044448170f * dd) : 0.f;
+      else v = (jA < jc) ? __builtin_amdgcn_rsqf(1.0f + dd) : 0.f;
       kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
     }
   }

@@ -74,3 +74,33 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "dust_oracle" not in txt, f
+
+
+def test_hot_kernels_do_not_spill(built, tmp_path):
+    """hipcc's register allocation of the fully unrolled pairwise passes sits right under its VGPR cap: one extra operation in
+    the distance pass once tipped `pairwise_kernel<K1,4>` into 117 spilled registers (2.4x slower, every result still
+    correct - nothing else would have flagged it).  The gfx950 code object's metadata must show no VGPR spills and no
+    scratch for the kernels of the product tick and of the pairwise passes at D <= 64."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    so = str(tmp_path / "l.so")
+    shutil.copy(built, so)
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", "l.so"], cwd=str(tmp_path), check=True, capture_output=True)
+    co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert co, "no gfx950 code object in libdust_amd.so"
+    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co[0]], cwd=str(tmp_path), check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
+        blk = m.group(2)
+        kernels[m.group(1)] = (int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)),
+                               int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    hot = [k for k in kernels if re.search(r"svgd_iter_kernel|fused_prior_rollout_kernel|stein_update_kernel|rollout_stream_kernel|"
+                                           r"rollout_kernelILi\d+ELb\dELb1|pairwise_kernelILi\d+ELi[48]E|finalize_roll_kernel|"
+                                           r"pairwise_big_kernelILi\d+ELi32E", k)]
+    assert len(hot) >= 30, sorted(kernels)
+    bad = {k: kernels[k] for k in hot if kernels[k] != (0, 0)}
+    assert not bad, "VGPR spills / scratch in hot kernels (name: (spilled VGPRs, scratch bytes)): %r" % bad
