@@ -15,7 +15,8 @@ theta); `value` counts 1024-particle shard-ticks per second
 `joint_ticks_per_s` is the joint rate itself.  The pairwise passes are N_loc x N, so per-rank work grows with N by design.
 
 Extra objects in the JSON line (tier contract): `roofline` for the rollout kernel in its HBM-streaming form (external
-noise read from HBM, the variant the parity tests drive), timed with HIP events inside this process (one event pair around
+noise read from HBM, the variant the parity tests drive; run as dust_likelihood_sample runs it - rollouts, costs, weights,
+likelihood score, MPPI side update - without the combine of the prior partials, which SURVEY 8d's B_roll does not count), timed with HIP events inside this process (one event pair around
 400 back-to-back launches on the context's stream; `traffic` from the committed PMC summary under profiles/); `cpu_baseline` =
 the CPU oracle (oracle/dust_oracle.c, a port - the reference is Python and cannot travel) on the host cores.
 """

@@ -1789,13 +1789,12 @@ extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float
   if (c->cfg.dim_p > 0) return fail(DUST_ERR_UNSUPPORTED, "dust_profile_rollout: contexts without sampled parameters only");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, nullptr, 0));
-  TRY(launch_prior(c));  // the partials the kernel's combine stage reads
   SampleOpts o;
   memset(&o, 0, sizeof o);
   o.noise_mode = NOISE_EPS;
   o.base = c->theta;
   o.update_a_mat = 1;
-  o.merge_prior = 1;
+  o.merge_prior = 0;  // the rollout kernel as dust_likelihood_sample runs it (SURVEY 8d B_roll has no prior-partial traffic)
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats
   c->noise_f16 = (flags & DUST_EPS_F16) != 0;
   const bool prof = c->prof;
