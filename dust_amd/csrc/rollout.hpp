@@ -44,7 +44,7 @@ struct RolloutArgs {
   float alpha, temp, a_reg;
   float chol_a[4], sigma_a[4], a_pre[4];
   PriorMerge pm;
-  const float *state;   // [ds] (device; refreshed by an async copy from a pinned ring before each tick)
+  const float *state;   // [ds] (device; refreshed by a 4-lane launch carrying the plant state as its argument before each tick)
   uint32_t *ctr;        // device counters {tick, iter, adam_step}: the Philox stream position (static under hipGraph replay)
   int bump_adam;        // an optimiser step follows: advance adam_step (read by update_kernel, never by this kernel)
   unsigned int *rearm;  // arrival counters of the Stein+update launch (fused.hpp), zeroed here for its next use, or nullptr
