@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
   }
 }
 
-static inline int launch_k2(hipStream_t stream, const K2Args &a) {
+// the two halves of the K2 step: bandwidths (read theta only) and phi (reads the score as well)
+static inline int launch_k2_bandwidth(hipStream_t stream, const K2Args &a) {
   const int G = a.shared ? a.H : a.D;
+  if (a.da > 2) return DUST_ERR_UNSUPPORTED;  // models on the path have d_a <= 2
   if (a.shared) {
     k2_bandwidth_pairs_kernel<<<G, 1024, (size_t)a.da * a.N * sizeof(float), stream>>>(a);
   } else {
@@ -322,13 +324,19 @@ static inline int launch_k2(hipStream_t stream, const K2Args &a) {
     if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
     else k2_bandwidth_sorted_big_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
   }
-  if (hipGetLastError() != hipSuccess) return DUST_ERR_HIP;
-  if (a.da > 2) return DUST_ERR_UNSUPPORTED;  // models on the path have d_a <= 2
+  return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
+}
+static inline int launch_k2_phi(hipStream_t stream, const K2Args &a) {
+  const int G = a.shared ? a.H : a.D;
+  if (a.da > 2) return DUST_ERR_UNSUPPORTED;
   dim3 grid((a.n_local + 63) / 64, G);
   if (a.shared && a.da == 2) k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
   else k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
-  if (hipGetLastError() != hipSuccess) return DUST_ERR_HIP;
-  return DUST_OK;
+  return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
+}
+static inline int launch_k2(hipStream_t stream, const K2Args &a) {
+  const int s = launch_k2_bandwidth(stream, a);
+  return s != DUST_OK ? s : launch_k2_phi(stream, a);
 }
 
 }  // namespace dust

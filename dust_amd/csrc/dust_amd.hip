@@ -109,6 +109,7 @@ struct dust_ctx {
   int graph_seen;     // consecutive eager ticks with the same shape (capture on the 2nd)
   bool capturing;
   bool have_sample, actions_valid;
+  bool k2_bw_ahead;   // K2: transpose + bandwidths of the current theta are already in flight on the side stream
   bool noise_f16;     // the eps / actions handed to the current call are binary16 (DUST_EPS_F16), set by the API entry points
   bool actions_f16;   // the kept actions were stored as binary16
   int graph_flags;
@@ -1146,29 +1147,38 @@ static UpdateArgs update_args(dust_ctx *c, int apply) {
   return u;
 }
 
+static K2Args k2_args(dust_ctx *c) {
+  K2Args k;
+  memset(&k, 0, sizeof k);
+  k.N = c->N;
+  k.H = c->H;
+  k.da = c->da;
+  k.D = c->D;
+  k.shared = c->cfg.kernel == DUST_KERNEL_K2_SHARED;
+  k.i0 = c->n0;
+  k.n_local = c->nloc;
+  k.bw_scale = c->cfg.bw_scale;
+  k.theta = c->theta;
+  k.thetaT = c->thetaT;
+  k.score = c->score;
+  k.h = c->bw;
+  k.phi = c->phi;
+  return k;
+}
+
 // Stein pass (+ optimiser step when apply != 0).  K1 / IMQ: tiled partials -> update_kernel; K2: bandwidths + phi, then update.
 static int launch_stein_update(dust_ctx *c, int apply) {
   const int n = c->nloc * c->D;
   if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
     {
       Prof p(c, DUST_K_BANDWIDTH);
-      TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
-      K2Args k;
-      memset(&k, 0, sizeof k);
-      k.N = c->N;
-      k.H = c->H;
-      k.da = c->da;
-      k.D = c->D;
-      k.shared = c->cfg.kernel == DUST_KERNEL_K2_SHARED;
-      k.i0 = c->n0;
-      k.n_local = c->nloc;
-      k.bw_scale = c->cfg.bw_scale;
-      k.theta = c->theta;
-      k.thetaT = c->thetaT;
-      k.score = c->score;
-      k.h = c->bw;
-      k.phi = c->phi;
-      TRY(launch_k2(c->stream, k));
+      const K2Args k = k2_args(c);
+      if (!c->k2_bw_ahead) {  // (else: the bandwidths of this theta were computed beside the rollouts, step_device)
+        TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+        TRY(launch_k2_bandwidth(c->stream, k));
+      }
+      c->k2_bw_ahead = false;
+      TRY(launch_k2_phi(c->stream, k));
     }
     if (apply) {
       UpdateArgs u = update_args(c, 1);
@@ -1459,6 +1469,24 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
   bool done = false;
   TRY(launch_iter(c, noise_dev, param_set, &done));
   if (done) return DUST_OK;
+  // K2: the per-dimension median bandwidths read theta only (a few dozen single-workgroup sorts, 60 us on 30 CUs): they run on
+  // the side stream beside the prior + rollout launch and join before the phi kernel
+  static const bool k2_serial = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_K2_SERIAL") != nullptr;  // development switches
+  const bool k2 = c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED;
+  if (k2 && !k2_serial && !c->prof && c->stream2 && c->own_stream) {
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    const int n = c->N * c->D;
+    transpose_kernel<<<(n + 255) / 256, 256, 0, c->stream2>>>(c->theta, c->thetaT, c->N, c->D);
+    HIP_TRY(hipGetLastError());
+    TRY(launch_k2_bandwidth(c->stream2, k2_args(c)));
+    HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+    int s = local_score_device(c, noise_dev, param_set);
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // (join even on failure: the capture, if any, must see the side stream return)
+    TRY(s);
+    c->k2_bw_ahead = true;
+    return launch_stein_update(c, 1);
+  }
   TRY(local_score_device(c, noise_dev, param_set));
   TRY(launch_stein_update(c, 1));
   return DUST_OK;
