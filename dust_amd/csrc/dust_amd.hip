@@ -101,6 +101,7 @@ struct dust_ctx {
   // one-launch SVGD iteration (fused.hpp svgd_iter_kernel): two sets of [tiles | JS | tiles] counter lines, then the time-out flag
   unsigned int *iter_cnt;
   int iter_tiles, iter_js, iter_set;
+  float *score_hs;  // [2][N][D] score rows handed over as data inside the one-launch iteration (sentinel-filled between uses)
   // hipGraph replay of a whole tick (dust_svmpc_tick)
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
@@ -268,6 +269,7 @@ static void free_all(dust_ctx *c) {
   if (c->fused_cnt) (void)hipFree(c->fused_cnt);
   if (c->stein_cnt) (void)hipFree(c->stein_cnt);
   if (c->iter_cnt) (void)hipFree(c->iter_cnt);
+  if (c->score_hs) (void)hipFree(c->score_hs);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1409,6 +1411,8 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
     c->iter_tiles = f.tiles;
     c->iter_js = JS;
     c->iter_set = 0;
+    if (!c->score_hs) TRY(dalloc(&c->score_hs, (size_t)2 * c->N * c->D));
+    HIP_TRY(hipMemsetAsync(c->score_hs, 0xFF, (size_t)2 * c->N * c->D * sizeof(float), c->stream));  // SCORE_SENTINEL in every word
   }
   // Stein role: same geometry as the prior pass (pair_geometry), keys = queries = theta, values = the score rows
   f.stein = f.prior;
@@ -1438,6 +1442,12 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   f.zero_base = c->iter_cnt + (size_t)(1 - c->iter_set) * lines * CNT_STRIDE;
   f.zero_lines = lines;
   f.timeout_flag = c->iter_cnt + (size_t)2 * lines * CNT_STRIDE;
+  static const bool score_by_counter = getenv("DUST_SCORE_CNT") != nullptr;  // development switch: counter hand-off of the score rows
+  if (!score_by_counter) {
+    f.score_pub = c->score_hs + (size_t)c->iter_set * c->N * c->D;
+    f.score_reset = reinterpret_cast<unsigned int *>(c->score_hs + (size_t)(1 - c->iter_set) * c->N * c->D);
+    f.score_elems = c->N * c->D;
+  }
   f.tl = c->tl_dev;
   const int n = c->nloc * c->D;
   const int grid = 2 * f.n_pair_blocks + f.n_roll_blocks + (n + PAIR_NT - 1) / PAIR_NT;
@@ -1560,6 +1570,8 @@ static int forward_finish_device(dust_ctx *c) {
   if (c->iter_cnt) {
     r.rearm = c->iter_cnt;
     r.rearm_lines = 2 * (2 * c->iter_tiles + c->iter_js);
+    r.hs = reinterpret_cast<unsigned int *>(c->score_hs);
+    r.hs_n = 2 * c->N * c->D;
   }
   if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && c->D <= 128 && !c->prof) {
     // out-of-place roll: independent of finalize (which gathers a_seq from the buffer the roll only reads) -> one launch

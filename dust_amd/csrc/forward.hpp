@@ -186,6 +186,8 @@ struct RollArgs {
   uint32_t *ctr;
   unsigned int *rearm;  // hand-off counters of the one-launch SVGD iteration (both sets; one 128-byte line each) or nullptr:
   int rearm_lines;      // zeroed here, so that a tick - and a replayed graph - starts with both sets clean
+  unsigned int *hs;     // both score hand-off buffers of the one-launch iteration (stein.hpp SCORE_SENTINEL) or nullptr:
+  int hs_n;             // filled with the sentinel again
 };
 
 __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
   }
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t < a.rearm_lines; t += blockDim.x) a.rearm[t * 32] = 0u;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.hs_n; e += gridDim.x * blockDim.x) a.hs[e] = SCORE_SENTINEL;
   const int i = a.i0 + blockIdx.x;
   const int D = a.H * a.da, j = threadIdx.x, da = a.da;
   const float *th = a.theta + (size_t)i * D;
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(1024) void finalize_roll_kernel(const FinalizeArgs 
   }
   if (blockIdx.x == 1)
     for (int t = threadIdx.x; t < a.rearm_lines; t += 1024) a.rearm[t * 32] = 0u;
+  for (int e = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x; e < a.hs_n; e += ((int)gridDim.x - 1) * 1024) a.hs[e] = SCORE_SENTINEL;
   const int il = ((int)blockIdx.x - 1) * 8 + ((int)threadIdx.x >> 7), j = threadIdx.x & 127;
   if (il >= a.n_local) return;
   const int i = a.i0 + il, D = a.H * a.da;

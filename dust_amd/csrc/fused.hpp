@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
     const int nb = (int)gridDim.x - f.n_pair_blocks;
     const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
-    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0, nullptr};
+    const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0, nullptr, nullptr};
     rollout_body<MODEL, 12, GROUPS, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
   }
 }
@@ -130,6 +130,11 @@ struct IterArgs {
   int zero_lines;                                   // ... of this many 128-byte lines
   unsigned int *timeout_flag;
   unsigned long long *tl;                           // diagnostic build only: [grid][4] launch timeline (common.hpp DUST_TL)
+  // score rows handed over as data (rollout.hpp FusedWait::score_pub): this launch's buffer, and the other one, which the
+  // prior tiles fill with the sentinel again for the next launch (its readers finished with the previous launch)
+  float *score_pub;
+  unsigned int *score_reset;
+  int score_elems;
 };
 
 template <int MODEL, int MODE, int CPT>
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
   if (b0 < f.n_pair_blocks) {
     if (b0 == 0)
       for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
+    if (f.score_reset)
+      for (int e = b0 * PAIR_NT + (int)threadIdx.x; e < f.score_elems; e += f.n_pair_blocks * PAIR_NT) f.score_reset[e] = SCORE_SENTINEL;
     const int tile_x = b0 % f.tiles, js = b0 / f.tiles;
     pairwise_body<PAIR_PRIOR, CPT>(f.prior, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -150,13 +157,13 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
     const int br = b0 - f.n_pair_blocks;
     const int b = ((f.n_pair_blocks | f.n_roll_blocks) & 7) ? br : xcd_contiguous(br, f.n_roll_blocks);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
-    const FusedWait fw{f.cnt_prior, (unsigned int)f.prior.JS, f.timeout_flag, f.cnt_score, f.stein.slice, f.per_block, f.tl};
+    const FusedWait fw{f.cnt_prior, (unsigned int)f.prior.JS, f.timeout_flag, f.cnt_score, f.stein.slice, f.per_block, f.tl, f.score_pub};
     rollout_body<MODEL, 12, false, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);
     DUST_TL(f.tl, 3);
   } else if (b0 < 2 * f.n_pair_blocks + f.n_roll_blocks) {
     const int bs = b0 - f.n_pair_blocks - f.n_roll_blocks;
     const int tile_x = bs % f.tiles, js = bs / f.tiles;
-    stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.timeout_flag, f.tl);
+    stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.score_pub, f.timeout_flag, f.tl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_stein + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

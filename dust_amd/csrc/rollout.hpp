@@ -114,6 +114,9 @@ struct FusedWait {
   int score_slice;          // keys per slice (a multiple of the particles per workgroup)
   int score_add;            // particles per workgroup
   unsigned long long *tl;   // diagnostic build only: launch timeline words
+  // score rows published AS DATA: written through into a buffer that holds a sentinel in every word until then; the Stein
+  // tiles poll the rows themselves - no drain, no barrier, no counter between the last store and the consumer (or nullptr)
+  float *score_pub;
 };
 
 // `tid`/`nt` are the lane index and lane count of the sub-block that owns local particle `nl`; barriers are workgroup
@@ -556,20 +559,26 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         gp = prior_merge_col(a.pm, nl, D, tid, DA, m, l);
       }
       a.grad_pri[o] = gp;
-      if (fw && fw->score_cnt) __hip_atomic_store(a.score + o, gs + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else a.score[o] = gs + gp;
+      if (fw && fw->score_pub) {
+        a.score[o] = gs + gp;
+        __hip_atomic_store(fw->score_pub + o, gs + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (fw && fw->score_cnt) {
+        __hip_atomic_store(a.score + o, gs + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.score[o] = gs + gp;
+      }
     }
   }
   if (a.bump_adam && nl == 0 && tid == 0) {
     // (one-launch iteration: the update role of the same launch reads adam_step - device-scope RMW, read there with an sc1 load)
-    if (fw && fw->score_cnt) __hip_atomic_fetch_add(a.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fw && (fw->score_cnt || fw->score_pub)) __hip_atomic_fetch_add(a.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else a.ctr[2] += 1u;
   }
   if (a.rearm && nl == 0)
     for (int t = tid; t < a.rearm_n; t += nt) a.rearm[t * CNT_STRIDE] = 0u;
   DUST_STAMP(a.stamps, 5);
   DUST_TL(fw ? fw->tl : nullptr, 2);
-  if (fw && fw->score_cnt) {
+  if (fw && fw->score_cnt && !fw->score_pub) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
     __syncthreads();                                    // ... before the one lane that signals for the workgroup
     if (threadIdx.x == 0)

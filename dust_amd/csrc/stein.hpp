@@ -24,6 +24,8 @@ namespace dust {
 
 enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2, PAIR_LOGP = 3 };  // LOGP: the prior pass of SVMPC.forward - log p only, no gradient
 enum { PAIR_TI = 32, PAIR_JC = 64, PAIR_NT = 256 };
+// a word no arithmetic produces (hardware NaNs are the canonical quiet NaN, inputs never carry this payload): "not written yet"
+static constexpr unsigned int SCORE_SENTINEL = 0xFFFFFFFFu;
 
 struct PairArgs {
   int N, D, da, H;
@@ -312,7 +314,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 // 16-byte partial stores remain on the critical path.  Accumulation orders are those of pairwise_body (bitwise equal).
 template <int MODE, int CPT>
 __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, const int tile_x, const int js, const unsigned int *score_cnt,
-                                                 unsigned int *timeout_flag, unsigned long long *tl) {
+                                                 const float *score_pub, unsigned int *timeout_flag, unsigned long long *tl) {
   static_assert(MODE == PAIR_K1 || MODE == PAIR_IMQ, "Stein modes only");
   static_assert(CPT <= 8, "the Gram x score product runs on the matrix cores (D <= 64)");
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
@@ -400,28 +402,52 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
   }
   // ---- the score rows of this key slice, published by the rollout role of this launch ----
   DUST_TL(tl, 1);
-  if (tid == 0) {
-    const unsigned int target = (unsigned int)(jend - jbeg);
+  using RLV = RowLane<JC, DP, NT>;
+  float vv[RLV::NB];
+  const int vlr = tid / RLV::W, vlc = min(tid % RLV::W, D - 1);
+  if (score_pub) {
+    // handed over as data: every word of the buffer holds SCORE_SENTINEL until its row is written (through) by the rollout
+    // role.  A cheap look at the last word of each row until all 64 have landed, then the tile is loaded and EVERY word is
+    // checked (a row is several memory transactions; no assumption on their order or granularity); bounded.
+    const float *base = score_pub + (size_t)jbeg * D + vlc;
     unsigned int spins = 0;
-    while (__hip_atomic_load(score_cnt + js * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // 32 = CNT_STRIDE (rollout.hpp)
+    for (;;) {
+      {
+        int any = 0;
+#pragma unroll
+        for (int u = 0; u < RLV::NB; ++u) {
+          vv[u] = __hip_atomic_load(base + (size_t)min(u * RLV::RB + vlr, jc - 1) * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          any |= __float_as_uint(vv[u]) == SCORE_SENTINEL;
+        }
+        if (!__syncthreads_or(any)) break;
+      }
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 24)) {
-        *timeout_flag = 1u;
+      if (++spins > (1u << 22)) {
+        if (tid == 0) *timeout_flag = 1u;
         break;
       }
     }
-  }
-  DUST_TL(tl, 2);
-  __syncthreads();
-  {  // row-lane staging with sc1 loads (the rows were written through by other CUs in this launch)
-    using RL = RowLane<JC, DP, NT>;
-    float vv[RL::NB];
-    const int lr = tid / RL::W, lc = min(tid % RL::W, D - 1);
-    const float *base = a.V + (size_t)jbeg * D + lc;
+    DUST_TL(tl, 2);
+  } else {
+    if (tid == 0) {
+      const unsigned int target = (unsigned int)(jend - jbeg);
+      unsigned int spins = 0;
+      while (__hip_atomic_load(score_cnt + js * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // 32 = CNT_STRIDE (rollout.hpp)
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 24)) {
+          *timeout_flag = 1u;
+          break;
+        }
+      }
+    }
+    DUST_TL(tl, 2);
+    __syncthreads();
+    // row-lane staging with sc1 loads (the rows were written through by other CUs in this launch)
+    const float *base = a.V + (size_t)jbeg * D + vlc;
 #pragma unroll
-    for (int u = 0; u < RL::NB; ++u) vv[u] = __hip_atomic_load(base + (size_t)min(u * RL::RB + lr, jc - 1) * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);
+    for (int u = 0; u < RLV::NB; ++u) vv[u] = __hip_atomic_load(base + (size_t)min(u * RLV::RB + vlr, jc - 1) * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);
   __syncthreads();
   v4f accM[TPW];
 #pragma unroll
