@@ -452,6 +452,14 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   }
 
   DUST_STAMP(a.stamps, 3);
+  if (a.bump_adam && nl == 0 && tid == 0) {
+    // one-launch iteration: the update role of the same launch reads adam_step (sc1 load) - a device-scope RMW, issued HERE,
+    // ahead of the prior-partial loads below: vector-memory operations retire in order, so the wait on those loads (which the
+    // score needs) also covers this add, and the score rows - the update role's only way to learn that the rollouts are done -
+    // cannot become visible before it
+    if (fw && (fw->score_cnt || fw->score_pub)) __hip_atomic_fetch_add(a.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.ctr[2] += 1u;
+  }
   // prior partials of this row: the (independent) loads are issued HERE - after the softmax, whose wave reductions would
   // otherwise run into waits on them (in-order vmcnt + register reuse) - and land under the weighted reductions below.
   // (the per-slice max / mass words are the same for every column: lanes 0..15 fetch one slice each and hand the combine
@@ -568,11 +576,6 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         a.score[o] = gs + gp;
       }
     }
-  }
-  if (a.bump_adam && nl == 0 && tid == 0) {
-    // (one-launch iteration: the update role of the same launch reads adam_step - device-scope RMW, read there with an sc1 load)
-    if (fw && (fw->score_cnt || fw->score_pub)) __hip_atomic_fetch_add(a.ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else a.ctr[2] += 1u;
   }
   if (a.rearm && nl == 0)
     for (int t = tid; t < a.rearm_n; t += nt) a.rearm[t * CNT_STRIDE] = 0u;

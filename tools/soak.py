@@ -13,7 +13,7 @@ import numpy as np
 from dust_amd import Context
 
 
-def run(model, N, S, M, H, ticks, kernel="K1", check_every=250):
+def run(model, N, S, M, H, ticks, kernel="K1", optimizer="SGD", check_every=250):
     da = 1 if model == "pendulum" else 2
     rng = np.random.default_rng(N + H)
     mu = rng.standard_normal((N, H, da)).astype(np.float32)
@@ -26,7 +26,8 @@ def run(model, N, S, M, H, ticks, kernel="K1", check_every=250):
         grid = grid_4x4_map()
     cs = []
     for unfused in (False, True):
-        c = Context(model=model, N=N, S=S, M=M, H=H, kernel=kernel, lr=0.5, sigma_a=1.0, sigma_p=1.0, grid=grid, seed=3)
+        c = Context(model=model, N=N, S=S, M=M, H=H, kernel=kernel, lr=0.5 if optimizer == "SGD" else 0.02, optimizer=optimizer, sigma_a=1.0,
+                    sigma_p=1.0, grid=grid, seed=3)
         c.set_theta(th); c.set_prior(mu); c.set_a_mat(th)
         c.profile(unfused)
         cs.append(c)
@@ -42,7 +43,7 @@ def run(model, N, S, M, H, ticks, kernel="K1", check_every=250):
         a, b = cs[0].get_theta(), cs[1].get_theta()
         assert np.array_equal(a, b), "fused and un-fused paths diverged after %d ticks (max |diff| %g)" % (done, np.abs(a - b).max())
         assert np.isfinite(a).all()
-    print("%-9s N=%-5d S=%-4d M=%d H=%-3d %s: %d ticks bitwise equal to the un-fused path, %.1f s" % (model, N, S, M, H, kernel, ticks, time.perf_counter() - t0), flush=True)
+    print("%-9s N=%-5d S=%-4d M=%d H=%-3d %s %s: %d ticks bitwise equal to the un-fused path, %.1f s" % (model, N, S, M, H, kernel, optimizer, ticks, time.perf_counter() - t0), flush=True)
     for c in cs:
         c.close()
 
@@ -52,6 +53,8 @@ if __name__ == "__main__":
     run("pendulum", 1024, 128, 1, 30, T)
     run("pendulum", 1024, 128, 1, 30, T // 2, kernel="IMQ")
     run("pendulum", 100, 40, 1, 7, T)
+    run("pendulum", 100, 40, 1, 7, T // 2, optimizer="Adam")
+    run("pendulum", 1024, 128, 1, 30, T // 2, optimizer="Adam")
     run("pendulum", 96, 256, 1, 33, T // 2)
     run("particle", 40, 30, 1, 31, T // 2)
     run("pendulum", 512, 64, 1, 12, T)
