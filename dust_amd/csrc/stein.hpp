@@ -588,7 +588,6 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
   // counters: this kernel READS adam_step (bumped by the rollout kernel of the same iteration) and ADVANCES iter (read
   // only by rollout kernels) - no launch both reads and writes the same counter
   const float adam_t = SC1 ? (float)__hip_atomic_load(a.ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (float)a.ctr[2];
-  if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const int il = idx / a.D, d = idx - il * a.D;
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   float th = a.apply ? a.theta[o] : 0.f;  // independent of the partials: in flight together with them
@@ -613,6 +612,8 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
         sb += vb[u];
       }
   }
+  // (after the partials have been read: whatever admitted this lane to them also means every rollout has read the counter)
+  if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
   const float phi = sb * a.inv_l2 + sa * a.inv_n;
   a.phi[o] = phi;
   if (!a.apply) return;
