@@ -26,7 +26,15 @@
   do {                                                                                                                      \
     if ((p) && threadIdx.x == 0) (p)[4 * blockIdx.x + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime();          \
   } while (0)
+// persistent tick (persist.hpp): wall-clock stamp into slot k of the workgroup's current iteration block
+#define DUST_TLP(p, k)                                                                                     \
+  do {                                                                                                      \
+    if ((p) && threadIdx.x == 0) (p)[k] = (unsigned long long)__builtin_amdgcn_s_memrealtime();             \
+  } while (0)
 #else
+#define DUST_TLP(p, k) \
+  do {                 \
+  } while (0)
 #define DUST_STAMP(p, k) \
   do {                   \
   } while (0)

@@ -16,6 +16,7 @@
 #include "forward.hpp"
 #include "fused.hpp"
 #include "pairwise_big.hpp"
+#include "persist.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -102,6 +103,11 @@ struct dust_ctx {
   unsigned int *iter_cnt;
   int iter_tiles, iter_js, iter_set;
   float *score_hs;  // [2][N][D] score rows handed over as data inside the one-launch iteration (sentinel-filled between uses)
+  // persistent one-launch tick (persist.hpp svmpc_tick_kernel): two sets of 5 x [tiles] arrival lines, then the time-out flag
+  unsigned int *tick_cnt;
+  int tick_tiles, tick_set;
+  int tick_occ;       // resident workgroups per CU of the instantiation in use (0: not queried yet)
+  size_t tick_occ_lds;
   // hipGraph replay of a whole tick (dust_svmpc_tick)
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
@@ -270,6 +276,7 @@ static void free_all(dust_ctx *c) {
   if (c->stein_cnt) (void)hipFree(c->stein_cnt);
   if (c->iter_cnt) (void)hipFree(c->iter_cnt);
   if (c->score_hs) (void)hipFree(c->score_hs);
+  if (c->tick_cnt) (void)hipFree(c->tick_cnt);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -375,6 +382,9 @@ extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
 }
 
 static void graph_drop(dust_ctx *c);
+static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
+                          bool *done);
+static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights);
 
 extern "C" int dust_sync(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
@@ -393,6 +403,11 @@ extern "C" int dust_sync(dust_ctx *c) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(DUST_ERR_HIP, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid)");
+  }
+  if (c->tick_cnt) {
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->tick_cnt + (size_t)2 * (5 * c->tick_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid)");
   }
   return DUST_OK;
 }
@@ -1508,6 +1523,11 @@ extern "C" int dust_svmpc_optimize(dust_ctx *c, const float *state, int n_steps,
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: drive it with dust_svmpc_local_score / dust_svmpc_apply_phi");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (n_steps >= 1) {
+    bool done = false;
+    TRY(try_persistent(c, state, n_steps, eps, params, flags, /*do_forward=*/false, &done));
+    if (done) return DUST_OK;
+  }
   TRY(upload_state_params(c, state, params, n_steps));
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats (binary16: S*N*D is even or n_steps is 1)
   if ((flags & DUST_EPS_F16) && eps && n_steps > 1 && (((size_t)c->S * c->N * c->D) & 1))
@@ -1567,6 +1587,8 @@ static int forward_finish_device(dust_ctx *c) {
   r.i0 = c->n0;
   r.n_local = c->nloc;
   r.ctr = c->ctr_dev;
+  r.adam_m = c->adam_m;
+  r.adam_v = c->adam_v;
   if (c->iter_cnt) {
     r.rearm = c->iter_cnt;
     r.rearm_lines = 2 * (2 * c->iter_tiles + c->iter_js);
@@ -1602,6 +1624,219 @@ extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
   return DUST_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launch per control tick (persist.hpp).  *done stays false when the shape / configuration does not qualify; the caller
+// then runs the launch-per-iteration path.  eps_dev: device [n_steps][S][N][D] fp32 or nullptr (Philox).
+template <int MODEL, int MODE, int CPT>
+static int tick_occupancy(size_t lds, int *occ) {
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)svmpc_tick_kernel<MODEL, MODE, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, (const void *)svmpc_tick_kernel<MODEL, MODE, CPT>, PAIR_NT, lds));
+  return DUST_OK;
+}
+
+static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
+  *done = false;
+  const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;  // development switches (read per call)
+  if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
+  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
+  if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
+  if (do_forward && !c->have_sample && n_steps == 0) return DUST_OK;
+  if (c->noise_f16 && eps_dev) return DUST_OK;
+  if (c->N > 4096) return DUST_OK;
+  const int cpt = cpt_for(c->D);
+  if (cpt > 8) return DUST_OK;
+  TickArgs f;
+  memset(&f, 0, sizeof f);
+  TRY(prior_args(c, f.prior, &f.tiles));
+  if (f.prior.JS > 16 || f.prior.slice > PAIR_JC) return DUST_OK;
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = eps_dev ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = eps_dev;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  o.bump_adam = 1;
+  o.merge_prior = 1;
+  int nt;
+  size_t lds_r;
+  TRY(rollout_args(c, o, f.ra, &nt, &lds_r));
+  if (f.ra.tile_scratch || (PAIR_NT % nt) != 0 || f.ra.G > 1) return DUST_OK;
+  if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // LEAN rollout body only
+  f.ra.rearm = nullptr;
+  f.ra.rearm_n = 0;
+  f.sub_nt = nt;
+  f.per_block = PAIR_NT / nt;
+  if (c->N % f.per_block || PAIR_TI % f.per_block) return DUST_OK;
+  // prior means aliasing theta + isotropic prior scale: the pair role stages once and computes the pair distances once
+  {
+    bool iso = true;
+    for (int d = 1; d < c->da; ++d) iso = iso && c->cfg.sigma_p[d] == c->cfg.sigma_p[0];
+    const bool no_share = getenv("DUST_NO_SHARE") != nullptr;  // development switch
+    f.share_pair = (c->mu_aliased && iso && !no_share) ? 1 : 0;
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    const float r = c->cfg.sigma_p[0] / ell;
+    f.stein_ratio = r * r;
+  }
+  const size_t lds_p = pairwise_lds_bytes(PAIR_K1, cpt) + sizeof(float) * (size_t)PAIR_TI * (PAIR_JC + 1) + sizeof(float) * PAIR_TI;  // + kvS, mrow
+  f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
+  const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
+  if (lds > 160 * 1024) return DUST_OK;
+  f.JS = f.prior.JS;
+  f.n_pair_blocks = f.tiles * f.JS;
+  f.n_own_blocks = c->N / f.per_block;
+  const int grid = f.n_pair_blocks + f.n_own_blocks;
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  // every workgroup must be resident for the whole launch: check the grid against the occupancy the runtime reports
+  if (!c->tick_occ || c->tick_occ_lds != lds) {
+    int occ = 0;
+#define DUST_TICK_OCC(MODEL, MODE, CPT) TRY((tick_occupancy<MODEL, MODE, CPT>(lds, &occ)))
+#define DUST_TICK_OCC_PICK(MODEL)                            \
+  do {                                                       \
+    if (c->cfg.kernel == DUST_KERNEL_IMQ) {                  \
+      if (cpt == 4) DUST_TICK_OCC(MODEL, PAIR_IMQ, 4);       \
+      else DUST_TICK_OCC(MODEL, PAIR_IMQ, 8);                \
+    } else {                                                 \
+      if (cpt == 4) DUST_TICK_OCC(MODEL, PAIR_K1, 4);        \
+      else DUST_TICK_OCC(MODEL, PAIR_K1, 8);                 \
+    }                                                        \
+  } while (0)
+    if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_TICK_OCC_PICK(DUST_MODEL_PENDULUM);
+    else DUST_TICK_OCC_PICK(DUST_MODEL_PARTICLE);
+#undef DUST_TICK_OCC_PICK
+#undef DUST_TICK_OCC
+    c->tick_occ = occ > 0 ? occ : -1;
+    c->tick_occ_lds = lds;
+  }
+  int n_cu = 0;
+  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device));
+  if (c->tick_occ < 1 || grid > c->tick_occ * n_cu) return DUST_OK;
+  {
+    const size_t nd = (size_t)f.JS * c->nloc * 8 * cpt;
+    TRY(ensure(&c->pS, &c->pS_cap, nd));
+  }
+  const int lines = 5 * f.tiles + 1;  // + the global log-weight line
+  if (!c->tick_cnt || c->tick_tiles != f.tiles) {
+    if (c->tick_cnt) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipFree(c->tick_cnt));
+    }
+    c->tick_cnt = nullptr;
+    TRY(dalloc(&c->tick_cnt, ((size_t)2 * lines + 1) * CNT_STRIDE));
+    HIP_TRY(hipMemsetAsync(c->tick_cnt, 0, ((size_t)2 * lines + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+    c->tick_tiles = f.tiles;
+    c->tick_set = 0;
+  }
+  if (c->cfg.dim_p > 0 && c->M >= 1 && !c->params_dev) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  f.stein = f.prior;
+  f.stein.V = c->score;
+  f.stein.logmix = nullptr;
+  {
+    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+    for (int d = 0; d < 4; ++d) f.stein.inv_s[d] = 1.0f / ell;
+  }
+  f.stein.pA = c->pS;
+  f.stein.pB = c->pB;
+  f.stein.pM = nullptr;
+  f.stein.pL = nullptr;
+  f.stein.stamps = nullptr;
+  f.prior.stamps = nullptr;
+  f.ra.stamps = nullptr;
+  f.ua = update_args(c, 1);
+  f.ua.pA = c->pS;
+  f.ua.fused_cnt = nullptr;
+  f.ua.fused_tiles = 0;
+  f.pm = prior_merge_args(c);
+  f.n_iters = n_steps;
+  f.do_forward = do_forward ? 1 : 0;
+  f.mu_aliased = c->mu_aliased ? 1 : 0;
+  f.roll_strategy = c->cfg.roll_strategy;
+  f.weighted_prior = c->cfg.weighted_prior;
+  f.theta_buf0 = c->theta;
+  f.theta_buf1 = c->theta_alt;
+  f.mu = c->mu;
+  for (int k = 0; k < 4; ++k) f.x0[k] = k < c->ds ? state[k] : 0.f;
+  f.eps = eps_dev;
+  f.eps_stride = (size_t)c->S * c->N * c->D;
+  f.params = (c->cfg.dim_p > 0 && c->params_dev) ? c->params_dev : nullptr;
+  unsigned int *set = c->tick_cnt + (size_t)c->tick_set * lines * CNT_STRIDE;
+  f.cnt_theta = set;
+  f.cnt_prior = set + (size_t)1 * f.tiles * CNT_STRIDE;
+  f.cnt_score = set + (size_t)2 * f.tiles * CNT_STRIDE;
+  f.cnt_stein = set + (size_t)3 * f.tiles * CNT_STRIDE;
+  f.cnt_lw = set + (size_t)4 * f.tiles * CNT_STRIDE;
+  f.zero_base = c->tick_cnt + (size_t)(1 - c->tick_set) * lines * CNT_STRIDE;
+  f.zero_lines = lines;
+  f.timeout_flag = c->tick_cnt + (size_t)2 * lines * CNT_STRIDE;
+  f.logp = c->logp;
+  f.lw = c->lw;
+  f.pw = c->pw;
+  f.a_seq_out = c->a_seq_out;
+  f.logmix = c->logmix;
+  f.mixw = c->mixw;
+  f.istar = c->istar;
+  f.tl = c->tl_dev;
+#define DUST_LAUNCH_TICK(MODEL, MODE, CPT) svmpc_tick_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
+#define DUST_PICK_TICK(MODEL)                                       \
+  do {                                                              \
+    if (c->cfg.kernel == DUST_KERNEL_IMQ) {                         \
+      if (cpt == 4) DUST_LAUNCH_TICK(MODEL, PAIR_IMQ, 4);           \
+      else DUST_LAUNCH_TICK(MODEL, PAIR_IMQ, 8);                    \
+    } else {                                                        \
+      if (cpt == 4) DUST_LAUNCH_TICK(MODEL, PAIR_K1, 4);            \
+      else DUST_LAUNCH_TICK(MODEL, PAIR_K1, 8);                     \
+    }                                                               \
+  } while (0)
+  if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_TICK(DUST_MODEL_PENDULUM);
+  else DUST_PICK_TICK(DUST_MODEL_PARTICLE);
+#undef DUST_PICK_TICK
+#undef DUST_LAUNCH_TICK
+  HIP_TRY(hipGetLastError());
+  c->tick_set ^= 1;
+  if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
+  if (do_forward) c->mu_aliased = true;
+  c->actions_valid = false;
+  c->have_sample = true;
+  c->fused_dirty = c->fused_dirty;  // (the launch-per-iteration paths' counters are untouched)
+  *done = true;
+  return DUST_OK;
+}
+
+
+// stage the caller's inputs and try the persistent launch; *done = false -> nothing was launched
+static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
+                          bool *done) {
+  *done = false;
+  const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;
+  if (off || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
+  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
+  if (c->N > 4096 || c->D > 64 || pair_is_big(c)) return DUST_OK;
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, nullptr, params, n_steps));
+  const float *eps_dev = eps;
+  c->noise_f16 = false;
+  if (eps && !(flags & DUST_PTR_DEVICE)) {
+    const size_t n = (size_t)n_steps * c->S * c->N * c->D;
+    TRY(ensure(&c->noise_stage, &c->noise_cap, n));
+    TRY(h2d(c, c->noise_stage, eps, n * sizeof(float)));
+    eps_dev = c->noise_stage;
+  }
+  return launch_tick(c, state, n_steps, eps_dev, do_forward, done);
+}
+
+// a_seq / p_weights of the tick just enqueued -> host; a timed-out hand-off inside the tick is an ERROR here, not stale data
+static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights) {
+  if (a_seq) HIP_TRY(hipMemcpyAsync(a_seq, c->a_seq_out, c->D * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (p_weights) HIP_TRY(hipMemcpyAsync(p_weights, c->pw, c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  unsigned int flag = 0;
+  if (c->tick_cnt) HIP_TRY(hipMemcpyAsync(&flag, c->tick_cnt + (size_t)2 * (5 * c->tick_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (flag) return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+  return DUST_OK;
+}
+
 static void graph_drop(dust_ctx *c) {
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -1616,6 +1851,14 @@ static void graph_drop(dust_ctx *c) {
 extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags,
                                float *a_seq, float *p_weights) {
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  {  // one persistent launch for the whole tick when the shape allows it (persist.hpp)
+    bool done = false;
+    TRY(try_persistent(c, state, n_steps, eps, params, flags, /*do_forward=*/true, &done));
+    if (done) {
+      if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+      return DUST_OK;
+    }
+  }
   static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
                          c->mu_aliased && c->own_stream;
@@ -1919,8 +2162,8 @@ extern "C" int dust_debug_stamps(dust_ctx *c, int kernel_id, unsigned long long 
   if (!c->stamps_dev) {
     HIP_TRY(hipMalloc((void **)&c->stamps_dev, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->stamps_dev, 0, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&c->tl_dev, 8192 * 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->tl_dev, 0, 8192 * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&c->tl_dev, 2048 * 64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->tl_dev, 0, 2048 * 64 * sizeof(unsigned long long)));
     return DUST_OK;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -188,13 +188,17 @@ struct RollArgs {
   int rearm_lines;      // zeroed here, so that a tick - and a replayed graph - starts with both sets clean
   unsigned int *hs;     // both score hand-off buffers of the one-launch iteration (stein.hpp SCORE_SENTINEL) or nullptr:
   int hs_n;             // filled with the sentinel again
+  // SVMPC.roll builds a NEW parameter tensor (theta.roll(...), svmpc.py:142-158) and stores it into the optimiser's param group:
+  // torch keys optimiser state by tensor object, so Adam's exp_avg / exp_avg_sq / step restart at zero after every forward()
+  float *adam_m, *adam_v;  // [N][D] or nullptr (SGD)
 };
 
 __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
   __shared__ float red[32];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // next tick: new Philox sub-stream
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // next tick: new Philox sub-stream, fresh optimiser step count
     a.ctr[0] += 1u;
     a.ctr[1] = 0u;
+    a.ctr[2] = 0u;
   }
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t < a.rearm_lines; t += blockDim.x) a.rearm[t * 32] = 0u;
@@ -212,7 +216,13 @@ __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
     }
   }
   __syncthreads();
-  if (j < D) a.theta_dst[(size_t)i * D + j] = out;
+  if (j < D) {
+    a.theta_dst[(size_t)i * D + j] = out;
+    if (a.adam_m) {
+      a.adam_m[(size_t)i * D + j] = 0.f;
+      a.adam_v[(size_t)i * D + j] = 0.f;
+    }
+  }
 }
 
 // finalize + roll in ONE launch (1024-lane workgroups: workgroup 0 finalizes, every other one rolls 8 particles).  Only
@@ -224,6 +234,7 @@ __global__ __launch_bounds__(1024) void finalize_roll_kernel(const FinalizeArgs 
     if (threadIdx.x == 0) {
       a.ctr[0] += 1u;
       a.ctr[1] = 0u;
+      a.ctr[2] = 0u;
     }
     return;
   }
@@ -234,7 +245,13 @@ __global__ __launch_bounds__(1024) void finalize_roll_kernel(const FinalizeArgs 
   if (il >= a.n_local) return;
   const int i = a.i0 + il, D = a.H * a.da;
   const float *th = a.theta + (size_t)i * D;
-  if (j < D) a.theta_dst[(size_t)i * D + j] = (j + a.da < D) ? th[j + a.da] : th[j];
+  if (j < D) {
+    a.theta_dst[(size_t)i * D + j] = (j + a.da < D) ? th[j + a.da] : th[j];
+    if (a.adam_m) {
+      a.adam_m[(size_t)i * D + j] = 0.f;
+      a.adam_v[(size_t)i * D + j] = 0.f;
+    }
+  }
 }
 
 // a_mix = softmax_n(eta) disco.py:393 (single workgroup)

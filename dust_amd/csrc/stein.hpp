@@ -67,19 +67,24 @@ struct RowLane {
   static constexpr int RB = NT / W;
   static constexpr int NB = TR / RB;
 };
-template <int TR, int DP, int NT>
-__device__ __forceinline__ void rowlane_issue(const float *__restrict__ src, int r0, int nrows, int D, float (&v)[RowLane<TR, DP, NT>::NB]) {
+// SC1: the rows were written (write-through) by other workgroups of the SAME launch: every load bypasses this CU's L1
+template <int TR, int DP, int NT, bool SC1 = false>
+__device__ __forceinline__ void rowlane_issue(const float *__restrict__ src, int r0, int nrows, int D, float (&v)[RowLane<TR, DP, NT>::NB],
+                                              const int tx = (int)threadIdx.x) {
   using RL = RowLane<TR, DP, NT>;
-  const int lr = (int)threadIdx.x / RL::W, lc = min((int)threadIdx.x % RL::W, D - 1);
+  const int lr = tx / RL::W, lc = min(tx % RL::W, D - 1);
   const float *base = src + (size_t)r0 * D + lc;
 #pragma unroll
-  for (int u = 0; u < RL::NB; ++u) v[u] = base[(size_t)min(u * RL::RB + lr, nrows - 1) * D];
+  for (int u = 0; u < RL::NB; ++u) {
+    const float *p = base + (size_t)min(u * RL::RB + lr, nrows - 1) * D;
+    v[u] = SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+  }
 }
 template <int TR, int DP, int LS, int NT, bool SCALE>
 __device__ __forceinline__ void rowlane_commit(const float (&v)[RowLane<TR, DP, NT>::NB], int nrows, int D, int da, const float *colscale,
-                                               float *dst) {
+                                               float *dst, const int tx = (int)threadIdx.x) {
   using RL = RowLane<TR, DP, NT>;
-  const int lr = (int)threadIdx.x / RL::W, lc = (int)threadIdx.x % RL::W;
+  const int lr = tx / RL::W, lc = tx % RL::W;
   if (lc >= DP) return;  // W > DP (DP = 96): idle lanes
   const float sc = SCALE ? colscale[da == 1 ? 0 : (da == 2 ? (lc & 1) : lc % da)] : 1.0f;
   const bool cv = lc < D;
@@ -90,8 +95,12 @@ __device__ __forceinline__ void rowlane_commit(const float (&v)[RowLane<TR, DP, 
   }
 }
 
-template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */>
-__device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, const int tile_x, const int js, const bool write_through = false) {
+template <int MODE, int CPT /* columns per lane in pass B: multiple of 4, 8*CPT >= D */, bool SC1 = false /* X / Y were written inside this launch */>
+__device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, const int tile_x, const int js, const bool write_through = false,
+                                              const float *Xo = nullptr, const float *Yo = nullptr /* override a.X / a.Y (persistent tick) */,
+                                              const int tx = (int)threadIdx.x /* lane index; the persistent tick passes an opaque copy per
+                                              iteration so that the lane-derived addresses of every body are not all hoisted out of its loop */,
+                                              unsigned long long *tlp = nullptr /* diagnostic build: timeline slots */) {
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
   constexpr bool PRI = MODE == PAIR_PRIOR || MODE == PAIR_LOGP;  // softmax-weighted passes over the prior mixture
   constexpr bool LOGP = MODE == PAIR_LOGP;                        // ... of which forward needs only the log-density
@@ -104,7 +113,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   float *Vs = Ys + JC * YS;         // [JC][YS]   score (Stein), unscaled
   float *kv = Vs + (PRI ? 0 : JC * YS);  // [TI][JC + 1]
   float *mrow = kv + TI * (JC + 1); // [TI] running max
-  const int tid = threadIdx.x;
+  const int tid = tx;
   const int D = a.D, da = a.da, N = a.N;
   const int ib = a.i0 + tile_x * TI;  // first query (global index)
   const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
@@ -114,13 +123,13 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   const int nq = min(TI, a.i0 + a.n_local - ib), jc0 = min(JC, jend - jbeg);
   {
     float vx[RowLane<TI, DP, NT>::NB], vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
-    rowlane_issue<TI, DP, NT>(a.X, ib, nq, D, vx);
-    rowlane_issue<JC, DP, NT>(a.Y, jbeg, jc0, D, vy);
-    if (!PRI) rowlane_issue<JC, DP, NT>(a.V, jbeg, jc0, D, vv);
+    rowlane_issue<TI, DP, NT, SC1>(Xo ? Xo : a.X, ib, nq, D, vx, tid);
+    rowlane_issue<JC, DP, NT, SC1>(Yo ? Yo : a.Y, jbeg, jc0, D, vy, tid);
+    if (!PRI) rowlane_issue<JC, DP, NT, SC1>(a.V, jbeg, jc0, D, vv, tid);
     if (tid < TI) mrow[tid] = -INFINITY;
-    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs);
-    rowlane_commit<JC, DP, YS, NT, true>(vy, jc0, D, da, a.inv_s, Ys);
-    if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc0, D, da, a.inv_s, Vs);
+    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs, tid);
+    rowlane_commit<JC, DP, YS, NT, true>(vy, jc0, D, da, a.inv_s, Ys, tid);
+    if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc0, D, da, a.inv_s, Vs, tid);
   }
 
   // pass-B ownership: query iB, columns [cB, cB + CPT)
@@ -152,13 +161,14 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     const float lm = (PRI) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;  // issued with the tile loads
     if (j0 != jbeg) {  // later chunks of a long slice (the first one was staged with the query tile)
       float vy[RowLane<JC, DP, NT>::NB], vv[RowLane<JC, DP, NT>::NB];
-      rowlane_issue<JC, DP, NT>(a.Y, j0, jc, D, vy);
-      if (!PRI) rowlane_issue<JC, DP, NT>(a.V, j0, jc, D, vv);
-      rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys);  // the barrier that ended the previous chunk's pass B
-      if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);  // protects these writes
+      rowlane_issue<JC, DP, NT, SC1>(Yo ? Yo : a.Y, j0, jc, D, vy, tid);
+      if (!PRI) rowlane_issue<JC, DP, NT, SC1>(a.V, j0, jc, D, vv, tid);
+      rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys, tid);  // the barrier that ended the previous chunk's pass B
+      if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs, tid);  // protects these writes
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 2);
+    DUST_TLP(tlp, 3);
     // ---- pass A: lane = key j, QPG queries per lane; packed math: 2 dims per v_pk_add / v_pk_fma ----
     {
       // packed math: 2 dims per v_pk_add / v_pk_fma.  (The Gram value uses the bare v_exp_f32: inlining ocml expf eight
@@ -189,6 +199,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       }
     }
     __syncthreads();
+    DUST_TLP(tlp, 4);
     if (PRI) {
       // online softmax over key chunks: row max (8 lanes per query), rescale, exponentiate in place
       float m = -INFINITY;
@@ -219,6 +230,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       __syncthreads();
     }
     DUST_STAMP(a.stamps, 3);
+    DUST_TLP(tlp, 5);
     // ---- pass B: lane = (query, 8 column groups); packed math ----
     if (MFMA_A) {
       // A[i = col][k = key] = S[key][col] (lane: i = l % 16, k = l / 16), B[k = key][j = query] = K[query][key] (lane:
@@ -262,6 +274,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
   }
 
   DUST_STAMP(a.stamps, 4);
+  DUST_TLP(tlp, 6);
   // ---- partial outputs (differences were accumulated in scaled coordinates: undo the 1/s_d) ----
   const int il = tile_x * TI + iB;  // local row
   if (il < a.n_local) {
@@ -305,6 +318,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
     }
   }
   DUST_STAMP(a.stamps, 5);
+  DUST_TLP(tlp, 7);
 }
 
 // Stein tile of the one-launch SVGD iteration (fused.hpp svgd_iter_kernel): the same arithmetic as pairwise_body<K1|IMQ> on a
@@ -312,9 +326,36 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 // theta - the Gram values (pass A) and the repulsive term sum_j k'_ij (x_i - x_j) - runs BEFORE the wait on the score rows,
 // i.e. underneath the rollouts of the same launch; after the wait only the score tile load, the Gram x score MFMAs and the
 // 16-byte partial stores remain on the critical path.  Accumulation orders are those of pairwise_body (bitwise equal).
-template <int MODE, int CPT>
+// Bounded wait of ONE lane on a monotonic arrival counter (wrap-safe compare).  A spin gives up after ~50 ms of wall clock
+// (s_memrealtime, 100 MHz) or as soon as another waiter has given up, and raises the flag: the host reports it as an error.
+__device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned int target, unsigned int *flag) {
+  unsigned int spins = 0;
+  unsigned long long t0 = 0;
+  while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255u) == 0u) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (!t0) t0 = now;
+      else if (now - t0 > 5000000ull || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+// arrival lines [line0, line0 + nlines) of `cnt` (one counter per 128-byte line), each with its own target
+struct LineGate {
+  const unsigned int *cnt;
+  int line0, nlines;
+  unsigned int target0, target1;
+};
+
+template <int MODE, int CPT, bool SC1 = false>
 __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, const int tile_x, const int js, const unsigned int *score_cnt,
-                                                 const float *score_pub, unsigned int *timeout_flag, unsigned long long *tl) {
+                                                 const float *score_pub, unsigned int *timeout_flag, unsigned long long *tl,
+                                                 const LineGate *gate = nullptr, const float *XYo = nullptr /* override a.X = a.Y */,
+                                                 const int tx = (int)threadIdx.x, unsigned long long *tlp = nullptr) {
   static_assert(MODE == PAIR_K1 || MODE == PAIR_IMQ, "Stein modes only");
   static_assert(CPT <= 8, "the Gram x score product runs on the matrix cores (D <= 64)");
   constexpr int TI = PAIR_TI, JC = PAIR_JC, NT = PAIR_NT;
@@ -323,17 +364,17 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
   float *Ys = Xs + TI * DP;          // [JC][YS]  keys / ell
   float *Vs = Ys + JC * YS;          // [JC][YS]  score rows
   float *kv = Vs + JC * YS;          // [TI][JC + 1] Gram values
-  const int tid = threadIdx.x;
+  const int tid = tx;
   const int D = a.D, da = a.da, N = a.N;
   const int ib = a.i0 + tile_x * TI;
   const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
   const int nq = min(TI, a.i0 + a.n_local - ib), jc = min(JC, jend - jbeg);
   {
     float vx[RowLane<TI, DP, NT>::NB], vy[RowLane<JC, DP, NT>::NB];
-    rowlane_issue<TI, DP, NT>(a.X, ib, nq, D, vx);
-    rowlane_issue<JC, DP, NT>(a.Y, jbeg, jc, D, vy);
-    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs);
-    rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys);
+    rowlane_issue<TI, DP, NT, SC1>(XYo ? XYo : a.X, ib, nq, D, vx, tid);
+    rowlane_issue<JC, DP, NT, SC1>(XYo ? XYo : a.Y, jbeg, jc, D, vy, tid);
+    rowlane_commit<TI, DP, DP, NT, true>(vx, nq, D, da, a.inv_s, Xs, tid);
+    rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys, tid);
   }
   const int iB = tid >> 3, cB = (tid & 7) * CPT;
   v2f accB[CPT / 2];
@@ -341,6 +382,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
   for (int c = 0; c < CPT / 2; ++c) accB[c] = v2f{0.f, 0.f};
   const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;
   __syncthreads();
+  DUST_TLP(tlp, 8);
   v2f xB[CPT / 2];
 #pragma unroll
   for (int c = 0; c < CPT / 2; ++c) xB[c] = *reinterpret_cast<const v2f *>(&Xs[iB * DP + cB + 2 * c]);
@@ -371,6 +413,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
     }
   }
   __syncthreads();
+  DUST_TLP(tlp, 9);
   // repulsive term: lane = (query, 8 column groups)
 #pragma unroll 4
   for (int jj = 0; jj < JC; ++jj) {
@@ -402,6 +445,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
   }
   // ---- the score rows of this key slice, published by the rollout role of this launch ----
   DUST_TL(tl, 1);
+  DUST_TLP(tlp, 10);
   using RLV = RowLane<JC, DP, NT>;
   float vv[RLV::NB];
   const int vlr = tid / RLV::W, vlc = min(tid % RLV::W, D - 1);
@@ -429,7 +473,9 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
     }
     DUST_TL(tl, 2);
   } else {
-    if (tid == 0) {
+    if (gate) {  // persistent tick (persist.hpp): the keys' score rows are counted per 32-particle group
+      if (tid < gate->nlines) spin_until(gate->cnt + (size_t)(gate->line0 + tid) * 32, tid == 0 ? gate->target0 : gate->target1, timeout_flag);
+    } else if (tid == 0) {
       const unsigned int target = (unsigned int)(jend - jbeg);
       unsigned int spins = 0;
       while (__hip_atomic_load(score_cnt + js * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {  // 32 = CNT_STRIDE (rollout.hpp)
@@ -447,7 +493,9 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
 #pragma unroll
     for (int u = 0; u < RLV::NB; ++u) vv[u] = __hip_atomic_load(base + (size_t)min(u * RLV::RB + vlr, jc - 1) * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs);
+  DUST_TLP(tlp, 11);
+  if (gate) __builtin_amdgcn_s_setprio(3);  // persistent tick: from here on the tile is on the critical path
+  rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs, tid);
   __syncthreads();
   v4f accM[TPW];
 #pragma unroll
@@ -491,6 +539,7 @@ struct PriorMerge {
   float log_norm;  // -H sum(log sigma_p) - D/2 log(2 pi)
 };
 // loads are issued in batches of 8 with clamped (never predicated) indices so they overlap instead of serialising
+template <bool SC1 = false /* the partials were written (write-through) inside this launch */>
 __device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, float *m_out, float *l_out) {
   float m = -INFINITY, l = 0.f;
   for (int q0 = 0; q0 < pm.JS; q0 += 16) {  // 32 independent loads in flight: one round trip for JS <= 16
@@ -498,8 +547,8 @@ __device__ __forceinline__ void prior_merge_row(const PriorMerge &pm, int il, fl
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const size_t r = (size_t)min(q0 + u, pm.JS - 1) * pm.n_local + il;
-      mq[u] = pm.pM[r];
-      lq[u] = pm.pL[r];
+      mq[u] = SC1 ? __hip_atomic_load(pm.pM + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pm.pM[r];
+      lq[u] = SC1 ? __hip_atomic_load(pm.pL + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pm.pL[r];
     }
     float mc = -INFINITY;
 #pragma unroll
@@ -581,6 +630,22 @@ struct UpdateArgs {
 
 // `sc1`: the partials were published inside the SAME launch (fused.hpp stein_update_kernel) with write-through stores and
 // must be read with sc1 loads; across a kernel boundary plain loads do.
+// torch.optim.Adam, single-tensor CPU path (svgd.py:115 is the reference's class default), on grad = -phi: lerp_ for exp_avg
+// (vectorised form: fmadd(w, grad - m, m)), mul_ + addcmul_ for exp_avg_sq ((value * g) * g), bias corrections / step size /
+// sqrt(bias_correction2) as Python floats (double), addcdiv_ as self + (value * m) / denom.  `t` is the 1-based step count
+// since the last roll (the optimiser state restarts at every forward(): forward.hpp RollArgs).
+__device__ __forceinline__ float adam_step(float th, const float g, float &m, float &v, const float lr, const float beta1, const float beta2,
+                                           const float eps, const float t) {
+  const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float value = (float)(-((double)lr / bc1)), bc2s = (float)sqrt(bc2);
+  m = fmaf(w1, g - m, m);
+  v = v * beta2;
+  v = v + (w2 * g) * g;
+  const float denom = sqrtf(v) / bc2s + eps;
+  return th + (value * m) / denom;
+}
+
 template <bool SC1>
 __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) {
   if (idx < a.fused_tiles) a.fused_cnt[idx * 32] = 0u;  // CNT_STRIDE (rollout.hpp): one counter per 128-byte line
@@ -622,13 +687,9 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
     th = fmaf(-a.lr, g, th);  // torch SGD: p.add_(grad, alpha=-lr), a vectorised fmadd
   } else {  // torch.optim.Adam (no weight decay, no amsgrad)
     float m = a.adam_m[o], v = a.adam_v[o];
-    m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
-    v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+    th = adam_step(th, g, m, v, a.lr, a.beta1, a.beta2, a.eps, adam_t);
     a.adam_m[o] = m;
     a.adam_v[o] = v;
-    const float bc1 = 1.f - powf(a.beta1, adam_t), bc2 = 1.f - powf(a.beta2, adam_t);
-    const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
-    th = th - (a.lr / bc1) * (m / denom);
   }
   a.theta_out[o] = th;
 }
@@ -650,13 +711,9 @@ __global__ void update_from_phi_kernel(const UpdateArgs a) {
     th = fmaf(-a.lr, g, th);
   } else {
     float m = a.adam_m[o], v = a.adam_v[o];
-    m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
-    v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+    th = adam_step(th, g, m, v, a.lr, a.beta1, a.beta2, a.eps, adam_t);
     a.adam_m[o] = m;
     a.adam_v[o] = v;
-    const float bc1 = 1.f - powf(a.beta1, adam_t), bc2 = 1.f - powf(a.beta2, adam_t);
-    const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
-    th = th - (a.lr / bc1) * (m / denom);
   }
   a.theta[o] = th;
 }

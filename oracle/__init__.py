@@ -240,6 +240,14 @@ class Oracle:
         lib().orc_sgd(C.c_int(theta.size), C.c_float(lr), _p(phi), _p(theta))
         return theta
 
+    @staticmethod
+    def adam(theta, phi, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam step (svgd.py:115); returns (theta, m, v).  `step` is 1-based and restarts after every roll."""
+        theta, phi, m, v = _f(theta).copy(), _f(phi), _f(m).copy(), _f(v).copy()
+        lib().orc_adam(C.c_int(theta.size), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps), C.c_int(step),
+                       _p(phi), _p(theta), _p(m), _p(v))
+        return theta, m, v
+
     # -- a12
     def forward(self, costs, theta, mu, mix_weights, sigma_p, alpha, lik=LIK_EXP_UTILITY, weighted_prior=False, roll=ROLL_REPEAT):
         c = self.c

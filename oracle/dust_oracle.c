@@ -490,6 +490,28 @@ void orc_sgd(int n, float lr, const float *phi, float *theta) {
   for (int i = 0; i < n; ++i) theta[i] = fmaf(lr, phi[i], theta[i]); /* add_(grad, alpha=-lr) is a vec fmadd */
 }
 
+/* torch.optim.Adam (the reference's class default, svgd.py:115; no weight decay, no amsgrad), as torch 2.x's single-tensor CPU
+ * path runs it with theta.grad = -phi (svmpc.py:93-94):
+ *   exp_avg.lerp_(grad, 1 - beta1)                       vectorised lerp, |w| < 0.5: fmadd(w, grad - exp_avg, exp_avg)
+ *   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)  self + (value * t1) * t2
+ *   bias corrections, step size and sqrt(bias_correction2) are Python floats (double);
+ *   denom = exp_avg_sq.sqrt() / sqrt(bc2) + eps;  param.addcdiv_(exp_avg, denom, value=-step_size): self + (value * t1) / t2
+ * `step` is the 1-based step count SINCE THE LAST roll: SVMPC.roll (svmpc.py:142-158) replaces theta by a new tensor and torch
+ * keys optimiser state by tensor object, so exp_avg / exp_avg_sq / step restart at every forward(). */
+void orc_adam(int n, float lr, float beta1, float beta2, float eps, int step, const float *phi, float *theta, float *m, float *v) {
+  const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float value = (float)(-((double)lr / bc1)), bc2s = (float)sqrt(bc2);
+  for (int i = 0; i < n; ++i) {
+    const float g = -phi[i];
+    m[i] = fmaf(w1, g - m[i], m[i]);
+    v[i] = v[i] * beta2;
+    v[i] = v[i] + (w2 * g) * g;
+    const float denom = sqrtf(v[i]) / bc2s + eps;
+    theta[i] = theta[i] + (value * m[i]) / denom;
+  }
+}
+
 /* svmpc.py:128-200 */
 void orc_forward(const orc_cfg *c, int lik_kind, float alpha, const float *costs, float *theta, float *mu,
                  float *mix_weights, const float *sigma_p, int weighted_prior, int roll_strategy, float *log_l,

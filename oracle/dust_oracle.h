@@ -96,6 +96,8 @@ void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, const float *th
 
 /* a8 SGD step svmpc.py:87-95 */
 void orc_sgd(int n, float lr, const float *phi, float *theta);
+/* torch.optim.Adam step on theta.grad = -phi (svgd.py:115, svmpc.py:87-95); step counts from 1 after every roll */
+void orc_adam(int n, float lr, float beta1, float beta2, float eps, int step, const float *phi, float *theta, float *m, float *v);
 
 /* a12 SVMPC.forward svmpc.py:128-200 + likelihoods.py:113-135 + svgd.py:84-89 */
 void orc_forward(const orc_cfg *c, int lik_kind, float alpha, const float *costs, float *theta, float *mu,

@@ -147,6 +147,9 @@ def run_svmpc(
     state0=None,
     theta_shrink=1.0,
     ctrl_penalty=1.0,
+    optimizer="SGD",
+    lr_override=None,
+    k1_f64=False,
 ):
     torch.manual_seed(seed)
     params_log_space = False
@@ -173,6 +176,8 @@ def run_svmpc(
         elif params_kind == "scalar_normal":  # particle_example.py:55 when use_mpf is false (scalar event)
             pdist = RecordingDist(dist.Normal(2.0, 0.1))
 
+    if lr_override is not None:
+        lr = lr_override
     mu0 = torch.randn(N, H, da)
     prior = get_gmm(mu0, torch.ones(N), sigma_p ** 2 * torch.eye(da))
     theta0 = prior.sample([N])
@@ -216,7 +221,7 @@ def run_svmpc(
         n_particles=N,
         bw_scale=1.0,
         n_steps=1,
-        optimizer_class=torch.optim.SGD,
+        optimizer_class=torch.optim.SGD if optimizer == "SGD" else torch.optim.Adam,
         lr=lr,
         weighted_prior=weighted_prior,
         roll_strategy=roll_strategy,
@@ -230,7 +235,15 @@ def run_svmpc(
         theta0=npf(theta0), mu0=npf(mu0), mix0=np.ones(N, np.float32), a_mat0=npf(controller.a_mat),
     )
     keys = ["state", "eps", "params", "params_log_p", "actions", "costs", "omega_amat", "a_mix", "grad_pri", "phi",
-            "theta_after", "states_iter0"]
+            "theta_after", "states_iter0", "theta_in", "score", "phi_f64"]
+    # K1 third-party boundary (k1_f64): record the score the reference hands to its kernel branch (the tensordot operand at
+    # svmpc.py:83) and evaluate that same branch - svmpc.py:76-83, the gpytorch-semantics kernel - in float64 on the same inputs
+    _orig_tensordot = torch.tensordot
+    _td = []
+
+    def _rec_tensordot(a_, b_, dims=2, **kw):
+        _td.append((a_.detach().clone(), b_.detach().clone()))
+        return _orig_tensordot(a_, b_, dims, **kw)
     per = {k: [] for k in keys}
     tick = {k: [] for k in ["log_l", "log_p", "p_weights", "a_seq", "theta_rolled", "prior_means", "prior_probs"]}
 
@@ -243,7 +256,22 @@ def run_svmpc(
             _REC.clear()
             if pdist is not None:
                 pdist.draws.clear()
+            if k1_f64:
+                per["theta_in"].append(npf(svmpc.theta))
+                _td.clear()
+                torch.tensordot = _rec_tensordot
             svmpc.optimize(state, pdist, n_steps=1)  # svmpc.py:97 -> step -> phi -> likelihood.sample -> forward
+            if k1_f64:
+                torch.tensordot = _orig_tensordot
+                k_xx32, score32 = _td[-1]  # svmpc.py:83
+                assert tuple(score32.shape) == (N, H, da) and tuple(k_xx32.shape) == (N, N)
+                per["score"].append(npf(score32))
+                x64 = torch.from_numpy(per["theta_in"][-1]).double().requires_grad_(True)
+                k64 = ref_shim.RBFKernel()
+                k64.raw_lengthscale = k64.raw_lengthscale.double()
+                kxx = k64(x64.flatten(1, -1), x64.detach().clone().flatten(1, -1)).evaluate()
+                grad_k = torch.autograd.grad(kxx.sum(), x64)[0]
+                per["phi_f64"].append(npf(grad_k + _orig_tensordot(kxx.detach(), score32.double(), 1) / x64.size(0)))
             eps = [r for r in _REC if tuple(r.shape) == (S, N, H, da)]
             assert len(eps) == 1, [tuple(r.shape) for r in _REC]
             per["eps"].append(npf(eps[0]))

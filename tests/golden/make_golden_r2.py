@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Round-2 golden vectors, produced by running the REFERENCE (lubaroli/dust) in this container - TEST INFRASTRUCTURE.
+
+  python tests/golden/make_golden_r2.py          (needs /root/reference; writes tests/golden/*.npz)
+
+  * pend_k1_adam / part_k1_adam: SVMPC with the reference's class-default optimiser, torch.optim.Adam (svgd.py:115), over three
+    control ticks: pins the Adam step AND the reset of its state at every forward() (SVMPC.roll makes a new parameter tensor,
+    svmpc.py:142-158, so torch's per-tensor optimiser state starts again);
+  * pend_k1_f64 / pend_k1_mid_f64: the K1 kernel branch (svmpc.py:76-83; gpytorch RBFKernel semantics - third party, absent) ALSO
+    evaluated in float64 on the recorded fp32 inputs (theta, score): the fp32 stand-in carries cancellation noise of its
+    matmul-trick distance, the float64 run does not, so oracle and HIP can be held to 1e-5 against it.
+Same recording machinery as make_golden.py (run_svmpc); nothing here re-implements the reference's arithmetic.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg  # noqa: E402  (installs the shim, imports the reference)
+
+if __name__ == "__main__":
+    mg.run_svmpc("pend_k1_adam", "pendulum", N=16, H=10, S=8, M=1, kernel_kind="K1", n_iters=3, n_ticks=3, seed=20, optimizer="Adam",
+                 lr_override=0.1)
+    mg.run_svmpc("part_k1_adam", "particle", N=8, H=12, S=8, M=4, kernel_kind="K1", weighted_prior=True, n_iters=2, n_ticks=3, seed=21,
+                 params_kind="logmass_gmm", optimizer="Adam", lr_override=0.5)
+    mg.run_svmpc("pend_k1_f64", "pendulum", N=16, H=10, S=8, M=1, kernel_kind="K1", n_iters=2, n_ticks=2, seed=22, theta_shrink=0.05,
+                 k1_f64=True, lr_override=0.02)  # (small step: the particles stay within a few lengthscales of each other)
+    mg.run_svmpc("pend_k1_mid_f64", "pendulum", N=24, H=12, S=8, M=1, kernel_kind="K1", n_iters=2, n_ticks=1, seed=23, theta_shrink=0.12,
+                 k1_f64=True, lr_override=0.02)

@@ -13,6 +13,18 @@ def elem_relerr(a, b, atol=0.0):
     return float((np.abs(a - b) / (np.abs(b) + atol + 1e-300)).max())
 
 
+def elemerr(a, b, floor=None):
+    """ELEMENT-WISE relative error with a stated absolute floor: max_i |a_i - b_i| / (|b_i| + floor).
+
+    floor defaults to rms(b): an entry is held to `tol` relative to its own magnitude or to the tensor's RMS, whichever is
+    larger (sums with cancellation - phi, grad_pri - cannot be relatively exact in their near-zero entries; the RMS floor is
+    1-2 orders tighter than the tensor-max form `relerr` and cannot hide a wrong small entry behind one large one)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if floor is None:
+        floor = float(np.sqrt(np.mean(b * b)))
+    return float((np.abs(a - b) / (np.abs(b) + floor + 1e-300)).max())
+
+
 def scenario_kwargs(g):
     """Oracle/ctx constructor kwargs for a golden SVMPC scenario (tests/golden/make_golden.py:run_svmpc)."""
     kind = str(g["model_kind"])
@@ -27,3 +39,8 @@ def scenario_kwargs(g):
         kw["params_log_space"] = bool(int(g["params_log_space"]))
         kw["params_scalar_event"] = bool(int(g["params_scalar_event"]))
     return kw
+
+
+def is_adam(name):
+    """Golden scenarios run with the reference's class-default optimiser (tests/golden/make_golden_r2.py)."""
+    return name.endswith("_adam")

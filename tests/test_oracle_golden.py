@@ -9,11 +9,13 @@ import pytest
 
 import oracle
 from oracle import Oracle
-from helpers import relerr, scenario_kwargs
+from helpers import elemerr, is_adam, relerr, scenario_kwargs
 
 TOL = 1e-5
 SVMPC_CASES = ["pend_k1", "pend_k1_close", "pend_k2", "pend_k1_params", "pend_k1_expcost", "pend_k1_ctrlpen", "pend_k1_mean",
-               "pend_cfg1", "part_k1_gmm", "part_k2_gmm", "part_k2shared", "part_k1_scalar", "part_k1_near_obst"]
+               "pend_cfg1", "part_k1_gmm", "part_k2_gmm", "part_k2shared", "part_k1_scalar", "part_k1_near_obst",
+               "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64"]
+K1_F64_CASES = ["pend_k1_f64", "pend_k1_mid_f64"]
 
 
 def k1_tolerance(theta):
@@ -46,13 +48,14 @@ def test_actions_rollout_costs(golden, name):
             a_pre = 1.0 / _sig(g, "sigma_a") ** 2
             if k == 0:
                 costs, states = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre, want_states=True)
-                assert relerr(states, g["states_iter0"][t]) < TOL
+                assert elemerr(states, g["states_iter0"][t]) < TOL
             else:
                 costs = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre)
-            assert relerr(costs, g["costs"][t, k]) < TOL, name
+            assert elemerr(costs, g["costs"][t, k]) < TOL, name
             # a6 side effects (MultiDISCO.forward): a_mat += sum_s omega eps ; a_mix
             _, a_mat, a_mix = o.disco_weights(g["costs"][t, k], actions, np.zeros(o.D), float(g["temperature"]), a_mat)
-            assert relerr(a_mat, g["omega_amat"][t, k]) < TOL
+            # omega-weighted sums of signed noise cancel (Particle: a handful of samples carry all the weight): 1e-4 element-wise
+            assert elemerr(a_mat, g["omega_amat"][t, k]) < (TOL if name != "part_k1_adam" else 1e-4)
             assert relerr(a_mix, g["a_mix"][t, k], floor=1e-30) < 1e-4  # softmax of O(1e3) logits: ulp(cost) amplification
             a_mat = g["omega_amat"][t, k]
             theta = g["theta_after"][t, k]
@@ -84,7 +87,7 @@ def test_score_phi_update(golden, name):
             mu, mix = _prior_at(g, t, theta)
             gl, gp, sc = o.score(theta, mu, mix, _sig(g, "sigma_p"), g["costs"][t, k], g["actions"][t, k], float(g["alpha"]),
                                  _sig(g, "sigma_a"))
-            assert relerr(gp, g["grad_pri"][t, k]) < TOL
+            assert elemerr(gp, g["grad_pri"][t, k]) < TOL
             if kind == "K1":
                 phi = o.phi_k1(theta, sc, variant=0)
                 tol = k1_tolerance(theta)
@@ -94,11 +97,36 @@ def test_score_phi_update(golden, name):
             else:
                 phi, _ = o.phi_k2(theta, sc, indep=False)
                 tol = TOL
-            assert relerr(phi, g["phi"][t, k]) < tol, (name, t, k)
-            th1 = o.sgd(theta, g["phi"][t, k], float(g["lr"]))
-            assert relerr(th1, g["theta_after"][t, k]) < 1e-6
+            assert elemerr(phi, g["phi"][t, k]) < tol, (name, t, k)
+            if is_adam(name):  # the reference's class default (svgd.py:115); its state restarts at every roll (svmpc.py:142-158)
+                if k == 0:
+                    m, v = np.zeros_like(theta), np.zeros_like(theta)
+                th1, m, v = o.adam(theta, g["phi"][t, k], m, v, k + 1, float(g["lr"]))
+                assert elemerr(th1, g["theta_after"][t, k]) < 2e-6, (name, t, k)
+            else:
+                th1 = o.sgd(theta, g["phi"][t, k], float(g["lr"]))
+                assert elemerr(th1, g["theta_after"][t, k]) < 1e-6
             theta = g["theta_after"][t, k]
         theta = g["tick_theta_rolled"][t]
+
+
+@pytest.mark.parametrize("name", K1_F64_CASES)
+def test_k1_branch_vs_float64_reference(golden, name):
+    """K1 (gpytorch RBFKernel semantics; third party, absent) against the SAME reference call evaluated in float64 on the
+    recorded fp32 inputs: the fp32 stand-in's matmul-trick distance carries cancellation noise (k1_tolerance), the float64 run
+    does not - so here the oracle meets 1e-5, element-wise, on particle sets close enough for a non-trivial Gram matrix."""
+    g = golden(name)
+    o = Oracle(**scenario_kwargs(g))
+    T, K = g["eps"].shape[:2]
+    worst_fp32, interacting = 0.0, 0
+    for t in range(T):
+        for k in range(K):
+            phi, gram = o.phi_k1(g["theta_in"][t, k], g["score"][t, k], variant=0, want_gram=True)
+            interacting += int((gram - np.diag(np.diag(gram))).max() > 1e-2)
+            assert elemerr(phi, g["phi_f64"][t, k]) < TOL, (name, t, k)
+            worst_fp32 = max(worst_fp32, elemerr(g["phi"][t, k], g["phi_f64"][t, k]))
+    assert interacting >= 2, "the fixture must have interacting particles (a Gram matrix that is not the identity)"
+    assert worst_fp32 < 5e-3  # (the fp32 stand-in itself is only this close to its own float64 evaluation)
 
 
 @pytest.mark.parametrize("name", SVMPC_CASES)
@@ -113,8 +141,8 @@ def test_forward(golden, name):
         mu, mix = _prior_at(g, t, g["theta_after"][t, K - 1])
         r = o.forward(g["costs"][t, K - 1], g["theta_after"][t, K - 1], mu, mix, _sig(g, "sigma_p"), float(g["alpha"]), lik,
                       bool(int(g["weighted_prior"])), roll)
-        assert relerr(r["log_l"], g["tick_log_l"][t]) < TOL
-        assert relerr(r["log_p"], g["tick_log_p"][t]) < TOL
+        assert elemerr(r["log_l"], g["tick_log_l"][t]) < TOL
+        assert elemerr(r["log_p"], g["tick_log_p"][t]) < TOL
         assert r["i_star"] == int(np.argmax(g["tick_p_weights"][t]))
         assert relerr(r["p_weights"], g["tick_p_weights"][t]) < 2e-3  # exp of O(1e3) log-weights: 1 ulp of log_l = 2e-4 rel
         assert np.array_equal(r["a_seq"], g["tick_a_seq"][t])
