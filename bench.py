@@ -3,22 +3,30 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workload at every N = BASELINE.json configs[1]: Pendulum, 1024 Stein particles PER GPU, S=128 action samples, M=1,
-H=30, 5 SVGD iterations per tick, gpytorch-RBF ("K1") kernel, SGD lr 2, fp32, synthetic seeded inputs resident in HBM.
-One "step" = one control tick = SVMPC.optimize(5 iterations) + SVMPC.forward (weights, argmax, roll, prior refresh).
-Policy noise is drawn on the device inside the timed region (Philox, fused into the rollout kernel) - the reference also
-draws its noise inside the tick - so no work is skipped.
+N = 1 (the contract's workload): BASELINE.json configs[1] - Pendulum, 1024 Stein particles, S=128 action samples, M=1, H=30,
+5 SVGD iterations per tick, gpytorch-RBF ("K1") kernel, SGD lr 2, fp32, synthetic seeded inputs resident in HBM.  One "step" =
+one control tick = SVMPC.optimize(5 iterations) + SVMPC.forward (weights, argmax, roll, prior refresh): ONE persistent kernel
+launch (dust_amd/csrc/persist.hpp).  Policy noise is drawn on the device inside the timed region (Philox, in registers) - the
+reference also draws its noise inside the tick - so no work is skipped.  `value` is the open-loop rate (ticks enqueued back to
+back, plant state constant); `closed_loop_ticks_per_s` is the rate when every tick's first action is read back (one pinned
+device-to-host copy + one stream synchronisation), stepped through a host plant model and fed to the next tick - the loop order
+of dust/utils/simulations.py:104-123.
 
-N>1 shards the particle index over the ranks (weak scaling: 1024 particles per GPU, N*1024 in the joint problem) with two
-in-place RCCL all-gathers per SVGD iteration (score before the Stein pass, theta after the update - the prior means alias
-theta); `value` counts 1024-particle shard-ticks per second summed over ranks (= joint ticks/s * N),
-`joint_ticks_per_s` is the joint rate itself.  The pairwise passes are N_loc x N, so per-rank work grows with N by design.
+N > 1: BASELINE.json configs[3] - Particle (2-D point mass, obstacle grid), 16384 Stein particles, S=64, M=4, H=40, 1 SVGD
+iteration per tick - sharded over the N ranks by particle index (strong scaling: the joint problem is fixed), with the in-place
+RCCL all-gathers of DESIGN.md section 6; `value` = joint ticks/s.  `weak_cfg2` carries the round-1 weak-scaled figure
+(1024 Pendulum particles per GPU) as a secondary field when --weak is given.
 
-Extra objects in the JSON line (tier contract): `roofline` for the rollout kernel in its HBM-streaming form (external
-noise read from HBM, the variant the parity tests drive; run as dust_likelihood_sample runs it - rollouts, costs, weights,
-likelihood score, MPPI side update - without the combine of the prior partials, which SURVEY 8d's B_roll does not count), timed with HIP events inside this process (one event pair around
-400 back-to-back launches on the context's stream; `traffic` from the committed PMC summary under profiles/); `cpu_baseline` =
-the CPU oracle (oracle/dust_oracle.c, a port - the reference is Python and cannot travel) on the host cores.
+Extra objects in the JSON line (tier contract):
+  roofline      the rollout kernel in its HBM-BOUND form - stored states (MultiDISCO.forward returns them), BASELINE configs[2]
+                size: Particle N=4096, S=64, M=64, H=40 -> 11.1 GB written per launch, far beyond the 256 MiB Infinity Cache -
+                timed with one HIP-event pair around back-to-back launches on the context's stream; `forms` adds the no-store
+                form at cfg2 size over a > 256 MiB noise working set, and `product_kernel` the persistent tick kernel with its
+                VALU-issue fraction (it is latency-bound, not bandwidth-bound: DESIGN.md section 5).  `traffic` comes from the
+                committed PMC summary under profiles/ (PMC passes cannot run inside this process).
+  cpu_baseline  the CPU oracle (oracle/dust_oracle.c, a scalar C port - the reference is Python and cannot travel) on the host:
+                all threads on whole ticks, and ONE core on one SVGD iteration of the same tick; CPU model string included.
+                It is a checker, not a tuned CPU implementation: no credit attaches to the ratio.
 """
 import argparse
 import json
@@ -32,19 +40,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(model="pendulum", N=1024, S=128, M=1, H=30, n_iters=5, kernel="K1", lr=2.0, alpha=1.0, sigma_a=2.0, sigma_p=2.0)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+CFG3 = dict(model="particle", N=4096, S=64, M=64, H=40)            # roofline: stored-states form
+CFG4 = dict(model="particle", N=16384, S=64, M=4, H=40, n_iters=1)  # multi-GPU workload
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2  # 1024 SIMD-32 units, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
-def synth(N, H, da, seed=0):
+def synth(N, H, da, seed=0, spread=2.0):
     rng = np.random.default_rng(seed)
     mu = rng.standard_normal((N, H, da)).astype(np.float32)
-    theta = (mu + 2.0 * rng.standard_normal((N, H, da))).astype(np.float32)
+    theta = (mu + spread * rng.standard_normal((N, H, da))).astype(np.float32)
     return mu, theta
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle (C port, OpenMP) on the host cores, same workload, bounded to ~budget_s seconds."""
-    from oracle import Oracle, num_threads
+def particle_grid():
+    """220 x 220 cells of 0.1 m, 4 x 4 block obstacles (the demo's grid_4x4 pattern; synthetic occupancy)."""
+    g = np.zeros((220, 220), np.float32)
+    for bx in range(4):
+        for by in range(4):
+            x0, y0 = 30 + bx * 45, 30 + by * 45
+            g[x0:x0 + 18, y0:y0 + 18] = 1.0
+    return g
+
+
+def pendulum_plant(state, u, dt=0.05, g=9.8, m=1.0, l=1.0):
+    """Host plant step for the closed-loop figure (the stand-in plant of dust_amd/utils/simulations.py: PendulumModel.step,
+    pendulum.py:61-100, nominal parameters)."""
+    th, thd = float(state[0]), float(state[1])
+    u = min(max(float(u), -2.0), 2.0)
+    thd = thd + dt * (-3.0 * g / (2.0 * l) * np.sin(th + np.pi) + 3.0 * u / (m * l * l))
+    thd = min(max(thd, -8.0), 8.0)
+    return np.array([th + thd * dt, thd], np.float32)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=10.0):
+    """Oracle (scalar C port, OpenMP) on the host cores, same workload; bounded to ~budget_s per leg."""
+    from oracle import Oracle, num_threads, set_num_threads
 
     w = WORKLOAD
     o = Oracle(model=w["model"], N=w["N"], S=w["S"], M=1, H=w["H"])
@@ -53,18 +95,94 @@ def cpu_baseline(budget_s=12.0):
     eps = rng.standard_normal((w["n_iters"], w["S"], w["N"], w["H"], 1)).astype(np.float32)
     state = np.array([3.0, 0.0], np.float32)
     mix = np.ones(w["N"], np.float32)
+    n_all = num_threads()
     t0 = time.perf_counter()
     ticks = 0
+    th, m_, mx = theta, mu, mix
     while True:
-        r = o.tick_k1(state, theta, mu, mix, w["sigma_p"], w["sigma_a"], eps, w["n_iters"], w["alpha"], w["lr"], theta)
-        theta, mu, mix = r["theta"], r["mu"], r["mix"]
+        r = o.tick_k1(state, th, m_, mx, w["sigma_p"], w["sigma_a"], eps, w["n_iters"], w["alpha"], w["lr"], th)
+        th, m_, mx = r["theta"], r["mu"], r["mix"]
         ticks += 1
         el = time.perf_counter() - t0
         if el > budget_s or ticks >= 200:
             break
-    return dict(value=ticks / el, unit="control steps/s", cores=num_threads(), kind="port",
-                sample="%d full ticks of the same workload (N=%d,S=%d,H=%d,%d iters) in %.1f s, OpenMP over all host threads"
-                       % (ticks, w["N"], w["S"], w["H"], w["n_iters"], el))
+    all_rate = ticks / el
+    # ONE core: one SVGD iteration of the same tick (a whole tick on one core is minutes), scaled by the iteration count
+    one = None
+    if set_num_threads(1):
+        t1 = time.perf_counter()
+        o.tick_k1(state, theta, mu, mix, w["sigma_p"], w["sigma_a"], eps[:1], 1, w["alpha"], w["lr"], theta)
+        e1 = time.perf_counter() - t1
+        set_num_threads(n_all)
+        one = dict(value=1.0 / (e1 * w["n_iters"]), seconds_per_iteration=e1,
+                   sample="1 SVGD iteration (+ forward) of the same tick on 1 thread, scaled by the 5 iterations of a tick")
+    return dict(value=all_rate, unit="control steps/s", cores=n_all, kind="port", cpu=cpu_model(),
+                sample="%d full ticks of the same workload (N=%d,S=%d,H=%d,%d iters) in %.1f s, OpenMP over all %d host threads"
+                       % (ticks, w["N"], w["S"], w["H"], w["n_iters"], el, n_all),
+                one_core=one,
+                note="scalar C restatement used as the parity checker (O(S N^2 D) work of the reference skipped where it is discarded); "
+                     "not a tuned CPU implementation - no credit attaches to the GPU/CPU ratio")
+
+
+def roofline_section(local, state_pend):
+    """Roofline of the rollout kernel (HIP events inside this process) + the product kernel's issue fraction."""
+    from dust_amd import Context
+
+    out = {}
+    # ---- (1) HBM-bound form: stored states at cfg3 size
+    c3 = CFG3
+    rng = np.random.default_rng(3)
+    th = rng.standard_normal((c3["N"], c3["H"], 2)).astype(np.float32)
+    params = (1.0 + 0.1 * rng.standard_normal((c3["M"], 1))).astype(np.float32)
+    c = Context(model="particle", N=c3["N"], S=c3["S"], M=c3["M"], H=c3["H"], kernel="K1", sigma_a=1.0, sigma_p=1.0,
+                uncertain_params=("mass",), grid=particle_grid(), seed=7, device=local)
+    c.set_theta(th); c.set_prior(th); c.set_a_mat(th)
+    st = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    n_slices = 4
+    slice_f = c3["S"] * c3["N"] * c3["H"] * 2
+    ptr = c.device_noise(n_slices * slice_f, seed=99)
+    eps0 = rng.standard_normal((c3["S"], c3["N"], c3["H"], 2)).astype(np.float32)
+    c.likelihood_sample(st, eps0, params)  # uploads the dynamics samples (they stay on the device)
+    reps = 20
+    avg_s = c.profile_rollout(st, ptr, n_slices, reps, store_states=True) * 1e-3
+    b_alg = c.rollout_bytes(store_states=True)
+    ach = b_alg / avg_s / 1e9
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, "profiles", "round2_rollout_states_traffic.json")
+    if os.path.exists(tf):
+        with open(tf) as fh:
+            tj = json.load(fh)
+        traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round2_rollout_states_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    out.update(kernel="dust::rollout_stream_kernel<1,true,false,true> (rollout kernel, stored-states form: states [M][S][N][H+1][ds] written)",
+               bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+               algorithmic_bytes_per_launch=b_alg, avg_launch_us=avg_s * 1e6, launches=reps,
+               workload="Particle N=%d, S=%d, M=%d, H=%d (BASELINE configs[2]): %.2f GB of states per launch (working set >> 256 MiB Infinity Cache)"
+                        % (c3["N"], c3["S"], c3["M"], c3["H"], b_alg / 1e9),
+               timing="one HIP event pair around %d back-to-back launches on the context's stream" % reps)
+    # the same shape without stored states (compute / latency bound: 86 MB per launch)
+    avg_ns = c.profile_rollout(st, ptr, n_slices, reps) * 1e-3
+    b_ns = c.rollout_bytes()
+    forms = {"cfg3_no_store": dict(avg_launch_us=avg_ns * 1e6, algorithmic_bytes_per_launch=b_ns, achieved=b_ns / avg_ns / 1e9,
+                                   frac=b_ns / avg_ns / 1e9 / HBM_PEAK_GBS)}
+    c.device_free(ptr)
+    c.close()
+    # ---- (2) cfg2 no-store form over a noise working set beyond the Infinity Cache (20 x 15.7 MB = 315 MB)
+    w = WORKLOAD
+    c1 = Context(model="pendulum", N=w["N"], S=w["S"], M=1, H=w["H"], kernel="K1", lr=w["lr"], sigma_a=2.0, sigma_p=2.0, seed=1234, device=local)
+    mu1, th1 = synth(w["N"], w["H"], 1)
+    c1.set_theta(th1); c1.set_prior(mu1); c1.set_a_mat(th1)
+    n2 = 20
+    sf = w["S"] * w["N"] * w["H"]
+    p2 = c1.device_noise(n2 * sf, seed=98)
+    a2 = c1.profile_rollout(state_pend, p2, n2, 400) * 1e-3
+    b2 = c1.rollout_bytes()
+    forms["cfg2_no_store"] = dict(avg_launch_us=a2 * 1e6, algorithmic_bytes_per_launch=b2, achieved=b2 / a2 / 1e9, frac=b2 / a2 / 1e9 / HBM_PEAK_GBS,
+                                  working_set_mb=n2 * sf * 4 / 1e6,
+                                  note="131072 rollouts = 2 waves per SIMD: one resident wave of workgroups, latency-bound (DESIGN.md section 5)")
+    c1.device_free(p2)
+    c1.close()
+    out["forms"] = forms
+    return out
 
 
 def main():
@@ -74,12 +192,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--f16-variant", action="store_true", help="also time the rollout kernel over binary16-stored noise (informational)")
+    ap.add_argument("--weak", action="store_true", help="N>1: also time the weak-scaled cfg2 form (1024 Pendulum particles per GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    import __graft_entry__ as entry
+
+    if rank == 0:  # (before anything initialises the GPU in this process: a stale library would compile in a child process)
+        entry.build()
     import torch
 
     dist = None
@@ -92,135 +214,126 @@ def main():
     n_gpus = max(world, 1)
     if args.gpus != n_gpus and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
-    import __graft_entry__ as entry
-
-    if rank == 0:
-        entry.build()
     if dist is not None:
         dist.barrier()
     from dust_amd import Context
     from dust_amd.parallel import ShardedSVMPC
 
+    def timed(tick, sync):
+        for _ in range(args.warmup):
+            tick()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tick()
+        sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     w = WORKLOAD
-    n_loc = w["N"]
-    n_tot = n_loc * n_gpus
-    mu, theta = synth(n_tot, w["H"], 1)
     state = np.array([3.0, 0.0], np.float32)
-    common = dict(model=w["model"], N=n_tot, S=w["S"], M=1, H=w["H"], kernel=w["kernel"], lr=w["lr"], alpha=w["alpha"],
-                  sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
+    extra = {}
     if dist is None:
-        ctx = Context(**common)
+        mu, theta = synth(w["N"], w["H"], 1)
+        ctx = Context(model=w["model"], N=w["N"], S=w["S"], M=1, H=w["H"], kernel=w["kernel"], lr=w["lr"], alpha=w["alpha"],
+                      sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
         ctx.set_theta(theta)
         ctx.set_prior(mu)
         ctx.set_a_mat(theta)
-
-        def tick():
-            ctx.svmpc_tick(state, w["n_iters"], want_outputs=False)
-
-        def sync():
-            ctx.sync()
+        el = timed(lambda: ctx.svmpc_tick(state, w["n_iters"], want_outputs=False), ctx.sync)
+        # closed loop (simulations.py:104-123): optimize + forward -> first action -> plant -> next tick
+        st = state.copy()
+        for _ in range(min(args.warmup, 10)):
+            a_seq, _ = ctx.svmpc_tick(st, w["n_iters"], want_outputs=True)
+        n_cl = args.steps
+        t0 = time.perf_counter()
+        for _ in range(n_cl):
+            a_seq, _ = ctx.svmpc_tick(st, w["n_iters"], want_outputs=True)
+            st = pendulum_plant(st, a_seq[0, 0])
+        extra["closed_loop_ticks_per_s"] = n_cl / (time.perf_counter() - t0)
+        extra["closed_loop_note"] = ("every tick returns a_seq + p_weights (one pinned D2H copy + one stream sync), the first action steps a "
+                                     "host pendulum plant, the new state feeds the next tick")
+        ctx.close()
+        workload = ("Pendulum N=%d, S=128, M=1, H=30, 5 SVGD iters, K1 (gpytorch-RBF) kernel, SGD, device Philox noise inside the tick; "
+                    "one persistent kernel launch per tick" % w["N"])
+        par = "single GPU"
+        value = args.steps / el
+        unit = "control steps/s"
     else:
+        c4 = CFG4
+        mu, theta = synth(c4["N"], c4["H"], 2, spread=1.0)
+        common = dict(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
+                      uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
+        rngp = np.random.default_rng(5)
+        params = (1.0 + 0.1 * rngp.standard_normal((c4["n_iters"], c4["M"], 1))).astype(np.float32)
+        st4 = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
         sh = ShardedSVMPC(common, rank, n_gpus, dist)
         sh.set_state(theta, mu)
-        ctx = sh.ctx
+        el = timed(lambda: sh.tick(st4, c4["n_iters"], params=params), sh.sync)
+        workload = ("Particle N=%d total (%d per GPU), S=64, M=4, H=40, 1 SVGD iter, K1 kernel, SGD, device Philox noise inside the tick"
+                    % (c4["N"], c4["N"] // n_gpus))
+        par = "particles sharded x%d (strong scaling), in-place RCCL all-gathers of score and theta per SVGD iteration" % n_gpus
+        value = args.steps / el
+        unit = "control steps/s (joint N=16384 problem)"
+        if args.weak:
+            n_tot = w["N"] * n_gpus
+            mu2, th2 = synth(n_tot, w["H"], 1)
+            common2 = dict(model=w["model"], N=n_tot, S=w["S"], M=1, H=w["H"], kernel=w["kernel"], lr=w["lr"], alpha=w["alpha"],
+                           sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
+            sh2 = ShardedSVMPC(common2, rank, n_gpus, dist)
+            sh2.set_state(th2, mu2)
+            el2 = timed(lambda: sh2.tick(state, w["n_iters"]), sh2.sync)
+            extra["weak_cfg2"] = dict(joint_ticks_per_s=args.steps / el2, n_particles_total=n_tot,
+                                      shard_ticks_per_s=args.steps / el2 * n_gpus)
 
-        def tick():
-            sh.tick(state, w["n_iters"])
-
-        def sync():
-            sh.sync()
-
-    for _ in range(args.warmup):
-        tick()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tick()
-    sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # ---- per-kernel HIP-event timing of the product tick + roofline of the HBM-streaming rollout kernel (rank 0, N=1 form)
-    per_kernel, roofline = {}, None
-    if rank == 0 and not args.no_roofline:
-        c1 = Context(**dict(common, N=n_loc))
-        mu1, th1 = synth(n_loc, w["H"], 1)
-        c1.set_theta(th1)
-        c1.set_prior(mu1)
-        c1.set_a_mat(th1)
-        c1.profile(True)
-        for _ in range(20):
-            c1.svmpc_tick(state, w["n_iters"], want_outputs=False)
-        c1.sync()
-        per_kernel = {k: dict(avg_us=1e3 * ms / n, launches=n) for k, (ms, n) in c1.profile_get().items()}
-        # HBM-streaming form: eps [iters][S][N][D] resident in HBM, one distinct slice per launch
-        n_slices = 8
-        slice_f = w["S"] * n_loc * w["H"]
-        ptr = c1.device_noise(n_slices * slice_f, seed=99)
-        avg_s = c1.profile_rollout(state, ptr, n_slices, 400) * 1e-3
-        bytes_alg = c1.rollout_bytes()
-        ach = bytes_alg / avg_s / 1e9
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "round1_rollout_traffic.json")
-        if os.path.exists(tf):  # PMC passes cannot run inside this process: the committed summary of the same kernel / shape
-            with open(tf) as fh:
-                tj = json.load(fh)
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round1_rollout_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        roofline = dict(kernel="dust::rollout_stream_kernel<0> (rollout kernel, HBM-streaming form: caller-supplied eps)", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                        algorithmic_bytes_per_launch=bytes_alg, avg_launch_us=avg_s * 1e6, launches=400,
-                        timing="one HIP event pair around 400 back-to-back launches on the context's stream")
-        c1.device_free(ptr)
-        if args.f16_variant:
-            # the same kernel over binary16-stored noise (BASELINE.json config 5 "fp16 rollout"): informational, never the roofline
-            # line; opt-in, so that the default run's rocprofv3 row of this kernel holds the fp32 launches only
-            ptr16 = c1.device_noise(n_slices * slice_f, seed=99, f16=True)
-            t16 = c1.profile_rollout(state, ptr16, n_slices, 400, f16=True) * 1e-3
-            b16 = c1.rollout_bytes(eps_f16=True)
-            roofline["f16_storage_variant"] = dict(avg_launch_us=t16 * 1e6, algorithmic_bytes_per_launch=b16, achieved=b16 / t16 / 1e9,
-                                                   frac=b16 / t16 / 1e9 / HBM_PEAK_GBS)
-            c1.device_free(ptr16)
-        c1.profile(False)
-        c1.close()
+    roofline = None
+    if rank == 0 and not args.no_roofline and dist is None:
+        roofline = roofline_section(local, state)
+        pf = os.path.join(ROOT, "profiles", "round2_tick_pmc.json")
+        if os.path.exists(pf):  # VALU issue fraction of the persistent tick kernel from the committed SQ counter pass
+            with open(pf) as fh:
+                pj = json.load(fh)
+            insts = pj.get("SQ_INSTS_VALU_per_tick")
+            if insts:
+                issue_s = insts / VALU_PEAK_WAVE_INSTR_PER_S
+                roofline["product_kernel"] = dict(
+                    kernel="dust::svmpc_tick_kernel<0,1,4> (one launch = one control tick)", bound="valu-issue / hand-off latency",
+                    valu_wave_instructions_per_tick=insts, valu_issue_floor_us=issue_s * 1e6, measured_us=1e6 * el / args.steps,
+                    frac=issue_s / (el / args.steps), source="profiles/round2_tick_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
-        joint = args.steps / el
         out = {
-            "metric": "MPC control steps/sec (SVGD-MPC tick: 5 SVGD iterations + forward)",
-            "value": joint * n_gpus,
-            "unit": "control steps/s (1024-particle shard-ticks summed over GPUs)",
+            "metric": "MPC control steps/sec (SVGD-MPC tick: SVGD iterations + forward)",
+            "value": value,
+            "unit": unit,
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if n_gpus == 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Pendulum N=%d particles/GPU (%d total), S=128, M=1, H=30, 5 SVGD iters, K1 (gpytorch-RBF) kernel, SGD, "
-                                   "device Philox noise inside the tick" % (n_loc, n_tot),
-                       "parallelism": "particles sharded x%d, two in-place RCCL all-gathers (score, theta) per SVGD iteration" % n_gpus if n_gpus > 1 else "single GPU"},
-            "joint_ticks_per_s": joint,
-            "n_particles_total": n_tot,
-            "per_kernel": per_kernel,
+            "config": {"workload": workload, "parallelism": par},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        out.update(extra)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -307,11 +307,13 @@ class Context:
                 out[L.load().dust_kernel_name(k).decode()] = (ms.value, n.value)
         return out
 
-    def profile_rollout(self, state, eps_dev, n_slices, reps, f16=False):
-        """Average launch-to-launch time (ms) of the standalone rollout kernel over device-resident eps slices."""
+    def profile_rollout(self, state, eps_dev, n_slices, reps, f16=False, store_states=False, store_f16=False):
+        """Average launch-to-launch time (ms) of the standalone rollout kernel over device-resident eps slices
+        (store_states: the HBM-bound form that also writes states [M][S][N][H+1][ds])."""
         ms = C.c_double(0)
+        fl = (L.EPS_F16 if f16 else 0) | (L.STORE_STATES if store_states else 0) | (L.STORE_F16 if store_f16 else 0)
         L.check(L.load().dust_profile_rollout(self._h, _p(np.ascontiguousarray(state, np.float32)), C.c_void_p(eps_dev), int(n_slices),
-                                              int(reps), L.EPS_F16 if f16 else 0, C.byref(ms)))
+                                              int(reps), fl, C.byref(ms)))
         return ms.value
 
     def rollout_bytes(self, store_states=False, eps_f16=False, store_f16=False):

@@ -103,6 +103,11 @@ struct dust_ctx {
   unsigned int *iter_cnt;
   int iter_tiles, iter_js, iter_set;
   float *score_hs;  // [2][N][D] score rows handed over as data inside the one-launch iteration (sentinel-filled between uses)
+  // tick outputs: a_seq_out | p_weights | time-out word of the persistent tick live in ONE device block, copied with ONE
+  // hipMemcpyAsync into a pinned host buffer (then one stream synchronisation per tick that returns outputs)
+  float *outblk;
+  size_t out_floats;   // a_seq (D rounded up to 32) + N + 32
+  float *out_pinned;   // host, pinned: out_floats + 4 words for the hand-off flags of the launch-per-iteration paths
   // persistent one-launch tick (persist.hpp svmpc_tick_kernel): two sets of 5 x [tiles] arrival lines, then the time-out flag
   unsigned int *tick_cnt;
   int tick_tiles, tick_set;
@@ -264,8 +269,8 @@ static int validate(const dust_config *g) {
 static void free_all(dust_ctx *c) {
   // {theta, theta_alt} are always the two particle buffers, whichever is current
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
-                  &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw, &c->pw,
-                  &c->a_seq_out, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
+                  &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
+                  &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
                   &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
@@ -277,6 +282,7 @@ static void free_all(dust_ctx *c) {
   if (c->iter_cnt) (void)hipFree(c->iter_cnt);
   if (c->score_hs) (void)hipFree(c->score_hs);
   if (c->tick_cnt) (void)hipFree(c->tick_cnt);
+  if (c->out_pinned) (void)hipHostFree(c->out_pinned);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -333,13 +339,21 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   c->theta_home = c->theta;
     HIP_TRY(hipMemsetAsync(*p, 0, ND * sizeof(float), c->stream));
   }
-  float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw, &c->pw};
+  float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw};
   for (auto p : nn) {
     TRY(dalloc(p, (size_t)c->N));
     HIP_TRY(hipMemsetAsync(*p, 0, c->N * sizeof(float), c->stream));
   }
   TRY(dalloc(&c->a_seq, (size_t)c->D));
-  TRY(dalloc(&c->a_seq_out, (size_t)c->D));
+  {
+    const size_t dpad = ((size_t)c->D + 31) & ~(size_t)31;
+    c->out_floats = dpad + (size_t)c->N + 32;
+    TRY(dalloc(&c->outblk, c->out_floats));
+    HIP_TRY(hipMemsetAsync(c->outblk, 0, c->out_floats * sizeof(float), c->stream));
+    c->a_seq_out = c->outblk;
+    c->pw = c->outblk + dpad;
+    HIP_TRY(hipHostMalloc((void **)&c->out_pinned, (c->out_floats + 4) * sizeof(float), hipHostMallocDefault));
+  }
   TRY(dalloc(&c->bw, (size_t)c->D));
   HIP_TRY(hipMemsetAsync(c->a_seq, 0, c->D * sizeof(float), c->stream));
   TRY(dalloc(&c->costsT, SN));
@@ -406,8 +420,11 @@ extern "C" int dust_sync(dust_ctx *c) {
   }
   if (c->tick_cnt) {
     unsigned int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c->tick_cnt + (size_t)2 * (5 * c->tick_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid)");
+    HIP_TRY(hipMemcpy(&flag, c->outblk + c->out_floats - 32, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+      HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, sizeof flag));  // reported: clear
+      return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid)");
+    }
   }
   return DUST_OK;
 }
@@ -746,11 +763,16 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
       nt = sub * G;  // >= 128 >= D
     }
   }
-  size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true);
+  if (c->cfg.model == DUST_MODEL_PARTICLE && a.dm.with_obstacle && c->grid_bits) {
+    const int words = (c->nx * c->ny + 31) / 32;
+    if (words <= 4096) a.grid_words = (words + 3) & ~3;  // <= 16 KB: the map rides in LDS
+  }
+  const bool stage_states = o.want_states;
+  size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true, stage_states, a.grid_words);
   if (lds > 96 * 1024) {  // keep >= 1 workgroup per CU resident with room to spare; larger tiles go to an HBM slab
     TRY(ensure(&c->tile_scratch, &c->tile_cap, (size_t)c->nloc * c->S * (c->D | 1)));
     a.tile_scratch = c->tile_scratch;
-    lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false);
+    lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false, o.want_states, a.grid_words);  // (HBM tile: full-feature kernel)
     if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "n_samples too large for one workgroup (%zu B of LDS)", lds);
   }
   {
@@ -775,12 +797,16 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
     KERNEL<<<c->nloc, nt, lds, c->stream>>>(a);                                                                                 \
   } while (0)
   const bool stream_form = a.noise_mode == NOISE_EPS;
-  // LEAN instances: the optional features compiled out (rollout.hpp)
-  const bool lean = !a.states_out && !a.actions_out && !a.costs_in && a.a_reg == 0.0f && !a.mw && !a.tile_scratch && !a.omegaT;
-#define DUST_PICK_ROLLOUT3(MODEL, GR, LN)                                            \
-  do {                                                                              \
-    if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, GR, LN>));    \
-    else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, GR, LN>));                       \
+  // LEAN instances: the optional features compiled out (rollout.hpp); STATES: the stored-states form (states staged through LDS,
+  // the Particle map in LDS); both need the occupancy grid in LDS when there is one
+  const bool grid_ok = c->cfg.model != DUST_MODEL_PARTICLE || !a.dm.with_obstacle || a.grid_words > 0;
+  const bool lean = !a.states_out && !a.actions_out && !a.costs_in && a.a_reg == 0.0f && !a.mw && !a.tile_scratch && !a.omegaT && grid_ok;
+  const bool states_form = a.states_out && !a.costs_in && !a.mw && !a.tile_scratch && grid_ok && stream_form;
+#define DUST_PICK_ROLLOUT3(MODEL, GR, LN)                                                            \
+  do {                                                                                              \
+    if (states_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, GR, false, true>));           \
+    else if (stream_form) DUST_LAUNCH_ROLLOUT((rollout_stream_kernel<MODEL, GR, LN>));               \
+    else DUST_LAUNCH_ROLLOUT((rollout_kernel<MODEL, GR, LN>));                                       \
   } while (0)
 #define DUST_PICK_ROLLOUT(MODEL)                                     \
   do {                                                               \
@@ -1062,6 +1088,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   TRY(rollout_args(c, oo, f.ra, &nt, &lds_r));
   if (f.ra.tile_scratch || (PAIR_NT % nt) != 0) return DUST_OK;
   if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // the fused launch carries the LEAN rollout body only
+  if (c->cfg.model == DUST_MODEL_PARTICLE && f.ra.dm.with_obstacle && f.ra.grid_words == 0) return DUST_OK;  // (LEAN: map in LDS)
   f.sub_nt = nt;
   f.per_block = PAIR_NT / nt;
   if (c->nloc % f.per_block || PAIR_TI % f.per_block) return DUST_OK;
@@ -1076,11 +1103,12 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
     if (c->fused_cnt) HIP_TRY(hipFree(c->fused_cnt));
     c->fused_cnt = nullptr;
     TRY(dalloc(&c->fused_cnt, ((size_t)f.tiles + 1) * CNT_STRIDE));
+    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, ((size_t)f.tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));  // incl. the time-out word
     c->fused_tiles = f.tiles;
     c->fused_dirty = true;
   }
   if (c->fused_dirty)  // previous fused launch was not followed by an update kernel (which re-arms the counters)
-    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, ((size_t)f.tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->fused_cnt, 0, (size_t)f.tiles * CNT_STRIDE * sizeof(unsigned int), c->stream));  // (not the time-out word behind the counters)
   f.n_pair_blocks = f.tiles * f.pa.JS;
   f.cnt = c->fused_cnt;
   f.timeout_flag = c->fused_cnt + (size_t)f.tiles * CNT_STRIDE;
@@ -1237,13 +1265,14 @@ static int launch_stein_update(dust_ctx *c, int apply) {
         if (c->stein_cnt) HIP_TRY(hipFree(c->stein_cnt));
         c->stein_cnt = nullptr;
         TRY(dalloc(&c->stein_cnt, ((size_t)tiles + 2) * CNT_STRIDE));
+        HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 2) * CNT_STRIDE * sizeof(unsigned int), c->stream));  // incl. the time-out word
         c->stein_tiles = tiles;
         c->stein_dirty = true;  // the rollout launch that preceded this call did not know the buffer
       }
     }
     if (fuse) {
       // Stein tiles + update role in ONE launch (fused.hpp): the update launch and its ramp disappear
-      if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 2) * CNT_STRIDE * sizeof(unsigned int), c->stream));
+      if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));  // (not the time-out word)
       SteinUpdateArgs f;
       memset(&f, 0, sizeof f);
       f.pa = a;
@@ -1402,6 +1431,7 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   TRY(sr);
   if (f.ra.tile_scratch || (PAIR_NT % nt) != 0 || f.ra.G > 1) return DUST_OK;
   if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // LEAN rollout body only
+  if (c->cfg.model == DUST_MODEL_PARTICLE && f.ra.dm.with_obstacle && f.ra.grid_words == 0) return DUST_OK;  // (LEAN: map in LDS)
   f.ra.rearm = nullptr;
   f.ra.rearm_n = 0;
   f.sub_nt = nt;
@@ -1619,8 +1649,7 @@ extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(forward_device(c));
   TRY(forward_finish_device(c));
-  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
-  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
   return DUST_OK;
 }
 
@@ -1768,7 +1797,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   f.cnt_lw = set + (size_t)4 * f.tiles * CNT_STRIDE;
   f.zero_base = c->tick_cnt + (size_t)(1 - c->tick_set) * lines * CNT_STRIDE;
   f.zero_lines = lines;
-  f.timeout_flag = c->tick_cnt + (size_t)2 * lines * CNT_STRIDE;
+  f.timeout_flag = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
   f.logp = c->logp;
   f.lw = c->lw;
   f.pw = c->pw;
@@ -1826,14 +1855,26 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
   return launch_tick(c, state, n_steps, eps_dev, do_forward, done);
 }
 
-// a_seq / p_weights of the tick just enqueued -> host; a timed-out hand-off inside the tick is an ERROR here, not stale data
+// a_seq / p_weights of the tick (or forward) just enqueued -> host: ONE device-to-host copy into pinned memory and ONE stream
+// synchronisation.  A timed-out in-kernel hand-off (persistent tick, or any of the launch-per-iteration fused forms) is an ERROR
+// here - the outputs of that tick are invalid and must not reach the plant.
 static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights) {
-  if (a_seq) HIP_TRY(hipMemcpyAsync(a_seq, c->a_seq_out, c->D * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  if (p_weights) HIP_TRY(hipMemcpyAsync(p_weights, c->pw, c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  unsigned int flag = 0;
-  if (c->tick_cnt) HIP_TRY(hipMemcpyAsync(&flag, c->tick_cnt + (size_t)2 * (5 * c->tick_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->out_pinned, c->outblk, c->out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  unsigned int *lf = reinterpret_cast<unsigned int *>(c->out_pinned + c->out_floats);
+  lf[0] = lf[1] = lf[2] = 0u;
+  if (c->fused_cnt) HIP_TRY(hipMemcpyAsync(lf + 0, c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->stein_cnt) HIP_TRY(hipMemcpyAsync(lf + 1, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->iter_cnt)
+    HIP_TRY(hipMemcpyAsync(lf + 2, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (flag) return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+  const unsigned int tick_flag = *reinterpret_cast<const unsigned int *>(c->out_pinned + c->out_floats - 32);
+  if (tick_flag) {
+    HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, 4));
+    return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+  }
+  if (lf[0] | lf[1] | lf[2]) return fail(DUST_ERR_HIP, "a fused launch's in-kernel hand-off timed out (results of this tick are invalid)");
+  if (a_seq) memcpy(a_seq, c->out_pinned, c->D * sizeof(float));
+  if (p_weights) memcpy(p_weights, c->out_pinned + (c->pw - c->outblk), c->N * sizeof(float));
   return DUST_OK;
 }
 
@@ -1923,8 +1964,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     TRY(forward_finish_device(c));
     if (graphable) c->graph_seen++;
   }
-  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
-  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
   return DUST_OK;
 }
 
@@ -2035,8 +2075,7 @@ extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_wei
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(forward_finish_device(c));
-  if (a_seq) TRY(d2h(c, a_seq, c->a_seq_out, c->D * sizeof(float)));
-  if (p_weights) TRY(d2h(c, p_weights, c->pw, c->N * sizeof(float)));
+  if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
   return DUST_OK;
 }
 
@@ -2064,7 +2103,8 @@ extern "C" int dust_profile_get(dust_ctx *c, int id, double *ms, int64_t *n) {
 // duration without per-launch event overhead (bench.py's roofline; compare rocprofv3 --kernel-trace --stats).
 extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float *eps_dev, int n_slices, int reps, int flags, double *avg_ms) {
   if (!c || !state || !eps_dev || !avg_ms || n_slices < 1 || reps < 1) return fail(DUST_ERR_INVALID, "bad argument");
-  if (c->cfg.dim_p > 0) return fail(DUST_ERR_UNSUPPORTED, "dust_profile_rollout: contexts without sampled parameters only");
+  if (c->cfg.dim_p > 0 && !c->params_dev)
+    return fail(DUST_ERR_STATE, "dust_profile_rollout: sampled parameters - run one dust_likelihood_sample with `params` first (they stay on the device)");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, nullptr, 0));
   SampleOpts o;
@@ -2073,6 +2113,8 @@ extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float
   o.base = c->theta;
   o.update_a_mat = 1;
   o.merge_prior = 0;  // the rollout kernel as dust_likelihood_sample runs it (SURVEY 8d B_roll has no prior-partial traffic)
+  o.want_states = (flags & DUST_STORE_STATES) != 0;  // the stored-states form ("for both store_states settings")
+  o.store_f16 = (flags & DUST_STORE_F16) != 0;
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats
   c->noise_f16 = (flags & DUST_EPS_F16) != 0;
   const bool prof = c->prof;

@@ -22,6 +22,10 @@
 #include "common.hpp"
 #include "stein.hpp"
 
+#ifndef DUST_STG_CHUNK
+#define DUST_STG_CHUNK 128  // bytes of a trajectory staged per flush of the stored-states form (rollout_body)
+#endif
+
 namespace dust {
 
 enum { NOISE_EPS = 0, NOISE_ACTIONS = 1, NOISE_PHILOX = 2 };
@@ -49,6 +53,9 @@ struct RolloutArgs {
   int bump_adam;        // an optimiser step follows: advance adam_step (read by update_kernel, never by this kernel)
   unsigned int *rearm;  // arrival counters of the Stein+update launch (fused.hpp), zeroed here for its next use, or nullptr
   int rearm_n;
+  int grid_words;       // Particle: the bit-packed occupancy grid is staged into LDS (this many words, a multiple of 4), or 0: HBM.
+                        // A lookup from HBM is a vector load whose in-order vmcnt wait also drains every state store in flight
+                        // (one wait per time step): with the map in LDS the stores of the staged-states form overlap the loop
   int coef_given;       // no sampled parameters: the model coefficients were evaluated once on the host
   float coef_host[2];
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
@@ -123,7 +130,8 @@ struct FusedWait {
 // wide (every sub-block of a workgroup runs the same control flow), reductions are sub-block local.
 template <int MODEL, int NB /* staged noise loads in flight per lane: 32 standalone, 12 inside the fused launch (VGPR budget) */,
           bool GROUPS /* lane = (sample, dynamics group): a.G > 1 */,
-          bool LEAN /* none of: stored states / actions / omega, injected costs, control cost, sigma-point weights, HBM tile */>
+          bool LEAN /* none of: stored states / actions / omega, injected costs, control cost, sigma-point weights, HBM tile */,
+          bool STATES = false /* the stored-states form (HBM-bound): states_out set; no injected costs / sigma-point weights / HBM tile */>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, const int tid, const int nt, const int nl,
                                              const FusedWait *fw) {
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
@@ -135,10 +143,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // block no longer has to stay live in SGPRs across the hot loops (the full kernel spills ~1000 scalars to VGPR lanes).
   float *const f_states = LEAN ? nullptr : a.states_out;
   float *const f_actions = LEAN ? nullptr : a.actions_out;
-  const float *const f_costs_in = LEAN ? nullptr : a.costs_in;
+  const float *const f_costs_in = (LEAN || STATES) ? nullptr : a.costs_in;
   const float f_a_reg = LEAN ? 0.0f : a.a_reg;
-  const float *const f_mw = LEAN ? nullptr : a.mw;
-  float *const f_tile_scratch = LEAN ? nullptr : a.tile_scratch;
+  const float *const f_mw = (LEAN || STATES) ? nullptr : a.mw;
+  float *const f_tile_scratch = (LEAN || STATES) ? nullptr : a.tile_scratch;
   float *const f_omegaT = LEAN ? nullptr : a.omegaT;
   // the S x D action tile lives in LDS; when it would not fit (huge S*D) it spills to a per-workgroup HBM scratch slab
   float *tile = f_tile_scratch ? f_tile_scratch + (size_t)nl * S * Dp : lds;  // [S][Dp] actions
@@ -177,6 +185,20 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // fixed stride in HBM and in LDS.  The first NB loads of every lane are issued BEFORE the wait on the theta row, so the
   // two round trips overlap (at S <= NB R - cfg2: 128 rows = 32 batches of 4 - that is the whole tile: one memory round
   // trip for stage 1).  Offsets are clamped, never predicated (a conditional load makes hipcc branch and wait per element).
+  // occupancy grid -> LDS (Particle; 6 KB for the demo map), right behind the coefficients
+  // (offsets are formed in the index domain: a round trip through an integer would lose the LDS address space and turn every
+  // access below into a flat load that waits on vmcnt AND lgkmcnt)
+  const int off_grid = ((int)((coefs + 2 * a.M) - lds) + 3) & ~3;
+  uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + off_grid);
+  // (compile-time in the LEAN and STATES instances - the host gives them the map in LDS whenever there is one: a run-time choice
+  // between an LDS and an HBM pointer would make every lookup a flat load, which waits on vmcnt AND lgkmcnt)
+  constexpr bool GRID_LDS = (LEAN || STATES) && MODEL == DUST_MODEL_PARTICLE;
+  DevModel dml = a.dm;
+  if (GRID_LDS) {
+    const int words = a.dm.with_obstacle ? (a.dm.nx * a.dm.ny + 31) >> 5 : 0;
+    for (int w = tid; w < words; w += nt) gridl[w] = a.dm.grid_bits[w];
+    dml.grid_bits = gridl;
+  }
   float v[NB];
   const int lgW = a.lgW, R = nt >> lgW;
   const int sr = tid >> lgW, sj = tid & ((1 << lgW) - 1);
@@ -272,10 +294,28 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     cst[s] = cost;
     a.costsT[(size_t)n * S + s] = cost;
   };
-  for (int s = ts; s < S; s += sub) {
+  // Stored states (MultiDISCO.forward returns them, disco.py:394; 11 GB at cfg3): the HBM-bound form of this kernel.  A lane's
+  // trajectory is one contiguous (H + 1) * ds run, but the lanes of a wave are N rows apart, so per-lane stores are 4-16-byte
+  // scatters (measured 0.43 TB/s).  Instead every wave stages its 64 trajectories in LDS in 128-byte chunks (chunk = 128 /
+  // bytes-per-state steps) and writes a chunk out cooperatively: 8 consecutive lanes store the 8 16-byte pieces of ONE
+  // trajectory's chunk - full 128-byte runs - 8 trajectories per store instruction.  Whole waves take part (lanes past S roll a
+  // clamped duplicate out and store nothing).
+  const int bps = DS * (a.store_f16 ? 2 : 4);  // bytes per stored state
+  constexpr int CHB = DUST_STG_CHUNK;          // staged bytes per lane and flush: one 128-byte line (or half of one)
+  constexpr int STG_ROW = CHB + 16;            // LDS bytes per lane (+16: bank spread)
+  constexpr int PC = CHB / 16;                 // 16-byte pieces per chunk = lanes that share one trajectory's chunk
+  char *stg = nullptr;
+  if (f_states) {
+    stg = reinterpret_cast<char *>(gridl + (GRID_LDS ? a.grid_words : 0)) + (size_t)(tid >> 6) * 64 * STG_ROW;
+  }
+  const int lane64 = tid & 63;
+  const int S_loop = f_states ? min(sub, (S + 63) & ~63) : S;
+  for (int s_raw = ts; s_raw < S_loop; s_raw += sub) {
+    const bool live = s_raw < S;
+    const int s = live ? s_raw : S - 1;
     float *act = tile + s * Dp;
     if (f_costs_in) {
-      if (mg == 0) cst[s] = f_costs_in[(size_t)s * N + n];
+      if (mg == 0 && live) cst[s] = f_costs_in[(size_t)s * N + n];
       continue;
     }
     double acc_m = 0.0, ut_term = 0.0;
@@ -314,31 +354,81 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         q = W * (q * q);
         traj = (float)tot + (q.x + q.y);
       } else {
-        float *so = f_states ? f_states + (((size_t)r * (H + 1) * DS) >> (a.store_f16 ? 1 : 0)) : nullptr;  // binary16: half the stride
-        auto put_state = [&](const int row) {
+        const bool so = f_states != nullptr;
+        // trajectory j of this wave (lane j's) is row r_first + j N of the [M][S][N] rollout index
+        const long r_first = ((long)m * SN + (long)(s_raw - lane64) * N + n);
+        const int n_traj = min(64, S - (s_raw - lane64));  // valid trajectories of this wave
+        const size_t rowb = (size_t)(H + 1) * bps;
+        // chunk boundaries sit on 128-byte LINES of the output when every trajectory of the wave has the same alignment (N rows
+        // apart: N * rowb a multiple of 128 - cfg3: 4096 * 656): a store instruction then writes whole lines, and only a
+        // trajectory's first / last partial chunk shares its line with the neighbouring row
+        const int ph = ((size_t)N * rowb) % CHB == 0 ? (int)(((size_t)r_first * rowb) % CHB) : 0;  // bytes; a multiple of 4
+        auto put_state = [&](const int row) {  // this lane's state -> its staging row
+          char *dst = stg + lane64 * STG_ROW + ((row * bps + ph) & (CHB - 1));
+          if (a.store_f16) {
+            _Float16 hx[DS];
 #pragma unroll
-          for (int k = 0; k < DS; ++k) {
-            if (a.store_f16) reinterpret_cast<_Float16 *>(so)[(size_t)row * DS + k] = (_Float16)x[k];
-            else so[(size_t)row * DS + k] = x[k];
+            for (int k = 0; k < DS; ++k) hx[k] = (_Float16)x[k];
+            if (DS == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(hx);
+            else {
+              reinterpret_cast<uint32_t *>(dst)[0] = reinterpret_cast<const uint32_t *>(hx)[0];
+              reinterpret_cast<uint32_t *>(dst)[1] = reinterpret_cast<const uint32_t *>(hx)[1];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < DS; ++k) reinterpret_cast<float *>(dst)[k] = x[k];  // (4-byte aligned in general; merged when the phase allows)
           }
         };
-        if (so) put_state(0);
+        auto flush = [&](const int chunk, const int lo, const int hi) {  // staged bytes [lo, hi) of the wave's chunk -> HBM
+          char *gbase = reinterpret_cast<char *>(f_states) + (size_t)chunk * CHB - ph;
+          const int piece = lane64 & (PC - 1);
+          v4f pv[PC];
+#pragma unroll
+          for (int i = 0; i < PC; ++i) pv[i] = *reinterpret_cast<const v4f *>(stg + ((lane64 / PC) + (64 / PC) * i) * STG_ROW + piece * 16);  // all reads in flight
+          const bool pok = piece * 16 >= lo && piece * 16 + 16 <= hi;
+#pragma unroll
+          for (int i = 0; i < PC; ++i) {
+            const int j = (lane64 / PC) + (64 / PC) * i;
+            if (j < n_traj && pok) {
+#ifdef DUST_STATES_NT
+              __builtin_nontemporal_store(pv[i], reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16));
+#else
+              *reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16) = pv[i];
+#endif
+            }
+          }
+          // words of partially covered 16-byte pieces at either end (at most 3 + 3): lane j copies trajectory j's
+          const int head_end = min(hi, (lo + 15) & ~15), tail_beg = max(head_end, hi & ~15);
+          if (lane64 < n_traj) {
+            char *grow = gbase + (size_t)(r_first + (long)lane64 * N) * rowb;
+            const char *srow = stg + lane64 * STG_ROW;
+            for (int o4 = lo; o4 < head_end; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
+            for (int o4 = tail_beg; o4 < hi; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
+          }
+        };
+        auto put_and_flush = [&](const int row) {
+          put_state(row);
+          const int endb = (row + 1) * bps + ph;  // staged bytes so far, counted from the start of chunk 0's line
+          if ((endb & (CHB - 1)) == 0) flush(endb / CHB - 1, endb == CHB ? ph : 0, CHB);
+          else if (row == H) flush(endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
+        };
+        if (so) put_and_flush(0);
         for (int t = 0; t < H; ++t) {
           float at[DA];
 #pragma unroll
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
-          const float ci = step_with_cost<MODEL>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+          const float ci = step_with_cost<MODEL>(dml, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
           tot += f_mw ? (double)f_mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
-          if (so) put_state(t + 1);
+          if (so) put_and_flush(t + 1);
         }
         if (f_mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
-          ut_term += (double)f_mw[m] * (double)term_cost<MODEL>(a.dm, x);
+          ut_term += (double)f_mw[m] * (double)term_cost<MODEL>(dml, x);
           traj = (float)tot;  // unused
           acc_m += tot;
           continue;
         }
-        traj = (float)tot + term_cost<MODEL>(a.dm, x);
+        traj = (float)tot + term_cost<MODEL>(dml, x);
       }
       acc_m += (double)traj;
     }
@@ -346,6 +436,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       accp[mg * sub + ts] = acc_m;
       continue;
     }
+    if (!live) continue;
     if (f_mw) finish_cost(s, (double)((float)acc_m + (float)ut_term), true);  // weighted sum over sigma points, not a mean
     else finish_cost(s, acc_m);
   }
@@ -598,22 +689,24 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {
   return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
 }
 
-template <int MODEL, bool GROUPS, bool LEAN>
+template <int MODEL, bool GROUPS, bool LEAN, bool STATES = false>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32, GROUPS, LEAN>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS, LEAN, STATES>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
 // Same body under its own symbol for the HBM-streaming form (caller-supplied eps resident in HBM): profiles and PMC
 // passes then attribute it separately from the Philox form.
-template <int MODEL, bool GROUPS, bool LEAN>
+template <int MODEL, bool GROUPS, bool LEAN, bool STATES = false>
 __global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rollout_body<MODEL, 32, GROUPS, LEAN>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
+  rollout_body<MODEL, 32, GROUPS, LEAN, STATES>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
-static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds) {
-  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + 2 + (size_t)D + 2 * (size_t)M);
+static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds, bool stage_states = false, int grid_words = 0) {
+  return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + 2 + (size_t)D + 2 * (size_t)M) + 16 +
+         sizeof(uint32_t) * (size_t)grid_words +                     // occupancy grid (Particle)
+         (stage_states ? (size_t)(nt / 64) * 64 * (DUST_STG_CHUNK + 16) : 0);  // + one staging row (chunk + 16 B) per lane
 }
 
 }  // namespace dust

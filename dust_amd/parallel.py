@@ -224,8 +224,8 @@ class ShardedSVMPC:
     def set_state(self, theta, mu, a_mat=None):
         self.shard.set_state(theta, mu, a_mat)
 
-    def tick(self, state, n_iters, eps=None, want_outputs=False):
-        return tick((self.shard,), self.comm, state, n_iters, eps, None, want_outputs)
+    def tick(self, state, n_iters, eps=None, want_outputs=False, params=None):
+        return tick((self.shard,), self.comm, state, n_iters, eps, params, want_outputs)
 
     def sync(self):
         self.shard.sync()

@@ -327,3 +327,8 @@ class Oracle:
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    """OpenMP thread count of the following oracle calls; False when the oracle was built without OpenMP."""
+    return bool(lib().orc_set_num_threads(C.c_int(int(n))))

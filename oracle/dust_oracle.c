@@ -27,6 +27,16 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+/* bench.py's cpu_baseline reports an all-threads and a one-thread figure; returns 0 when built without OpenMP */
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+  return 1;
+#else
+  (void)n;
+  return 0;
+#endif
+}
 
 /* ---- Python/torch mixed scalar-tensor arithmetic, as the interpreter evaluates pendulum.py:93-96 ----
  * kind 0: Python float (double);  kind 1/2: fp32 tensor element. */

@@ -130,6 +130,7 @@ void orc_tick_k1(const orc_cfg *c, const float *state, float *theta, float *mu, 
                  const float *sigma_a, const float *eps, int n_iters, float alpha, float lr, float *a_mat, float *a_seq_out,
                  float *p_weights, float *costs_out);
 int orc_num_threads(void);
+int orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }
