@@ -121,6 +121,19 @@ class Context:
             self.set_grid(grid)
 
     # ---- lifecycle
+    # ---- C-side multi-GPU tick (include/dust_amd.h dust_comm_*): one RCCL communicator per sharded context
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId on the calling rank: 128 opaque bytes to hand to every rank (e.g. torch.distributed.broadcast_object_list)."""
+        buf = C.create_string_buffer(128)
+        L.check(L.load().dust_comm_unique_id(C.cast(buf, L.VP)))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """ncclCommInitRank (collective over the ranks).  Afterwards svmpc_tick / svmpc_optimize / svmpc_forward run the sharded tick."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(L.load().dust_comm_init(self._h, C.cast(buf, L.VP), int(rank), int(world)))
+
     def close(self):
         if self._h is not None:
             L.load().dust_destroy(self._h)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -103,6 +104,9 @@ struct dust_ctx {
   unsigned int *iter_cnt;
   int iter_tiles, iter_js, iter_set;
   float *score_hs;  // [2][N][D] score rows handed over as data inside the one-launch iteration (sentinel-filled between uses)
+  // C-side RCCL communicator of a sharded context (dust_comm_init): the sharded tick issues its all-gathers on the context's stream
+  void *comm;  // ncclComm_t
+  int comm_rank, comm_world;
   // tick outputs: a_seq_out | p_weights | time-out word of the persistent tick live in ONE device block, copied with ONE
   // hipMemcpyAsync into a pinned host buffer (then one stream synchronisation per tick that returns outputs)
   float *outblk;
@@ -293,10 +297,18 @@ static void free_all(dust_ctx *c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
+// a communicator of one rank is the unsharded problem: it runs the single-GPU path (DUST_COMM_FORCE=1: development switch that
+// sends a world-1 context through the sharded tick and its RCCL calls, for tests and per-collective latency measurements)
+static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || getenv("DUST_COMM_FORCE") != nullptr); }
+static void comm_release(dust_ctx *c);
+static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
+static int sharded_forward(dust_ctx *c);
+
 extern "C" void dust_destroy(dust_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
+  comm_release(c);
   free_all(c);
   delete c;
 }
@@ -1551,7 +1563,11 @@ extern "C" int dust_svmpc_optimize(dust_ctx *c, const float *state, int n_steps,
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
   if (n_steps < 0) return fail(DUST_ERR_INVALID, "n_steps < 0");
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
-  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: drive it with dust_svmpc_local_score / dust_svmpc_apply_phi");
+  if (comm_active(c)) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return sharded_steps(c, state, n_steps, eps, params, flags);
+  }
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context without a communicator: dust_comm_init, or drive it with dust_svmpc_local_score / dust_svmpc_apply_phi");
   HIP_TRY(hipSetDevice(c->cfg.device));
   if (n_steps >= 1) {
     bool done = false;
@@ -1645,7 +1661,13 @@ static int forward_finish_device(dust_ctx *c) {
 
 extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
-  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: use dust_svmpc_forward_local / _finish");
+  if (comm_active(c)) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(sharded_forward(c));
+    if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+    return DUST_OK;
+  }
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context without a communicator: dust_comm_init, or use dust_svmpc_forward_local / _finish");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(forward_device(c));
   TRY(forward_finish_device(c));
@@ -1833,6 +1855,129 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// RCCL (the NCCL API on ROCm), bound at run time: libdust_amd.so carries no link-time dependency on it (single-GPU hosts need
+// none), and a process that already holds an RCCL (torch.distributed's) shares that copy instead of loading a second one.
+namespace rccl {
+typedef int (*get_unique_id_t)(void *);
+struct UniqueId {
+  char internal[128];
+};
+typedef int (*all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*comm_destroy_t)(void *);
+typedef const char *(*get_error_string_t)(int);
+static void *handle = nullptr;
+static get_unique_id_t get_unique_id = nullptr;
+static int (*comm_init_rank)(void **, int, UniqueId, int) = nullptr;
+static all_gather_t all_gather = nullptr;
+static comm_destroy_t comm_destroy = nullptr;
+static get_error_string_t get_error_string = nullptr;
+enum { ncclFloat32 = 7 };
+static int load() {
+  if (all_gather) return DUST_OK;
+  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {  // a copy already mapped into the process first (torch's), then the ROCm installation's
+    handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (handle) break;
+  }
+  for (int i = 0; !handle && i < 3; ++i) handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!handle) return fail(DUST_ERR_UNSUPPORTED, "RCCL not found (librccl.so): %s", dlerror());
+  get_unique_id = (get_unique_id_t)dlsym(handle, "ncclGetUniqueId");
+  comm_init_rank = (int (*)(void **, int, UniqueId, int))dlsym(handle, "ncclCommInitRank");
+  all_gather = (all_gather_t)dlsym(handle, "ncclAllGather");
+  comm_destroy = (comm_destroy_t)dlsym(handle, "ncclCommDestroy");
+  get_error_string = (get_error_string_t)dlsym(handle, "ncclGetErrorString");
+  if (!get_unique_id || !comm_init_rank || !all_gather || !comm_destroy) {
+    all_gather = nullptr;
+    return fail(DUST_ERR_UNSUPPORTED, "librccl.so lacks the NCCL entry points");
+  }
+  return DUST_OK;
+}
+static int check(int r, const char *what) {
+  if (r == 0) return DUST_OK;
+  return fail(DUST_ERR_HIP, "%s failed: %s", what, get_error_string ? get_error_string(r) : "RCCL error");
+}
+}  // namespace rccl
+
+static void comm_release(dust_ctx *c) {
+  if (c->comm && rccl::comm_destroy) (void)rccl::comm_destroy(c->comm);
+  c->comm = nullptr;
+}
+
+extern "C" int dust_comm_unique_id(void *id) {
+  if (!id) return fail(DUST_ERR_INVALID, "null id");
+  TRY(rccl::load());
+  return rccl::check(rccl::get_unique_id(id), "ncclGetUniqueId");
+}
+
+extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) {
+  if (!c || !id) return fail(DUST_ERR_INVALID, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(DUST_ERR_INVALID, "bad rank %d of %d", rank, world);
+  if (c->N % world || c->nloc != c->N / world || c->n0 != rank * (c->N / world))
+    return fail(DUST_ERR_INVALID, "context shard [%d,+%d) is not rank %d's equal share of %d particles over %d ranks", c->n0, c->nloc, rank, c->N, world);
+  if (c->comm) return fail(DUST_ERR_STATE, "the context already has a communicator");
+  TRY(rccl::load());
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  rccl::UniqueId uid;
+  memcpy(uid.internal, id, sizeof uid.internal);
+  void *comm = nullptr;
+  TRY(rccl::check(rccl::comm_init_rank(&comm, world, uid, rank), "ncclCommInitRank"));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  // the collectives gather IN PLACE in the context's [N][D] buffers: theta stays in one buffer from here on
+  if (c->theta != c->theta_home) {
+    TRY(d2d(c, c->theta_home, c->theta, (size_t)c->N * c->D * sizeof(float)));
+    c->theta_alt = c->theta;
+    c->theta = c->theta_home;
+  }
+  if (c->graph_exec) graph_drop(c);
+  c->theta_pinned = true;
+  return DUST_OK;
+}
+
+extern "C" int dust_comm_destroy(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->comm) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)rccl::comm_destroy(c->comm);
+    c->comm = nullptr;
+  }
+  return DUST_OK;
+}
+
+// in-place all-gather of every rank's `count` floats (rank r's piece at buf + r * count), on the context's stream
+static int gather_inplace(dust_ctx *c, float *buf, size_t count) {
+  return rccl::check(rccl::all_gather(buf + (size_t)c->comm_rank * count, buf, count, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather");
+}
+
+// One control tick of a SHARDED context with its own communicator (north_star: "an RCCL all-gather over xGMI of
+// particle states before the pairwise kernel step"): rank-local rollouts / prior rows / score -> all-gather(score) -> Stein pass
+// + update of the rank's rows -> all-gather(theta) (the prior means alias theta: the next prior pass needs every rank's new
+// particles) ... -> local log-weights -> all-gather -> finalize + roll -> all-gather(theta).  Kernels and collectives share the
+// context's stream: no host synchronisation inside the tick.
+static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags) {
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  TRY(upload_state_params(c, state, params, n_steps));
+  const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
+  const size_t shard = (size_t)c->nloc * c->D;
+  for (int k = 0; k < n_steps; ++k) {
+    const float *nd = nullptr;
+    TRY(stage_noise(c, eps ? eps + (size_t)k * slice : nullptr, flags, &nd));
+    TRY(local_score_device(c, nd, k));
+    TRY(gather_inplace(c, c->score, shard));
+    TRY(launch_stein_update(c, 1));
+    TRY(gather_inplace(c, c->theta, shard));
+  }
+  return DUST_OK;
+}
+static int sharded_forward(dust_ctx *c) {
+  TRY(forward_device(c));  // rank-local log p and log-weights
+  TRY(gather_inplace(c, c->lw, (size_t)c->nloc));
+  TRY(forward_finish_device(c));
+  return gather_inplace(c, c->theta, (size_t)c->nloc * c->D);  // the other ranks' rolled rows
+}
+
 // stage the caller's inputs and try the persistent launch; *done = false -> nothing was launched
 static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
                           bool *done) {
@@ -1892,6 +2037,13 @@ static void graph_drop(dust_ctx *c) {
 extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags,
                                float *a_seq, float *p_weights) {
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (comm_active(c)) {  // sharded context with its own RCCL communicator
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(sharded_steps(c, state, n_steps, eps, params, flags));
+    TRY(sharded_forward(c));
+    if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+    return DUST_OK;
+  }
   {  // one persistent launch for the whole tick when the shape allows it (persist.hpp)
     bool done = false;
     TRY(try_persistent(c, state, n_steps, eps, params, flags, /*do_forward=*/true, &done));

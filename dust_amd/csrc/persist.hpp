@@ -903,6 +903,12 @@ template <int MODEL, int MODE, int CPT>
 __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svmpc_tick_kernel(const TickArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b0 = (int)blockIdx.x;
+#ifdef DUST_STAMPS
+  if (f.tl && threadIdx.x == 0) {  // placement census: raw HW_ID (wave / simd / cu / sh / se fields) and XCC_ID of every workgroup
+    f.tl[128 * blockIdx.x + 126] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    f.tl[128 * blockIdx.x + 127] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+  }
+#endif
   if (b0 == 0)
     for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
   if (b0 < f.n_pair_blocks) {

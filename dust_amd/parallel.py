@@ -214,18 +214,43 @@ def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False
 
 
 class ShardedSVMPC:
-    """Convenience wrapper: one rank of a torch.distributed job."""
+    """One rank of a torch.distributed job.
 
-    def __init__(self, common_cfg, rank, world, dist):
-        self.shard = DeviceShard(common_cfg, rank, world, device_index=common_cfg.get("device", 0))
-        self.comm = TorchComm(dist, rank)
-        self.ctx = self.shard.ctx
+    c_side=True (default on GPUs): the context owns an RCCL communicator (dust_comm_init) and libdust_amd runs the whole sharded
+    tick itself - kernels and all-gathers on one stream, no Python between them; torch.distributed only carries the 128-byte
+    communicator id from rank 0 to the others.  c_side=False: the phase / collective order is stepped from Python through
+    torch.distributed (the form the gloo CPU tests and the single-GPU LocalComm equivalence tests drive)."""
+
+    def __init__(self, common_cfg, rank, world, dist, c_side=True):
+        self.c_side = bool(c_side)
+        self.rank, self.world = rank, world
+        if self.c_side:
+            off, n_loc = shard_bounds(common_cfg["N"], rank, world)
+            self.ctx = Context(**dict(common_cfg, shard_offset=off, shard_size=n_loc))
+            ids = [Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            self.ctx.comm_init(ids[0], rank, world)
+            self.shard = None
+        else:
+            self.shard = DeviceShard(common_cfg, rank, world, device_index=common_cfg.get("device", 0))
+            self.comm = TorchComm(dist, rank)
+            self.ctx = self.shard.ctx
 
     def set_state(self, theta, mu, a_mat=None):
-        self.shard.set_state(theta, mu, a_mat)
+        if self.c_side:
+            self.ctx.set_theta(theta)
+            self.ctx.set_prior(mu)
+            self.ctx.set_a_mat(theta if a_mat is None else a_mat)
+        else:
+            self.shard.set_state(theta, mu, a_mat)
 
     def tick(self, state, n_iters, eps=None, want_outputs=False, params=None):
+        if self.c_side:
+            return self.ctx.svmpc_tick(state, n_iters, eps, params, want_outputs=want_outputs)
         return tick((self.shard,), self.comm, state, n_iters, eps, params, want_outputs)
 
     def sync(self):
-        self.shard.sync()
+        if self.c_side:
+            self.ctx.sync()
+        else:
+            self.shard.sync()

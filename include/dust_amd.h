@@ -192,6 +192,18 @@ int dust_svmpc_local_prior_score(dust_ctx *ctx);
 int dust_svmpc_apply_phi(dust_ctx *ctx);
 int dust_svmpc_forward_local(dust_ctx *ctx, void **log_w_all, size_t *shard_bytes);
 int dust_svmpc_forward_finish(dust_ctx *ctx, float *a_seq, float *p_weights);
+/* C-side multi-GPU tick (BASELINE.json north_star: "particle batches shard across the 8 GPUs of one node with an
+ * RCCL all-gather over xGMI of particle states before the pairwise kernel step").  One process per GPU, each with a context created
+ * for its shard (shard_offset = rank * N / world, shard_size = N / world).  Rank 0 calls dust_comm_unique_id and hands the bytes to
+ * every rank out of band (MPI, a file, torch.distributed.broadcast_object_list, ...); every rank then calls dust_comm_init
+ * (ncclCommInitRank - collective).  From then on dust_svmpc_tick / _optimize / _forward run the sharded tick themselves: the
+ * in-place all-gathers of score and theta (per SVGD iteration) and of the log-weights and rolled particles (per tick) are issued
+ * on the context's stream between the kernels - no host synchronisation, no Python in the loop.  RCCL is bound at run time
+ * (dlopen of librccl.so): single-GPU hosts need none. */
+#define DUST_COMM_ID_BYTES 128
+int dust_comm_unique_id(void *id /* DUST_COMM_ID_BYTES */);
+int dust_comm_init(dust_ctx *ctx, const void *id, int rank, int world);
+int dust_comm_destroy(dust_ctx *ctx);
 /* run the context's kernels on an external HIP stream (hipStream_t), e.g. torch's current stream */
 int dust_set_stream(dust_ctx *ctx, void *hip_stream);
 

@@ -415,6 +415,92 @@ def test_sharded_equals_unsharded(golden, world, overlap):
         assert relerr(pw, rp) < 1e-5 and np.array_equal(a_seq, ra)
 
 
+def _synthetic_case(model, N, S, M, H, seed=3):
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(seed)
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    th = (mu + rng.standard_normal((N, H, da))).astype(np.float32)
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    up = None if M == 1 else ("mass",)
+    grid = None
+    if model == "particle":
+        from oracle import grid_4x4_map  # data only (the demo's occupancy grid)
+
+        grid = grid_4x4_map()
+    return da, rng, mu, th, state, up, grid
+
+
+@pytest.mark.parametrize("model,N,S,M,H,kernel", [("pendulum", 256, 64, 1, 12, "K1"), ("particle", 128, 64, 4, 40, "K1"),
+                                                  ("particle", 96, 32, 1, 40, "IMQ"), ("pendulum", 128, 64, 1, 10, "K2")])
+def test_sharded_ticks_equal_unsharded_synthetic(model, N, S, M, H, kernel):
+    """Particle sharding on ONE GPU (2 and 4 sharded contexts in one process, all-gathers as slice copies) beyond the Pendulum
+    golden: Particle with D = H * da = 80 (the cfg4 shape), the IMQ kernel, and K2, whose per-dimension median bandwidths are
+    GLOBAL order statistics over every rank's particles."""
+    from dust_amd import Context
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    da, rng, mu, th, state, up, grid = _synthetic_case(model, N, S, M, H)
+    K, T = 2, 2
+    eps = rng.standard_normal((T, K, S, N, H, da)).astype(np.float32)
+    params = None if M == 1 else (1.0 + 0.1 * rng.standard_normal((T, K, M, 1))).astype(np.float32)
+    kw = dict(model=model, N=N, S=S, M=M, H=H, kernel=kernel, lr=0.5, sigma_a=1.0, sigma_p=1.0, uncertain_params=up, seed=11)
+    ref = Context(grid=grid, **kw)
+    ref.set_theta(th); ref.set_prior(mu); ref.set_a_mat(th)
+    outs = []
+    for t in range(T):
+        outs.append(ref.svmpc_tick(state, K, eps[t], None if params is None else params[t]))
+    rt = ref.get_theta()
+    for world in (2, 4):
+        shards = tuple(DeviceShard(dict(kw, grid=grid), r, world) for r in range(world))
+        for sh in shards:
+            sh.set_state(th, mu, th)
+        for t in range(T):
+            a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], None if params is None else params[t], want_outputs=True)
+            assert np.array_equal(a_seq, outs[t][0]), (world, t)
+            assert relerr(pw, outs[t][1]) < 1e-5
+        for sh in shards:
+            sh.sync()
+            assert elemerr(sh.ctx.get_theta(), rt) < 2e-6, (world, sh.rank)
+            sh.ctx.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 256, 64, 1, 12), ("particle", 128, 64, 4, 40)])
+def test_c_side_rccl_tick_world1(model, N, S, M, H):
+    """The C-side sharded tick (dust_comm_init: the context's own RCCL communicator, all-gathers issued on its stream by
+    libdust_amd) on a world of ONE rank, forced through the sharded code path (DUST_COMM_FORCE): every ncclAllGather runs, the
+    result must equal the unsharded launch-per-iteration tick bit for bit.  (World sizes > 1 need one GPU per rank: the driver's
+    multi-GPU bench; the phase order itself is covered by the LocalComm / gloo tests.)"""
+    from dust_amd import Context
+
+    da, rng, mu, th, state, up, grid = _synthetic_case(model, N, S, M, H)
+    K, T = 3, 3
+    eps = rng.standard_normal((T, K, S, N, H, da)).astype(np.float32)
+    params = None if M == 1 else (1.0 + 0.1 * rng.standard_normal((T, K, M, 1))).astype(np.float32)
+    kw = dict(model=model, N=N, S=S, M=M, H=H, kernel="K1", lr=0.5, sigma_a=1.0, sigma_p=1.0, uncertain_params=up, grid=grid, seed=11)
+    res = []
+    for env, sharded in (({"DUST_NO_PERSIST": "1"}, False), ({"DUST_COMM_FORCE": "1"}, True)):
+        saved = {k: os.environ.pop(k, None) for k in ("DUST_NO_PERSIST", "DUST_COMM_FORCE")}
+        os.environ.update(env)
+        try:
+            c = Context(shard_offset=0, shard_size=N, **kw) if sharded else Context(**kw)
+            if sharded:
+                c.comm_init(Context.comm_unique_id(), 0, 1)
+            c.set_theta(th); c.set_prior(mu); c.set_a_mat(th)
+            outs = [c.svmpc_tick(state, K, eps[t], None if params is None else params[t]) for t in range(T)]
+            res.append((c.get_theta(), outs))
+            c.close()
+        finally:
+            for k in ("DUST_NO_PERSIST", "DUST_COMM_FORCE"):
+                os.environ.pop(k, None)
+                if saved[k] is not None:
+                    os.environ[k] = saved[k]
+    (t0, o0), (t1, o1) = res
+    assert np.array_equal(t0, t1)
+    for (a0, p0), (a1, p1) in zip(o0, o1):
+        assert np.array_equal(a0, a1) and relerr(p1, p0) < 1e-5
+
+
 @pytest.mark.parametrize("model,N,S,M,H", [("pendulum", 1024, 128, 1, 30), ("pendulum", 512, 64, 1, 12), ("particle", 256, 64, 4, 20),
                                            ("pendulum", 100, 40, 1, 7), ("pendulum", 33, 130, 3, 3), ("particle", 64, 96, 2, 9),
                                            ("pendulum", 96, 256, 1, 33), ("particle", 40, 30, 1, 31)])

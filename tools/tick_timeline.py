@@ -54,6 +54,24 @@ def main(N=1024, S=128, H=30, kernel="K1", iters=5, show=(2,)):
     for k, name, lab, lo, med, hi in marks:
         if k in show or k == iters or not lab.startswith("  "):
             print("  k=%d %-6s %-26s %7.2f %7.2f %7.2f" % (k, name, lab, lo, med, hi))
+    # placement census: which workgroups share a CU (HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13; XCC_ID bits 3:0)
+    hw, xcc = v[:, 126], v[:, 127] & 0xF
+    cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)
+    from collections import Counter
+    mix = Counter()
+    for key in np.unique(cu):
+        blocks = np.nonzero(cu == key)[0]
+        mix[(int((blocks < P).sum()), int((blocks >= P).sum()))] += 1
+    print("CUs by (pair workgroups, owner workgroups) resident:", dict(mix), " distinct CUs:", len(np.unique(cu)))
+    own_done = (v[P:, 16 * 2 + 2] - t0) * 0.01
+    for key in list(np.unique(cu))[:0]:
+        pass
+    # rollouts-done time of owners grouped by how many owner workgroups share their CU
+    per_cu_owner = {key: int(((cu == key) & (np.arange(G) >= P)).sum()) for key in np.unique(cu)}
+    for n_own in sorted(set(per_cu_owner.values())):
+        sel = np.array([per_cu_owner[k] == n_own for k in cu[P:]])
+        if sel.any():
+            print("  owners on CUs with %d owner workgroups: rollouts done (k=2) median %.2f max %.2f  (n=%d)" % (n_own, np.median(own_done[sel]), own_done[sel].max(), sel.sum()))
     c.close()
 
 
