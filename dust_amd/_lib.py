@@ -16,7 +16,7 @@ COST_PENDULUM_QUADCOS, COST_PARTICLE_DEFAULT = 0, 1
 KERNEL_K1_RBF, KERNEL_K2_IIDMP, KERNEL_K2_SHARED, KERNEL_IMQ = 0, 1, 2, 3
 LIK_EXP_UTILITY, LIK_EXPECTED_COST = 0, 1
 OPT_SGD, OPT_ADAM = 0, 1
-ROLL_REPEAT, ROLL_MEAN = 0, 1
+ROLL_REPEAT, ROLL_MEAN, ROLL_RESAMPLE = 0, 1, 2
 STEP_ARGMAX, STEP_AVERAGE, STEP_EXTERNAL = 0, 1, 2
 PARAM_PYFLOAT, PARAM_SAMPLED, PARAM_TENSOR0D = 0, 1, 2
 PTR_DEVICE, STORE_STATES, EPS_AROUND_A_MAT, EPS_F16, STORE_F16 = 1, 2, 4, 8, 16
@@ -101,6 +101,11 @@ SYMBOLS = {
     "dust_svmpc_step": (C.c_int, [VP, FP, VP, FP, C.c_int]),
     "dust_svmpc_optimize": (C.c_int, [VP, FP, C.c_int, VP, FP, C.c_int]),
     "dust_svmpc_forward": (C.c_int, [VP, FP, FP]),
+    "dust_svmpc_get_weights": (C.c_int, [VP, FP]),
+    "dust_svmpc_roll": (C.c_int, [VP, C.c_int, C.c_int, FP]),
+    "dust_svmpc_update_prior": (C.c_int, [VP, FP]),
+    "dust_svmpc_forward_ex": (C.c_int, [VP, C.c_int, FP, FP, FP]),
+    "dust_likelihood_sample_at": (C.c_int, [VP, FP, FP, VP, FP, C.c_int, FP, FP]),
     "dust_svmpc_tick": (C.c_int, [VP, FP, C.c_int, VP, FP, C.c_int, FP, FP]),
     "dust_get_costs": (C.c_int, [VP, FP]),
     "dust_get_actions": (C.c_int, [VP, FP]),

@@ -59,7 +59,7 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     c.kernel = {"K1": L.KERNEL_K1_RBF, "K2": L.KERNEL_K2_IIDMP, "K2shared": L.KERNEL_K2_SHARED, "IMQ": L.KERNEL_IMQ}[kernel]
     c.likelihood = L.LIK_EXP_UTILITY if likelihood == "ExponentiatedUtility" else L.LIK_EXPECTED_COST
     c.optimizer = L.OPT_SGD if optimizer == "SGD" else L.OPT_ADAM
-    c.roll_strategy = {"repeat": L.ROLL_REPEAT, "mean": L.ROLL_MEAN}[roll_strategy]
+    c.roll_strategy = {"repeat": L.ROLL_REPEAT, "mean": L.ROLL_MEAN, "resample": L.ROLL_RESAMPLE}[roll_strategy]
     c.weighted_prior = int(weighted_prior)
     c.params_log_space = int(params_log_space)
     c.params_interleave = int(params_scalar_event)
@@ -273,6 +273,39 @@ class Context:
         a_seq = np.empty((self.H, self.da), np.float32)
         pw = np.empty(self.N, np.float32)
         L.check(L.load().dust_svmpc_forward(self._h, _p(a_seq), _p(pw)))
+        return a_seq, pw
+
+    def likelihood_sample_at(self, state, theta, eps=None, params=None, want_actions=False):
+        """CostLikelihood.sample(theta, ...) for a theta that is not the optimiser's: the context's particles / Adam state stay."""
+        st = _f(state, (self.ds,))
+        th = _f(theta, (self.N, self.H, self.da))
+        e, fl = _fh(eps, (self.S, self.N, self.H, self.da))
+        pr = self._params(params)
+        costs = np.empty((self.S, self.N), np.float32)
+        aout = np.empty((self.S, self.N, self.H, self.da), np.float32) if want_actions else None
+        L.check(L.load().dust_likelihood_sample_at(self._h, _p(st), _p(th), _vp(e), _p(pr), fl, _p(costs), _p(aout)))
+        return (costs, aout) if want_actions else costs
+
+    def svmpc_get_weights(self):
+        pw = np.empty(self.N, np.float32)
+        L.check(L.load().dust_svmpc_get_weights(self._h, _p(pw)))
+        return pw
+
+    def svmpc_roll(self, steps=-1, strategy="repeat", last_row=None):
+        st = {"repeat": L.ROLL_REPEAT, "mean": L.ROLL_MEAN, "resample": L.ROLL_RESAMPLE}.get(strategy)
+        if st is None:
+            raise ValueError("{} is an invalid roll strategy.".format(strategy))
+        lr = None if last_row is None else _f(last_row, (self.N, self.da))
+        L.check(L.load().dust_svmpc_roll(self._h, int(steps), st, _p(lr)))
+
+    def svmpc_update_prior(self, weights=None):
+        w = None if weights is None else _f(weights, (self.N,))
+        L.check(L.load().dust_svmpc_update_prior(self._h, _p(w)))
+
+    def svmpc_forward_ex(self, steps=-1, resample_last_row=None):
+        a_seq, pw = np.empty((self.H, self.da), np.float32), np.empty(self.N, np.float32)
+        lr = None if resample_last_row is None else _f(resample_last_row, (self.N, self.da))
+        L.check(L.load().dust_svmpc_forward_ex(self._h, int(steps), _p(lr), _p(a_seq), _p(pw)))
         return a_seq, pw
 
     def svmpc_tick(self, state, n_steps, eps=None, params=None, eps_dev_ptr=None, want_outputs=True):

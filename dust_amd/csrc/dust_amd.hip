@@ -985,6 +985,36 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
   return DUST_OK;
 }
 
+extern "C" int dust_likelihood_sample_at(dust_ctx *c, const float *state, const float *theta, const float *eps, const float *params, int flags,
+                                         float *costs, float *actions_out) {
+  if (!c || !state || !theta) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(upload_state_params(c, state, params, 1));
+  const float *nd = nullptr;
+  TRY(stage_noise(c, eps, flags, &nd));
+  // the caller's theta rides in the spare particle buffer of the ping-pong: the optimiser's particles and moments stay untouched
+  float *base = c->theta_alt && c->theta_alt != c->theta ? c->theta_alt : nullptr;
+  if (!base) return fail(DUST_ERR_STATE, "no spare particle buffer");
+  TRY(h2d(c, base, theta, (size_t)c->N * c->D * sizeof(float)));
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = eps ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = nd;
+  o.base = base;
+  o.update_a_mat = 1;
+  o.want_actions = actions_out != nullptr;
+  o.want_states = (flags & DUST_STORE_STATES) != 0;
+  o.store_f16 = (flags & DUST_STORE_F16) != 0;
+  TRY(launch_rollout(c, o));
+  c->have_sample = true;
+  bump_iter_kernel<<<1, 1, 0, c->stream>>>(c->ctr_dev);
+  HIP_TRY(hipGetLastError());
+  if (costs) TRY(copy_out_SN(c, c->costsT, costs));
+  if (actions_out) TRY(d2h(c, actions_out, c->actions, (size_t)c->S * c->N * c->D * (o.store_f16 ? 2 : sizeof(float))));
+  return DUST_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pairwise passes (tiled: PAIR_TI queries x key slices; partials combined by the next kernel in the chain)
 
@@ -1601,8 +1631,7 @@ static int forward_device(dust_ctx *c) {
   return DUST_OK;
 }
 
-static int forward_finish_device(dust_ctx *c) {
-  Prof p(c, DUST_K_FORWARD);
+static FinalizeArgs finalize_args(dust_ctx *c, bool keep_prior) {
   FinalizeArgs f;
   memset(&f, 0, sizeof f);
   f.N = c->N;
@@ -1617,11 +1646,15 @@ static int forward_finish_device(dust_ctx *c) {
   f.logmix = c->logmix;
   f.mixw = c->mixw;
   f.weighted_prior = c->cfg.weighted_prior;
+  f.keep_prior = keep_prior ? 1 : 0;
   if (c->nloc == c->N) {
     f.merge_logp = 1;
     f.logp_out = c->logp;
     f.pm = prior_merge_args(c);
   }
+  return f;
+}
+static RollArgs roll_args(dust_ctx *c, int steps, int strategy, const float *last_row_dev) {
   RollArgs r;
   memset(&r, 0, sizeof r);
   r.theta = c->theta;
@@ -1629,7 +1662,9 @@ static int forward_finish_device(dust_ctx *c) {
   r.N = c->N;
   r.H = c->H;
   r.da = c->da;
-  r.strategy = c->cfg.roll_strategy;
+  r.strategy = strategy;
+  r.steps = steps;
+  r.last_row = last_row_dev;
   r.i0 = c->n0;
   r.n_local = c->nloc;
   r.ctr = c->ctr_dev;
@@ -1641,7 +1676,21 @@ static int forward_finish_device(dust_ctx *c) {
     r.hs = reinterpret_cast<unsigned int *>(c->score_hs);
     r.hs_n = 2 * c->N * c->D;
   }
-  if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && c->D <= 128 && !c->prof) {
+  return r;
+}
+static void roll_done(dust_ctx *c) {
+  if (c->theta != c->theta_home) {
+    c->theta_alt = c->theta;
+    c->theta = c->theta_home;
+  }
+}
+
+// weights + argmax (+ prior refresh), then the roll: SVMPC.forward's tail (svmpc.py:190-200)
+static int forward_finish_device(dust_ctx *c, int steps = -1, const float *last_row_dev = nullptr) {
+  Prof p(c, DUST_K_FORWARD);
+  const FinalizeArgs f = finalize_args(c, false);
+  const RollArgs r = roll_args(c, steps, c->cfg.roll_strategy, last_row_dev);
+  if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && steps == -1 && c->D <= 128 && !c->prof) {
     // out-of-place roll: independent of finalize (which gathers a_seq from the buffer the roll only reads) -> one launch
     finalize_roll_kernel<<<1 + (c->nloc + 7) / 8, 1024, 0, c->stream>>>(f, r);
     HIP_TRY(hipGetLastError());
@@ -1651,16 +1700,77 @@ static int forward_finish_device(dust_ctx *c) {
     roll_kernel<<<c->nloc, 128, 0, c->stream>>>(r);
     HIP_TRY(hipGetLastError());
   }
-  if (c->theta != c->theta_home) {
-    c->theta_alt = c->theta;
-    c->theta = c->theta_home;
-  }
+  roll_done(c);
   c->mu_aliased = true;  // update_prior: the new GMM's means alias theta from here on (svmpc.py:160-170, svgd.py:87)
   return DUST_OK;
 }
 
-extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
+static int resample_rows(dust_ctx *c, const float *host_rows, const float **dev) {
+  *dev = nullptr;
+  if (c->cfg.roll_strategy != DUST_ROLL_RESAMPLE && !host_rows) return DUST_OK;
+  if (!host_rows) return fail(DUST_ERR_INVALID, "roll strategy 'resample' needs the last action of a prior sample per particle ([N][da])");
+  TRY(ensure(&c->tmp, &c->tmp_cap, (size_t)c->N * c->da));
+  TRY(h2d(c, c->tmp, host_rows, (size_t)c->N * c->da * sizeof(float)));
+  *dev = c->tmp;
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_get_weights(dust_ctx *c, float *p_weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: get_weights is part of the sharded forward");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(forward_device(c));
+  const FinalizeArgs f = finalize_args(c, true);
+  finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
+  HIP_TRY(hipGetLastError());
+  if (p_weights) TRY(tick_outputs(c, nullptr, p_weights));
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float *last_row) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (strategy < DUST_ROLL_REPEAT || strategy > DUST_ROLL_RESAMPLE) return fail(DUST_ERR_INVALID, "%d is an invalid roll strategy.", strategy);
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the roll is part of the sharded forward");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->graph_exec) graph_drop(c);
+  const float *lr = nullptr;
+  if (strategy == DUST_ROLL_RESAMPLE) {
+    if (!last_row) return fail(DUST_ERR_INVALID, "strategy 'resample' needs last_row [N][da]");
+    TRY(ensure(&c->tmp, &c->tmp_cap, (size_t)c->N * c->da));
+    TRY(h2d(c, c->tmp, last_row, (size_t)c->N * c->da * sizeof(float)));
+    lr = c->tmp;
+  }
+  const RollArgs r = roll_args(c, steps, strategy, lr);
+  roll_kernel<<<c->nloc, 128, 0, c->stream>>>(r);
+  HIP_TRY(hipGetLastError());
+  roll_done(c);
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_update_prior(dust_ctx *c, const float *weights) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->graph_exec) graph_drop(c);
+  std::vector<float> w((size_t)c->N, 1.0f);
+  if (weights && c->cfg.weighted_prior) {  // svmpc.py:162-165: mix = ones unless weighted_prior
+    for (int i = 0; i < c->N; ++i) {
+      if (!(weights[i] >= 0.f)) return fail(DUST_ERR_INVALID, "mixture weights must be >= 0 (torch.distributions.Categorical)");
+      w[i] = weights[i];
+    }
+  }
+  TRY(h2d(c, c->mixw, w.data(), c->N * sizeof(float)));
+  logmix_kernel<<<1, 1024, 0, c->stream>>>(c->mixw, c->logmix, c->N);
+  HIP_TRY(hipGetLastError());
+  c->mu_aliased = true;  // get_gmm(self.theta, ...): the means alias theta (svgd.py:87)
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) { return dust_svmpc_forward_ex(c, -1, nullptr, a_seq, p_weights); }
+
+extern "C" int dust_svmpc_forward_ex(dust_ctx *c, int steps, const float *resample_last_row, float *a_seq, float *p_weights) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE && !resample_last_row)
+    return fail(DUST_ERR_INVALID, "roll strategy 'resample': pass the last action of a prior sample per particle ([N][da])");
   if (comm_active(c)) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(sharded_forward(c));
@@ -1669,8 +1779,11 @@ extern "C" int dust_svmpc_forward(dust_ctx *c, float *a_seq, float *p_weights) {
   }
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context without a communicator: dust_comm_init, or use dust_svmpc_forward_local / _finish");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (steps != -1 && c->graph_exec) graph_drop(c);
+  const float *lr = nullptr;
+  TRY(resample_rows(c, resample_last_row, &lr));
   TRY(forward_device(c));
-  TRY(forward_finish_device(c));
+  TRY(forward_finish_device(c, steps, lr));
   if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
   return DUST_OK;
 }
@@ -1693,6 +1806,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
+  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE) return DUST_OK;  // the last row comes from a host-drawn prior sample
   if (do_forward && !c->have_sample && n_steps == 0) return DUST_OK;
   if (c->noise_f16 && eps_dev) return DUST_OK;
   if (c->N > 4096) return DUST_OK;
@@ -2037,6 +2151,8 @@ static void graph_drop(dust_ctx *c) {
 extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags,
                                float *a_seq, float *p_weights) {
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE)
+    return fail(DUST_ERR_UNSUPPORTED, "roll strategy 'resample' draws from the prior on the host: call dust_svmpc_optimize, then dust_svmpc_forward_ex");
   if (comm_active(c)) {  // sharded context with its own RCCL communicator
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(sharded_steps(c, state, n_steps, eps, params, flags));

@@ -20,6 +20,7 @@ struct FinalizeArgs {
   float *logmix;             // [N] out: new prior log mixture weights
   float *mixw;               // [N] out: new prior mixture weights as given to get_gmm (ones or p)
   int weighted_prior;
+  int keep_prior;            // SVMPC.get_weights alone (svmpc.py:128-140): weights / argmax only, the prior mixture stays
   int merge_logp;            // unsharded path: combine the prior-pass partials here (log p, then lw = logl + logp)
   float *logp_out;           // [N]
   PriorMerge pm;
@@ -123,6 +124,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
   }
   if (tid == 0) *a.istar = bi;
   for (int d = tid; d < a.D; d += nt) a.a_seq_out[d] = a.theta[(size_t)bi * a.D + d];
+  if (a.keep_prior) return;
   // new prior mixture: Categorical(probs = w / sum w) -> logits = log(clamp(probs, eps, 1 - eps)) -> log_softmax
   if (!a.weighted_prior) {  // uniform: every logit is log(1/N) and the log_softmax of a constant vector is -log N exactly
     const float l = logf(fminf(fmaxf(1.0f / (float)a.N, 1.1920929e-07f), 1.0f - 1.1920929e-07f));
@@ -191,6 +193,8 @@ struct RollArgs {
   // SVMPC.roll builds a NEW parameter tensor (theta.roll(...), svmpc.py:142-158) and stores it into the optimiser's param group:
   // torch keys optimiser state by tensor object, so Adam's exp_avg / exp_avg_sq / step restart at zero after every forward()
   float *adam_m, *adam_v;  // [N][D] or nullptr (SGD)
+  int steps;               // theta.roll(steps, dims=-2): circular shift along the horizon (svmpc.py:144); -1 in SVMPC.forward's default
+  const float *last_row;   // [N][da] strategy "resample": the last action of a fresh prior sample per particle (svmpc.py:148-150)
 };
 
 __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
@@ -207,8 +211,16 @@ __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
   const int D = a.H * a.da, j = threadIdx.x, da = a.da;
   const float *th = a.theta + (size_t)i * D;
   const float own = j < D ? th[j] : 0.f;
-  const float nxt = (j + da < D) ? th[j + da] : own;  // "repeat": the last row keeps its value
-  float out = nxt;
+  // torch.roll is circular: row t of the result is row (t - steps) mod H; the strategy then overwrites the LAST row only
+  const int H = a.H, t = j / da, cdim = j - t * da;
+  const int sh = ((-a.steps) % H + H) % H;  // rows move up by sh (steps = -1: sh = 1)
+  float out = own;
+  if (j < D) {
+    int src = (t + sh) % H;
+    if (t == H - 1 && a.strategy == DUST_ROLL_REPEAT && H >= 2) src = (H - 2 + sh) % H;  // theta[-1] = theta[-2] of the ROLLED tensor
+    out = th[src * da + cdim];
+    if (t == H - 1 && a.strategy == DUST_ROLL_RESAMPLE) out = a.last_row[(size_t)i * da + cdim];
+  }
   if (a.strategy == DUST_ROLL_MEAN) {  // mean over the horizon of each control dimension (svmpc.py:151-153)
     for (int c = 0; c < da; ++c) {
       const float s = block_reduce<RED_SUM>((j < D && j % da == c) ? own : 0.f, red);

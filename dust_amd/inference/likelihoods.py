@@ -19,11 +19,12 @@ class CostLikelihood:
         c._svmpc_cfg.setdefault("likelihood", self.kind)
         c._svmpc_cfg["alpha"] = float(self.alpha)
         ctx = c._ensure_ctx(self.model, params_dist)
-        ctx.set_theta(torch.as_tensor(theta, dtype=torch.float).detach().numpy())
         params, self.params_log_p = c._sample_params(params_dist)
         st = torch.as_tensor(state, dtype=torch.float).reshape(-1).numpy()
-        costs, actions = ctx.likelihood_sample(st, None if eps is None else np.asarray(eps, np.float32),
-                                               None if params is None else params[0], want_actions=True)
+        # theta is an ARGUMENT here (the reference never writes SVMPC.theta or the optimiser state from sample())
+        costs, actions = ctx.likelihood_sample_at(st, torch.as_tensor(theta, dtype=torch.float).detach().numpy(),
+                                                  None if eps is None else np.asarray(eps, np.float32),
+                                                  None if params is None else params[0], want_actions=True)
         self.last_costs, self.last_actions = torch.from_numpy(costs), torch.from_numpy(actions)
         return self.last_costs, self.last_actions
 
@@ -65,3 +66,22 @@ class GaussianLikelihood:
 
     def condition(self, action, new_obs, covariance_matrix=None):
         self.past_obs, self.loc, self.past_action = self.loc, torch.as_tensor(new_obs, dtype=torch.float).reshape(-1), action
+
+    @property
+    def density(self):  # likelihoods.py:62-64
+        import torch.distributions as dist
+
+        return dist.MultivariateNormal(self.loc, self.sigma ** 2 * torch.eye(self.dim))
+
+    def sample(self, theta):
+        """likelihoods.py:30-46: one-step predictions of the model under each parameter particle (host side: the MPF kernel
+        evaluates the same step and its parameter Jacobian on the device; this is the object-protocol form)."""
+        assert self.past_action is not None, "Previous action is None. Need at least one observation to start sampling."
+        theta = torch.as_tensor(theta, dtype=torch.float)
+        params = theta.exp() if self.log_space else theta
+        params_dict = self.model.params_to_dict(params)
+        states = self.past_obs.repeat(theta.shape[0], 1)
+        return self.model.step(states, torch.as_tensor(self.past_action, dtype=torch.float), params_dict)
+
+    def log_prob(self, samples):  # likelihoods.py:48-49
+        return self.density.log_prob(torch.as_tensor(samples, dtype=torch.float)).unsqueeze(-1)

@@ -14,8 +14,8 @@ class SVMPC:
         self.n_steps = n_steps
         self.optimizer_class, self.opt_args = optimizer_class, opt_args
         self.w_prior, self.roll_strategy = weighted_prior, roll_strategy
-        if roll_strategy not in ("repeat", "mean"):
-            raise NotImplementedError("roll strategy %r has no HIP kernel ('resample' draws from the prior on the host)" % roll_strategy)
+        if roll_strategy not in ("repeat", "mean", "resample"):
+            raise ValueError("{} is an invalid roll strategy.".format(roll_strategy))
         if optimizer_class is torch.optim.SGD:
             opt = dict(optimizer="SGD", lr=float(opt_args.get("lr", 1e-3)))
         elif optimizer_class is torch.optim.Adam:
@@ -34,7 +34,11 @@ class SVMPC:
         self._theta0 = torch.as_tensor(init_particles, dtype=torch.float).detach().clone()
         self._prior0 = (comp.loc.detach().clone(), prior.mixture_distribution.probs.detach().clone())
         self._uploaded = False
-        self.prior = prior
+        self._prior_obj, self._prior_cov = prior, cov
+        self._prior_stale = False
+        # attribute compatibility (simulations.py never touches it): torch's optimiser object over a placeholder - the optimiser
+        # STATE lives on the device and restarts at every roll, as torch's does when roll() swaps the parameter tensor
+        self.optimizer = optimizer_class(params=[torch.zeros(1, requires_grad=True)], **opt_args)
 
     # -- device plumbing
     def _ctx(self, params_dist=None):
@@ -67,6 +71,27 @@ class SVMPC:
         if self._uploaded:
             self._ctx().set_theta(self._theta0.numpy())
 
+    @property
+    def prior(self):
+        """The GMM in force (svmpc.py:160-170): after a forward() / update_prior() its means are the current particles."""
+        if self._prior_stale and self._uploaded:
+            from .svgd import get_gmm
+
+            means, probs = self._ctx().get_prior()
+            self._prior_obj = get_gmm(torch.from_numpy(means), torch.from_numpy(probs), self._prior_cov)
+            self._prior_stale = False
+        return self._prior_obj
+
+    @prior.setter
+    def prior(self, p):
+        self._prior_obj = p
+        comp = p.component_distribution.base_dist
+        self._prior_stale = False
+        if self._uploaded:
+            self._ctx().set_prior(comp.loc.detach().numpy(), p.mixture_distribution.probs.detach().numpy())
+        else:
+            self._prior0 = (comp.loc.detach().clone(), p.mixture_distribution.probs.detach().clone())
+
     # -- svmpc.py:32-85
     def phi(self, log_p, bw=None, sigma=None):
         ctx = self._ctx()
@@ -90,14 +115,37 @@ class SVMPC:
         ctx.svmpc_optimize(self._state(state), n_steps, eps, params)
 
     # -- svmpc.py:128-200
-    def forward(self, state, params_dist, steps=-1, fast_pred=True):
-        if steps != -1:
-            raise NotImplementedError("roll by %d steps: only steps=-1 (one control tick) is implemented" % steps)
+    def _resample(self, ctx):
+        if self.roll_strategy != "resample":
+            return None
+        # svmpc.py:148-150: the last action of a fresh prior sample per particle (torch's RNG, as in the reference)
+        return self.prior.sample([self.n_particles])[..., -1, :].reshape(self.n_particles, -1).numpy()
+
+    def get_weights(self, state, params_dist, fast_pred=True):
         ctx = self._ctx(params_dist)
         if not fast_pred:
             params, _ = self.likelihood.controller._sample_params(params_dist)
             ctx.likelihood_sample(self._state(state), None, None if params is None else params[0])
-        a_seq, pw = ctx.svmpc_forward()
+        return torch.from_numpy(ctx.svmpc_get_weights())
+
+    def roll(self, steps=-1, strategy="repeat"):
+        ctx = self._ctx()
+        last = None
+        if strategy == "resample":
+            last = self.prior.sample([self.n_particles])[..., -1, :].reshape(self.n_particles, -1).numpy()
+        ctx.svmpc_roll(steps, strategy, last)
+
+    def update_prior(self, weights=None):
+        self._ctx().svmpc_update_prior(None if weights is None else torch.as_tensor(weights, dtype=torch.float).numpy())
+        self._prior_stale = True
+
+    def forward(self, state, params_dist, steps=-1, fast_pred=True):
+        ctx = self._ctx(params_dist)
+        if not fast_pred:
+            params, _ = self.likelihood.controller._sample_params(params_dist)
+            ctx.likelihood_sample(self._state(state), None, None if params is None else params[0])
+        a_seq, pw = ctx.svmpc_forward_ex(steps, self._resample(ctx))
+        self._prior_stale = True
         return torch.from_numpy(a_seq), torch.from_numpy(pw)
 
     def tick(self, state, params_dist, n_steps=None, eps=None):
@@ -105,5 +153,10 @@ class SVMPC:
         ctx = self._ctx(params_dist)
         n_steps = self.n_steps if n_steps is None else n_steps
         params, _ = self.likelihood.controller._sample_params(params_dist, n_steps)
-        a_seq, pw = ctx.svmpc_tick(self._state(state), n_steps, eps, params)
+        if self.roll_strategy == "resample":  # the last row is drawn on the host between the two halves
+            ctx.svmpc_optimize(self._state(state), n_steps, eps, params)
+            a_seq, pw = ctx.svmpc_forward_ex(-1, self._resample(ctx))
+        else:
+            a_seq, pw = ctx.svmpc_tick(self._state(state), n_steps, eps, params)
+        self._prior_stale = True
         return torch.from_numpy(a_seq), torch.from_numpy(pw)

@@ -46,7 +46,7 @@ enum dust_cost { DUST_COST_PENDULUM_QUADCOS = 0, DUST_COST_PARTICLE_DEFAULT = 1 
 enum dust_kernel { DUST_KERNEL_K1_RBF = 0, DUST_KERNEL_K2_IIDMP = 1, DUST_KERNEL_K2_SHARED = 2, DUST_KERNEL_IMQ = 3 };
 enum dust_likelihood { DUST_LIK_EXP_UTILITY = 0, DUST_LIK_EXPECTED_COST = 1 }; /* likelihoods.py:122-135 / 106-119 */
 enum dust_optimizer { DUST_OPT_SGD = 0, DUST_OPT_ADAM = 1 };                   /* svgd.py:115, demos use SGD */
-enum dust_roll { DUST_ROLL_REPEAT = 0, DUST_ROLL_MEAN = 1 };                    /* svmpc.py:142-158 */
+enum dust_roll { DUST_ROLL_REPEAT = 0, DUST_ROLL_MEAN = 1, DUST_ROLL_RESAMPLE = 2 }; /* svmpc.py:142-158 */
 enum dust_step_strategy { DUST_STEP_ARGMAX = 0, DUST_STEP_AVERAGE = 1, DUST_STEP_EXTERNAL = 2 }; /* disco.py:396-417 */
 /* how a model parameter enters the arithmetic: a Python float (double), a 0-dim fp32 tensor, or a sampled column */
 enum dust_param_kind { DUST_PARAM_PYFLOAT = 0, DUST_PARAM_SAMPLED = 1, DUST_PARAM_TENSOR0D = 2 };
@@ -168,7 +168,21 @@ int dust_svmpc_optimize(dust_ctx *ctx, const float *state, int n_steps, const fl
 /* SVMPC.forward(state, params_dist, fast_pred=True) svmpc.py:172-200: weights, argmax, roll, prior refresh.
  * a_seq [H][da], p_weights [N] (either may be NULL) */
 int dust_svmpc_forward(dust_ctx *ctx, float *a_seq, float *p_weights);
-/* one whole control tick = optimize(n_steps) + forward(), enqueued without host round trips (replayed as a hipGraph) */
+/* The pieces of SVMPC.forward as the reference exposes them (svmpc.py:128-170), for callers that use them one by one:
+ * get_weights (fast_pred=True: the costs of the last sample; weights only - theta and the prior stay as they are),
+ * roll(steps, strategy) - theta.roll(steps, dims=-2) is CIRCULAR, the strategy then rewrites the last row; strategy "resample" takes
+ * the last action of a prior sample per particle, drawn by the caller (`last_row` [N][da]; the reference draws prior.sample([N])) -
+ * and update_prior(weights) (weights NULL: ones).  dust_svmpc_forward_ex = forward(steps, ...) with the context's roll strategy. */
+int dust_svmpc_get_weights(dust_ctx *ctx, float *p_weights);
+int dust_svmpc_roll(dust_ctx *ctx, int steps, int strategy, const float *last_row);
+int dust_svmpc_update_prior(dust_ctx *ctx, const float *weights);
+int dust_svmpc_forward_ex(dust_ctx *ctx, int steps, const float *resample_last_row, float *a_seq, float *p_weights);
+/* CostLikelihood.sample(theta, state, params_dist) for a theta that is NOT the optimiser's (likelihoods.py:81-101 takes theta as an
+ * argument and touches neither SVMPC.theta nor the optimiser state): rollouts around `theta` [N][H][da], the context's particles,
+ * Adam moments and a_mat side effects as in the reference (a_mat is MultiDISCO state and does change). */
+int dust_likelihood_sample_at(dust_ctx *ctx, const float *state, const float *theta, const float *eps, const float *params, int flags,
+                              float *costs, float *actions_out);
+/* one whole control tick = optimize(n_steps) + forward(), enqueued without host round trips (one persistent launch where eligible) */
 int dust_svmpc_tick(dust_ctx *ctx, const float *state, int n_steps, const float *eps, const float *params, int flags,
                     float *a_seq, float *p_weights);
 

@@ -229,3 +229,111 @@ def test_unscented_transform_disco_vs_reference(golden):
     c2 = copy.deepcopy(ctrl)  # the weights travel with the clone
     c3, *_ = c2.forward(state, model, dyn, ext_actions=torch.tensor(g["ext_actions"]))
     assert np.isfinite(c3.numpy()).all()
+
+
+def test_forward_pieces_get_weights_roll_update_prior(golden):
+    """SVMPC.get_weights / roll / update_prior one by one (svmpc.py:128-170), the refreshed `prior` object, roll strategies
+    incl. 'resample' (host-drawn prior sample, torch's RNG as in the reference), forward(steps=-2), and likelihood.sample(theta)
+    leaving the optimiser's particles alone (likelihoods.py:81-101 takes theta as an argument)."""
+    from dust_amd.kernels import RBFKernel
+
+    g = golden("pend_k1")
+    N, H = int(g["N"]), int(g["H"])
+    model, ctrl, lik, sv = build_pendulum(g, RBFKernel())
+    state = torch.tensor(g["state"][0, 0])
+    sv.optimize(state, None, n_steps=2, eps=g["eps"][0][:2])
+    th = sv.theta.clone()
+    # get_weights: weights only - theta and the prior stay
+    w = sv.get_weights(state, None)
+    assert torch.equal(sv.theta, th)
+    assert relerr(sv.prior.component_distribution.base_dist.loc.numpy(), g["mu0"]) < 1e-7
+    # likelihood.sample with another theta: the optimiser's particles are untouched
+    other = th + 0.5
+    lik.sample(other, state, None, eps=g["eps"][0, 0])
+    assert torch.equal(sv.theta, th)
+    # roll == torch semantics (circular shift, then the last row per strategy)
+    for steps, strat in ((-1, "repeat"), (-2, "repeat"), (-1, "mean"), (-3, "mean")):
+        sv.theta = th
+        sv.roll(steps, strat)
+        ref = th.roll(steps, dims=-2)
+        ref[..., -1, :] = ref[..., -2, :] if strat == "repeat" else ref.mean(dim=-2)
+        assert relerr(sv.theta.numpy(), ref.numpy()) < 1e-6, (steps, strat)
+    sv.theta = th
+    torch.manual_seed(5)
+    sv.roll(-1, "resample")
+    torch.manual_seed(5)
+    ref = th.roll(-1, dims=-2)
+    ref[..., -1, :] = sv.prior.sample([N])[..., -1, :]
+    assert relerr(sv.theta.numpy(), ref.numpy()) < 1e-6
+    with pytest.raises(ValueError):
+        sv.roll(-1, "nope")
+    # update_prior: means alias the particles, mixture = ones (weighted_prior False)
+    sv.theta = th
+    sv.update_prior(w)
+    p = sv.prior
+    assert relerr(p.component_distribution.base_dist.loc.numpy(), th.numpy()) < 1e-7
+    assert relerr(p.mixture_distribution.probs.numpy(), np.full(N, 1.0 / N)) < 1e-6
+    # forward(steps=-2): same weights / action sequence as get_weights (same costs, same prior), particles rolled by two
+    w = sv.get_weights(state, None)
+    a_seq, pw = sv.forward(state, None, steps=-2)
+    assert relerr(pw.numpy(), w.numpy()) < 1e-5
+    assert torch.equal(a_seq, th[int(w.argmax())])
+    ref = th.roll(-2, dims=-2)
+    ref[..., -1, :] = ref[..., -2, :]
+    assert relerr(sv.theta.numpy(), ref.numpy()) < 1e-6
+    assert relerr(sv.prior.component_distribution.base_dist.loc.numpy(), ref.numpy()) < 1e-7  # refreshed prior object
+    assert isinstance(sv.optimizer, torch.optim.SGD)
+
+
+def test_resample_strategy_ticks(golden):
+    """roll_strategy='resample' through forward() and tick(): the last action row is the last row of a fresh prior sample."""
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import SVMPC, ExponentiatedUtility, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import PendulumModel
+
+    g = golden("pend_k1")
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    model = PendulumModel()
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=1.0, a_cov=4.0 * torch.eye(1), inst_cost_fn=inst_cost,
+                      term_cost_fn=term_cost, params_sampling=None)
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), 4.0 * torch.eye(1))
+    lik = ExponentiatedUtility(alpha=1.0, n_samples=S, controller=ctrl, model=model)
+    sv = SVMPC(init_particles=torch.tensor(g["theta0"]), prior=prior, likelihood=lik, kernel=RBFKernel(), n_particles=N, n_steps=1,
+               optimizer_class=torch.optim.SGD, lr=2.0, roll_strategy="resample")
+    state = torch.tensor(g["state"][0, 0])
+    sv.optimize(state, None, n_steps=1, eps=g["eps"][0][:1])
+    th = sv.theta.clone()
+    torch.manual_seed(9)
+    last = sv.prior.sample([N])[..., -1, :]
+    torch.manual_seed(9)
+    sv.forward(state, None)
+    ref = th.roll(-1, dims=-2)
+    ref[..., -1, :] = last
+    assert relerr(sv.theta.numpy(), ref.numpy()) < 1e-6
+    a_seq, pw = sv.tick(state, None, n_steps=1)  # optimize + host draw + forward
+    assert a_seq.shape == (H, 1) and abs(float(pw.sum()) - 1) < 5e-4
+
+
+def test_gaussian_likelihood_sample_and_log_prob():
+    """GaussianLikelihood.sample / log_prob (likelihoods.py:30-49): one-step predictions per parameter particle and the
+    observation density - the object-protocol form of what the MPF kernel evaluates on the device."""
+    from dust_amd.inference import GaussianLikelihood
+    from dust_amd.models import PendulumModel
+
+    model = PendulumModel(uncertain_params=("length", "mass"))
+    lik = GaussianLikelihood(torch.tensor([3.0, 0.0]), obs_std=0.1, model=model, log_space=True)
+    with pytest.raises(AssertionError):
+        lik.sample(torch.zeros(4, 2))
+    lik.condition(torch.tensor([1.3]), torch.tensor([2.9, -0.4]))
+    theta = torch.log(torch.tensor([[0.9, 1.1], [1.2, 0.8], [1.0, 1.0]]))
+    pred = lik.sample(theta)
+    assert pred.shape == (3, 2)
+    for i in range(3):
+        m = PendulumModel(length=float(theta[i, 0].exp()), mass=float(theta[i, 1].exp()))
+        ref = m.step(torch.tensor([[3.0, 0.0]]), torch.tensor([[1.3]]))
+        assert relerr(pred[i].numpy(), ref[0].numpy()) < 1e-6
+    lp = lik.log_prob(pred)
+    d = pred - torch.tensor([2.9, -0.4])
+    ref_lp = -0.5 * (d * d).sum(-1) / 0.01 - np.log(2 * np.pi * 0.01)
+    assert lp.shape == (3, 1) and relerr(lp[:, 0].numpy(), ref_lp.numpy()) < 1e-5
