@@ -655,3 +655,106 @@ def test_large_key_set_pairwise_vs_oracle(model, N, H, kernel):
     fw = o.forward(c.get_costs(), th1, mu, np.ones(N), sp, 1.0)
     assert relerr(lp, fw["log_p"]) < 1e-5
     c.close()
+
+
+@pytest.mark.parametrize("model,N,S,H,K", [("pendulum", 64, 32, 15, 3), ("particle", 32, 64, 20, 2)])
+def test_philox_tick_replayed_through_oracle(model, N, S, H, K):
+    """The product tick draws its policy noise on the device (Philox, in registers - the noise never exists in HBM).  Here the
+    SAME draws are fetched as actions through the stand-alone sample entry point of a second context walked through the same
+    (tick, iteration) stream positions, replayed through the CPU oracle for one whole tick (rollouts, costs, score, K1 phi, SGD,
+    forward), and the result is compared with the particles the persistent one-launch tick produced from them on the device."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    da = 1 if model == "pendulum" else 2
+    sig = 2.0 if model == "pendulum" else 5.0
+    lr = 0.5 if model == "pendulum" else 20.0
+    alpha = 1.0 if model == "pendulum" else 1e-4
+    rng = np.random.default_rng(17)
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    theta = (mu + 0.5 * rng.standard_normal((N, H, da))).astype(np.float32)
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    grid = grid_4x4_map() if model == "particle" else None
+    kw = dict(model=model, N=N, S=S, M=1, H=H, kernel="K1", lr=lr, alpha=alpha, sigma_a=sig, sigma_p=sig, grid=grid, seed=4242)
+    prod = Context(**kw)
+    prod.set_theta(theta); prod.set_prior(mu); prod.set_a_mat(theta)
+    a_seq, pw = prod.svmpc_tick(state, K)  # device Philox noise, one persistent launch
+    th_prod = prod.get_theta()
+    # replay: a second context hands out the draws of stream positions (tick 0, iteration k) as actions around the ORACLE's theta
+    tap = Context(**kw)
+    tap.set_prior(mu); tap.set_a_mat(theta)
+    o = Oracle(model=model, N=N, S=S, M=1, H=H, grid=grid)
+    sg = np.full(da, sig, np.float32)
+    th, mix = theta.copy(), np.ones(N, np.float32)
+    for k in range(K):
+        tap.set_theta(th)
+        costs_dev, actions = tap.likelihood_sample(state, None, None, want_actions=True)  # Philox draw k of tick 0
+        eps = (actions - th[None]) / sig
+        assert abs(float(eps.mean())) < 0.05 and abs(float(eps.std()) - 1.0) < 0.05
+        costs = o.rollout_cost(state, actions)
+        assert elemerr(costs_dev, costs) < TOL
+        _, _, sc = o.score(th, mu, mix, sg, costs, actions, alpha, sg)
+        th = o.sgd(th, o.phi_k1(th, sc), lr)
+    r = o.forward(costs, th, mu, mix, sg, alpha)
+    # whole-tick chain: softmax amplification of cost ulps (module docstring) - 2e-3, as the golden chain test
+    scale = np.abs(r["theta"]).max()
+    assert np.abs(th_prod - r["theta"]).max() / scale < 2e-3
+    srt = np.sort(r["p_weights"])
+    if srt[-1] > 1.5 * srt[-2]:
+        assert int(np.argmax(pw)) == r["i_star"]
+        assert np.abs(a_seq - r["a_seq"]).max() / scale < 2e-3
+
+
+def test_cfg5_shaped_dual_loop_vs_oracle():
+    """BASELINE.json configs[4] in one loop, at reduced N: Pendulum dual inference - control SVGD with the IMQ kernel over
+    binary16-STORED policy noise (fp32 arithmetic), M = 8 dynamics samples drawn per tick from the GMM over an M_p = 256
+    dynamics-particle filter, then 20 MPF steps on the new observation - against the CPU oracle fed the same draws."""
+    from dust_amd import Context
+    from dust_amd.backend import MpfContext
+    from oracle import Oracle
+
+    N, S, H, M, Mp, K, T = 96, 64, 30, 8, 256, 2, 2
+    rng = np.random.default_rng(55)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal((N, H, 1))).astype(np.float32)
+    x0 = rng.uniform(0.6, 1.3, (Mp, 2)).astype(np.float32)
+    state = np.array([3.0, 0.0], np.float32)
+    ell, lr, sig = 1.5, 0.5, 2.0
+    c = Context(model="pendulum", N=N, S=S, M=M, H=H, kernel="IMQ", imq_ell=ell, lr=lr, sigma_a=sig, sigma_p=sig,
+                uncertain_params=("length", "mass"), seed=3)
+    c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+    # (filter step size / bandwidth chosen so that 20 SVGD steps of 256 particles are a contraction: with the demo's lr = 1e-3 and
+    # bw = 0.08 the 256-particle system is chaotic - device and oracle agree to 1e-7 after one step and drift apart exponentially)
+    mlr, mbw = 1e-4, 0.2
+    mpf = MpfContext(x0, state, model="pendulum", uncertain_params=("length", "mass"), obs_std=0.1, lr=mlr, init_bw=mbw)
+    o = Oracle(model="pendulum", N=N, S=S, M=M, H=H, uncertain_params=("length", "mass"))
+    sg = np.full(1, sig, np.float32)
+    th, m_, mix = theta.copy(), mu.copy(), np.ones(N, np.float32)
+    xo, pmo, pbw, obs_prev = x0.copy(), x0.copy(), mbw, state.copy()
+    for t in range(T):
+        params = np.stack([mpf.prior_sample(M, seed=100 * t + k) for k in range(K)])  # [K][M][2] from the filter's GMM
+        assert np.all(np.isfinite(params))
+        eps16 = rng.standard_normal((K, S, N, H, 1)).astype(np.float16)
+        a_seq, pw = c.svmpc_tick(state, K, eps16, params)
+        for k in range(K):  # oracle: the same binary16-rounded noise widened on the host
+            actions = o.sample_actions(th, eps16[k].astype(np.float32), sg)
+            costs = o.rollout_cost(state, actions, params[k])
+            mu_k = m_ if t == 0 else th  # from the second tick on the prior means ARE the current particles (svgd.py:87)
+            _, _, sc = o.score(th, mu_k, mix, sg, costs, actions, 1.0, sg)
+            th = o.sgd(th, o.phi_imq(th, sc, ell), lr)
+        r = o.forward(costs, th, m_ if t == 0 else th, mix, sg, 1.0)
+        assert np.abs(c.get_theta() - r["theta"]).max() / np.abs(r["theta"]).max() < 2e-3, t
+        th, m_, mix = r["theta"], r["mu"], r["mix"]
+        c.set_theta(th)  # re-synchronise (stage-local comparison), keep the device's prior refresh
+        # plant + dynamics filter (simulations.py:129-138)
+        action = np.clip(a_seq[0], -2.0, 2.0)
+        from dust_amd.models import PendulumModel
+        import torch
+
+        plant = PendulumModel(g=10.0, length=0.9, mass=1.1)
+        new_obs = plant.step(torch.tensor(obs_prev)[None], torch.tensor(action).reshape(1, 1))[0].numpy()
+        mpf.optimize(action, new_obs, mbw, 20)
+        xo, pmo, pbw, _ = o.mpf_optimize(xo, pmo, pbw, obs_prev, action, new_obs, 0.1, False, mbw, mlr, 20)
+        assert elemerr(mpf.get_particles(), xo) < 2e-5, t
+        obs_prev = new_obs
+        state = new_obs.astype(np.float32)
