@@ -179,9 +179,12 @@ class MultiDISCO:
         if self._tf is not None:
             sp, lp = self._sigma_params(params_dist)
             return np.repeat(sp, n_sets, axis=0), lp
+        from ..utils import replay
+
         ps, lps = [], []
         for _ in range(n_sets):
-            p = params_dist.sample([self.n_params])
+            rec = replay.next_params()  # recorded dynamics samples of a reference run (parity tests), else a fresh draw
+            p = params_dist.sample([self.n_params]) if rec is None else torch.as_tensor(rec, dtype=torch.float)
             lps.append(params_dist.log_prob(p))
             ps.append(p.reshape(self.n_params, -1))
         return torch.stack(ps).numpy(), lps[-1]

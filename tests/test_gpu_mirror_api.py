@@ -337,3 +337,61 @@ def test_gaussian_likelihood_sample_and_log_prob():
     d = pred - torch.tensor([2.9, -0.4])
     ref_lp = -0.5 * (d * d).sum(-1) / 0.01 - np.log(2 * np.pi * 0.01)
     assert lp.shape == (3, 1) and relerr(lp[:, 0].numpy(), ref_lp.numpy()) < 1e-5
+
+
+def test_pendulum_driver_vs_reference_driver(golden):
+    """the build's `run_pendulum_simulation` against the REFERENCE's own driver loop
+    (dust/utils/simulations.py:13-190, run by tests/golden/make_golden_driver.py with a stand-in plant) over three control ticks of
+    the dual-inference configuration: same call order per tick (optimize -> forward unless warming up -> plant step ->
+    mpf.optimize), every random draw of the reference run replayed (dust_amd.utils.replay).  Per-tick products: applied action,
+    plant state, particle weights, the particles' first action after forward, the dynamics filter's particles."""
+    import torch.distributions as dist
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import MPF, GaussianLikelihood, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import PendulumModel
+    from dust_amd.utils import replay
+    from dust_amd.utils.simulations import run_pendulum_simulation
+
+    g = golden("driver_pend_dual")
+    N, H, S, M, Mp = (int(g[k]) for k in ("N", "H", "S", "M", "Mp"))
+    steps, warm = int(g["steps"]), int(g["warm_up"])
+    env_model = PendulumModel()
+    init_state = torch.tensor(g["init_state"])
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), float(g["sigma"]) ** 2 * torch.eye(1))
+    init_policies = torch.tensor(g["init_policies"])
+    dyn_prior = dist.Independent(dist.Uniform(torch.tensor([0.6, 0.6]), torch.tensor([1.3, 1.3])), 1)
+    ctrl = MultiDISCO(observation_space=env_model.observation_space, action_space=env_model.action_space, hz_len=H, action_samples=S,
+                      params_samples=M, temperature=1.0, a_cov=float(g["sigma"]) ** 2 * torch.eye(1), inst_cost_fn=inst_cost,
+                      term_cost_fn=term_cost, params_sampling=True, n_policies=N, params_log_space=False)
+    lik = GaussianLikelihood(initial_obs=init_state, obs_std=float(g["obs_std"]), model=PendulumModel(uncertain_params=("length", "mass")),
+                             log_space=False)
+    mpf = MPF(init_particles=torch.tensor(g["mpf_init"]), likelihood=lik, optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]),
+              bw=float(g["mpf_bw"]), bw_scale=1.0)
+    with replay.feed(eps=list(g["eps"]), params=list(g["params"])):
+        df = run_pendulum_simulation(
+            init_state, init_policies, {"uncertain_params": ("length", "mass")}, dyn_prior,
+            [{"length": float(g["true_length"]), "mass": float(g["true_mass"])}], ctrl, use_exact_model=False, use_svmpc=True,
+            svmpc_kwargs=dict(init_particles=init_policies, prior=prior, kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1,
+                              optimizer_class=torch.optim.SGD, lr=float(g["lr"])),
+            lik_kwargs={"alpha": 1.0, "n_samples": S}, mpf=mpf, mpf_bw=float(g["mpf_bw"]), mpf_steps=int(g["mpf_steps"]), episodes=1,
+            steps=steps, warm_up=warm)
+    assert len(df) == steps
+    for t in range(steps):
+        # the state each tick started from (tick t+1's input = the plant state after tick t's action)
+        if t + 1 < steps:
+            got = np.array([df["Position"].iloc[t], df["Speed"].iloc[t]], np.float32)
+            assert relerr(got, g["state_in"][t + 1]) < 1e-4, t
+        dyn = np.asarray(df["DynParticles"].iloc[t], np.float32)
+        assert relerr(dyn, g["mpf_x"][t]) < (1e-5 if t == 0 else 1e-3), t
+        if t < warm:
+            assert float(df["Actions"].iloc[t]) == 0.0
+            continue
+        k = t - warm
+        ref_pw = g["p_weights"][k]
+        pw = np.asarray(df["Weights"].iloc[t], np.float32)
+        assert int(np.argmax(pw)) == int(np.argmax(ref_pw)), t
+        assert relerr(pw, ref_pw) < 5e-3, t  # exp of O(1e3) log-weights (tests/test_gpu_parity.py)
+        assert abs(float(df["Actions"].iloc[t]) - float(g["a_seq"][k][0, 0])) < 2e-3 * max(1.0, abs(float(g["a_seq"][k][0, 0]))), t
+        assert relerr(np.asarray(df["PolParticles"].iloc[t], np.float32), g["theta_fwd"][k][:, 0, 0]) < 2e-3, t
