@@ -14,14 +14,21 @@ class MockShard:
         self.cfg, self.rank, self.world = cfg, rank, world
         self.N, self.S, self.H = cfg["N"], cfg["S"], cfg["H"]
         self.off, self.n_loc = shard_bounds(self.N, rank, world)
-        self.o = Oracle(model="pendulum", N=self.N, S=self.S, M=1, H=self.H)
-        self.D = self.H
+        self.model = cfg.get("model", "pendulum")
+        self.da = 1 if self.model == "pendulum" else 2
+        self.M = cfg.get("M", 1)
+        if self.model == "particle":  # the cfg4 family: 2-D point mass on the demo's occupancy grid, sampled mass
+            self.o = Oracle(model="particle", N=self.N, S=self.S, M=self.M, H=self.H, uncertain_params=("mass",), mass=2.0,
+                            grid=oracle.grid_4x4_map())
+        else:
+            self.o = Oracle(model="pendulum", N=self.N, S=self.S, M=1, H=self.H)
+        self.D = self.H * self.da
         self.shard_elems = self.n_loc * self.D
         self.theta_all = torch.zeros(self.N * self.D)
         self.score_all = torch.zeros(self.N * self.D)
         self.lw_all = torch.zeros(self.N)
-        self.sig = np.array([cfg["sigma_a"]], np.float32)
-        self.sp = np.array([cfg["sigma_p"]], np.float32)
+        self.sig = np.full(self.da, cfg["sigma_a"], np.float32)
+        self.sp = np.full(self.da, cfg["sigma_p"], np.float32)
         self.aliased = False
         self.a_seq = None
         self.pw = None
@@ -31,24 +38,24 @@ class MockShard:
 
     def set_state(self, theta, mu, a_mat=None, mix=None):
         self.theta_all[:] = torch.from_numpy(np.asarray(theta, np.float32).reshape(-1))
-        self.mu = np.asarray(mu, np.float32).reshape(self.N, self.H, 1).copy()
+        self.mu = np.asarray(mu, np.float32).reshape(self.N, self.H, self.da).copy()
         self.mix = np.ones(self.N, np.float32)
 
     def _theta(self):
-        return self.theta_all.numpy().reshape(self.N, self.H, 1)
+        return self.theta_all.numpy().reshape(self.N, self.H, self.da)
 
     def local_score(self, state, eps=None, params=None):
         th = self._theta()
         mu = th if self.aliased else self.mu
         actions = self.o.sample_actions(th, eps, self.sig)
-        self.costs = self.o.rollout_cost(state, actions)
+        self.costs = self.o.rollout_cost(state, actions, params)
         _, _, sc = self.o.score(th, mu, self.mix, self.sp, self.costs, actions, self.cfg["alpha"], self.sig)
         self._rows(self.score_all)[:] = torch.from_numpy(sc.reshape(-1))[self.off * self.D:(self.off + self.n_loc) * self.D]
 
     def local_rollout(self, state, eps=None, params=None):
         th = self._theta()  # the other shards' rows may still be in flight here: only the local rows are used below
         self._actions = self.o.sample_actions(th, eps, self.sig)
-        self.costs = self.o.rollout_cost(state, self._actions)
+        self.costs = self.o.rollout_cost(state, self._actions, params)
         self._local_rows = th[self.off:self.off + self.n_loc].copy()
 
     def local_prior_score(self):
@@ -61,7 +68,7 @@ class MockShard:
 
     def apply_phi(self):
         th = self._theta()
-        phi = self.o.phi_k1(th, self.score_all.numpy().reshape(self.N, self.H, 1))
+        phi = self.o.phi_k1(th, self.score_all.numpy().reshape(self.N, self.H, self.da))
         new = Oracle.sgd(th, phi, self.cfg["lr"]).reshape(-1)
         self._rows(self.theta_all)[:] = torch.from_numpy(new)[self.off * self.D:(self.off + self.n_loc) * self.D]
 

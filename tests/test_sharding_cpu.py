@@ -10,15 +10,24 @@ import torch.multiprocessing as mp
 
 from dust_amd.parallel import LocalComm, TorchComm, shard_bounds, tick
 
-CFG = dict(N=8, S=6, H=5, sigma_a=2.0, sigma_p=2.0, alpha=1.0, lr=0.5)
+CFGS = {
+    "pendulum": dict(model="pendulum", N=8, S=6, H=5, sigma_a=2.0, sigma_p=2.0, alpha=1.0, lr=0.5),
+    # the multi-GPU bench's family (BASELINE configs[3]): Particle, D = H * da, sampled mass, occupancy grid
+    "particle": dict(model="particle", N=8, S=6, H=5, M=2, sigma_a=5.0, sigma_p=5.0, alpha=1e-4, lr=20.0),
+}
+CFG = CFGS["pendulum"]
 
 
-def _inputs():
+def _inputs(cfg=None):
+    cfg = CFG if cfg is None else cfg
+    da = 1 if cfg["model"] == "pendulum" else 2
     rng = np.random.default_rng(3)
-    mu = rng.standard_normal((CFG["N"], CFG["H"], 1)).astype(np.float32)
+    mu = rng.standard_normal((cfg["N"], cfg["H"], da)).astype(np.float32)
     theta = (mu + 0.3 * rng.standard_normal(mu.shape)).astype(np.float32)
-    eps = rng.standard_normal((2, 2, CFG["S"], CFG["N"], CFG["H"], 1)).astype(np.float32)
-    return mu, theta, eps, np.array([3.0, 0.0], np.float32)
+    eps = rng.standard_normal((2, 2, cfg["S"], cfg["N"], cfg["H"], da)).astype(np.float32)
+    state = np.array([3.0, 0.0], np.float32) if da == 1 else np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    params = None if da == 1 else (2.0 + 0.1 * rng.standard_normal((2, 2, cfg["M"], 1))).astype(np.float32)
+    return mu, theta, eps, state, params
 
 
 def test_shard_bounds():
@@ -31,35 +40,38 @@ def test_shard_bounds():
         shard_bounds(8, 4, 4)
 
 
-def _run_unsharded():
+def _run_unsharded(cfg=None):
     from mock_shard import MockShard
 
-    mu, theta, eps, state = _inputs()
-    sh = MockShard(CFG, 0, 1)
+    cfg = CFG if cfg is None else cfg
+    mu, theta, eps, state, params = _inputs(cfg)
+    sh = MockShard(cfg, 0, 1)
     sh.set_state(theta, mu)
     outs = []
     for t in range(2):
-        outs.append(tick((sh,), LocalComm(), state, 2, eps[t], None, want_outputs=True))
+        outs.append(tick((sh,), LocalComm(), state, 2, eps[t], None if params is None else params[t], want_outputs=True))
     return sh.theta_all.numpy().copy(), outs
 
 
 @pytest.mark.parametrize("overlap", [False, True])
-def test_local_comm_two_shards_equal_unsharded(overlap):
+@pytest.mark.parametrize("family", ["pendulum", "particle"])
+def test_local_comm_two_shards_equal_unsharded(family, overlap):
     from mock_shard import MockShard
 
-    mu, theta, eps, state = _inputs()
-    ref_theta, ref_outs = _run_unsharded()
-    shards = tuple(MockShard(CFG, r, 2) for r in range(2))
+    cfg = CFGS[family]
+    mu, theta, eps, state, params = _inputs(cfg)
+    ref_theta, ref_outs = _run_unsharded(cfg)
+    shards = tuple(MockShard(cfg, r, 2) for r in range(2))
     for s in shards:
         s.set_state(theta, mu)
     for t in range(2):
-        a_seq, pw = tick(shards, LocalComm(), state, 2, eps[t], None, want_outputs=True, overlap=overlap)
+        a_seq, pw = tick(shards, LocalComm(), state, 2, eps[t], None if params is None else params[t], want_outputs=True, overlap=overlap)
         assert np.allclose(a_seq, ref_outs[t][0], atol=1e-6) and np.allclose(pw, ref_outs[t][1], atol=1e-6)
     for s in shards:
         assert np.allclose(s.theta_all.numpy(), ref_theta, atol=1e-6)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, family="pendulum"):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -68,24 +80,26 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    mu, theta, eps, state = _inputs()
-    sh = MockShard(CFG, rank, world)
+    cfg = CFGS[family]
+    mu, theta, eps, state, params = _inputs(cfg)
+    sh = MockShard(cfg, rank, world)
     sh.set_state(theta, mu)
     comm = TorchComm(dist, rank)
     outs = []
     for t in range(2):
-        outs.append(tick((sh,), comm, state, 2, eps[t], None, want_outputs=True))
+        outs.append(tick((sh,), comm, state, 2, eps[t], None if params is None else params[t], want_outputs=True))
     q.put((rank, sh.theta_all.numpy().copy(), outs[-1][1]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gloo_world2_equals_unsharded():
-    ref_theta, ref_outs = _run_unsharded()
+@pytest.mark.parametrize("family", ["pendulum", "particle"])
+def test_gloo_world2_equals_unsharded(family):
+    ref_theta, ref_outs = _run_unsharded(CFGS[family])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if family == "particle" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, family)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in procs]
