@@ -267,6 +267,70 @@ __device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &
   }
 }
 
+// ---- Particle fast path: FINITE operands only (the caller checks, wave-uniformly: finite start state and actions, a finite normal
+// non-zero mass).  Same fp32 operations in the same order as step_with_cost<PARTICLE> / term_cost; what changes is the code
+// shape: the occupancy lookup is branch-free (selects instead of four exec-mask branches: two independent rollouts of one lane
+// then interleave in the scheduler), clamps are single v_med3_f32 (it would swallow a NaN that torch.clamp propagates - hence the
+// precondition), and a / mass is formed from the hoisted reciprocal with one correction on the exact residual (Markstein: with
+// r = RN(1/m), q = RN(a r), e = a - q m exactly (fma), RN(q + e r) is the correctly rounded quotient - the value the IEEE
+// division of the reference produces - for normal operands) instead of the 11-instruction v_div_scale / v_div_fmas sequence.
+__device__ __forceinline__ float collision_bf(const DevModel &dm, float px, float py) {
+  const float fx = floorf(px * dm.inv_cell + dm.off_x), fy = floorf(py * dm.inv_cell + dm.off_y);
+  // negative -> 0 (fmaxf also sends NaN to 0); > 9.2e18 (int64 overflow on the reference's host -> INT64_MIN -> clamp) -> 0
+  float cx = fminf(fmaxf(fx, 0.f), (float)(dm.nx - 1)), cy = fminf(fmaxf(fy, 0.f), (float)(dm.ny - 1));
+  cx = fx <= 9.2e18f ? cx : 0.f;
+  cy = fy <= 9.2e18f ? cy : 0.f;
+  const int bit = (int)cx * dm.ny + (int)cy;
+  return (float)((dm.grid_bits[bit >> 5] >> (bit & 31)) & 1u);
+}
+__device__ __forceinline__ float div_by_const(const float a, const float m, const float r /* RN(1/m) */) {
+  const float q = a * r;
+  return fmaf(fmaf(-q, m, a), r, q);
+}
+// OBST / CRASH are the (wave-uniform, run-time) flags with_obstacle / can_crash && with_obstacle as TEMPLATE arguments: the caller
+// picks the instance outside its time loop, so the loop body is one basic block
+template <bool OBST, bool CRASH>
+__device__ __forceinline__ float particle_step_cost_fast(const DevModel &dm, const float mass, const float rmass, float *x, const float *a) {
+  constexpr bool crash = CRASH;
+  const float coll = OBST ? collision_bf(dm, x[0], x[1]) : 0.f;
+  double sc = 0.0, cc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = x[k] - dm.target[k];
+    sc += (double)((d * d) * dm.w_state[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
+  const float ob = OBST ? dm.w_obs * coll : 0.0f;
+  const float cost = ((float)sc + (float)cc) + ob;
+  const float dt = (float)dm.dt;
+  const float ax = __builtin_amdgcn_fmed3f(div_by_const(a[0], mass, rmass), -dm.max_acc, dm.max_acc);
+  const float ay = __builtin_amdgcn_fmed3f(div_by_const(a[1], mass, rmass), -dm.max_acc, dm.max_acc);
+  const float xd[4] = {x[2], x[3], ax, ay};
+  if (crash) {
+    const float om = 1.0f - coll;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x[k] + (xd[k] * dt) * om;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x[k] + xd[k] * dt;
+  }
+  x[2] = __builtin_amdgcn_fmed3f(x[2], -dm.max_speed, dm.max_speed);
+  x[3] = __builtin_amdgcn_fmed3f(x[3], -dm.max_speed, dm.max_speed);
+  return cost;
+}
+template <bool OBST>
+__device__ __forceinline__ float particle_term_cost_fast(const DevModel &dm, const float *x) {
+  double sc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = x[k] - dm.target[k];
+    sc += (double)((d * d) * dm.w_term[k]);
+  }
+  const float ob = OBST ? dm.w_obs * collision_bf(dm, x[0], x[1]) : 0.0f;
+  return (float)sc + ob;
+}
+
 template <int MODEL>
 __device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
   if (MODEL == DUST_MODEL_PENDULUM) {

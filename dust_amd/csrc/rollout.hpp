@@ -251,6 +251,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const long SN = (long)S * N;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
+  const bool fast_part = MODEL == DUST_MODEL_PARTICLE && red[40] == 0.f && fabsf(x0[0]) <= 3.0e38f && fabsf(x0[1]) <= 3.0e38f &&
+                         fabsf(x0[DS > 2 ? 2 : 0]) <= 3.0e38f && fabsf(x0[DS > 3 ? 3 : 0]) <= 3.0e38f;
   const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !f_states && !f_tile_scratch && red[40] == 0.f && !f_mw &&
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
@@ -319,7 +321,43 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       continue;
     }
     double acc_m = 0.0, ut_term = 0.0;
-    for (int m = mg; m < a.M; m += G) {
+    int m_begin = mg;
+    if (MODEL == DUST_MODEL_PARTICLE && LEAN && fast_part) {
+      // Particle, finite operands, nothing stored: TWO dynamics samples (m, m + G) of this lane's action row roll out side by
+      // side - two independent dependency chains per lane, interleaved by the scheduler (the loop is latency-bound: ~150
+      // dependent instructions per step at 3-5 waves per SIMD); accumulation order over m is unchanged (m, then m + G, ...)
+      const float *actl = lds + s * Dp;
+      int m = mg;
+      for (; m + G < a.M; m += 2 * G) {
+        const int pa = a.dm.interleave ? (int)(((long)m * SN + (long)s * N + n) % a.M) : m;
+        const int pb = a.dm.interleave ? (int)(((long)(m + G) * SN + (long)s * N + n) % a.M) : m + G;
+        const float ma = coefs[2 * pa], mb = coefs[2 * pb];
+        if (!(fabsf(ma) >= 1.0e-30f && fabsf(ma) <= 1.0e30f && fabsf(mb) >= 1.0e-30f && fabsf(mb) <= 1.0e30f)) break;  // general loop
+        const float ra = 1.0f / ma, rb = 1.0f / mb;
+        float xa[4], xb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xa[k] = xb[k] = x0[k];
+        double ta = 0.0, tb = 0.0;
+        float tca, tcb;
+        auto pair_loop = [&](auto obst, auto crash) {
+          constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
+          for (int t = 0; t < H; ++t) {
+            const float at[2] = {actl[2 * t], actl[2 * t + 1]};
+            ta += (double)particle_step_cost_fast<OB, CR>(dml, ma, ra, xa, at);
+            tb += (double)particle_step_cost_fast<OB, CR>(dml, mb, rb, xb, at);
+          }
+          tca = particle_term_cost_fast<OB>(dml, xa);
+          tcb = particle_term_cost_fast<OB>(dml, xb);
+        };
+        if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{});
+        else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{});
+        else pair_loop(std::true_type{}, std::false_type{});
+        acc_m += (double)((float)ta + tca);
+        acc_m += (double)((float)tb + tcb);
+      }
+      m_begin = m;
+    }
+    for (int m = m_begin; m < a.M; m += G) {
       const long r = (long)m * SN + (long)s * N + n;
       const int pidx = a.dm.interleave ? (int)(r % a.M) : m;
       Coef cf;
