@@ -53,6 +53,8 @@ struct DevParam {
   double value;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 (2 flops per lane-op)
+
 struct DevModel {
   int model;
   int P;
@@ -329,6 +331,87 @@ __device__ __forceinline__ float particle_term_cost_fast(const DevModel &dm, con
   }
   const float ob = OBST ? dm.w_obs * collision_bf(dm, x[0], x[1]) : 0.0f;
   return (float)sc + ob;
+}
+
+// ---- two dynamics samples per lane in the halves of packed-fp32 registers (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 process
+// both in one issue slot; the rollout loop is VALU-issue-bound - measured 143 instructions per pair-step at ~100 % issue).
+// .x = sample A, .y = sample B; same fp32 operations per sample, in the same order, as particle_step_cost_fast.
+// Extra precondition (checked by the caller): positions stay small enough that floor(p / cell + off) cannot reach the
+// int64-overflow branch, so the cell clamp is one v_med3_f32 (which also sends NaN to 0, as the reference's cast does).
+__device__ __forceinline__ v2f collision_pair(const DevModel &dm, const uint32_t *grid, const v2f px, const v2f py) {
+  const v2f fx = __builtin_elementwise_floor(px * dm.inv_cell + dm.off_x), fy = __builtin_elementwise_floor(py * dm.inv_cell + dm.off_y);
+  const float hx = (float)(dm.nx - 1), hy = (float)(dm.ny - 1), fny = (float)dm.ny;
+  v2f cx, cy;
+  cx.x = __builtin_amdgcn_fmed3f(fx.x, 0.f, hx);
+  cx.y = __builtin_amdgcn_fmed3f(fx.y, 0.f, hx);
+  cy.x = __builtin_amdgcn_fmed3f(fy.x, 0.f, hy);
+  cy.y = __builtin_amdgcn_fmed3f(fy.y, 0.f, hy);
+  const v2f cell = __builtin_elementwise_fma(cx, (v2f){fny, fny}, cy);  // exact: < 2^24 cells
+  const uint32_t ia = (uint32_t)(int)cell.x, ib = (uint32_t)(int)cell.y;
+  v2f c;
+  c.x = (float)__builtin_amdgcn_ubfe(grid[ia >> 5], ia, 1u);  // bit (ia & 31): v_bfe_u32 takes the offset modulo 32
+  c.y = (float)__builtin_amdgcn_ubfe(grid[ib >> 5], ib, 1u);
+  return c;
+}
+__device__ __forceinline__ v2f round_sum4(const v2f t0, const v2f t1, const v2f t2, const v2f t3) {  // RN32 of the exact sums
+  const double sa = (((double)t0.x + (double)t1.x) + (double)t2.x) + (double)t3.x;
+  const double sb = (((double)t0.y + (double)t1.y) + (double)t2.y) + (double)t3.y;
+  return (v2f){(float)sa, (float)sb};
+}
+template <bool OBST, bool CRASH>
+__device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const uint32_t *grid, const v2f mass, const v2f rmass, v2f *x, const float a0, const float a1,
+                                                  const float cc /* control cost of (a0, a1), shared by both samples */) {
+  v2f coll = {0.f, 0.f};
+  if (OBST) coll = collision_pair(dm, grid, x[0], x[1]);
+  v2f tk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const v2f d = x[k] - dm.target[k];
+    tk[k] = (d * d) * dm.w_state[k];
+  }
+  v2f cost = round_sum4(tk[0], tk[1], tk[2], tk[3]) + cc;
+  if (OBST) cost = cost + dm.w_obs * coll;  // (without obstacles the reference adds +0 to a non-negative sum: identity)
+  const float dt = (float)dm.dt;
+  const v2f av[2] = {{a0, a0}, {a1, a1}};
+  v2f acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const v2f q = av[k] * rmass;
+    const v2f qq = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, mass, av[k]), rmass, q);
+    acc[k].x = __builtin_amdgcn_fmed3f(qq.x, -dm.max_acc, dm.max_acc);
+    acc[k].y = __builtin_amdgcn_fmed3f(qq.y, -dm.max_acc, dm.max_acc);
+  }
+  const v2f xd[4] = {x[2], x[3], acc[0], acc[1]};
+  if (CRASH) {
+    const v2f om = 1.0f - coll;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x[k] + (xd[k] * dt) * om;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x[k] + xd[k] * dt;
+  }
+#pragma unroll
+  for (int k = 2; k < 4; ++k) {
+    x[k].x = __builtin_amdgcn_fmed3f(x[k].x, -dm.max_speed, dm.max_speed);
+    x[k].y = __builtin_amdgcn_fmed3f(x[k].y, -dm.max_speed, dm.max_speed);
+  }
+  return cost;
+}
+__device__ __forceinline__ float particle_ctrl_cost(const DevModel &dm, const float a0, const float a1) {
+  const double cc = (double)((a0 * a0) * dm.w_ctrl[0]) + (double)((a1 * a1) * dm.w_ctrl[1]);
+  return (float)cc;
+}
+template <bool OBST>
+__device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint32_t *grid, const v2f *x) {
+  v2f tk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const v2f d = x[k] - dm.target[k];
+    tk[k] = (d * d) * dm.w_term[k];
+  }
+  v2f c = round_sum4(tk[0], tk[1], tk[2], tk[3]);
+  if (OBST) c = c + dm.w_obs * collision_pair(dm, grid, x[0], x[1]);
+  return c;
 }
 
 template <int MODEL>

@@ -780,11 +780,12 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
     if (words <= 4096) a.grid_words = (words + 3) & ~3;  // <= 16 KB: the map rides in LDS
   }
   const bool stage_states = o.want_states;
-  size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true, stage_states, a.grid_words);
+  const int stage_b = stage_states ? rollout_stage_bytes_per_lane(c->cfg.model) : 0;
+  size_t lds = rollout_lds_bytes(c->S, c->D, c->M, nt, true, stage_b, a.grid_words);
   if (lds > 96 * 1024) {  // keep >= 1 workgroup per CU resident with room to spare; larger tiles go to an HBM slab
     TRY(ensure(&c->tile_scratch, &c->tile_cap, (size_t)c->nloc * c->S * (c->D | 1)));
     a.tile_scratch = c->tile_scratch;
-    lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false, o.want_states, a.grid_words);  // (HBM tile: full-feature kernel)
+    lds = rollout_lds_bytes(c->S, c->D, c->M, nt, false, stage_b, a.grid_words);  // (HBM tile: full-feature kernel)
     if (lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "n_samples too large for one workgroup (%zu B of LDS)", lds);
   }
   {

@@ -25,6 +25,9 @@
 #ifndef DUST_STG_CHUNK
 #define DUST_STG_CHUNK 128  // bytes of a trajectory staged per flush of the stored-states form (rollout_body)
 #endif
+#ifndef DUST_STG_CHUNK_PART
+#define DUST_STG_CHUNK_PART 64  // the same for the Particle family (two staged trajectories per lane)
+#endif
 
 namespace dust {
 
@@ -252,7 +255,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
   // |theta| stays below |theta_0| + max_speed dt H: wave-uniform test for the branch-free trig path
   const bool fast_part = MODEL == DUST_MODEL_PARTICLE && red[40] == 0.f && fabsf(x0[0]) <= 3.0e38f && fabsf(x0[1]) <= 3.0e38f &&
-                         fabsf(x0[DS > 2 ? 2 : 0]) <= 3.0e38f && fabsf(x0[DS > 3 ? 3 : 0]) <= 3.0e38f;
+                         fabsf(x0[DS > 2 ? 2 : 0]) <= 3.0e38f && fabsf(x0[DS > 3 ? 3 : 0]) <= 3.0e38f &&
+                         // reachable positions keep floor(p / cell + off) far from the int64 edge (collision_pair)
+                         (fabsf(x0[0]) + fabsf(x0[1]) + (fabsf(x0[DS > 2 ? 2 : 0]) + fabsf(x0[DS > 3 ? 3 : 0]) + a.dm.max_speed * (float)H) * fabsf((float)a.dm.dt)) *
+                                     fabsf(a.dm.inv_cell) + fabsf(a.dm.off_x) + fabsf(a.dm.off_y) < 1.0e17f;
   const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !f_states && !f_tile_scratch && red[40] == 0.f && !f_mw &&
                          fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   // lane = (sample s, dynamics group mg): with several dynamics samples per rollout (M > 1) and few action samples the
@@ -303,12 +309,15 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   // trajectory's chunk - full 128-byte runs - 8 trajectories per store instruction.  Whole waves take part (lanes past S roll a
   // clamped duplicate out and store nothing).
   const int bps = DS * (a.store_f16 ? 2 : 4);  // bytes per stored state
-  constexpr int CHB = DUST_STG_CHUNK;          // staged bytes per lane and flush: one 128-byte line (or half of one)
+  // staged bytes per lane and flush: one 128-byte line; Particle: half a line for each of the pair path's two trajectories (the
+  // halves of a line are written 4 steps apart and merge in L2), which keeps the staging at 160 B per lane
+  constexpr int CHB = MODEL == DUST_MODEL_PARTICLE ? DUST_STG_CHUNK_PART : DUST_STG_CHUNK;
   constexpr int STG_ROW = CHB + 16;            // LDS bytes per lane (+16: bank spread)
   constexpr int PC = CHB / 16;                 // 16-byte pieces per chunk = lanes that share one trajectory's chunk
   char *stg = nullptr;
   if (f_states) {
-    stg = reinterpret_cast<char *>(gridl + (GRID_LDS ? a.grid_words : 0)) + (size_t)(tid >> 6) * 64 * STG_ROW;
+    // (Particle: two staging areas per wave - the pair path rolls two trajectories per lane)
+    stg = reinterpret_cast<char *>(gridl + (GRID_LDS ? a.grid_words : 0)) + (size_t)(tid >> 6) * (MODEL == DUST_MODEL_PARTICLE ? 2 : 1) * 64 * STG_ROW;
   }
   const int lane64 = tid & 63;
   const int S_loop = f_states ? min(sub, (S + 63) & ~63) : S;
@@ -322,7 +331,53 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
     double acc_m = 0.0, ut_term = 0.0;
     int m_begin = mg;
-    if (MODEL == DUST_MODEL_PARTICLE && LEAN && fast_part) {
+    // ---- stored states: staging row write / cooperative chunk flush, for the trajectory block whose first row is r_first
+    const size_t rowb = (size_t)(H + 1) * bps;
+    const int n_traj = min(64, S - (s_raw - lane64));  // valid trajectories of this wave
+    auto put_state_at = [&](char *sg, const int ph, const int row, const float *xs) {  // this lane's state -> its staging row
+      char *dst = sg + lane64 * STG_ROW + ((row * bps + ph) & (CHB - 1));
+      if (a.store_f16) {
+        _Float16 hx[DS];
+#pragma unroll
+        for (int k = 0; k < DS; ++k) hx[k] = (_Float16)xs[k];
+        if (DS == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(hx);
+        else {
+          reinterpret_cast<uint32_t *>(dst)[0] = reinterpret_cast<const uint32_t *>(hx)[0];
+          reinterpret_cast<uint32_t *>(dst)[1] = reinterpret_cast<const uint32_t *>(hx)[1];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < DS; ++k) reinterpret_cast<float *>(dst)[k] = xs[k];  // (4-byte aligned in general; merged when the phase allows)
+      }
+    };
+    auto flush_at = [&](const char *sg, const long r_first, const int ph, const int chunk, const int lo, const int hi) {  // staged bytes [lo, hi) of the wave's chunk -> HBM
+      char *gbase = reinterpret_cast<char *>(f_states) + (size_t)chunk * CHB - ph;
+      const int piece = lane64 & (PC - 1);
+      v4f pv[PC];
+#pragma unroll
+      for (int i = 0; i < PC; ++i) pv[i] = *reinterpret_cast<const v4f *>(sg + ((lane64 / PC) + (64 / PC) * i) * STG_ROW + piece * 16);  // all reads in flight
+      const bool pok = piece * 16 >= lo && piece * 16 + 16 <= hi;
+#pragma unroll
+      for (int i = 0; i < PC; ++i) {
+        const int j = (lane64 / PC) + (64 / PC) * i;
+        if (j < n_traj && pok) {
+#ifdef DUST_STATES_NT
+          __builtin_nontemporal_store(pv[i], reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16));
+#else
+          *reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16) = pv[i];
+#endif
+        }
+      }
+      // words of partially covered 16-byte pieces at either end (at most 3 + 3): lane j copies trajectory j's
+      const int head_end = min(hi, (lo + 15) & ~15), tail_beg = max(head_end, hi & ~15);
+      if (lane64 < n_traj) {
+        char *grow = gbase + (size_t)(r_first + (long)lane64 * N) * rowb;
+        const char *srow = sg + lane64 * STG_ROW;
+        for (int o4 = lo; o4 < head_end; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
+        for (int o4 = tail_beg; o4 < hi; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
+      }
+    };
+    if (MODEL == DUST_MODEL_PARTICLE && (LEAN || STATES) && fast_part) {
       // Particle, finite operands, nothing stored: TWO dynamics samples (m, m + G) of this lane's action row roll out side by
       // side - two independent dependency chains per lane, interleaved by the scheduler (the loop is latency-bound: ~150
       // dependent instructions per step at 3-5 waves per SIMD); accumulation order over m is unchanged (m, then m + G, ...)
@@ -334,20 +389,44 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         const float ma = coefs[2 * pa], mb = coefs[2 * pb];
         if (!(fabsf(ma) >= 1.0e-30f && fabsf(ma) <= 1.0e30f && fabsf(mb) >= 1.0e-30f && fabsf(mb) <= 1.0e30f)) break;  // general loop
         const float ra = 1.0f / ma, rb = 1.0f / mb;
-        float xa[4], xb[4];
+        const v2f m2 = {ma, mb}, r2 = {ra, rb};
+        v2f xp[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xa[k] = xb[k] = x0[k];
+        for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
         double ta = 0.0, tb = 0.0;
         float tca, tcb;
+        // stored states: the two trajectories (rows G S N apart: the same alignment phase) stage side by side and their chunks
+        // flush together - 2 PC LDS reads, then 2 PC stores in flight per flush
+        const long rA = (long)m * SN + (long)(s_raw - lane64) * N + n, rB = rA + (long)G * SN;
+        const int ph = (STATES && ((size_t)N * rowb) % CHB == 0) ? (int)(((size_t)rA * rowb) % CHB) : 0;
+        char *stgB = stg + 64 * STG_ROW;
+        auto put_pair = [&](const int row) {
+          if (!STATES) return;
+          const float sa[4] = {xp[0].x, xp[1].x, xp[2].x, xp[3].x}, sb[4] = {xp[0].y, xp[1].y, xp[2].y, xp[3].y};
+          put_state_at(stg, ph, row, sa);
+          put_state_at(stgB, ph, row, sb);
+          const int endb = (row + 1) * bps + ph;  // staged bytes so far, counted from the start of chunk 0's line
+          if ((endb & (CHB - 1)) == 0) {
+            flush_at(stg, rA, ph, endb / CHB - 1, endb == CHB ? ph : 0, CHB);
+            flush_at(stgB, rB, ph, endb / CHB - 1, endb == CHB ? ph : 0, CHB);
+          } else if (row == H) {
+            flush_at(stg, rA, ph, endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
+            flush_at(stgB, rB, ph, endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
+          }
+        };
         auto pair_loop = [&](auto obst, auto crash) {
           constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
+          put_pair(0);
           for (int t = 0; t < H; ++t) {
-            const float at[2] = {actl[2 * t], actl[2 * t + 1]};
-            ta += (double)particle_step_cost_fast<OB, CR>(dml, ma, ra, xa, at);
-            tb += (double)particle_step_cost_fast<OB, CR>(dml, mb, rb, xb, at);
+            const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
+            const v2f c = particle_pair_step<OB, CR>(a.dm, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
+            ta += (double)c.x;
+            tb += (double)c.y;
+            put_pair(t + 1);
           }
-          tca = particle_term_cost_fast<OB>(dml, xa);
-          tcb = particle_term_cost_fast<OB>(dml, xb);
+          const v2f tc = particle_pair_term<OB>(a.dm, dml.grid_bits, xp);
+          tca = tc.x;
+          tcb = tc.y;
         };
         if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{});
         else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{});
@@ -395,55 +474,14 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         const bool so = f_states != nullptr;
         // trajectory j of this wave (lane j's) is row r_first + j N of the [M][S][N] rollout index
         const long r_first = ((long)m * SN + (long)(s_raw - lane64) * N + n);
-        const int n_traj = min(64, S - (s_raw - lane64));  // valid trajectories of this wave
-        const size_t rowb = (size_t)(H + 1) * bps;
         // chunk boundaries sit on 128-byte LINES of the output when every trajectory of the wave has the same alignment (N rows
         // apart: N * rowb a multiple of 128 - cfg3: 4096 * 656): a store instruction then writes whole lines, and only a
         // trajectory's first / last partial chunk shares its line with the neighbouring row
         const int ph = ((size_t)N * rowb) % CHB == 0 ? (int)(((size_t)r_first * rowb) % CHB) : 0;  // bytes; a multiple of 4
         auto put_state = [&](const int row) {  // this lane's state -> its staging row
-          char *dst = stg + lane64 * STG_ROW + ((row * bps + ph) & (CHB - 1));
-          if (a.store_f16) {
-            _Float16 hx[DS];
-#pragma unroll
-            for (int k = 0; k < DS; ++k) hx[k] = (_Float16)x[k];
-            if (DS == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(hx);
-            else {
-              reinterpret_cast<uint32_t *>(dst)[0] = reinterpret_cast<const uint32_t *>(hx)[0];
-              reinterpret_cast<uint32_t *>(dst)[1] = reinterpret_cast<const uint32_t *>(hx)[1];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < DS; ++k) reinterpret_cast<float *>(dst)[k] = x[k];  // (4-byte aligned in general; merged when the phase allows)
-          }
+          put_state_at(stg, ph, row, x);
         };
-        auto flush = [&](const int chunk, const int lo, const int hi) {  // staged bytes [lo, hi) of the wave's chunk -> HBM
-          char *gbase = reinterpret_cast<char *>(f_states) + (size_t)chunk * CHB - ph;
-          const int piece = lane64 & (PC - 1);
-          v4f pv[PC];
-#pragma unroll
-          for (int i = 0; i < PC; ++i) pv[i] = *reinterpret_cast<const v4f *>(stg + ((lane64 / PC) + (64 / PC) * i) * STG_ROW + piece * 16);  // all reads in flight
-          const bool pok = piece * 16 >= lo && piece * 16 + 16 <= hi;
-#pragma unroll
-          for (int i = 0; i < PC; ++i) {
-            const int j = (lane64 / PC) + (64 / PC) * i;
-            if (j < n_traj && pok) {
-#ifdef DUST_STATES_NT
-              __builtin_nontemporal_store(pv[i], reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16));
-#else
-              *reinterpret_cast<v4f *>(gbase + (size_t)(r_first + (long)j * N) * rowb + piece * 16) = pv[i];
-#endif
-            }
-          }
-          // words of partially covered 16-byte pieces at either end (at most 3 + 3): lane j copies trajectory j's
-          const int head_end = min(hi, (lo + 15) & ~15), tail_beg = max(head_end, hi & ~15);
-          if (lane64 < n_traj) {
-            char *grow = gbase + (size_t)(r_first + (long)lane64 * N) * rowb;
-            const char *srow = stg + lane64 * STG_ROW;
-            for (int o4 = lo; o4 < head_end; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
-            for (int o4 = tail_beg; o4 < hi; o4 += 4) *reinterpret_cast<float *>(grow + o4) = *reinterpret_cast<const float *>(srow + o4);
-          }
-        };
+        auto flush = [&](const int chunk, const int lo, const int hi) { flush_at(stg, r_first, ph, chunk, lo, hi); };
         auto put_and_flush = [&](const int row) {
           put_state(row);
           const int endb = (row + 1) * bps + ph;  // staged bytes so far, counted from the start of chunk 0's line
@@ -741,10 +779,13 @@ __global__ __launch_bounds__(256) void rollout_stream_kernel(const RolloutArgs a
   rollout_body<MODEL, 32, GROUPS, LEAN, STATES>(a, lds, threadIdx.x, blockDim.x, xcd_contiguous(blockIdx.x, gridDim.x), nullptr);
 }
 
-static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds, bool stage_states = false, int grid_words = 0) {
+static inline int rollout_stage_bytes_per_lane(int model) {
+  return model == DUST_MODEL_PARTICLE ? 2 * (DUST_STG_CHUNK_PART + 16) : DUST_STG_CHUNK + 16;
+}
+static inline size_t rollout_lds_bytes(int S, int D, int M, int nt, bool tile_in_lds, int stage_bytes_per_lane = 0, int grid_words = 0) {
   return sizeof(float) * ((tile_in_lds ? (size_t)S * (D | 1) : 0) + 2 * (size_t)S + 96 + 2 * (size_t)nt + 2 + (size_t)D + 2 * (size_t)M) + 16 +
          sizeof(uint32_t) * (size_t)grid_words +                     // occupancy grid (Particle)
-         (stage_states ? (size_t)(nt / 64) * 64 * (DUST_STG_CHUNK + 16) : 0);  // + one staging row (chunk + 16 B) per lane
+         (size_t)(nt / 64) * 64 * stage_bytes_per_lane;  // + staging rows (chunk + 16 B) per lane when states are stored
 }
 
 }  // namespace dust

@@ -55,7 +55,6 @@ __device__ __forceinline__ void store16(float *p, v4f v, bool wt) {
   if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else *reinterpret_cast<v4f *>(p) = v;
 }
-typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 math: v_pk_add_f32 / v_pk_fma_f32 (2 flops per lane-op)
 
 // Row-lane tile staging: W = 2^k >= DP lanes per row, RB = NT / W rows per batch; a lane keeps ONE column (its scale is a
 // per-lane constant, no index division) and walks the rows with a fixed stride in HBM and LDS.  Rows / columns outside the
