@@ -358,16 +358,36 @@ __device__ __forceinline__ v2f round_sum4(const v2f t0, const v2f t1, const v2f 
   const double sb = (((double)t0.y + (double)t1.y) + (double)t2.y) + (double)t3.y;
   return (v2f){(float)sa, (float)sb};
 }
+// the per-dimension target / state-cost weights as packed pairs (both halves equal): built once per kernel by the caller - in
+// SGPR pairs when the compiler has them to spare, in VGPR pairs (PairK::pin) when it does not (a splat of an odd-indexed SGPR
+// otherwise goes through a stack slot: a scratch load, and with it a vmcnt wait behind every store in flight, per time step)
+struct PairK {
+  v2f target[4], w_state[4];
+  __device__ __forceinline__ void load(const DevModel &dm) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      target[k] = (v2f){dm.target[k], dm.target[k]};
+      w_state[k] = (v2f){dm.w_state[k], dm.w_state[k]};
+    }
+  }
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      asm volatile("" : "+v"(target[k]));
+      asm volatile("" : "+v"(w_state[k]));
+    }
+  }
+};
 template <bool OBST, bool CRASH>
-__device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const uint32_t *grid, const v2f mass, const v2f rmass, v2f *x, const float a0, const float a1,
-                                                  const float cc /* control cost of (a0, a1), shared by both samples */) {
+__device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const PairK &pk, const uint32_t *grid, const v2f mass, const v2f rmass, v2f *x, const float a0,
+                                                  const float a1, const float cc /* control cost of (a0, a1), shared by both samples */) {
   v2f coll = {0.f, 0.f};
   if (OBST) coll = collision_pair(dm, grid, x[0], x[1]);
   v2f tk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const v2f d = x[k] - dm.target[k];
-    tk[k] = (d * d) * dm.w_state[k];
+    const v2f d = x[k] - pk.target[k];
+    tk[k] = (d * d) * pk.w_state[k];
   }
   v2f cost = round_sum4(tk[0], tk[1], tk[2], tk[3]) + cc;
   if (OBST) cost = cost + dm.w_obs * coll;  // (without obstacles the reference adds +0 to a non-negative sum: identity)

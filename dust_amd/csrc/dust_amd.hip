@@ -18,6 +18,7 @@
 #include "fused.hpp"
 #include "pairwise_big.hpp"
 #include "persist.hpp"
+#include "rollout_states.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -58,7 +59,7 @@ extern "C" int dust_device_count(int *count) {
 }
 
 static const char *k_names[DUST_K_COUNT] = {"rollout_kernel", "pairwise_kernel<PRIOR>", "pairwise_kernel<STEIN>", "update_kernel",
-                                            "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", ""};
+                                            "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", "particle_states_kernel"};
 extern "C" const char *dust_kernel_name(int id) { return (id >= 0 && id < DUST_K_COUNT) ? k_names[id] : ""; }
 
 struct dust_ctx {
@@ -797,11 +798,48 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   return DUST_OK;
 }
 
-static int launch_rollout(dust_ctx *c, const SampleOpts &o) {
+// The whole-line stored-states form (rollout_states.hpp): Particle, fp32 in and out, 8-particle groups that are whole lines.
+static bool states_whole_lines(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, int *gw_out, size_t *lds_out) {
+  const char *env = getenv("DUST_STATES_FORM");  // development switch: 0 keeps the per-particle staging kernel
+  if (env && atoi(env) == 0) return false;
+  if (c->cfg.model != DUST_MODEL_PARTICLE || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
+  if (o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
+  if (((c->H + 1) & 1) == 0 || c->H + 1 < 9) return false;
+  if ((c->N % 8) || (c->n0 % 8) || (c->nloc % 8)) return false;
+  if (a.dm.with_obstacle && a.grid_words == 0) return false;
+  int gw = 4;
+  while (gw > 1 && c->M % (2 * gw)) gw >>= 1;
+  if (c->M % (2 * gw)) return false;
+  const size_t lds = particle_states_lds_bytes(c->D, c->M, a.grid_words, gw);
+  if (lds > 80 * 1024) return false;
+  *gw_out = gw;
+  *lds_out = lds;
+  return true;
+}
+
+static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
+  SampleOpts o = o_in;
   RolloutArgs a;
   int nt;
   size_t lds;
   TRY(rollout_args(c, o, a, &nt, &lds));
+  {
+    int gw;
+    size_t lds_s;
+    if (states_whole_lines(c, o, a, &gw, &lds_s)) {
+      // pass 1: rollouts + states + costs; pass 2 (below): the regular kernel in its injected-costs mode - softmax, weights, score
+      {
+        Prof ps(c, DUST_K_ROLLOUT_STATES);
+        if (lds_s > 64 * 1024 && !c->capturing)
+          HIP_TRY(hipFuncSetAttribute((const void *)particle_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        particle_states_kernel<<<(c->nloc / 8) * ((c->S + 7) / 8), 64 * gw, lds_s, c->stream>>>(a, c->costs_stage, gw);
+        HIP_TRY(hipGetLastError());
+      }
+      o.want_states = false;
+      o.costs_in = c->costs_stage;
+      TRY(rollout_args(c, o, a, &nt, &lds));
+    }
+  }
   Prof p(c, DUST_K_ROLLOUT);
 #define DUST_LAUNCH_ROLLOUT(KERNEL)                                                                                            \
   do {                                                                                                                          \

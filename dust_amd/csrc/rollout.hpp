@@ -414,12 +414,14 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
             flush_at(stgB, rB, ph, endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
           }
         };
+        PairK pk;
+        pk.load(a.dm);
         auto pair_loop = [&](auto obst, auto crash) {
           constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
           put_pair(0);
           for (int t = 0; t < H; ++t) {
             const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
-            const v2f c = particle_pair_step<OB, CR>(a.dm, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
+            const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
             ta += (double)c.x;
             tb += (double)c.y;
             put_pair(t + 1);

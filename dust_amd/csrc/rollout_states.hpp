@@ -1,0 +1,268 @@
+// Stored-states rollouts, whole-line form (Particle family): the HBM-bound kernel of the path.
+//
+// MultiDISCO.forward returns every rollout's state trajectory (disco.py:394): [M][S][N][(H+1)][ds] floats, 11 GB at cfg3.  A
+// trajectory is one (H+1)*16-byte run (656 B at H = 40) - NOT a multiple of the 128-byte line, so 2 of a row's ~6 lines are
+// shared with the neighbouring rows n-1 / n+1.  Measured on MI355X (tools/store_pattern_bench.hip): a kernel that writes such
+// rows from one workgroup per particle - whatever the staging - tops out at 2.6-3.2 TB/s, because the shared lines reach HBM as
+// two partial writes from two different XCDs; the same pattern with 640-byte rows reaches 5.4 TB/s, the flat-fill rate.
+//
+// So here a wave owns GROUPS OF 8 ADJACENT particles: 8 rows = 8*16*(H+1) bytes = (H+1) whole lines.  lane = (sample s_sub = lane/8,
+// particle n_sub = lane%8); a workgroup = 8 samples x 8 particles, its waves split the M dynamics samples and share the 64 action
+// rows.  Only whole lines are ever stored:
+//   - a lane keeps the last 8 states of its trajectory in registers (a ring indexed by row % 8, static after 8x unrolling); row
+//     n_sub starts 16*p bytes into a line, p = ((H+1)*n_sub) % 8 - a different phase per lane (H+1 odd: p is a permutation) - so
+//     at every time step exactly ONE particle per group completes a line: its 8 lanes (one per sample) dump their rings into a
+//     128-byte transient line in LDS and the whole wave writes these 8 lines, 8 lanes x 16 bytes per line;
+//   - the first line of a row with p != 0 is a HEAD shared with the previous row's TAIL: the head states (rows 0..6) stay in
+//     registers until the rollout ends, then tails and heads are assembled in LDS into the 7 straddling lines per group.
+// Two dynamics samples (m, m + GW) roll out side by side per lane in packed fp32 (common.hpp particle_pair_step), as in the
+// lean kernel; costs go to a [S][N] buffer that the regular kernel then consumes (its injected-costs mode) for the softmax /
+// weights / score stage.  Any non-finite operand or abnormal mass sends the workgroup down the general (reference-order,
+// branchy) step functions - same storage scheme, bit-identical results to rollout_body's general loop.
+#pragma once
+#include "rollout.hpp"
+
+namespace dust {
+
+enum { SG_ROW = 144 };  // LDS bytes per staged 128-byte line (+16: bank spread)
+enum { SP_FAST_FREE = 0, SP_FAST_OBST = 1, SP_FAST_CRASH = 2, SP_GENERAL = 3 };
+
+template <int MODE>
+__device__ __forceinline__ v2f sg_pair_step(const DevModel &dmk, const PairK &pk, const uint32_t *grid, const v2f m2, const v2f r2, v2f *xp, const float a0, const float a1) {
+  if (MODE == SP_GENERAL) {
+    float xa[4], xb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xa[k] = xp[k].x;
+      xb[k] = xp[k].y;
+    }
+    const float at[2] = {a0, a1};
+    Coef ca, cb;
+    ca.c0 = m2.x;
+    cb.c0 = m2.y;
+    ca.c1 = cb.c1 = 0.f;
+    v2f c;
+    c.x = step_with_cost<DUST_MODEL_PARTICLE>(dmk, ca, xa, at);  // (the rare path looks the map up in HBM: no private copy of the model)
+    c.y = step_with_cost<DUST_MODEL_PARTICLE>(dmk, cb, xb, at);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xp[k] = (v2f){xa[k], xb[k]};
+    return c;
+  } else {
+    return particle_pair_step<MODE != SP_FAST_FREE, MODE == SP_FAST_CRASH>(dmk, pk, grid, m2, r2, xp, a0, a1, particle_ctrl_cost(dmk, a0, a1));
+  }
+}
+template <int MODE>
+__device__ __forceinline__ v2f sg_pair_term(const DevModel &dmk, const uint32_t *grid, const v2f *xp) {
+  if (MODE == SP_GENERAL) {
+    float xa[4], xb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xa[k] = xp[k].x;
+      xb[k] = xp[k].y;
+    }
+    return (v2f){term_cost<DUST_MODEL_PARTICLE>(dmk, xa), term_cost<DUST_MODEL_PARTICLE>(dmk, xb)};
+  } else {
+    return particle_pair_term<MODE != SP_FAST_FREE>(dmk, grid, xp);
+  }
+}
+
+// One lane's two trajectories (m, m + GW) for every pair of this wave's share of the dynamics samples.
+template <int MODE>
+__device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint32_t *grid, const float *actl, const float *coefs, char *area, const int lane,
+                                                const int w, const int GW, const bool live, char *gsg /* this lane's s-group, m = 0, + 16 * (lane % 8) */,
+                                                const float *x0) {
+  const int H = a.H, Hp1 = H + 1;
+  const int j = lane & 7, sgrp = lane >> 3;
+  const int pj = (Hp1 * j) & 7;  // this row's phase: it starts 16 * pj bytes into a line
+  const int inv8 = Hp1 & 7;      // x * x = 1 (mod 8) for odd x: the particle whose phase is ph is (ph * inv8) % 8
+  const uint32_t rowb = 16u * (uint32_t)Hp1;
+  const size_t mstride = (size_t)a.S * a.N_total * rowb;  // bytes between consecutive dynamics samples
+  char *const my_row = area + lane * SG_ROW;
+  char *const prev_row = area + (lane - 1) * SG_ROW;
+  char *const tr_w = area + (64 + sgrp) * SG_ROW;                 // transient line of this lane's s-group (sample B's dumps)
+  const char *const tr_r = area + (64 + sgrp) * SG_ROW + j * 16;  // flusher role: piece j of it
+  const char *const end_r = area + (lane & ~7) * SG_ROW + j * 16; // flusher role at the end: + it * SG_ROW
+  int slot16[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) slot16[q] = ((q + pj) & 7) * 16;
+  PairK pk;
+  pk.load(a.dm);
+  pk.pin();
+  double acc = 0.0;
+  for (int m = w; m + GW < a.M; m += 2 * GW) {
+    const float ma = coefs[2 * m], mb = coefs[2 * (m + GW)];
+    const v2f m2 = {ma, mb}, r2 = {1.0f / ma, 1.0f / mb};
+    char *const gA = gsg + (size_t)m * mstride, *const gB = gA + (size_t)GW * mstride;
+    v2f xp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
+    v4f cB[8];  // sample B's state ring (row % 8); sample A's lives in the staging area (slot = (row + pj) % 8 of the lane's line)
+    double ta = 0.0, tb = 0.0;
+    // one row of both trajectories.  From row 7 on, the particle whose line completes at this row: A's line is read straight
+    // from the area, B's 8 lanes dump their rings into the transient lines first; the wave stores 8 + 8 whole lines.
+    auto emit = [&](const int q /* row % 8, static */, const int row) {
+      *reinterpret_cast<v4f *>(my_row + slot16[q]) = (v4f){xp[0].x, xp[1].x, xp[2].x, xp[3].x};
+      cB[q] = (v4f){xp[0].y, xp[1].y, xp[2].y, xp[3].y};
+      if (row < 7) return;  // (lines completing before row 7 are heads: assembled at the end)
+      const int ph = (7 - q) & 7;
+      const int jn = (ph * inv8) & 7;
+      const uint32_t line = (rowb * (uint32_t)jn + 16u * (uint32_t)(row + 1)) / 128u - 1u;  // of the group, wave-uniform
+      __builtin_amdgcn_wave_barrier();
+      const v4f pa = *reinterpret_cast<const v4f *>(end_r + jn * SG_ROW);
+      if (pj == ph) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(tr_w + slot16[u]) = cB[u];
+      }
+      __builtin_amdgcn_wave_barrier();
+      const v4f pb = *reinterpret_cast<const v4f *>(tr_r);
+      __builtin_amdgcn_wave_barrier();
+      if (live) {
+        *reinterpret_cast<v4f *>(gA + (size_t)line * 128u) = pa;
+        *reinterpret_cast<v4f *>(gB + (size_t)line * 128u) = pb;
+      }
+    };
+    emit(0, 0);
+    for (int base = 0; base < H; base += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = base + i;
+        if (t < H) {
+          const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
+          const v2f c = sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xp, a0, a1);
+          ta += (double)c.x;
+          tb += (double)c.y;
+          emit((i + 1) & 7, t + 1);
+        }
+      }
+    }
+    const v2f tc = sg_pair_term<MODE>(a.dm, grid, xp);
+    acc += (double)((float)ta + tc.x);
+    acc += (double)((float)tb + tc.y);
+    // ---- the 7 straddling lines of each group: tail of row j (slots 0 .. t-1) + head of row j+1 (slots t .. 7) ----
+    // head rows 1..6 are rolled out AGAIN (same instructions, same operands: the same bits) rather than held in 48 registers
+    // through the whole rollout
+    v4f hA[6], hB[6];
+    {
+      v2f xh[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xh[k] = (v2f){x0[k], x0[k]};
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        (void)sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xh, actl[2 * q], actl[2 * q + 1]);
+        hA[q] = (v4f){xh[0].x, xh[1].x, xh[2].x, xh[3].x};
+        hB[q] = (v4f){xh[0].y, xh[1].y, xh[2].y, xh[3].y};
+      }
+    }
+    const v4f first = {x0[0], x0[1], x0[2], x0[3]};
+    auto assemble = [&](const v4f *ring /* or nullptr: the tails are in the area already */, const v4f *head, char *g) {
+      if (ring != nullptr && j < 7) {  // (row 7 of a group ends on a line boundary: no tail)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(my_row + slot16[u]) = ring[u];  // tail slots valid, the rest overwritten below
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (j >= 1) {  // pj >= 1: rows 0 .. 7-pj of this trajectory complete the previous row's last line
+        *reinterpret_cast<v4f *>(prev_row + pj * 16) = first;
+#pragma unroll
+        for (int q = 1; q <= 6; ++q)
+          if (q + pj <= 7) *reinterpret_cast<v4f *>(prev_row + (q + pj) * 16) = head[q - 1];
+      }
+      __builtin_amdgcn_wave_barrier();
+      v4f pv[7];
+#pragma unroll
+      for (int it = 0; it < 7; ++it) pv[it] = *reinterpret_cast<const v4f *>(end_r + it * SG_ROW);
+      __builtin_amdgcn_wave_barrier();
+      if (live) {
+#pragma unroll
+        for (int it = 0; it < 7; ++it) *reinterpret_cast<v4f *>(g + (size_t)((rowb * (uint32_t)(it + 1)) / 128u) * 128u) = pv[it];
+      }
+    };
+    assemble(nullptr, hA, gA);
+    assemble(cB, hB, gB);
+  }
+  return acc;
+}
+
+// grid = (n_local / 8) * ceil(S / 8) workgroups of 64 * GW lanes.  Preconditions (checked by the host): Particle, fp32 noise
+// or actions (NOISE_EPS / NOISE_ACTIONS) and fp32 states, H + 1 odd and >= 9, N_total, n0, n_local multiples of 8, M a multiple of 2 * GW, no parameter
+// interleave, no sigma-point weights, a_reg == 0 (the second pass adds nothing to the costs)
+__global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutArgs a, float *costs_sn, const int GW) {
+  extern __shared__ float lds[];
+  const int S = a.S, D = a.D, H = a.H, N = a.N_total, M = a.M;
+  const int Dp = D | 1;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+  const int nblk = (int)gridDim.x / ((S + 7) >> 3);  // particle groups
+  const int nb = blockIdx.x % nblk, sb = blockIdx.x / nblk;
+  const int n_first = a.n0 + nb * 8;
+  float *tile = lds;                         // [64][Dp] action rows, row = lane
+  float *coefs = tile + 64 * Dp;             // [M][2]
+  float *flags = coefs + 2 * M;              // [4]
+  const int off_grid = ((int)((flags + 4) - lds) + 3) & ~3;
+  uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + off_grid);
+  const int off_acc = (off_grid + a.grid_words + 3) & ~3;
+  double *accp = reinterpret_cast<double *>(lds + off_acc);                  // [GW][64]
+  char *areas = reinterpret_cast<char *>(lds + off_acc + 2 * GW * 64);        // [GW][72][SG_ROW]
+  if (tid == 0) flags[0] = 0.f;
+  float x0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x0[k] = a.state[k];
+  __syncthreads();
+  bool bad = false;
+  for (int m = tid; m < M; m += nt) {
+    float c0;
+    if (a.coef_given) c0 = a.coef_host[0];
+    else c0 = make_coef(a.dm, a.params ? a.params + (size_t)m * a.dm.P : nullptr).c0;
+    coefs[2 * m] = c0;
+    coefs[2 * m + 1] = 0.f;
+    bad |= !(fabsf(c0) >= 1.0e-30f && fabsf(c0) <= 1.0e30f);
+  }
+  {
+    const int words = a.dm.with_obstacle ? (a.dm.nx * a.dm.ny + 31) >> 5 : 0;
+    for (int i = tid; i < words; i += nt) gridl[i] = a.dm.grid_bits[i];
+  }
+  // action rows: actions[s][n][:] = theta[n][:] + chol_a * eps[s][n][:] (or the caller's actions); the 8 particles of a sample are
+  // one contiguous 8 D run
+  for (int idx = tid; idx < 64 * D; idx += nt) {
+    const int row = (int)__umulhi((uint32_t)idx, a.magicD), k = idx - row * D;
+    const int s = min(sb * 8 + (row >> 3), S - 1), n = n_first + (row & 7);
+    const float e = a.noise[((size_t)s * N + n) * D + k];
+    const float thk = a.noise_mode == NOISE_EPS ? a.theta[(size_t)n * D + k] : 0.f;
+    const float lk = a.noise_mode == NOISE_EPS ? ((k & 1) ? a.chol_a[1] : a.chol_a[0]) : 1.f;
+    const float av = thk + lk * e;  // caller-supplied actions: 0 + 1 * v (exact), as rollout_body stages them
+    tile[row * Dp + k] = av;
+    bad |= av != av;
+  }
+  if (bad) flags[0] = 1.f;
+  __syncthreads();
+  const bool fast = flags[0] == 0.f && fabsf(x0[0]) <= 3.0e38f && fabsf(x0[1]) <= 3.0e38f && fabsf(x0[2]) <= 3.0e38f && fabsf(x0[3]) <= 3.0e38f &&
+                    (fabsf(x0[0]) + fabsf(x0[1]) + (fabsf(x0[2]) + fabsf(x0[3]) + a.dm.max_speed * (float)H) * fabsf((float)a.dm.dt)) * fabsf(a.dm.inv_cell) +
+                                fabsf(a.dm.off_x) + fabsf(a.dm.off_y) <
+                        1.0e17f;
+  const int s = sb * 8 + (lane >> 3);
+  const bool live = s < S;
+  const int sc = live ? s : S - 1;
+  const uint32_t rowb = 16u * (uint32_t)(H + 1);
+  char *gsg = reinterpret_cast<char *>(a.states_out) + ((size_t)sc * N + n_first) * rowb + (lane & 7) * 16;
+  const float *actl = tile + lane * Dp;
+  char *area = areas + (size_t)w * 72 * SG_ROW;  // 64 staging lines + 8 transient lines per wave
+  double acc;
+  if (!fast) acc = sg_roll_pairs<SP_GENERAL>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
+  else if (!a.dm.with_obstacle) acc = sg_roll_pairs<SP_FAST_FREE>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
+  else if (a.dm.can_crash) acc = sg_roll_pairs<SP_FAST_CRASH>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
+  else acc = sg_roll_pairs<SP_FAST_OBST>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
+  accp[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0 && live) {  // fixed-order sum of the wave partials, then the mean over the dynamics samples (rollout_body finish_cost)
+    double t = accp[lane];
+    for (int g = 1; g < GW; ++g) t += accp[g * 64 + lane];
+    const float cost = M == 1 ? (float)t : (float)(t / M);
+    costs_sn[(size_t)s * N + n_first + (lane & 7)] = cost;
+    a.costsT[(size_t)(n_first + (lane & 7)) * S + s] = cost;
+  }
+}
+
+static inline size_t particle_states_lds_bytes(int D, int M, int grid_words, int GW) {
+  const size_t floats = (size_t)64 * (D | 1) + 2 * (size_t)M + 4 + 4 + (size_t)grid_words + 4 + 2 * (size_t)GW * 64;
+  return floats * sizeof(float) + (size_t)GW * 72 * SG_ROW + 16;
+}
+
+}  // namespace dust

@@ -1,0 +1,86 @@
+"""The whole-line stored-states kernel (dust_amd/csrc/rollout_states.hpp) against the oracle and against the per-particle
+staging kernel it replaces (DUST_STATES_FORM=0): same costs, same states, bit for bit between the two device kernels.
+
+MultiDISCO.forward returns `states` [M][S][N][H+1][ds] (dust/controllers/disco.py:394); the Particle family at fp32 takes the
+whole-line form when 8-particle groups are whole 128-byte lines (N % 8 == 0, H + 1 odd and >= 9) and M is even."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _run(N, S, M, H, can_crash, with_obstacle, poison=None, state=None, seed=0):
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    rng = np.random.default_rng(seed + 7 * N + S)
+    grid = grid_4x4_map() if with_obstacle else None
+    up = ("mass",) if M > 1 else None
+    kw = dict(model="particle", N=N, S=S, M=M, H=H, uncertain_params=up, can_crash=can_crash, with_obstacle=with_obstacle)
+    actions = (1.5 * rng.standard_normal((S, N, H, 2))).astype(np.float32)
+    if poison is not None:
+        actions[poison] = np.nan
+    params = None if up is None else rng.uniform(0.6, 1.6, (M, 1)).astype(np.float32)
+    st = np.array([-5.2, -7.3, 4.0, 3.0] if state is None else state, np.float32)
+    o = Oracle(grid=grid, **kw)
+    ref_costs, ref_states = o.rollout_cost(st, actions, params, want_states=True)
+    out = {}
+    for form in ("1", "0"):
+        os.environ["DUST_STATES_FORM"] = form
+        try:
+            c = Context(grid=grid, kernel="K1", alpha=1e-4, sigma_a=5.0, sigma_p=5.0, **kw)
+            c.set_a_mat(np.zeros((N, H, 2), np.float32))
+            c.profile(True)
+            costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True)
+            used = "particle_states_kernel" in c.profile_get()
+            c.close()
+        finally:
+            os.environ.pop("DUST_STATES_FORM", None)
+        out[form] = (costs, states, omega, used)
+    return ref_costs, ref_states, out
+
+
+@pytest.mark.parametrize("N,S,M,H,can_crash,with_obstacle", [
+    (16, 12, 4, 10, True, True),     # ragged S (12 = 8 + 4), two waves
+    (8, 8, 2, 8, False, False),      # smallest legal shape, no map
+    (24, 64, 8, 40, False, True),    # cfg3's S / H, four waves, obstacles that do not stop the particle
+    (32, 17, 16, 12, True, True),    # two pair iterations per wave
+])
+def test_whole_line_states_vs_oracle_and_staged_kernel(N, S, M, H, can_crash, with_obstacle):
+    ref_costs, ref_states, out = _run(N, S, M, H, can_crash, with_obstacle)
+    costs, states, omega, used = out["1"]
+    costs0, states0, omega0, used0 = out["0"]
+    assert used and not used0  # the new kernel really ran (and the switch really selects the old one)
+    assert relerr(costs, ref_costs) < TOL
+    assert relerr(states, ref_states) < TOL
+    assert np.array_equal(states, states0)  # every byte of every line, heads and tails included
+    assert np.array_equal(costs, costs0)
+    assert np.array_equal(omega, omega0)
+
+
+def test_whole_line_states_general_path_on_nan_action():
+    """A NaN action sends that workgroup down the reference-order step functions (torch.clamp propagates NaN, v_med3 would not):
+    same bits as the staged kernel's general loop, NaNs in the same places."""
+    ref_costs, ref_states, out = _run(16, 16, 4, 10, True, True, poison=(3, 5, 2, 1))
+    costs, states, omega, used = out["1"]
+    costs0, states0, omega0, _ = out["0"]
+    assert used
+    assert np.array_equal(np.isnan(states), np.isnan(ref_states))
+    assert np.array_equal(states, states0, equal_nan=True)
+    assert np.array_equal(costs, costs0, equal_nan=True)
+    ok = ~np.isnan(ref_costs)
+    assert relerr(costs[ok], ref_costs[ok]) < TOL
+
+
+def test_whole_line_states_not_taken_when_lines_do_not_close():
+    """H + 1 even (rows of 16 (H+1) bytes pair up into lines differently) or N % 8 != 0: the staged kernel runs, results as before."""
+    for N, H in ((16, 11), (12, 10)):
+        ref_costs, ref_states, out = _run(N, 8, 2, H, True, True)
+        costs, states, _, used = out["1"]
+        assert not used
+        assert relerr(states, ref_states) < TOL and relerr(costs, ref_costs) < TOL

@@ -26,6 +26,10 @@ def run(model, N, S, M, H, store, f16=False, reps=3):
     pk = c.profile_get()
     ms, n = pk["rollout_kernel"]
     us = 1e3 * ms / n
+    if "particle_states_kernel" in pk:
+        ms2, n2 = pk["particle_states_kernel"]
+        print("   whole-line states kernel %.1f us + second pass %.1f us" % (1e3 * ms2 / n2, us))
+        us += 1e3 * ms2 / n2
     R = M * S * N
     b_states = (2 if f16 else 4) * R * (H + 1) * ds if store else 0
     b_alg = 4 * (S * N * H * da + 2 * N * H * da + S * N) + b_states
