@@ -378,11 +378,14 @@ struct PairK {
     }
   }
 };
+// coll_io (optional): the occupancy of the CURRENT state on entry (looked up by the previous call), of the NEXT state on exit - the
+// lookup's LDS round trip then overlaps whatever the caller does between two steps instead of opening every step
 template <bool OBST, bool CRASH>
 __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const PairK &pk, const uint32_t *grid, const v2f mass, const v2f rmass, v2f *x, const float a0,
-                                                  const float a1, const float cc /* control cost of (a0, a1), shared by both samples */) {
+                                                  const float a1, const float cc /* control cost of (a0, a1), shared by both samples */,
+                                                  v2f *coll_io = nullptr) {
   v2f coll = {0.f, 0.f};
-  if (OBST) coll = collision_pair(dm, grid, x[0], x[1]);
+  if (OBST) coll = coll_io ? *coll_io : collision_pair(dm, grid, x[0], x[1]);
   v2f tk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -415,6 +418,7 @@ __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const Pair
     x[k].x = __builtin_amdgcn_fmed3f(x[k].x, -dm.max_speed, dm.max_speed);
     x[k].y = __builtin_amdgcn_fmed3f(x[k].y, -dm.max_speed, dm.max_speed);
   }
+  if (OBST && coll_io) *coll_io = collision_pair(dm, grid, x[0], x[1]);
   return cost;
 }
 __device__ __forceinline__ float particle_ctrl_cost(const DevModel &dm, const float a0, const float a1) {
@@ -422,7 +426,7 @@ __device__ __forceinline__ float particle_ctrl_cost(const DevModel &dm, const fl
   return (float)cc;
 }
 template <bool OBST>
-__device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint32_t *grid, const v2f *x) {
+__device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint32_t *grid, const v2f *x, const v2f *coll_in = nullptr) {
   v2f tk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -430,7 +434,7 @@ __device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint
     tk[k] = (d * d) * dm.w_term[k];
   }
   v2f c = round_sum4(tk[0], tk[1], tk[2], tk[3]);
-  if (OBST) c = c + dm.w_obs * collision_pair(dm, grid, x[0], x[1]);
+  if (OBST) c = c + dm.w_obs * (coll_in ? *coll_in : collision_pair(dm, grid, x[0], x[1]));
   return c;
 }
 

@@ -88,6 +88,8 @@ struct dust_ctx {
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
   size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
+  float *wg_flags;  // one word per workgroup of the whole-line stored-states kernel: "take the general path" (rollout_states.hpp)
+  size_t wg_flags_cap;
   uint32_t *grid_bits;
   int nx, ny;
   float off_x, off_y;
@@ -276,7 +278,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->mw_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -830,9 +832,19 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       // pass 1: rollouts + states + costs; pass 2 (below): the regular kernel in its injected-costs mode - softmax, weights, score
       {
         Prof ps(c, DUST_K_ROLLOUT_STATES);
-        if (lds_s > 64 * 1024 && !c->capturing)
-          HIP_TRY(hipFuncSetAttribute((const void *)particle_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-        particle_states_kernel<<<(c->nloc / 8) * ((c->S + 7) / 8), 64 * gw, lds_s, c->stream>>>(a, c->costs_stage, gw);
+        const int blocks = (c->nloc / 8) * ((c->S + 7) / 8);
+        TRY(ensure(&c->wg_flags, &c->wg_flags_cap, (size_t)blocks));
+#define DUST_LAUNCH_STATES(MODE)                                                                                                             \
+  do {                                                                                                                                       \
+    if (lds_s > 64 * 1024 && !c->capturing)                                                                                                  \
+      HIP_TRY(hipFuncSetAttribute((const void *)particle_states_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));      \
+    particle_states_kernel<MODE><<<blocks, 64 * gw, lds_s, c->stream>>>(a, c->costs_stage, gw, reinterpret_cast<unsigned int *>(c->wg_flags));                                 \
+  } while (0)
+        if (!a.dm.with_obstacle) DUST_LAUNCH_STATES(SP_FAST_FREE);
+        else if (a.dm.can_crash) DUST_LAUNCH_STATES(SP_FAST_CRASH);
+        else DUST_LAUNCH_STATES(SP_FAST_OBST);
+        DUST_LAUNCH_STATES(SP_GENERAL);  // only the workgroups the fast kernel flagged (non-finite operands) do any work here
+#undef DUST_LAUNCH_STATES
         HIP_TRY(hipGetLastError());
       }
       o.want_states = false;

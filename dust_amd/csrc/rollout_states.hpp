@@ -28,7 +28,8 @@ enum { SG_ROW = 144 };  // LDS bytes per staged 128-byte line (+16: bank spread)
 enum { SP_FAST_FREE = 0, SP_FAST_OBST = 1, SP_FAST_CRASH = 2, SP_GENERAL = 3 };
 
 template <int MODE>
-__device__ __forceinline__ v2f sg_pair_step(const DevModel &dmk, const PairK &pk, const uint32_t *grid, const v2f m2, const v2f r2, v2f *xp, const float a0, const float a1) {
+__device__ __forceinline__ v2f sg_pair_step(const DevModel &dmk, const PairK &pk, const uint32_t *grid, const v2f m2, const v2f r2, v2f *xp, const float a0, const float a1,
+                                            v2f *coll_io) {
   if (MODE == SP_GENERAL) {
     float xa[4], xb[4];
 #pragma unroll
@@ -48,11 +49,11 @@ __device__ __forceinline__ v2f sg_pair_step(const DevModel &dmk, const PairK &pk
     for (int k = 0; k < 4; ++k) xp[k] = (v2f){xa[k], xb[k]};
     return c;
   } else {
-    return particle_pair_step<MODE != SP_FAST_FREE, MODE == SP_FAST_CRASH>(dmk, pk, grid, m2, r2, xp, a0, a1, particle_ctrl_cost(dmk, a0, a1));
+    return particle_pair_step<MODE != SP_FAST_FREE, MODE == SP_FAST_CRASH>(dmk, pk, grid, m2, r2, xp, a0, a1, particle_ctrl_cost(dmk, a0, a1), coll_io);
   }
 }
 template <int MODE>
-__device__ __forceinline__ v2f sg_pair_term(const DevModel &dmk, const uint32_t *grid, const v2f *xp) {
+__device__ __forceinline__ v2f sg_pair_term(const DevModel &dmk, const uint32_t *grid, const v2f *xp, const v2f *coll_in) {
   if (MODE == SP_GENERAL) {
     float xa[4], xb[4];
 #pragma unroll
@@ -62,7 +63,7 @@ __device__ __forceinline__ v2f sg_pair_term(const DevModel &dmk, const uint32_t 
     }
     return (v2f){term_cost<DUST_MODEL_PARTICLE>(dmk, xa), term_cost<DUST_MODEL_PARTICLE>(dmk, xb)};
   } else {
-    return particle_pair_term<MODE != SP_FAST_FREE>(dmk, grid, xp);
+    return particle_pair_term<MODE != SP_FAST_FREE>(dmk, grid, xp, coll_in);
   }
 }
 
@@ -82,9 +83,12 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
   char *const tr_w = area + (64 + sgrp) * SG_ROW;                 // transient line of this lane's s-group (sample B's dumps)
   const char *const tr_r = area + (64 + sgrp) * SG_ROW + j * 16;  // flusher role: piece j of it
   const char *const end_r = area + (lane & ~7) * SG_ROW + j * 16; // flusher role at the end: + it * SG_ROW
-  int slot16[8];
+  // ring entry q (row % 8) sits in 16-byte slot (q + pj) % 8 of its line: the 8 slot addresses of the transient line (B's dumps);
+  // the lane's own line in the staging area (A's rows, the tails at the end) is a constant `own` bytes below
+  char *tw[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) slot16[q] = ((q + pj) & 7) * 16;
+  for (int q = 0; q < 8; ++q) tw[q] = tr_w + ((q + pj) & 7) * 16;
+  const int own = (int)(my_row - tr_w);
   PairK pk;
   pk.load(a.dm);
   pk.pin();
@@ -101,7 +105,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
     // one row of both trajectories.  From row 7 on, the particle whose line completes at this row: A's line is read straight
     // from the area, B's 8 lanes dump their rings into the transient lines first; the wave stores 8 + 8 whole lines.
     auto emit = [&](const int q /* row % 8, static */, const int row) {
-      *reinterpret_cast<v4f *>(my_row + slot16[q]) = (v4f){xp[0].x, xp[1].x, xp[2].x, xp[3].x};
+      *reinterpret_cast<v4f *>(tw[q] + own) = (v4f){xp[0].x, xp[1].x, xp[2].x, xp[3].x};
       cB[q] = (v4f){xp[0].y, xp[1].y, xp[2].y, xp[3].y};
       if (row < 7) return;  // (lines completing before row 7 are heads: assembled at the end)
       const int ph = (7 - q) & 7;
@@ -111,7 +115,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
       const v4f pa = *reinterpret_cast<const v4f *>(end_r + jn * SG_ROW);
       if (pj == ph) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(tr_w + slot16[u]) = cB[u];
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(tw[u]) = cB[u];
       }
       __builtin_amdgcn_wave_barrier();
       const v4f pb = *reinterpret_cast<const v4f *>(tr_r);
@@ -121,21 +125,29 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
         *reinterpret_cast<v4f *>(gB + (size_t)line * 128u) = pb;
       }
     };
+    // software pipeline across the steps: the next step's two actions and the occupancy of the state just produced are read
+    // from LDS BEFORE the row is emitted, so their latency hides under the dump / store sequence (2 waves per SIMD only)
+    float a0 = actl[0], a1 = actl[1];
+    v2f coll = {0.f, 0.f};
+    if (MODE == SP_FAST_OBST || MODE == SP_FAST_CRASH) coll = collision_pair(a.dm, grid, xp[0], xp[1]);
+    auto step = [&](const int i /* static */, const int t) {
+      const v2f c = sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xp, a0, a1, &coll);
+      const int tn = min(t + 1, H - 1);
+      a0 = actl[2 * tn];
+      a1 = actl[2 * tn + 1];
+      ta += (double)c.x;
+      tb += (double)c.y;
+      emit((i + 1) & 7, t + 1);
+    };
     emit(0, 0);
+    // (8x unrolled for the static ring index; the per-step test keeps every step its own scheduling region: with whole blocks as
+    // one region the scheduler spends 60 more VGPRs - spills - for no measurable gain)
     for (int base = 0; base < H; base += 8) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int t = base + i;
-        if (t < H) {
-          const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
-          const v2f c = sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xp, a0, a1);
-          ta += (double)c.x;
-          tb += (double)c.y;
-          emit((i + 1) & 7, t + 1);
-        }
-      }
+      for (int i = 0; i < 8; ++i)
+        if (base + i < H) step(i, base + i);
     }
-    const v2f tc = sg_pair_term<MODE>(a.dm, grid, xp);
+    const v2f tc = sg_pair_term<MODE>(a.dm, grid, xp, &coll);
     acc += (double)((float)ta + tc.x);
     acc += (double)((float)tb + tc.y);
     // ---- the 7 straddling lines of each group: tail of row j (slots 0 .. t-1) + head of row j+1 (slots t .. 7) ----
@@ -148,7 +160,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
       for (int k = 0; k < 4; ++k) xh[k] = (v2f){x0[k], x0[k]};
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
-        (void)sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xh, actl[2 * q], actl[2 * q + 1]);
+        (void)sg_pair_step<MODE>(a.dm, pk, grid, m2, r2, xh, actl[2 * q], actl[2 * q + 1], nullptr);
         hA[q] = (v4f){xh[0].x, xh[1].x, xh[2].x, xh[3].x};
         hB[q] = (v4f){xh[0].y, xh[1].y, xh[2].y, xh[3].y};
       }
@@ -157,7 +169,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
     auto assemble = [&](const v4f *ring /* or nullptr: the tails are in the area already */, const v4f *head, char *g) {
       if (ring != nullptr && j < 7) {  // (row 7 of a group ends on a line boundary: no tail)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(my_row + slot16[u]) = ring[u];  // tail slots valid, the rest overwritten below
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<v4f *>(tw[u] + own) = ring[u];  // tail slots valid, the rest overwritten below
       }
       __builtin_amdgcn_wave_barrier();
       if (j >= 1) {  // pj >= 1: rows 0 .. 7-pj of this trajectory complete the previous row's last line
@@ -185,7 +197,13 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
 // grid = (n_local / 8) * ceil(S / 8) workgroups of 64 * GW lanes.  Preconditions (checked by the host): Particle, fp32 noise
 // or actions (NOISE_EPS / NOISE_ACTIONS) and fp32 states, H + 1 odd and >= 9, N_total, n0, n_local multiples of 8, M a multiple of 2 * GW, no parameter
 // interleave, no sigma-point weights, a_reg == 0 (the second pass adds nothing to the costs)
-__global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutArgs a, float *costs_sn, const int GW) {
+// MODE: SP_FAST_* as the host's configuration says (obstacle map / crash semantics); a workgroup whose operands fail the fast
+// path's preconditions raises its word of wg_flags and leaves - particle_states_kernel<SP_GENERAL>, launched right behind, rolls
+// exactly those workgroups out with the general step functions (and returns at once everywhere else).  One kernel holding both
+// paths would carry the general path's register pressure into the fast one (measured: 39 spilled VGPRs, +8 % time).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutArgs a, float *costs_sn, const int GW, unsigned int *wg_flags) {
+  if (MODE == SP_GENERAL && wg_flags[blockIdx.x] == 0u) return;
   extern __shared__ float lds[];
   const int S = a.S, D = a.D, H = a.H, N = a.N_total, M = a.M;
   const int Dp = D | 1;
@@ -238,17 +256,21 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
                                 fabsf(a.dm.off_x) + fabsf(a.dm.off_y) <
                         1.0e17f;
   const int s = sb * 8 + (lane >> 3);
+#ifdef DUST_SG_NOSTORE
+  const bool live = s < S && a.H < 0;  // development: compute-only timing
+#else
   const bool live = s < S;
+#endif
   const int sc = live ? s : S - 1;
   const uint32_t rowb = 16u * (uint32_t)(H + 1);
   char *gsg = reinterpret_cast<char *>(a.states_out) + ((size_t)sc * N + n_first) * rowb + (lane & 7) * 16;
   const float *actl = tile + lane * Dp;
   char *area = areas + (size_t)w * 72 * SG_ROW;  // 64 staging lines + 8 transient lines per wave
-  double acc;
-  if (!fast) acc = sg_roll_pairs<SP_GENERAL>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
-  else if (!a.dm.with_obstacle) acc = sg_roll_pairs<SP_FAST_FREE>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
-  else if (a.dm.can_crash) acc = sg_roll_pairs<SP_FAST_CRASH>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
-  else acc = sg_roll_pairs<SP_FAST_OBST>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
+  if (MODE != SP_GENERAL) {
+    if (tid == 0) wg_flags[blockIdx.x] = fast ? 0u : 1u;
+    if (!fast) return;
+  }
+  const double acc = sg_roll_pairs<MODE>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
   accp[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0 && live) {  // fixed-order sum of the wave partials, then the mean over the dynamics samples (rollout_body finish_cost)
