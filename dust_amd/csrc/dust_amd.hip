@@ -19,6 +19,7 @@
 #include "pairwise_big.hpp"
 #include "persist.hpp"
 #include "rollout_states.hpp"
+#include "pairwise_fused.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -85,6 +86,9 @@ struct dust_ctx {
   float *mw_dev;             // [M] unscented-transform weights of the dynamics samples (nullptr: mean)
   float *xpad;               // [N][DPB] zero-padded query rows of the large-N pairwise kernel
   size_t xpad_cap;
+  float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
+  size_t kmat_cap;
+  bool kmat_valid;
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
   size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
@@ -278,7 +282,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->mw_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -577,6 +581,7 @@ extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
   if (!c || !theta) return fail(DUST_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(h2d(c, c->theta, theta, (size_t)c->N * c->D * sizeof(float)));
+  c->kmat_valid = false;
   if (c->adam_m) {
     HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->N * c->D * sizeof(float), c->stream));
@@ -663,18 +668,46 @@ struct SampleOpts {
 // Measured (round 1, N = 16384 / 4096, D = 30): Stein 1107 / 82 us vs 1730 / 115 us, prior 1367 / 99 vs 1799 / 119 us; D = 40:
 // 5-15 % faster; D = 80 (DPB = 128, 32-query tiles): 1630 / 1394 us vs 1060 / 905 us at N = 8192, so D > 64 keeps the 32 x 64 kernel.  Sharded
 // contexts (few query tiles per rank) keep it too: it allows JS <= 16 and with that the fused launches.
+// Round 2: once the prior means alias theta (every tick after the first) large sets take the fused pair of launches of
+// pairwise_fused.hpp - one distance pass for prior + repulsion + the Gram matrix, then Gram x score as a GEMM - for D <= 80.
 static int pair_dpb(int D) { return D <= 32 ? 32 : 64; }
+static int fused_dpb(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : 80); }
+static int fused_tq(int D) { return D <= 32 ? FusedGeom<32>::TQ : (D <= 64 ? FusedGeom<64>::TQ : FusedGeom<80>::TQ); }
+// "large key set": none of the small-N launch fusions (fused.hpp, persist.hpp) applies
 static bool pair_is_big(const dust_ctx *c) {
-  static const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel
+  const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel
   if (env && atoi(env) == 0) return false;
-  return c->N >= 2048 && c->D <= 64 && c->nloc == c->N;
+  return c->N >= 2048 && c->D <= 80 && c->nloc == c->N;
 }
+static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64; }  // pairwise_big.hpp (unfused passes)
+static bool pair_fused_ok(const dust_ctx *c) {
+  const char *env = getenv("DUST_PAIR_FUSED");  // development switch: 0 keeps the two unfused passes
+  if (env && atoi(env) == 0) return false;
+  return pair_is_big(c) && c->mu_aliased && (c->cfg.kernel == DUST_KERNEL_K1_RBF || c->cfg.kernel == DUST_KERNEL_IMQ);
+}
+// key slices: `tiles` is the query-tile count of the PRIMARY kernel of the current state; a launcher whose kernel has another
+// tile size recomputes it (the partial-output layout [js][n_local][ldp] does not depend on the tile size)
 static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
-  const int ti = pair_is_big(c) ? 4096 / pair_dpb(c->D) : PAIR_TI;
+  const bool fz = pair_fused_ok(c);
+  const int ti = fz ? fused_tq(c->D) : (pair_big_kernel(c) ? 4096 / pair_dpb(c->D) : PAIR_TI);
   *tiles = (c->nloc + ti - 1) / ti;
   const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
   int js = (512 + *tiles - 1) / *tiles;
   js = std::max(1, std::min(js, chunks));
+  if (fz) {
+    // two workgroups per CU stay resident (512 slots): a grid of 513 workgroups would take two rounds for the work of one.
+    // Pick the slice count whose grid fills whole rounds best (slices of >= 8 chunks: the tile prologue stays amortised)
+    double best = -1.0;
+    for (int cand = 1; cand <= std::min(16, std::max(1, chunks / 8)); ++cand) {
+      const int cps = (chunks + cand - 1) / cand, real = (chunks + cps - 1) / cps;
+      const long wgs = (long)*tiles * real, rounds = (wgs + 511) / 512;
+      const double fill = (double)wgs / (double)(rounds * 512) - 1e-3 * real;  // (ties: fewer slices)
+      if (fill > best) {
+        best = fill;
+        js = real;
+      }
+    }
+  }
   const int cps = (chunks + js - 1) / js;  // chunks per slice
   *slice = cps * PAIR_JC;
   *JS = (c->N + *slice - 1) / *slice;
@@ -1074,7 +1107,8 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles);
 
 template <int MODE>
 static int launch_pair(dust_ctx *c, const PairArgs &a, int tiles) {
-  if (pair_is_big(c)) return launch_pair_big<MODE>(c, a, tiles);
+  if (pair_big_kernel(c)) return launch_pair_big<MODE>(c, a, (a.n_local + 4096 / pair_dpb(a.D) - 1) / (4096 / pair_dpb(a.D)));
+  tiles = (a.n_local + PAIR_TI - 1) / PAIR_TI;  // (the caller's count is the primary kernel's: pair_geometry)
   const int cpt = cpt_for(a.D);
   const size_t lds = pairwise_lds_bytes(MODE, cpt);
   dim3 grid(tiles, a.JS);
@@ -1124,6 +1158,78 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
+// pass 1 of the fused pair (pairwise_fused.hpp): prior partials + repulsion partials + the Gram matrix of the current theta
+static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
+  const int dpb = fused_dpb(a.D);
+  TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
+  const int ldK = ((c->N + 63) / 64) * 64;
+  TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)c->nloc * ldK));
+  {
+    const int n = c->N * dpb;
+    pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
+    HIP_TRY(hipGetLastError());
+  }
+  PairFusedArgs b;
+  memset(&b, 0, sizeof b);
+  b.p = a;
+  b.Xp = c->xpad;
+  b.ldp = 8 * cpt_for(a.D);
+  b.wP[0] = a.inv_s[0] * a.inv_s[0];
+  b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
+  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+  b.wS[0] = b.wS[1] = (1.0f / ell) * (1.0f / ell);
+  b.pB = c->pB;
+  b.K = c->kmat;
+  b.ldK = ldK;
+  dim3 grid(tiles, a.JS);
+#define DUST_LAUNCH_FUSED(MODE, DPB)                                                                                                      \
+  do {                                                                                                                                    \
+    const size_t lds = pairwise_fused_lds_bytes<DPB>();                                                                                   \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                                 \
+      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_fused_kernel<MODE, DPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    pairwise_fused_kernel<MODE, DPB><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                          \
+  } while (0)
+#define DUST_PICK_FUSED(MODE)                  \
+  do {                                         \
+    if (dpb == 32) DUST_LAUNCH_FUSED(MODE, 32); \
+    else if (dpb == 64) DUST_LAUNCH_FUSED(MODE, 64); \
+    else DUST_LAUNCH_FUSED(MODE, 80);          \
+  } while (0)
+  if (c->cfg.kernel == DUST_KERNEL_IMQ) DUST_PICK_FUSED(PAIR_IMQ);
+  else DUST_PICK_FUSED(PAIR_K1);
+#undef DUST_PICK_FUSED
+#undef DUST_LAUNCH_FUSED
+  HIP_TRY(hipGetLastError());
+  c->kmat_valid = true;
+  return DUST_OK;
+}
+
+// pass 2: pA = K x score over the same key slices (matrix cores)
+static int launch_gram_score(dust_ctx *c, const PairArgs &a) {
+  const int dpb = fused_dpb(a.D);
+  GramScoreArgs g;
+  memset(&g, 0, sizeof g);
+  g.N = c->N;
+  g.D = c->D;
+  g.i0 = c->n0;
+  g.n_local = c->nloc;
+  g.JS = a.JS;
+  g.slice = a.slice;
+  g.ldp = 8 * cpt_for(a.D);
+  g.ldK = ((c->N + 63) / 64) * 64;
+  g.K = c->kmat;
+  g.V = c->score;
+  g.pA = c->pA;
+  dim3 grid((c->nloc + 63) / 64, a.JS);
+#define DUST_LAUNCH_GS(DPB) gram_score_kernel<DPB><<<grid, PAIR_NT, gram_score_lds_bytes<DPB>(), c->stream>>>(g)
+  if (dpb == 32) DUST_LAUNCH_GS(32);
+  else if (dpb == 64) DUST_LAUNCH_GS(64);
+  else DUST_LAUNCH_GS(80);
+#undef DUST_LAUNCH_GS
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
 static int ensure_partials(dust_ctx *c, int JS) {
   const size_t nd = (size_t)JS * c->nloc * 8 * cpt_for(c->D), nn = (size_t)JS * c->nloc;
   TRY(ensure(&c->pA, &c->pA_cap, nd));
@@ -1161,7 +1267,8 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   int tiles;
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
-  if (logp_only && !pair_is_big(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
+  if (logp_only && !pair_big_kernel(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
+  if (!logp_only && pair_fused_ok(c)) return launch_pair_fused(c, a, tiles);              // + repulsion + Gram matrix (pairwise_fused.hpp)
   return launch_pair<PAIR_PRIOR>(c, a, tiles);
 }
 
@@ -1396,9 +1503,13 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       return DUST_OK;
     }
     Prof p(c, DUST_K_STEIN);
-    if (c->cfg.kernel == DUST_KERNEL_IMQ) TRY(launch_pair<PAIR_IMQ>(c, a, tiles));
+    if (c->kmat_valid && pair_fused_ok(c)) {
+      // the prior pass of this iteration already produced the repulsion partials and the Gram matrix of this theta
+      TRY(launch_gram_score(c, a));
+    } else if (c->cfg.kernel == DUST_KERNEL_IMQ) TRY(launch_pair<PAIR_IMQ>(c, a, tiles));
     else TRY(launch_pair<PAIR_K1>(c, a, tiles));
   }
+  c->kmat_valid = false;  // (theta moves below; a later Stein pass without a fresh prior pass recomputes)
   UpdateArgs u = update_args(c, apply);
   Prof p(c, DUST_K_UPDATE);
   update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
@@ -1730,6 +1841,7 @@ static RollArgs roll_args(dust_ctx *c, int steps, int strategy, const float *las
   return r;
 }
 static void roll_done(dust_ctx *c) {
+  c->kmat_valid = false;  // theta rolled: the Gram matrix of pairwise_fused.hpp belongs to the old particles
   if (c->theta != c->theta_home) {
     c->theta_alt = c->theta;
     c->theta = c->theta_home;
@@ -2454,12 +2566,25 @@ extern "C" int dust_profile_rollout(dust_ctx *c, const float *state, const float
     }
     (void)hipEventRecord(e1, c->stream);
   }
-  c->prof = prof;
   if (st == DUST_OK) {
     float ms = 0.f;
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = fail(DUST_ERR_HIP, "event timing failed");
     *avg_ms = (double)ms / reps;
   }
+  if (st == DUST_OK && o.want_states) {
+    // the stored-states form may be two launches (rollout_states.hpp + the injected-costs pass): time them apart as well, one event
+    // pair per launch, into the per-kernel slots (dust_profile_get: DUST_K_ROLLOUT_STATES / DUST_K_ROLLOUT)
+    c->prof = true;
+    for (int k = 0; k < DUST_K_COUNT; ++k) {
+      c->prof_ms[k] = 0.0;
+      c->prof_n[k] = 0;
+    }
+    for (int r = 0; r < reps && st == DUST_OK; ++r) {
+      o.noise_dev = eps_dev + (size_t)(r % n_slices) * slice;
+      st = launch_rollout(c, o);
+    }
+  }
+  c->prof = prof;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   c->have_sample = true;

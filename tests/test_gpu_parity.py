@@ -758,3 +758,47 @@ def test_cfg5_shaped_dual_loop_vs_oracle():
         assert elemerr(mpf.get_particles(), xo) < 2e-5, t
         obs_prev = new_obs
         state = new_obs.astype(np.float32)
+
+
+@pytest.mark.parametrize("model,N,H,kernel", [("particle", 2048, 40, "K1"), ("pendulum", 2304, 30, "K1"), ("particle", 2100, 20, "K1"),
+                                              ("particle", 2048, 40, "IMQ"), ("pendulum", 2048, 17, "IMQ")])
+def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
+    """Prior means aliasing theta + N >= 2048: ONE distance pass serves the prior score, the Stein repulsion and the Gram matrix,
+    then Gram x score runs as a GEMM (pairwise_fused.hpp) - D = 80 / 30 / 40 / 17 (tile widths 80 / 32 / 64 / 32), ragged N,
+    non-uniform mixture weights.  grad_pri and phi against the oracle, and against the two unfused passes (DUST_PAIR_FUSED=0)."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(3 * N + H)
+    S = 8
+    theta = (0.25 * rng.standard_normal((N, H, da))).astype(np.float32)  # (close enough for the mixture weights to overlap)
+    costs = (30.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, da))).astype(np.float32)
+    mixw = rng.random(N).astype(np.float32) + 0.05
+    mixw /= mixw.sum()
+    grid = grid_4x4_map() if model == "particle" else None
+    o = Oracle(model=model, N=N, S=S, M=1, H=H, grid=grid)
+    sg = np.full(da, 1.5, np.float32)
+    sp = np.array([1.5, 0.8], np.float32)[:da]
+    gl, gp, sc = o.score(theta, theta, mixw, sp, costs, actions, 1.0, sg)
+    ref = o.phi_k1(theta, sc) if kernel == "K1" else o.phi_imq(theta, sc, 0.9)
+    got = {}
+    for fused in ("1", "0"):
+        os.environ["DUST_PAIR_FUSED"] = fused
+        try:
+            c = Context(model=model, N=N, S=S, M=1, H=H, kernel=kernel, imq_ell=0.9, lr=0.5, sigma_a=sg, sigma_p=sp, grid=grid,
+                        weighted_prior=True)
+            c.set_theta(theta)
+            c.set_prior(theta)
+            c.set_a_mat(theta)
+            c.svmpc_update_prior(mixw)  # the means alias theta from here on (svmpc.py:160-170)
+            got[fused] = c.svmpc_phi(costs, actions)
+            c.close()
+        finally:
+            os.environ.pop("DUST_PAIR_FUSED", None)
+    phi, dgl, dgp = got["1"]
+    assert elemerr(dgp, gp) < TOL
+    assert elemerr(phi, ref) < (k1_tolerance(theta) if kernel == "K1" else TOL)
+    phi0, _, dgp0 = got["0"]
+    assert elemerr(dgp, dgp0) < TOL and elemerr(phi, phi0) < TOL
