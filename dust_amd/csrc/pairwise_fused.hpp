@@ -73,28 +73,54 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   const bool pb = qg < TQ / 4;                                  // (DPB = 80: 240 of the 256 lanes)
   const int qgc = pb ? qg : 0;
 
-  v4f xB[4][NV], accA[4][NV], accB[4][NV];
+  v4f xB[4][NV] /* -x_i */, accA[4][NV], accB[4][NV];
   float accL[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gi = min(ib + 4 * qgc + r, N - 1);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      xB[r][u] = *reinterpret_cast<const v4f *>(b.Xp + (size_t)gi * DPB + c0 + 4 * u);
+      xB[r][u] = -*reinterpret_cast<const v4f *>(b.Xp + (size_t)gi * DPB + c0 + 4 * u);  // NEGATED: y + (-x) is one v_pk_add_f32 per pair of columns
+      asm volatile("" : "+v"(xB[r][u]));  // (opaque: otherwise the negation folds back into 4 scalar v_sub_f32 per difference)
       accA[r][u] = accB[r][u] = v4f{0.f, 0.f, 0.f, 0.f};
     }
     accL[r] = 0.f;
   }
   for (int i = tid; i < TQ; i += NT) mrow[i] = -INFINITY;
 
+  // Key chunks: the keys ARE the particles (prior means aliased to theta), so a chunk is rows j0 .. j0 + 63 of the padded copy -
+  // one contiguous 64 * DPB float run, fetched with 16-byte loads (NLD per lane).  The NEXT chunk's loads are issued before pass B
+  // and committed to LDS after it: their HBM / L2 latency hides under pass B instead of opening every chunk (2 workgroups per CU
+  // cannot hide it by themselves: measured 0.7 of 3.0 ms at cfg4).
+  constexpr int NLD = (JC * DPB / 4 + NT - 1) / NT;
+  v4f ky[NLD];
+  float lm_next;
+  auto keys_issue = [&](const int j0) {
+    const int jc = min(JC, jend - j0);
+    const v4f *src = reinterpret_cast<const v4f *>(b.Xp + (size_t)j0 * DPB);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int f = tid + NT * u;                       // 16-byte piece of the chunk
+      const int row = (f * 4) / DPB;                    // (DPB % 4 == 0: a piece never straddles two rows)
+      ky[u] = src[min(row, jc - 1) * (DPB / 4) + (f - row * (DPB / 4))];  // rows past the slice: clamped, zeroed at the commit
+    }
+    lm_next = a.logmix[j0 + min(jA, jc - 1)];
+  };
+  auto keys_commit = [&](const int j0) {
+    const int jc = min(JC, jend - j0);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int f = tid + NT * u;
+      const int row = (f * 4) / DPB, col = f * 4 - row * DPB;
+      if (row < JC) *reinterpret_cast<v4f *>(&Ys[row * YS + col]) = row < jc ? ky[u] : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  keys_issue(jbeg);
+  keys_commit(jbeg);
   for (int j0 = jbeg; j0 < jend; j0 += JC) {
     const int jc = min(JC, jend - j0);
-    float vy[RowLane<JC, DPB, NT>::NB];
-    rowlane_issue<JC, DPB, NT>(a.Y, j0, jc, D, vy);
-    const float lm = a.logmix[j0 + min(jA, jc - 1)];
-    __syncthreads();  // the previous chunk's pass B is done with Ys / kvP / kvS
-    rowlane_commit<JC, DPB, YS, NT, false>(vy, jc, D, a.da, a.inv_s, Ys);
-    __syncthreads();
+    const float lm = lm_next;
+    __syncthreads();  // Ys holds this chunk
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
       v2f y[DPB / 2];
@@ -187,6 +213,8 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
         accL[r] *= sc;
       }
     }
+    const bool more = j0 + JC < jend;
+    if (more) keys_issue(j0 + JC);  // in flight during pass B
     // ---- pass B: lane = 4 queries x CB columns; the difference y_j - x_i feeds the prior sum and the repulsion sum ----
     if (pb) {
 #pragma unroll 2
@@ -202,7 +230,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
           const float nk = (MODE == PAIR_K1) ? ks : (ks * ks) * ks;
 #pragma unroll
           for (int u = 0; u < NV; ++u) {
-            const v4f diff = yv[u] - xB[r][u];
+            const v4f diff = yv[u] + xB[r][u];  // y_j - x_i
             accA[r][u] = __builtin_elementwise_fma(v4f{wp, wp, wp, wp}, diff, accA[r][u]);
             accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
           }
@@ -210,6 +238,8 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
         }
       }
     }
+    __syncthreads();  // pass B is done with Ys / kvP / kvS
+    if (more) keys_commit(j0 + JC);
   }
 
   // ---- partial outputs (layout of stein.hpp: [js][n_local][ldp], raw coordinates) ----
