@@ -677,9 +677,10 @@ static int fused_tq(int D) { return D <= 32 ? FusedGeom<32>::TQ : (D <= 64 ? Fus
 static bool pair_is_big(const dust_ctx *c) {
   const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel
   if (env && atoi(env) == 0) return false;
-  return c->N >= 2048 && c->D <= 80 && c->nloc == c->N;
+  // (a rank of a sharded run qualifies from 512 local particles on: the fused pass slices the keys finely enough to fill the chip)
+  return c->N >= 2048 && c->D <= 80 && (c->nloc == c->N || c->nloc >= 512);
 }
-static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64; }  // pairwise_big.hpp (unfused passes)
+static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64 && c->nloc == c->N; }  // pairwise_big.hpp (unfused passes)
 static bool pair_fused_ok(const dust_ctx *c) {
   const char *env = getenv("DUST_PAIR_FUSED");  // development switch: 0 keeps the two unfused passes
   if (env && atoi(env) == 0) return false;
@@ -698,7 +699,7 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
     // two workgroups per CU stay resident (512 slots): a grid of 513 workgroups would take two rounds for the work of one.
     // Pick the slice count whose grid fills whole rounds best (slices of >= 8 chunks: the tile prologue stays amortised)
     double best = -1.0;
-    for (int cand = 1; cand <= std::min(16, std::max(1, chunks / 8)); ++cand) {
+    for (int cand = 1; cand <= std::min(32, std::max(1, chunks / 8)); ++cand) {
       const int cps = (chunks + cand - 1) / cand, real = (chunks + cps - 1) / cps;
       const long wgs = (long)*tiles * real, rounds = (wgs + 511) / 512;
       const double fill = (double)wgs / (double)(rounds * 512) - 1e-3 * real;  // (ties: fewer slices)

@@ -802,3 +802,33 @@ def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
     assert elemerr(phi, ref) < (k1_tolerance(theta) if kernel == "K1" else TOL)
     phi0, _, dgp0 = got["0"]
     assert elemerr(dgp, dgp0) < TOL and elemerr(phi, phi0) < TOL
+
+
+def test_sharded_large_set_takes_fused_pairwise():
+    """A rank of a sharded run with >= 512 local particles and N >= 2048 keys takes the fused large-set pairwise launches too
+    (its Gram matrix is [n_local][N]): 2 and 4 shards in one process against the unsharded context, Particle D = 80."""
+    from dust_amd import Context
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    model, N, S, M, H = "particle", 2048, 8, 1, 40
+    da, rng, mu, th, state, up, grid = _synthetic_case(model, N, S, M, H)
+    K, T = 2, 2
+    eps = rng.standard_normal((T, K, S, N, H, da)).astype(np.float32)
+    kw = dict(model=model, N=N, S=S, M=M, H=H, kernel="K1", lr=0.5, sigma_a=1.0, sigma_p=1.0, uncertain_params=up, seed=11)
+    ref = Context(grid=grid, **kw)
+    ref.set_theta(th); ref.set_prior(mu); ref.set_a_mat(th)
+    outs = [ref.svmpc_tick(state, K, eps[t]) for t in range(T)]
+    rt = ref.get_theta()
+    for world in (2, 4):
+        shards = tuple(DeviceShard(dict(kw, grid=grid), r, world) for r in range(world))
+        for sh in shards:
+            sh.set_state(th, mu, th)
+        for t in range(T):
+            a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], None, want_outputs=True)
+            assert np.array_equal(a_seq, outs[t][0]), (world, t)
+            assert relerr(pw, outs[t][1]) < 1e-5
+        for sh in shards:
+            sh.sync()
+            assert elemerr(sh.ctx.get_theta(), rt) < 1e-5, (world, sh.rank)
+            sh.ctx.close()
+    ref.close()
