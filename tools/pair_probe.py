@@ -1,4 +1,7 @@
-"""Development probe: prior / Stein pass times at large N (cfg4 shape: Particle N=16384, H=40 -> D=80)."""
+"""Prior / Stein pass times at large N (cfg4 shape: Particle N=16384, H=40 -> D=80), fused (pairwise_fused.hpp) and unfused.
+
+  python tools/pair_probe.py          all shapes, DUST_PAIR_FUSED=1 and 0
+  python tools/pair_probe.py cfg4     the cfg4 shape only (the command profiled for profiles/round2_pair_*)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,6 +32,9 @@ def run(model, N, H, S=8, kernel="K1", iters=3, alias=True):
     c.close()
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
+        run("particle", 16384, 40, iters=5)
+        sys.exit(0)
     for fused in ("1", "0"):
         os.environ["DUST_PAIR_FUSED"] = fused
         run("particle", 16384, 40)
