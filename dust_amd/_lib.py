@@ -5,6 +5,7 @@ MI355X is visible, `dust_create` fails with DUST_ERR_NO_DEVICE and `check()` rai
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUST_AMD_LIB", os.path.join(_HERE, "libdust_amd.so"))  # override: diagnostic builds only
@@ -149,10 +150,31 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  torch wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's): whichever copy is
+    loaded first serves both, and torch on top of a runtime it was not built against reports "No HIP GPUs are available" (measured:
+    Context first, torch.cuda afterwards).  libdust_amd.so only uses the stable HIP API, so when torch is installed but not yet
+    imported its copy is loaded first - without importing torch.  DUST_AMD_SYSTEM_HIP=1 skips this (a process that never uses
+    torch.cuda)."""
+    if "torch" in sys.modules or os.environ.get("DUST_AMD_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:  # no torch here: the system runtime is the only one
+        pass
+
+
 def load():
     """Load the HIP library; raises if it was never built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found: the HIP extension is not built and dust_amd has NO CPU fallback. "

@@ -697,12 +697,13 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   js = std::max(1, std::min(js, chunks));
   if (fz) {
     // two workgroups per CU stay resident (512 slots): a grid of 513 workgroups would take two rounds for the work of one.
-    // Pick the slice count whose grid fills whole rounds best (slices of >= 8 chunks: the tile prologue stays amortised)
+    // Pick the slice count whose grid fills whole rounds best (a small penalty per slice: every slice repeats the tile prologue
+    // and adds a row of partial outputs) - at N = 2048 that is one 64-key chunk per workgroup, at N = 16384 about twenty
     double best = -1.0;
-    for (int cand = 1; cand <= std::min(32, std::max(1, chunks / 8)); ++cand) {
+    for (int cand = 1; cand <= std::min(64, chunks); ++cand) {
       const int cps = (chunks + cand - 1) / cand, real = (chunks + cps - 1) / cps;
       const long wgs = (long)*tiles * real, rounds = (wgs + 511) / 512;
-      const double fill = (double)wgs / (double)(rounds * 512) - 1e-3 * real;  // (ties: fewer slices)
+      const double fill = (double)wgs / (double)(rounds * 512) - 2e-3 * real;  // (ties: fewer slices)
       if (fill > best) {
         best = fill;
         js = real;
@@ -1205,6 +1206,32 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
+// log p(theta) only, large aliased sets (SVMPC.forward): the distance pass + log-sum-exp of pairwise_fused.hpp
+static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
+  const int dpb = fused_dpb(a.D);
+  TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
+  {
+    const int n = c->N * dpb;
+    pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
+    HIP_TRY(hipGetLastError());
+  }
+  PairFusedArgs b;
+  memset(&b, 0, sizeof b);
+  b.p = a;
+  b.Xp = c->xpad;
+  b.ldp = 8 * cpt_for(a.D);
+  b.wP[0] = a.inv_s[0] * a.inv_s[0];
+  b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
+  dim3 grid(tiles, a.JS);
+#define DUST_LAUNCH_LOGP(DPB) pairwise_logp_big_kernel<DPB><<<grid, PAIR_NT, pairwise_logp_big_lds_bytes<DPB>(), c->pair_stream>>>(b)
+  if (dpb == 32) DUST_LAUNCH_LOGP(32);
+  else if (dpb == 64) DUST_LAUNCH_LOGP(64);
+  else DUST_LAUNCH_LOGP(80);
+#undef DUST_LAUNCH_LOGP
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
 // pass 2: pA = K x score over the same key slices (matrix cores)
 static int launch_gram_score(dust_ctx *c, const PairArgs &a) {
   const int dpb = fused_dpb(a.D);
@@ -1268,6 +1295,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   int tiles;
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
+  if (logp_only && pair_fused_ok(c)) return launch_pair_logp_big(c, a, tiles);            // large aliased set: distance pass + log-sum-exp
   if (logp_only && !pair_big_kernel(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
   if (!logp_only && pair_fused_ok(c)) return launch_pair_fused(c, a, tiles);              // + repulsion + Gram matrix (pairwise_fused.hpp)
   return launch_pair<PAIR_PRIOR>(c, a, tiles);
