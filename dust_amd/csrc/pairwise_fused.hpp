@@ -55,6 +55,8 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   using G = FusedGeom<DPB>;
   constexpr int JC = PAIR_JC, NT = PAIR_NT, TQ = G::TQ, YS = G::YS, KS = G::KS, CB = G::CB, LCG = G::LCG, NV = CB / 4;
   constexpr int QW = TQ / 4;                                  // queries per wave in pass A
+  constexpr int QS = TQ / 4;  // pass-B ownership: lane group qg holds queries qg + QS r (r < 4): with the odd row stride KS the
+                              // per-key weight reads of a wave then fall into TQ / 4 different banks (rows 4 qg + r collide 3-way)
   constexpr int LQ = NT / TQ >= 8 ? 8 : (NT / TQ >= 4 ? 4 : 2);  // lanes per query in the softmax step
   static_assert(MODE == PAIR_K1 || MODE == PAIR_IMQ, "Stein kernel family");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   const int ib = a.i0 + tile * TQ;  // first query (global index)
   const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), jA = tid & 63;
-  const int qg = tid / LCG, cg = tid - qg * LCG, c0 = CB * cg;  // pass-B ownership: queries 4 qg .. 4 qg + 3, columns c0 .. c0 + CB - 1
+  const int qg = tid / LCG, cg = tid - qg * LCG, c0 = CB * cg;  // pass-B ownership: queries qg + QS r, columns c0 .. c0 + CB - 1
   const bool pb = qg < TQ / 4;                                  // (DPB = 80: 240 of the 256 lanes)
   const int qgc = pb ? qg : 0;
 
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   float accL[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int gi = min(ib + 4 * qgc + r, N - 1);
+    const int gi = min(ib + qgc + QS * r, N - 1);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       xB[r][u] = -*reinterpret_cast<const v4f *>(b.Xp + (size_t)gi * DPB + c0 + 4 * u);  // NEGATED: y + (-x) is one v_pk_add_f32 per pair of columns
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float sc = scl[4 * qgc + r];
+        const float sc = scl[qgc + QS * r];
 #pragma unroll
         for (int u = 0; u < NV; ++u) accA[r][u] *= sc;
         accL[r] *= sc;
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
         for (int u = 0; u < NV; ++u) yv[u] = *reinterpret_cast<const v4f *>(&Ys[jj * YS + c0 + 4 * u]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float wp = kvP[(4 * qg + r) * KS + jj];
-          const float ks = kvS[(4 * qg + r) * KS + jj];
+          const float wp = kvP[(qg + QS * r) * KS + jj];
+          const float ks = kvS[(qg + QS * r) * KS + jj];
           // -k' of stein.hpp's pass B: accB += k' (x_i - y_j) = (-k') (y_j - x_i), the same product bit for bit
           const float nk = (MODE == PAIR_K1) ? ks : (ks * ks) * ks;
 #pragma unroll
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   if (pb) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int il = tile * TQ + 4 * qg + r;
+      const int il = tile * TQ + qg + QS * r;
       if (il >= a.n_local) continue;
       const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
 #pragma unroll
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
           *reinterpret_cast<v4f *>(b.pB + row + c0 + 4 * u) = accB[r][u];
         }
       if (cg == 0) {
-        a.pM[(size_t)js * a.n_local + il] = mrow[4 * qg + r];
+        a.pM[(size_t)js * a.n_local + il] = mrow[qg + QS * r];
         a.pL[(size_t)js * a.n_local + il] = accL[r];
       }
     }
