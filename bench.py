@@ -302,6 +302,22 @@ def main():
         par = "particles sharded x%d (strong scaling), in-place RCCL all-gathers of score and theta per SVGD iteration" % n_gpus
         value = args.steps / el
         unit = "control steps/s (joint N=16384 problem)"
+        # the SAME joint problem on ONE GPU (unsharded context, rank 0, outside the timed region; the other ranks wait): the figure a
+        # strong-scaling efficiency of this line has to be computed against - `python bench.py --gpus 1` runs cfg2, not this
+        if rank == 0 and n_gpus > 1:
+            one = Context(**dict(common))
+            one.set_theta(theta); one.set_prior(mu); one.set_a_mat(theta)
+            for _ in range(3):
+                one.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
+            one.sync()
+            t1 = time.perf_counter()
+            n1 = 10
+            for _ in range(n1):
+                one.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
+            one.sync()
+            extra["one_gpu_same_workload_ticks_per_s"] = n1 / (time.perf_counter() - t1)
+            one.close()
+        dist.barrier()
         if args.weak:
             n_tot = w["N"] * n_gpus
             mu2, th2 = synth(n_tot, w["H"], 1)
