@@ -304,7 +304,7 @@ def main():
         unit = "control steps/s (joint N=16384 problem)"
         # the SAME joint problem on ONE GPU (unsharded context, rank 0, outside the timed region; the other ranks wait): the figure a
         # strong-scaling efficiency of this line has to be computed against - `python bench.py --gpus 1` runs cfg2, not this
-        if rank == 0 and n_gpus > 1:
+        if rank == 0 and (n_gpus > 1 or os.environ.get("DUST_BENCH_FORCE_DIST")):
             one = Context(**dict(common))
             one.set_theta(theta); one.set_prior(mu); one.set_a_mat(theta)
             for _ in range(3):
