@@ -761,7 +761,8 @@ def test_cfg5_shaped_dual_loop_vs_oracle():
 
 
 @pytest.mark.parametrize("model,N,H,kernel", [("particle", 2048, 40, "K1"), ("pendulum", 2304, 30, "K1"), ("particle", 2100, 20, "K1"),
-                                              ("particle", 2048, 40, "IMQ"), ("pendulum", 2048, 17, "IMQ")])
+                                              ("particle", 2048, 40, "IMQ"), ("pendulum", 2048, 17, "IMQ"),
+                                              ("particle", 16384, 40, "K1")])  # the cfg4 shape itself: N = 16384, D = 80
 def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
     """Prior means aliasing theta + N >= 2048: ONE distance pass serves the prior score, the Stein repulsion and the Gram matrix,
     then Gram x score runs as a GEMM (pairwise_fused.hpp) - D = 80 / 30 / 40 / 17 (tile widths 80 / 32 / 64 / 32), ragged N,
