@@ -379,7 +379,8 @@ class Context:
 
 class MpfContext:
     def __init__(self, init_particles, initial_obs, model="pendulum", uncertain_params=("length", "mass"), log_space=False,
-                 obs_std=0.1, lr=1e-3, bw_scale=1.0, init_bw=0.1, device=0, grid=None, _handle=None, **model_kw):
+                 obs_std=0.1, lr=1e-3, bw_scale=1.0, init_bw=0.1, device=0, grid=None, _handle=None, optimizer="SGD", betas=(0.9, 0.999),
+                 eps=1e-8, **model_kw):
         lib = L.load()
         x = _f(init_particles)
         self.Mp, self.P = x.shape
@@ -398,6 +399,10 @@ class MpfContext:
         if grid is not None:
             g = _f(grid)
             L.check(lib.dust_mpf_set_grid(self._h, _p(g), g.shape[0], g.shape[1], float(int(g.shape[0] / 2)), float(int(g.shape[1] / 2))))
+        if optimizer not in ("SGD", "Adam"):
+            raise NotImplementedError("MPF optimiser %r: the device filter implements SGD and Adam" % (optimizer,))
+        if optimizer == "Adam":  # the reference's class default (svgd.py:115); its state persists across optimize() calls
+            L.check(lib.dust_mpf_set_optimizer(self._h, L.OPT_ADAM, float(betas[0]), float(betas[1]), float(eps)))
 
     def close(self):
         if getattr(self, "_h", None) is not None:

@@ -24,6 +24,11 @@ struct MpfArgs {
   float *x;           // [Mp][P] in/out
   float *grad_norms;  // [n_steps] or nullptr
   float *phi_out;     // [Mp][P] or nullptr (phi of the first step, when n_steps == 0 semantics are wanted use n_steps=1, lr=0)
+  // optimiser (SVGD.__init__ svgd.py:115: the class default is torch.optim.Adam; built once in MPF.__init__ mpf.py:24, so its
+  // state persists across optimize() calls): DUST_OPT_SGD, or DUST_OPT_ADAM with moments [Mp][P] in / out and t0 steps taken so far
+  int optimizer, t0;
+  float beta1, beta2, eps;
+  float *adam_m, *adam_v;
 };
 
 // d(next state)/d(params) of one model step, as autograd returns it through model.step (incl. clamp masks).
@@ -114,6 +119,13 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
   const float bw2 = (float)((double)a.bw * (double)a.bw);
   const double inv_pbw = 1.0 / (double)a.prior_bw, inv_pbw2 = inv_pbw * inv_pbw;
   const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw), inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
+  float am[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};  // Adam moments of this lane's particle (registers for the whole launch)
+  const bool adam = a.optimizer == DUST_OPT_ADAM;
+  if (adam && on && r == 0)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      am[p] = a.adam_m[i * P + p];
+      av[p] = a.adam_v[i * P + p];
+    }
   for (int it = 0; it < a.n_steps; ++it) {
     float xi[4] = {0.f, 0.f, 0.f, 0.f};
     if (on) {
@@ -206,12 +218,24 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
     if (threadIdx.x == 0 && a.grad_norms) a.grad_norms[it] = sqrtf(n2);
     if (on && r == 0 && it == 0 && a.phi_out)
       _Pragma("unroll") for (int p = 0; p < P; ++p) a.phi_out[i * P + p] = ph[p];
-    if (on && r == 0)
-      _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = fmaf(a.lr, ph[p], xi[p]);
+    if (on && r == 0) {
+      if (adam) {  // x.grad = -phi; optimizer.step() (mpf.py:59-62), the single-tensor Adam of stein.hpp adam_step
+        _Pragma("unroll") for (int p = 0; p < P; ++p)
+            xs[i * P + p] = adam_step(xi[p], -ph[p], am[p], av[p], a.lr, a.beta1, a.beta2, a.eps, (float)(a.t0 + it + 1));
+      } else {
+        _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = fmaf(a.lr, ph[p], xi[p]);
+      }
+    }
     __syncthreads();
   }
-  if (on && r == 0)
+  if (on && r == 0) {
     _Pragma("unroll") for (int p = 0; p < P; ++p) a.x[i * P + p] = xs[i * P + p];
+    if (adam)
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        a.adam_m[i * P + p] = am[p];
+        a.adam_v[i * P + p] = av[p];
+      }
+  }
 }
 
 __global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, int K, int P, float bw, float *out) {
@@ -258,6 +282,9 @@ struct dust_mpf {
   hipStream_t stream;
   float *x, *gn, *phi, *tmp;
   size_t tmp_cap;
+  int optimizer, adam_t;       // dust_mpf_set_optimizer; steps taken so far
+  float beta1, beta2, adam_eps;
+  float *adam_m, *adam_v;      // [Mp][P] or nullptr (SGD)
   uint32_t *grid_bits;
   int nx, ny;
   float off_x, off_y;
@@ -284,7 +311,7 @@ extern "C" void dust_mpf_destroy(dust_mpf *m) {
   if (!m) return;
   (void)hipSetDevice(m->cfg.device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  float *fp[] = {m->x, m->gn, m->phi, m->tmp};
+  float *fp[] = {m->x, m->gn, m->phi, m->tmp, m->adam_m, m->adam_v};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (m->grid_bits) (void)hipFree(m->grid_bits);
@@ -344,6 +371,26 @@ extern "C" int dust_mpf_set_grid(dust_mpf *m, const float *grid, int nx, int ny,
   return DUST_OK;
 }
 
+// MPF(optimizer_class=..., **opt_args) (svgd.py:108-122): SGD (the demos' choice) or Adam (the class default).  (Re)starts the state.
+extern "C" int dust_mpf_set_optimizer(dust_mpf *m, int optimizer, float beta1, float beta2, float eps) {
+  if (!m) return fail(DUST_ERR_INVALID, "null mpf");
+  if (optimizer != DUST_OPT_SGD && optimizer != DUST_OPT_ADAM) return fail(DUST_ERR_UNSUPPORTED, "MPF optimiser: SGD or Adam");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  m->optimizer = optimizer;
+  m->adam_t = 0;
+  m->beta1 = beta1;
+  m->beta2 = beta2;
+  m->adam_eps = eps;
+  if (optimizer == DUST_OPT_ADAM) {
+    const size_t n = (size_t)m->Mp * m->P;
+    if (!m->adam_m) TRY(dalloc(&m->adam_m, n));
+    if (!m->adam_v) TRY(dalloc(&m->adam_v, n));
+    HIP_TRY(hipMemsetAsync(m->adam_m, 0, n * sizeof(float), m->stream));
+    HIP_TRY(hipMemsetAsync(m->adam_v, 0, n * sizeof(float), m->stream));
+  }
+  return DUST_OK;
+}
+
 extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   if (!src || !out) return fail(DUST_ERR_INVALID, "null argument");
   std::vector<float> x((size_t)src->Mp * src->P);
@@ -356,6 +403,13 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   memcpy(m->past_obs, src->past_obs, sizeof m->past_obs);
   memcpy(m->past_action, src->past_action, sizeof m->past_action);
   m->have_past = src->have_past;
+  if (src->optimizer == DUST_OPT_ADAM) {
+    TRY(dust_mpf_set_optimizer(m, DUST_OPT_ADAM, src->beta1, src->beta2, src->adam_eps));
+    const size_t nb = (size_t)src->Mp * src->P * sizeof(float);
+    HIP_TRY(hipMemcpy(m->adam_m, src->adam_m, nb, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(m->adam_v, src->adam_v, nb, hipMemcpyDeviceToDevice));
+    m->adam_t = src->adam_t;
+  }
   if (src->grid_bits) {
     const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
     TRY(dalloc(&m->grid_bits, words));
@@ -368,7 +422,7 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   return DUST_OK;
 }
 
-static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev) {
+static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true) {
   if (m->cfg.model_cfg.model == DUST_MODEL_PARTICLE && m->cfg.model_cfg.with_obstacle && m->cfg.model_cfg.can_crash && !m->grid_bits)
     return fail(DUST_ERR_STATE, "Particle model with obstacles: call dust_mpf_set_grid first");
   MpfArgs a;
@@ -393,6 +447,13 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.x = m->x;
   a.grad_norms = gn_dev;
   a.phi_out = phi_dev;
+  a.optimizer = (optimise && m->optimizer == DUST_OPT_ADAM) ? DUST_OPT_ADAM : DUST_OPT_SGD;  // (the bare phi evaluation takes no step)
+  a.t0 = m->adam_t;
+  a.beta1 = m->beta1;
+  a.beta2 = m->beta2;
+  a.eps = m->adam_eps;
+  a.adam_m = m->adam_m;
+  a.adam_v = m->adam_v;
   const int mpad = ((m->Mp + 63) / 64) * 64;
   int R = 1;
   while (mpad * R * 2 <= 1024) R *= 2;
@@ -425,6 +486,7 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
   }
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr));
+  if (m->optimizer == DUST_OPT_ADAM) m->adam_t += n_steps;
   m->prior_bw = bw;  // update_prior(bw) mpf.py:85
   if (grad_norms && n_steps > 0) {
     HIP_TRY(hipMemcpyAsync(grad_norms, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -437,7 +499,7 @@ extern "C" int dust_mpf_phi(dust_mpf *m, float bw, float *phi) {
   if (!m || !phi) return fail(DUST_ERR_INVALID, "null argument");
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   HIP_TRY(hipSetDevice(m->cfg.device));
-  TRY(mpf_launch(m, bw, 0.0f, 1, nullptr, m->phi));  // lr = 0: particles unchanged
+  TRY(mpf_launch(m, bw, 0.0f, 1, nullptr, m->phi, false));  // lr = 0, SGD form: particles and optimiser state unchanged
   HIP_TRY(hipMemcpyAsync(phi, m->phi, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return DUST_OK;

@@ -48,11 +48,21 @@ class _DevicePrior:
 
 
 class MPF:
-    def __init__(self, init_particles, likelihood, bw=None, bw_scale=1.0, optimizer_class=torch.optim.SGD, n_steps=100, **opt_args):
+    def __init__(self, init_particles, likelihood, bw=None, bw_scale=1.0, optimizer_class=torch.optim.Adam, n_steps=100, **opt_args):
+        """optimizer_class: torch.optim.Adam (the reference's class default, svgd.py:115) or torch.optim.SGD (what the demos pass);
+        as in the reference the optimiser is built once, so Adam's moments persist across optimize() calls (mpf.py:24)."""
         init_particles = torch.as_tensor(init_particles, dtype=torch.float)
         assert init_particles.ndim == 2, "Particles must be two dimension with batch on dim 0."
-        if optimizer_class is not torch.optim.SGD:
-            raise NotImplementedError("MPF on the device uses SGD (the demos' choice)")
+        if optimizer_class is torch.optim.SGD:
+            opt_kw, allowed = dict(optimizer="SGD"), {"lr"}
+        elif optimizer_class is torch.optim.Adam:
+            opt_kw = dict(optimizer="Adam", betas=tuple(opt_args.get("betas", (0.9, 0.999))), eps=float(opt_args.get("eps", 1e-8)))
+            allowed = {"lr", "betas", "eps"}
+        else:
+            raise NotImplementedError("MPF on the device implements torch.optim.SGD and torch.optim.Adam, not %r" % (optimizer_class,))
+        extra = set(opt_args) - allowed
+        if extra:
+            raise NotImplementedError("optimiser options %s are not implemented on the device" % sorted(extra))
         self.likelihood, self.bw_scale = likelihood, bw_scale
         if bw is None:
             b = bw_silverman(init_particles.flatten(1, -1), bw_scale)
@@ -70,6 +80,7 @@ class MPF:
             kw.update(max_speed=float(model._max_speed), max_accel=float(model._max_acc), can_crash=bool(model.can_crash),
                       with_obstacle=bool(model.with_obstacle), cell_size=float(model.map_cell_size or 0.1))
             grid = model.obst_map.map.astype(np.float32) if model.obst_map is not None else None
+        kw.update(opt_kw)
         self._dev = MpfContext(init_particles.numpy(), likelihood.loc.numpy(), grid=grid, **kw)
         self.prior = _DevicePrior(self)
 

@@ -254,6 +254,10 @@ typedef struct dust_mpf_config {
 } dust_mpf_config;
 int dust_mpf_create(const dust_mpf_config *cfg, const float *init_particles, const float *initial_obs, dust_mpf **out);
 int dust_mpf_clone(const dust_mpf *src, dust_mpf **out);
+/* MPF(optimizer_class=, **opt_args) svgd.py:108-122, mpf.py:24: DUST_OPT_SGD (default here, the demos' choice) or DUST_OPT_ADAM (the
+ * reference's class default; betas / eps as torch.optim.Adam).  The optimiser state starts at zero and persists across
+ * dust_mpf_optimize calls, as the reference's does (the optimiser is built once in MPF.__init__). */
+int dust_mpf_set_optimizer(dust_mpf *mpf, int optimizer, float beta1, float beta2, float eps);
 void dust_mpf_destroy(dust_mpf *mpf);
 /* MPF.optimize(action, new_obs, bw, n_steps) mpf.py:64-86 -> grad_norms [n_steps] */
 int dust_mpf_optimize(dust_mpf *mpf, const float *action, const float *new_obs, float bw, int n_steps, float *grad_norms);

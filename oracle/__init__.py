@@ -304,6 +304,19 @@ class Oracle:
                                C.c_float(obs_std), C.c_int(int(log_space)), C.c_float(bw), C.c_float(lr), C.c_int(n_steps), _p(gn))
         return x, pm, pbw.value, gn
 
+    def mpf_optimize_adam(self, x, prior_means, prior_bw, past_obs, past_action, obs, obs_std, log_space, bw, lr, n_steps, m=None, v=None,
+                          step=0, betas=(0.9, 0.999), eps=1e-8):
+        """MPF.optimize with the class-default Adam optimiser; (m, v, step) carry the optimiser state between calls."""
+        x, pm, po, pa, ob = _f(x).copy(), _f(prior_means).copy(), _f(past_obs), _f(past_action).reshape(-1), _f(obs)
+        m = np.zeros_like(x) if m is None else _f(m).copy()
+        v = np.zeros_like(x) if v is None else _f(v).copy()
+        gn = np.empty(n_steps, np.float32)
+        pbw, st = C.c_float(prior_bw), C.c_int(int(step))
+        lib().orc_mpf_optimize_adam(C.byref(self.c), C.c_int(x.shape[0]), _p(x), _p(pm), C.byref(pbw), _p(po), _p(pa), _p(ob),
+                                    C.c_float(obs_std), C.c_int(int(log_space)), C.c_float(bw), C.c_float(lr), C.c_float(betas[0]),
+                                    C.c_float(betas[1]), C.c_float(eps), _p(m), _p(v), C.byref(st), C.c_int(n_steps), _p(gn))
+        return x, pm, pbw.value, gn, m, v, st.value
+
     @staticmethod
     def gmm_log_prob(x, means, bw):
         x, means = _f(x), _f(means)

@@ -766,6 +766,26 @@ void orc_mpf_optimize(const orc_cfg *c, int Mp, float *x, float *prior_means, fl
   free(phi);
 }
 
+/* MPF with the class-default optimiser (SVGD.__init__ svgd.py:115: optim.Adam; built ONCE in MPF.__init__ mpf.py:24, so exp_avg /
+ * exp_avg_sq / step persist across optimize() calls): m, v [Mp][P] and *step (steps taken so far) are in/out. */
+void orc_mpf_optimize_adam(const orc_cfg *c, int Mp, float *x, float *prior_means, float *prior_bw, const float *past_obs,
+                           const float *past_action, const float *obs, float obs_std, int log_space, float bw, float lr, float beta1,
+                           float beta2, float eps, float *m, float *v, int *step, int n_steps, float *grad_norms) {
+  const int P = c->P;
+  float *phi = (float *)malloc(sizeof(float) * (size_t)Mp * P);
+  for (int it = 0; it < n_steps; ++it) {
+    orc_mpf_phi(c, Mp, x, x, *prior_bw, past_obs, past_action, obs, obs_std, log_space, bw, phi);
+    double nn = 0.0;
+    for (int i = 0; i < Mp * P; ++i) nn += (double)phi[i] * (double)phi[i];
+    if (grad_norms) grad_norms[it] = (float)sqrt(nn);
+    *step += 1;
+    orc_adam(Mp * P, lr, beta1, beta2, eps, *step, phi, x, m, v);
+  }
+  memcpy(prior_means, x, sizeof(float) * (size_t)Mp * P);
+  *prior_bw = bw;
+  free(phi);
+}
+
 /* ------------------------------------------------------------------ whole tick (cpu_baseline timing only) */
 void orc_tick_k1(const orc_cfg *c, const float *state, float *theta, float *mu, float *mix_weights, const float *sigma_p,
                  const float *sigma_a, const float *eps, int n_iters, float alpha, float lr, float *a_mat, float *a_seq_out,

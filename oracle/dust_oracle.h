@@ -119,6 +119,9 @@ void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_me
 void orc_mpf_optimize(const orc_cfg *c, int Mp, float *x, float *prior_means, float *prior_bw, const float *past_obs,
                       const float *past_action, const float *obs, float obs_std, int log_space, float bw, float lr,
                       int n_steps, float *grad_norms);
+void orc_mpf_optimize_adam(const orc_cfg *c, int Mp, float *x, float *prior_means, float *prior_bw, const float *past_obs,
+                           const float *past_action, const float *obs, float obs_std, int log_space, float bw, float lr, float beta1,
+                           float beta2, float eps, float *m, float *v, int *step, int n_steps, float *grad_norms);
 void orc_gmm_log_prob(int n, int K, int P, const float *x, const float *means, float bw, float *out);
 
 /* occupancy lookup obstacle_map.py:64-93 */

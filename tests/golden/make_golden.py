@@ -348,7 +348,7 @@ def run_disco(tag, seed=3):
 
 
 # ---------------------------------------------------------------- MPF scenarios
-def run_mpf(tag, model_kind, Mp, n_steps, log_space, bw, seed=5):
+def run_mpf(tag, model_kind, Mp, n_steps, log_space, bw, seed=5, optimizer="SGD", lr_override=None):
     torch.manual_seed(seed)
     if model_kind == "pendulum":
         model = PendulumModel(uncertain_params=("length", "mass"))
@@ -368,10 +368,16 @@ def run_mpf(tag, model_kind, Mp, n_steps, log_space, bw, seed=5):
         obs1 = true_model.step(obs0, action)
     if log_space:
         x0 = x0.clamp(min=1e-6).log()
+    if lr_override is not None:
+        lr = lr_override
     lik = GaussianLikelihood(initial_obs=obs0, obs_std=0.1, model=model, log_space=log_space)
-    mpf = MPF(init_particles=x0.clone(), likelihood=lik, optimizer_class=torch.optim.SGD, lr=lr, bw=bw, bw_scale=1.0)
+    if optimizer == "Adam":  # the class default of SVGD (svgd.py:115): state persists across optimize() calls (mpf.py:24)
+        mpf = MPF(init_particles=x0.clone(), likelihood=lik, lr=lr, bw=bw, bw_scale=1.0)
+        assert isinstance(mpf.optimizer, torch.optim.Adam)
+    else:
+        mpf = MPF(init_particles=x0.clone(), likelihood=lik, optimizer_class=torch.optim.SGD, lr=lr, bw=bw, bw_scale=1.0)
     g = dict(Mp=Mp, P=x0.shape[1], n_steps=n_steps, log_space=int(log_space), bw=bw, lr=lr, obs_std=0.1,
-             x0=npf(x0), obs0=npf(obs0), obs1=npf(obs1), action=npf(action).reshape(-1), model_kind=model_kind)
+             x0=npf(x0), obs0=npf(obs0), obs1=npf(obs1), action=npf(action).reshape(-1), model_kind=model_kind, optimizer=optimizer)
     # one bare phi evaluation (mpf.py:40) on the conditioned likelihood
     lik.condition(action, obs1)
     g["phi0"] = npf(mpf.phi(bw))

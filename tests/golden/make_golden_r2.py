@@ -9,7 +9,9 @@
   * pend_k1_f64 / pend_k1_mid_f64: the K1 kernel branch (svmpc.py:76-83; gpytorch RBFKernel semantics - third party, absent) ALSO
     evaluated in float64 on the recorded fp32 inputs (theta, score): the fp32 stand-in carries cancellation noise of its
     matmul-trick distance, the float64 run does not, so oracle and HIP can be held to 1e-5 against it.
-Same recording machinery as make_golden.py (run_svmpc); nothing here re-implements the reference's arithmetic.
+  * mpf_pend_adam / mpf_part_log_adam: MPF with the class-default optimiser (Adam; its state persists across optimize() calls:
+    the optimiser is built once in MPF.__init__, mpf.py:24): two filter updates each.
+Same recording machinery as make_golden.py (run_svmpc, run_mpf); nothing here re-implements the reference's arithmetic.
 """
 import os
 import sys
@@ -26,3 +28,5 @@ if __name__ == "__main__":
                  k1_f64=True, lr_override=0.02)  # (small step: the particles stay within a few lengthscales of each other)
     mg.run_svmpc("pend_k1_mid_f64", "pendulum", N=24, H=12, S=8, M=1, kernel_kind="K1", n_iters=2, n_ticks=1, seed=23, theta_shrink=0.12,
                  k1_f64=True, lr_override=0.02)
+    mg.run_mpf("mpf_pend_adam", "pendulum", Mp=10, n_steps=6, log_space=False, bw=0.08, optimizer="Adam", lr_override=0.01)
+    mg.run_mpf("mpf_part_log_adam", "particle", Mp=12, n_steps=12, log_space=True, bw=0.5, optimizer="Adam", lr_override=0.02)

@@ -266,6 +266,32 @@ def test_mpf(golden, name):
     assert abs(float(smp.mean()) - float(means.mean())) < 0.02 and pbw == pytest.approx(bw)
 
 
+@pytest.mark.parametrize("name", ["mpf_pend_adam", "mpf_part_log_adam"])
+def test_mpf_adam(golden, name):
+    """MPF with the reference's class-default optimiser (torch.optim.Adam): two filter updates from the reference's own run; the
+    moments and the step count persist from the first optimize() to the second (mpf.py:24), a bare phi() and a clone leave / carry
+    them."""
+    from dust_amd import MpfContext
+    from oracle import grid_4x4_map
+
+    g = golden(name)
+    kind = str(g["model_kind"])
+    up = ("length", "mass") if kind == "pendulum" else ("mass",)
+    bw, ls, n = float(g["bw"]), bool(int(g["log_space"])), int(g["n_steps"])
+    m = MpfContext(g["x0"], g["obs0"], model=kind, uncertain_params=up, log_space=ls, obs_std=float(g["obs_std"]), lr=float(g["lr"]),
+                   init_bw=bw, grid=grid_4x4_map() if kind == "particle" else None, mass=2.0 if kind == "particle" else 1.0,
+                   optimizer="Adam")
+    gn = m.optimize(g["action"], g["obs1"], bw, n)
+    assert relerr(m.get_particles(), g["x_final"]) < TOL
+    assert relerr(gn, g["grad_norms"]) < 2e-4
+    m.phi(bw)  # takes no optimiser step
+    mc = m.clone()  # carries the optimiser state
+    for mm in (m, mc):
+        gn2 = mm.optimize(g["action2"], g["obs2"], bw, n)
+        assert relerr(mm.get_particles(), g["x_final2"]) < TOL
+        assert relerr(gn2, g["grad_norms2"]) < 2e-4
+
+
 def test_collisions_and_edges(golden):
     """Occupancy lookups at edge / out-of-bounds points, through a 1-step Particle rollout whose cost isolates the map."""
     from dust_amd import Context
@@ -277,8 +303,6 @@ def test_collisions_and_edges(golden):
     grid = grid_4x4_map()
     # H=1, zero actions: cost = inst(x0) + term(x1); with w_state = w_term = w_ctrl = 0 and w_obs = 1 the cost counts
     # collisions of x0 and x1 = x0 (crashed or zero velocity), i.e. 2 * map[x0]
-    for i in range(0, 64):
-        pass
     o = Oracle(model="particle", N=1, S=1, M=1, H=1, uncertain_params=None, grid=grid, w_state=(0, 0, 0, 0), w_term=(0, 0, 0, 0),
                w_ctrl=(0, 0), w_obs=1.0)
     c = Context(model="particle", N=1, S=1, M=1, H=1, grid=grid, w_state=(0, 0, 0, 0), w_term=(0, 0, 0, 0), w_ctrl=(0, 0), w_obs=1.0,

@@ -211,6 +211,30 @@ def test_mpf(golden, name):
     assert relerr(Oracle.gmm_log_prob(g["probe"], pm2, bw), g["probe_log_prob"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["mpf_pend_adam", "mpf_part_log_adam"])
+def test_mpf_adam(golden, name):
+    """MPF with the reference's class-default optimiser (torch.optim.Adam, svgd.py:115), two filter updates: the optimiser is built
+    once (mpf.py:24), so its moments and step count carry over from the first optimize() to the second."""
+    g = golden(name)
+    assert str(g["optimizer"]) == "Adam"
+    kind = str(g["model_kind"])
+    up = ("length", "mass") if kind == "pendulum" else ("mass",)
+    o = Oracle(model=kind, uncertain_params=up, mass=2.0 if kind == "particle" else 1.0)
+    bw, ls, lr, n = float(g["bw"]), bool(int(g["log_space"])), float(g["lr"]), int(g["n_steps"])
+    x, pm, pbw, gn, m, v, st = o.mpf_optimize_adam(g["x0"], g["x0"], bw, g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), ls, bw, lr, n)
+    assert st == n
+    assert relerr(x, g["x_final"]) < TOL
+    assert relerr(gn, g["grad_norms"]) < 2e-4  # (see test_mpf: the first gradient norms carry the libm-vs-torch exp ulp)
+    x2, pm2, _, gn2, _, _, st2 = o.mpf_optimize_adam(x, pm, pbw, g["obs1"], g["action2"], g["obs2"], float(g["obs_std"]), ls, bw, lr, n,
+                                                    m=m, v=v, step=st)
+    assert st2 == 2 * n
+    assert relerr(x2, g["x_final2"]) < TOL
+    assert relerr(gn2, g["grad_norms2"]) < 2e-4
+    # restarting the optimiser state at the second call (what SVMPC does at every roll) must NOT reproduce the reference here
+    x2r, *_ = o.mpf_optimize_adam(x, pm, pbw, g["obs1"], g["action2"], g["obs2"], float(g["obs_std"]), ls, bw, lr, n)
+    assert relerr(x2r, g["x_final2"]) > 10 * TOL
+
+
 def test_unscented_transform_costs_vs_reference(golden):
     """sigma-point rollouts.  The oracle's restatement (incl. the reference's (sigma, step) weight pattern,
     disco.py:314-316) against MultiDISCO(params_sampling=MerweScaledUTF(n=2, alpha=0.5)).forward of the reference."""
