@@ -256,11 +256,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
                                 fabsf(a.dm.off_x) + fabsf(a.dm.off_y) <
                         1.0e17f;
   const int s = sb * 8 + (lane >> 3);
-#ifdef DUST_SG_NOSTORE
-  const bool live = s < S && a.H < 0;  // development: compute-only timing
-#else
   const bool live = s < S;
-#endif
   const int sc = live ? s : S - 1;
   const uint32_t rowb = 16u * (uint32_t)(H + 1);
   char *gsg = reinterpret_cast<char *>(a.states_out) + ((size_t)sc * N + n_first) * rowb + (lane & 7) * 16;

@@ -1,4 +1,4 @@
-"""Development probe: rollout kernel with stored states at cfg3 size (HBM-bound regime)."""
+"""Rollout kernel at cfg3 size with and without stored states (whole-line form + second pass, binary16 fallback), Pendulum stored form."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
