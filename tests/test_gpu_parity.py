@@ -784,10 +784,14 @@ def test_cfg5_shaped_dual_loop_vs_oracle():
         state = new_obs.astype(np.float32)
 
 
-@pytest.mark.parametrize("model,N,H,kernel", [("particle", 2048, 40, "K1"), ("pendulum", 2304, 30, "K1"), ("particle", 2100, 20, "K1"),
-                                              ("particle", 2048, 40, "IMQ"), ("pendulum", 2048, 17, "IMQ"),
-                                              ("particle", 16384, 40, "K1")])  # the cfg4 shape itself: N = 16384, D = 80
-def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
+@pytest.mark.parametrize("model,N,H,kernel,spread", [
+    ("particle", 2048, 40, "K1", 0.25), ("pendulum", 2304, 30, "K1", 0.25), ("particle", 2100, 20, "K1", 0.25),
+    ("particle", 2048, 40, "IMQ", 0.25), ("pendulum", 2048, 17, "IMQ", 0.25),
+    ("particle", 16384, 40, "K1", 0.25),  # the cfg4 shape itself: N = 16384, D = 80
+    ("particle", 2048, 40, "K1", 1.2),    # far-apart particles: almost every Stein kernel value underflows to 0
+    ("pendulum", 4096, 30, "K1", 2.0),
+    ("particle", 2048, 40, "K1", 0.02)])  # nearly collapsed set: every kernel value ~ 1
+def test_fused_large_pairwise_vs_oracle(model, N, H, kernel, spread):
     """Prior means aliasing theta + N >= 2048: ONE distance pass serves the prior score, the Stein repulsion and the Gram matrix,
     then Gram x score runs as a GEMM (pairwise_fused.hpp) - D = 80 / 30 / 40 / 17 (tile widths 80 / 32 / 64 / 32), ragged N,
     non-uniform mixture weights.  grad_pri and phi against the oracle, and against the two unfused passes (DUST_PAIR_FUSED=0)."""
@@ -797,7 +801,7 @@ def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
     da = 1 if model == "pendulum" else 2
     rng = np.random.default_rng(3 * N + H)
     S = 8
-    theta = (0.25 * rng.standard_normal((N, H, da))).astype(np.float32)  # (close enough for the mixture weights to overlap)
+    theta = (spread * rng.standard_normal((N, H, da))).astype(np.float32)  # (0.25: close enough for the mixture weights to overlap)
     costs = (30.0 * rng.random((S, N))).astype(np.float32)
     actions = (theta[None] + rng.standard_normal((S, N, H, da))).astype(np.float32)
     mixw = rng.random(N).astype(np.float32) + 0.05
@@ -823,10 +827,12 @@ def test_fused_large_pairwise_vs_oracle(model, N, H, kernel):
         finally:
             os.environ.pop("DUST_PAIR_FUSED", None)
     phi, dgl, dgp = got["1"]
-    assert elemerr(dgp, gp) < TOL
+    # sparse cases: the surviving weights are exp(-100) and the like, where the bare v_exp_f32's relative error |x| 2^-24 shows
+    tol_p = TOL if spread < 1.0 else 4e-5
+    assert elemerr(dgp, gp) < tol_p
     assert elemerr(phi, ref) < (k1_tolerance(theta) if kernel == "K1" else TOL)
     phi0, _, dgp0 = got["0"]
-    assert elemerr(dgp, dgp0) < TOL and elemerr(phi, phi0) < TOL
+    assert elemerr(dgp, dgp0) < tol_p and elemerr(phi, phi0) < TOL
 
 
 def test_sharded_large_set_takes_fused_pairwise():
