@@ -784,6 +784,41 @@ def test_cfg5_shaped_dual_loop_vs_oracle():
         state = new_obs.astype(np.float32)
 
 
+def test_cfg5_shaped_sharded_equals_unsharded():
+    """The control half of BASELINE.json configs[4] (Pendulum, IMQ kernel, M = 8 sampled dynamics per iteration, binary16-stored
+    noise) SHARDED over 2 and 4 contexts against the unsharded context: the unsharded tick reads the binary16 noise, the shards the
+    same values widened on the host (storage format only: the steps are identical), all-gathers as slice copies."""
+    from dust_amd import Context
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    N, S, H, M, K, T = 128, 64, 30, 8, 2, 2
+    rng = np.random.default_rng(56)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal((N, H, 1))).astype(np.float32)
+    state = np.array([3.0, 0.0], np.float32)
+    kw = dict(model="pendulum", N=N, S=S, M=M, H=H, kernel="IMQ", imq_ell=1.5, lr=0.5, sigma_a=2.0, sigma_p=2.0,
+              uncertain_params=("length", "mass"), seed=3)
+    eps16 = rng.standard_normal((T, K, S, N, H, 1)).astype(np.float16)
+    params = rng.uniform(0.7, 1.3, (T, K, M, 2)).astype(np.float32)
+    ref = Context(**kw)
+    ref.set_theta(theta); ref.set_prior(mu); ref.set_a_mat(theta)
+    outs = [ref.svmpc_tick(state, K, eps16[t], params[t]) for t in range(T)]
+    rt = ref.get_theta()
+    for world in (2, 4):
+        shards = tuple(DeviceShard(dict(kw), r, world) for r in range(world))
+        for sh in shards:
+            sh.set_state(theta, mu, theta)
+        for t in range(T):
+            a_seq, pw = tick(shards, LocalComm(), state, K, eps16[t].astype(np.float32), params[t], want_outputs=True)
+            assert np.array_equal(a_seq, outs[t][0]), (world, t)
+            assert relerr(pw, outs[t][1]) < 1e-5
+        for sh in shards:
+            sh.sync()
+            assert elemerr(sh.ctx.get_theta(), rt) < 2e-6, (world, sh.rank)
+            sh.ctx.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("model,N,H,kernel,spread", [
     ("particle", 2048, 40, "K1", 0.25), ("pendulum", 2304, 30, "K1", 0.25), ("particle", 2100, 20, "K1", 0.25),
     ("particle", 2048, 40, "IMQ", 0.25), ("pendulum", 2048, 17, "IMQ", 0.25),
