@@ -135,6 +135,7 @@ SYMBOLS = {
     "dust_device_free": (C.c_int, [VP, VP]),
     "dust_mpf_create": (C.c_int, [C.POINTER(MpfConfig), FP, FP, C.POINTER(VP)]),
     "dust_mpf_clone": (C.c_int, [VP, C.POINTER(VP)]),
+    "dust_set_k2_bandwidth": (C.c_int, [VP, C.c_float, C.c_float]),
     "dust_mpf_set_optimizer": (C.c_int, [VP, C.c_int, C.c_float, C.c_float, C.c_float]),
     "dust_mpf_destroy": (None, [VP]),
     "dust_mpf_optimize": (C.c_int, [VP, FP, FP, C.c_float, C.c_int, FP]),

@@ -104,6 +104,7 @@ class Context:
     def __init__(self, cfg=None, grid=None, _handle=None, **kw):
         self._h = None
         lib = L.load()
+        k2_bw, k2_min = kw.pop("k2_bandwidth", None), kw.pop("k2_minimum_bw", 1e-5)
         if _handle is not None:
             self._h = _handle
         else:
@@ -119,6 +120,8 @@ class Context:
         self.D = self.H * self.da
         if grid is not None:
             self.set_grid(grid)
+        if k2_bw is not None and float(k2_bw) >= 0:  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth instead of the median trick
+            L.check(lib.dust_set_k2_bandwidth(self._h, float(k2_bw), float(k2_min)))
 
     # ---- lifecycle
     # ---- C-side multi-GPU tick (include/dust_amd.h dust_comm_*): one RCCL communicator per sharded context

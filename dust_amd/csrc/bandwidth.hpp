@@ -23,6 +23,7 @@ struct K2Args {
   int shared;  // 1: one kernel per timestep (indep_controls=False)
   int i0, n_local;
   float bw_scale;
+  float fixed_h;        // > 0: RBF(bandwidth >= 0) base_kernels.py:66-67 - every kernel uses this h (host-evaluated), no median pass
   const float *theta;   // [N][D]
   const float *thetaT;  // [D][N]
   const float *score;   // [N][D]
@@ -312,10 +313,19 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
   }
 }
 
+__global__ void k2_bandwidth_fixed_kernel(float *h, int G, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G) h[i] = v;
+}
+
 // the two halves of the K2 step: bandwidths (read theta only) and phi (reads the score as well)
 static inline int launch_k2_bandwidth(hipStream_t stream, const K2Args &a) {
   const int G = a.shared ? a.H : a.D;
   if (a.da > 2) return DUST_ERR_UNSUPPORTED;  // models on the path have d_a <= 2
+  if (a.fixed_h > 0.f) {
+    k2_bandwidth_fixed_kernel<<<(G + 255) / 256, 256, 0, stream>>>(a.h, G, a.fixed_h);
+    return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
+  }
   if (a.shared) {
     k2_bandwidth_pairs_kernel<<<G, 1024, (size_t)a.da * a.N * sizeof(float), stream>>>(a);
   } else {

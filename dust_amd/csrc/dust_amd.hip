@@ -133,6 +133,7 @@ struct dust_ctx {
   bool capturing;
   bool have_sample, actions_valid;
   bool k2_bw_ahead;   // K2: transpose + bandwidths of the current theta are already in flight on the side stream
+  float k2_fixed_h;   // > 0: fixed-bandwidth RBF (dust_set_k2_bandwidth), else the median trick
   bool noise_f16;     // the eps / actions handed to the current call are binary16 (DUST_EPS_F16), set by the API entry points
   bool actions_f16;   // the kept actions were stored as binary16
   int graph_flags;
@@ -589,6 +590,27 @@ extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
   }
   return DUST_OK;
 }
+// RBF(bandwidth=, minimum_bw=) base_kernels.py:44-92 for the K2 kernels: bandwidth < 0 = the median trick (default); otherwise
+// h = clip(bw_scale * bandwidth^2 / log(N + 1), minimum_bw), evaluated here in double as the reference's Python floats are,
+// then used as an fp32 scalar by the tensor ops (K = exp(-d2 / h), dK = K (x - y) 2 / h).
+extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum_bw) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->cfg.kernel != DUST_KERNEL_K2_IIDMP && c->cfg.kernel != DUST_KERNEL_K2_SHARED)
+    return fail(DUST_ERR_STATE, "dust_set_k2_bandwidth: the context's kernel is not iid_mp(RBF)");
+  if (bandwidth < 0.f) {
+    c->k2_fixed_h = 0.f;
+    return DUST_OK;
+  }
+  double h = (double)bandwidth * (double)bandwidth;
+  h = h / log((double)c->N + 1.0);
+  h = (double)c->cfg.bw_scale * h;
+  if (h < (double)minimum_bw) h = (double)minimum_bw;
+  c->k2_fixed_h = (float)h;
+  if (!(c->k2_fixed_h > 0.f)) return fail(DUST_ERR_INVALID, "bandwidth and minimum_bw give h = 0");
+  if (c->graph_exec) graph_drop(c);
+  return DUST_OK;
+}
+
 extern "C" int dust_get_theta(dust_ctx *c, float *theta) {
   if (!c || !theta) return fail(DUST_ERR_INVALID, "null argument");
   return d2h(c, theta, c->theta, (size_t)c->N * c->D * sizeof(float));
@@ -1435,6 +1457,7 @@ static K2Args k2_args(dust_ctx *c) {
   k.i0 = c->n0;
   k.n_local = c->nloc;
   k.bw_scale = c->cfg.bw_scale;
+  k.fixed_h = c->k2_fixed_h;
   k.theta = c->theta;
   k.thetaT = c->thetaT;
   k.score = c->score;

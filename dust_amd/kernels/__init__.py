@@ -5,8 +5,6 @@ csrc/stein.hpp and csrc/bandwidth.hpp."""
 
 class RBF:
     def __init__(self, bandwidth=-1, bw_scale=1.0, analytic_grad=True, minimum_bw=1e-5, **kwargs):
-        if bandwidth >= 0:
-            raise NotImplementedError("fixed-bandwidth RBF is not wired; the reference's demos use the median trick (bandwidth=-1)")
         self.ell, self.ell_scale, self.analytic_grad, self.minimum_bw = bandwidth, bw_scale, analytic_grad, minimum_bw
 
 
@@ -31,7 +29,10 @@ def kernel_config(kernel):
     if kernel is None or isinstance(kernel, RBFKernel) or type(kernel).__name__ == "RBFKernel":
         return dict(kernel="K1")
     if isinstance(kernel, iid_mp):
-        return dict(kernel="K2" if kernel.indep_controls else "K2shared", bw_scale=kernel.base_kernel.ell_scale)
+        if kernel.base_kernel.ell < 0 and kernel.base_kernel.minimum_bw != 1e-5:
+            raise NotImplementedError("RBF(minimum_bw != 1e-5) with the median trick is not implemented on the device")
+        return dict(kernel="K2" if kernel.indep_controls else "K2shared", bw_scale=kernel.base_kernel.ell_scale,
+                    k2_bandwidth=kernel.base_kernel.ell, k2_minimum_bw=kernel.base_kernel.minimum_bw)
     if isinstance(kernel, IMQ):
         return dict(kernel="IMQ", imq_ell=kernel.ell)
     if isinstance(kernel, RBF):

@@ -224,14 +224,14 @@ class Oracle:
         lib().orc_phi_imq(C.c_int(N), C.c_int(theta.size // N), _p(theta), _p(score), C.c_float(ell), _p(phi))
         return phi
 
-    def phi_k2(self, theta, score, indep=True, bw_scale=1.0):
+    def phi_k2(self, theta, score, indep=True, bw_scale=1.0, bandwidth=-1.0, minimum_bw=1e-5):
         c = self.c
         theta, score = _f(theta), _f(score)
         N = theta.shape[0]
         phi = np.empty_like(theta)
         h = np.empty(self.D if indep else c.H, np.float32)
-        lib().orc_phi_k2(C.c_int(N), C.c_int(c.H), C.c_int(c.da), C.c_int(int(indep)), C.c_float(bw_scale), _p(theta), _p(score),
-                         _p(phi), _p(h))
+        lib().orc_phi_k2(C.c_int(N), C.c_int(c.H), C.c_int(c.da), C.c_int(int(indep)), C.c_float(bw_scale), C.c_float(bandwidth),
+                         C.c_float(minimum_bw), _p(theta), _p(score), _p(phi), _p(h))
         return phi, h
 
     @staticmethod

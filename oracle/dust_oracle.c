@@ -452,8 +452,8 @@ static int cmp_float(const void *a, const void *b) {
 }
 
 /* svmpc.py:64-74 -> composite_kernels.py:33-64 -> base_kernels.py:53-108 */
-void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, const float *theta, const float *score, float *phi,
-                float *h_out) {
+void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, float fixed_bw, float min_bw, const float *theta,
+                const float *score, float *phi, float *h_out) {
   const int D = H * da;
   const int G = indep ? D : H;      /* number of independent kernels */
   const int gd = indep ? 1 : da;    /* dims per kernel */
@@ -475,10 +475,19 @@ void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, const float *th
       }
     memcpy(srt, pw, sizeof(float) * (size_t)N * N);
     qsort(srt, (size_t)N * N, sizeof(float), cmp_float);
-    float h = srt[((size_t)N * N - 1) / 2]; /* torch.median: lower middle */
-    h = h / (float)log((double)N + 1.0);
-    h = bw_scale * h;
-    if (h < 1e-5f) h = 1e-5f;
+    float h;
+    if (fixed_bw < 0.f) {
+      h = srt[((size_t)N * N - 1) / 2]; /* torch.median: lower middle */
+      h = h / (float)log((double)N + 1.0);
+      h = bw_scale * h;
+      if (h < min_bw) h = min_bw;
+    } else { /* RBF(bandwidth >= 0) base_kernels.py:66-67: Python floats (double) until the tensor ops use h as an fp32 scalar */
+      double hd = (double)fixed_bw * (double)fixed_bw;
+      hd = hd / log((double)N + 1.0);
+      hd = (double)bw_scale * hd;
+      if (hd < (double)min_bw) hd = (double)min_bw;
+      h = (float)hd;
+    }
     if (h_out) h_out[gI] = h;
     for (int i = 0; i < N; ++i)
       for (int q = 0; q < gd; ++q) {

@@ -91,7 +91,8 @@ void orc_phi_k1(int N, int D, const float *theta, const float *score, int varian
 void orc_phi_imq(int N, int D, const float *theta, const float *score, float ell, float *phi);
 
 /* a11 kernel branch K2 svmpc.py:64-74 -> composite_kernels.py:33-64 -> base_kernels.py:53-108 */
-void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, const float *theta, const float *score, float *phi,
+void orc_phi_k2(int N, int H, int da, int indep, float bw_scale, float fixed_bw /* < 0: median trick */, float min_bw,
+                const float *theta, const float *score, float *phi,
                 float *h_out);
 
 /* a8 SGD step svmpc.py:87-95 */

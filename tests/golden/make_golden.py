@@ -136,6 +136,7 @@ def run_svmpc(
     S,
     M,
     kernel_kind="K1",
+    k2_bandwidth=-1,
     lik_kind="ExponentiatedUtility",
     weighted_prior=False,
     roll_strategy="repeat",
@@ -206,9 +207,9 @@ def run_svmpc(
     if kernel_kind == "K1":
         kernel = ref_shim.RBFKernel()
     elif kernel_kind == "K2":
-        kernel = iid_mp(base_kernel=RBF(bandwidth=-1), ctrl_dim=da, indep_controls=True)
+        kernel = iid_mp(base_kernel=RBF(bandwidth=k2_bandwidth), ctrl_dim=da, indep_controls=True)
     elif kernel_kind == "K2shared":
-        kernel = iid_mp(base_kernel=RBF(bandwidth=-1), ctrl_dim=da, indep_controls=False)
+        kernel = iid_mp(base_kernel=RBF(bandwidth=k2_bandwidth), ctrl_dim=da, indep_controls=False)
     else:
         raise ValueError(kernel_kind)
     lik_cls = ExponentiatedUtility if lik_kind == "ExponentiatedUtility" else ExpectedCost
@@ -306,6 +307,7 @@ def run_svmpc(
     for k, v in tick.items():
         g["tick_" + k] = np.stack(v)
     g["kernel_kind"] = kernel_kind
+    g["k2_bandwidth"] = float(k2_bandwidth)
     g["lik_kind"] = lik_kind
     g["roll_strategy"] = roll_strategy
     g["model_kind"] = model_kind

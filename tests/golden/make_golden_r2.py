@@ -11,6 +11,7 @@
     matmul-trick distance, the float64 run does not, so oracle and HIP can be held to 1e-5 against it.
   * mpf_pend_adam / mpf_part_log_adam: MPF with the class-default optimiser (Adam; its state persists across optimize() calls:
     the optimiser is built once in MPF.__init__, mpf.py:24): two filter updates each.
+  * pend_k2_fixedbw / part_k2shared_fixedbw: iid_mp(RBF(bandwidth >= 0)) - the fixed-bandwidth branch of base_kernels.py:66-67.
 Same recording machinery as make_golden.py (run_svmpc, run_mpf); nothing here re-implements the reference's arithmetic.
 """
 import os
@@ -30,3 +31,6 @@ if __name__ == "__main__":
                  k1_f64=True, lr_override=0.02)
     mg.run_mpf("mpf_pend_adam", "pendulum", Mp=10, n_steps=6, log_space=False, bw=0.08, optimizer="Adam", lr_override=0.01)
     mg.run_mpf("mpf_part_log_adam", "particle", Mp=12, n_steps=12, log_space=True, bw=0.5, optimizer="Adam", lr_override=0.02)
+    mg.run_svmpc("pend_k2_fixedbw", "pendulum", N=16, H=10, S=8, M=1, kernel_kind="K2", k2_bandwidth=0.7, n_iters=2, n_ticks=2, seed=24)
+    mg.run_svmpc("part_k2shared_fixedbw", "particle", N=8, H=12, S=8, M=4, kernel_kind="K2shared", k2_bandwidth=1.5, n_iters=2, n_ticks=1,
+                 seed=25, params_kind="logmass_gmm")

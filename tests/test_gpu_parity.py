@@ -23,6 +23,8 @@ def ctx_kwargs(g):
               weighted_prior=bool(int(g["weighted_prior"])), roll_strategy=str(g["roll_strategy"]))
     a_reg, temp = float(g["a_reg"]), float(g["temperature"])
     kw["ctrl_penalty"] = 1.0 - a_reg / temp
+    if "k2_bandwidth" in g and float(g["k2_bandwidth"]) >= 0:
+        kw["k2_bandwidth"] = float(g["k2_bandwidth"])  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth
     return kw
 
 

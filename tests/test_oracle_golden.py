@@ -14,7 +14,7 @@ from helpers import elemerr, is_adam, relerr, scenario_kwargs
 TOL = 1e-5
 SVMPC_CASES = ["pend_k1", "pend_k1_close", "pend_k2", "pend_k1_params", "pend_k1_expcost", "pend_k1_ctrlpen", "pend_k1_mean",
                "pend_cfg1", "part_k1_gmm", "part_k2_gmm", "part_k2shared", "part_k1_scalar", "part_k1_near_obst",
-               "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64"]
+               "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64", "pend_k2_fixedbw", "part_k2shared_fixedbw"]
 K1_F64_CASES = ["pend_k1_f64", "pend_k1_mid_f64"]
 
 
@@ -92,10 +92,10 @@ def test_score_phi_update(golden, name):
                 phi = o.phi_k1(theta, sc, variant=0)
                 tol = k1_tolerance(theta)
             elif kind == "K2":
-                phi, _ = o.phi_k2(theta, sc, indep=True)
+                phi, _ = o.phi_k2(theta, sc, indep=True, bandwidth=float(g["k2_bandwidth"]) if "k2_bandwidth" in g else -1.0)
                 tol = TOL
             else:
-                phi, _ = o.phi_k2(theta, sc, indep=False)
+                phi, _ = o.phi_k2(theta, sc, indep=False, bandwidth=float(g["k2_bandwidth"]) if "k2_bandwidth" in g else -1.0)
                 tol = TOL
             assert elemerr(phi, g["phi"][t, k]) < tol, (name, t, k)
             if is_adam(name):  # the reference's class default (svgd.py:115); its state restarts at every roll (svmpc.py:142-158)
