@@ -10,6 +10,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+# The persistent tick's SHARED prior / Stein tiles (one distance pass in the prior's scaling, persist.hpp tick_pair_shared) differ
+# from the un-fused kernels in the last bit of the Stein distances, and 250 closed-loop-free ticks amplify that chaotically; with
+# separate tiles the tick is bit-identical to the un-fused path, which is what lets this tool detect a hand-off race.
+os.environ.setdefault("DUST_NO_SHARE", "1")
+
 from dust_amd import Context
 
 
