@@ -234,7 +234,9 @@ int dust_profile_get(dust_ctx *ctx, int kernel_id, double *total_ms, int64_t *la
 int dust_profile_reset(dust_ctx *ctx);
 /* reps back-to-back launches of the standalone rollout kernel over device-resident eps [n_slices][S][N][D] (slice r %
  * n_slices per launch) between one pair of HIP events on the context's stream; *avg_ms = elapsed / reps.
- * flags: DUST_EPS_F16 when eps_dev holds binary16 values. */
+ * flags: DUST_EPS_F16 when eps_dev holds binary16 values; DUST_STORE_STATES (| DUST_STORE_F16): the stored-states form - it may
+ * be two launches (rollout_states.hpp + the injected-costs pass), so a second series of `reps` launches is then timed one event
+ * pair per launch into the per-kernel slots (dust_profile_get: DUST_K_ROLLOUT_STATES, DUST_K_ROLLOUT; earlier totals are reset). */
 int dust_profile_rollout(dust_ctx *ctx, const float *state, const float *eps_dev, int n_slices, int reps, int flags, double *avg_ms);
 const char *dust_kernel_name(int kernel_id);
 /* algorithmic bytes one launch of the rollout kernel moves (SURVEY.md section 8d B_roll) */
