@@ -416,7 +416,7 @@ static inline size_t gram_score_lds_bytes() {
 // chunks of 64.  D'[col][query] += V^T[col][key] K^T[key][query]: the A operand is a score column block, the B operand the Gram
 // rows - both read from LDS as stein.hpp's pass B reads them.  The K tile arrives with 16-byte loads along the key index.
 template <int DPB>
-__global__ __launch_bounds__(PAIR_NT, 2) void gram_score_kernel(const GramScoreArgs a) {
+__global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreArgs a) {
   constexpr int JC = PAIR_JC, NT = PAIR_NT, YS = DPB + 4, KS2 = JC + 4, NCT = DPB / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Vs = lds;            // [JC][YS] score rows of the chunk
