@@ -70,6 +70,8 @@ class MultiDISCO:
 
     # ------------------------------------------------------------------ context management
     def _config(self, model, params_dist):
+        if model.family not in ("pendulum", "particle"):
+            raise NotImplementedError("no rollout kernel family for %s (the reference ships no cost functions for it either)" % type(model).__name__)
         chol = torch.linalg.cholesky(self.a_dist.covariance_matrix).diag()
         sigma = self.a_dist.covariance_matrix.diag().sqrt()  # svmpc.py:107-111
         cfg = dict(model=model.family, N=self.n_pol, S=self.n_actions, M=self._tf.pts if self._tf is not None else self.n_params, H=self.hz_len,

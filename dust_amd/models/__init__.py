@@ -143,3 +143,36 @@ class Particle(BaseModel):
         obst = self.w_obs * self.obst_map.get_collisions(states[..., 0:2]) if self.with_obstacle else 0.0
         d = states - self.target
         return (d * d * self.w_term).sum(-1) + obst
+
+
+class SkidSteerRobot(BaseModel):
+    """dust/models/skid_steer_robot.py:9-122 (Kozlowski & Pazderski's simplified kinematic model).  Plant-side only: the reference
+    ships no cost family and no demo for it, so there is no rollout kernel family - handing it to MultiDISCO raises.  State
+    (x, y, theta, v, omega), action (right, left) wheel speeds [rot/s]."""
+
+    family = "skid_steer"
+
+    def __init__(self, delta_t, x_icr=0.2, wheel_radius=0.0625, axial_distance=0.475, min_wheel_speed=-0.5, max_wheel_speed=0.5, **kwargs):
+        super().__init__(dt=delta_t, params_dict={"x_icr": x_icr, "wheel_radius": wheel_radius, "axial_distance": axial_distance}, **kwargs)
+        self._observation_space = Box(dim=5, low=-float("inf"), high=float("inf"), dtype=torch.float)
+        self._action_space = Box(dim=2, low=min_wheel_speed, high=max_wheel_speed, dtype=torch.float)
+
+    observation_space = property(lambda self: self._observation_space)
+    action_space = property(lambda self: self._action_space)
+
+    def step(self, states, actions, params_dict=None):
+        p = self._merged(params_dict)
+        x_icr, radius, axial = p["x_icr"], p["wheel_radius"], p["axial_distance"]
+        states = torch.as_tensor(states, dtype=torch.float)
+        x, y, theta, _, _ = states.chunk(5, dim=1)
+        right, left = torch.as_tensor(actions, dtype=torch.float).clone().chunk(2, dim=1)
+        right = right.clamp(self.action_space.low[0], self.action_space.high[0])
+        left = left.clamp(self.action_space.low[1], self.action_space.high[1])
+        linear = (right + left) * math.pi * radius
+        angular = (right - left) * 2 * math.pi * radius / axial
+        forward = linear * self.dt
+        lateral = -angular * x_icr * self.dt
+        new_x = x + forward * torch.cos(theta) - lateral * torch.sin(theta)
+        new_y = y + forward * torch.sin(theta) + lateral * torch.cos(theta)
+        new_theta = theta + angular * self.dt
+        return torch.cat([new_x, new_y, new_theta, linear.expand_as(x), angular.expand_as(x)], dim=1)

@@ -84,3 +84,21 @@ def test_plant_steps_match_reference_rollouts(golden):
         x = p.step(x, torch.tensor(ac[:, t]), {"mass": torch.full((x.shape[0], 1), float(prm[0]))})
         assert np.allclose(x.numpy(), st[:, t + 1], rtol=1e-5, atol=1e-5)
     assert p.params_to_dict(torch.tensor([[1.0], [2.0]]))["mass"].shape == (2, 1)
+
+
+def test_skid_steer_plant_step_matches_reference(golden):
+    """SkidSteerRobot.step (skid_steer_robot.py:73-122) - plant-side only: default parameters, per-row parameter
+    columns (params_dict), other bounds and time step; and no rollout kernel family exists for it."""
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.models import SkidSteerRobot
+
+    g = golden("skid_steer")
+    m = SkidSteerRobot(delta_t=0.1)
+    assert m.observation_space.dim == 5 and m.action_space.dim == 2 and m.action_space.high.tolist() == [0.5, 0.5]
+    st, ac = torch.tensor(g["states"]), torch.tensor(g["actions"])
+    assert np.allclose(m.step(st, ac).numpy(), g["next"], rtol=1e-6, atol=1e-7)
+    pd = {k: torch.tensor(g[k]) for k in ("x_icr", "wheel_radius", "axial_distance")}
+    assert np.allclose(m.step(st, ac, pd).numpy(), g["next_params"], rtol=1e-6, atol=1e-7)
+    m2 = SkidSteerRobot(delta_t=0.05, x_icr=0.1, wheel_radius=0.08, axial_distance=0.5, min_wheel_speed=-1.0, max_wheel_speed=0.8)
+    assert np.allclose(m2.step(st, ac * 2).numpy(), g["next2"], rtol=1e-6, atol=1e-7)
+    assert m.params_dict == {"x_icr": 0.2, "wheel_radius": 0.0625, "axial_distance": 0.475}
