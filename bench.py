@@ -149,9 +149,9 @@ def roofline_section(local, state_pend):
     b_alg = c.rollout_bytes(store_states=True)
     kname = "dust::rollout_stream_kernel<1,true,false,true> (rollout kernel, stored-states form: states [M][S][N][H+1][ds] written)"
     avg_s, second_pass = both_s, None
-    if "particle_states_kernel" in per_kernel:
+    if "states_kernel" in per_kernel:
         # the whole-line form: rollouts + states + costs in particle_states_kernel, then the regular kernel's injected-costs pass
-        ms_k, n_k = per_kernel["particle_states_kernel"]
+        ms_k, n_k = per_kernel["states_kernel"]
         avg_s = ms_k / n_k * 1e-3
         ms_2, n_2 = per_kernel["rollout_kernel"]
         second_pass = ms_2 / n_2 * 1e3

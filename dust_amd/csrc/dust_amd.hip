@@ -60,7 +60,7 @@ extern "C" int dust_device_count(int *count) {
 }
 
 static const char *k_names[DUST_K_COUNT] = {"rollout_kernel", "pairwise_kernel<PRIOR>", "pairwise_kernel<STEIN>", "update_kernel",
-                                            "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", "particle_states_kernel"};
+                                            "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", "states_kernel"};
 extern "C" const char *dust_kernel_name(int id) { return (id >= 0 && id < DUST_K_COUNT) ? k_names[id] : ""; }
 
 struct dust_ctx {
@@ -879,6 +879,20 @@ static bool states_whole_lines(const dust_ctx *c, const SampleOpts &o, const Rol
   return true;
 }
 
+// ... and its Pendulum counterpart: 16-particle groups of 8 (H+1)-byte rows
+static bool states_whole_lines_pend(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, size_t *lds_out) {
+  const char *env = getenv("DUST_STATES_FORM");
+  if (env && atoi(env) == 0) return false;
+  if (c->cfg.model != DUST_MODEL_PENDULUM || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
+  if (o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
+  if (((c->H + 1) & 1) == 0 || c->H < 16) return false;
+  if ((c->N % 16) || (c->n0 % 16) || (c->nloc % 16)) return false;
+  const size_t lds = pendulum_states_lds_bytes(c->D, c->M);
+  if (lds > 80 * 1024) return false;
+  *lds_out = lds;
+  return true;
+}
+
 static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
   SampleOpts o = o_in;
   RolloutArgs a;
@@ -905,6 +919,23 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
         else DUST_LAUNCH_STATES(SP_FAST_OBST);
         DUST_LAUNCH_STATES(SP_GENERAL);  // only the workgroups the fast kernel flagged (non-finite operands) do any work here
 #undef DUST_LAUNCH_STATES
+        HIP_TRY(hipGetLastError());
+      }
+      o.want_states = false;
+      o.costs_in = c->costs_stage;
+      TRY(rollout_args(c, o, a, &nt, &lds));
+    } else if (states_whole_lines_pend(c, o, a, &lds_s)) {
+      {
+        Prof ps(c, DUST_K_ROLLOUT_STATES);
+        const int blocks = (c->nloc / 16) * ((c->S + 15) / 16);
+        TRY(ensure(&c->wg_flags, &c->wg_flags_cap, (size_t)blocks));
+        unsigned int *fl = reinterpret_cast<unsigned int *>(c->wg_flags);
+        if (lds_s > 64 * 1024 && !c->capturing) {
+          HIP_TRY(hipFuncSetAttribute((const void *)pendulum_states_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+          HIP_TRY(hipFuncSetAttribute((const void *)pendulum_states_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        }
+        pendulum_states_kernel<false><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);
+        pendulum_states_kernel<true><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);  // flagged workgroups only
         HIP_TRY(hipGetLastError());
       }
       o.want_states = false;

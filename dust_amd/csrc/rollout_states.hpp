@@ -278,6 +278,195 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
   }
 }
 
+// =====================================================================================================================
+// Pendulum family: states are 8 bytes, a trajectory is 8 (H+1) bytes (248 at H = 30) - groups of 16 ADJACENT particles are H+1 whole
+// lines.  Same scheme as above with 16 slots per line: lane = (sample s_sub = lane / 16, particle n_sub = lane % 16), a workgroup =
+// 16 samples x 16 particles (its four waves take four samples each), ONE trajectory per lane at a time (the M dynamics samples in
+// sequence); every lane writes its state into slot (row + p) % 16 of its own line in the staging area, phase p = ((H+1) n_sub) % 16
+// (H+1 odd: a permutation), so at every step one particle per group completes a line: half a wave reads these 4 lines, and every
+// second step the whole wave stores 8 whole lines.  A head can be 15 of the 31 states here, so heads stay in registers (30 VGPRs;
+// rolling them out again would add half the rollout).
+// GENERAL = false: branch-free trig path (finite operands); a workgroup that cannot take it raises its flag and the GENERAL = true
+// instance, launched right behind, rolls it out with the reference-order step functions.
+template <bool GENERAL>
+__global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutArgs a, float *costs_sn, unsigned int *wg_flags) {
+  if (GENERAL && wg_flags[blockIdx.x] == 0u) return;
+  extern __shared__ float lds[];
+  const int S = a.S, D = a.D, H = a.H, N = a.N_total, M = a.M, Hp1 = H + 1;
+  const int Dp = D | 1;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+  const int nblk = (int)gridDim.x / ((S + 15) >> 4);
+  const int nb = blockIdx.x % nblk, sb = blockIdx.x / nblk;
+  const int n_first = a.n0 + nb * 16;
+  float *tile = lds;               // [256][Dp] action rows, row = tid
+  float *coefs = tile + 256 * Dp;  // [M][2]
+  float *flags = coefs + 2 * M;    // [4]
+  const int off_area = ((int)((flags + 4) - lds) + 3) & ~3;
+  char *areas = reinterpret_cast<char *>(lds + off_area);  // [4 waves][64][SG_ROW]: one staged line per lane
+  if (tid == 0) flags[0] = 0.f;
+  const float x0[2] = {a.state[0], a.state[1]};
+  __syncthreads();
+  bool bad = false;
+  for (int m = tid; m < M; m += nt) {
+    Coef cf;
+    if (a.coef_given) {
+      cf.c0 = a.coef_host[0];
+      cf.c1 = a.coef_host[1];
+    } else {
+      cf = make_coef(a.dm, a.params ? a.params + (size_t)m * a.dm.P : nullptr);
+    }
+    coefs[2 * m] = cf.c0;
+    coefs[2 * m + 1] = cf.c1;
+    bad |= !(fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f);
+  }
+  for (int idx = tid; idx < 256 * D; idx += nt) {
+    const int row = (int)__umulhi((uint32_t)idx, a.magicD), k = idx - row * D;
+    const int s = min(sb * 16 + (row >> 6) * 4 + ((row & 63) >> 4), S - 1), n = n_first + (row & 15);
+    const float e = a.noise[((size_t)s * N + n) * D + k];
+    const float thk = a.noise_mode == NOISE_EPS ? a.theta[(size_t)n * D + k] : 0.f;
+    const float lk = a.noise_mode == NOISE_EPS ? a.chol_a[0] : 1.f;
+    const float av = thk + lk * e;
+    tile[row * Dp + k] = av;
+    bad |= av != av;
+  }
+  if (bad) flags[0] = 1.f;
+  __syncthreads();
+  const bool fast = flags[0] == 0.f && fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
+  if (!GENERAL) {
+    if (tid == 0) wg_flags[blockIdx.x] = fast ? 0u : 1u;
+    if (!fast) return;
+  }
+  const int j = lane & 15, ssub = lane >> 4;
+  const int s = sb * 16 + w * 4 + ssub;
+  const bool live = s < S;
+  const int sc = live ? s : S - 1;
+  // flusher role: each half of the wave owns (line of sample sf, 16-byte piece); the halves take alternate steps
+  const int sf_sub = (lane >> 3) & 3, piece = lane & 7;
+  const int sf = sb * 16 + w * 4 + sf_sub;
+  const bool flive = sf < S;
+  const bool half1 = lane >= 32;
+  const uint32_t rowb = 8u * (uint32_t)Hp1;
+  const size_t mstride = (size_t)S * N * rowb;
+  char *const gF = reinterpret_cast<char *>(a.states_out) + ((size_t)min(sf, S - 1) * N + n_first) * rowb + piece * 16;
+  const int pj = (Hp1 * j) & 15;
+  int inv16 = 1;
+  for (int c = 1; c < 16; c += 2)
+    if (((Hp1 * c) & 15) == 1) inv16 = c;
+  char *const area = areas + (size_t)w * 64 * SG_ROW;
+  char *const my_row = area + lane * SG_ROW;
+  char *const prev_row = area + (lane - 1) * SG_ROW;
+  const char *const fl_r = area + (sf_sub * 16) * SG_ROW + piece * 16;  // flusher role: + jn * SG_ROW
+  const float *actl = tile + tid * Dp;
+  const float dt = (float)a.dm.dt, mt = a.dm.max_torque, ms = a.dm.max_speed_pend;
+  const v2f W = {a.dm.w_cos, a.dm.w_vel};
+  double acc = 0.0;
+  for (int m = 0; m < M; ++m) {
+    Coef cf;
+    cf.c0 = coefs[2 * m];
+    cf.c1 = coefs[2 * m + 1];
+    char *const g = gF + (size_t)m * mstride;
+    float x[2] = {x0[0], x0[1]};
+    v2f head[15];  // rows 0 .. 14
+    v4f pv = {0.f, 0.f, 0.f, 0.f};  // a line read by the first half of the wave, stored together with the second half's next step
+    uint32_t pline = 0u;
+    double tot = 0.0;
+    auto emit = [&](const int q /* row % 16, static */, const int row) {
+      *reinterpret_cast<v2f *>(my_row + (((q + pj) & 15) << 3)) = (v2f){x[0], x[1]};
+      if (row < 15) {  // (lines completing before row 15 are heads)
+        head[q < 15 ? q : 0] = (v2f){x[0], x[1]};
+        return;
+      }
+      const int ph = (15 - q) & 15;
+      const int jn = (ph * inv16) & 15;
+      const uint32_t line = (rowb * (uint32_t)jn + 8u * (uint32_t)(row + 1)) / 128u - 1u;
+      __builtin_amdgcn_wave_barrier();
+      if (((row - 15) & 1) == 0) {  // first of a pair of steps: lanes 0..31 take this line
+        if (!half1) {
+          pv = *reinterpret_cast<const v4f *>(fl_r + jn * SG_ROW);
+          pline = line;
+        }
+      } else {                      // second: lanes 32..63 take this one, the whole wave stores
+        if (half1) {
+          pv = *reinterpret_cast<const v4f *>(fl_r + jn * SG_ROW);
+          pline = line;
+        }
+        if (flive) *reinterpret_cast<v4f *>(g + (size_t)pline * 128u) = pv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto step = [&](const int t) {
+      const float at[1] = {actl[t]};
+      if (GENERAL) {
+        tot += (double)step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+      } else {
+        float sn, cs;
+        pendulum_trig(x[0], &sn, &cs);
+        v2f qv = {cs - 1.0f, x[1]};
+        qv = W * (qv * qv);
+        tot += (double)(qv.x + qv.y);
+        const float u = __builtin_amdgcn_fmed3f(at[0], -mt, mt);
+        float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
+        thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
+        x[0] = x[0] + thd * dt;
+        x[1] = thd;
+      }
+    };
+    emit(0, 0);
+    for (int base = 0; base < H; base += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (base + i < H) {
+          step(base + i);
+          emit((i + 1) & 15, base + i + 1);
+        }
+    }
+    float traj;
+    if (GENERAL) {
+      traj = (float)tot + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
+    } else {
+      float sn, cs;
+      pendulum_trig(x[0], &sn, &cs);
+      v2f qv = {cs - 1.0f, x[1]};
+      qv = W * (qv * qv);
+      traj = (float)tot + (qv.x + qv.y);
+    }
+    acc += (double)traj;
+    if (((H - 15) & 1) == 0 && !half1 && flive) *reinterpret_cast<v4f *>(g + (size_t)pline * 128u) = pv;  // an unpaired last line
+    // ---- the 15 straddling lines of each group: tail of row j (slots 0 .. t-1, in the area already) + head of row j+1 ----
+    __builtin_amdgcn_wave_barrier();
+    if (j >= 1) {  // pj >= 1: rows 0 .. 15-pj of this trajectory complete the previous row's last line
+#pragma unroll
+      for (int q = 0; q < 15; ++q)
+        if (q + pj <= 15) *reinterpret_cast<v2f *>(prev_row + (q + pj) * 8) = head[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 4 samples x 15 lines x 8 pieces = 480 pieces over the wave's 64 lanes
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int P = it * 64 + lane, ln = P >> 3, pc = P & 7;
+      const int ss = ln / 15, jb = ln - ss * 15;
+      if (ln < 60) {
+        const v4f pv = *reinterpret_cast<const v4f *>(area + (ss * 16 + jb) * SG_ROW + pc * 16);
+        const int sg = sb * 16 + w * 4 + ss;
+        if (sg < S)
+          *reinterpret_cast<v4f *>(reinterpret_cast<char *>(a.states_out) + ((size_t)m * S * N + (size_t)sg * N + n_first) * rowb +
+                                   (size_t)((rowb * (uint32_t)(jb + 1)) / 128u) * 128u + pc * 16) = pv;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (live) {
+    const float cost = M == 1 ? (float)acc : (float)(acc / M);
+    costs_sn[(size_t)s * N + n_first + j] = cost;
+    a.costsT[(size_t)(n_first + j) * S + s] = cost;
+  }
+}
+
+static inline size_t pendulum_states_lds_bytes(int D, int M) {
+  const size_t floats = (size_t)256 * (D | 1) + 2 * (size_t)M + 4 + 4;
+  return floats * sizeof(float) + (size_t)4 * 64 * SG_ROW + 16;
+}
+
 static inline size_t particle_states_lds_bytes(int D, int M, int grid_words, int GW) {
   const size_t floats = (size_t)64 * (D | 1) + 2 * (size_t)M + 4 + 4 + (size_t)grid_words + 4 + 2 * (size_t)GW * 64;
   return floats * sizeof(float) + (size_t)GW * 72 * SG_ROW + 16;

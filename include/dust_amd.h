@@ -227,7 +227,7 @@ int dust_set_stream(dust_ctx *ctx, void *hip_stream);
 /* timing / roofline support: HIP-event timing of each kernel family on the context's stream */
 enum dust_kernel_id {
   DUST_K_ROLLOUT = 0, DUST_K_PRIOR_SCORE = 1, DUST_K_STEIN = 2, DUST_K_UPDATE = 3, DUST_K_FORWARD = 4, DUST_K_BANDWIDTH = 5,
-  DUST_K_MPF = 6, DUST_K_ROLLOUT_STATES = 7 /* whole-line stored-states rollouts (Particle) */, DUST_K_COUNT = 8
+  DUST_K_MPF = 6, DUST_K_ROLLOUT_STATES = 7 /* whole-line stored-states rollouts */, DUST_K_COUNT = 8
 };
 int dust_profile_enable(dust_ctx *ctx, int on);
 int dust_profile_get(dust_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

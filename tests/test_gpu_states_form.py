@@ -2,7 +2,8 @@
 staging kernel it replaces (DUST_STATES_FORM=0): same costs, same states, bit for bit between the two device kernels.
 
 MultiDISCO.forward returns `states` [M][S][N][H+1][ds] (dust/controllers/disco.py:394); the Particle family at fp32 takes the
-whole-line form when 8-particle groups are whole 128-byte lines (N % 8 == 0, H + 1 odd and >= 9) and M is even."""
+whole-line form when 8-particle groups are whole 128-byte lines (N % 8 == 0, H + 1 odd and >= 9) and M is even; the Pendulum
+family when 16-particle groups are (N % 16 == 0, H + 1 odd, H >= 16)."""
 import os
 
 import numpy as np
@@ -37,7 +38,7 @@ def _run(N, S, M, H, can_crash, with_obstacle, poison=None, state=None, seed=0):
             c.set_a_mat(np.zeros((N, H, 2), np.float32))
             c.profile(True)
             costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True)
-            used = "particle_states_kernel" in c.profile_get()
+            used = "states_kernel" in c.profile_get()
             c.close()
         finally:
             os.environ.pop("DUST_STATES_FORM", None)
@@ -82,5 +83,71 @@ def test_whole_line_states_not_taken_when_lines_do_not_close():
     for N, H in ((16, 11), (12, 10)):
         ref_costs, ref_states, out = _run(N, 8, 2, H, True, True)
         costs, states, _, used = out["1"]
+        assert not used
+        assert relerr(states, ref_states) < TOL and relerr(costs, ref_costs) < TOL
+
+
+def _run_pend(N, S, M, H, poison=None, seed=0):
+    from dust_amd import Context
+    from oracle import Oracle
+
+    rng = np.random.default_rng(seed + 5 * N + S)
+    up = ("length", "mass") if M > 1 else None
+    kw = dict(model="pendulum", N=N, S=S, M=M, H=H, uncertain_params=up)
+    actions = (1.5 * rng.standard_normal((S, N, H, 1))).astype(np.float32)
+    if poison is not None:
+        actions[poison] = np.nan
+    params = None if up is None else rng.uniform(0.6, 1.4, (M, 2)).astype(np.float32)
+    st = np.array([3.0, -0.4], np.float32)
+    o = Oracle(**kw)
+    ref_costs, ref_states = o.rollout_cost(st, actions, params, want_states=True)
+    out = {}
+    for form in ("1", "0"):
+        os.environ["DUST_STATES_FORM"] = form
+        try:
+            c = Context(kernel="K1", sigma_a=2.0, sigma_p=2.0, **kw)
+            c.set_a_mat(np.zeros((N, H, 1), np.float32))
+            c.profile(True)
+            costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True)
+            used = "states_kernel" in c.profile_get()
+            c.set_a_mat(np.zeros((N, H, 1), np.float32))
+            lean_costs = c.disco_forward(st, actions, params, want_states=False)[0]  # the rollout kernel without stored states
+            c.close()
+        finally:
+            os.environ.pop("DUST_STATES_FORM", None)
+        out[form] = (costs, states, omega, used, lean_costs)
+    return ref_costs, ref_states, out
+
+
+@pytest.mark.parametrize("N,S,M,H", [
+    (16, 16, 1, 30),   # cfg2's horizon: 248-byte rows, 31 lines per 16-particle group
+    (32, 21, 3, 16),   # shortest legal horizon, ragged S, three dynamics samples in sequence
+    (48, 128, 8, 30),  # cfg5's S / M / H
+    (16, 5, 2, 38),
+])
+def test_pendulum_whole_line_states_vs_oracle_and_staged_kernel(N, S, M, H):
+    """The Pendulum form of the whole-line kernel (16-particle groups, 16 eight-byte slots per line, heads held in registers).  It
+    runs the branch-free trig path of the rollout kernel WITHOUT stored states (the staged kernel runs the reference-order step
+    functions): costs bit-equal to that kernel's, states within an ulp or two of the staged kernel's."""
+    ref_costs, ref_states, out = _run_pend(N, S, M, H)
+    costs, states, omega, used, lean = out["1"]
+    costs0, states0, omega0, used0, _ = out["0"]
+    assert used and not used0
+    assert relerr(costs, ref_costs) < TOL
+    assert relerr(states, ref_states) < TOL
+    assert np.array_equal(costs, lean)
+    assert relerr(states, states0) < 2e-6 and relerr(costs, costs0) < 2e-6 and relerr(omega, omega0) < 1e-4
+
+
+def test_pendulum_whole_line_states_general_path_and_fallbacks():
+    ref_costs, ref_states, out = _run_pend(16, 16, 2, 20, poison=(2, 7, 3, 0))
+    costs, states, _, used, _ = out["1"]
+    costs0, states0, _, _, _ = out["0"]
+    assert used
+    assert np.array_equal(np.isnan(states), np.isnan(ref_states))
+    assert np.array_equal(states, states0, equal_nan=True) and np.array_equal(costs, costs0, equal_nan=True)
+    for N, H in ((16, 15), (16, 31), (24, 30)):  # too short / H + 1 even / N % 16 != 0: the staged kernel
+        ref_costs, ref_states, out = _run_pend(N, 8, 1, H)
+        costs, states, _, used, _ = out["1"]
         assert not used
         assert relerr(states, ref_states) < TOL and relerr(costs, ref_costs) < TOL

@@ -26,8 +26,8 @@ def run(model, N, S, M, H, store, f16=False, reps=3):
     pk = c.profile_get()
     ms, n = pk["rollout_kernel"]
     us = 1e3 * ms / n
-    if "particle_states_kernel" in pk:
-        ms2, n2 = pk["particle_states_kernel"]
+    if "states_kernel" in pk:
+        ms2, n2 = pk["states_kernel"]
         print("   whole-line states kernel %.1f us + second pass %.1f us" % (1e3 * ms2 / n2, us))
         us += 1e3 * ms2 / n2
     R = M * S * N
