@@ -103,7 +103,7 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
                                            r"pairwise_big_kernelILi\d+ELi32E|"
                                            # round 2: the stored-states kernel's fast instances (3 = the general path), the
                                            # fused large-set pairwise passes, the Gram x score GEMM, the log p pass
-                                           r"particle_states_kernelILi[012]E|pairwise_fused_kernel|gram_score_kernel|"
+                                           r"particle_states_kernelILi[012]E|pendulum_states_kernelILb0E|pairwise_fused_kernel|gram_score_kernel|"
                                            r"pairwise_logp_big_kernel", k)]
     assert len(hot) >= 45, sorted(kernels)
     bad = {k: kernels[k] for k in hot if kernels[k] != (0, 0)}
