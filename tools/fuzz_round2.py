@@ -1,0 +1,94 @@
+"""Randomised shape fuzz of the round-2 kernels against the kernels they replace (run on the GPU box):
+  * whole-line stored states (Particle / Pendulum) vs the staged kernel: bit-equal states (Particle), 2e-6 (Pendulum);
+  * fused large-set pairwise (+ Gram x score GEMM, log p pass) vs the unfused passes: 1e-5 element-wise.
+    python tools/fuzz_round2.py [n_cases] [seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+from dust_amd import Context
+from helpers import elemerr, relerr
+from oracle import grid_4x4_map  # data only
+
+
+def states_case(rng, model):
+    pend = model == "pendulum"
+    g = 16 if pend else 8
+    N = g * int(rng.integers(1, 5))
+    S = int(rng.integers(1, 70))
+    M = int(rng.integers(1, 5)) if pend else 2 * int(rng.integers(1, 6))
+    H = 2 * int(rng.integers(8 if pend else 4, 22))  # H + 1 odd
+    da = 1 if pend else 2
+    up = (("length", "mass") if pend else ("mass",)) if M > 1 else None
+    kw = dict(model=model, N=N, S=S, M=M, H=H, uncertain_params=up)
+    if not pend:
+        kw.update(can_crash=bool(rng.integers(0, 2)), with_obstacle=bool(rng.integers(0, 2)))
+    grid = grid_4x4_map() if (not pend and kw["with_obstacle"]) else None
+    actions = (1.5 * rng.standard_normal((S, N, H, da))).astype(np.float32)
+    params = None if up is None else rng.uniform(0.6, 1.6, (M, len(up))).astype(np.float32)
+    st = np.array([3.0, -0.4] if pend else [-5.2, -7.3, 4.0, 3.0], np.float32)
+    out = {}
+    for form in ("1", "0"):
+        os.environ["DUST_STATES_FORM"] = form
+        c = Context(grid=grid, kernel="K1", alpha=1e-4, sigma_a=2.0, sigma_p=2.0, **kw)
+        c.set_a_mat(np.zeros((N, H, da), np.float32))
+        c.profile(True)
+        costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True)
+        out[form] = (costs, states, "states_kernel" in c.profile_get())
+        c.close()
+    os.environ.pop("DUST_STATES_FORM", None)
+    (c1, s1, used), (c0, s0, _) = out["1"], out["0"]
+    assert used, kw
+    if pend:
+        assert relerr(s1, s0) < 2e-6 and relerr(c1, c0) < 2e-6, kw
+    else:
+        assert np.array_equal(s1, s0) and np.array_equal(c1, c0), kw
+    return kw
+
+
+def pair_case(rng):
+    model = "pendulum" if rng.integers(0, 2) else "particle"
+    da = 1 if model == "pendulum" else 2
+    N = int(rng.integers(2048, 3000))
+    H = int(rng.integers(6, 41)) if da == 2 else int(rng.integers(6, 65))
+    kernel = "IMQ" if rng.integers(0, 3) == 0 else "K1"
+    S = 4
+    spread = float(rng.choice([0.05, 0.25, 1.0]))
+    theta = (spread * rng.standard_normal((N, H, da))).astype(np.float32)
+    costs = (30.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, da))).astype(np.float32)
+    mixw = rng.random(N).astype(np.float32) + 0.05
+    sp = np.array([1.5, 0.8], np.float32)[:da]
+    got = {}
+    for fused in ("1", "0"):
+        os.environ["DUST_PAIR_FUSED"] = fused
+        c = Context(model=model, N=N, S=S, M=1, H=H, kernel=kernel, imq_ell=0.9, lr=0.0, sigma_a=1.5, sigma_p=sp, seed=5,
+                    grid=grid_4x4_map() if da == 2 else None, weighted_prior=True)
+        c.set_theta(theta); c.set_prior(theta); c.set_a_mat(theta)
+        c.svmpc_update_prior(mixw)
+        phi, _, gp = c.svmpc_phi(costs, actions)
+        c.svmpc_optimize(np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32), 1)  # (lr = 0: theta stays; device noise)
+        c.svmpc_forward()
+        _, lp = c.get_log_weights()
+        got[fused] = (phi, gp, lp)
+        c.close()
+    os.environ.pop("DUST_PAIR_FUSED", None)
+    tol = 1e-5 if spread < 1.0 else 4e-5
+    assert elemerr(got["1"][0], got["0"][0]) < 1e-5 and elemerr(got["1"][1], got["0"][1]) < tol, (model, N, H, kernel, spread)
+    assert relerr(got["1"][2], got["0"][2]) < 1e-5, (model, N, H, kernel, spread)
+    return (model, N, H, kernel, spread)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    for i in range(n):
+        states_case(rng, "particle")
+        states_case(rng, "pendulum")
+        if i % 3 == 0:
+            print("pair", pair_case(rng), flush=True)
+    print("fuzz ok: %d stored-states cases per family, %d pairwise cases" % (n, (n + 2) // 3))
