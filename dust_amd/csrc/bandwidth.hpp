@@ -35,9 +35,9 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
+  wg_sync();
   if (lane == 0) scratch[wid] = v;
-  __syncthreads();
+  wg_sync();
   unsigned long long r = 0;
   for (int w = 0; w < nw; ++w) r += scratch[w];
   return r;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   __shared__ unsigned redc[16 * 8];
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
   for (int i = tid; i < npow2; i += nt) xs[i] = i < N ? a.thetaT[(size_t)c * N + i] : INFINITY;
-  __syncthreads();
+  wg_sync();
   for (int k = 2; k <= npow2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < npow2; i += nt) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
           }
         }
       }
-      __syncthreads();
+      wg_sync();
     }
   const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
   const float span = xs[N - 1] - xs[0];
@@ -104,12 +104,12 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt[c] += __shfl_xor(cnt[c], o, 64);
-      __syncthreads();
+      wg_sync();
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) redc[wid * 8 + c] = cnt[c];
       }
-      __syncthreads();
+      wg_sync();
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         unsigned t = lane < nw ? redc[lane * 8 + c] : 0u;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_big_kernel(const K2A
   __shared__ unsigned long long red64[16];
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
   for (int i = tid; i < npow2; i += nt) xs[i] = i < N ? a.thetaT[(size_t)c * N + i] : INFINITY;
-  __syncthreads();
+  wg_sync();
   for (int k = 2; k <= npow2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < npow2; i += nt) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_big_kernel(const K2A
           }
         }
       }
-      __syncthreads();
+      wg_sync();
     }
   const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
   const float span = xs[N - 1] - xs[0];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_pairs_kernel(const K2Args a
   __shared__ float redf[32];
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, da = a.da, g = blockIdx.x;
   for (int idx = tid; idx < da * N; idx += nt) xs[idx] = a.thetaT[(size_t)(g * da) * N + idx];
-  __syncthreads();
+  wg_sync();
   float mx = 0.f;
   for (int i = tid; i < N; i += nt)
     for (int j = 0; j < N; ++j) {
@@ -267,13 +267,13 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
     if (q < gd) xi[q] = a.thetaT[(size_t)(c0 + q) * N + i];
   for (int jb = 0; jb < N; jb += K2_JT) {
     const int jn = min(K2_JT, N - jb);
-    __syncthreads();
+    wg_sync();
     for (int idx = threadIdx.x; idx < gd * jn; idx += 256) {
       const int q = idx / jn, j = idx - q * jn;
       xcol[q][j] = a.thetaT[(size_t)(c0 + q) * N + jb + j];
       scol[q][j] = a.score[(size_t)(jb + j) * D + c0 + q];
     }
-    __syncthreads();
+    wg_sync();
     const int per = (jn + 3) >> 2, j0 = js * per, j1 = min(jn, j0 + per);
 #pragma unroll 8
     for (int j = j0; j < j1; ++j) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
     part[js][ii][q] = g1[q];
     part[js][ii][2 + q] = g2[q];
   }
-  __syncthreads();
+  wg_sync();
   if (js == 0 && on) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)

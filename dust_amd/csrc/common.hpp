@@ -45,6 +45,16 @@
 
 namespace dust {
 
+// Workgroup barrier.  `s_barrier` does not wait for LDS instructions of the issuing wave that are still queued: a ds_write
+// issued just before it can land AFTER another wave's post-barrier ds_read.  __syncthreads() normally carries the
+// `s_waitcnt lgkmcnt(0)` that closes this, but the compiler drops it where it believes nothing is pending - observed at a loop
+// header whose back edge ends in ds_write_b128 (pairwise_fused_kernel's key commit: 1 launch in ~10 read 4 stale key rows,
+// tools/fused_race.hip).  The wait is therefore spelled out; tools/barrier_audit.py checks the generated code.
+__device__ __forceinline__ void wg_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Device-side model description (by-value kernel argument; lives in SGPRs / constant cache).
 struct DevParam {
@@ -538,9 +548,9 @@ template <int OP>
 __device__ __forceinline__ float block_reduce(float v, float *scratch) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   v = OP == RED_SUM ? wave_sum(v) : (OP == RED_MAX ? wave_max(v) : wave_min(v));
-  __syncthreads();  // scratch may still be read from a previous reduction
+  wg_sync();  // scratch may still be read from a previous reduction
   if (lane == 0) scratch[wid] = v;
-  __syncthreads();
+  wg_sync();
   // second level in registers: lane w < nw picks up wave w's value, one more wave reduction (a serial walk over the
   // nw LDS words costs nw dependent reads: ~1.5k cycles per reduction in the 1024-lane single-workgroup kernels)
   float r = lane < nw ? scratch[lane] : (OP == RED_SUM ? 0.f : (OP == RED_MAX ? -INFINITY : INFINITY));

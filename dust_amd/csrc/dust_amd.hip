@@ -2701,7 +2701,7 @@ __global__ void narrow_f16_kernel(float *buf, size_t n) {  // in place: value i 
   for (size_t base = 0; base < n; base += (size_t)gridDim.x * blockDim.x) {
     const size_t i = base + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float v = i < n ? buf[i] : 0.f;
-    __syncthreads();
+    wg_sync();
     if (i < n) out[i] = (_Float16)v;
   }
 }

@@ -37,12 +37,12 @@ __device__ __forceinline__ void block_reduce2(float &mx, float &sm, float *scrat
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   mx = wave_max(mx);
   sm = wave_sum(sm);
-  __syncthreads();
+  wg_sync();
   if (lane == 0) {
     scratch[wid] = mx;
     scratch[16 + wid] = sm;
   }
-  __syncthreads();
+  wg_sync();
   mx = scratch[0];
   sm = scratch[16];
   for (int w = 1; w < nw; ++w) {
@@ -106,12 +106,12 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a) {
       bi = oi;
     }
   }
-  __syncthreads();
+  wg_sync();
   if (lane == 0) {
     red[wid] = best;
     redi[wid] = bi;
   }
-  __syncthreads();
+  wg_sync();
   best = lane < nw ? red[lane] : -INFINITY;  // second level in registers (lane w holds wave w's candidate)
   bi = lane < nw ? redi[lane] : 0x7fffffff;
   for (int o = 32; o > 0; o >>= 1) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(128) void roll_kernel(const RollArgs a) {
       if (j + da >= D && j < D && j % da == c) out = s / (float)a.H;
     }
   }
-  __syncthreads();
+  wg_sync();
   if (j < D) {
     a.theta_dst[(size_t)i * D + j] = out;
     if (a.adam_m) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(1024) void disco_step_kernel(const StepArgs a) {
       red[tid >> 6] = best;
       redi[tid >> 6] = bi;
     }
-    __syncthreads();
+    wg_sync();
     if (tid == 0) {
       for (int w = 1; w < (nt + 63) / 64; ++w)
         if (red[w] > best || (red[w] == best && redi[w] < bi)) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void disco_step_kernel(const StepArgs a) {
         }
       s_best = bi;
     }
-    __syncthreads();
+    wg_sync();
     for (int j = tid; j < D; j += nt) {
       const float v = clampf(a.a_mat[(size_t)s_best * D + j], a.min_a[j % a.da], a.max_a[j % a.da]);
       seq[j] = v;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void disco_step_kernel(const StepArgs a) {
   } else {
     for (int j = tid; j < D; j += nt) seq[j] = clampf(a.ext[j], a.min_a[j % a.da], a.max_a[j % a.da]);
   }
-  __syncthreads();
+  wg_sync();
   for (int j = tid; j < a.steps * a.da; j += nt) a.next[j] = seq[j];
   const int sh = a.steps * a.da;
   for (int j = tid; j < D; j += nt) a.a_seq[j] = (j + sh < D) ? seq[j + sh] : 0.f;

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollo
     const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
     pairwise_body<PAIR_PRIOR, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores ...
-    __syncthreads();                                    // ... before the one lane that signals for the workgroup
+    wg_sync();                                    // ... before the one lane that signals for the workgroup
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     const int nb = (int)gridDim.x - f.n_pair_blocks;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kern
     const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
     pairwise_body<MODE, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_sync();
     if (threadIdx.x == 0) {
       const unsigned int prev = __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (prev + 1u == (unsigned int)f.pa.JS)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void stein_update_kern
           }
         }
     }
-    __syncthreads();
+    wg_sync();
     update_body<true>(f.ua, idx);
   }
 }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
     const int tile_x = b0 % f.tiles, js = b0 / f.tiles;
     pairwise_body<PAIR_PRIOR, CPT>(f.prior, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_sync();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_prior + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DUST_TL(f.tl, 3);
   } else if (b0 < f.n_pair_blocks + f.n_roll_blocks) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
     const int tile_x = bs % f.tiles, js = bs / f.tiles;
     stein_split_body<MODE, CPT>(f.stein, lds, tile_x, js, f.cnt_score, f.score_pub, f.timeout_flag, f.tl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_sync();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt_stein + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DUST_TL(f.tl, 3);
   } else {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svgd_iter_kernel(
         }
     }
     DUST_TL(f.tl, 1);
-    __syncthreads();
+    wg_sync();
     update_body<true>(f.ua, idx);
     DUST_TL(f.tl, 3);
   }

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
   const int per = (Mp + R - 1) / R, k0 = r * per, k1 = min(Mp, k0 + per);
   if (on && r == 0)
     _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = a.x[i * P + p];
-  __syncthreads();
+  wg_sync();
   const float bw2 = (float)((double)a.bw * (double)a.bw);
   const double inv_pbw = 1.0 / (double)a.prior_bw, inv_pbw2 = inv_pbw * inv_pbw;
   const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw), inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
       d[0] = zs;
       _Pragma("unroll") for (int p = 0; p < P; ++p) d[1 + p] = acc[p];  // 1 + P <= 2 P slots
     }
-    __syncthreads();
+    wg_sync();
     if (on && r == 0) {
       double zs = 0.0, acc[4] = {0, 0, 0, 0};
       for (int rr = 0; rr < R; ++rr) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
       _Pragma("unroll") for (int p = 0; p < P; ++p) nn = nn + xi[p] * xi[p];
       nrm[i] = nn;
     }
-    __syncthreads();
+    wg_sync();
     // kernel + phi (svgd.py:92-99, mpf.py:52-56).  squared_distance's fp32 addmm rounding is followed: it is part of the
     // reference's result (d^2 / bw^2 amplifies it) - dot as an fma chain, then |b|^2 - 2 a.b, then + |a|^2, clamp 0.
     if (on) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
         d[P + p] = ks[p];
       }
     }
-    __syncthreads();
+    wg_sync();
     float ph[4] = {0.f, 0.f, 0.f, 0.f};
     if (on && r == 0) {
       double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
         _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = fmaf(a.lr, ph[p], xi[p]);
       }
     }
-    __syncthreads();
+    wg_sync();
   }
   if (on && r == 0) {
     _Pragma("unroll") for (int p = 0; p < P; ++p) a.x[i * P + p] = xs[i * P + p];

@@ -80,10 +80,10 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
     rowlane_issue<JC, DPB, NT>(a.Y, j0, jc, D, vy);
     if (MODE != PAIR_PRIOR) rowlane_issue<JC, DPB, NT>(a.V, j0, jc, D, vv);
     const float lm = (MODE == PAIR_PRIOR) ? a.logmix[j0 + min(jA, jc - 1)] : 0.f;
-    __syncthreads();  // the previous chunk's pass B is done with Ys / Vs / kv
+    wg_sync();  // the previous chunk's pass B is done with Ys / Vs / kv
     rowlane_commit<JC, DPB, YS, NT, false>(vy, jc, D, a.da, a.inv_s, Ys);
     if (MODE != PAIR_PRIOR) rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, a.da, a.inv_s, Vs);
-    __syncthreads();
+    wg_sync();
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
       v2f y[DPB / 2];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
         kv[(i + 1) * KS + jA] = gram(db2);
       }
     }
-    __syncthreads();
+    wg_sync();
     if (MODE == PAIR_PRIOR) {
       // online softmax over key chunks: LQ consecutive lanes per query (DPP max, bare v_exp_f32 as in the 32 x 64 kernel)
       const int q = tid / LQ, l = tid - q * LQ;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(PAIR_NT, (DPB <= 64 ? 2 : 1)) void pairwise_big_ker
         mrow[q] = mn;
         scl[q] = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
       }
-      __syncthreads();
+      wg_sync();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float sc = scl[4 * qg + r];

@@ -50,8 +50,11 @@ static inline size_t pairwise_fused_lds_bytes() {
   return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 2 * (size_t)G::TQ);
 }
 
+#ifndef DUST_FUSED_WGS
+#define DUST_FUSED_WGS 2  // resident workgroups per CU the register budget is set for (tools/fused_race.hip builds it at 1 too)
+#endif
 template <int MODE /* PAIR_K1 / PAIR_IMQ: the Stein kernel */, int DPB>
-__global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFusedArgs b) {
+__global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel(const PairFusedArgs b) {
   using G = FusedGeom<DPB>;
   constexpr int JC = PAIR_JC, NT = PAIR_NT, TQ = G::TQ, YS = G::YS, KS = G::KS, CB = G::CB, LCG = G::LCG, NV = CB / 4;
   constexpr int QW = TQ / 4;                                  // queries per wave in pass A
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
   for (int j0 = jbeg; j0 < jend; j0 += JC) {
     const int jc = min(JC, jend - j0);
     const float lm = lm_next;
-    __syncthreads();  // Ys holds this chunk
+    wg_sync();  // Ys holds this chunk
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
       v2f y[DPB / 2];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
         if (kval && il + 1 < a.n_local) b.K[(size_t)(il + 1) * b.ldK + j0 + jA] = kb;
       }
     }
-    __syncthreads();
+    wg_sync();
     {
       // online softmax over key chunks: LQ consecutive lanes per query (DPP max, bare v_exp_f32 as in the 32 x 64 kernel)
       const int q = tid / LQ, l = tid - q * LQ;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
           scl[q] = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
         }
       }
-      __syncthreads();
+      wg_sync();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float sc = scl[qgc + QS * r];
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(PAIR_NT, 2) void pairwise_fused_kernel(const PairFu
         }
       }
     }
-    __syncthreads();  // pass B is done with Ys / kvP / kvS
+    wg_sync();  // pass B is done with Ys / kvP / kvS
     if (more) keys_commit(j0 + JC);
   }
 
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(PAIR_NT, 3) void pairwise_logp_big_kernel(const Pai
   for (int j0 = jbeg; j0 < jend; j0 += JC) {
     const int jc = min(JC, jend - j0);
     const float lm = lm_next;
-    __syncthreads();  // Ys holds this chunk; the previous chunk's reduction is done with kvP
+    wg_sync();  // Ys holds this chunk; the previous chunk's reduction is done with kvP
     const bool more = j0 + JC < jend;
     v2f y[DPB / 2];
 #pragma unroll
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(PAIR_NT, 3) void pairwise_logp_big_kernel(const Pai
       y[2 * p] = v2f{t.x, t.y};
       y[2 * p + 1] = v2f{t.z, t.w};
     }
-    __syncthreads();  // every lane holds its key row: Ys may be refilled
+    wg_sync();  // every lane holds its key row: Ys may be refilled
     if (more) keys_issue(j0 + JC);  // in flight during the distance pass
     const bool kval = jA < jc;
     for (int qi = 0; qi < QW; qi += 2) {
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(PAIR_NT, 3) void pairwise_logp_big_kernel(const Pai
       kvP[(i + 1) * KS + jA] = kval ? lm - 0.5f * pbq : -INFINITY;
     }
     if (more) keys_commit(j0 + JC);
-    __syncthreads();
+    wg_sync();
     {
       const int q = tid / LQ, l = tid - q * LQ;
       if (q < TQ) {
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(PAIR_NT, 3) void pairwise_logp_big_kernel(const Pai
       }
     }
   }
-  __syncthreads();
+  wg_sync();
   for (int i = tid; i < TQ; i += NT) {
     const int il = tile * TQ + i;
     if (il < a.n_local) {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       const int il = min(il0 + kr + 16 * u, a.n_local - 1);
       kt[u] = *reinterpret_cast<const v4f *>(a.K + (size_t)il * a.ldK + j0 + kc);  // (ldK is a multiple of 64: in bounds; the tail is masked)
     }
-    __syncthreads();  // the previous chunk's products are done with Vs / Kt
+    wg_sync();  // the previous chunk's products are done with Vs / Kt
     rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, 1, nullptr, Vs);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       t.w = kc + 3 < jc ? t.w : 0.f;
       *reinterpret_cast<v4f *>(&Kt[(kr + 16 * u) * KS2 + kc]) = t;
     }
-    __syncthreads();
+    wg_sync();
 #pragma unroll 4
     for (int k4 = 0; k4 < JC / 4; ++k4) {
       const float bq = Kt[(wave * 16 + (jA & 15)) * KS2 + 4 * k4 + (jA >> 4)];

@@ -96,7 +96,7 @@ struct TickArgs {
 // publish: every storing wave drains its write-through stores, barrier, one lane signals for the workgroup
 __device__ __forceinline__ void arrive(unsigned int *line) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  wg_sync();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -160,7 +160,7 @@ __device__ __forceinline__ void tick_pair_shared(const TickArgs &f, float *lds, 
   const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;
   const int jA = tid & (JC - 1), igA = tid / JC;
   const float lm = a.logmix[jbeg + min(jA, jc - 1)];
-  __syncthreads();
+  wg_sync();
   DUST_TLP(tlp, 3);
   v2f xB[CPT / 2];
 #pragma unroll
@@ -193,7 +193,7 @@ __device__ __forceinline__ void tick_pair_shared(const TickArgs &f, float *lds, 
       kvS[(igA * QPG + ii) * (JC + 1) + jA] = v;
     }
   }
-  __syncthreads();
+  wg_sync();
   DUST_TLP(tlp, 4);
   {  // prior softmax over the chunk (single chunk: no running rescale)
     float m = -INFINITY;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void tick_pair_shared(const TickArgs &f, float *lds, 
       const float l = kvP[iB * (JC + 1) + jj];
       kvP[iB * (JC + 1) + jj] = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((l - m) * 1.44269504088896340736f);
     }
-    __syncthreads();
+    wg_sync();
   }
   DUST_TLP(tlp, 5);
   // pass B, prior half first (its partials are what the owners wait for)
@@ -272,7 +272,7 @@ __device__ __forceinline__ void tick_pair_shared(const TickArgs &f, float *lds, 
   DUST_TLP(tlp, 10);
   // score rows of the key slice (owners, this iteration)
   if (tid < gate.nlines) spin_until(gate.cnt + (size_t)(gate.line0 + tid) * CNT_STRIDE, tid == 0 ? gate.target0 : gate.target1, f.timeout_flag);
-  __syncthreads();
+  wg_sync();
   DUST_PRIO(3);
   DUST_TLP(tlp, 11);
   using RLV = RowLane<JC, DP, NT>;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void tick_pair_shared(const TickArgs &f, float *lds, 
     rowlane_issue<JC, DP, NT, true>(f.stein.V, jbeg, jc, D, vv, tid);
     rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs, tid);
   }
-  __syncthreads();
+  wg_sync();
   v4f accM[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -322,7 +322,7 @@ __device__ __forceinline__ void tick_pair(const TickArgs &f, float *lds, const i
       if (threadIdx.x == 0) spin_until(f.cnt_theta + (size_t)tile_x * CNT_STRIDE, (unsigned int)k * aq, f.timeout_flag);
       if (threadIdx.x == 1) spin_until(f.cnt_theta + (size_t)g0 * CNT_STRIDE, (unsigned int)k * a0, f.timeout_flag);
       if (threadIdx.x == 2 && g1 != g0) spin_until(f.cnt_theta + (size_t)g1 * CNT_STRIDE, (unsigned int)k * a1, f.timeout_flag);
-      __syncthreads();
+      wg_sync();
     }
     DUST_TLK(f.tl, 16 * k + 0);
     const float *ky = f.mu_aliased ? th : f.mu;
@@ -458,12 +458,12 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
     }
     if (own) th[tid] = thv;
     if (tid == 0) red[40] = 0.f;
-    __syncthreads();
+    wg_sync();
     // the tile keeps the raw noise; actions = theta + L eps (likelihoods.py:81-101) are formed where they are used (same two
     // operations, same rounding).  red[40]: some action may be NaN (non-finite theta / noise): the general loop, whose
     // clamps propagate NaN as torch.clamp does, instead of the v_med3 fast path
     if (eps_bad || (own && !(fabsf(thv) <= 3.0e38f))) red[40] = 1.f;
-    __syncthreads();
+    wg_sync();
     DUST_TLK(f.tl, 16 * k + 1);
 
     // ---- 2. rollouts: lane = sample, dynamics samples looped in registers (rollout_body stage 2, LEAN, G == 1) ----
@@ -521,7 +521,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
       cst[s] = cost;
       a.costsT[(size_t)n * S + s] = cost;
     }
-    __syncthreads();
+    wg_sync();
     DUST_TLK(f.tl, 16 * k + 2);
 
     // ---- 3. softmax over samples (rollout_body stage 3) ----
@@ -620,7 +620,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
     DUST_TLK(f.tl, 16 * k + 9);
     // ---- prior partials of this group's query tile (pair role, this iteration) ----
     if (threadIdx.x == 0) spin_until(f.cnt_prior + (size_t)grp * CNT_STRIDE, (unsigned int)(k + 1) * (unsigned int)f.JS, f.timeout_flag);
-    __syncthreads();
+    wg_sync();
     DUST_TLK(f.tl, 16 * k + 3);
 
     // prior partials of this row (write-through by the pair role: sc1 loads), issued as soon as the tile has arrived
@@ -691,7 +691,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
 
     // ---- Stein partials of this group's query tile -> phi -> optimiser step (update_body) ----
     if (threadIdx.x == 0) spin_until(f.cnt_stein + (size_t)grp * CNT_STRIDE, (unsigned int)(k + 1) * (unsigned int)f.JS, f.timeout_flag);
-    __syncthreads();
+    wg_sync();
     DUST_PRIO(DUST_PRIO_OWNER);
     DUST_TLK(f.tl, 16 * k + 6);
     if (own) {
@@ -742,7 +742,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
   // ---- SVMPC.forward (svmpc.py:172-200), fast_pred: the last iteration's costs ----
   if (own) th[tid] = thv;
   if (threadIdx.x == 0) spin_until(f.cnt_prior + (size_t)grp * CNT_STRIDE, (unsigned int)(kf + 1) * (unsigned int)f.JS, f.timeout_flag);
-  __syncthreads();
+  wg_sync();
   DUST_TLK(f.tl, 16 * kf + 0);
   if (tid == 0) {  // log p(theta_n) from the slice partials (finalize_body), log_w = log_l + log_p (svmpc.py:137-138)
     float pmx, pl;
@@ -753,13 +753,13 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
   }
   // two-level arrival: the last owner workgroup of a group bumps the global line (cnt_lw[tiles]); every owner polls that one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  wg_sync();
   if (threadIdx.x == 0) {
     const unsigned int prev = __hip_atomic_fetch_add(f.cnt_lw + (size_t)grp * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1u == arr) __hip_atomic_fetch_add(f.cnt_lw + (size_t)f.tiles * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     spin_until(f.cnt_lw + (size_t)f.tiles * CNT_STRIDE, (unsigned int)f.tiles, f.timeout_flag);
   }
-  __syncthreads();
+  wg_sync();
   DUST_TLK(f.tl, 16 * kf + 1);
   // softmax over all particles, first-index argmax (finalize_body), computed by every owner workgroup for itself
   {
@@ -807,13 +807,13 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
         bi = oi;
       }
     }
-    __syncthreads();
+    wg_sync();
     int *redi = reinterpret_cast<int *>(wred + 32);
     if (lane2 == 0) {
       wred[wid2] = best;
       redi[wid2] = bi;
     }
-    __syncthreads();
+    wg_sync();
     best = wred[0];
     bi = redi[0];
     for (int w = 1; w < PAIR_NT / 64; ++w)
@@ -821,7 +821,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
         best = wred[w];
         bi = redi[w];
       }
-    __syncthreads();
+    wg_sync();
     if (bi >= n_first && bi < n_first + f.per_block) {  // the owner of the best particle hands out its action sequence
       const float *thb = lds_all + (size_t)(bi - n_first) * f.lds_roll_floats + (th - lds);
       if (t == 0) *f.istar = bi;
@@ -865,7 +865,7 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
         if (i >= n_first && i < n_first + f.per_block) f.logmix[i] = lwr[r] - lzz;
       }
     }
-    __syncthreads();
+    wg_sync();
   }
   // roll (svmpc.py:142-158): shift left along H, last row per strategy; into the home buffer.  Every reader of theta(kf) in
   // either buffer has finished: the log-weights of ALL particles needed every log-density tile.
@@ -875,9 +875,9 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
     for (int c = 0; c < DA; ++c) {
       const float v = (own && tid % DA == c) ? thv : 0.f;
       const float ws = wave_sum(v);
-      __syncthreads();
+      wg_sync();
       if ((tid & 63) == 0 && (tid >> 6) < 2) part[tid >> 6] = ws;
-      __syncthreads();
+      wg_sync();
       const float s = nt >= 128 ? part[0] + part[1] : part[0];
       if (own && tid + DA >= D && tid % DA == c) outv = s / (float)H;
     }

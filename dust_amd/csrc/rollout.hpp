@@ -101,7 +101,7 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   *cos_th = cs;
 }
 
-// Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (__syncthreads()
+// Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (wg_sync()
 // drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -224,7 +224,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   };
   if (a.noise_mode != NOISE_PHILOX) issue_loads();
   if (tid < D) th[tid] = thv;
-  __syncthreads();
+  wg_sync();
   bool nanf = tid < D && thv != thv;
   if (a.noise_mode != NOISE_PHILOX) {
     const float thj = a.noise_mode == NOISE_EPS ? th[min(sj, D - 1)] : 0.f;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     }
   }
   if (nanf) red[40] = 1.f;
-  __syncthreads();
+  wg_sync();
 
   DUST_STAMP(a.stamps, 1);
   // ---- 2. rollouts: lane = sample s, dynamics samples m looped in registers (a2-a5) ----
@@ -283,7 +283,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         }
       }
     }
-    if (G > 1) __syncthreads();  // G == 1: every lane consumes only the row it filled itself
+    if (G > 1) wg_sync();  // G == 1: every lane consumes only the row it filled itself
   }
   // [G][sub] per-group partial sums over m (G > 1); `part` is only 4-byte aligned for odd S: round up (one spare pair of
   // floats is reserved in rollout_lds_bytes)
@@ -519,14 +519,14 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
     else finish_cost(s, acc_m);
   }
   if (G > 1) {  // fixed-order sum of the group partials (the barrier sits outside the sample loop: lanes without a sample reach it too)
-    __syncthreads();
+    wg_sync();
     if (mg == 0 && ts < S && !f_costs_in) {
       double acc_m = accp[ts];
       for (int g = 1; g < G; ++g) acc_m += accp[g * sub + ts];
       finish_cost(ts, acc_m);
     }
   }
-  __syncthreads();
+  wg_sync();
   if (f_actions) {
     for (int idx = tid; idx < S * D; idx += nt) {
       const int s = (int)__umulhi((uint32_t)idx, a.magicD), j = idx - s * D;
@@ -551,7 +551,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         }
       }
     }
-    __syncthreads();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
+    wg_sync();  // the partials below are read with sc1 loads only (they were stored sc1): no acquire fence needed
   }
   DUST_STAMP(a.stamps, 2);
   // ---- 3. softmax over samples: likelihood weights w (alpha) and MPPI weights omega (1/temp) ----
@@ -752,7 +752,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   DUST_TL(fw ? fw->tl : nullptr, 2);
   if (fw && fw->score_cnt && !fw->score_pub) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
-    __syncthreads();                                    // ... before the one lane that signals for the workgroup
+    wg_sync();                                    // ... before the one lane that signals for the workgroup
     if (threadIdx.x == 0)
       __hip_atomic_fetch_add(fw->score_cnt + (nl / fw->score_slice) * CNT_STRIDE, (unsigned int)fw->score_add, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);

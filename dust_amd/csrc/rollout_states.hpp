@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
   float x0[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) x0[k] = a.state[k];
-  __syncthreads();
+  wg_sync();
   bool bad = false;
   for (int m = tid; m < M; m += nt) {
     float c0;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
     bad |= av != av;
   }
   if (bad) flags[0] = 1.f;
-  __syncthreads();
+  wg_sync();
   const bool fast = flags[0] == 0.f && fabsf(x0[0]) <= 3.0e38f && fabsf(x0[1]) <= 3.0e38f && fabsf(x0[2]) <= 3.0e38f && fabsf(x0[3]) <= 3.0e38f &&
                     (fabsf(x0[0]) + fabsf(x0[1]) + (fabsf(x0[2]) + fabsf(x0[3]) + a.dm.max_speed * (float)H) * fabsf((float)a.dm.dt)) * fabsf(a.dm.inv_cell) +
                                 fabsf(a.dm.off_x) + fabsf(a.dm.off_y) <
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_kernel(const RolloutAr
   }
   const double acc = sg_roll_pairs<MODE>(a, gridl, actl, coefs, area, lane, w, GW, live, gsg, x0);
   accp[w * 64 + lane] = acc;
-  __syncthreads();
+  wg_sync();
   if (w == 0 && live) {  // fixed-order sum of the wave partials, then the mean over the dynamics samples (rollout_body finish_cost)
     double t = accp[lane];
     for (int g = 1; g < GW; ++g) t += accp[g * 64 + lane];
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
   char *areas = reinterpret_cast<char *>(lds + off_area);  // [4 waves][64][SG_ROW]: one staged line per lane
   if (tid == 0) flags[0] = 0.f;
   const float x0[2] = {a.state[0], a.state[1]};
-  __syncthreads();
+  wg_sync();
   bool bad = false;
   for (int m = tid; m < M; m += nt) {
     Coef cf;
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
     bad |= av != av;
   }
   if (bad) flags[0] = 1.f;
-  __syncthreads();
+  wg_sync();
   const bool fast = flags[0] == 0.f && fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
   if (!GENERAL) {
     if (tid == 0) wg_flags[blockIdx.x] = fast ? 0u : 1u;

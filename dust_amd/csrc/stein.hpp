@@ -147,7 +147,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 #pragma unroll
   for (int t = 0; t < TPW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};
   const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;  // MFMA ownership
-  __syncthreads();
+  wg_sync();
   v2f xB[CPT / 2];
 #pragma unroll
   for (int c = 0; c < CPT / 2; ++c) xB[c] = *reinterpret_cast<const v2f *>(&Xs[iB * DP + cB + 2 * c]);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       if (!PRI) rowlane_issue<JC, DP, NT, SC1>(a.V, j0, jc, D, vv, tid);
       rowlane_commit<JC, DP, YS, NT, true>(vy, jc, D, da, a.inv_s, Ys, tid);  // the barrier that ended the previous chunk's pass B
       if (!PRI) rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs, tid);  // protects these writes
-      __syncthreads();
+      wg_sync();
     }
     DUST_STAMP(a.stamps, 2);
     DUST_TLP(tlp, 3);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
       }
     }
-    __syncthreads();
+    wg_sync();
     DUST_TLP(tlp, 4);
     if (PRI) {
       // online softmax over key chunks: row max (8 lanes per query), rescale, exponentiate in place
@@ -226,7 +226,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
         if (LOGP) rs += e;
       }
       if (LOGP) accL += oct_sum(rs);  // mass of this chunk (pass B, which would add it up, is skipped)
-      __syncthreads();
+      wg_sync();
     }
     DUST_STAMP(a.stamps, 3);
     DUST_TLP(tlp, 5);
@@ -269,7 +269,7 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
       }
       if (PRI) accL += k;
     }
-    __syncthreads();
+    wg_sync();
   }
 
   DUST_STAMP(a.stamps, 4);
@@ -380,7 +380,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
 #pragma unroll
   for (int c = 0; c < CPT / 2; ++c) accB[c] = v2f{0.f, 0.f};
   const int mw = tid >> 6, ml = tid & 63, mqh = mw >> 1, mct0 = (mw & 1) * TPW;
-  __syncthreads();
+  wg_sync();
   DUST_TLP(tlp, 8);
   v2f xB[CPT / 2];
 #pragma unroll
@@ -411,7 +411,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
       kv[(igA * QPG + ii) * (JC + 1) + jA] = v;
     }
   }
-  __syncthreads();
+  wg_sync();
   DUST_TLP(tlp, 9);
   // repulsive term: lane = (query, 8 column groups)
 #pragma unroll 4
@@ -486,7 +486,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
       }
     }
     DUST_TL(tl, 2);
-    __syncthreads();
+    wg_sync();
     // row-lane staging with sc1 loads (the rows were written through by other CUs in this launch)
     const float *base = a.V + (size_t)jbeg * D + vlc;
 #pragma unroll
@@ -495,7 +495,7 @@ __device__ __forceinline__ void stein_split_body(const PairArgs &a, float *lds, 
   DUST_TLP(tlp, 11);
   if (gate) __builtin_amdgcn_s_setprio(3);  // persistent tick: from here on the tile is on the critical path
   rowlane_commit<JC, DP, YS, NT, false>(vv, jc, D, da, a.inv_s, Vs, tid);
-  __syncthreads();
+  wg_sync();
   v4f accM[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) accM[t] = v4f{0.f, 0.f, 0.f, 0.f};

@@ -78,6 +78,13 @@ def pair_case(rng):
         c.close()
     os.environ.pop("DUST_PAIR_FUSED", None)
     tol = 1e-5 if spread < 1.0 else 4e-5
+    e_phi, e_gp = elemerr(got["1"][0], got["0"][0]), elemerr(got["1"][1], got["0"][1])
+    if not (e_phi < 1e-5 and e_gp < tol):
+        a, b = got["1"][0].reshape(N, -1), got["0"][0].reshape(N, -1)
+        d = np.abs(a - b)
+        r = np.unravel_index(d.argmax(), d.shape)
+        print("MISMATCH", (model, N, H, kernel, spread), "phi", e_phi, "gp", e_gp, "worst phi", r, a[r], b[r], "rms", float(np.sqrt((b * b).mean())),
+              "rows", np.where(d.max(1) > 1e-5 * np.sqrt((b * b).mean()))[0][:12], flush=True)
     assert elemerr(got["1"][0], got["0"][0]) < 1e-5 and elemerr(got["1"][1], got["0"][1]) < tol, (model, N, H, kernel, spread)
     assert relerr(got["1"][2], got["0"][2]) < 1e-5, (model, N, H, kernel, spread)
     return (model, N, H, kernel, spread)
