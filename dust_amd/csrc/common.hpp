@@ -506,6 +506,14 @@ __device__ __forceinline__ float quad_max(float v) {
   v = pair_max(v);
   return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
 }
+// sum over aligned groups of 2 / 4 consecutive lanes (every lane of the group gets it)
+__device__ __forceinline__ float pair_sum(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v = pair_sum(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+}
 // sum over each aligned group of 8 consecutive lanes
 __device__ __forceinline__ float oct_sum(float v) {
   auto dpp = [&](float x, auto ctrl) {

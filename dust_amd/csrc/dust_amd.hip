@@ -89,6 +89,7 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  int prior_js;  // slices of the prior partials when pairwise_fused_kernel wrote them (its own split); 0 = pair_geometry's
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
   size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
@@ -710,6 +711,15 @@ static bool pair_fused_ok(const dust_ctx *c) {
 }
 // key slices: `tiles` is the query-tile count of the PRIMARY kernel of the current state; a launcher whose kernel has another
 // tile size recomputes it (the partial-output layout [js][n_local][ldp] does not depend on the tile size)
+// resident workgroup slots of pairwise_fused_kernel: two per CU
+static int fused_slots(const dust_ctx *c) {
+  static int n_cu = 0;
+  if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) n_cu = 256;
+  static const char *env = getenv("DUST_FUSED_SLOTS");  // development switch
+  if (env) return atoi(env);
+  return 4 * n_cu;  // two rounds of two per CU: workgroups half as long, whose phases drift apart (measured: 2 460 vs 2 565 us at cfg4)
+}
+
 static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   const bool fz = pair_fused_ok(c);
   const int ti = fz ? fused_tq(c->D) : (pair_big_kernel(c) ? 4096 / pair_dpb(c->D) : PAIR_TI);
@@ -718,14 +728,14 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   int js = (512 + *tiles - 1) / *tiles;
   js = std::max(1, std::min(js, chunks));
   if (fz) {
-    // two workgroups per CU stay resident (512 slots): a grid of 513 workgroups would take two rounds for the work of one.
-    // Pick the slice count whose grid fills whole rounds best (a small penalty per slice: every slice repeats the tile prologue
-    // and adds a row of partial outputs) - at N = 2048 that is one 64-key chunk per workgroup, at N = 16384 about twenty
+    // (the regular grid of the log-p-only kernel; pairwise_fused_kernel itself splits the work by fused_geometry below)
+    // three workgroups per CU stay resident: pick the slice count whose grid fills whole rounds best (a small penalty per slice:
+    // every slice repeats the tile prologue and adds a row of partial outputs)
     double best = -1.0;
     for (int cand = 1; cand <= std::min(64, chunks); ++cand) {
       const int cps = (chunks + cand - 1) / cand, real = (chunks + cps - 1) / cps;
-      const long wgs = (long)*tiles * real, rounds = (wgs + 511) / 512;
-      const double fill = (double)wgs / (double)(rounds * 512) - 2e-3 * real;  // (ties: fewer slices)
+      const long wgs = (long)*tiles * real, rounds = (wgs + 767) / 768;
+      const double fill = (double)wgs / (double)(rounds * 768) - 2e-3 * real;  // (ties: fewer slices)
       if (fill > best) {
         best = fill;
         js = real;
@@ -737,6 +747,14 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   *JS = (c->N + *slice - 1) / *slice;
 }
 
+// pairwise_fused_kernel: tiles x chunks units in equal contiguous runs, one per resident workgroup (fused_balance); JS = the
+// largest number of runs that touch one tile = partial rows per particle
+static void fused_geometry(const dust_ctx *c, int *tiles, int *W, int *JS) {
+  const int ti = fused_tq(c->D);
+  *tiles = (c->nloc + ti - 1) / ti;
+  fused_balance(*tiles, (c->N + PAIR_JC - 1) / PAIR_JC, fused_slots(c), W, JS);
+}
+
 static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }  // pass-B columns per lane
 
 static PriorMerge prior_merge_args(const dust_ctx *c) {
@@ -744,6 +762,7 @@ static PriorMerge prior_merge_args(const dust_ctx *c) {
   memset(&pm, 0, sizeof pm);
   int tiles, slice;
   pair_geometry(c, &tiles, &pm.JS, &slice);
+  if (c->prior_js) pm.JS = c->prior_js;  // (the partials came from pairwise_fused_kernel: its own slice count)
   pm.n_local = c->nloc;
   pm.ldp = 8 * cpt_for(c->D);
   pm.pA = c->pA;
@@ -1216,12 +1235,15 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
+static void gram_geometry(const dust_ctx *c, int *JS, int *slice);
+static int ensure_partials(dust_ctx *c, int JS);
+
 // pass 1 of the fused pair (pairwise_fused.hpp): prior partials + repulsion partials + the Gram matrix of the current theta
 static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   const int dpb = fused_dpb(a.D);
   TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
   const int ldK = ((c->N + 63) / 64) * 64;
-  TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)c->nloc * ldK));
+  TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)tiles * fused_tq(a.D) * ldK));  // whole query tiles: the kernel stores rows unconditionally
   {
     const int n = c->N * dpb;
     pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
@@ -1236,16 +1258,34 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
   const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
   b.wS[0] = b.wS[1] = (1.0f / ell) * (1.0f / ell);
-  b.pB = c->pB;
   b.K = c->kmat;
   b.ldK = ldK;
-  dim3 grid(tiles, a.JS);
-#define DUST_LAUNCH_FUSED(MODE, DPB)                                                                                                      \
-  do {                                                                                                                                    \
-    const size_t lds = pairwise_fused_lds_bytes<DPB>();                                                                                   \
-    if (lds > 64 * 1024 && !c->capturing)                                                                                                 \
-      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_fused_kernel<MODE, DPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    pairwise_fused_kernel<MODE, DPB><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                          \
+  b.tiles = tiles;
+  b.chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
+  int W, tl;
+  fused_geometry(c, &tl, &W, &b.p.JS);  // (a.JS / a.slice describe the regular grid of the other kernels)
+  int jsg, slg;
+  gram_geometry(c, &jsg, &slg);
+  TRY(ensure_partials(c, std::max(std::max(a.JS, b.p.JS), jsg)));  // before anything is written: pass 2 adds its pA rows later
+  b.p.pA = c->pA;
+  b.p.pM = c->pM;
+  b.p.pL = c->pL;
+  c->prior_js = b.p.JS;
+  // the Gram rows are streamed past the caches when they exceed what L2 + Infinity Cache would hand to pass 2 anyway
+  const bool stream_k = (size_t)c->nloc * ldK * sizeof(float) > ((size_t)128 << 20);
+  b.pB = c->pB;
+  dim3 grid(W);
+#define DUST_LAUNCH_FUSED2(MODE, DPB, SK)                                                                                                     \
+  do {                                                                                                                                        \
+    const size_t lds = pairwise_fused_lds_bytes<DPB>();                                                                                       \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_fused_kernel<MODE, DPB, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    pairwise_fused_kernel<MODE, DPB, SK><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                          \
+  } while (0)
+#define DUST_LAUNCH_FUSED(MODE, DPB)                   \
+  do {                                                 \
+    if (stream_k) DUST_LAUNCH_FUSED2(MODE, DPB, true); \
+    else DUST_LAUNCH_FUSED2(MODE, DPB, false);         \
   } while (0)
 #define DUST_PICK_FUSED(MODE)                  \
   do {                                         \
@@ -1257,6 +1297,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   else DUST_PICK_FUSED(PAIR_K1);
 #undef DUST_PICK_FUSED
 #undef DUST_LAUNCH_FUSED
+#undef DUST_LAUNCH_FUSED2
   HIP_TRY(hipGetLastError());
   c->kmat_valid = true;
   return DUST_OK;
@@ -1288,8 +1329,20 @@ static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
-// pass 2: pA = K x score over the same key slices (matrix cores)
-static int launch_gram_score(dust_ctx *c, const PairArgs &a) {
+// key slices of pass 2: its own regular grid (64-query tiles x slices), one resident round of four workgroups per CU when the
+// set allows it - the fewer slices, the fewer partial rows the update kernel has to sum
+static void gram_geometry(const dust_ctx *c, int *JS, int *slice) {
+  const int tiles = (c->nloc + 63) / 64, chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
+  static const char *env = getenv("DUST_GRAM_SLOTS");  // development switch
+  const int slots = env ? atoi(env) : 2 * fused_slots(c);
+  int js = std::max(1, std::min(chunks, slots / tiles));
+  const int cps = (chunks + js - 1) / js;
+  *slice = cps * PAIR_JC;
+  *JS = (c->N + *slice - 1) / *slice;
+}
+
+// pass 2: pA = K x score over key slices (matrix cores)
+static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
   const int dpb = fused_dpb(a.D);
   GramScoreArgs g;
   memset(&g, 0, sizeof g);
@@ -1297,14 +1350,14 @@ static int launch_gram_score(dust_ctx *c, const PairArgs &a) {
   g.D = c->D;
   g.i0 = c->n0;
   g.n_local = c->nloc;
-  g.JS = a.JS;
-  g.slice = a.slice;
+  gram_geometry(c, &g.JS, &g.slice);  // (the partial buffers were sized for it by launch_pair_fused)
+  *JS_out = g.JS;
   g.ldp = 8 * cpt_for(a.D);
   g.ldK = ((c->N + 63) / 64) * 64;
   g.K = c->kmat;
   g.V = c->score;
   g.pA = c->pA;
-  dim3 grid((c->nloc + 63) / 64, a.JS);
+  dim3 grid((c->nloc + 63) / 64, g.JS);
 #define DUST_LAUNCH_GS(DPB) gram_score_kernel<DPB><<<grid, PAIR_NT, gram_score_lds_bytes<DPB>(), c->stream>>>(g)
   if (dpb == 32) DUST_LAUNCH_GS(32);
   else if (dpb == 64) DUST_LAUNCH_GS(64);
@@ -1351,6 +1404,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   int tiles;
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
+  c->prior_js = 0;  // (launch_pair_fused sets its own slice count)
   if (logp_only && pair_fused_ok(c)) return launch_pair_logp_big(c, a, tiles);            // large aliased set: distance pass + log-sum-exp
   if (logp_only && !pair_big_kernel(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
   if (!logp_only && pair_fused_ok(c)) return launch_pair_fused(c, a, tiles);              // + repulsion + Gram matrix (pairwise_fused.hpp)
@@ -1500,6 +1554,7 @@ static K2Args k2_args(dust_ctx *c) {
 // Stein pass (+ optimiser step when apply != 0).  K1 / IMQ: tiled partials -> update_kernel; K2: bandwidths + phi, then update.
 static int launch_stein_update(dust_ctx *c, int apply) {
   const int n = c->nloc * c->D;
+  int jsa = 0;  // slices of pA when pass 2 of the fused pair wrote it
   if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
     {
       Prof p(c, DUST_K_BANDWIDTH);
@@ -1591,12 +1646,17 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     Prof p(c, DUST_K_STEIN);
     if (c->kmat_valid && pair_fused_ok(c)) {
       // the prior pass of this iteration already produced the repulsion partials and the Gram matrix of this theta
-      TRY(launch_gram_score(c, a));
+      TRY(launch_gram_score(c, a, &jsa));
     } else if (c->cfg.kernel == DUST_KERNEL_IMQ) TRY(launch_pair<PAIR_IMQ>(c, a, tiles));
     else TRY(launch_pair<PAIR_K1>(c, a, tiles));
   }
   c->kmat_valid = false;  // (theta moves below; a later Stein pass without a fresh prior pass recomputes)
   UpdateArgs u = update_args(c, apply);
+  if (jsa) {  // pA from pass 2 (its own slices), pB from pairwise_fused_kernel
+    int tl, W;
+    u.JSA = jsa;
+    fused_geometry(c, &tl, &W, &u.JS);
+  }
   Prof p(c, DUST_K_UPDATE);
   update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
   HIP_TRY(hipGetLastError());

@@ -30,9 +30,29 @@ struct PairFusedArgs {
   float wP[2];      // 1 / sigma_p^2 for even / odd dimensions
   float wS[2];      // 1 / ell^2 (both)
   float *pB;        // [JS][n_local][ldp] repulsion partials
-  float *K;         // [n_local][ldK] Stein kernel values
+  float *K;         // [tiles * TQ][ldK] Stein kernel values (tiles * TQ >= n_local: whole query tiles)
   int ldK;
+  int tiles, chunks;  // query tiles of TQ rows, key chunks of 64: the launch covers tiles * chunks units (see fused_balance)
 };
+
+// Work split of pairwise_fused_kernel.  A unit is (query tile, 64-key chunk), units ordered tile-major; workgroup s of W takes the
+// contiguous run [s T / W, (s + 1) T / W) of the T = tiles * chunks units: every workgroup does the same work to within one
+// chunk and the launch is ONE resident round (W = 2 per CU).  A (tile, key slice) grid has to round its workgroup count up to
+// whole rounds instead - 171 tiles x 20 slices = 6.7 rounds of 512 at N = 16384: 4 % idle, and 20 partial rows per particle
+// for the merge kernels against 4 here.  A run that crosses a tile boundary flushes its partial sums and starts the next tile;
+// the runs that cover tile t are numbered 0 .. m(t) - 1 in order (the partial-slice index), JS = max m(t); the run holding a
+// tile's last chunk also writes the neutral rows of the unused slices.  Static, so the summation order is fixed.
+static inline long fused_first_wg(long unit, long W, long T) { return ((unit + 1) * W - 1) / T; }  // the workgroup whose run holds `unit`
+static inline void fused_balance(int tiles, int chunks, int slots, int *W_out, int *JS_out) {
+  const long T = (long)tiles * chunks, W = T < slots ? T : slots;
+  int js = 1;
+  for (int t = 0; t < tiles; ++t) {
+    const long m = fused_first_wg((long)t * chunks + chunks - 1, W, T) - fused_first_wg((long)t * chunks, W, T) + 1;
+    js = m > js ? (int)m : js;
+  }
+  *W_out = (int)W;
+  *JS_out = js;
+}
 
 template <int DPB>
 struct FusedGeom {
@@ -47,13 +67,13 @@ struct FusedGeom {
 template <int DPB>
 static inline size_t pairwise_fused_lds_bytes() {
   using G = FusedGeom<DPB>;
-  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 2 * (size_t)G::TQ);
+  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 3 * (size_t)G::TQ);
 }
 
 #ifndef DUST_FUSED_WGS
 #define DUST_FUSED_WGS 2  // resident workgroups per CU the register budget is set for (tools/fused_race.hip builds it at 1 too)
 #endif
-template <int MODE /* PAIR_K1 / PAIR_IMQ: the Stein kernel */, int DPB>
+template <int MODE /* PAIR_K1 / PAIR_IMQ: the Stein kernel */, int DPB, bool STREAM_K = true>
 __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel(const PairFusedArgs b) {
   using G = FusedGeom<DPB>;
   constexpr int JC = PAIR_JC, NT = PAIR_NT, TQ = G::TQ, YS = G::YS, KS = G::KS, CB = G::CB, LCG = G::LCG, NV = CB / 4;
@@ -65,21 +85,29 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const PairArgs &a = b.p;
   float *Ys = lds;                 // [JC][YS] keys (raw coordinates, zero padded)
-  float *kvP = Ys + JC * YS;       // [TQ][KS] prior logits -> softmax terms
-  float *kvS = kvP + TQ * KS;      // [TQ][KS] Stein kernel values
-  float *mrow = kvS + TQ * KS;     // [TQ] running max
-  float *scl = mrow + TQ;          // [TQ] rescale factor of this chunk
+  v2f *kv = reinterpret_cast<v2f *>(Ys + JC * YS);  // [TQ][KS] (prior logit -> softmax term, Stein kernel value): pass B fetches the
+  float *kvf = reinterpret_cast<float *>(kv);       //           two weights of a (query, key) with one 8-byte read
+  float *mrow = kvf + 2 * TQ * KS;  // [TQ] running max
+  float *scl = mrow + TQ;           // [TQ] rescale factor of this chunk
+  float *lrow = scl + TQ;           // [TQ] running sum of the softmax terms (relative to mrow)
   const int tid = threadIdx.x, D = a.D, N = a.N;
-  const int tile = blockIdx.x, js = blockIdx.y;
-  const int ib = a.i0 + tile * TQ;  // first query (global index)
-  const int jbeg = js * a.slice, jend = min(N, jbeg + a.slice);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), jA = tid & 63;
   const int qg = tid / LCG, cg = tid - qg * LCG, c0 = CB * cg;  // pass-B ownership: queries qg + QS r, columns c0 .. c0 + CB - 1
   const bool pb = qg < TQ / 4;                                  // (DPB = 80: 240 of the 256 lanes)
   const int qgc = pb ? qg : 0;
 
+  // this workgroup's run of units (fused_balance), one tile segment at a time
+  const long T = (long)b.tiles * b.chunks;
+  int unit = (int)((long)blockIdx.x * T / gridDim.x);
+  const int unit_end = (int)(((long)blockIdx.x + 1) * T / gridDim.x);
+  while (unit < unit_end) {
+  const int tile = unit / b.chunks, ch0 = unit - tile * b.chunks, ch1 = min(b.chunks, ch0 + (unit_end - unit));
+  const int js = (int)blockIdx.x - (int)((((long)tile * b.chunks + 1) * gridDim.x - 1) / T);  // ordinal of this run within the tile
+  const int ib = a.i0 + tile * TQ;  // first query (global index)
+  const int jbeg = ch0 * JC, jend = min(N, ch1 * JC);
+  unit += ch1 - ch0;
+
   v4f xB[4][NV] /* -x_i */, accA[4][NV], accB[4][NV];
-  float accL[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gi = min(ib + qgc + QS * r, N - 1);
@@ -89,9 +117,11 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       asm volatile("" : "+v"(xB[r][u]));  // (opaque: otherwise the negation folds back into 4 scalar v_sub_f32 per difference)
       accA[r][u] = accB[r][u] = v4f{0.f, 0.f, 0.f, 0.f};
     }
-    accL[r] = 0.f;
   }
-  for (int i = tid; i < TQ; i += NT) mrow[i] = -INFINITY;
+  for (int i = tid; i < TQ; i += NT) {
+    mrow[i] = -INFINITY;
+    lrow[i] = 0.f;
+  }
 
   // Key chunks: the keys ARE the particles (prior means aliased to theta), so a chunk is rows j0 .. j0 + 63 of the padded copy -
   // one contiguous 64 * DPB float run, fetched with 16-byte loads (NLD per lane).  The NEXT chunk's loads are issued before pass B
@@ -140,7 +170,9 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         const int i = wave * QW + qi;  // wave-uniform
         // uniform addresses -> scalar loads.  The kernel also STORES to global memory inside this loop (the Gram rows), so a plain
         // load of Xp counts as clobberable and would become a per-lane vector load; the padded query copy is never written by
-        // this kernel: address it through the constant address space, whose loads are invariant by definition
+        // this kernel: address it through the constant address space, whose loads are invariant by definition.  (Scalar loads
+        // return out of order, so each wait drains all of them: 3 waits per query pair.  Rotating two register sets so that a
+        // batch lands under the previous one's FMAs changed nothing - the second wave of the SIMD already covers the latency.)
         typedef const v2f __attribute__((address_space(4))) * cv2;
         const cv2 xa = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i, N - 1) * DPB);
         const cv2 xb = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i + 1, N - 1) * DPB);
@@ -167,8 +199,6 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         // prior logit and Stein kernel value from the same squared differences
         const float pa = da2.x * b.wP[0] + da2.y * b.wP[1], pbq = db2.x * b.wP[0] + db2.y * b.wP[1];
         const float sa = da2.x * b.wS[0] + da2.y * b.wS[1], sb = db2.x * b.wS[0] + db2.y * b.wS[1];
-        kvP[i * KS + jA] = kval ? lm - 0.5f * pa : -INFINITY;
-        kvP[(i + 1) * KS + jA] = kval ? lm - 0.5f * pbq : -INFINITY;
         float ka, kb;
         if (MODE == PAIR_K1) {
           ka = __builtin_amdgcn_exp2f(-0.72134752044448170f * sa);
@@ -179,12 +209,21 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         }
         ka = kval ? ka : 0.f;
         kb = kval ? kb : 0.f;
-        kvS[i * KS + jA] = ka;
-        kvS[(i + 1) * KS + jA] = kb;
-        // Gram matrix rows for pass 2: one 256-byte run per query and wave
+        kv[i * KS + jA] = v2f{kval ? lm - 0.5f * pa : -INFINITY, ka};
+        kv[(i + 1) * KS + jA] = v2f{kval ? lm - 0.5f * pbq : -INFINITY, kb};
+        // Gram matrix rows for pass 2: one 256-byte run per query and wave, streamed past the caches when pass 2 will read them
+        // from HBM anyway (a 1 GB matrix at N = 16384: -7 % on this kernel).  Unconditional - no exec-mask branches inside the
+        // distance loop (-6 %): K holds gridDim.x * TQ rows of ldK >= 64 ceil(N / 64) floats, so the rows behind n_local and the
+        // columns behind N exist (the latter receive 0)
         const int il = tile * TQ + i;
-        if (kval && il < a.n_local) b.K[(size_t)il * b.ldK + j0 + jA] = ka;
-        if (kval && il + 1 < a.n_local) b.K[(size_t)(il + 1) * b.ldK + j0 + jA] = kb;
+        float *ka_p = &b.K[(size_t)il * b.ldK + j0 + jA], *kb_p = ka_p + b.ldK;
+        if (STREAM_K) {
+          __builtin_nontemporal_store(ka, ka_p);
+          __builtin_nontemporal_store(kb, kb_p);
+        } else {
+          *ka_p = ka;
+          *kb_p = kb;
+        }
       }
     }
     wg_sync();
@@ -194,19 +233,25 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       if (q < TQ) {
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < JC / LQ; ++t) m = fmaxf(m, kvP[q * KS + l + LQ * t]);
+        for (int t = 0; t < JC / LQ; ++t) m = fmaxf(m, kvf[2 * (q * KS + l + LQ * t)]);
         m = LQ == 8 ? oct_max(m) : (LQ == 4 ? quad_max(m) : pair_max(m));
         const float mo = mrow[q];
         const float mn = fmaxf(mo, m);
+        float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < JC / LQ; ++t) {
           const int jj = l + LQ * t;
-          const float lg = kvP[q * KS + jj];
-          kvP[q * KS + jj] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((lg - mn) * 1.44269504088896340736f);
+          const float lg = kvf[2 * (q * KS + jj)];
+          const float e = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((lg - mn) * 1.44269504088896340736f);
+          kvf[2 * (q * KS + jj)] = e;  // (a 4-byte store: the kernel value beside it stays)
+          sum += e;
         }
+        sum = LQ == 8 ? oct_sum(sum) : (LQ == 4 ? quad_sum(sum) : pair_sum(sum));  // the chunk's mass of this query
         if (l == 0) {  // the LQ lanes of a query run in lockstep: all have read mrow[q] by now
+          const float sc = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
           mrow[q] = mn;
-          scl[q] = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
+          scl[q] = sc;
+          lrow[q] = lrow[q] * sc + sum;
         }
       }
       wg_sync();
@@ -215,7 +260,6 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         const float sc = scl[qgc + QS * r];
 #pragma unroll
         for (int u = 0; u < NV; ++u) accA[r][u] *= sc;
-        accL[r] *= sc;
       }
     }
     const bool more = j0 + JC < jend;
@@ -229,8 +273,8 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         for (int u = 0; u < NV; ++u) yv[u] = *reinterpret_cast<const v4f *>(&Ys[jj * YS + c0 + 4 * u]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float wp = kvP[(qg + QS * r) * KS + jj];
-          const float ks = kvS[(qg + QS * r) * KS + jj];
+          const v2f wk = kv[(qg + QS * r) * KS + jj];
+          const float wp = wk.x, ks = wk.y;
           // -k' of stein.hpp's pass B: accB += k' (x_i - y_j) = (-k') (y_j - x_i), the same product bit for bit
           const float nk = (MODE == PAIR_K1) ? ks : (ks * ks) * ks;
 #pragma unroll
@@ -239,11 +283,10 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
             accA[r][u] = __builtin_elementwise_fma(v4f{wp, wp, wp, wp}, diff, accA[r][u]);
             accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
           }
-          accL[r] += wp;
         }
       }
     }
-    wg_sync();  // pass B is done with Ys / kvP / kvS
+    wg_sync();  // pass B is done with Ys / kv
     if (more) keys_commit(j0 + JC);
   }
 
@@ -262,9 +305,25 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         }
       if (cg == 0) {
         a.pM[(size_t)js * a.n_local + il] = mrow[qg + QS * r];
-        a.pL[(size_t)js * a.n_local + il] = accL[r];
+        a.pL[(size_t)js * a.n_local + il] = lrow[qg + QS * r];
       }
     }
+  }
+  if (ch1 == b.chunks) {  // the tile is complete: neutral rows for the slices it does not use (-inf / 0 mass, zero sums)
+    const int rows = min(TQ, a.n_local - tile * TQ), l4 = b.ldp / 4;
+    for (int k = js + 1; k < a.JS; ++k) {
+      const size_t r0 = (size_t)k * a.n_local + (size_t)tile * TQ;
+      for (int idx = tid; idx < rows * l4; idx += NT) {
+        *reinterpret_cast<v4f *>(a.pA + r0 * b.ldp + 4 * (size_t)idx) = v4f{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<v4f *>(b.pB + r0 * b.ldp + 4 * (size_t)idx) = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int idx = tid; idx < rows; idx += NT) {
+        a.pM[r0 + idx] = -INFINITY;
+        a.pL[r0 + idx] = 0.f;
+      }
+    }
+  }
+  wg_sync();  // the next segment re-initialises mrow / lrow and refills Ys
   }
 }
 
@@ -297,6 +356,17 @@ __global__ __launch_bounds__(PAIR_NT, 3) void pairwise_logp_big_kernel(const Pai
   for (int i = tid; i < TQ; i += NT) {
     mrow[i] = -INFINITY;
     lrow[i] = 0.f;
+  }
+  if (jbeg >= jend) {  // (a slice behind the last key: neutral partials)
+    wg_sync();
+    for (int i = tid; i < TQ; i += NT) {
+      const int il = tile * TQ + i;
+      if (il < a.n_local) {
+        a.pM[(size_t)js * a.n_local + il] = -INFINITY;
+        a.pL[(size_t)js * a.n_local + il] = 0.f;
+      }
+    }
+    return;
   }
   constexpr int NLD = (JC * DPB / 4 + NT - 1) / NT;
   v4f ky[NLD];

@@ -613,6 +613,7 @@ __global__ void prior_finish_kernel(const PriorFinishArgs a) {
 // optimizer.step()).  Writes phi, theta in place (row-major) - each element is touched by exactly one lane.
 struct UpdateArgs {
   int N, D, i0, n_local, JS;
+  int JSA;               // slices of pA when they differ from pB's (pass 2 of pairwise_fused.hpp has its own grid); 0 = JS
   int ldp;               // row stride of pA / pB (D padded to 8*CPT)
   int optimizer, apply;  // apply = 0: only materialise phi (stage-wise SVMPC.phi)
   float lr, beta1, beta2, eps;
@@ -656,25 +657,26 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) 
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   float th = a.apply ? a.theta[o] : 0.f;  // independent of the partials: in flight together with them
   float sa = 0.f, sb = 0.f;
-  for (int q0 = 0; q0 < a.JS; q0 += 16) {  // 32 independent loads in flight (one round trip for JS <= 16), fixed summation order
+  const int JSA = a.JSA > 0 ? a.JSA : a.JS;
+  for (int q0 = 0; q0 < max(a.JS, JSA); q0 += 16) {  // 32 independent loads in flight (one round trip for JS <= 16), fixed summation order
     float va[16], vb[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const size_t p = ((size_t)min(q0 + u, a.JS - 1) * a.n_local + il) * a.ldp + d;
+      const size_t pa = ((size_t)min(q0 + u, JSA - 1) * a.n_local + il) * a.ldp + d;
+      const size_t pb = ((size_t)min(q0 + u, a.JS - 1) * a.n_local + il) * a.ldp + d;
       if (SC1) {
-        va[u] = __hip_atomic_load(a.pA + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        vb[u] = __hip_atomic_load(a.pB + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        va[u] = __hip_atomic_load(a.pA + pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb[u] = __hip_atomic_load(a.pB + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        va[u] = a.pA[p];
-        vb[u] = a.pB[p];
+        va[u] = a.pA[pa];
+        vb[u] = a.pB[pb];
       }
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (q0 + u < a.JS) {
-        sa += va[u];
-        sb += vb[u];
-      }
+    for (int u = 0; u < 16; ++u) {
+      if (q0 + u < JSA) sa += va[u];
+      if (q0 + u < a.JS) sb += vb[u];
+    }
   }
   // (after the partials have been read: whatever admitted this lane to them also means every rollout has read the counter)
   if (a.apply && idx == a.n_local * a.D - 1) a.ctr[1] += 1u;
