@@ -291,21 +291,28 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
   }
 
   // ---- partial outputs (layout of stein.hpp: [js][n_local][ldp], raw coordinates) ----
-  if (pb) {
+  {
+    // (lane coordinates re-derived from an opaque copy of tid: otherwise the output offsets, invariant across the segments, are
+    //  hoisted out of the segment loop and held - spilled - across the chunk loop)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int qg_e = tid_e / LCG, cg_e = tid_e - qg_e * LCG, c0_e = CB * cg_e;
+    if (qg_e < TQ / 4) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int il = tile * TQ + qg + QS * r;
-      if (il >= a.n_local) continue;
-      const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
+      for (int r = 0; r < 4; ++r) {
+        const int il = tile * TQ + qg_e + QS * r;
+        if (il >= a.n_local) continue;
+        const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
 #pragma unroll
-      for (int u = 0; u < NV; ++u)
-        if (c0 + 4 * u < b.ldp) {
-          *reinterpret_cast<v4f *>(a.pA + row + c0 + 4 * u) = accA[r][u];
-          *reinterpret_cast<v4f *>(b.pB + row + c0 + 4 * u) = accB[r][u];
+        for (int u = 0; u < NV; ++u)
+          if (c0_e + 4 * u < b.ldp) {
+            *reinterpret_cast<v4f *>(a.pA + row + c0_e + 4 * u) = accA[r][u];
+            *reinterpret_cast<v4f *>(b.pB + row + c0_e + 4 * u) = accB[r][u];
+          }
+        if (cg_e == 0) {
+          a.pM[(size_t)js * a.n_local + il] = mrow[qg_e + QS * r];
+          a.pL[(size_t)js * a.n_local + il] = lrow[qg_e + QS * r];
         }
-      if (cg == 0) {
-        a.pM[(size_t)js * a.n_local + il] = mrow[qg + QS * r];
-        a.pL[(size_t)js * a.n_local + il] = lrow[qg + QS * r];
       }
     }
   }
