@@ -108,3 +108,43 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
     assert len(hot) >= 45, sorted(kernels)
     bad = {k: kernels[k] for k in hot if kernels[k] != (0, 0)}
     assert not bad, "VGPR spills / scratch in hot kernels (name: (spilled VGPRs, scratch bytes)): %r" % bad
+
+
+def test_every_barrier_drains_lds_first(built, tmp_path):
+    """`s_barrier` does not wait for LDS instructions the issuing wave still has queued, and the compiler leaves the
+    `s_waitcnt lgkmcnt(0)` out of __syncthreads() where it believes nothing is pending - at a loop header whose back edge ended
+    in ds_write_b128 that cost pairwise_fused_kernel four stale key rows in one launch out of ten (round 2,
+    tools/fused_race.hip).  Every barrier of the library goes through wg_sync() / lds_barrier(), which spell the wait out: in the
+    shipped code object each s_barrier must have `s_waitcnt ... lgkmcnt(0)` among the few instructions before it with no LDS
+    memory access in between."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(llvm + "/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    so = str(tmp_path / "l.so")
+    shutil.copy(built, so)
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", "l.so"], cwd=str(tmp_path), check=True, capture_output=True)
+    co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert co, "no gfx950 code object in libdust_amd.so"
+    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", co[0]], cwd=str(tmp_path), check=True, capture_output=True,
+                         text=True).stdout.split("\n")
+    ins = [ln.split("//")[0].strip() for ln in dis]
+    lds_mem = re.compile(r"^ds_(read|write|load|store|add|sub|min|max|and|or|xor|inc|dec|cmpst|wrxchg|append|consume)")
+    total, bad = 0, []
+    for i, t in enumerate(ins):
+        if not t.startswith("s_barrier"):
+            continue
+        total += 1
+        ok = False
+        for j in range(i - 1, max(i - 40, 0), -1):  # (the scheduler may slide VALU work between the wait and the barrier)
+            if lds_mem.match(ins[j]):
+                break
+            if ins[j].startswith("s_waitcnt") and "lgkmcnt(0)" in ins[j]:
+                ok = True
+                break
+        if not ok:
+            bad.append(i)
+    assert total > 500, total
+    assert not bad, "%d of %d barriers without an LDS drain right before them (first at disassembly line %d)" % (len(bad), total, bad[0])

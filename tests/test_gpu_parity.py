@@ -887,6 +887,36 @@ def test_fused_large_pairwise_vs_oracle(model, N, H, kernel, spread):
             os.environ.pop("DUST_PAIR_FUSED", None)
 
 
+@pytest.mark.parametrize("N,H", [(2254, 56), (2986, 50), (2304, 30)])
+def test_fused_pairwise_is_deterministic(N, H):
+    """Twelve launches of the fused pair on the same nearly collapsed Pendulum set: bit-identical phi and grad_pri.  These are the
+    shapes (64-wide tiles, ragged N) at which one launch in ten used to read four stale key rows: `s_barrier` does not wait for
+    the issuing wave's queued LDS writes, and the compiler had left the `s_waitcnt lgkmcnt(0)` out of the barrier at the head of
+    the chunk loop (common.hpp wg_sync; tools/fused_race.hip runs the kernel alone)."""
+    from dust_amd import Context
+
+    rng = np.random.default_rng(N + H)
+    S = 4
+    theta = (0.05 * rng.standard_normal((N, H, 1))).astype(np.float32)
+    costs = (30.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, 1))).astype(np.float32)
+    mixw = rng.random(N).astype(np.float32) + 0.05
+    os.environ["DUST_PAIR_FUSED"] = "1"
+    try:
+        c = Context(model="pendulum", N=N, S=S, M=1, H=H, kernel="K1", lr=0.0, sigma_a=1.5, sigma_p=1.5, weighted_prior=True, seed=5)
+        c.set_theta(theta)
+        c.set_prior(theta)
+        c.set_a_mat(theta)
+        c.svmpc_update_prior(mixw)
+        phi, _, gp = c.svmpc_phi(costs, actions)
+        for rep in range(11):
+            phi2, _, gp2 = c.svmpc_phi(costs, actions)
+            assert np.array_equal(phi2, phi) and np.array_equal(gp2, gp), rep
+        c.close()
+    finally:
+        os.environ.pop("DUST_PAIR_FUSED", None)
+
+
 def test_sharded_large_set_takes_fused_pairwise():
     """A rank of a sharded run with >= 512 local particles and N >= 2048 keys takes the fused large-set pairwise launches too
     (its Gram matrix is [n_local][N]): 2 and 4 shards in one process against the unsharded context, Particle D = 80."""
