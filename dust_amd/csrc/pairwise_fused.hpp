@@ -16,8 +16,10 @@
 // 1 D (distance) + 2 D (difference, two FMAs) packed lane-ops here + D on the matrix cores, against 2 x (1 D + 1 D) + D before.
 //
 // Register blocking: pass A lane = key (row in registers), query rows wave-uniform through scalar loads (as pairwise_big.hpp);
-// pass B lane = 4 queries x CB columns.  CB = 8 at D > 64: per key 2 b128 reads of the key row + 8 b32 reads of the two weights
-// feed 72 packed lane-ops - the LDS pipe stays below half of the four SIMDs' demand (at CB = 4 it would saturate).
+// pass B lane = 4 queries x CB columns.  CB = 8 at D > 32: per key 2 b128 reads of the key row + 4 b64 reads of the (softmax
+// term, kernel value) pairs feed 48 packed lane-ops - the LDS pipe stays well below the four SIMDs' demand (at CB = 4 the two
+// balance: the 64-wide tile ran 1.75x slower per flop than the 80-wide one until it took CB = 8 with 28 of its 32 query groups).
+// Work split: equal contiguous runs of (query tile, key chunk) units per workgroup (fused_balance below), not a (tile, slice) grid.
 #pragma once
 #include "stein.hpp"
 
@@ -56,10 +58,11 @@ static inline void fused_balance(int tiles, int chunks, int slots, int *W_out, i
 
 template <int DPB>
 struct FusedGeom {
-  static constexpr int CB = DPB <= 64 ? 4 : 8;           // columns per lane in pass B
+  static constexpr int CB = DPB <= 32 ? 4 : 8;           // columns per lane in pass B
   static constexpr int LCG = DPB / CB;                   // column groups
   static constexpr int QG = (PAIR_NT / LCG) & ~1;        // query groups of 4 (even: pass A walks query pairs)
-  static constexpr int TQ = 4 * (QG > 32 ? 32 : QG);     // queries per tile: 128 / 64 / 96 at DPB = 32 / 64 / 80
+  static constexpr int QGU = DPB == 64 ? 28 : (QG > 32 ? 32 : QG);  // groups in use (DPB = 64: 32 would need 84 KB of LDS - one workgroup per CU)
+  static constexpr int TQ = 4 * QGU;                     // queries per tile: 128 / 112 / 96 at DPB = 32 / 64 / 80
   static constexpr int KS = PAIR_JC + 1;
   static constexpr int YS = DPB + 4;
 };

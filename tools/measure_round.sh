@@ -30,7 +30,7 @@ timeout 900 python tools/configs_bench.py $O/configs.json > $O/configs.log 2>&1
 timeout 300 python tools/pair_probe.py > $O/pair_probe.log 2>&1
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pair_stats -o p -- python3 $R/tools/pair_probe.py cfg4 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pair_pmc -o p -- python3 $R/tools/pair_probe.py cfg4 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pair_pmc -o p -- python3 $R/tools/pair_probe.py cfg4 > /dev/null 2>&1
 cd $R
 python tools/pmc_summary.py $O/pair_pmc.json $O/pair_pmc > /dev/null
 rm -rf $O/pair_pmc; find $O/pair_stats -name "*kernel_trace*" -delete
