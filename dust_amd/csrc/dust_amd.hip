@@ -711,13 +711,20 @@ static bool pair_fused_ok(const dust_ctx *c) {
 }
 // key slices: `tiles` is the query-tile count of the PRIMARY kernel of the current state; a launcher whose kernel has another
 // tile size recomputes it (the partial-output layout [js][n_local][ldp] does not depend on the tile size)
-// resident workgroup slots of pairwise_fused_kernel: two per CU
-static int fused_slots(const dust_ctx *c) {
+// workgroups of pairwise_fused_kernel for `units` (query tile, key chunk) units: two stay resident per CU.  Two rounds of
+// half-length workgroups run 4 % faster than one (their phases drift apart: 2 460 vs 2 565 us at cfg4) as long as a workgroup
+// keeps >= 16 chunks to amortise its tile prologue / partial rows over; below that (a rank of an 8-way sharded cfg4: 5.5 chunks)
+// one round - half the partial rows for the merge and update kernels (523 vs 536 us per iteration there)
+static int device_cus(const dust_ctx *c) {
   static int n_cu = 0;
   if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) n_cu = 256;
+  return n_cu;
+}
+static int fused_slots(const dust_ctx *c, long units) {
   static const char *env = getenv("DUST_FUSED_SLOTS");  // development switch
   if (env) return atoi(env);
-  return 4 * n_cu;  // two rounds of two per CU: workgroups half as long, whose phases drift apart (measured: 2 460 vs 2 565 us at cfg4)
+  const int n_cu = device_cus(c);
+  return units >= 16L * 4 * n_cu ? 4 * n_cu : 2 * n_cu;
 }
 
 static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
@@ -752,7 +759,8 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
 static void fused_geometry(const dust_ctx *c, int *tiles, int *W, int *JS) {
   const int ti = fused_tq(c->D);
   *tiles = (c->nloc + ti - 1) / ti;
-  fused_balance(*tiles, (c->N + PAIR_JC - 1) / PAIR_JC, fused_slots(c), W, JS);
+  const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
+  fused_balance(*tiles, chunks, fused_slots(c, (long)*tiles * chunks), W, JS);
 }
 
 static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }  // pass-B columns per lane
@@ -1334,7 +1342,7 @@ static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
 static void gram_geometry(const dust_ctx *c, int *JS, int *slice) {
   const int tiles = (c->nloc + 63) / 64, chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
   static const char *env = getenv("DUST_GRAM_SLOTS");  // development switch
-  const int slots = env ? atoi(env) : 2 * fused_slots(c);
+  const int slots = env ? atoi(env) : 8 * device_cus(c);
   int js = std::max(1, std::min(chunks, slots / tiles));
   const int cps = (chunks + js - 1) / js;
   *slice = cps * PAIR_JC;

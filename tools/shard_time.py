@@ -9,7 +9,7 @@ import numpy as np
 
 from dust_amd.parallel import DeviceShard
 
-for G in (1, 2, 4, 8):
+for G in (() if (len(sys.argv) > 1 and sys.argv[1] == "cfg4") else (1, 2, 4, 8)):
     N = 1024 * G
     cfg = dict(model="pendulum", N=N, S=128, M=1, H=30, kernel="K1", lr=2.0, sigma_a=2.0, sigma_p=2.0, seed=3)
     rng = np.random.default_rng(0)
@@ -35,3 +35,37 @@ for G in (1, 2, 4, 8):
     pk = {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}
     print("G=%d N=%d: %.1f us per iteration (local score + Stein/update), unfused kernels: %s" % (G, N, el * 1e6, pk), flush=True)
     sh.ctx.close()
+
+# the strong-scaled bench (`bench.py --gpus G`: BASELINE cfg4, Particle N = 16384 in total): one rank's share, collectives excluded
+if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
+    from bench import particle_grid
+
+    for G in ([int(g) for g in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
+        N, S, M, H = 16384, 64, 4, 40
+        cfg = dict(model="particle", N=N, S=S, M=M, H=H, kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0, uncertain_params=("mass",),
+                   grid=particle_grid(), seed=3)
+        rng = np.random.default_rng(0)
+        mu = rng.standard_normal((N, H, 2)).astype(np.float32)
+        th = (mu + rng.standard_normal((N, H, 2))).astype(np.float32)
+        sh = DeviceShard(cfg, 0, G, use_torch_stream=False)
+        sh.set_state(th, th)
+        sh.ctx.svmpc_update_prior(np.full(N, 1.0 / N, np.float32))  # the prior means alias theta, as after every forward()
+        state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+        params = (1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+        for rep in range(2):
+            sh.ctx.sync()
+            t0 = time.perf_counter()
+            iters = 20
+            for _ in range(iters):
+                sh.local_score(state, params=params)
+                sh.apply_phi()
+            sh.ctx.sync()
+            el = (time.perf_counter() - t0) / iters
+        sh.ctx.profile(True)
+        for _ in range(5):
+            sh.local_score(state, params=params)
+            sh.apply_phi()
+        sh.ctx.sync()
+        pk = {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}
+        print("cfg4 G=%d n_local=%d: %.0f us per iteration (local score + Stein/update), kernels: %s" % (G, N // G, el * 1e6, pk), flush=True)
+        sh.ctx.close()
