@@ -2802,8 +2802,8 @@ extern "C" int dust_debug_stamps(dust_ctx *c, int kernel_id, unsigned long long 
   if (!c->stamps_dev) {
     HIP_TRY(hipMalloc((void **)&c->stamps_dev, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->stamps_dev, 0, 16 * DUST_K_COUNT * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&c->tl_dev, 2048 * 64 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->tl_dev, 0, 2048 * 64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&c->tl_dev, 2048 * 128 * sizeof(unsigned long long)));  // (the tick kernel stamps 128 words per workgroup)
+    HIP_TRY(hipMemset(c->tl_dev, 0, 2048 * 128 * sizeof(unsigned long long)));
     return DUST_OK;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
