@@ -34,8 +34,10 @@ t = buf.reshape(W, 128).astype(np.int64)
 live = t.max(1) > 0
 t0 = t[live][t[live] > 0].min()
 us = lambda x: (x - t0) / 100.0
-owners = live & (t[:, 8] > 0)
-pairs = live & ~owners
+n_pair = (N // 32) * 16  # pair workgroups come first in the grid (32-query tiles x 16 key slices), then 2 particles per owner workgroup
+idx = np.arange(W)
+owners = live & (idx >= n_pair)
+pairs = live & (idx < n_pair)
 print("workgroups stamped: %d owners, %d pair" % (owners.sum(), pairs.sum()))
 names = {0: "start", 1: "actions formed", 2: "rollouts done", 8: "softmax done", 9: "weighted sums done", 3: "prior partials arrived",
          10: "merged", 11: "score row formed", 4: "score published", 5: "next noise drawn", 6: "Stein partials arrived", 12: "phi formed", 7: "theta published"}
@@ -63,4 +65,25 @@ for i in range(3):
     if len(w):
         print("forward stamp %d: median %.2f max %.2f" % (i, float(np.median(us(w))), us(w.max())))
 print("last stamp of the launch: %.2f us" % us(t[live].max()))
+
+
+# placement census (words 126 / 127 of every workgroup: HW_ID and XCC_ID): how the dispatcher spread the two roles over the CUs
+t2 = buf.reshape(W, 128)
+hw, xcc = t2[:, 126].astype(np.int64), t2[:, 127].astype(np.int64) & 0xF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+import collections
+own_per, pair_per = collections.Counter(key[owners]), collections.Counter(key[pairs])
+mix = collections.Counter((own_per.get(k_, 0), pair_per.get(k_, 0)) for k_ in set(key[live]))
+print("CUs in use: %d; (owner workgroups, pair workgroups) per CU -> number of CUs: %s" % (len(set(key[live])), dict(sorted(mix.items()))))
+k = 2
+dur = {}
+for wg in np.where(owners)[0]:
+    a_, b_ = t[wg, 16 * k + 0], t[wg, 16 * k + 2]
+    if a_ > 0 and b_ > 0:
+        dur.setdefault(own_per[key[wg]], []).append((b_ - a_) / 100.0)
+for n_own, v in sorted(dur.items()):
+    print("owners on a CU with %d owner workgroups: start -> rollouts done median %.2f us (min %.2f max %.2f, %d workgroups)" % (n_own, np.median(v), min(v), max(v), len(v)))
 c.close()
