@@ -2003,10 +2003,16 @@ static void roll_done(dust_ctx *c) {
 }
 
 // weights + argmax (+ prior refresh), then the roll: SVMPC.forward's tail (svmpc.py:190-200)
-static int forward_finish_device(dust_ctx *c, int steps = -1, const float *last_row_dev = nullptr) {
+// `roll_all`: a sharded context that holds every rank's particles (just gathered) rolls ALL N rows itself instead of rolling its
+// own and gathering the others' - the roll is a pure function of the row (strategies "repeat" / "mean")
+static int forward_finish_device(dust_ctx *c, int steps = -1, const float *last_row_dev = nullptr, bool roll_all = false) {
   Prof p(c, DUST_K_FORWARD);
   const FinalizeArgs f = finalize_args(c, false);
-  const RollArgs r = roll_args(c, steps, c->cfg.roll_strategy, last_row_dev);
+  RollArgs r = roll_args(c, steps, c->cfg.roll_strategy, last_row_dev);
+  if (roll_all) {
+    r.i0 = 0;
+    r.n_local = c->N;
+  }
   if (c->theta != c->theta_home && c->cfg.roll_strategy == DUST_ROLL_REPEAT && steps == -1 && c->D <= 128 && !c->prof) {
     // out-of-place roll: independent of finalize (which gathers a_seq from the buffer the roll only reads) -> one launch
     finalize_roll_kernel<<<1 + (c->nloc + 7) / 8, 1024, 0, c->stream>>>(f, r);
@@ -2014,7 +2020,7 @@ static int forward_finish_device(dust_ctx *c, int steps = -1, const float *last_
   } else {
     finalize_kernel<<<1, 1024, 0, c->stream>>>(f);
     HIP_TRY(hipGetLastError());
-    roll_kernel<<<c->nloc, 128, 0, c->stream>>>(r);
+    roll_kernel<<<r.n_local, 128, 0, c->stream>>>(r);
     HIP_TRY(hipGetLastError());
   }
   roll_done(c);
@@ -2385,8 +2391,8 @@ static int gather_inplace(dust_ctx *c, float *buf, size_t count) {
 // One control tick of a SHARDED context with its own communicator (north_star: "an RCCL all-gather over xGMI of
 // particle states before the pairwise kernel step"): rank-local rollouts / prior rows / score -> all-gather(score) -> Stein pass
 // + update of the rank's rows -> all-gather(theta) (the prior means alias theta: the next prior pass needs every rank's new
-// particles) ... -> local log-weights -> all-gather -> finalize + roll -> all-gather(theta).  Kernels and collectives share the
-// context's stream: no host synchronisation inside the tick.
+// particles) ... -> local log-weights -> all-gather -> finalize + roll of ALL rows (strategy "resample": roll of the rank's rows ->
+// all-gather(theta)).  Kernels and collectives share the context's stream: no host synchronisation inside the tick.
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags) {
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
   TRY(upload_state_params(c, state, params, n_steps));
@@ -2405,7 +2411,11 @@ static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const flo
 static int sharded_forward(dust_ctx *c) {
   TRY(forward_device(c));  // rank-local log p and log-weights
   TRY(gather_inplace(c, c->lw, (size_t)c->nloc));
-  TRY(forward_finish_device(c));
+  // every rank holds all N particles of this tick (gathered after the last update): "repeat" / "mean" roll each row from itself,
+  // so the rank rolls all of them (16 384 rows: ~10 us) and the tick ends without a third 5 MB all-gather
+  const bool roll_all = c->cfg.roll_strategy != DUST_ROLL_RESAMPLE && c->theta == c->theta_home;
+  TRY(forward_finish_device(c, -1, nullptr, roll_all));
+  if (roll_all) return DUST_OK;
   return gather_inplace(c, c->theta, (size_t)c->nloc * c->D);  // the other ranks' rolled rows
 }
 
@@ -2659,7 +2669,9 @@ extern "C" int dust_svmpc_forward_local(dust_ctx *c, void **log_w_all, size_t *s
 extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
-  TRY(forward_finish_device(c));
+  // a sharded context rolls every rank's rows (it holds them all: gathered after the last update), see sharded_forward
+  const bool roll_all = c->nloc != c->N && c->cfg.roll_strategy != DUST_ROLL_RESAMPLE && c->theta == c->theta_home;
+  TRY(forward_finish_device(c, -1, nullptr, roll_all));
   if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
   return DUST_OK;
 }

@@ -172,7 +172,7 @@ class LocalComm:
                     getattr(dst, name)[lo:lo + shard_elems].copy_(piece)
 
 
-def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False, overlap=False):
+def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False, overlap=False, final_gather=True):
     """One control tick = n_iters SVGD iterations + forward, for the shard(s) this process drives.
 
     `shards` is a 1-tuple under torch.distributed (one rank per process) or all shards under LocalComm.
@@ -209,7 +209,11 @@ def tick(shards, comm, state, n_iters, eps=None, params=None, want_outputs=False
         sh.forward_local()
     comm.all_gather_inplace(shards, "lw_all", shards[0].n_loc)
     outs = [sh.forward_finish(want_outputs) for sh in shards]
-    comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)  # rolled rows of the other shards
+    # rolled rows of the other shards.  (A GPU shard rolls ALL rows itself when the strategy is "repeat" / "mean" - it holds every
+    # rank's particles at this point - which is what the C-side sharded tick relies on to end without this gather;
+    # final_gather=False checks exactly that.)
+    if final_gather:
+        comm.all_gather_inplace(shards, "theta_all", shards[0].shard_elems)
     return outs[0]
 
 

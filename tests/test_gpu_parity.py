@@ -481,7 +481,10 @@ def test_sharded_ticks_equal_unsharded_synthetic(model, N, S, M, H, kernel):
         for sh in shards:
             sh.set_state(th, mu, th)
         for t in range(T):
-            a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], None if params is None else params[t], want_outputs=True)
+            # world 4: WITHOUT the gather of the rolled rows - every shard rolls all N rows itself (forward_finish on a sharded
+            # context; what the C-side sharded tick relies on to end without a third all-gather of theta)
+            a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], None if params is None else params[t], want_outputs=True,
+                             final_gather=(world == 2))
             assert np.array_equal(a_seq, outs[t][0]), (world, t)
             assert relerr(pw, outs[t][1]) < 1e-5
         for sh in shards:

@@ -68,4 +68,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
         sh.ctx.sync()
         pk = {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}
         print("cfg4 G=%d n_local=%d: %.0f us per iteration (local score + Stein/update), kernels: %s" % (G, N // G, el * 1e6, pk), flush=True)
+        sh.ctx.profile(False)
+        for rep in range(2):  # the whole tick of one rank without its collectives: iteration + forward (local log p, finalize over all N, roll)
+            sh.ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                sh.local_score(state, params=params)
+                sh.apply_phi()
+                sh.forward_local()
+                sh.forward_finish()
+            sh.ctx.sync()
+            el2 = (time.perf_counter() - t0) / iters
+        print("        whole tick of the rank (collectives excluded): %.0f us -> forward %.0f us" % (el2 * 1e6, (el2 - el) * 1e6), flush=True)
         sh.ctx.close()
