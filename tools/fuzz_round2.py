@@ -95,6 +95,45 @@ def pair_case(rng):
     return (model, N, H, kernel, spread)
 
 
+def shard_case(rng):
+    """A large aliased set sharded 2 / 3 / 4 ways in one process (all-gathers as slice copies) against the unsharded context: every
+    rank takes the fused large-set pairwise launches on its [n_local][N] block (ragged tiles, runs that cross tile boundaries)."""
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    model = "pendulum" if rng.integers(0, 2) else "particle"
+    da = 1 if model == "pendulum" else 2
+    world = int(rng.integers(2, 5))
+    nloc = int(rng.integers(512, 1200))
+    N = world * nloc
+    H = int(rng.integers(6, 41)) if da == 2 else int(rng.integers(6, 65))
+    kernel = "IMQ" if rng.integers(0, 3) == 0 else "K1"
+    S, K, T = 8, 2, 2
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    th = (mu + 0.3 * rng.standard_normal((N, H, da))).astype(np.float32)
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    eps = rng.standard_normal((T, K, S, N, H, da)).astype(np.float32)
+    kw = dict(model=model, N=N, S=S, M=1, H=H, kernel=kernel, imq_ell=0.9, lr=0.3, sigma_a=1.0, sigma_p=1.0, seed=11,
+              grid=grid_4x4_map() if da == 2 else None)
+    ref = Context(**kw)
+    ref.set_theta(th); ref.set_prior(mu); ref.set_a_mat(th)
+    outs = [ref.svmpc_tick(state, K, eps[t]) for t in range(T)]
+    rt = ref.get_theta()
+    ref.close()
+    shards = tuple(DeviceShard(dict(kw), r, world) for r in range(world))
+    for sh in shards:
+        sh.set_state(th, mu, th)
+    for t in range(T):
+        a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], want_outputs=True, final_gather=bool(t & 1))
+        # (not bitwise: a rank's runs of (tile, chunk) units differ from the unsharded context's, so the partial sums associate differently)
+        assert elemerr(a_seq, outs[t][0]) < 1e-5, (model, N, world, H, kernel, t, float(elemerr(a_seq, outs[t][0])))
+        assert relerr(pw, outs[t][1]) < 1e-5, (model, N, world, H, kernel, t, float(relerr(pw, outs[t][1])))
+    for sh in shards:
+        sh.sync()
+        assert elemerr(sh.ctx.get_theta(), rt) < 1e-5, (model, N, world, H, kernel, sh.rank)
+        sh.ctx.close()
+    return (model, N, world, H, kernel)
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -103,4 +142,6 @@ if __name__ == "__main__":
         states_case(rng, "pendulum")
         if i % 3 == 0:
             print("pair", pair_case(rng), flush=True)
+        if i % 10 == 5:
+            print("shard", shard_case(rng), flush=True)
     print("fuzz ok: %d stored-states cases per family, %d pairwise cases" % (n, (n + 2) // 3))
