@@ -2808,6 +2808,13 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
   return DUST_OK;
 }
 
+// (not part of include/dust_amd.h) host arithmetic of pairwise_fused_kernel's work split (no device involved: callable in a CPU-only process)
+extern "C" int dust_debug_fused_balance(int tiles, int chunks, int slots, int *W, int *JS) {
+  if (tiles < 1 || chunks < 1 || slots < 1 || !W || !JS) return DUST_ERR_INVALID;
+  fused_balance(tiles, chunks, slots, W, JS);
+  return DUST_OK;
+}
+
 #ifdef DUST_STAMPS
 // diagnostic build only (not part of include/dust_amd.h): s_memtime phase stamps of block 0 of the last launch of a kernel
 extern "C" int dust_debug_stamps(dust_ctx *c, int kernel_id, unsigned long long *out16) {
