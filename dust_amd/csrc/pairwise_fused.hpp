@@ -514,18 +514,25 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
   for (int t = 0; t < NCT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
   // K tile loads: lane = (query row kr + 16 u, 4 keys at kc): 4 b128 loads per lane and chunk
   const int kr = tid >> 4, kc = 4 * (tid & 15);
-  for (int j0 = jbeg; j0 < jend; j0 += JC) {
-    const int jc = min(JC, jend - j0);
-    float vv[RowLane<JC, DPB, NT>::NB];
-    rowlane_issue<JC, DPB, NT>(a.V, j0, jc, D, vv);
-    v4f kt[4];
+  auto products = [&]() {
+#pragma unroll 4
+    for (int k4 = 0; k4 < JC / 4; ++k4) {
+      const float bq = Kt[(wave * 16 + (jA & 15)) * KS2 + 4 * k4 + (jA >> 4)];
+      float as[NCT];
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) as[t] = Vs[(4 * k4 + (jA >> 4)) * YS + 16 * t + (jA & 15)];
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[t], bq, acc[t], 0, 0, 0);
+    }
+  };
+  auto k_issue = [&](const int j0, v4f (&kt)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int il = min(il0 + kr + 16 * u, a.n_local - 1);
       kt[u] = *reinterpret_cast<const v4f *>(a.K + (size_t)il * a.ldK + j0 + kc);  // (ldK is a multiple of 64: in bounds; the tail is masked)
     }
-    wg_sync();  // the previous chunk's products are done with Vs / Kt
-    rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, 1, nullptr, Vs);
+  };
+  auto k_commit = [&](const int jc, const v4f (&kt)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       v4f t = kt[u];
@@ -535,15 +542,56 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       t.w = kc + 3 < jc ? t.w : 0.f;
       *reinterpret_cast<v4f *>(&Kt[(kr + 16 * u) * KS2 + kc]) = t;
     }
-    wg_sync();
-#pragma unroll 4
-    for (int k4 = 0; k4 < JC / 4; ++k4) {
-      const float bq = Kt[(wave * 16 + (jA & 15)) * KS2 + 4 * k4 + (jA >> 4)];
-      float as[NCT];
+  };
+  if ((D & 3) == 0) {
+    // D % 4 == 0: the score chunk is one contiguous 64 x D float run whose 16-byte pieces never straddle two rows - NLV b128 loads
+    // per lane (5 at D = 80; the row-per-lane-group staging of stein.hpp needs 32 dword registers).  Few enough registers to hold
+    // the NEXT chunk's K tile and score pieces across the products: their HBM / L2 latency runs under the MFMAs instead of
+    // opening every chunk (the products alone bound this kernel: 443 of 456 us with the K loads removed, tools/gram_probe.hip)
+    constexpr int NLV = (JC * DPB / 4 + NT - 1) / NT;
+    const int D4 = D >> 2;
+    const uint32_t magic4 = (uint32_t)((1ull << 32) / (uint64_t)D4) + 1u;
+    for (int e = tid; e < JC * (DPB - D); e += NT) {  // columns D .. DPB - 1: never staged, read as zeros
+      const int r = e / (DPB - D);
+      Vs[r * YS + D + (e - r * (DPB - D))] = 0.f;
+    }
+    v4f kt[4], vq[NLV];
+    auto v_issue = [&](const int j0) {
+      const int jc = min(JC, jend - j0);
+      const v4f *src = reinterpret_cast<const v4f *>(a.V + (size_t)j0 * D);
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) as[t] = Vs[(4 * k4 + (jA >> 4)) * YS + 16 * t + (jA & 15)];
+      for (int u = 0; u < NLV; ++u) vq[u] = src[min(tid + NT * u, jc * D4 - 1)];  // (pieces past the slice: clamped, zeroed at the commit)
+    };
+    v_issue(jbeg);
+    k_issue(jbeg, kt);
+    for (int j0 = jbeg; j0 < jend; j0 += JC) {
+      const int jc = min(JC, jend - j0);
+      wg_sync();  // the previous chunk's products are done with Vs / Kt
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[t], bq, acc[t], 0, 0, 0);
+      for (int u = 0; u < NLV; ++u) {
+        const int f = tid + NT * u, row = (int)__umulhi((uint32_t)f, magic4), c4 = f - row * D4;
+        if (row < JC) *reinterpret_cast<v4f *>(&Vs[row * YS + 4 * c4]) = row < jc ? vq[u] : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      k_commit(jc, kt);
+      wg_sync();
+      if (j0 + JC < jend) {  // in flight during the products
+        v_issue(j0 + JC);
+        k_issue(j0 + JC, kt);
+      }
+      products();
+    }
+  } else {
+    for (int j0 = jbeg; j0 < jend; j0 += JC) {
+      const int jc = min(JC, jend - j0);
+      float vv[RowLane<JC, DPB, NT>::NB];
+      rowlane_issue<JC, DPB, NT>(a.V, j0, jc, D, vv);
+      v4f kt[4];
+      k_issue(j0, kt);
+      wg_sync();  // the previous chunk's products are done with Vs / Kt
+      rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, 1, nullptr, Vs);
+      k_commit(jc, kt);
+      wg_sync();
+      products();
     }
   }
   // rows from the accumulators: query = l % 16 of the wave's tile, columns 16 t + 4 (l / 16) ..
