@@ -1366,11 +1366,16 @@ static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
   g.V = c->score;
   g.pA = c->pA;
   dim3 grid((c->nloc + 63) / 64, g.JS);
+  // (its own column padding: whole 16-column MFMA tiles, not the 32 / 64 / 80 of pass 1 - D = 40 runs 3 column tiles instead of 4)
 #define DUST_LAUNCH_GS(DPB) gram_score_kernel<DPB><<<grid, PAIR_NT, gram_score_lds_bytes<DPB>(), c->stream>>>(g)
-  if (dpb == 32) DUST_LAUNCH_GS(32);
-  else if (dpb == 64) DUST_LAUNCH_GS(64);
+  const int dpg = ((a.D + 15) / 16) * 16;
+  if (dpg == 16) DUST_LAUNCH_GS(16);
+  else if (dpg == 32) DUST_LAUNCH_GS(32);
+  else if (dpg == 48) DUST_LAUNCH_GS(48);
+  else if (dpg == 64) DUST_LAUNCH_GS(64);
   else DUST_LAUNCH_GS(80);
 #undef DUST_LAUNCH_GS
+  (void)dpb;
   HIP_TRY(hipGetLastError());
   return DUST_OK;
 }

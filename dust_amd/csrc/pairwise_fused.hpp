@@ -543,24 +543,34 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       *reinterpret_cast<v4f *>(&Kt[(kr + 16 * u) * KS2 + kc]) = t;
     }
   };
-  if ((D & 3) == 0) {
-    // D % 4 == 0: the score chunk is one contiguous 64 x D float run whose 16-byte pieces never straddle two rows - NLV b128 loads
-    // per lane (5 at D = 80; the row-per-lane-group staging of stein.hpp needs 32 dword registers).  Few enough registers to hold
-    // the NEXT chunk's K tile and score pieces across the products: their HBM / L2 latency runs under the MFMAs instead of
-    // opening every chunk (the products alone bound this kernel: 443 of 456 us with the K loads removed, tools/gram_probe.hip)
+  {
+    // The score chunk is one contiguous 64 x D float run from a 16-byte aligned offset (j0 is a multiple of 64): NLV b128 loads per
+    // lane (5 at D = 80; the row-per-lane-group staging of stein.hpp needs 32 dword registers).  Few enough registers to hold the
+    // NEXT chunk's K tile and score pieces across the products: their HBM / L2 latency runs under the MFMAs instead of opening
+    // every chunk (the products alone bound this kernel: 443 of 456 us with the K loads removed, tools/gram_probe.hip).
+    // D % 4 == 0: a piece never straddles two rows and is committed with one b128 write; otherwise element by element.
     constexpr int NLV = (JC * DPB / 4 + NT - 1) / NT;
-    const int D4 = D >> 2;
-    const uint32_t magic4 = (uint32_t)((1ull << 32) / (uint64_t)D4) + 1u;
+    const bool vec4 = (D & 3) == 0;
+    const uint32_t magicD = (uint32_t)((1ull << 32) / (uint64_t)D) + 1u;
     for (int e = tid; e < JC * (DPB - D); e += NT) {  // columns D .. DPB - 1: never staged, read as zeros
       const int r = e / (DPB - D);
       Vs[r * YS + D + (e - r * (DPB - D))] = 0.f;
     }
     v4f kt[4], vq[NLV];
     auto v_issue = [&](const int j0) {
-      const int jc = min(JC, jend - j0);
-      const v4f *src = reinterpret_cast<const v4f *>(a.V + (size_t)j0 * D);
+      const int nval = min(JC, jend - j0) * D;  // floats of the chunk
+      const float *src = a.V + (size_t)j0 * D;
 #pragma unroll
-      for (int u = 0; u < NLV; ++u) vq[u] = src[min(tid + NT * u, jc * D4 - 1)];  // (pieces past the slice: clamped, zeroed at the commit)
+      for (int u = 0; u < NLV; ++u) {
+        const int e = 4 * (tid + NT * u);
+        if (e + 3 < nval) vq[u] = *reinterpret_cast<const v4f *>(src + e);
+        else {  // the piece that holds the end of the chunk (D % 4 != 0), and the ones behind it
+          vq[u].x = e + 0 < nval ? src[e + 0] : 0.f;
+          vq[u].y = e + 1 < nval ? src[e + 1] : 0.f;
+          vq[u].z = e + 2 < nval ? src[e + 2] : 0.f;
+          vq[u].w = 0.f;
+        }
+      }
     };
     v_issue(jbeg);
     k_issue(jbeg, kt);
@@ -569,8 +579,17 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       wg_sync();  // the previous chunk's products are done with Vs / Kt
 #pragma unroll
       for (int u = 0; u < NLV; ++u) {
-        const int f = tid + NT * u, row = (int)__umulhi((uint32_t)f, magic4), c4 = f - row * D4;
-        if (row < JC) *reinterpret_cast<v4f *>(&Vs[row * YS + 4 * c4]) = row < jc ? vq[u] : v4f{0.f, 0.f, 0.f, 0.f};
+        const int e = 4 * (tid + NT * u);
+        if (vec4) {
+          const int row = (int)__umulhi((uint32_t)e, magicD), col = e - row * D;
+          if (row < JC) *reinterpret_cast<v4f *>(&Vs[row * YS + col]) = vq[u];  // (pieces behind the slice were loaded as zeros)
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = (int)__umulhi((uint32_t)(e + q), magicD), col = e + q - row * D;
+            if (row < JC) Vs[row * YS + col] = vq[u][q];
+          }
+        }
       }
       k_commit(jc, kt);
       wg_sync();
@@ -578,19 +597,6 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
         v_issue(j0 + JC);
         k_issue(j0 + JC, kt);
       }
-      products();
-    }
-  } else {
-    for (int j0 = jbeg; j0 < jend; j0 += JC) {
-      const int jc = min(JC, jend - j0);
-      float vv[RowLane<JC, DPB, NT>::NB];
-      rowlane_issue<JC, DPB, NT>(a.V, j0, jc, D, vv);
-      v4f kt[4];
-      k_issue(j0, kt);
-      wg_sync();  // the previous chunk's products are done with Vs / Kt
-      rowlane_commit<JC, DPB, YS, NT, false>(vv, jc, D, 1, nullptr, Vs);
-      k_commit(jc, kt);
-      wg_sync();
       products();
     }
   }

@@ -107,7 +107,10 @@ def shard_case(rng):
     N = world * nloc
     H = int(rng.integers(6, 41)) if da == 2 else int(rng.integers(6, 65))
     kernel = "IMQ" if rng.integers(0, 3) == 0 else "K1"
-    S, K, T = 8, 2, 2
+    # one SVGD iteration per tick: a rank's runs of (tile, chunk) units differ from the unsharded context's, so partial sums
+    # associate differently (3e-7 after one iteration) and every further iteration of this stiff little problem multiplies that
+    # by ~10 (measured: 2e-6 after two, 2e-5 after four) - the second tick is there for the roll / prior-refresh path
+    S, K, T = 8, 1, 2
     mu = rng.standard_normal((N, H, da)).astype(np.float32)
     th = (mu + 0.3 * rng.standard_normal((N, H, da))).astype(np.float32)
     state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
@@ -124,12 +127,12 @@ def shard_case(rng):
         sh.set_state(th, mu, th)
     for t in range(T):
         a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], want_outputs=True, final_gather=bool(t & 1))
-        # (not bitwise: a rank's runs of (tile, chunk) units differ from the unsharded context's, so the partial sums associate differently)
-        assert elemerr(a_seq, outs[t][0]) < 1e-5, (model, N, world, H, kernel, t, float(elemerr(a_seq, outs[t][0])))
-        assert relerr(pw, outs[t][1]) < 1e-5, (model, N, world, H, kernel, t, float(relerr(pw, outs[t][1])))
+        tol = 1e-5 if t == 0 else 1e-4
+        assert elemerr(a_seq, outs[t][0]) < tol, (model, N, world, H, kernel, t, float(elemerr(a_seq, outs[t][0])))
+        assert relerr(pw, outs[t][1]) < tol, (model, N, world, H, kernel, t, float(relerr(pw, outs[t][1])))
     for sh in shards:
         sh.sync()
-        assert elemerr(sh.ctx.get_theta(), rt) < 1e-5, (model, N, world, H, kernel, sh.rank)
+        assert elemerr(sh.ctx.get_theta(), rt) < 1e-4, (model, N, world, H, kernel, sh.rank, float(elemerr(sh.ctx.get_theta(), rt)))
         sh.ctx.close()
     return (model, N, world, H, kernel)
 
