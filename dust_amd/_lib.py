@@ -81,6 +81,7 @@ SYMBOLS = {
     "dust_clone": (C.c_int, [VP, C.POINTER(VP)]),
     "dust_destroy": (None, [VP]),
     "dust_sync": (C.c_int, [VP]),
+    "dust_tick_stats": (C.c_int, [VP, C.POINTER(C.c_longlong)]),
     "dust_get_config": (C.c_int, [VP, C.POINTER(Config)]),
     "dust_set_model_param": (C.c_int, [VP, C.c_char_p, C.c_double, C.c_int]),
     "dust_set_param_weights": (C.c_int, [VP, FP]),

@@ -159,6 +159,13 @@ class Context:
     def sync(self):
         L.check(L.load().dust_sync(self._h))
 
+    def tick_stats(self):
+        """Sticky counts of the device path that served optimize / tick calls: owner-computes one-launch ticks, tiled one-launch
+        ticks, and ticks replayed on the launch-per-iteration path because the device was shared."""
+        n = (C.c_longlong * 4)()
+        L.check(L.load().dust_tick_stats(self._h, n))
+        return dict(tick2=int(n[0]), tick1=int(n[1]), replayed=int(n[3]))
+
     def set_grid(self, grid, off=None):
         g = _f(grid)
         nx, ny = g.shape

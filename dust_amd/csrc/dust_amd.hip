@@ -18,6 +18,7 @@
 #include "fused.hpp"
 #include "pairwise_big.hpp"
 #include "persist.hpp"
+#include "tick2_args.hpp"
 #include "rollout_states.hpp"
 #include "pairwise_fused.hpp"
 #include "rollout.hpp"
@@ -125,6 +126,18 @@ struct dust_ctx {
   int tick_tiles, tick_set;
   int tick_occ;       // resident workgroups per CU of the instantiation in use (0: not queried yet)
   size_t tick_occ_lds;
+  // owner-computes persistent tick (tick2.hpp): exchange buffers, two counter sets, bookkeeping of ticks that did not start
+  float *t2_xq, *t2_sq, *t2_lwq;
+  unsigned int *t2_cnt;
+  int t2_set, t2_occ;
+  size_t t2_occ_lds;
+  unsigned int t2_aborts_seen;  // value of the device-side "did not start" counter already accounted for
+  bool t2_inflight;             // a tick2 launch was enqueued since the last check
+  float t2_state[4];            // inputs of the last tick2 launch (replayed on the launch-per-iteration path if it did not start)
+  int t2_steps;
+  bool t2_fwd, t2_replayable;
+  long long t2_replays;         // sticky: ticks replayed so far (dust_tick_stats)
+  long long n_tick2, n_tick1, n_tick_other;  // sticky: optimize / tick calls served by tick2.hpp, persist.hpp, the other paths
   // hipGraph replay of a whole tick (dust_svmpc_tick)
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
@@ -295,6 +308,10 @@ static void free_all(dust_ctx *c) {
   if (c->iter_cnt) (void)hipFree(c->iter_cnt);
   if (c->score_hs) (void)hipFree(c->score_hs);
   if (c->tick_cnt) (void)hipFree(c->tick_cnt);
+  if (c->t2_cnt) (void)hipFree(c->t2_cnt);
+  if (c->t2_xq) (void)hipFree(c->t2_xq);
+  if (c->t2_sq) (void)hipFree(c->t2_sq);
+  if (c->t2_lwq) (void)hipFree(c->t2_lwq);
   if (c->out_pinned) (void)hipHostFree(c->out_pinned);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
@@ -356,10 +373,10 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   float **nd[] = {&c->theta, &c->thetaT, &c->mu, &c->muT, &c->a_mat, &c->grad_lik, &c->grad_pri, &c->score, &c->phi};
   for (auto p : nd) {
     TRY(dalloc(p, ND));
-  TRY(dalloc(&c->theta_alt, ND));
-  c->theta_home = c->theta;
     HIP_TRY(hipMemsetAsync(*p, 0, ND * sizeof(float), c->stream));
   }
+  TRY(dalloc(&c->theta_alt, ND));
+  c->theta_home = c->theta;
   float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw};
   for (auto p : nn) {
     TRY(dalloc(p, (size_t)c->N));
@@ -420,10 +437,18 @@ static void graph_drop(dust_ctx *c);
 static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
                           bool *done);
 static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights);
+static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed);
 
 extern "C" int dust_sync(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->t2_inflight) {  // owner-computes ticks that did not start (device shared with another context) run now, on the other path
+    unsigned int w[2] = {0u, 0u};
+    HIP_TRY(hipMemcpy(w, c->outblk + c->out_floats - 32, sizeof w, hipMemcpyDeviceToHost));
+    bool replayed = false;
+    TRY(t2_settle(c, w[1], &replayed));
+    if (replayed) HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (c->fused_cnt) {  // bounded spin of the fused launch's in-kernel hand-off: report instead of hanging
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
@@ -439,7 +464,7 @@ extern "C" int dust_sync(dust_ctx *c) {
     HIP_TRY(hipMemcpy(&flag, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(DUST_ERR_HIP, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid)");
   }
-  if (c->tick_cnt) {
+  if (c->tick_cnt || c->t2_cnt) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->outblk + c->out_floats - 32, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
@@ -2286,12 +2311,154 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 #undef DUST_PICK_TICK
 #undef DUST_LAUNCH_TICK
   HIP_TRY(hipGetLastError());
+  c->n_tick1++;
   c->tick_set ^= 1;
   if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
   if (do_forward) c->mu_aliased = true;
   c->actions_valid = false;
   c->have_sample = true;
   c->fused_dirty = c->fused_dirty;  // (the launch-per-iteration paths' counters are untouched)
+  *done = true;
+  return DUST_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launch per control tick, owner-computes form (tick2.hpp): two all-to-all hand-offs per SVGD iteration instead of four.
+// *done stays false when the shape / configuration does not qualify (persist.hpp's form or the launch-per-iteration path run).
+static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
+  *done = false;
+  if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return DUST_OK;  // development switches (read per call)
+  if (c->prof || c->nloc != c->N || c->theta_pinned || c->capturing || !c->mu_aliased) return DUST_OK;
+  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
+  if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
+  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE) return DUST_OK;
+  if (do_forward && !c->have_sample && n_steps == 0) return DUST_OK;
+  if (c->noise_f16 && eps_dev) return DUST_OK;
+  if (c->N % T2_PW || c->D > T2_ROW || c->N / T2_PW > device_cus(c)) return DUST_OK;
+  for (int d = 1; d < c->da; ++d)
+    if (c->cfg.sigma_p[d] != c->cfg.sigma_p[0]) return DUST_OK;  // isotropic prior scale: one squared distance serves both kernels
+  SampleOpts o;
+  memset(&o, 0, sizeof o);
+  o.noise_mode = eps_dev ? NOISE_EPS : NOISE_PHILOX;
+  o.noise_dev = eps_dev;
+  o.base = c->theta;
+  o.update_a_mat = 1;
+  RolloutArgs ra;
+  int nt;
+  size_t lds_r;
+  TRY(rollout_args(c, o, ra, &nt, &lds_r));
+  if (ra.a_reg != 0.0f || ra.mw || ra.omegaT) return DUST_OK;
+  if (c->cfg.model == DUST_MODEL_PARTICLE && ra.dm.with_obstacle && ra.grid_words == 0) return DUST_OK;
+  Tick2Args f;
+  memset(&f, 0, sizeof f);
+  f.dm = ra.dm;
+  f.N = c->N;
+  f.S = c->S;
+  f.M = c->M;
+  f.H = c->H;
+  f.D = c->D;
+  f.n_iters = n_steps;
+  f.do_forward = do_forward ? 1 : 0;
+  f.steps = (c->N + 63) / 64;
+  f.lik = ra.lik;
+  f.update_a_mat = 1;
+  f.eps_base_mode = ra.eps_base_mode;
+  f.optimizer = c->cfg.optimizer;
+  f.roll_strategy = c->cfg.roll_strategy;
+  f.weighted_prior = c->cfg.weighted_prior;
+  f.coef_given = ra.coef_given;
+  f.grid_words = c->cfg.model == DUST_MODEL_PARTICLE ? ra.grid_words : 0;
+  f.coef_host[0] = ra.coef_host[0];
+  f.coef_host[1] = ra.coef_host[1];
+  f.alpha = ra.alpha;
+  f.temp = ra.temp;
+  for (int d = 0; d < 4; ++d) {
+    f.chol_a[d] = ra.chol_a[d];
+    f.sigma_a[d] = ra.sigma_a[d];
+  }
+  const size_t lds = (size_t)tick2_lds(c->S, c->D, c->M, f.steps, f.grid_words).total * sizeof(float);
+  if (lds > 160 * 1024) return DUST_OK;
+  const int mode = c->cfg.kernel == DUST_KERNEL_IMQ ? PAIR_IMQ : PAIR_K1;
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  if (!c->t2_occ || c->t2_occ_lds != lds) {
+    int occ = 0;
+    HIP_TRY((hipError_t)tick2_occupancy(c->cfg.model, mode, lds, &occ));
+    c->t2_occ = occ > 0 ? occ : -1;
+    c->t2_occ_lds = lds;
+  }
+  const int grid = c->N / T2_PW;
+  if (c->t2_occ < 1 || grid > c->t2_occ * device_cus(c)) return DUST_OK;
+  if (c->cfg.dim_p > 0 && c->M >= 1 && !c->params_dev) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  if (!c->t2_xq) {
+    TRY(dalloc(&c->t2_xq, (size_t)c->N * T2_ROW));
+    TRY(dalloc(&c->t2_sq, (size_t)c->N * T2_ROW));
+    TRY(dalloc(&c->t2_lwq, (size_t)c->N));
+    TRY(dalloc(&c->t2_cnt, (size_t)2 * T2_SETS * T2_CNT_STRIDE));
+    HIP_TRY(hipMemsetAsync(c->t2_xq, 0, (size_t)c->N * T2_ROW * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->t2_sq, 0, (size_t)c->N * T2_ROW * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->t2_cnt, 0, (size_t)2 * T2_SETS * T2_CNT_STRIDE * sizeof(unsigned int), c->stream));
+    c->t2_set = 0;
+  }
+  const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
+  const float sp = c->cfg.sigma_p[0];
+  f.inv_sp2 = 1.0f / (sp * sp);
+  f.cP = (float)(-0.5 * 1.4426950408889634 / ((double)sp * (double)sp));
+  f.cS = mode == PAIR_IMQ ? (float)(1.0 / ((double)ell * (double)ell)) : (float)(-0.5 * 1.4426950408889634 / ((double)ell * (double)ell));
+  {
+    const UpdateArgs ua = update_args(c, 1);
+    f.inv_l2 = ua.inv_l2;
+    f.inv_n = ua.inv_n;
+    f.lr = ua.lr;
+    f.beta1 = ua.beta1;
+    f.beta2 = ua.beta2;
+    f.adam_eps = ua.eps;
+    const PriorMerge pm = prior_merge_args(c);
+    f.log_norm = pm.log_norm;
+  }
+  for (int k = 0; k < 4; ++k) f.x0[k] = k < c->ds ? state[k] : 0.f;
+  f.seed = c->cfg.seed;
+  f.ctr = c->ctr_dev;
+  f.eps = eps_dev;
+  f.eps_stride = (size_t)c->S * c->N * c->D;
+  f.params = (c->cfg.dim_p > 0 && c->params_dev) ? c->params_dev : nullptr;
+  f.a_seq = c->a_seq;
+  f.theta = c->theta;
+  f.xq = c->t2_xq;
+  f.sq = c->t2_sq;
+  f.lwq = c->t2_lwq;
+  f.logmix = c->logmix;
+  f.mixw = c->mixw;
+  f.a_mat = c->a_mat;
+  f.adam_m = c->adam_m;
+  f.adam_v = c->adam_v;
+  f.costsT = c->costsT;
+  f.grad_lik = c->grad_lik;
+  f.grad_pri = c->grad_pri;
+  f.score = c->score;
+  f.phi = c->phi;
+  f.logl = c->logl;
+  f.eta = c->eta;
+  f.logp = c->logp;
+  f.lw = c->lw;
+  f.pw = c->pw;
+  f.a_seq_out = c->a_seq_out;
+  f.istar = c->istar;
+  f.cnt = c->t2_cnt + (size_t)c->t2_set * T2_SETS * T2_CNT_STRIDE;
+  f.zero_base = c->t2_cnt + (size_t)(1 - c->t2_set) * T2_SETS * T2_CNT_STRIDE;
+  f.status = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
+  f.tl = c->tl_dev;
+  HIP_TRY((hipError_t)tick2_launch(f, c->cfg.model, mode, grid, lds, c->stream));
+  c->t2_set ^= 1;
+  c->n_tick2++;
+  c->t2_inflight = true;
+  for (int k = 0; k < 4; ++k) c->t2_state[k] = f.x0[k];
+  c->t2_steps = n_steps;
+  c->t2_fwd = do_forward;
+  c->t2_replayable = eps_dev == nullptr;
+  if (do_forward) c->mu_aliased = true;
+  c->actions_valid = false;
+  c->have_sample = true;
   *done = true;
   return DUST_OK;
 }
@@ -2443,6 +2610,8 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
     TRY(h2d(c, c->noise_stage, eps, n * sizeof(float)));
     eps_dev = c->noise_stage;
   }
+  TRY(launch_tick2(c, state, n_steps, eps_dev, do_forward, done));
+  if (*done) return DUST_OK;
   return launch_tick(c, state, n_steps, eps_dev, do_forward, done);
 }
 
@@ -2450,22 +2619,64 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
 // synchronisation.  A timed-out in-kernel hand-off (persistent tick, or any of the launch-per-iteration fused forms) is an ERROR
 // here - the outputs of that tick are invalid and must not reach the plant.
 static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights) {
-  HIP_TRY(hipMemcpyAsync(c->out_pinned, c->outblk, c->out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   unsigned int *lf = reinterpret_cast<unsigned int *>(c->out_pinned + c->out_floats);
-  lf[0] = lf[1] = lf[2] = 0u;
-  if (c->fused_cnt) HIP_TRY(hipMemcpyAsync(lf + 0, c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
-  if (c->stein_cnt) HIP_TRY(hipMemcpyAsync(lf + 1, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
-  if (c->iter_cnt)
-    HIP_TRY(hipMemcpyAsync(lf + 2, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  const unsigned int tick_flag = *reinterpret_cast<const unsigned int *>(c->out_pinned + c->out_floats - 32);
-  if (tick_flag) {
-    HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, 4));
-    return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+  for (int pass = 0; pass < 2; ++pass) {
+    HIP_TRY(hipMemcpyAsync(c->out_pinned, c->outblk, c->out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    lf[0] = lf[1] = lf[2] = 0u;
+    if (c->fused_cnt) HIP_TRY(hipMemcpyAsync(lf + 0, c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->stein_cnt) HIP_TRY(hipMemcpyAsync(lf + 1, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->iter_cnt)
+      HIP_TRY(hipMemcpyAsync(lf + 2, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned int *st = reinterpret_cast<const unsigned int *>(c->out_pinned + c->out_floats - 32);
+    if (st[0]) {
+      HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, 4));
+      c->t2_inflight = false;
+      return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+    }
+    // an owner-computes tick whose workgroups were not all resident left the state untouched: run it on the other path, read again
+    bool replayed = false;
+    TRY(t2_settle(c, st[1], &replayed));
+    if (!replayed) break;
   }
   if (lf[0] | lf[1] | lf[2]) return fail(DUST_ERR_HIP, "a fused launch's in-kernel hand-off timed out (results of this tick are invalid)");
   if (a_seq) memcpy(a_seq, c->out_pinned, c->D * sizeof(float));
   if (p_weights) memcpy(p_weights, c->out_pinned + (c->pw - c->outblk), c->N * sizeof(float));
+  return DUST_OK;
+}
+
+// Ticks of the owner-computes kernel (tick2.hpp) that did not start - workgroup 0 did not see every workgroup arrive within its
+// bound, i.e. the grid was not co-resident (another context or process on the device) - have changed nothing.  They are run here,
+// late but on unchanged state, through the launch-per-iteration path, which needs no co-residency.  The controller loses no tick;
+// dust_tick_stats() reports how often this happened.
+static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
+  *replayed = false;
+  c->t2_inflight = false;
+  const unsigned int n = aborts_now - c->t2_aborts_seen;
+  c->t2_aborts_seen = aborts_now;
+  if (!n) return DUST_OK;
+  if (!c->t2_replayable)
+    return fail(DUST_ERR_HIP, "%u control tick(s) with caller-supplied noise did not start (device shared with another context): repeat them", n);
+  for (unsigned int i = 0; i < n; ++i) {
+    TRY(upload_state_params(c, c->t2_state, nullptr, c->t2_steps));
+    c->noise_f16 = false;
+    for (int k = 0; k < c->t2_steps; ++k) TRY(step_device(c, nullptr, k));
+    if (c->t2_fwd) {
+      TRY(forward_device(c));
+      TRY(forward_finish_device(c));
+    }
+    c->t2_replays++;
+  }
+  *replayed = true;
+  return DUST_OK;
+}
+
+extern "C" int dust_tick_stats(dust_ctx *c, long long out[4]) {
+  if (!c || !out) return fail(DUST_ERR_INVALID, "null argument");
+  out[0] = c->n_tick2;
+  out[1] = c->n_tick1;
+  out[2] = c->n_tick_other;
+  out[3] = c->t2_replays;
   return DUST_OK;
 }
 

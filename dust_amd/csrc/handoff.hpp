@@ -1,0 +1,113 @@
+// handoff.hpp - small device helpers shared by every kernel header AND by the second translation unit (tick2.hip), which
+// must not see the non-template kernels of stein.hpp / forward.hpp: kernel-mode enums, the bounded counter wait, write-through
+// scalar loads / stores, the optimiser step, the pendulum's shared-reduction trig, wave priorities.
+#pragma once
+#include "common.hpp"
+
+namespace dust {
+
+enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2, PAIR_LOGP = 3 };  // LOGP: the prior pass of SVMPC.forward - log p only, no gradient
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Bounded wait of ONE lane on a monotonic arrival counter (wrap-safe compare).  A spin gives up after ~50 ms of wall clock
+// (s_memrealtime, 100 MHz) or as soon as another waiter has given up, and raises the flag: the host reports it as an error.
+__device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned int target, unsigned int *flag) {
+  unsigned int spins = 0;
+  unsigned long long t0 = 0;
+  while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255u) == 0u) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (!t0) t0 = now;
+      else if (now - t0 > 5000000ull || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// torch.optim.Adam, single-tensor CPU path (svgd.py:115 is the reference's class default), on grad = -phi: lerp_ for exp_avg
+// (vectorised form: fmadd(w, grad - m, m)), mul_ + addcmul_ for exp_avg_sq ((value * g) * g), bias corrections / step size /
+// sqrt(bias_correction2) as Python floats (double), addcdiv_ as self + (value * m) / denom.  `t` is the 1-based step count
+// since the last roll (the optimiser state restarts at every forward(): forward.hpp RollArgs).
+__device__ __forceinline__ float adam_step(float th, const float g, float &m, float &v, const float lr, const float beta1, const float beta2,
+                                           const float eps, const float t) {
+  const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float value = (float)(-((double)lr / bc1)), bc2s = (float)sqrt(bc2);
+  m = fmaf(w1, g - m, m);
+  v = v * beta2;
+  v = v + (w2 * g) * g;
+  const float denom = sqrtf(v) / bc2s + eps;
+  return th + (value * m) / denom;
+}
+
+
+// sin(fl(theta + pi_f)) and cos(theta) from ONE Cody-Waite reduction of theta.  fl(theta + pi_f) = theta + pi + e with
+// e = (pi_f - pi) - err, err the rounding error of the fp32 add recovered exactly by TwoSum; then
+// sin(theta + pi + e) = -(sin theta cos e + cos theta sin e) = -(sin theta + e cos theta) up to e^2 < 1e-13.
+__device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
+  int q;
+  const float r = trig_reduce(th, &q);
+  const float ps = poly_sin(r), pc = poly_cos(r);
+  float sn = (q & 1) ? pc : ps;
+  float cs = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -sn : sn;
+  cs = ((q + 1) & 2) ? -cs : cs;
+  const float tp = th + PI_F;
+  const float bb = tp - th;
+  const float err = (th - (tp - bb)) + (PI_F - bb);  // exact: th + PI_F = tp + err
+  const float e = 8.742278000372485e-8f - err;       // pi_f - pi
+  *sin_tp = -fmaf(e, cs, sn);
+  *cos_th = cs;
+}
+
+// Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (wg_sync()
+// drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// v[j % DA] for a kernel-ARGUMENT array without a per-lane index: a lane-varying index into the argument block becomes a
+// vector memory load (whose in-order vmcnt wait covers every prefetch issued before it); DA is 1 or 2, so a select does.
+template <int DA>
+__device__ __forceinline__ float pick_da(const float (&v)[4], int j) {
+  return DA == 1 ? v[0] : ((j & 1) ? v[1] : v[0]);
+}
+
+
+__device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// an opaque copy of a lane index: everything derived from it is recomputed where it is used instead of being hoisted out of the
+// iteration loop and kept in registers across it (the three pair bodies' hoisted addresses alone spilled ~100 VGPRs)
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ int opaque_s(int v) {  // the same for a wave-uniform value (stays in an SGPR)
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+
+}  // namespace dust
+
+// wave priorities by phase (s_setprio): 0 = background.  -DDUST_NO_PRIO compiles them out (A/B measurements).
+#ifdef DUST_NO_PRIO
+#define DUST_PRIO(x) \
+  do {               \
+  } while (0)
+#else
+#define DUST_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+// measured at cfg2 (us per tick): owners 3 / prior 2: 155; none: 155; owners 1 / prior 1 (both above the background phases -
+// noise drawing, the theta-only half of the Stein tile): 148.5; owners 2 / prior 3: 150
+#ifndef DUST_PRIO_OWNER
+#define DUST_PRIO_OWNER 1
+#endif
+#ifndef DUST_PRIO_PRIOR
+#define DUST_PRIO_PRIOR 1
+#endif
+

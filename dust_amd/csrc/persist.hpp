@@ -47,23 +47,6 @@ namespace dust {
   } while (0)
 #endif
 
-// wave priorities by phase (s_setprio): 0 = background.  -DDUST_NO_PRIO compiles them out (A/B measurements).
-#ifdef DUST_NO_PRIO
-#define DUST_PRIO(x) \
-  do {               \
-  } while (0)
-#else
-#define DUST_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
-// measured at cfg2 (us per tick): owners 3 / prior 2: 155; none: 155; owners 1 / prior 1 (both above the background phases -
-// noise drawing, the theta-only half of the Stein tile): 148.5; owners 2 / prior 3: 150
-#ifndef DUST_PRIO_OWNER
-#define DUST_PRIO_OWNER 1
-#endif
-#ifndef DUST_PRIO_PRIOR
-#define DUST_PRIO_PRIOR 1
-#endif
-
 struct TickArgs {
   PairArgs prior, stein;  // geometry and constants; X / Y / V are set per iteration inside the kernel
   RolloutArgs ra;         // LEAN rollout configuration; theta / noise / params are set per iteration inside the kernel
@@ -99,21 +82,6 @@ __device__ __forceinline__ void arrive(unsigned int *line) {
   wg_sync();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// an opaque copy of a lane index: everything derived from it is recomputed where it is used instead of being hoisted out of the
-// iteration loop and kept in registers across it (the three pair bodies' hoisted addresses alone spilled ~100 VGPRs)
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-__device__ __forceinline__ int opaque_s(int v) {  // the same for a wave-uniform value (stays in an SGPR)
-  asm volatile("" : "+s"(v));
-  return v;
-}
-
 __device__ __forceinline__ unsigned int group_arrivals(const int g, const int N, const int per_block) {
   return (unsigned int)(min(PAIR_TI, N - g * PAIR_TI) / per_block);
 }

@@ -82,36 +82,6 @@ struct RolloutArgs {
   unsigned long long *stamps;  // diagnostic build only
 };
 
-// sin(fl(theta + pi_f)) and cos(theta) from ONE Cody-Waite reduction of theta.  fl(theta + pi_f) = theta + pi + e with
-// e = (pi_f - pi) - err, err the rounding error of the fp32 add recovered exactly by TwoSum; then
-// sin(theta + pi + e) = -(sin theta cos e + cos theta sin e) = -(sin theta + e cos theta) up to e^2 < 1e-13.
-__device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
-  int q;
-  const float r = trig_reduce(th, &q);
-  const float ps = poly_sin(r), pc = poly_cos(r);
-  float sn = (q & 1) ? pc : ps;
-  float cs = (q & 1) ? ps : pc;
-  sn = (q & 2) ? -sn : sn;
-  cs = ((q + 1) & 2) ? -cs : cs;
-  const float tp = th + PI_F;
-  const float bb = tp - th;
-  const float err = (th - (tp - bb)) + (PI_F - bb);  // exact: th + PI_F = tp + err
-  const float e = 8.742278000372485e-8f - err;       // pi_f - pi
-  *sin_tp = -fmaf(e, cs, sn);
-  *cos_th = cs;
-}
-
-// Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (wg_sync()
-// drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// v[j % DA] for a kernel-ARGUMENT array without a per-lane index: a lane-varying index into the argument block becomes a
-// vector memory load (whose in-order vmcnt wait covers every prefetch issued before it); DA is 1 or 2, so a select does.
-template <int DA>
-__device__ __forceinline__ float pick_da(const float (&v)[4], int j) {
-  return DA == 1 ? v[0] : ((j & 1) ? v[1] : v[0]);
-}
-
 // In-launch hand-off from the prior-pass workgroups of a fused launch (fused.hpp): per query tile, a monotonic arrival
 // counter; `target` arrivals mean every key slice of that tile has published its partials.
 struct FusedWait {

@@ -19,10 +19,10 @@
 // Nothing N x N ever reaches HBM (the reference materialises [N,N,H,da] through autograd).
 #pragma once
 #include "common.hpp"
+#include "handoff.hpp"
 
 namespace dust {
 
-enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2, PAIR_LOGP = 3 };  // LOGP: the prior pass of SVMPC.forward - log p only, no gradient
 enum { PAIR_TI = 32, PAIR_JC = 64, PAIR_NT = 256 };
 // a word no arithmetic produces (hardware NaNs are the canonical quiet NaN, inputs never carry this payload): "not written yet"
 static constexpr unsigned int SCORE_SENTINEL = 0xFFFFFFFFu;
@@ -46,7 +46,6 @@ struct PairArgs {
   unsigned long long *stamps;  // diagnostic build only
 };
 
-typedef float v4f __attribute__((ext_vector_type(4)));
 // 16-byte global store; `wt` = write-through to memory (sc1), readable by sc1 loads from any CU of the device in the same launch
 __device__ __forceinline__ void store16(float *p, v4f v, bool wt) {
   // s_nop AFTER the store: a > 8-byte VMEM store reads its data registers late, and a VALU write of them in the next
@@ -325,24 +324,6 @@ __device__ __forceinline__ void pairwise_body(const PairArgs &a, float *lds, con
 // theta - the Gram values (pass A) and the repulsive term sum_j k'_ij (x_i - x_j) - runs BEFORE the wait on the score rows,
 // i.e. underneath the rollouts of the same launch; after the wait only the score tile load, the Gram x score MFMAs and the
 // 16-byte partial stores remain on the critical path.  Accumulation orders are those of pairwise_body (bitwise equal).
-// Bounded wait of ONE lane on a monotonic arrival counter (wrap-safe compare).  A spin gives up after ~50 ms of wall clock
-// (s_memrealtime, 100 MHz) or as soon as another waiter has given up, and raises the flag: the host reports it as an error.
-__device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned int target, unsigned int *flag) {
-  unsigned int spins = 0;
-  unsigned long long t0 = 0;
-  while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 255u) == 0u) {
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      if (!t0) t0 = now;
-      else if (now - t0 > 5000000ull || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
-    }
-  }
-  return true;
-}
 // arrival lines [line0, line0 + nlines) of `cnt` (one counter per 128-byte line), each with its own target
 struct LineGate {
   const unsigned int *cnt;
@@ -630,22 +611,6 @@ struct UpdateArgs {
 
 // `sc1`: the partials were published inside the SAME launch (fused.hpp stein_update_kernel) with write-through stores and
 // must be read with sc1 loads; across a kernel boundary plain loads do.
-// torch.optim.Adam, single-tensor CPU path (svgd.py:115 is the reference's class default), on grad = -phi: lerp_ for exp_avg
-// (vectorised form: fmadd(w, grad - m, m)), mul_ + addcmul_ for exp_avg_sq ((value * g) * g), bias corrections / step size /
-// sqrt(bias_correction2) as Python floats (double), addcdiv_ as self + (value * m) / denom.  `t` is the 1-based step count
-// since the last roll (the optimiser state restarts at every forward(): forward.hpp RollArgs).
-__device__ __forceinline__ float adam_step(float th, const float g, float &m, float &v, const float lr, const float beta1, const float beta2,
-                                           const float eps, const float t) {
-  const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
-  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-  const float value = (float)(-((double)lr / bc1)), bc2s = (float)sqrt(bc2);
-  m = fmaf(w1, g - m, m);
-  v = v * beta2;
-  v = v + (w2 * g) * g;
-  const float denom = sqrtf(v) / bc2s + eps;
-  return th + (value * m) / denom;
-}
-
 template <bool SC1>
 __device__ __forceinline__ void update_body(const UpdateArgs &a, const int idx) {
   if (idx < a.fused_tiles) a.fused_cnt[idx * 32] = 0u;  // CNT_STRIDE (rollout.hpp): one counter per 128-byte line

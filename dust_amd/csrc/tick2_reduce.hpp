@@ -1,0 +1,54 @@
+// tick2_reduce.hpp - sum NV per-lane values over the 8 key sub-slices of a wave (lane = (u, c): u = lane >> 3 the key
+// sub-slice, c = lane & 7 the column group) without LDS: a transposing butterfly.  Each step halves the number of values a
+// lane carries - a lane keeps the half selected by one bit of u and hands the other half to its partner:
+//   bit 3 (partner 8 lanes away, same 16-lane row): DPP row_ror:8
+//   bit 4 (partner row):   v_permlane16_swap_b32 (gfx950) - swaps the odd rows of one register with the even rows of another
+//   bit 5 (partner half):  v_permlane32_swap_b32 (gfx950) - swaps the upper half of one register with the lower half of another
+// After the three steps lane (u, c) holds NV / 8 complete sums: result i is the sum of input index reduce_u_index<NV>(i, lane).
+// ~2 VALU operations per input value, against 6 DPP steps per value for a plain wave reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dust {
+
+typedef unsigned int t2_v2u __attribute__((ext_vector_type(2)));
+
+template <int NV>
+__device__ __forceinline__ int reduce_u_index(const int i, const int lane) {
+  return i + (NV / 8) * ((lane >> 5) & 1) + (NV / 4) * ((lane >> 4) & 1) + (NV / 2) * ((lane >> 3) & 1);
+}
+
+// The two swaps as inline assembly: hipcc (ROCm 7.2) folds `s.x + s.y` of __builtin_amdgcn_permlane16_swap's result pair into
+// `v_add_f32 v1, v1, v1` (both results taken from the first register; seen in tools/reduce_probe.hip).  s_nop 1 in front: the
+// hazard recogniser does not see inside the asm (VALU write -> lane-swap read needs wait states).
+__device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+template <int NV>
+__device__ __forceinline__ void reduce_u(const float (&v)[NV], float (&out)[NV / 8], const int lane) {
+  static_assert(NV % 8 == 0, "NV must be a multiple of 8");
+  const bool b3 = (lane & 8) != 0;
+  float w[NV / 2];
+#pragma unroll
+  for (int i = 0; i < NV / 2; ++i) {
+    const float keep = b3 ? v[i + NV / 2] : v[i];
+    const float give = b3 ? v[i] : v[i + NV / 2];
+    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    w[i] = keep + got;
+  }
+  float x[NV / 4];
+#pragma unroll
+  for (int i = 0; i < NV / 4; ++i) {
+    float a = w[i], b = w[i + NV / 4];
+    swap16(a, b);
+    x[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < NV / 8; ++i) {
+    float a = x[i], b = x[i + NV / 8];
+    swap32(a, b);
+    out[i] = a + b;
+  }
+}
+
+}  // namespace dust

@@ -119,6 +119,11 @@ int dust_create(const dust_config *cfg, dust_ctx **out);
 int dust_clone(const dust_ctx *src, dust_ctx **out);
 void dust_destroy(dust_ctx *ctx);
 int dust_sync(dust_ctx *ctx);
+/* Which device path served the SVMPC.optimize / forward calls so far (svmpc.py:97-200; sticky counts since creation):
+ * out[0] one-launch ticks, owner-computes form (tick2.hpp); out[1] one-launch ticks, tiled form (persist.hpp); out[2] unused;
+ * out[3] ticks whose one-launch kernel found the device shared with other work (its workgroups were not all resident) and that
+ * were therefore run on the launch-per-iteration path instead - late, on unchanged state, never lost. */
+int dust_tick_stats(dust_ctx *ctx, long long out[4]);
 int dust_get_config(const dust_ctx *ctx, dust_config *out);
 /* model.params_dict[...] = v after construction (particle_example.py:178-179) */
 int dust_set_model_param(dust_ctx *ctx, const char *name, double value, int kind);

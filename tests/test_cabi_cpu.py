@@ -92,7 +92,9 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
     subprocess.run([llvm + "/llvm-objdump", "--offloading", "l.so"], cwd=str(tmp_path), check=True, capture_output=True)
     co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
     assert co, "no gfx950 code object in libdust_amd.so"
-    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co[0]], cwd=str(tmp_path), check=True, capture_output=True, text=True).stdout
+    # (one code object per translation unit: dust_amd.hip, tick2.hip)
+    notes = "".join(subprocess.run([llvm + "/llvm-readelf", "--notes", f], cwd=str(tmp_path), check=True, capture_output=True, text=True).stdout
+                    for f in co)
     kernels = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
         blk = m.group(2)
@@ -128,8 +130,10 @@ def test_every_barrier_drains_lds_first(built, tmp_path):
     subprocess.run([llvm + "/llvm-objdump", "--offloading", "l.so"], cwd=str(tmp_path), check=True, capture_output=True)
     co = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
     assert co, "no gfx950 code object in libdust_amd.so"
-    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", co[0]], cwd=str(tmp_path), check=True, capture_output=True,
-                         text=True).stdout.split("\n")
+    dis = []
+    for f in co:  # one code object per translation unit
+        dis += subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", f], cwd=str(tmp_path), check=True, capture_output=True,
+                              text=True).stdout.split("\n")
     ins = [ln.split("//")[0].strip() for ln in dis]
     lds_mem = re.compile(r"^ds_(read|write|load|store|add|sub|min|max|and|or|xor|inc|dec|cmpst|wrxchg|append|consume)")
     total, bad = 0, []

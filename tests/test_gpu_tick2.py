@@ -1,0 +1,191 @@
+"""Owner-computes one-launch tick (dust_amd/csrc/tick2.hpp) against the tiled one-launch tick (persist.hpp), the
+launch-per-iteration path and the CPU oracle.  The reference path is `optimize(); forward()` of dust/utils/simulations.py:104-123
+(SVMPC.optimize svmpc.py:97-126, SVMPC.forward svmpc.py:172-200).  tick2 takes a tick when the prior means alias the particles
+(every tick after the first forward), N % 4 == 0, N <= 1024, H * d_a <= 32; `tick_stats()` tells which path served a call."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import elemerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # element-wise (|a - b| / (|b| + rms b)): sums over keys / samples are taken in another order than in persist.hpp
+
+
+def _state(model):
+    return np.array([3.0, 0.0], np.float32) if model == "pendulum" else np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+
+
+def _make(model, N, S, H, M=1, kernel="K1", optimizer="SGD", seed=0, weighted_prior=False, roll="repeat", lik=None):
+    from dust_amd import Context
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(seed)
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    th = (mu + 2 * rng.standard_normal((N, H, da))).astype(np.float32)
+    kw = {}
+    if model == "particle":
+        from oracle import grid_4x4_map
+
+        kw["grid"] = grid_4x4_map()
+        if M > 1:
+            kw["uncertain_params"] = ("mass",)
+    elif M > 1:
+        kw["uncertain_params"] = ("length", "mass")
+    if lik:
+        kw["likelihood"] = lik
+    sig = 2.0 if model == "pendulum" else 5.0
+    c = Context(model=model, N=N, S=S, M=M, H=H, kernel=kernel, lr=2.0 if model == "pendulum" else 100.0, sigma_a=sig, sigma_p=sig,
+                optimizer=optimizer, weighted_prior=weighted_prior, roll_strategy=roll, seed=77, **kw)
+    c.set_theta(th)
+    c.set_prior(mu)
+    c.set_a_mat(th)
+    return c, rng
+
+
+def _snapshot(c):
+    ll, lp = c.get_log_weights()
+    return dict(theta=c.get_theta(), a_mat=c.get_a_mat(), costs=c.get_costs(), score=c.get_score(), phi=c.get_phi(), ll=ll, lp=lp,
+                mix=c.get_prior()[1])
+
+
+def _run(env, model, N, S, H, iters, ticks, ext_noise, M=1, **kw):
+    saved = {k: os.environ.pop(k, None) for k in ("DUST_NO_TICK2", "DUST_NO_PERSIST")}
+    os.environ.update(env)
+    try:
+        c, rng = _make(model, N, S, H, M=M, **kw)
+        da = 1 if model == "pendulum" else 2
+        st = _state(model)
+        outs = []
+        for t in range(ticks):
+            eps = rng.standard_normal((iters, S, N, H, da)).astype(np.float32) if ext_noise else None
+            params = None
+            if M > 1:
+                P = 1 if model == "particle" else 2
+                params = (1.0 + 0.1 * rng.standard_normal((iters, M, P))).astype(np.float32)
+            a_seq, pw = c.svmpc_tick(st, iters, eps=eps, params=params)
+            outs.append(dict(a_seq=a_seq.copy(), pw=pw.copy(), **_snapshot(c)))
+        stats = c.tick_stats()
+        c.close()
+        return outs, stats
+    finally:
+        for k in ("DUST_NO_TICK2", "DUST_NO_PERSIST"):
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+SHAPES = [
+    # model, N, S, H, iters, M, kw
+    ("pendulum", 64, 128, 15, 3, 1, {}),
+    ("pendulum", 1024, 128, 30, 5, 1, {}),                      # BASELINE configs[1]
+    ("pendulum", 128, 128, 30, 2, 1, dict(kernel="IMQ")),
+    ("pendulum", 96, 64, 20, 3, 1, dict(optimizer="Adam")),      # N not a multiple of 64: masked keys; S = 64: one wave per particle
+    ("pendulum", 64, 96, 12, 2, 4, {}),                          # sampled dynamics (length, mass), S not a multiple of 64
+    ("pendulum", 256, 128, 30, 2, 1, dict(weighted_prior=True)),
+    ("pendulum", 64, 128, 16, 2, 1, dict(roll="mean")),
+    ("pendulum", 64, 128, 16, 2, 1, dict(lik="ExpectedCost")),
+    ("particle", 64, 64, 12, 2, 1, {}),
+    ("particle", 128, 64, 16, 2, 4, dict(kernel="IMQ")),
+]
+
+
+@pytest.mark.parametrize("ext_noise", [True, False])
+@pytest.mark.parametrize("model,N,S,H,iters,M,kw", SHAPES)
+def test_tick2_equals_tiled_tick(model, N, S, H, iters, M, kw, ext_noise):
+    """Three ticks from the same start: tick 1 runs the tiled form on both sides (the prior means do not alias the particles yet),
+    ticks 2-3 run tick2.hpp on one side and persist.hpp on the other.  Caller-supplied noise and the device Philox stream (same
+    counter layout in both kernels)."""
+    a, sa = _run({}, model, N, S, H, iters, 3, ext_noise, M=M, **kw)
+    b, sb = _run({"DUST_NO_TICK2": "1"}, model, N, S, H, iters, 3, ext_noise, M=M, **kw)
+    assert sa["tick2"] == 2 and sa["replayed"] == 0, sa
+    assert sb["tick2"] == 0, sb
+    for t in range(3):
+        for k in ("costs", "score", "phi", "theta", "a_mat", "ll", "lp", "a_seq"):
+            # ticks after the first amplify: chaotic rollouts, softmax over costs of O(1e3) - tolerance follows the tick index
+            tol = TOL * (1 if t < 2 else 40)
+            if t >= 1 and k in ("score", "phi", "theta", "a_mat", "a_seq", "ll"):
+                tol *= 25  # downstream of exp(-alpha * cost): one ulp of a cost of 1e3 is 1e-4 on a weight
+            assert elemerr(a[t][k], b[t][k]) < tol, (t, k, elemerr(a[t][k], b[t][k]))
+        assert np.abs(a[t]["pw"] - b[t]["pw"]).max() < 2e-3 * (1 if t < 2 else 20)
+
+
+def test_tick2_optimize_only_then_forward():
+    """SVMPC.optimize alone (particles and Adam state stay, svmpc.py:97-126) followed by a separate forward: both through tick2."""
+    res = []
+    for env in ({}, {"DUST_NO_TICK2": "1"}):
+        saved = os.environ.pop("DUST_NO_TICK2", None)
+        os.environ.update(env)
+        try:
+            c, rng = _make("pendulum", 64, 128, 15, optimizer="Adam")
+            st = _state("pendulum")
+            eps = rng.standard_normal((3, 128, 64, 15, 1)).astype(np.float32)
+            c.svmpc_tick(st, 1, eps=eps[:1])          # aliases the prior
+            c.svmpc_optimize(st, 2, eps=eps[1:])      # two Adam steps, no forward
+            th_mid = c.get_theta()
+            a_seq, pw = c.svmpc_forward()
+            res.append((th_mid, a_seq, pw, c.get_theta(), c.tick_stats()))
+            c.close()
+        finally:
+            os.environ.pop("DUST_NO_TICK2", None)
+            if saved is not None:
+                os.environ["DUST_NO_TICK2"] = saved
+    (t0, a0, p0, e0, s0), (t1, a1, p1, e1, s1) = res
+    assert s0["tick2"] >= 1 and s1["tick2"] == 0
+    assert elemerr(t0, t1) < 1e-4 and elemerr(a0, a1) < 1e-4 and elemerr(e0, e1) < 1e-4
+    assert np.abs(p0 - p1).max() < 2e-3
+
+
+def test_tick2_against_oracle_whole_tick():
+    """One whole tick (5 iterations + forward) at the product shape against the CPU oracle fed the same noise."""
+    from oracle import Oracle
+
+    N, S, H, K = 256, 128, 30, 3
+    c, rng = _make("pendulum", N, S, H)
+    st = _state("pendulum")
+    eps0 = rng.standard_normal((1, S, N, H, 1)).astype(np.float32)
+    c.svmpc_tick(st, 1, eps=eps0)  # tick 1 (tiled form): afterwards the prior means alias the particles
+    th, (mu, mix), am = c.get_theta(), c.get_prior(), c.get_a_mat()
+    eps = rng.standard_normal((K, S, N, H, 1)).astype(np.float32)
+    a_seq, pw = c.svmpc_tick(st, K, eps=eps)
+    assert c.tick_stats()["tick2"] == 1
+    o = Oracle(model="pendulum", N=N, S=S, M=1, H=H)
+    r = o.tick_k1(st, th, th, mix, 2.0, 2.0, eps, K, 1.0, 2.0, am)
+    # the tick's particles BEFORE the roll are not kept; compare the rolled particles and the chosen sequence
+    assert elemerr(c.get_theta(), r["theta"]) < 2e-3, elemerr(c.get_theta(), r["theta"])
+    assert np.abs(pw - r["p_weights"]).max() < 2e-3
+    if np.sort(r["p_weights"])[-1] - np.sort(r["p_weights"])[-2] > 1e-2:
+        assert elemerr(a_seq.reshape(-1), r["a_seq"].reshape(-1)) < 2e-3
+    c.close()
+
+
+def test_tick2_long_run_stays_consistent():
+    """400 product ticks (device noise) through tick2 and through the tiled form from the same start: finite throughout, and the
+    first 3 ticks - before chaos separates the two summation orders - agree."""
+    N, S, H = 1024, 128, 30
+    st = _state("pendulum")
+    outs = []
+    for env in ({}, {"DUST_NO_TICK2": "1"}):
+        saved = os.environ.pop("DUST_NO_TICK2", None)
+        os.environ.update(env)
+        try:
+            c, _ = _make("pendulum", N, S, H)
+            hist = []
+            for t in range(400):
+                a_seq, pw = c.svmpc_tick(st, 5)
+                if t < 3:
+                    hist.append((a_seq.copy(), pw.copy()))
+                assert np.isfinite(a_seq).all() and abs(float(pw.sum()) - 1.0) < 1e-3, t
+            assert np.isfinite(c.get_theta()).all()
+            outs.append((hist, c.tick_stats()))
+            c.close()
+        finally:
+            os.environ.pop("DUST_NO_TICK2", None)
+            if saved is not None:
+                os.environ["DUST_NO_TICK2"] = saved
+    (h0, s0), (h1, s1) = outs
+    assert s0["tick2"] == 399 and s0["replayed"] == 0 and s1["tick2"] == 0
+    for t in range(2):
+        assert elemerr(h0[t][0], h1[t][0]) < 1e-3, t
