@@ -2360,7 +2360,7 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   f.D = c->D;
   f.n_iters = n_steps;
   f.do_forward = do_forward ? 1 : 0;
-  f.steps = (c->N + 63) / 64;
+  f.steps = (((c->N + 63) / 64) + 15) & ~15;  // 16-key steps of a pair wave (theta-only pass), in whole groups of 16
   f.lik = ra.lik;
   f.update_a_mat = 1;
   f.eps_base_mode = ra.eps_base_mode;
@@ -2377,8 +2377,8 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
     f.chol_a[d] = ra.chol_a[d];
     f.sigma_a[d] = ra.sigma_a[d];
   }
-  const size_t lds = (size_t)tick2_lds(c->S, c->D, c->M, f.steps, f.grid_words).total * sizeof(float);
-  if (lds > 160 * 1024) return DUST_OK;
+  const size_t lds = (size_t)tick2_lds(c->S, c->D, f.steps, f.grid_words).total * sizeof(float);
+  if (lds > 160 * 1024 || c->M > T2_MAXM) return DUST_OK;
   const int mode = c->cfg.kernel == DUST_KERNEL_IMQ ? PAIR_IMQ : PAIR_K1;
   HIP_TRY(hipSetDevice(c->cfg.device));
   if (!c->t2_occ || c->t2_occ_lds != lds) {

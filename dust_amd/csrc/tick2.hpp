@@ -40,10 +40,21 @@ namespace dust {
 
 typedef unsigned int t2_v4u __attribute__((ext_vector_type(4)));
 
+// The argument block is read through the kernel-argument segment pointer (scalar loads), and that pointer is made OPAQUE once per
+// SVGD iteration: everything derived from the arguments is then recomputed inside the iteration instead of being hoisted out of
+// the iteration loop by LICM and kept - i.e. spilled: 270 scalars to VGPR lanes and 60-330 vector registers to scratch, inside
+// every phase of the loop - across it.
+typedef const Tick2Args __attribute__((address_space(4))) *T2ArgPtr;
+__device__ __forceinline__ T2ArgPtr t2_args() {
+  T2ArgPtr p = (T2ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 #ifdef DUST_STAMPS
 #define T2_TL(w, k)                                                                                                       \
   do {                                                                                                                    \
-    if (f.tl && (int)threadIdx.x == 64 * (w) && (k) < 128) f.tl[128 * blockIdx.x + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); \
+    if (f->tl && (int)threadIdx.x == 64 * (w) && (k) < 128) f->tl[128 * blockIdx.x + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define T2_TL(w, k) \
@@ -79,78 +90,79 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lan
   if (lane == 0) __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One pairwise pass of a P wave over its share of the keys.
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees only the kernel's signature: it cannot read through constant-address-space pointers)
+// One pairwise pass of a P wave over its share of the keys.  Lane = (key sub-slice u = lane >> 2, column group c = lane & 3): a step
+// is 16 key rows; a lane holds 8 columns (two 16-byte pieces) of its key row.  The per-(query, key) scalar work - the reduction of
+// the squared distance over the column lanes, the two exponentials, the masks - is shared by 4 lanes here; with 8 column lanes of
+// 4 columns it made up 60 % of the pass (2 560 instructions per wave against 960).
 //   FULL = true : the theta-only half of SVMPC.phi (svmpc.py:38-41, 76-83): prior softmax mass L, weighted sum a = sum e (y - x),
-//                 Stein repulsion b = sum k' (y - x) with k' = k (K1) or k^3 (IMQ), and k_ij -> LDS ksl[key][4]
-//   FULL = false: the log-density pass of SVMPC.forward (svmpc.py:137): L only
-// Keys: padded rows of the exchange buffer (sc1 loads) or, before anything was published in this launch, the rows of theta itself.
+//                 Stein repulsion b = sum k' (y - x) with k' = k (K1) or k^3 (IMQ), and k_ij -> LDS ksl[key][4].  A wave takes TWO of
+//                 the workgroup's four queries (waves 8-11: queries 0-1, waves 12-15: queries 2-3) and a quarter of the keys: with
+//                 all four queries in one wave the accumulators alone pushed the pass over the 128-register budget of a 16-wave
+//                 workgroup (330 spilled registers).
+//   FULL = false: the log-density pass of SVMPC.forward (svmpc.py:137): L only, four queries per wave, an eighth of the keys.
+// Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
+// f->steps (a multiple of 16, the host rounds up) = steps of a FULL pass; steps past the last key run on clamped rows, weight 0.
 template <int MODE, bool FULL>
-__device__ __forceinline__ void t2_pair_pass(const Tick2Args &f, const float *thq /* LDS [4][32] own query rows */, float *ksl, const int pw, const int lane,
-                                             const bool from_theta, const float lm_ref, float (&red)[5] /* reduce_u<40> result (FULL) or L in red[0..3] */) {
-  const int u = lane >> 3, c = lane & 7, N = f.N, D = f.D;
-  v2f xq[T2_PW][2];
+__device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq /* LDS [4][32] own query rows */, float *ksl, const int pw, const int lane,
+                                             const float lm_ref, float (&red)[4] /* FULL: reduce_u16<48> result; else L of the 4 queries */) {
+  constexpr int NQ = FULL ? 2 : 4;        // queries per wave
+  constexpr int NKW = FULL ? 4 : 8;       // waves that share the keys
+  const int u = lane >> 2, c = lane & 3, N = f->N, D = f->D;
+  const int kw = FULL ? (pw & 3) : pw, q0 = FULL ? (pw >> 2) * 2 : 0;
+  v2f xq[NQ][4];
 #pragma unroll
-  for (int q = 0; q < T2_PW; ++q) {
-    const float4 xv = *reinterpret_cast<const float4 *>(&thq[q * T2_ROW + 4 * c]);
-    xq[q][0] = v2f{xv.x, xv.y};
-    xq[q][1] = v2f{xv.z, xv.w};
+  for (int q = 0; q < NQ; ++q) {
+    const float4 xa = *reinterpret_cast<const float4 *>(&thq[(q0 + q) * T2_ROW + 8 * c]);
+    const float4 xb = *reinterpret_cast<const float4 *>(&thq[(q0 + q) * T2_ROW + 8 * c + 4]);
+    xq[q][0] = v2f{xa.x, xa.y};
+    xq[q][1] = v2f{xa.z, xa.w};
+    xq[q][2] = v2f{xb.x, xb.y};
+    xq[q][3] = v2f{xb.z, xb.w};
   }
-  v2f accA[T2_PW][2], accB[T2_PW][2];
-  float accL[T2_PW];
+  v2f accA[NQ][4], accB[NQ][4];
+  float accL[NQ];
 #pragma unroll
-  for (int q = 0; q < T2_PW; ++q) {
-    accA[q][0] = accA[q][1] = accB[q][0] = accB[q][1] = v2f{0.f, 0.f};
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) accA[q][h] = accB[q][h] = v2f{0.f, 0.f};
     accL[q] = 0.f;
   }
-  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f.xq, N * T2_ROW);
-  constexpr int PF = 4;  // key steps in flight
-  v4f ybuf[PF];
+  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq, N * T2_ROW);
+  constexpr int PF = 2;  // key steps in flight (4 spilled the accumulators; the pass is issue-bound, tools/allgather_probe.hip: 1..16 in flight time alike)
+  v4f ya[PF], yb[PF];
   float lbuf[PF];
-  auto issue = [&](const int t, v4f &y, float &lm) {
-    const int j = min((t * 8 + pw) * 8 + u, N - 1);
-    if (from_theta) {
-      const float *row = f.theta + (size_t)j * D;
-      const int c0 = 4 * c;
-      y[0] = row[min(c0, D - 1)];
-      y[1] = row[min(c0 + 1, D - 1)];
-      y[2] = row[min(c0 + 2, D - 1)];
-      y[3] = row[min(c0 + 3, D - 1)];
-    } else {
-      y = t2_ld16(rx, (j * T2_ROW + 4 * c) * 4);
-    }
-    lm = f.logmix[j];
+  auto issue = [&](const int t, v4f &y0, v4f &y1, float &lm) {
+    const int j = min((t * NKW + kw) * 16 + u, N - 1);
+    y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
+    y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
+    lm = f->logmix[j];
   };
-  const int steps = f.steps;
+  const int steps = FULL ? f->steps : f->steps / 2;
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p < steps) issue(p, ybuf[p], lbuf[p]);
-  const float cP = f.cP, cS = f.cS;
+  for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p], lbuf[p]);
+  const float cP = f->cP, cS = f->cS;
   for (int t0 = 0; t0 < steps; t0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int t = t0 + p;
-      if (t >= steps) continue;
-      v4f y = ybuf[p];
+      v4f y0 = ya[p], y1 = yb[p];
       const float lm = lbuf[p];
-      if (t + PF < steps) issue(t + PF, ybuf[p], lbuf[p]);
-      if (from_theta) {  // columns past D read a clamped duplicate: zero them (the padded rows hold zeros there)
-        const int c0 = 4 * c;
-        y[0] = c0 < D ? y[0] : 0.f;
-        y[1] = c0 + 1 < D ? y[1] : 0.f;
-        y[2] = c0 + 2 < D ? y[2] : 0.f;
-        y[3] = c0 + 3 < D ? y[3] : 0.f;
-      }
-      const int j = (t * 8 + pw) * 8 + u;
+      issue(min(t + PF, steps - 1), ya[p], yb[p], lbuf[p]);  // (the last group re-reads its last rows: no branch in the loop)
+      const int j = (t * NKW + kw) * 16 + u;
       const bool valid = j < N;
       const float lm2 = (lm - lm_ref) * 1.44269504088896340736f;
-      const v2f y01 = {y[0], y[1]}, y23 = {y[2], y[3]};
-      float kq[T2_PW];
+      const v2f yv[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
+      float kq[NQ];
 #pragma unroll
-      for (int q = 0; q < T2_PW; ++q) {
-        const v2f z01 = y01 - xq[q][0], z23 = y23 - xq[q][1];
-        v2f d2 = z01 * z01;
-        d2 = __builtin_elementwise_fma(z23, z23, d2);
-        const float dd = oct_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 8
+      for (int q = 0; q < NQ; ++q) {
+        v2f z[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) z[h] = yv[h] - xq[q][h];
+        v2f d2 = z[0] * z[0];
+#pragma unroll
+        for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
+        const float dd = quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
         const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
         accL[q] += e;
         if (FULL) {
@@ -160,59 +172,85 @@ __device__ __forceinline__ void t2_pair_pass(const Tick2Args &f, const float *th
           kq[q] = k;
           const float kp = MODE == PAIR_K1 ? k : (k * k) * k;
           const v2f ee = {e, e}, kk = {kp, kp};
-          accA[q][0] = __builtin_elementwise_fma(ee, z01, accA[q][0]);
-          accA[q][1] = __builtin_elementwise_fma(ee, z23, accA[q][1]);
-          accB[q][0] = __builtin_elementwise_fma(kk, z01, accB[q][0]);
-          accB[q][1] = __builtin_elementwise_fma(kk, z23, accB[q][1]);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            accA[q][h] = __builtin_elementwise_fma(ee, z[h], accA[q][h]);
+            accB[q][h] = __builtin_elementwise_fma(kk, z[h], accB[q][h]);
+          }
         }
       }
-      if (FULL && c == 0) *reinterpret_cast<float4 *>(&ksl[(size_t)j * 4]) = float4{kq[0], kq[1], kq[2], kq[3]};
+      if (FULL && c == 0) *reinterpret_cast<float2 *>(&ksl[(size_t)j * 4 + q0]) = float2{kq[0], kq[1]};
     }
   }
   if (FULL) {
-    float v[40];
+    float v[48], r3[3];  // a[2][8] | b[2][8] | L[2] | padding
 #pragma unroll
-    for (int q = 0; q < T2_PW; ++q) {
-      v[q * 4 + 0] = accA[q][0].x;
-      v[q * 4 + 1] = accA[q][0].y;
-      v[q * 4 + 2] = accA[q][1].x;
-      v[q * 4 + 3] = accA[q][1].y;
-      v[16 + q * 4 + 0] = accB[q][0].x;
-      v[16 + q * 4 + 1] = accB[q][0].y;
-      v[16 + q * 4 + 2] = accB[q][1].x;
-      v[16 + q * 4 + 3] = accB[q][1].y;
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        v[q * 8 + 2 * h] = accA[q][h].x;
+        v[q * 8 + 2 * h + 1] = accA[q][h].y;
+        v[16 + q * 8 + 2 * h] = accB[q][h].x;
+        v[16 + q * 8 + 2 * h + 1] = accB[q][h].y;
+      }
       v[32 + q] = accL[q];
-      v[36 + q] = 0.f;
     }
-    reduce_u<40>(v, red, lane);
+#pragma unroll
+    for (int i = 34; i < 48; ++i) v[i] = 0.f;
+    reduce_u16<48>(v, r3, lane);
+    red[0] = r3[0];
+    red[1] = r3[1];
+    red[2] = r3[2];
+    red[3] = 0.f;
   } else {
 #pragma unroll
-    for (int q = 0; q < T2_PW; ++q) {  // 4 values: a plain all-reduce over u (row rotate, then the LDS crossbar for the rows)
+    for (int q = 0; q < NQ; ++q) {  // 4 values: a plain all-reduce over u (row shifts, then the LDS crossbar for the rows)
       float s = accL[q];
+      s += __shfl_xor(s, 4, 64);
       s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x128, 0xf, 0xf, false));
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       red[q] = s;
     }
-    red[4] = 0.f;
   }
 }
 
+// the general (reference-order) step / terminal cost with the Particle's occupancy grid read from LDS: the model block is copied
+// only inside the Particle instance, where it is used
+template <int MODEL>
+__device__ __forceinline__ float t2_step_with_cost(const T2ArgPtr f, const float *grid_lds, const Coef &cf, float *x, const float *a) {
+  DevModel dml = f->dm;  // (a private copy: only the fields the instance uses survive)
+  if (MODEL == DUST_MODEL_PARTICLE) dml.grid_bits = reinterpret_cast<const uint32_t *>(grid_lds);
+  return step_with_cost<MODEL>(dml, cf, x, a);
+}
+template <int MODEL>
+__device__ __forceinline__ float t2_term_cost(const T2ArgPtr f, const float *grid_lds, const float *x) {
+  DevModel dml = f->dm;
+  if (MODEL == DUST_MODEL_PARTICLE) dml.grid_bits = reinterpret_cast<const uint32_t *>(grid_lds);
+  return term_cost<MODEL>(dml, x);
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
+
 template <int MODEL, int MODE>
-__global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f) {
+__global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f_by_value) {
+  (void)f_by_value;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const T2ArgPtr f0 = t2_args();
+  T2ArgPtr f = f0;
   constexpr int DS = MODEL == DUST_MODEL_PENDULUM ? 2 : 4;
   constexpr int DA = MODEL == DUST_MODEL_PENDULUM ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid0 = (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int S = f.S, D = f.D, H = f.H, N = f.N, M = f.M, Dp = D | 1;
+  const int S = f->S, D = f->D, H = f->H, N = f->N, M = f->M, Dp = D | 1;
   const int G = (int)gridDim.x, b = (int)blockIdx.x, n_first = b * T2_PW, sh = b % T2_NSH;
-  const Tick2Lds L = tick2_lds(S, D, M, f.steps, f.grid_words);
+  const Tick2Lds L = tick2_lds(S, D, f->steps, f->grid_words);
   float *tile = lds + L.tile;    // [4][S][Dp] standard normals of the current iteration
   float *cst = lds + L.cst;      // [4][S] costs -> softmax weights
   float *omg = lds + L.omg;      // [4][S] omega weights (alpha * temp != 1)
-  float *th = lds + L.th;        // [4][32] the workgroup's particles, zero padded
-  float *misc = lds + L.misc;
+  float *th = lds + T2_L_TH;     // [4][32] the workgroup's particles, zero padded
+  float *misc = lds + T2_L_MISC;
   float *red_w = misc;           // [4][2][4] per (particle, wave): cost min, sum exp, sum exp (omega), cost sum
   float *zfin = misc + 32;       // [4][2] softmax masses
   float *ll = misc + 40;         // [4] log-likelihood of the last sample (SVMPC.forward, fast_pred)
@@ -221,22 +259,22 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *lmref = misc + 56;      // max_j log pi_j
   unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived
   float *wred = misc + 64;       // [128] block-reduction scratch
-  float *coefs = lds + L.coefs;
+  float *coefs = lds + T2_L_COEFS;
   float *ksl = lds + L.ksl;
-  float *ppart = lds + L.ppart;
-  float *gpl = lds + L.gp, *rpl = lds + L.rp;
-  float *wpart = lds + L.wpart;
-  float *kpart = lds + L.kpart;
-  float *scl = lds + L.scl;
-  unsigned int *cnt_start = f.cnt;
-  unsigned int *cnt_theta = f.cnt + (size_t)1 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *cnt_score = f.cnt + (size_t)2 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *cnt_lw = f.cnt + (size_t)3 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *go = f.cnt + (size_t)4 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *tflag = f.status;
+  float *ppart = lds + T2_L_PPART;
+  float *gpl = lds + T2_L_GP, *rpl = lds + T2_L_RP;
+  float *wpart = lds + T2_L_WPART;
+  float *kpart = lds + T2_L_KPART;
+  float *scl = lds + T2_L_SCL;
+  unsigned int *cnt_start = f->cnt;
+  unsigned int *cnt_theta = f->cnt + (size_t)1 * T2_NSH * T2_CNT_STRIDE;
+  unsigned int *cnt_score = f->cnt + (size_t)2 * T2_NSH * T2_CNT_STRIDE;
+  unsigned int *cnt_lw = f->cnt + (size_t)3 * T2_NSH * T2_CNT_STRIDE;
+  unsigned int *go = f->cnt + (size_t)4 * T2_NSH * T2_CNT_STRIDE;
+  unsigned int *tflag = f->status;
 
   if (b == 0)
-    for (int t = tid0; t < T2_SETS; t += T2_NT) f.zero_base[(size_t)t * T2_CNT_STRIDE] = 0u;
+    for (int t = tid0; t < T2_SETS; t += T2_NT) f->zero_base[(size_t)t * T2_CNT_STRIDE] = 0u;
   if (tid0 == 15 * 64) __hip_atomic_fetch_add(cnt_start + (size_t)sh * T2_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   T2_TL(0, 120);
 
@@ -245,38 +283,36 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   const int ol = tid0 - 512, op = (ol >> 5) & 3, od = ol & 31;
   const bool ownv = isown && od < D;
   const size_t no = (size_t)(n_first + op) * D + (ownv ? od : 0);
-  const bool adam = f.optimizer == DUST_OPT_ADAM;
+  const bool adam = f->optimizer == DUST_OPT_ADAM;
   float thv = 0.f, amv = 0.f, adm = 0.f, adv = 0.f;
   if (ownv) {
-    thv = f.theta[no];
-    if (f.update_a_mat) amv = f.a_mat[no];
+    thv = f->theta[no];
+    if (f->update_a_mat) amv = f->a_mat[no];
     if (adam) {
-      adm = f.adam_m[no];
-      adv = f.adam_v[no];
+      adm = f->adam_m[no];
+      adv = f->adam_v[no];
     }
   }
-  const uint32_t ctr_tick = f.ctr[0], ctr_iter0 = f.ctr[1], adam0 = f.ctr[2];
+  const uint32_t ctr_tick = f->ctr[0], ctr_iter0 = f->ctr[1], adam0 = f->ctr[2];
   float x0[DS];
 #pragma unroll
-  for (int k = 0; k < DS; ++k) x0[k] = f.x0[k];
+  for (int k = 0; k < DS; ++k) x0[k] = f->x0[k];
   if (tid0 < 16) misc[44 + tid0] = 0.f;  // flags
   if (tid0 == 16) {
     sig[0] = 0u;
     sig[1] = 0u;
   }
-  if (tid0 >= 32 && tid0 < 32 + T2_PW) ll[tid0 - 32] = f.logl[n_first + tid0 - 32];
+  if (tid0 >= 32 && tid0 < 32 + T2_PW) ll[tid0 - 32] = f->logl[n_first + tid0 - 32];
   {  // max_j log pi_j: an upper bound of every prior logit (the exponent reference of the pair passes)
     float m = -INFINITY;
-    for (int i = tid0; i < N; i += T2_NT) m = fmaxf(m, f.logmix[i]);
+    for (int i = tid0; i < N; i += T2_NT) m = fmaxf(m, f->logmix[i]);
     m = wave_max(m);
     if ((tid0 & 63) == 0) wred[wave] = m;
   }
-  DevModel dml = f.dm;
-  if (MODEL == DUST_MODEL_PARTICLE) {
+  if (MODEL == DUST_MODEL_PARTICLE) {  // occupancy grid -> LDS
     uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + L.grid);
-    const int words = f.dm.with_obstacle ? (f.dm.nx * f.dm.ny + 31) >> 5 : 0;
-    for (int w = tid0; w < words; w += T2_NT) gridl[w] = f.dm.grid_bits[w];
-    dml.grid_bits = gridl;
+    const int words = f->dm.with_obstacle ? (f->dm.nx * f->dm.ny + 31) >> 5 : 0;
+    for (int w = tid0; w < words; w += T2_NT) gridl[w] = f->dm.grid_bits[w];
   }
   wg_sync();
   if (tid0 == 0) {
@@ -291,13 +327,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   }
 
   // dynamics coefficients of iteration k (rollout_body stage 1); wave 11
-  auto make_coefs = [&](const int k) {
+  auto make_coefs = [&](const T2ArgPtr f, const int k) {
+    const DevModel dmc = f->dm;
     for (int m = (tid0 & 63); m < M; m += 64) {
-      if (f.coef_given) {
-        coefs[2 * m] = f.coef_host[0];
-        coefs[2 * m + 1] = f.coef_host[1];
+      if (f->coef_given) {
+        coefs[2 * m] = f->coef_host[0];
+        coefs[2 * m + 1] = f->coef_host[1];
       } else {
-        const Coef cf = make_coef(f.dm, f.params ? f.params + ((size_t)k * M + m) * f.dm.P : nullptr);
+        const Coef cf = make_coef(dmc, f->params ? f->params + ((size_t)k * M + m) * f->dm.P : nullptr);
         coefs[2 * m] = cf.c0;
         coefs[2 * m + 1] = cf.c1;
       }
@@ -305,9 +342,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   };
   // standard normals of iteration k into the tile: `nl` lanes (lane index `lid`) share the 4 S rows; with twice as many lanes as
   // rows two lanes split a row's Philox blocks.  Same counter layout as rollout.hpp / persist.hpp: element (s, n, j).
-  auto draw_noise = [&](const int k, const int lid, const int nl) {
+  auto draw_noise = [&](const T2ArgPtr f, const int k, const int lid, const int nl) {
     const int rows = T2_PW * S;
-    if (f.eps == nullptr) {
+    if (f->eps == nullptr) {
       const int split = nl >= 2 * rows ? 2 : 1;
       const int half = split == 2 ? (lid & 1) : 0;
       for (int r = split == 2 ? (lid >> 1) : lid; r < rows; r += nl / split) {
@@ -315,14 +352,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         float *row = tile + (size_t)r * Dp;
         for (int j4 = half; j4 * 4 < D; j4 += split) {
           float z[4];
-          philox_normal4(f.seed, (uint32_t)j4, (uint32_t)(s * N + n_first + p), ctr_iter0 + (uint32_t)k, ctr_tick, z);
+          philox_normal4(f->seed, (uint32_t)j4, (uint32_t)(s * N + n_first + p), ctr_iter0 + (uint32_t)k, ctr_tick, z);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (j4 * 4 + q < D) row[j4 * 4 + q] = z[q];
         }
       }
     } else {
-      const float *base = f.eps + (size_t)k * f.eps_stride;
+      const float *base = f->eps + (size_t)k * f->eps_stride;
       const int total = rows * D;
       for (int e0 = lid; e0 < total; e0 += 8 * nl) {
         float v[8];
@@ -344,9 +381,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
     }
   };
-  if (f.n_iters > 0) {
-    draw_noise(0, tid0, T2_NT);
-    if (wave == 11) make_coefs(0);
+  T2_TL(0, 122);
+  if (f->n_iters > 0) {
+    draw_noise(f, 0, tid0, T2_NT);
+    if (wave == 11) make_coefs(f, 0);
   }
   // start barrier (wave 15, underneath the first rollouts): workgroup 0 collects the arrivals - bounded: ~200 us - and publishes
   // go / abort
@@ -367,7 +405,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
       const bool all_ok = __all(ok ? 1 : 0) && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
       if (lane == 0) {
-        if (!all_ok) __hip_atomic_fetch_add(f.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!all_ok) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(go, all_ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t2_lds_st(sig, all_ok ? 1u : 2u);
       }
@@ -394,12 +432,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   wg_sync();
   T2_TL(0, 121);
   const float lm_ref = lmref[0];
-  const bool same_w = (f.alpha * f.temp == 1.0f);
+  const bool same_w = (f->alpha * f->temp == 1.0f);
   const int lane0 = tid0 & 63;
-  const __amdgpu_buffer_rsrc_t rxq = t2_rsrc(f.xq, N * T2_ROW), rsq = t2_rsrc(f.sq, N * T2_ROW);
 
   // publish rows of the workgroup's particles held in LDS ([4][32]) as whole 128-byte lines: waves 8 / 9 take two rows each
-  auto publish_rows = [&](const float *src, __amdgpu_buffer_rsrc_t r, unsigned int *lines) {
+  auto publish_rows = [&](const float *src, const float *dst, unsigned int *lines) {
+    const __amdgpu_buffer_rsrc_t r = t2_rsrc(dst, N * T2_ROW);
     const int lane = tid0 & 63;
     if (lane < 16) {
       const int pl = (wave - 8) * 2 + (lane >> 3), c = lane & 7;
@@ -409,10 +447,21 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     t2_arrive_wave(lines + (size_t)sh * T2_CNT_STRIDE, lane);
   };
 
-  for (int k = 0; k < f.n_iters; ++k) {
+  if (isown) publish_rows(th, f->xq, cnt_theta);  // theta generation 0 (the exchange buffer is scratch: harmless if the tick does not start)
+  const int wave0 = wave;
+  for (int k = 0; k < f->n_iters; ++k) {
+    // opaque copies of the lane and wave index: everything derived from them is recomputed where it is used instead of being hoisted
+    // out of the iteration loop and kept (or spilled) across it
+    T2ArgPtr f = t2_args();  // (made opaque again behind every barrier: a phase recomputes what it needs from the arguments)
+    const int S = f->S, D = f->D, H = f->H, N = f->N, M = f->M, Dp = D | 1;
     const int tid = opaque(tid0);
+    const int wave = opaque_s(wave0);
     const int lane = tid & 63;
-    T2_TL(0, 8 * k + 0);
+    const bool isown = wave == 8 || wave == 9;
+    const int ol = tid - 512, op = (ol >> 5) & 3, od = ol & 31;
+    const bool ownv = isown && od < D;
+    const size_t no = (size_t)(n_first + op) * D + (ownv ? od : 0);
+    T2_TL(0, 16 * k + 0);
     if (wave < 8) {
       // ================= R waves, phase 1: rollouts (tick_owner stage 2; lane = sample) =================
       DUST_PRIO(DUST_PRIO_OWNER);
@@ -424,13 +473,13 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       const bool bad = flag_th[rp] != 0.f || flag_eps[rp] != 0.f;
       const long SN = (long)S * N;
       const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !bad && fabsf(x0[1]) <= 3.0e38f &&
-                             (fabsf(x0[0]) + f.dm.max_speed_pend * (float)f.dm.dt * (float)H < 5.0e4f);
+                             (fabsf(x0[0]) + f->dm.max_speed_pend * (float)f->dm.dt * (float)H < 5.0e4f);
       for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
         const float *act = tile_p + s * Dp;
         double acc_m = 0.0;
         for (int m = 0; m < M; ++m) {
           const long r = (long)m * SN + (long)s * N + n;
-          const int pidx = f.dm.interleave ? (int)(r % M) : m;
+          const int pidx = f->dm.interleave ? (int)(r % M) : m;
           Coef cf;
           cf.c0 = coefs[2 * pidx];
           cf.c1 = coefs[2 * pidx + 1];
@@ -440,8 +489,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           double tot = 0.0;
           float traj;
           if (fast_trig && fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f) {
-            const float dt = (float)f.dm.dt, mt = f.dm.max_torque, ms = f.dm.max_speed_pend, chol0 = f.chol_a[0];
-            const v2f W = {f.dm.w_cos, f.dm.w_vel};
+            const float dt = (float)f->dm.dt, mt = f->dm.max_torque, ms = f->dm.max_speed_pend, chol0 = f->chol_a[0];
+            const v2f W = {f->dm.w_cos, f->dm.w_vel};
             float sn, cs;
 #pragma unroll 2
             for (int t = 0; t < H; ++t) {
@@ -463,24 +512,24 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
             for (int t = 0; t < H; ++t) {
               float at[DA];
 #pragma unroll
-              for (int q = 0; q < DA; ++q) at[q] = th_p[t * DA + q] + f.chol_a[q] * act[t * DA + q];
-              const float ci = step_with_cost<MODEL>(dml, cf, x, at);
+              for (int q = 0; q < DA; ++q) at[q] = th_p[t * DA + q] + f->chol_a[q] * act[t * DA + q];
+              const float ci = t2_step_with_cost<MODEL>(f, lds + L.grid, cf, x, at);
               tot += (double)ci;
             }
-            traj = (float)tot + term_cost<MODEL>(dml, x);
+            traj = (float)tot + t2_term_cost<MODEL>(f, lds + L.grid, x);
           }
           acc_m += (double)traj;
         }
         const float cost = (M == 1) ? (float)acc_m : (float)(acc_m / M);
         cst_p[s] = cost;
       }
-      T2_TL(0, 8 * k + 1);
+      T2_TL(0, 16 * k + 1);
       {  // nothing leaves the workgroup before "go" (known long before the first rollouts end)
         unsigned int g = 1u;
         if (k == 0)
           while ((g = t2_lds_ld(sig)) == 0u) __builtin_amdgcn_s_sleep(1);
         if (g == 1u)
-          for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f.costsT[(size_t)n * S + s] = cst_p[s];
+          for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
       }
       // wave-local softmax pieces (merged after the barrier: one exchange instead of two)
       float m_w = INFINITY, cs_w = 0.f;
@@ -493,11 +542,11 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       float zw = 0.f, zo = 0.f;
       for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
         const float cc = cst_p[s];
-        const float ew = expf(-cc * f.alpha - (-m_w * f.alpha));
+        const float ew = expf(-cc * f->alpha - (-m_w * f->alpha));
         cst_p[s] = ew;
         zw += ew;
         if (!same_w) {
-          const float eo = expf((-1.0f * (cc - m_w)) / f.temp);
+          const float eo = expf((-1.0f * (cc - m_w)) / f->temp);
           omg_p[s] = eo;
           zo += eo;
         }
@@ -515,23 +564,22 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     } else {
       // ================= P waves, phase 1: the theta-only half of SVMPC.phi against all N keys =================
       const int pw = wave - 8;
-      if (k == 0) {
-        if (wave == 15) start_protocol();
-      } else {
-        if (wave == 15) {
-          t2_poll(cnt_theta, 2u, (unsigned int)k, G, lane, tflag);
-          if (lane == 0) t2_lds_st(sig + 1, (unsigned int)k);
-        }
-        while (t2_lds_ld(sig + 1) < (unsigned int)k) __builtin_amdgcn_s_sleep(1);
+      if (wave == 15) {  // theta generation k: published at the start of the tick (k = 0) or by iteration k - 1
+        if (k == 0) start_protocol();
+        t2_poll(cnt_theta, 2u, (unsigned int)(k + 1), G, lane, tflag);
+        if (lane == 0) t2_lds_st(sig + 1, (unsigned int)(k + 1));
       }
-      T2_TL(8, 8 * k + 2);
-      float red[5];
-      t2_pair_pass<MODE, true>(f, th, ksl, pw, lane, /*from_theta=*/k == 0, lm_ref, red);
+      while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
+      T2_TL(8, 16 * k + 2);
+      float red[4];
+      t2_pair_pass<MODE, true>(f, th, ksl, pw, lane, lm_ref, red);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) ppart[(pw * 40 + reduce_u_index<40>(i, lane)) * 8 + (lane & 7)] = red[i];
-      T2_TL(8, 8 * k + 3);
+      for (int i = 0; i < 3; ++i) ppart[(pw * 48 + reduce_u16_index<48>(i, lane)) * 4 + (lane & 3)] = red[i];
+      T2_TL(8, 16 * k + 3);
     }
     wg_sync();  // B1
+    f = t2_args();
+    T2_TL(0, 16 * k + 4);
     if (sig[0] == 2u) return;  // (uniform: no workgroup wrote anything)
     // ================= phase 2: merge the softmax pieces (R) | finish grad_pri / repulsion (P) =================
     if (wave < 8) {
@@ -539,12 +587,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       float *cst_p = cst + rp * S, *omg_p = omg + rp * S;
       const float *r0 = red_w + (rp * 2) * 4, *r1 = r0 + 4;
       const float m0 = r0[0], m1 = r1[0], cmin = fminf(m0, m1);
-      const float f0 = expf(-m0 * f.alpha - (-cmin * f.alpha)), f1 = expf(-m1 * f.alpha - (-cmin * f.alpha));
+      const float f0 = expf(-m0 * f->alpha - (-cmin * f->alpha)), f1 = expf(-m1 * f->alpha - (-cmin * f->alpha));
       const float zw = r0[1] * f0 + r1[1] * f1;
       float zo = zw, g0 = f0, g1 = f1;
       if (!same_w) {
-        g0 = expf((-1.0f * (m0 - cmin)) / f.temp);
-        g1 = expf((-1.0f * (m1 - cmin)) / f.temp);
+        g0 = expf((-1.0f * (m0 - cmin)) / f->temp);
+        g1 = expf((-1.0f * (m1 - cmin)) / f->temp);
         zo = r0[2] * g0 + r1[2] * g1;
       }
       const float fw = (wave & 1) ? f1 : f0, go_w = (wave & 1) ? g1 : g0;
@@ -557,38 +605,41 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         zfin[rp * 2] = zw;
         zfin[rp * 2 + 1] = zo;
         float last_logl;
-        if (f.lik == DUST_LIK_EXP_UTILITY) last_logl = ((-cmin * f.alpha) + logf(zw)) - logf((float)S);
-        else last_logl = -f.alpha * ((r0[3] + r1[3]) / (float)S);
+        if (f->lik == DUST_LIK_EXP_UTILITY) last_logl = ((-cmin * f->alpha) + logf(zw)) - logf((float)S);
+        else last_logl = -f->alpha * ((r0[3] + r1[3]) / (float)S);
         ll[rp] = last_logl;
-        f.logl[n] = last_logl;
-        f.eta[n] = (-cmin / f.temp) + logf(zo);
+        f->logl[n] = last_logl;
+        f->eta[n] = (-cmin / f->temp) + logf(zo);
       }
     } else {
       const int v = tid - 512;  // 0..511: [0,128) grad_pri (q, d), [128,256) repulsion (q, d)
       if (v < 256) {
-        const int q = (v >> 5) & 3, d = v & 31, c = d >> 2, cc = d & 3;
+        const int q = (v >> 5) & 3, d = v & 31, c = d >> 3, cc = d & 7;
         const bool rep = v >= 128;
         float s = 0.f, l = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          s += ppart[(w * 40 + (rep ? 16 : 0) + q * 4 + cc) * 8 + c];
-          l += ppart[(w * 40 + 32 + q) * 8 + c];
+        for (int w = 0; w < 4; ++w) {  // the four waves that hold this query's half: their key quarters, in order
+          const int pwq = (q >> 1) * 4 + w;
+          s += ppart[(pwq * 48 + (rep ? 16 : 0) + (q & 1) * 8 + cc) * 4 + c];
+          l += ppart[(pwq * 48 + 32 + (q & 1)) * 4 + c];
         }
         if (rep) rpl[q * T2_ROW + d] = s;
-        else gpl[q * T2_ROW + d] = (s / l) * f.inv_sp2;
+        else gpl[q * T2_ROW + d] = (s / l) * f->inv_sp2;
       } else if (v < 256 + T2_PW) {
         flag_eps[v - 256] = 0.f;  // consumed by this iteration's rollouts; the next noise is staged after barrier B3
       }
     }
     wg_sync();  // B2
+    f = t2_args();
+    T2_TL(0, 16 * k + 5);
     // ================= phase 3: weighted sums over the samples, all lanes: lane = (particle, sample slice, column) =================
     {
       const int p = tid >> 8, q = (tid >> 5) & 7, j = tid & 31;
       float g = 0.f, am = 0.f;
       if (j < D) {
-        const float thj = th[p * T2_ROW + j], lj = pick_da<DA>(f.chol_a, j);
-        const float is2 = 1.0f / (pick_da<DA>(f.sigma_a, j) * pick_da<DA>(f.sigma_a, j));
-        const float base = f.eps_base_mode ? thj : f.a_seq[j];
+        const float thj = th[p * T2_ROW + j], lj = pick_da<DA>(f->chol_a, j);
+        const float is2 = 1.0f / (pick_da<DA>(f->sigma_a, j) * pick_da<DA>(f->sigma_a, j));
+        const float base = f->eps_base_mode ? thj : f->a_seq[j];
         const float *tp = tile + (size_t)p * S * Dp + j;
         const float *wp = cst + p * S, *op_ = same_w ? wp : omg + p * S;
 #pragma unroll 4
@@ -602,7 +653,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       wpart[(T2_PW * 8 + p * 8 + q) * T2_ROW + j] = am;
     }
     wg_sync();  // B3
-    T2_TL(0, 8 * k + 4);
+    f = t2_args();
+    T2_TL(0, 16 * k + 6);
     // ================= phase 4: score rows out (waves 8-9) | score arrivals (wave 10) | next noise (R) =================
     float gs_keep = 0.f, gp_keep = 0.f;
     if (isown) {
@@ -614,105 +666,112 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
       const float gs = g / zfin[op * 2];
       const float as = am / zfin[op * 2 + 1];
-      if (f.update_a_mat) amv = amv + as;
+      if (f->update_a_mat) amv = amv + as;
       gp_keep = gpl[op * T2_ROW + od];
       gs_keep = gs;
       scl[op * T2_ROW + od] = ownv ? gs + gp_keep : 0.f;
-      publish_rows(scl, rsq, cnt_score);
+      publish_rows(scl, f->sq, cnt_score);
+      T2_TL(8, 16 * k + 7);
       if (ownv) {
-        f.score[no] = gs_keep + gp_keep;
-        f.grad_lik[no] = gs_keep;
-        f.grad_pri[no] = gp_keep;
-        if (f.update_a_mat) f.a_mat[no] = amv;
+        f->score[no] = gs_keep + gp_keep;
+        f->grad_lik[no] = gs_keep;
+        f->grad_pri[no] = gp_keep;
+        if (f->update_a_mat) f->a_mat[no] = amv;
       }
     } else if (wave == 10) {
       t2_poll(cnt_score, 2u, (unsigned int)(k + 1), G, lane, tflag);
+      T2_TL(10, 16 * k + 8);
     } else if (wave < 8) {
-      if (k + 1 < f.n_iters) draw_noise(k + 1, tid, 512);
+      if (k + 1 < f->n_iters) draw_noise(f, k + 1, tid, 512);
+      T2_TL(0, 16 * k + 9);
     } else if (wave == 11) {
-      if (k + 1 < f.n_iters) make_coefs(k + 1);
+      if (k + 1 < f->n_iters) make_coefs(f, k + 1);
     }
     wg_sync();  // B4
-    T2_TL(0, 8 * k + 5);
+    f = t2_args();
+    T2_TL(0, 16 * k + 10);
     // ================= phase 5: sum_j k_ij s_j (P waves stream the score rows) =================
     if (wave >= 8) {
-      const int pw = wave - 8, u = lane >> 3, c = lane & 7;
-      v2f acc[T2_PW][2];
+      const int pw = wave - 8, u = lane >> 2, c = lane & 3;
+      const __amdgpu_buffer_rsrc_t rsq = t2_rsrc(f->sq, N * T2_ROW);
+      v2f acc[T2_PW][4];
 #pragma unroll
-      for (int q = 0; q < T2_PW; ++q) acc[q][0] = acc[q][1] = v2f{0.f, 0.f};
-      constexpr int NB = 16;
-      for (int t0 = 0; t0 < f.steps; t0 += NB) {
-        v4f sv[NB];
+      for (int q = 0; q < T2_PW; ++q)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc[q][h] = v2f{0.f, 0.f};
+      constexpr int NB = 8;  // steps per chunk (f->steps / 2 is a multiple of 8): 16 loads = every row of a 1024-key set in flight at once
+      for (int t0 = 0; t0 < f->steps / 2; t0 += NB) {
+        v4f sa[NB], sb[NB];
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-          const int j = min(((t0 + p) * 8 + pw) * 8 + u, N - 1);
-          sv[p] = t2_ld16(rsq, (j * T2_ROW + 4 * c) * 4);
+          const int j = min(((t0 + p) * 8 + pw) * 16 + u, N - 1);
+          sa[p] = t2_ld16(rsq, (j * T2_ROW + 8 * c) * 4);
+          sb[p] = t2_ld16(rsq, (j * T2_ROW + 8 * c + 4) * 4);
         }
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-          const int t = t0 + p;
-          if (t < f.steps) {
-            const int j = (t * 8 + pw) * 8 + u;
-            const float4 kq = *reinterpret_cast<const float4 *>(&ksl[(size_t)j * 4]);  // (keys past N hold k = 0)
-            const v2f s01 = {sv[p][0], sv[p][1]}, s23 = {sv[p][2], sv[p][3]};
-            const float kk[T2_PW] = {kq.x, kq.y, kq.z, kq.w};
+          const int j = ((t0 + p) * 8 + pw) * 16 + u;
+          const float4 kq = *reinterpret_cast<const float4 *>(&ksl[(size_t)j * 4]);  // (keys past N hold k = 0)
+          const v2f sv[4] = {{sa[p][0], sa[p][1]}, {sa[p][2], sa[p][3]}, {sb[p][0], sb[p][1]}, {sb[p][2], sb[p][3]}};
+          const float kk[T2_PW] = {kq.x, kq.y, kq.z, kq.w};
 #pragma unroll
-            for (int q = 0; q < T2_PW; ++q) {
-              const v2f kv = {kk[q], kk[q]};
-              acc[q][0] = __builtin_elementwise_fma(kv, s01, acc[q][0]);
-              acc[q][1] = __builtin_elementwise_fma(kv, s23, acc[q][1]);
-            }
+          for (int q = 0; q < T2_PW; ++q) {
+            const v2f kv = {kk[q], kk[q]};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(kv, sv[h], acc[q][h]);
           }
         }
       }
-      float v[16], r2[2];
+      float v[32], r2[2];
 #pragma unroll
-      for (int q = 0; q < T2_PW; ++q) {
-        v[q * 4 + 0] = acc[q][0].x;
-        v[q * 4 + 1] = acc[q][0].y;
-        v[q * 4 + 2] = acc[q][1].x;
-        v[q * 4 + 3] = acc[q][1].y;
-      }
-      reduce_u<16>(v, r2, lane);
+      for (int q = 0; q < T2_PW; ++q)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) kpart[(pw * 16 + reduce_u_index<16>(i, lane)) * 8 + c] = r2[i];
+        for (int h = 0; h < 4; ++h) {
+          v[q * 8 + 2 * h] = acc[q][h].x;
+          v[q * 8 + 2 * h + 1] = acc[q][h].y;
+        }
+      reduce_u16<32>(v, r2, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) kpart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + c] = r2[i];
     }
     wg_sync();  // B5
-    T2_TL(0, 8 * k + 6);
+    f = t2_args();
+    T2_TL(0, 16 * k + 12);
     // ================= phase 6: phi, optimiser step, theta rows out (waves 8-9) =================
     if (isown) {
       float sa = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) sa += kpart[(w * 16 + op * 4 + (od & 3)) * 8 + (od >> 2)];
+      for (int w = 0; w < 8; ++w) sa += kpart[(w * 32 + op * 8 + (od & 7)) * 4 + (od >> 3)];
       const float sb = rpl[op * T2_ROW + od];
-      const float phi = sb * f.inv_l2 + sa * f.inv_n;
+      const float phi = sb * f->inv_l2 + sa * f->inv_n;
       const float gr = -phi;
-      if (!adam) thv = fmaf(-f.lr, gr, thv);
-      else thv = adam_step(thv, gr, adm, adv, f.lr, f.beta1, f.beta2, f.adam_eps, (float)(adam0 + (uint32_t)k + 1u));
+      if (!adam) thv = fmaf(-f->lr, gr, thv);
+      else thv = adam_step(thv, gr, adm, adv, f->lr, f->beta1, f->beta2, f->adam_eps, (float)(adam0 + (uint32_t)k + 1u));
       if (!ownv) thv = 0.f;
       th[op * T2_ROW + od] = thv;
       const unsigned long long badm = __ballot(ownv && !(fabsf(thv) <= 3.0e38f));
       if ((lane & 31) == 0) flag_th[op] = ((badm >> (lane & 32)) & 0xffffffffull) ? 1.f : 0.f;
-      if (k + 1 < f.n_iters || f.do_forward) publish_rows(th, rxq, cnt_theta);
-      if (ownv) f.phi[no] = phi;
+      if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq, cnt_theta);
+      T2_TL(8, 16 * k + 13);
+      if (ownv) f->phi[no] = phi;
     }
     wg_sync();  // B6
-    T2_TL(0, 8 * k + 7);
+    T2_TL(0, 16 * k + 14);
   }
 
-  const int kf = f.n_iters;
+  const int kf = f->n_iters;
   const int lane = tid0 & 63;
-  if (!f.do_forward) {  // SVMPC.optimize alone: particles and optimiser state stay (svmpc.py:97-126)
+  if (!f->do_forward) {  // SVMPC.optimize alone: particles and optimiser state stay (svmpc.py:97-126)
     if (ownv) {
-      f.theta[no] = thv;
+      f->theta[no] = thv;
       if (adam) {
-        f.adam_m[no] = adm;
-        f.adam_v[no] = adv;
+        f->adam_m[no] = adm;
+        f->adam_v[no] = adv;
       }
     }
     if (b == 0 && tid0 == 0) {
-      f.ctr[1] = ctr_iter0 + (uint32_t)kf;
-      f.ctr[2] = adam0 + (uint32_t)kf;
+      f->ctr[1] = ctr_iter0 + (uint32_t)kf;
+      f->ctr[2] = adam0 + (uint32_t)kf;
     }
     return;
   }
@@ -725,15 +784,13 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   }
   if (wave >= 8) {  // log p(theta_n) under the tick's prior, whose means ARE the particles (svmpc.py:137; svgd.py:87)
     const int pw = wave - 8;
-    if (kf > 0) {
-      if (wave == 15) {
-        t2_poll(cnt_theta, 2u, (unsigned int)kf, G, lane, tflag);
-        if (lane == 0) t2_lds_st(sig + 1, (unsigned int)kf);
-      }
-      while (t2_lds_ld(sig + 1) < (unsigned int)kf) __builtin_amdgcn_s_sleep(1);
+    if (wave == 15) {
+      t2_poll(cnt_theta, 2u, (unsigned int)(kf + 1), G, lane, tflag);
+      if (lane == 0) t2_lds_st(sig + 1, (unsigned int)(kf + 1));
     }
-    float red[5];
-    t2_pair_pass<MODE, false>(f, th, ksl, pw, lane, /*from_theta=*/kf == 0, lm_ref, red);
+    while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
+    float red[4];
+    t2_pair_pass<MODE, false>(f, th, ksl, pw, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;
@@ -743,33 +800,33 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
   }
   wg_sync();
-  T2_TL(0, 8 * kf + 0);
+  T2_TL(0, 16 * kf + 0);
   if (wave == 8) {
     if (lane < T2_PW) {
       float l = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) l += ppart[w * 4 + lane];
-      const float lp = (lm_ref + logf(l)) + f.log_norm;
+      const float lp = (lm_ref + logf(l)) + f->log_norm;
       const int n = n_first + lane;
-      f.logp[n] = lp;
+      f->logp[n] = lp;
       const float lwv = ll[lane] + lp;
-      f.lw[n] = lwv;
-      st_sc1(f.lwq + n, lwv);
+      f->lw[n] = lwv;
+      st_sc1(f->lwq + n, lwv);
     }
     t2_arrive_wave(cnt_lw + (size_t)sh * T2_CNT_STRIDE, lane);
     t2_poll(cnt_lw, 1u, 1u, G, lane, tflag);
   }
   wg_sync();
-  T2_TL(0, 8 * kf + 1);
+  T2_TL(0, 16 * kf + 1);
   // softmax over all particles, first-index argmax (finalize_body), computed by every workgroup for itself
   {
     const int t = tid0;
-    const float lwr = t < N ? ld_sc1(f.lwq + t) : -INFINITY;
+    const float lwr = t < N ? ld_sc1(f->lwq + t) : -INFINITY;
     const float m = block_reduce<RED_MAX>(lwr, wred);
     const float z = block_reduce<RED_SUM>(t < N ? expf(lwr - m) : 0.f, wred);
     const float lz = m + logf(z);
     const float p = t < N ? expf(lwr - lz) : 0.f;
-    if (t >= n_first && t < n_first + T2_PW) f.pw[t] = p;
+    if (t >= n_first && t < n_first + T2_PW) f->pw[t] = p;
     float best = t < N ? p : -INFINITY;
     int bi = t < N ? t : 0x7fffffff;
     for (int of = 32; of > 0; of >>= 1) {
@@ -796,16 +853,16 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
     wg_sync();
     if (bi >= n_first && bi < n_first + T2_PW) {  // the owner of the best particle hands out its action sequence
-      if (t == 0) *f.istar = bi;
-      if (t < D) f.a_seq_out[t] = th[(bi - n_first) * T2_ROW + t];
+      if (t == 0) *f->istar = bi;
+      if (t < D) f->a_seq_out[t] = th[(bi - n_first) * T2_ROW + t];
     }
     // new prior mixture (finalize_body): Categorical(probs) clamps, then log_softmax
-    if (!f.weighted_prior) {
+    if (!f->weighted_prior) {
       const float l = logf(fminf(fmaxf(1.0f / (float)N, 1.1920929e-07f), 1.0f - 1.1920929e-07f));
       const float lzz = l + logf((float)N);
       if (t < T2_PW) {
-        f.mixw[n_first + t] = 1.0f;
-        f.logmix[n_first + t] = l - lzz;
+        f->mixw[n_first + t] = 1.0f;
+        f->logmix[n_first + t] = l - lzz;
       }
     } else {
       const float psum = block_reduce<RED_SUM>(p, wred);
@@ -816,8 +873,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       const float zs = block_reduce<RED_SUM>(t < N ? expf(l - lm) : 0.f, wred);
       const float lzz = lm + logf(zs);
       if (t >= n_first && t < n_first + T2_PW) {
-        f.mixw[t] = p;
-        f.logmix[t] = l - lzz;
+        f->mixw[t] = p;
+        f->logmix[t] = l - lzz;
       }
     }
   }
@@ -825,7 +882,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   // log-weights of ALL particles needed every workgroup's log-density pass.
   if (isown) {
     float outv = 0.f;
-    if (f.roll_strategy == DUST_ROLL_MEAN) {  // each policy's mean over H, per control dimension (roll_kernel's order: a wave sum)
+    if (f->roll_strategy == DUST_ROLL_MEAN) {  // each policy's mean over H, per control dimension (roll_kernel's order: a wave sum)
       for (int c = 0; c < DA; ++c) {
         float v = (ownv && od % DA == c) ? thv : 0.f;
         // sum over the 32 lanes of this particle
@@ -836,20 +893,21 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     if (ownv) {
       float out = (od + DA < D) ? th[op * T2_ROW + od + DA] : thv;
-      if (f.roll_strategy == DUST_ROLL_MEAN && od + DA >= D) out = outv;
-      f.theta[no] = out;
+      if (f->roll_strategy == DUST_ROLL_MEAN && od + DA >= D) out = outv;
+      f->theta[no] = out;
       if (adam) {  // SVMPC.roll makes a NEW parameter tensor: torch's optimiser state restarts
-        f.adam_m[no] = 0.f;
-        f.adam_v[no] = 0.f;
+        f->adam_m[no] = 0.f;
+        f->adam_v[no] = 0.f;
       }
     }
   }
   if (b == 0 && tid0 == 0) {
-    f.ctr[0] = ctr_tick + 1u;
-    f.ctr[1] = 0u;
-    f.ctr[2] = 0u;
+    f->ctr[0] = ctr_tick + 1u;
+    f->ctr[1] = 0u;
+    f->ctr[2] = 0u;
   }
-  T2_TL(0, 8 * kf + 2);
+  T2_TL(0, 16 * kf + 2);
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 }  // namespace dust

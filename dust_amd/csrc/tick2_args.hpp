@@ -18,7 +18,7 @@ struct Tick2Args {
   DevModel dm;
   int N, S, M, H, D;
   int n_iters, do_forward;
-  int steps;             // ceil(N / 64): key steps of one pair wave (8 keys per step and wave, 8 waves)
+  int steps;             // ceil(N / 64) rounded up to a multiple of 16: 16-key steps of a pair wave in the theta-only pass (4 waves share the keys)
   int lik, update_a_mat, eps_base_mode, optimizer, roll_strategy, weighted_prior;
   int coef_given;
   int grid_words;        // Particle: words of the bit-packed occupancy grid staged in LDS (multiple of 4) or 0
@@ -49,30 +49,33 @@ struct Tick2Args {
   unsigned long long *tl;   // diagnostic build only: [grid][128] wall-clock stamps
 };
 
-// LDS bytes of one workgroup (host and device agree through these helpers)
-struct Tick2Lds {
-  int tile, cst, omg, th, misc, coefs, grid, ksl, ppart, gp, rp, wpart, kpart, scl, total;  // float offsets
+// LDS layout of one workgroup (float offsets; host and device agree through these).  The fixed-size regions come first, at
+// compile-time offsets (no registers held across the tick for them); the regions sized by S / D / N / the map follow.
+enum {
+  T2_MAXM = 64,                               // dynamics samples per rollout (coefficient pairs in LDS)
+  T2_L_TH = 0,                                // [4][32] the workgroup's particles, zero padded
+  T2_L_MISC = T2_L_TH + T2_PW * T2_ROW,       // [192] small words (see tick2.hpp)
+  T2_L_PPART = T2_L_MISC + 192,               // [8 waves][48 sums][4 column groups] partials of the theta-only pass
+  T2_L_GP = T2_L_PPART + 8 * 48 * 4,          // [4][32] grad_pri
+  T2_L_RP = T2_L_GP + T2_PW * T2_ROW,         // [4][32] Stein repulsion
+  T2_L_WPART = T2_L_RP + T2_PW * T2_ROW,      // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update)
+  T2_L_KPART = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [8 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
+  T2_L_SCL = T2_L_KPART + 8 * 32 * 4,         // [4][32] score rows on their way out
+  T2_L_COEFS = T2_L_SCL + T2_PW * T2_ROW,     // [T2_MAXM][2] dynamics coefficients of the iteration
+  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | grid | tile
 };
-__host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int M, int steps, int grid_words) {
+struct Tick2Lds {
+  int cst, omg, ksl, grid, tile, total;
+};
+__host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_words) {
   Tick2Lds l;
-  const int Dp = D | 1;
-  auto up4 = [](int x) { return (x + 3) & ~3; };
-  int o = 0;
-  l.tile = o;  o = up4(o + T2_PW * S * Dp);
-  l.cst = o;   o = up4(o + T2_PW * S);
-  l.omg = o;   o = up4(o + T2_PW * S);
-  l.th = o;    o += T2_PW * T2_ROW;
-  l.misc = o;  o += 192;
-  l.coefs = o; o = up4(o + 2 * M);
-  l.grid = o;  o += grid_words;
-  l.ksl = o;   o += steps * 64 * 4;        // Stein kernel values k_ij of the workgroup's 4 queries: [key][4]
-  l.ppart = o; o += 8 * 40 * 8;            // per pair wave: 40 reduced sums x 8 column groups
-  l.gp = o;    o += T2_PW * T2_ROW;
-  l.rp = o;    o += T2_PW * T2_ROW;
-  l.wpart = o; o += 2 * T2_PW * 8 * T2_ROW;  // weighted-sum partials (likelihood score, a_mat update)
-  l.kpart = o; o += 8 * 16 * 8;
-  l.scl = o;   o += T2_PW * T2_ROW;
-  l.total = o;
+  const int Dp = D | 1, ps = (T2_PW * S + 3) & ~3;
+  l.cst = T2_L_VAR;               // [4][S] costs -> softmax weights
+  l.omg = l.cst + ps;             // [4][S] omega weights
+  l.ksl = l.omg + ps;             // [steps * 64][4] Stein kernel values k_ij of the workgroup's 4 queries
+  l.grid = l.ksl + steps * 64 * 4;
+  l.tile = l.grid + grid_words;   // [4][S][Dp] standard normals of the current iteration
+  l.total = l.tile + T2_PW * S * Dp;
   return l;
 }
 

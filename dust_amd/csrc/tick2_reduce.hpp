@@ -51,4 +51,27 @@ __device__ __forceinline__ void reduce_u(const float (&v)[NV], float (&out)[NV /
   }
 }
 
+// The same over SIXTEEN sub-slices (lane = (u, c): u = lane >> 2, c = lane & 3): one more butterfly step in front, over lane bit 2
+// (partner 4 lanes away: row_shl:4 into banks 0 / 2 and row_shr:4 into banks 1 / 3 of every 16-lane row).  Result i of lane l is the
+// sum of input index reduce_u16_index<NV>(i, l); NV / 16 results per lane.
+template <int NV>
+__device__ __forceinline__ int reduce_u16_index(const int i, const int lane) {
+  return i + (NV / 16) * ((lane >> 5) & 1) + (NV / 8) * ((lane >> 4) & 1) + (NV / 4) * ((lane >> 3) & 1) + (NV / 2) * ((lane >> 2) & 1);
+}
+template <int NV>
+__device__ __forceinline__ void reduce_u16(const float (&v)[NV], float (&out)[NV / 16], const int lane) {
+  static_assert(NV % 16 == 0, "NV must be a multiple of 16");
+  const bool b2 = (lane & 4) != 0;
+  float h[NV / 2];
+#pragma unroll
+  for (int i = 0; i < NV / 2; ++i) {
+    const float keep = b2 ? v[i + NV / 2] : v[i];
+    const int give = __builtin_bit_cast(int, b2 ? v[i] : v[i + NV / 2]);
+    int got = __builtin_amdgcn_update_dpp(0, give, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    got = __builtin_amdgcn_update_dpp(got, give, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+    h[i] = keep + __builtin_bit_cast(float, got);
+  }
+  reduce_u<NV / 2>(h, out, lane);
+}
+
 }  // namespace dust

@@ -1,0 +1,263 @@
+// allgather_probe.hip - what does the all-to-all hand-off of tick2.hpp cost, and which form of it is fastest?
+// 256 workgroups x 1024 lanes (one per CU, all resident).  Per round every workgroup publishes 4 rows of 128 bytes (write-through),
+// signals a sharded counter, waits for all 256, then reads ALL 1024 rows (128 KB) and sums them.  Rounds alternate two buffers
+// so that a round's writers never race the previous round's readers (the probe has no second hop).  Forms of the READ:
+//   0  buffer_load_dwordx4 sc1, 8 waves x 16 rows-of-8 steps (tick2.hpp as first written)
+//   1  the same loads spread over all 16 waves
+//   2  plain loads after an agent-scope acquire (buffer_inv sc1) by every wave
+//   3  form 0 with the row order rotated per workgroup (no two CUs stream the same lines at the same time)
+//   4  nothing read (hop only: publish + counter + poll + barrier)
+//   hipcc --offload-arch=gfx950 -O3 tools/allgather_probe.hip -o tools/_allgather_probe && tools/_allgather_probe
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+enum { NSH = 16, STRIDE = 32, NWG = 256, ROWS = 1024 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *p, int n) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n * 4, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ v4f ld16(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
+}
+
+template <int FORM>
+__global__ __launch_bounds__(1024, 4) void probe(float *buf0, float *buf1, unsigned int *cnt, int rounds, float *out, unsigned long long *stamps) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+  const int u = lane >> 3, c = lane & 7;
+  float total = 0.f;
+  unsigned long long t_pub = 0, t_seen = 0, t_read = 0;
+  for (int r = 0; r < rounds; ++r) {
+    float *buf = (r & 1) ? buf1 : buf0;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(buf, ROWS * 32);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (wave == 8 || wave == 9) {  // publish 2 rows per wave
+      if (lane < 16) {
+        const int row = b * 4 + (wave - 8) * 2 + (lane >> 3);
+        v4f v = {(float)(r + 1), (float)row, 1.f, 2.f};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (row * 32 + 4 * (lane & 7)) * 4, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)(b % NSH) * STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (wave == 10 && lane < NSH) {
+      const unsigned int target = (unsigned int)(NWG / NSH) * 2u * (unsigned int)(r + 1);
+      while ((int)(__hip_atomic_load(cnt + (size_t)lane * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    if (FORM == 0 || FORM == 3) {
+      if (wave >= 8) {
+        const int pw = wave - 8;
+        const int rot = FORM == 3 ? (b * 37) & 15 : 0;
+        v4f sv[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const int t = (p + rot) & 15;
+          sv[p] = ld16<16>(rs, ((((t * 8 + pw) * 8 + u) * 32) + 4 * c) * 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc += sv[p];
+      }
+    } else if (FORM == 1) {
+      v4f sv[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) sv[p] = ld16<16>(rs, ((((p * 16 + wave) * 8 + u) * 32) + 4 * c) * 4);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc += sv[p];
+    } else if (FORM == 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      v4f sv[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) sv[p] = ld16<0>(rs, ((((p * 16 + wave) * 8 + u) * 32) + 4 * c) * 4);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc += sv[p];
+    }
+    total += acc[0] + acc[1] + acc[2] + acc[3];
+    __syncthreads();
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+    if (r >= rounds / 2) {
+      t_pub += t1 - t0;
+      t_seen += t2 - t1;
+      t_read += t3 - t2;
+    }
+  }
+  // reduce the checksum of this workgroup
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  if (lane == 0) red[wave] = total;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[b] = s;
+    stamps[b * 4 + 0] = t_pub;
+    stamps[b * 4 + 1] = t_seen;
+    stamps[b * 4 + 2] = t_read;
+  }
+}
+
+// pair-pass pattern: 8 waves, 16 steps each, 2 x 16 bytes per lane and step (16 rows), PF steps in flight, ~60 dependent-ish VALU per step
+template <int PF, bool TOUCH>
+__global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1, unsigned int *cnt, int rounds, float *out, unsigned long long *stamps) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+  const int u = lane >> 2, c = lane & 3;
+  float total = 0.f;
+  unsigned long long t_read = 0;
+  for (int r = 0; r < rounds; ++r) {
+    float *buf = (r & 1) ? buf1 : buf0;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(buf, ROWS * 32);
+    if (wave == 8 || wave == 9) {
+      if (lane < 16) {
+        const int row = b * 4 + (wave - 8) * 2 + (lane >> 3);
+        v4f v = {(float)(r + 1), (float)row, 1.f, 2.f};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (row * 32 + 4 * (lane & 7)) * 4, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)(b % NSH) * STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 10 && lane < NSH) {
+      const unsigned int target = (unsigned int)(NWG / NSH) * 2u * (unsigned int)(r + 1);
+      while ((int)(__hip_atomic_load(cnt + (size_t)lane * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    if (wave >= 8) {
+      const int kw = (wave - 8) & 3;
+      float warm = 0.f;
+      if (TOUCH)
+        for (int t4 = 0; t4 < 16; t4 += 4) warm += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (((t4 + (lane >> 4)) * 4 + kw) * 16 + (lane & 15)) * 128, 0, 16));
+      v4f ya[PF], yb[PF];
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int j = (p * 4 + kw) * 16 + u;
+        ya[p] = ld16<16>(rs, (j * 32 + 8 * c) * 4);
+        yb[p] = ld16<16>(rs, (j * 32 + 8 * c + 4) * 4);
+      }
+      for (int t0 = 0; t0 < 16; t0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          v4f y0 = ya[p], y1 = yb[p];
+          const int tn = min(t0 + p + PF, 15);
+          const int j = (tn * 4 + kw) * 16 + u;
+          ya[p] = ld16<16>(rs, (j * 32 + 8 * c) * 4);
+          yb[p] = ld16<16>(rs, (j * 32 + 8 * c + 4) * 4);
+          v4f z = y0 + y1;
+#pragma unroll
+          for (int q = 0; q < 12; ++q) z = z * 1.0001f + acc;  // ~48 dependent VALU
+          acc += z * 1e-3f;
+        }
+      }
+      if (warm == 1.234e-30f) acc[0] += warm;
+    }
+    total += acc[0] + acc[1] + acc[2] + acc[3];
+    __syncthreads();
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+    if (r >= rounds / 2) t_read += t3 - t2;
+  }
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  if (lane == 0) red[wave] = total;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[b] = s;
+    stamps[b * 4 + 2] = t_read;
+  }
+}
+template <int PF, bool TOUCH>
+static void run_stream(const char *name) {
+  float *b0, *b1, *out;
+  unsigned int *cnt;
+  unsigned long long *st;
+  hipMalloc(&b0, ROWS * 32 * 4);
+  hipMalloc(&b1, ROWS * 32 * 4);
+  hipMalloc(&out, NWG * 4);
+  hipMalloc(&cnt, NSH * STRIDE * 4);
+  hipMalloc(&st, NWG * 4 * 8);
+  const int rounds = 200;
+  std::vector<unsigned long long> hs(NWG * 4);
+  hipMemset(cnt, 0, NSH * STRIDE * 4);
+  stream_probe<PF, TOUCH><<<NWG, 1024>>>(b0, b1, cnt, rounds, out, st);
+  hipDeviceSynchronize();
+  hipMemcpy(hs.data(), st, NWG * 4 * 8, hipMemcpyDeviceToHost);
+  double rd = 0;
+  for (int i = 0; i < NWG; ++i) rd += hs[i * 4 + 2];
+  printf("%-56s read+compute %.2f us per pass\n", name, rd / ((double)NWG * (rounds - rounds / 2) * 100.0));
+  hipFree(b0); hipFree(b1); hipFree(out); hipFree(cnt); hipFree(st);
+}
+
+template <int FORM>
+static void run(const char *name) {
+  float *b0, *b1, *out;
+  unsigned int *cnt;
+  unsigned long long *st;
+  hipMalloc(&b0, ROWS * 32 * 4);
+  hipMalloc(&b1, ROWS * 32 * 4);
+  hipMalloc(&out, NWG * 4);
+  hipMalloc(&cnt, NSH * STRIDE * 4);
+  hipMalloc(&st, NWG * 4 * 8);
+  const int rounds = 200;
+  double best = 1e9;
+  std::vector<float> h(NWG);
+  std::vector<unsigned long long> hs(NWG * 4);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipMemset(cnt, 0, NSH * STRIDE * 4);
+    hipMemset(b0, 0, ROWS * 32 * 4);
+    hipMemset(b1, 0, ROWS * 32 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0);
+    probe<FORM><<<NWG, 1024>>>(b0, b1, cnt, rounds, out, st);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  hipMemcpy(h.data(), out, NWG * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(hs.data(), st, NWG * 4 * 8, hipMemcpyDeviceToHost);
+  // expected checksum per workgroup: sum over rounds r and rows of (r + 1) + row + 3
+  double want = 0;
+  for (int r = 0; r < rounds; ++r)
+    for (int row = 0; row < ROWS; ++row) want += 8.0 * ((double)(r + 1) + row + 3.0);
+  int bad = 0;
+  if (FORM != 4)
+    for (int i = 0; i < NWG; ++i)
+      if (fabs(h[i] - want) > 1e-3 * want) ++bad;
+  double p = 0, s = 0, rd = 0;
+  for (int i = 0; i < NWG; ++i) {
+    p += hs[i * 4];
+    s += hs[i * 4 + 1];
+    rd += hs[i * 4 + 2];
+  }
+  const double n = (double)NWG * (rounds - rounds / 2) * 100.0;  // 100 ticks per us
+  printf("%-56s %6.2f us/round  (publish %.2f, wait %.2f, read %.2f us; %d stale workgroups)\n", name, best * 1e3 / rounds, p / n, s / n, rd / n, bad);
+  hipFree(b0); hipFree(b1); hipFree(out); hipFree(cnt); hipFree(st);
+}
+
+int main() {
+  run<4>("hop only (publish + counter + poll + barrier)");
+  run<0>("sc1 loads, 8 waves x 16 steps");
+  run<1>("sc1 loads, 16 waves x 8 steps");
+  run<2>("agent acquire + plain loads, 16 waves x 8 steps");
+  run<3>("sc1 loads, 8 waves x 16 steps, rotated per workgroup");
+  run_stream<1, false>("stream 16 steps x 2 KB per wave, 1 step in flight");
+  run_stream<2, false>("stream, 2 steps in flight");
+  run_stream<2, true>("stream, 2 steps in flight, lines touched first");
+  run_stream<4, false>("stream, 4 steps in flight");
+  run_stream<4, true>("stream, 4 steps in flight, lines touched first");
+  run_stream<8, false>("stream, 8 steps in flight");
+  run_stream<16, false>("stream, 16 steps in flight");
+  return 0;
+}

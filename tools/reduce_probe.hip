@@ -22,6 +22,42 @@ __global__ void probe(const float *in, float *out) {
 }
 
 template <int NV>
+__global__ void probe16(const float *in, float *out) {
+  const int lane = threadIdx.x & 63;
+  float v[NV], r[NV / 16];
+  for (int i = 0; i < NV; ++i) v[i] = in[(size_t)lane * NV + i];
+  dust::reduce_u16<NV>(v, r, lane);
+  for (int i = 0; i < NV / 16; ++i) out[(size_t)dust::reduce_u16_index<NV>(i, lane) * 4 + (lane & 3)] = r[i];  // [NV][4 column groups]
+}
+
+template <int NV>
+static int run16() {
+  std::vector<float> h(64 * NV), o(NV * 4, -1.f);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 8.0f;
+  float *di, *dout;
+  hipMalloc(&di, h.size() * 4);
+  hipMalloc(&dout, o.size() * 4);
+  hipMemcpy(di, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemset(dout, 0xff, o.size() * 4);
+  probe16<NV><<<1, 64>>>(di, dout);
+  hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int idx = 0; idx < NV; ++idx)
+    for (int c = 0; c < 4; ++c) {
+      double ref = 0;
+      for (int u = 0; u < 16; ++u) ref += h[(size_t)(u * 4 + c) * NV + idx];
+      if (fabs(ref - o[idx * 4 + c]) > 1e-3 * (1 + fabs(ref))) {
+        if (bad < 5) printf("NV=%d idx %d c %d: got %g want %g\n", NV, idx, c, o[idx * 4 + c], ref);
+        ++bad;
+      }
+    }
+  printf("reduce_u16<%d>: %s (%d mismatches)\n", NV, bad ? "FAIL" : "ok", bad);
+  hipFree(di);
+  hipFree(dout);
+  return bad;
+}
+
+template <int NV>
 static int run() {
   std::vector<float> h(64 * NV), o(NV * 8, -1.f);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 8.0f;
@@ -48,4 +84,4 @@ static int run() {
   return bad;
 }
 
-int main() { return (run<40>() + run<16>() + run<8>()) ? 1 : 0; }
+int main() { return (run<40>() + run<16>() + run<8>() + run16<48>() + run16<32>() + run16<16>()) ? 1 : 0; }
