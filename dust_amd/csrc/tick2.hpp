@@ -91,25 +91,32 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lan
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees only the kernel's signature: it cannot read through constant-address-space pointers)
-// One pairwise pass of a P wave over its share of the keys.  Lane = (key sub-slice u = lane >> 2, column group c = lane & 3): a step
+// Pairwise passes of a P wave over its share of the keys.  Lane = (key sub-slice u = lane >> 2, column group c = lane & 3): a step
 // is 16 key rows; a lane holds 8 columns (two 16-byte pieces) of its key row.  The per-(query, key) scalar work - the reduction of
-// the squared distance over the column lanes, the two exponentials, the masks - is shared by 4 lanes here; with 8 column lanes of
-// 4 columns it made up 60 % of the pass (2 560 instructions per wave against 960).
-//   FULL = true : the theta-only half of SVMPC.phi (svmpc.py:38-41, 76-83): prior softmax mass L, weighted sum a = sum e (y - x),
-//                 Stein repulsion b = sum k' (y - x) with k' = k (K1) or k^3 (IMQ), and k_ij -> LDS ksl[key][4].  A wave takes TWO of
-//                 the workgroup's four queries (waves 8-11: queries 0-1, waves 12-15: queries 2-3) and a quarter of the keys: with
-//                 all four queries in one wave the accumulators alone pushed the pass over the 128-register budget of a 16-wave
-//                 workgroup (330 spilled registers).
-//   FULL = false: the log-density pass of SVMPC.forward (svmpc.py:137): L only, four queries per wave, an eighth of the keys.
+// the squared distance over the column lanes, the exponential, the mask - is shared by 4 lanes here; with 8 column lanes of
+// 4 columns it made up 60 % of the pass (2 560 instructions per wave against 960; measured again on the split passes below:
+// 150 against 130 us per tick, although the 8 x 8 form reads whole lines and every row once).
+// The theta-only half of SVMPC.phi (svmpc.py:38-41, 76-83) is cut in two at the point the SCORE needs:
+//   T2_PASS_PRIOR  (phase 1, underneath the rollouts; needed for the score rows): prior softmax mass L, weighted sum
+//                  a = sum_j e_ij (y_j - x_i); the squared distances go to LDS (dsl[key][4]).
+//   T2_PASS_STEIN  (phase 4, while the score rows of the other workgroups are in flight - the CU has nothing else to do then but
+//                  draw the next noise): k_ij from the kept distances -> LDS (ksl[key][4]), repulsion b = sum_j k'_ij (y_j - x_i)
+//                  with k' = k (K1) or k^3 (IMQ).  Re-reads the key rows and re-forms the differences: ~15 % more work in
+//                  all, a third of it off the path that the score rows wait for (146 -> 130 us per tick).
+//   In both a wave takes TWO of the workgroup's four queries (waves 8-11: queries 0-1, waves 12-15: queries 2-3) and a quarter of
+//   the keys: four queries per wave put the accumulators alone over the 128-register budget of a 16-wave workgroup.
+//   T2_PASS_LOGP   the log-density pass of SVMPC.forward (svmpc.py:137): L only, four queries per wave, an eighth of the keys.
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
-// f->steps (a multiple of 16, the host rounds up) = steps of a FULL pass; steps past the last key run on clamped rows, weight 0.
-template <int MODE, bool FULL>
-__device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq /* LDS [4][32] own query rows */, float *ksl, const int pw, const int lane,
-                                             const float lm_ref, float (&red)[4] /* FULL: reduce_u16<48> result; else L of the 4 queries */) {
-  constexpr int NQ = FULL ? 2 : 4;        // queries per wave
-  constexpr int NKW = FULL ? 4 : 8;       // waves that share the keys
-  const int u = lane >> 2, c = lane & 3, N = f->N, D = f->D;
-  const int kw = FULL ? (pw & 3) : pw, q0 = FULL ? (pw >> 2) * 2 : 0;
+// f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
+enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
+template <int MODE, int PASS>
+__device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq /* LDS [4][32] own query rows */, float *dsl, float *ksl, const int pw,
+                                             const int lane, const float lm_ref,
+                                             float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */) {
+  constexpr int NQ = PASS == T2_PASS_LOGP ? 4 : 2;   // queries per wave
+  constexpr int NKW = PASS == T2_PASS_LOGP ? 8 : 4;  // waves that share the keys
+  const int u = lane >> 2, c = lane & 3, N = f->N;
+  const int kw = PASS == T2_PASS_LOGP ? pw : (pw & 3), q0 = PASS == T2_PASS_LOGP ? 0 : (pw >> 2) * 2;
   v2f xq[NQ][4];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -120,25 +127,25 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq 
     xq[q][2] = v2f{xb.x, xb.y};
     xq[q][3] = v2f{xb.z, xb.w};
   }
-  v2f accA[NQ][4], accB[NQ][4];
+  v2f acc[NQ][4];
   float accL[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) accA[q][h] = accB[q][h] = v2f{0.f, 0.f};
+    for (int h = 0; h < 4; ++h) acc[q][h] = v2f{0.f, 0.f};
     accL[q] = 0.f;
   }
   const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq, N * T2_ROW);
-  constexpr int PF = 2;  // key steps in flight (4 spilled the accumulators; the pass is issue-bound, tools/allgather_probe.hip: 1..16 in flight time alike)
+  constexpr int PF = 2;  // key steps in flight (4 spill the prefetched rows themselves into the loop: 17 us per pass instead of 6)
   v4f ya[PF], yb[PF];
   float lbuf[PF];
   auto issue = [&](const int t, v4f &y0, v4f &y1, float &lm) {
     const int j = min((t * NKW + kw) * 16 + u, N - 1);
     y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
     y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
-    lm = f->logmix[j];
+    if (PASS != T2_PASS_STEIN) lm = f->logmix[j];
   };
-  const int steps = FULL ? f->steps : f->steps / 2;
+  const int steps = PASS == T2_PASS_LOGP ? f->steps / 2 : f->steps;
 #pragma unroll
   for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p], lbuf[p]);
   const float cP = f->cP, cS = f->cS;
@@ -146,62 +153,80 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq 
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int t = t0 + p;
-      v4f y0 = ya[p], y1 = yb[p];
+      const v4f y0 = ya[p], y1 = yb[p];
       const float lm = lbuf[p];
       issue(min(t + PF, steps - 1), ya[p], yb[p], lbuf[p]);  // (the last group re-reads its last rows: no branch in the loop)
       const int j = (t * NKW + kw) * 16 + u;
       const bool valid = j < N;
-      const float lm2 = (lm - lm_ref) * 1.44269504088896340736f;
       const v2f yv[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
-      float kq[NQ];
+      if (PASS == T2_PASS_STEIN) {
+        const float2 dq = *reinterpret_cast<const float2 *>(&dsl[(size_t)j * 4 + q0]);  // the distances of pass PRIOR
+        const float dd[2] = {dq.x, dq.y};
+        float kq[2];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        v2f z[4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) z[h] = yv[h] - xq[q][h];
-        v2f d2 = z[0] * z[0];
-#pragma unroll
-        for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
-        const float dd = quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
-        const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
-        accL[q] += e;
-        if (FULL) {
+        for (int q = 0; q < 2; ++q) {
           float k;
-          if (MODE == PAIR_K1) k = valid ? __builtin_amdgcn_exp2f(dd * cS) : 0.f;
-          else k = valid ? __builtin_amdgcn_rsqf(fmaf(dd, cS, 1.0f)) : 0.f;
+          if (MODE == PAIR_K1) k = valid ? __builtin_amdgcn_exp2f(dd[q] * cS) : 0.f;
+          else k = valid ? __builtin_amdgcn_rsqf(fmaf(dd[q], cS, 1.0f)) : 0.f;
           kq[q] = k;
           const float kp = MODE == PAIR_K1 ? k : (k * k) * k;
-          const v2f ee = {e, e}, kk = {kp, kp};
+          const v2f kk = {kp, kp};
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            accA[q][h] = __builtin_elementwise_fma(ee, z[h], accA[q][h]);
-            accB[q][h] = __builtin_elementwise_fma(kk, z[h], accB[q][h]);
+          for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(kk, yv[h] - xq[q][h], acc[q][h]);
+        }
+        if (c == 0) *reinterpret_cast<float2 *>(&ksl[(size_t)j * 4 + q0]) = float2{kq[0], kq[1]};
+      } else {
+        const float lm2 = (lm - lm_ref) * 1.44269504088896340736f;
+        float dk[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          v2f z[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) z[h] = yv[h] - xq[q][h];
+          v2f d2 = z[0] * z[0];
+#pragma unroll
+          for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
+          const float dd = quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
+          dk[q] = dd;
+          const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
+          accL[q] += e;
+          if (PASS == T2_PASS_PRIOR) {
+            const v2f ee = {e, e};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(ee, z[h], acc[q][h]);
           }
         }
+        if (PASS == T2_PASS_PRIOR && c == 0) *reinterpret_cast<float2 *>(&dsl[(size_t)j * 4 + q0]) = float2{dk[0], dk[1]};
       }
-      if (FULL && c == 0) *reinterpret_cast<float2 *>(&ksl[(size_t)j * 4 + q0]) = float2{kq[0], kq[1]};
     }
   }
-  if (FULL) {
-    float v[48], r3[3];  // a[2][8] | b[2][8] | L[2] | padding
+  if (PASS == T2_PASS_PRIOR) {
+    float v[32], r2[2];  // a[2][8] | L[2] | padding
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        v[q * 8 + 2 * h] = accA[q][h].x;
-        v[q * 8 + 2 * h + 1] = accA[q][h].y;
-        v[16 + q * 8 + 2 * h] = accB[q][h].x;
-        v[16 + q * 8 + 2 * h + 1] = accB[q][h].y;
+        v[q * 8 + 2 * h] = acc[q][h].x;
+        v[q * 8 + 2 * h + 1] = acc[q][h].y;
       }
-      v[32 + q] = accL[q];
+      v[16 + q] = accL[q];
     }
 #pragma unroll
-    for (int i = 34; i < 48; ++i) v[i] = 0.f;
-    reduce_u16<48>(v, r3, lane);
-    red[0] = r3[0];
-    red[1] = r3[1];
-    red[2] = r3[2];
-    red[3] = 0.f;
+    for (int i = 18; i < 32; ++i) v[i] = 0.f;
+    reduce_u16<32>(v, r2, lane);
+    red[0] = r2[0];
+    red[1] = r2[1];
+  } else if (PASS == T2_PASS_STEIN) {
+    float v[16], r1[1];  // b[2][8]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        v[q * 8 + 2 * h] = acc[q][h].x;
+        v[q * 8 + 2 * h + 1] = acc[q][h].y;
+      }
+    reduce_u16<16>(v, r1, lane);
+    red[0] = r1[0];
   } else {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {  // 4 values: a plain all-reduce over u (row shifts, then the LDS crossbar for the rows)
@@ -262,7 +287,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *coefs = lds + T2_L_COEFS;
   float *ksl = lds + L.ksl;
   float *ppart = lds + T2_L_PPART;
-  float *gpl = lds + T2_L_GP, *rpl = lds + T2_L_RP;
+  float *gpl = lds + T2_L_GP, *rpart = lds + T2_L_RP;
+  float *dsl = lds + L.dsl;
   float *wpart = lds + T2_L_WPART;
   float *kpart = lds + T2_L_KPART;
   float *scl = lds + T2_L_SCL;
@@ -572,9 +598,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      t2_pair_pass<MODE, true>(f, th, ksl, pw, lane, lm_ref, red);
+      t2_pair_pass<MODE, T2_PASS_PRIOR>(f, th, dsl, ksl, pw, lane, lm_ref, red);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) ppart[(pw * 48 + reduce_u16_index<48>(i, lane)) * 4 + (lane & 3)] = red[i];
+      for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
       T2_TL(8, 16 * k + 3);
     }
     wg_sync();  // B1
@@ -612,21 +638,19 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         f->eta[n] = (-cmin / f->temp) + logf(zo);
       }
     } else {
-      const int v = tid - 512;  // 0..511: [0,128) grad_pri (q, d), [128,256) repulsion (q, d)
-      if (v < 256) {
+      const int v = tid - 512;  // 0..511: [0,128) grad_pri (q, d)
+      if (v < 128) {
         const int q = (v >> 5) & 3, d = v & 31, c = d >> 3, cc = d & 7;
-        const bool rep = v >= 128;
         float s = 0.f, l = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {  // the four waves that hold this query's half: their key quarters, in order
           const int pwq = (q >> 1) * 4 + w;
-          s += ppart[(pwq * 48 + (rep ? 16 : 0) + (q & 1) * 8 + cc) * 4 + c];
-          l += ppart[(pwq * 48 + 32 + (q & 1)) * 4 + c];
+          s += ppart[(pwq * 32 + (q & 1) * 8 + cc) * 4 + c];
+          l += ppart[(pwq * 32 + 16 + (q & 1)) * 4 + c];
         }
-        if (rep) rpl[q * T2_ROW + d] = s;
-        else gpl[q * T2_ROW + d] = (s / l) * f->inv_sp2;
-      } else if (v < 256 + T2_PW) {
-        flag_eps[v - 256] = 0.f;  // consumed by this iteration's rollouts; the next noise is staged after barrier B3
+        gpl[q * T2_ROW + d] = (s / l) * f->inv_sp2;
+      } else if (v < 128 + T2_PW) {
+        flag_eps[v - 128] = 0.f;  // consumed by this iteration's rollouts; the next noise is staged after barrier B3
       }
     }
     wg_sync();  // B2
@@ -678,7 +702,13 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         f->grad_pri[no] = gp_keep;
         if (f->update_a_mat) f->a_mat[no] = amv;
       }
-    } else if (wave == 10) {
+    }
+    if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
+      float rb[4];
+      t2_pair_pass<MODE, T2_PASS_STEIN>(f, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
+      rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
+    }
+    if (wave == 10) {
       t2_poll(cnt_score, 2u, (unsigned int)(k + 1), G, lane, tflag);
       T2_TL(10, 16 * k + 8);
     } else if (wave < 8) {
@@ -742,7 +772,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       float sa = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) sa += kpart[(w * 32 + op * 8 + (od & 7)) * 4 + (od >> 3)];
-      const float sb = rpl[op * T2_ROW + od];
+      float sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sb += rpart[(((op >> 1) * 4 + w) * 16 + (op & 1) * 8 + (od & 7)) * 4 + (od >> 3)];
       const float phi = sb * f->inv_l2 + sa * f->inv_n;
       const float gr = -phi;
       if (!adam) thv = fmaf(-f->lr, gr, thv);
@@ -790,7 +822,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
-    t2_pair_pass<MODE, false>(f, th, ksl, pw, lane, lm_ref, red);
+    t2_pair_pass<MODE, T2_PASS_LOGP>(f, th, dsl, ksl, pw, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;

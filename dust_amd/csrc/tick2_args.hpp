@@ -55,17 +55,17 @@ enum {
   T2_MAXM = 64,                               // dynamics samples per rollout (coefficient pairs in LDS)
   T2_L_TH = 0,                                // [4][32] the workgroup's particles, zero padded
   T2_L_MISC = T2_L_TH + T2_PW * T2_ROW,       // [192] small words (see tick2.hpp)
-  T2_L_PPART = T2_L_MISC + 192,               // [8 waves][48 sums][4 column groups] partials of the theta-only pass
-  T2_L_GP = T2_L_PPART + 8 * 48 * 4,          // [4][32] grad_pri
-  T2_L_RP = T2_L_GP + T2_PW * T2_ROW,         // [4][32] Stein repulsion
-  T2_L_WPART = T2_L_RP + T2_PW * T2_ROW,      // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update)
+  T2_L_PPART = T2_L_MISC + 192,               // [8 waves][32 sums][4 column groups] partials of the prior pass
+  T2_L_GP = T2_L_PPART + 8 * 32 * 4,          // [4][32] grad_pri
+  T2_L_RP = T2_L_GP + T2_PW * T2_ROW,         // [8 waves][16 sums][4 column groups] partials of the Stein repulsion
+  T2_L_WPART = T2_L_RP + 8 * 16 * 4,          // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update)
   T2_L_KPART = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [8 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
   T2_L_SCL = T2_L_KPART + 8 * 32 * 4,         // [4][32] score rows on their way out
   T2_L_COEFS = T2_L_SCL + T2_PW * T2_ROW,     // [T2_MAXM][2] dynamics coefficients of the iteration
-  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | grid | tile
+  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | dsl | grid | tile
 };
 struct Tick2Lds {
-  int cst, omg, ksl, grid, tile, total;
+  int cst, omg, ksl, dsl, grid, tile, total;
 };
 __host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_words) {
   Tick2Lds l;
@@ -73,7 +73,8 @@ __host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_
   l.cst = T2_L_VAR;               // [4][S] costs -> softmax weights
   l.omg = l.cst + ps;             // [4][S] omega weights
   l.ksl = l.omg + ps;             // [steps * 64][4] Stein kernel values k_ij of the workgroup's 4 queries
-  l.grid = l.ksl + steps * 64 * 4;
+  l.dsl = l.ksl + steps * 64 * 4;   // [steps * 64][4] squared distances |y_j - x_q|^2 (prior pass -> Stein pass)
+  l.grid = l.dsl + steps * 64 * 4;
   l.tile = l.grid + grid_words;   // [4][S][Dp] standard normals of the current iteration
   l.total = l.tile + T2_PW * S * Dp;
   return l;

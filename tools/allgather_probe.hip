@@ -105,15 +105,17 @@ __global__ __launch_bounds__(1024, 4) void probe(float *buf0, float *buf1, unsig
 }
 
 // pair-pass pattern: 8 waves, 16 steps each, 2 x 16 bytes per lane and step (16 rows), PF steps in flight, ~60 dependent-ish VALU per step
-template <int PF, bool TOUCH>
+template <int PF, bool TOUCH, bool UNIQ = false>
 __global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1, unsigned int *cnt, int rounds, float *out, unsigned long long *stamps) {
+  constexpr int LAUX = UNIQ ? 0 : 16;  // UNIQ: a fresh buffer per round (buf0 holds `rounds` of them), read with PLAIN loads
   __shared__ float red[16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
   const int u = lane >> 2, c = lane & 3;
   float total = 0.f;
+  int stale = 0;
   unsigned long long t_read = 0;
   for (int r = 0; r < rounds; ++r) {
-    float *buf = (r & 1) ? buf1 : buf0;
+    float *buf = UNIQ ? buf0 + (size_t)r * ROWS * 32 : ((r & 1) ? buf1 : buf0);
     const __amdgpu_buffer_rsrc_t rs = rsrc(buf, ROWS * 32);
     if (wave == 8 || wave == 9) {
       if (lane < 16) {
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1
     __syncthreads();
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
     v4f acc = {0.f, 0.f, 0.f, 0.f};
+    float chk = 0.f;
     if (wave >= 8) {
       const int kw = (wave - 8) & 3;
       float warm = 0.f;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
         const int j = (p * 4 + kw) * 16 + u;
-        ya[p] = ld16<16>(rs, (j * 32 + 8 * c) * 4);
-        yb[p] = ld16<16>(rs, (j * 32 + 8 * c + 4) * 4);
+        ya[p] = ld16<LAUX>(rs, (j * 32 + 8 * c) * 4);
+        yb[p] = ld16<LAUX>(rs, (j * 32 + 8 * c + 4) * 4);
       }
       for (int t0 = 0; t0 < 16; t0 += PF) {
 #pragma unroll
@@ -149,17 +152,22 @@ __global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1
           v4f y0 = ya[p], y1 = yb[p];
           const int tn = min(t0 + p + PF, 15);
           const int j = (tn * 4 + kw) * 16 + u;
-          ya[p] = ld16<16>(rs, (j * 32 + 8 * c) * 4);
-          yb[p] = ld16<16>(rs, (j * 32 + 8 * c + 4) * 4);
+          ya[p] = ld16<LAUX>(rs, (j * 32 + 8 * c) * 4);
+          yb[p] = ld16<LAUX>(rs, (j * 32 + 8 * c + 4) * 4);
           v4f z = y0 + y1;
+          chk += y0[0] + y1[0];
 #pragma unroll
-          for (int q = 0; q < 12; ++q) z = z * 1.0001f + acc;  // ~48 dependent VALU
+          for (int q = 0; q < 3; ++q) z = z * 1.0001f + acc;  // ~12 dependent VALU
           acc += z * 1e-3f;
         }
       }
       if (warm == 1.234e-30f) acc[0] += warm;
     }
-    total += acc[0] + acc[1] + acc[2] + acc[3];
+    total += acc[0] * 1e-30f;
+    {  // every piece of every row must carry this round's tag
+      const float want = 2.f * 16.f * (float)(r + 1);
+      if (wave >= 8 && chk != want) stale = 1;
+    }
     __syncthreads();
     const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
     if (r >= rounds / 2) t_read += t3 - t2;
@@ -173,13 +181,16 @@ __global__ __launch_bounds__(1024, 4) void stream_probe(float *buf0, float *buf1
     out[b] = s;
     stamps[b * 4 + 2] = t_read;
   }
+  if (stale) atomicAdd((unsigned int *)&stamps[b * 4 + 3], 1u);
+  if (false) {
+  }
 }
-template <int PF, bool TOUCH>
+template <int PF, bool TOUCH, bool UNIQ = false>
 static void run_stream(const char *name) {
   float *b0, *b1, *out;
   unsigned int *cnt;
   unsigned long long *st;
-  hipMalloc(&b0, ROWS * 32 * 4);
+  hipMalloc(&b0, (size_t)(UNIQ ? 200 : 1) * ROWS * 32 * 4);
   hipMalloc(&b1, ROWS * 32 * 4);
   hipMalloc(&out, NWG * 4);
   hipMalloc(&cnt, NSH * STRIDE * 4);
@@ -187,12 +198,17 @@ static void run_stream(const char *name) {
   const int rounds = 200;
   std::vector<unsigned long long> hs(NWG * 4);
   hipMemset(cnt, 0, NSH * STRIDE * 4);
-  stream_probe<PF, TOUCH><<<NWG, 1024>>>(b0, b1, cnt, rounds, out, st);
+  hipMemset(st, 0, NWG * 4 * 8);
+  stream_probe<PF, TOUCH, UNIQ><<<NWG, 1024>>>(b0, b1, cnt, rounds, out, st);
   hipDeviceSynchronize();
   hipMemcpy(hs.data(), st, NWG * 4 * 8, hipMemcpyDeviceToHost);
   double rd = 0;
-  for (int i = 0; i < NWG; ++i) rd += hs[i * 4 + 2];
-  printf("%-56s read+compute %.2f us per pass\n", name, rd / ((double)NWG * (rounds - rounds / 2) * 100.0));
+  unsigned long long stale = 0;
+  for (int i = 0; i < NWG; ++i) {
+    rd += hs[i * 4 + 2];
+    stale += hs[i * 4 + 3];
+  }
+  printf("%-56s read+compute %.2f us per pass, %llu waves saw a stale or torn row\n", name, rd / ((double)NWG * (rounds - rounds / 2) * 100.0), stale);
   hipFree(b0); hipFree(b1); hipFree(out); hipFree(cnt); hipFree(st);
 }
 
@@ -259,5 +275,9 @@ int main() {
   run_stream<4, true>("stream, 4 steps in flight, lines touched first");
   run_stream<8, false>("stream, 8 steps in flight");
   run_stream<16, false>("stream, 16 steps in flight");
+  run_stream<1, false, true>("plain loads, buffer per round: 1 step in flight");
+  run_stream<2, false, true>("plain loads, buffer per round: 2 steps in flight");
+  run_stream<4, false, true>("plain loads, buffer per round: 4 steps in flight");
+  run_stream<16, false, true>("plain loads, buffer per round: 16 steps in flight");
   return 0;
 }

@@ -1,7 +1,7 @@
 # diagnostic build of the library with in-kernel phase stamps: tools/_libdust_stamps.so (use with DUST_AMD_LIB=...)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-F="--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -I$R/include -I$R/dust_amd/csrc -DDUST_STAMPS"
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -I$R/include -I$R/dust_amd/csrc -DDUST_STAMPS $T2X"
 mkdir -p $R/dust_amd/build
 /opt/rocm/bin/hipcc $F -c $R/dust_amd/csrc/dust_amd.hip -o $R/dust_amd/build/stamps_a.o &
 /opt/rocm/bin/hipcc $F -c $R/dust_amd/csrc/tick2.hip -o $R/dust_amd/build/stamps_b.o
