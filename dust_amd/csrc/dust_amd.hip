@@ -129,7 +129,7 @@ struct dust_ctx {
   // owner-computes persistent tick (tick2.hpp): exchange buffers, two counter sets, bookkeeping of ticks that did not start
   float *t2_xq, *t2_sq, *t2_lwq;
   unsigned int *t2_cnt;
-  int t2_set, t2_occ;
+  int t2_set, t2_occ, t2_gens;
   size_t t2_occ_lds;
   unsigned int t2_aborts_seen;  // value of the device-side "did not start" counter already accounted for
   bool t2_inflight;             // a tick2 launch was enqueued since the last check
@@ -2390,13 +2390,21 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   const int grid = c->N / T2_PW;
   if (c->t2_occ < 1 || grid > c->t2_occ * device_cus(c)) return DUST_OK;
   if (c->cfg.dim_p > 0 && c->M >= 1 && !c->params_dev) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
-  if (!c->t2_xq) {
-    TRY(dalloc(&c->t2_xq, (size_t)c->N * T2_ROW));
-    TRY(dalloc(&c->t2_sq, (size_t)c->N * T2_ROW));
+  if (!c->t2_xq || c->t2_gens < n_steps + 1) {  // one [N][32] block per generation of particles / score rows (tick2.hpp t2_ld16)
+    if (c->t2_xq) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      (void)hipFree(c->t2_xq);
+      (void)hipFree(c->t2_sq);
+      c->t2_xq = c->t2_sq = nullptr;
+    }
+    const int gens = std::max(n_steps + 1, 8);
+    TRY(dalloc(&c->t2_xq, (size_t)gens * c->N * T2_ROW));
+    TRY(dalloc(&c->t2_sq, (size_t)gens * c->N * T2_ROW));
+    c->t2_gens = gens;
+  }
+  if (!c->t2_cnt) {
     TRY(dalloc(&c->t2_lwq, (size_t)c->N));
     TRY(dalloc(&c->t2_cnt, (size_t)2 * T2_SETS * T2_CNT_STRIDE));
-    HIP_TRY(hipMemsetAsync(c->t2_xq, 0, (size_t)c->N * T2_ROW * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->t2_sq, 0, (size_t)c->N * T2_ROW * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->t2_cnt, 0, (size_t)2 * T2_SETS * T2_CNT_STRIDE * sizeof(unsigned int), c->stream));
     c->t2_set = 0;
   }

@@ -24,8 +24,8 @@
 // Hand-offs: write-through rows (one 128-byte line per particle, 16-byte sc1 stores) -> every storing wave drains vmcnt -> one
 // agent-scope add per storing wave on the workgroup's counter shard; consumers: one wave polls the T2_NSH shard lines with sc1
 // loads, then a workgroup barrier (or an LDS word), then sc1 loads only (cdna_hip_programming.md Guideline 16).  The exchange
-// buffers are single: a reader of theta(k) finishes before it publishes score(k), a writer of theta(k+1) has waited for every
-// score(k); likewise for the score rows.
+// buffers hold one [N][32] block PER GENERATION (particles: n_iters + 1, score rows: n_iters), which is what lets the consumers
+// use plain (L1 / L2-cached) loads - see t2_ld16.
 // Start barrier: every workgroup arrives on a counter; workgroup 0 waits (bounded) for all of them and publishes go / no-go.
 // Nothing is written before "go", so a launch whose workgroups cannot all be resident (another context on the device) leaves the
 // state untouched and the host runs that tick on the launch-per-iteration path instead.
@@ -65,9 +65,14 @@ __device__ __forceinline__ T2ArgPtr t2_args() {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t t2_rsrc(const float *p, const int n_floats) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n_floats * 4, 0x00020000);
 }
-// 16-byte loads / stores that bypass this CU's L1 / write through to memory (aux 16 = sc1 on gfx950)
+// 16-byte stores that write through to memory (aux 16 = sc1 on gfx950), and PLAIN 16-byte loads of the exchanged rows.  Plain loads
+// are coherent here by construction: every generation of particles / score rows has a buffer of its own (T2 exchange buffers are
+// [generation][N][32]), so no line of it can sit in this CU's L1 or this XCD's L2 before the generation was written through by its
+// owner - and nobody loads it before the arrival counters say so (L1 / L2 start a launch invalidated, as for any kernel that reads
+// what an earlier kernel wrote).  Against sc1 loads of ONE reused buffer: 3.2 instead of 4.5 us for a pass over 256 KB per CU
+// (tools/allgather_probe.hip, no stale or torn row in 200 rounds), and the rows two waves of a CU share come out of its L1.
 __device__ __forceinline__ v4f t2_ld16(__amdgpu_buffer_rsrc_t r, const int byte_off) {
-  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 __device__ __forceinline__ void t2_st16(__amdgpu_buffer_rsrc_t r, const int byte_off, const v4f v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(t2_v4u, v), r, byte_off, 0, 16);
@@ -105,16 +110,16 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lan
 //                  all, a third of it off the path that the score rows wait for (146 -> 130 us per tick).
 //   In both a wave takes TWO of the workgroup's four queries (waves 8-11: queries 0-1, waves 12-15: queries 2-3) and a quarter of
 //   the keys: four queries per wave put the accumulators alone over the 128-register budget of a 16-wave workgroup.
-//   T2_PASS_LOGP   the log-density pass of SVMPC.forward (svmpc.py:137): L only, four queries per wave, an eighth of the keys.
+//   T2_PASS_LOGP   the log-density pass of SVMPC.forward (svmpc.py:137): L only, four queries per wave, all 16 waves share the keys.
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
 // f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
 enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
 template <int MODE, int PASS>
-__device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq /* LDS [4][32] own query rows */, float *dsl, float *ksl, const int pw,
-                                             const int lane, const float lm_ref,
+__device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* theta generation */, const float *thq /* LDS [4][32] own query rows */,
+                                             float *dsl, float *ksl, const int pw, const int lane, const float lm_ref,
                                              float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */) {
   constexpr int NQ = PASS == T2_PASS_LOGP ? 4 : 2;   // queries per wave
-  constexpr int NKW = PASS == T2_PASS_LOGP ? 8 : 4;  // waves that share the keys
+  constexpr int NKW = PASS == T2_PASS_LOGP ? 16 : 4;  // waves that share the keys (forward: all 16 waves of the workgroup)
   const int u = lane >> 2, c = lane & 3, N = f->N;
   const int kw = PASS == T2_PASS_LOGP ? pw : (pw & 3), q0 = PASS == T2_PASS_LOGP ? 0 : (pw >> 2) * 2;
   v2f xq[NQ][4];
@@ -135,7 +140,7 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq 
     for (int h = 0; h < 4; ++h) acc[q][h] = v2f{0.f, 0.f};
     accL[q] = 0.f;
   }
-  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq, N * T2_ROW);
+  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq + (size_t)gen * N * T2_ROW, N * T2_ROW);
   constexpr int PF = 2;  // key steps in flight (4 spill the prefetched rows themselves into the loop: 17 us per pass instead of 6)
   v4f ya[PF], yb[PF];
   float lbuf[PF];
@@ -145,7 +150,7 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const float *thq 
     y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
     if (PASS != T2_PASS_STEIN) lm = f->logmix[j];
   };
-  const int steps = PASS == T2_PASS_LOGP ? f->steps / 2 : f->steps;
+  const int steps = PASS == T2_PASS_LOGP ? f->steps / 4 : f->steps;
 #pragma unroll
   for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p], lbuf[p]);
   const float cP = f->cP, cS = f->cS;
@@ -352,6 +357,20 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     if (badth) flag_th[op] = 1.f;
   }
 
+  // publish rows of the workgroup's particles held in LDS ([4][32]) as whole 128-byte lines: waves 8 / 9 take two rows each
+  auto publish_rows = [&](const float *src, const float *dst, unsigned int *lines) {
+    const __amdgpu_buffer_rsrc_t r = t2_rsrc(dst, N * T2_ROW);
+    const int lane = tid0 & 63;
+    if (lane < 16) {
+      const int pl = (wave - 8) * 2 + (lane >> 3), c = lane & 7;
+      const float4 v = *reinterpret_cast<const float4 *>(&src[pl * T2_ROW + 4 * c]);
+      t2_st16(r, ((n_first + pl) * T2_ROW + 4 * c) * 4, v4f{v.x, v.y, v.z, v.w});
+    }
+    t2_arrive_wave(lines + (size_t)sh * T2_CNT_STRIDE, lane);
+  };
+
+  if (isown) publish_rows(th, f->xq, cnt_theta);  // theta generation 0 (buffer 0) (the exchange buffer is scratch: harmless if the tick does not start)
+
   // dynamics coefficients of iteration k (rollout_body stage 1); wave 11
   auto make_coefs = [&](const T2ArgPtr f, const int k) {
     const DevModel dmc = f->dm;
@@ -461,19 +480,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   const bool same_w = (f->alpha * f->temp == 1.0f);
   const int lane0 = tid0 & 63;
 
-  // publish rows of the workgroup's particles held in LDS ([4][32]) as whole 128-byte lines: waves 8 / 9 take two rows each
-  auto publish_rows = [&](const float *src, const float *dst, unsigned int *lines) {
-    const __amdgpu_buffer_rsrc_t r = t2_rsrc(dst, N * T2_ROW);
-    const int lane = tid0 & 63;
-    if (lane < 16) {
-      const int pl = (wave - 8) * 2 + (lane >> 3), c = lane & 7;
-      const float4 v = *reinterpret_cast<const float4 *>(&src[pl * T2_ROW + 4 * c]);
-      t2_st16(r, ((n_first + pl) * T2_ROW + 4 * c) * 4, v4f{v.x, v.y, v.z, v.w});
-    }
-    t2_arrive_wave(lines + (size_t)sh * T2_CNT_STRIDE, lane);
-  };
-
-  if (isown) publish_rows(th, f->xq, cnt_theta);  // theta generation 0 (the exchange buffer is scratch: harmless if the tick does not start)
   const int wave0 = wave;
   for (int k = 0; k < f->n_iters; ++k) {
     // opaque copies of the lane and wave index: everything derived from them is recomputed where it is used instead of being hoisted
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      t2_pair_pass<MODE, T2_PASS_PRIOR>(f, th, dsl, ksl, pw, lane, lm_ref, red);
+      t2_pair_pass<MODE, T2_PASS_PRIOR>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
 #pragma unroll
       for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
       T2_TL(8, 16 * k + 3);
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       gp_keep = gpl[op * T2_ROW + od];
       gs_keep = gs;
       scl[op * T2_ROW + od] = ownv ? gs + gp_keep : 0.f;
-      publish_rows(scl, f->sq, cnt_score);
+      publish_rows(scl, f->sq + (size_t)k * N * T2_ROW, cnt_score);
       T2_TL(8, 16 * k + 7);
       if (ownv) {
         f->score[no] = gs_keep + gp_keep;
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
       float rb[4];
-      t2_pair_pass<MODE, T2_PASS_STEIN>(f, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
+      t2_pair_pass<MODE, T2_PASS_STEIN>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
       rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
     }
     if (wave == 10) {
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     // ================= phase 5: sum_j k_ij s_j (P waves stream the score rows) =================
     if (wave >= 8) {
       const int pw = wave - 8, u = lane >> 2, c = lane & 3;
-      const __amdgpu_buffer_rsrc_t rsq = t2_rsrc(f->sq, N * T2_ROW);
+      const __amdgpu_buffer_rsrc_t rsq = t2_rsrc(f->sq + (size_t)k * N * T2_ROW, N * T2_ROW);
       v2f acc[T2_PW][4];
 #pragma unroll
       for (int q = 0; q < T2_PW; ++q)
@@ -783,7 +789,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       th[op * T2_ROW + od] = thv;
       const unsigned long long badm = __ballot(ownv && !(fabsf(thv) <= 3.0e38f));
       if ((lane & 31) == 0) flag_th[op] = ((badm >> (lane & 32)) & 0xffffffffull) ? 1.f : 0.f;
-      if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq, cnt_theta);
+      if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq + (size_t)(k + 1) * N * T2_ROW, cnt_theta);
       T2_TL(8, 16 * k + 13);
       if (ownv) f->phi[no] = phi;
     }
@@ -814,21 +820,20 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     while (t2_lds_ld(sig) == 0u) __builtin_amdgcn_s_sleep(1);
     if (sig[0] == 2u) return;
   }
-  if (wave >= 8) {  // log p(theta_n) under the tick's prior, whose means ARE the particles (svmpc.py:137; svgd.py:87)
-    const int pw = wave - 8;
+  {  // log p(theta_n) under the tick's prior, whose means ARE the particles (svmpc.py:137; svgd.py:87): all 16 waves
     if (wave == 15) {
       t2_poll(cnt_theta, 2u, (unsigned int)(kf + 1), G, lane, tflag);
       if (lane == 0) t2_lds_st(sig + 1, (unsigned int)(kf + 1));
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
-    t2_pair_pass<MODE, T2_PASS_LOGP>(f, th, dsl, ksl, pw, lane, lm_ref, red);
+    t2_pair_pass<MODE, T2_PASS_LOGP>(f, kf, th, dsl, ksl, wave, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;
       s = lane == 2 ? red[2] : s;
       s = lane == 3 ? red[3] : s;
-      ppart[pw * 4 + lane] = s;
+      ppart[wave * 4 + lane] = s;
     }
   }
   wg_sync();
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     if (lane < T2_PW) {
       float l = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) l += ppart[w * 4 + lane];
+      for (int w = 0; w < 16; ++w) l += ppart[w * 4 + lane];
       const float lp = (lm_ref + logf(l)) + f->log_norm;
       const int n = n_first + lane;
       f->logp[n] = lp;
