@@ -6,7 +6,7 @@
 N = 1 (the contract's workload): BASELINE.json configs[1] - Pendulum, 1024 Stein particles, S=128 action samples, M=1, H=30,
 5 SVGD iterations per tick, gpytorch-RBF ("K1") kernel, SGD lr 2, fp32, synthetic seeded inputs resident in HBM.  One "step" =
 one control tick = SVMPC.optimize(5 iterations) + SVMPC.forward (weights, argmax, roll, prior refresh): ONE persistent kernel
-launch (dust_amd/csrc/persist.hpp).  Policy noise is drawn on the device inside the timed region (Philox, in registers) - the
+launch (dust_amd/csrc/tick2.hpp; the first tick of a context, whose prior does not alias the particles yet, runs persist.hpp).  Policy noise is drawn on the device inside the timed region (Philox, in registers) - the
 reference also draws its noise inside the tick - so no work is skipped.  `value` is the open-loop rate (ticks enqueued back to
 back, plant state constant); `closed_loop_ticks_per_s` is the rate when every tick's first action is read back (one pinned
 device-to-host copy + one stream synchronisation), stepped through a host plant model and fed to the next tick - the loop order
@@ -16,6 +16,16 @@ N > 1: BASELINE.json configs[3] - Particle (2-D point mass, obstacle grid), 1638
 iteration per tick - sharded over the N ranks by particle index (strong scaling: the joint problem is fixed), with the in-place
 RCCL all-gathers of DESIGN.md section 6; `value` = joint ticks/s.  `weak_cfg2` carries the round-1 weak-scaled figure
 (1024 Pendulum particles per GPU) as a secondary field when --weak is given.
+
+Warm-up: the W warm-up ticks are run, and then more of them until 0.4 s have passed (`warmup_ticks_run` says how many): the
+chip's clock needs load to settle - after the idle seconds of process start-up, 20 timed ticks take 137 us each behind 0.1 s of
+ticks and 126 us behind 0.3 s or more, whatever the kernel (tools/coldstart.py, tools/bench_timing_probe.py) - and the driver's
+W = 5 ticks are 0.6 ms.  The K timed ticks are exactly K.  torch's HIP context is created before the warm-up (its lazy creation
+inside the first torch.cuda.synchronize() stalled the 20 ticks behind it for 37 ms).
+
+`scale_workload` (every line, N = 1 included): BASELINE.json configs[3] (Particle N=16384, S=64, M=4, H=40, 1 iteration) on the
+N GPUs of the run - ticks/s, ms per tick and, for N > 1, the tick's all-gathers timed alone (comm_us_per_tick) - so that
+value(N) / value(1) can be formed on ONE workload from the driver's lines: scale_workload.ticks_per_s.
 
 Extra objects in the JSON line (tier contract):
   roofline      the rollout kernel in its HBM-BOUND form - stored states (MultiDISCO.forward returns them), BASELINE configs[2]
@@ -146,6 +156,12 @@ def roofline_section(local, state_pend):
     reps = 20
     both_s = c.profile_rollout(st, ptr, n_slices, reps, store_states=True) * 1e-3  # back-to-back launches, one event pair
     per_kernel = c.profile_get()  # ... and one event pair per launch, per kernel (dust_profile_rollout leaves them in the slots)
+    samples = []  # single launches, one event pair each: the spread (launches of this kernel range 2.0-2.8 ms run to run)
+    for _ in range(16):
+        c.profile_rollout(st, ptr, n_slices, 1, store_states=True)
+        pk = c.profile_get()
+        if "states_kernel" in pk:
+            samples.append(pk["states_kernel"][0] / pk["states_kernel"][1] * 1e3)
     b_alg = c.rollout_bytes(store_states=True)
     kname = "dust::rollout_stream_kernel<1,true,false,true> (rollout kernel, stored-states form: states [M][S][N][H+1][ds] written)"
     avg_s, second_pass = both_s, None
@@ -159,13 +175,16 @@ def roofline_section(local, state_pend):
                  "launch pair includes the (idle) general-path launch behind it)")
     ach = b_alg / avg_s / 1e9
     traffic, traffic_src = None, None
-    tf = os.path.join(ROOT, "profiles", "round2_rollout_states_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "round3_rollout_states_traffic.json")
     if os.path.exists(tf):
         with open(tf) as fh:
             tj = json.load(fh)
-        traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round2_rollout_states_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round3_rollout_states_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
     out.update(kernel=kname, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                algorithmic_bytes_per_launch=b_alg, avg_launch_us=avg_s * 1e6, launches=reps,
+               launch_us_median=(float(np.median(samples)) if samples else None),
+               launch_us_p90=(float(np.percentile(samples, 90)) if samples else None),
+               frac_at_median=(b_alg / (float(np.median(samples)) * 1e-6) / 1e9 / HBM_PEAK_GBS if samples else None),
                workload="Particle N=%d, S=%d, M=%d, H=%d (BASELINE configs[2]): %.2f GB of states per launch (working set >> 256 MiB Infinity Cache)"
                         % (c3["N"], c3["S"], c3["M"], c3["H"], b_alg / 1e9),
                timing=("one HIP event pair per launch on the context's stream, %d launches" % reps) if second_pass is not None
@@ -219,6 +238,12 @@ def main():
         entry.build()
     import torch
 
+    # torch initialises its HIP context lazily, at the first torch.cuda call - which would otherwise be the synchronize() in front of
+    # the timed region: the 20 ticks enqueued right behind it then took 37 ms instead of 0.13 (tools/bench_timing_probe.py)
+    torch.cuda.set_device(local)
+    torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
+
     dist = None
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if world > 1 or (under_launcher and os.environ.get("DUST_BENCH_FORCE_DIST")):
@@ -234,26 +259,41 @@ def main():
     from dust_amd import Context
     from dust_amd.parallel import ShardedSVMPC
 
+    MIN_WARM_S = float(os.environ.get("DUST_BENCH_WARM_S", "0.4"))  # clock ramp after the idle seconds of process start-up: 0.1 s of load left the 20 timed ticks at 137 us, 0.3 s and more at 126 us (tools/coldstart.py, tools/bench_timing_probe.py)
+
+    def warm(tick, sync, n_min):
+        """>= n_min warm-up ticks and >= MIN_WARM_S seconds of them, enqueued in small batches (the GPU, not the host queue, keeps time)."""
+        n, t0 = 0, time.perf_counter()
+        if dist is not None:  # a sharded tick is a collective: every rank must run the same number (cfg4 ticks are 1-4 ms each)
+            n_min = max(n_min, 30)
+        while n < n_min or (dist is None and time.perf_counter() - t0 < MIN_WARM_S):
+            for _ in range(max(1, min(25, n_min - n) if n < n_min else 25)):
+                tick()
+                n += 1
+            sync()
+        return n
+
     def timed(tick, sync):
-        for _ in range(args.warmup):
-            tick()
-        sync()
+        n_w = warm(tick, sync, args.warmup)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tick()
+        t_enq = time.perf_counter()
         sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
+        if os.environ.get("DUST_BENCH_DEBUG"):
+            print("timed region: enqueue %.1f us, total %.1f us, warm-up ticks %d" % ((t_enq - t0) * 1e6, el * 1e6, n_w), file=sys.stderr)
         if dist is not None:
             t = torch.tensor([el], device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el
+        return el, n_w
 
     w = WORKLOAD
     state = np.array([3.0, 0.0], np.float32)
@@ -265,13 +305,16 @@ def main():
         ctx.set_theta(theta)
         ctx.set_prior(mu)
         ctx.set_a_mat(theta)
-        el = timed(lambda: ctx.svmpc_tick(state, w["n_iters"], want_outputs=False), ctx.sync)
+        el, n_warm = timed(lambda: ctx.svmpc_tick(state, w["n_iters"], want_outputs=False), ctx.sync)
+        extra["warmup_ticks_run"] = n_warm
+        extra["tick_paths"] = ctx.tick_stats()  # which kernel served the ticks (tick2 = owner-computes one-launch tick)
         # closed loop (simulations.py:104-123): optimize + forward -> first action -> plant -> next tick
         st = state.copy()
-        # (steady state: the first ~200 ticks that read their outputs back run at 2.5x the time - a one-off of the HIP runtime's
-        # copy / wait path when torch is loaded in the process, measured with tools/host_timing.py - so this loop warms up longer)
-        for _ in range(max(args.warmup, 250)):
+        n_wcl, t0 = 0, time.perf_counter()
+        while n_wcl < args.warmup or time.perf_counter() - t0 < MIN_WARM_S:  # the same warm-up rule, by time
             a_seq, _ = ctx.svmpc_tick(st, w["n_iters"], want_outputs=True)
+            n_wcl += 1
+        extra["closed_loop_warmup_ticks_run"] = n_wcl
         n_cl = args.steps
         t0 = time.perf_counter()
         for _ in range(n_cl):
@@ -286,6 +329,25 @@ def main():
         par = "single GPU"
         value = args.steps / el
         unit = "control steps/s"
+        # the multi-GPU workload on this one GPU: the N = 1 point of the scaling curve
+        c4 = CFG4
+        mu4, theta4 = synth(c4["N"], c4["H"], 2, spread=1.0)
+        one = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
+                      uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
+        one.set_theta(theta4); one.set_prior(mu4); one.set_a_mat(theta4)
+        p4 = (1.0 + 0.1 * np.random.default_rng(5).standard_normal((c4["n_iters"], c4["M"], 1))).astype(np.float32)
+        st4 = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+        n4w = warm(lambda: one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False), one.sync, 3)
+        n4 = 20
+        t1 = time.perf_counter()
+        for _ in range(n4):
+            one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+        one.sync()
+        e4 = time.perf_counter() - t1
+        one.close()
+        extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
+                                       n_gpus=1, ticks_per_s=n4 / e4, ms_per_tick=1e3 * e4 / n4, comm_us_per_tick=0.0, ticks=n4,
+                                       warmup_ticks_run=n4w)
     else:
         c4 = CFG4
         mu, theta = synth(c4["N"], c4["H"], 2, spread=1.0)
@@ -296,7 +358,12 @@ def main():
         st4 = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
         sh = ShardedSVMPC(common, rank, n_gpus, dist)
         sh.set_state(theta, mu)
-        el = timed(lambda: sh.tick(st4, c4["n_iters"], params=params), sh.sync)
+        el, n_warm = timed(lambda: sh.tick(st4, c4["n_iters"], params=params), sh.sync)
+        extra["warmup_ticks_run"] = n_warm
+        comm_us = sh.ctx.comm_probe(c4["n_iters"], 50) if sh.c_side else None  # the tick's all-gathers alone (collective: every rank)
+        extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
+                                       n_gpus=n_gpus, ticks_per_s=args.steps / el, ms_per_tick=1e3 * el / args.steps, comm_us_per_tick=comm_us,
+                                       ticks=args.steps, warmup_ticks_run=n_warm)
         workload = ("Particle N=%d total (%d per GPU), S=64, M=4, H=40, 1 SVGD iter, K1 kernel, SGD, device Philox noise inside the tick"
                     % (c4["N"], c4["N"] // n_gpus))
         par = "particles sharded x%d (strong scaling), in-place RCCL all-gathers of score and theta per SVGD iteration" % n_gpus
@@ -316,6 +383,7 @@ def main():
                 one.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
             one.sync()
             extra["one_gpu_same_workload_ticks_per_s"] = n1 / (time.perf_counter() - t1)
+            extra["scale_workload"]["one_gpu_ticks_per_s"] = extra["one_gpu_same_workload_ticks_per_s"]
             one.close()
         dist.barrier()
         if args.weak:
@@ -325,14 +393,14 @@ def main():
                            sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
             sh2 = ShardedSVMPC(common2, rank, n_gpus, dist)
             sh2.set_state(th2, mu2)
-            el2 = timed(lambda: sh2.tick(state, w["n_iters"]), sh2.sync)
+            el2, _ = timed(lambda: sh2.tick(state, w["n_iters"]), sh2.sync)
             extra["weak_cfg2"] = dict(joint_ticks_per_s=args.steps / el2, n_particles_total=n_tot,
                                       shard_ticks_per_s=args.steps / el2 * n_gpus)
 
     roofline = None
     if rank == 0 and not args.no_roofline and dist is None:
         roofline = roofline_section(local, state)
-        pf = os.path.join(ROOT, "profiles", "round2_tick_pmc.json")
+        pf = os.path.join(ROOT, "profiles", "round3_tick_pmc.json")
         if os.path.exists(pf):  # VALU issue fraction of the persistent tick kernel from the committed SQ counter pass
             with open(pf) as fh:
                 pj = json.load(fh)
@@ -340,9 +408,9 @@ def main():
             if insts:
                 issue_s = insts / VALU_PEAK_WAVE_INSTR_PER_S
                 roofline["product_kernel"] = dict(
-                    kernel="dust::svmpc_tick_kernel<0,1,4> (one launch = one control tick)", bound="valu-issue / hand-off latency",
+                    kernel=pj.get("kernel", "dust::svmpc_tick2_kernel<0,1>") + " (one launch = one control tick)", bound="valu-issue / hand-off latency",
                     valu_wave_instructions_per_tick=insts, valu_issue_floor_us=issue_s * 1e6, measured_us=1e6 * el / args.steps,
-                    frac=issue_s / (el / args.steps), source="profiles/round2_tick_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)")
+                    frac=issue_s / (el / args.steps), source="profiles/round3_tick_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

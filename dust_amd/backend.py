@@ -137,6 +137,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         L.check(L.load().dust_comm_init(self._h, C.cast(buf, L.VP), int(rank), int(world)))
 
+    def comm_probe(self, n_steps, reps=50):
+        """Microseconds per tick of the sharded tick's all-gathers alone (collective over all ranks)."""
+        us = C.c_double(0.0)
+        L.check(L.load().dust_comm_probe(self._h, int(n_steps), int(reps), C.byref(us)))
+        return float(us.value)
+
     def close(self):
         if self._h is not None:
             L.load().dust_destroy(self._h)

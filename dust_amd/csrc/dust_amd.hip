@@ -2568,6 +2568,45 @@ static int gather_inplace(dust_ctx *c, float *buf, size_t count) {
   return rccl::check(rccl::all_gather(buf + (size_t)c->comm_rank * count, buf, count, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather");
 }
 
+// The collectives of one sharded control tick alone - per SVGD iteration the score and the particle all-gather, per tick the
+// log-weights - `reps` times back to back on the context's stream between one pair of HIP events: their cost when nothing
+// overlaps them (bench.py reports it as comm_us_per_tick beside the sharded rate).  A collective over all ranks.
+extern "C" int dust_comm_probe(dust_ctx *c, int n_steps, int reps, double *us_per_tick) {
+  if (!c || !us_per_tick || reps < 1 || n_steps < 0) return fail(DUST_ERR_INVALID, "bad argument");
+  if (!c->comm) return fail(DUST_ERR_STATE, "no communicator (dust_comm_init)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  const size_t shard = (size_t)c->nloc * c->D;
+  float *scratch = nullptr;  // gathers into scratch: the context's particles stay untouched
+  TRY(dalloc(&scratch, (size_t)c->N * c->D));
+  auto gather = [&](size_t count) {
+    return rccl::check(rccl::all_gather(scratch + (size_t)c->comm_rank * count, scratch, count, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather");
+  };
+  int st = DUST_OK;
+  for (int w = 0; w < 2 && st == DUST_OK; ++w) st = gather(shard);  // warm-up
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (st == DUST_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) st = fail(DUST_ERR_HIP, "hipEventCreate");
+  if (st == DUST_OK) {
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps && st == DUST_OK; ++r) {
+      for (int k = 0; k < n_steps && st == DUST_OK; ++k) {
+        st = gather(shard);
+        if (st == DUST_OK) st = gather(shard);
+      }
+      if (st == DUST_OK) st = gather((size_t)c->nloc);
+    }
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_tick = 1e3 * (double)ms / reps;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(scratch);
+  return st;
+}
+
 // One control tick of a SHARDED context with its own communicator (north_star: "an RCCL all-gather over xGMI of
 // particle states before the pairwise kernel step"): rank-local rollouts / prior rows / score -> all-gather(score) -> Stein pass
 // + update of the rank's rows -> all-gather(theta) (the prior means alias theta: the next prior pass needs every rank's new

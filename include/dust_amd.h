@@ -226,6 +226,10 @@ int dust_svmpc_forward_finish(dust_ctx *ctx, float *a_seq, float *p_weights);
 int dust_comm_unique_id(void *id /* DUST_COMM_ID_BYTES */);
 int dust_comm_init(dust_ctx *ctx, const void *id, int rank, int world);
 int dust_comm_destroy(dust_ctx *ctx);
+/* The all-gathers of one sharded tick alone (per SVGD iteration: score rows and particles; per tick: the log-weights), `reps` times
+ * back to back on the context's stream between one pair of HIP events -> microseconds per tick when nothing overlaps them.
+ * Collective over all ranks; the context's particles are not touched.  (Measurement aid; no reference counterpart.) */
+int dust_comm_probe(dust_ctx *ctx, int n_steps, int reps, double *us_per_tick);
 /* run the context's kernels on an external HIP stream (hipStream_t), e.g. torch's current stream */
 int dust_set_stream(dust_ctx *ctx, void *hip_stream);
 
