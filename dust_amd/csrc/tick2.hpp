@@ -286,7 +286,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *ll = misc + 40;         // [4] log-likelihood of the last sample (SVMPC.forward, fast_pred)
   float *flag_th = misc + 44;    // [4] non-finite particle
   float *flag_eps = misc + 48;   // [4] non-finite caller-supplied noise
-  float *lmref = misc + 56;      // max_j log pi_j
+  // (misc[56..59] unused)
   unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived
   float *wred = misc + 64;       // [128] block-reduction scratch
   float *coefs = lds + T2_L_COEFS;
@@ -333,29 +333,16 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     sig[0] = 0u;
     sig[1] = 0u;
   }
-  if (tid0 >= 32 && tid0 < 32 + T2_PW) ll[tid0 - 32] = f->logl[n_first + tid0 - 32];
-  {  // max_j log pi_j: an upper bound of every prior logit (the exponent reference of the pair passes)
-    float m = -INFINITY;
-    for (int i = tid0; i < N; i += T2_NT) m = fmaxf(m, f->logmix[i]);
-    m = wave_max(m);
-    if ((tid0 & 63) == 0) wred[wave] = m;
-  }
+  float ll0 = 0.f;
+  if (tid0 >= 32 && tid0 < 32 + T2_PW) ll0 = f->logl[n_first + tid0 - 32];
+  float lm_max = -INFINITY;  // max_j log pi_j: an upper bound of every prior logit (the exponent reference of the pair passes)
+  for (int i = tid0; i < N; i += T2_NT) lm_max = fmaxf(lm_max, f->logmix[i]);
   if (MODEL == DUST_MODEL_PARTICLE) {  // occupancy grid -> LDS
     uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + L.grid);
     const int words = f->dm.with_obstacle ? (f->dm.nx * f->dm.ny + 31) >> 5 : 0;
     for (int w = tid0; w < words; w += T2_NT) gridl[w] = f->dm.grid_bits[w];
   }
-  wg_sync();
-  if (tid0 == 0) {
-    float m = wred[0];
-    for (int w = 1; w < T2_NT / 64; ++w) m = fmaxf(m, wred[w]);
-    lmref[0] = m;
-  }
-  if (isown) {
-    th[op * T2_ROW + od] = thv;
-    const bool badth = ownv && !(fabsf(thv) <= 3.0e38f);
-    if (badth) flag_th[op] = 1.f;
-  }
+  lds_barrier();  // orders the flag reset against the first noise staging; the loads above stay in flight across it
 
   // publish rows of the workgroup's particles held in LDS ([4][32]) as whole 128-byte lines: waves 8 / 9 take two rows each
   auto publish_rows = [&](const float *src, const float *dst, unsigned int *lines) {
@@ -369,7 +356,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     t2_arrive_wave(lines + (size_t)sh * T2_CNT_STRIDE, lane);
   };
 
-  if (isown) publish_rows(th, f->xq, cnt_theta);  // theta generation 0 (buffer 0) (the exchange buffer is scratch: harmless if the tick does not start)
 
   // dynamics coefficients of iteration k (rollout_body stage 1); wave 11
   auto make_coefs = [&](const T2ArgPtr f, const int k) {
@@ -431,6 +417,17 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     draw_noise(f, 0, tid0, T2_NT);
     if (wave == 11) make_coefs(f, 0);
   }
+  // ... and now what the loads brought: the workgroup's particles into LDS and out to the other workgroups (generation 0; the
+  // exchange buffer is scratch: harmless if the tick does not start), the likelihood of the last sample, the logit reference
+  if (isown) {
+    th[op * T2_ROW + od] = thv;
+    const unsigned long long badm = __ballot(ownv && !(fabsf(thv) <= 3.0e38f));
+    if ((tid0 & 31) == 0) flag_th[op] = ((badm >> (tid0 & 32)) & 0xffffffffull) ? 1.f : 0.f;
+    publish_rows(th, f->xq, cnt_theta);
+  }
+  if (tid0 >= 32 && tid0 < 32 + T2_PW) ll[tid0 - 32] = ll0;
+  lm_max = wave_max(lm_max);
+  if ((tid0 & 63) == 0) wred[wave] = lm_max;
   // start barrier (wave 15, underneath the first rollouts): workgroup 0 collects the arrivals - bounded: ~200 us - and publishes
   // go / abort
   auto start_protocol = [&]() {
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   };
   wg_sync();
   T2_TL(0, 121);
-  const float lm_ref = lmref[0];
+  const float lm_ref = wave_max((tid0 & 63) < T2_NT / 64 ? wred[tid0 & 63] : -INFINITY);
   const bool same_w = (f->alpha * f->temp == 1.0f);
   const int lane0 = tid0 & 63;
 
@@ -859,36 +856,33 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   {
     const int t = tid0;
     const float lwr = t < N ? ld_sc1(f->lwq + t) : -INFINITY;
-    const float m = block_reduce<RED_MAX>(lwr, wred);
-    const float z = block_reduce<RED_SUM>(t < N ? expf(lwr - m) : 0.f, wred);
+    // per wave (max, sum exp) pieces, merged by every wave for itself: one barrier for the softmax
+    const float m_w = wave_max(lwr);
+    const float z_w = wave_sum(t < N ? expf(lwr - m_w) : 0.f);
+    if (lane == 0) {
+      wred[wave] = m_w;
+      wred[16 + wave] = z_w;
+    }
+    wg_sync();
+    const float mm = lane < T2_NT / 64 ? wred[lane] : -INFINITY;
+    const float m = wave_max(mm);
+    const float z = wave_sum((lane < T2_NT / 64 && mm != -INFINITY) ? wred[16 + lane] * expf(mm - m) : 0.f);
     const float lz = m + logf(z);
     const float p = t < N ? expf(lwr - lz) : 0.f;
     if (t >= n_first && t < n_first + T2_PW) f->pw[t] = p;
-    float best = t < N ? p : -INFINITY;
-    int bi = t < N ? t : 0x7fffffff;
-    for (int of = 32; of > 0; of >>= 1) {
-      const float obv = __shfl_xor(best, of, 64);
-      const int oi = __shfl_xor(bi, of, 64);
-      if (obv > best || (obv == best && oi < bi)) {
-        best = obv;
-        bi = oi;
-      }
-    }
-    wg_sync();
-    int *redi = reinterpret_cast<int *>(wred + 32);
+    // first-index argmax of p: per wave the largest value and its first lane, then the first wave that holds the largest
+    const float pb_w = wave_max(t < N ? p : -INFINITY);
+    const unsigned long long mk = __ballot(t < N && p == pb_w);
+    int *redi = reinterpret_cast<int *>(wred + 48);
     if (lane == 0) {
-      wred[wave] = best;
-      redi[wave] = bi;
+      wred[32 + wave] = pb_w;
+      redi[wave] = mk ? wave * 64 + (__ffsll((long long)mk) - 1) : 0x7fffffff;
     }
     wg_sync();
-    best = wred[0];
-    bi = redi[0];
-    for (int w = 1; w < T2_NT / 64; ++w)
-      if (wred[w] > best || (wred[w] == best && redi[w] < bi)) {
-        best = wred[w];
-        bi = redi[w];
-      }
-    wg_sync();
+    const float pv = lane < T2_NT / 64 ? wred[32 + lane] : -INFINITY;
+    const float best = wave_max(pv);
+    const unsigned long long mk2 = __ballot(lane < T2_NT / 64 && pv == best);
+    const int bi = redi[mk2 ? (__ffsll((long long)mk2) - 1) : 0];
     if (bi >= n_first && bi < n_first + T2_PW) {  // the owner of the best particle hands out its action sequence
       if (t == 0) *f->istar = bi;
       if (t < D) f->a_seq_out[t] = th[(bi - n_first) * T2_ROW + t];
