@@ -2093,6 +2093,13 @@ extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float
     TRY(h2d(c, c->tmp, last_row, (size_t)c->N * c->da * sizeof(float)));
     lr = c->tmp;
   }
+  // SVMPC.roll rebinds self.theta to a NEW tensor (svmpc.py:142: theta.roll(...)); the prior built by the last update_prior keeps
+  // the old storage as its means (svgd.py:87), so a stand-alone roll() leaves the prior where it was until update_prior() is
+  // called again.  When the device prior aliases theta, give it its own copy of the pre-roll particles first.
+  if (c->mu_aliased) {
+    TRY(d2d(c, c->mu, c->theta, (size_t)c->N * c->D * sizeof(float)));
+    c->mu_aliased = false;
+  }
   const RollArgs r = roll_args(c, steps, strategy, lr);
   roll_kernel<<<c->nloc, 128, 0, c->stream>>>(r);
   HIP_TRY(hipGetLastError());
@@ -2102,6 +2109,7 @@ extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float
 
 extern "C" int dust_svmpc_update_prior(dust_ctx *c, const float *weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the prior refresh is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
   if (c->graph_exec) graph_drop(c);
   std::vector<float> w((size_t)c->N, 1.0f);

@@ -14,8 +14,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned int target, unsigned int *flag) {
   unsigned int spins = 0;
   unsigned long long t0 = 0;
+#ifndef DUST_SPIN_SLEEP
+#define DUST_SPIN_SLEEP 2
+#endif
   while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(DUST_SPIN_SLEEP);
     if ((++spins & 255u) == 0u) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (!t0) t0 = now;

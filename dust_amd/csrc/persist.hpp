@@ -877,6 +877,11 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svmpc_tick_kernel
     f.tl[128 * blockIdx.x + 127] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
   }
 #endif
+  // A hand-off wait of an EARLIER launch timed out and the host has not seen it yet (open-loop callers read no outputs): every wait
+  // of this launch would leave after 256 spins and compute on stale data.  Do nothing instead - the particles, the optimiser state
+  // and the noise counters stay where the failed tick left them; the host reports the error at its next synchronisation and clears
+  // the flag (dust_sync / tick_outputs).  (The flag is only ever set inside a launch: uniform for this one.)
+  if (__hip_atomic_load(f.timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if (b0 == 0)
     for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
   if (b0 < f.n_pair_blocks) {

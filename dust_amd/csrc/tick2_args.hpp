@@ -5,10 +5,13 @@
 
 namespace dust {
 
+#ifndef T2_NSH_N
+#define T2_NSH_N 16
+#endif
 enum {
   T2_PW = 4,      // Stein particles per workgroup (4 x 128 action samples = 8 rollout waves)
   T2_NT = 1024,   // lanes per workgroup: waves 0-7 roll out, waves 8-15 run the pairwise passes
-  T2_NSH = 16,    // shards of every arrival counter (workgroup b signals shard b % T2_NSH; one 128-byte line each)
+  T2_NSH = T2_NSH_N,  // shards of every arrival counter (workgroup b signals shard b % T2_NSH; one 128-byte line each)
   T2_ROW = 32,    // floats per row of the exchange buffers (D <= 32 padded to one 128-byte line)
   T2_CNT_STRIDE = 32,
   T2_SETS = 4 * T2_NSH + 1  // lines of one counter set: start | theta | score | lw shards, then the go word
