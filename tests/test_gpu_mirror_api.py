@@ -413,3 +413,73 @@ def test_pendulum_driver_vs_reference_driver(golden):
         assert relerr(pw, ref_pw) < 5e-3, t  # exp of O(1e3) log-weights (tests/test_gpu_parity.py)
         assert abs(float(df["Actions"].iloc[t]) - float(g["a_seq"][k][0, 0])) < 2e-3 * max(1.0, abs(float(g["a_seq"][k][0, 0]))), t
         assert relerr(np.asarray(df["PolParticles"].iloc[t], np.float32), g["theta_fwd"][k][:, 0, 0]) < 2e-3, t
+
+
+@pytest.mark.parametrize("tag", ["run", "goal", "crash"])
+def test_particle_episode_vs_reference_driver(golden, tag):
+    """the build's `run_particle_episode` against the REFERENCE's own episode driver (dust/utils/simulations.py:197-260,
+    the loop demo/particle_example.py:150-254 runs inline; fixtures by tests/golden/make_golden_episode.py): the mass-change event at
+    steps // 4, zero actions while warming up, goal termination (|target - state| <= 1) and crash termination (cost inf), with every
+    random draw of the reference run replayed.  Checked per tick: the plant state the tick started from, the particles after
+    optimize, the chosen sequence and the particle weights; per episode: the number of steps run and the cumulative cost."""
+    import torch.distributions as dist
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import SVMPC, ExponentiatedUtility, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import Particle
+    from dust_amd.utils import replay
+    from dust_amd.utils.simulations import run_particle_episode
+
+    g = golden("episode_part_" + tag)
+    N, H, S, M = (int(g[k]) for k in ("N", "H", "S", "M"))
+    sigma = float(g["sigma"])
+    rec = dict(state_in=[], theta_opt=[], a_seq=[], p_weights=[])
+
+    class RecSVMPC(SVMPC):
+        def optimize(self, state, params_dist, *a, **k):
+            rec["state_in"].append(np.asarray(state, np.float32).reshape(-1).copy())
+            out = super().optimize(state, params_dist, *a, **k)
+            rec["theta_opt"].append(self.theta.numpy().copy())
+            return out
+
+        def forward(self, state, params_dist, *a, **k):
+            a_seq, pw = super().forward(state, params_dist, *a, **k)
+            rec["a_seq"].append(a_seq.numpy().copy())
+            rec["p_weights"].append(pw.numpy().copy())
+            return a_seq, pw
+
+    model = Particle(**PARTICLE_ENV, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), sigma ** 2 * torch.eye(2))
+    x = torch.tensor(g["dyn_means"])
+    dyn = dist.MixtureSameFamily(dist.Categorical(torch.ones(x.shape[0])),
+                                 dist.Independent(dist.MultivariateNormal(loc=x, covariance_matrix=float(g["dyn_bw"]) ** 2 * torch.eye(1)), 0))
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=1.0, a_cov=sigma ** 2 * torch.eye(2),
+                      params_sampling=True, params_samples=M, params_log_space=True, inst_cost_fn=model.default_inst_cost,
+                      term_cost_fn=model.default_term_cost)
+    lik = ExponentiatedUtility(1.0, controller=ctrl, model=model, n_samples=S)
+    sv = RecSVMPC(init_particles=torch.tensor(g["init_policies"]), prior=prior, likelihood=lik, kernel=RBFKernel(), n_particles=N,
+                  bw_scale=1.0, n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]), weighted_prior=True)
+    with replay.feed(eps=list(g["eps"]), params=list(g["params"])):
+        cum = run_particle_episode(torch.tensor(g["init_state"]), model, dyn, ctrl, use_svmpc=True, warm_up=int(g["warm_up"]), svmpc=sv,
+                                   load=float(g["load"]), steps=int(g["steps"]))
+    n_run = int(g["steps_run"])
+    assert len(rec["state_in"]) == n_run, (len(rec["state_in"]), n_run)  # same termination step
+    ref_cum = float(g["cum_cost"])
+    if np.isfinite(ref_cum):
+        assert abs(float(cum) - ref_cum) < 2e-3 * abs(ref_cum), (float(cum), ref_cum)
+    else:
+        assert not np.isfinite(float(cum))  # crashed: cost inf (simulations.py:241)
+    for t in range(n_run):
+        # the plant trajectory: tick t starts where tick t - 1's action (and, from steps // 4 on, the heavier system) left the state
+        assert elemerr(rec["state_in"][t], g["state_in"][t], floor=1.0) < 1e-4, t
+        # (crash: every rollout starts inside the obstacle cost, 1e6 per step - the costs are O(1e7), one fp32 ulp of them is a
+        # factor e on a softmax weight, and the particles after one step follow the weights)
+        assert elemerr(rec["theta_opt"][t], g["theta_opt"][t]) < (5e-2 if tag == "crash" else 2e-3), t
+    if "a_seq" in g:
+        assert len(rec["a_seq"]) == len(g["a_seq"])
+        for k in range(len(g["a_seq"])):
+            ref_pw = g["p_weights"][k]
+            assert int(np.argmax(rec["p_weights"][k])) == int(np.argmax(ref_pw)), k
+            assert np.abs(rec["p_weights"][k] - ref_pw).max() < 5e-3, k  # exp of O(1e3) log-weights (tests/test_gpu_parity.py)
+            assert elemerr(rec["a_seq"][k], g["a_seq"][k]) < 2e-3, k
