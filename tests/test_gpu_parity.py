@@ -951,3 +951,61 @@ def test_sharded_large_set_takes_fused_pairwise():
             assert elemerr(sh.ctx.get_theta(), rt) < 1e-5, (world, sh.rank)
             sh.ctx.close()
     ref.close()
+
+
+def test_particle_m64_small_n_vs_oracle():
+    """BASELINE configs[2]'s dynamics-sample count (M = 64, S = 64, H = 40: the lane-group split of the M loop at its real trip
+    counts) at a particle count the oracle finishes in seconds: every cost, then score and phi, element-wise."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    N, S, M, H = 64, 64, 64, 40
+    rng = np.random.default_rng(64)
+    mu = rng.standard_normal((N, H, 2)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    eps = rng.standard_normal((S, N, H, 2)).astype(np.float32)
+    state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    params = (1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+    grid = grid_4x4_map()
+    kw = dict(model="particle", N=N, S=S, M=M, H=H, uncertain_params=("mass",))
+    o = Oracle(grid=grid, **kw)
+    sg = np.full(2, 5.0, np.float32)
+    actions = o.sample_actions(theta, eps, sg)
+    ref_costs = o.rollout_cost(state, actions, params)
+    c = Context(grid=grid, kernel="K1", lr=0.5, alpha=1e-4, sigma_a=5.0, sigma_p=5.0, **kw)
+    c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+    costs = c.likelihood_sample(state, eps, params)
+    assert elemerr(costs, ref_costs) < TOL
+    gl, gp, sc = o.score(theta, mu, np.ones(N), sg, ref_costs, actions, 1e-4, sg)
+    phi, dgl, dgp = c.svmpc_phi(ref_costs, actions)
+    assert elemerr(dgl, gl) < TOL and elemerr(dgp, gp) < TOL and elemerr(phi, o.phi_k1(theta, sc)) < TOL
+    c.close()
+
+
+@pytest.mark.parametrize("name,N,S,M,H", [("cfg3", 4096, 64, 64, 40), ("cfg4", 16384, 64, 4, 40)])
+def test_full_size_rollouts_sampled_vs_oracle(name, N, S, M, H):
+    """BASELINE configs[2] / configs[3] at their REAL sizes (the shapes bench.py times): the costs of 64 randomly chosen particles
+    of the full launch against the oracle.  A particle's rollouts depend only on its own theta row, its own noise column, the M
+    dynamics samples and the plant state (disco.py:139-209 with 2-D parameter samples), so the oracle is run on the 64-particle
+    subset with the same inputs; every one of the 64 x S costs is compared element-wise."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    rng = np.random.default_rng(N)
+    mu = rng.standard_normal((N, H, 2)).astype(np.float32)
+    theta = (mu + 0.3 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    eps = rng.standard_normal((S, N, H, 2)).astype(np.float32)
+    state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    params = (1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+    grid = grid_4x4_map()
+    c = Context(model="particle", N=N, S=S, M=M, H=H, uncertain_params=("mass",), grid=grid, kernel="K1", lr=0.5, alpha=1e-4,
+                sigma_a=5.0, sigma_p=5.0)
+    c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+    costs = c.likelihood_sample(state, eps, params)  # [S][N], the full launch
+    idx = np.sort(rng.choice(N, 64, replace=False))
+    o = Oracle(model="particle", N=64, S=S, M=M, H=H, uncertain_params=("mass",), grid=grid)
+    sg = np.full(2, 5.0, np.float32)
+    actions = o.sample_actions(theta[idx], np.ascontiguousarray(eps[:, idx]), sg)
+    ref = o.rollout_cost(state, actions, params)
+    assert elemerr(costs[:, idx], ref) < TOL, name
+    c.close()
