@@ -114,7 +114,11 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lan
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
 // f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
 enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
-template <int MODE, int PASS>
+__device__ __forceinline__ float t2_quad_sum(float v) {  // quad permutes never read an invalid lane: bound_ctrl spares the `old` operand
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+}
+template <int MODE, int PASS, bool MASK /* the steps cover more than the N keys: those past the last one carry no weight */>
 __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* theta generation */, const float *thq /* LDS [4][32] own query rows */,
                                              float *dsl, float *ksl, const int pw, const int lane, const float lm_ref,
                                              float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */) {
@@ -162,7 +166,7 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
       const float lm = lbuf[p];
       issue(min(t + PF, steps - 1), ya[p], yb[p], lbuf[p]);  // (the last group re-reads its last rows: no branch in the loop)
       const int j = (t * NKW + kw) * 16 + u;
-      const bool valid = j < N;
+      const bool valid = !MASK || j < N;
       const v2f yv[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
       if (PASS == T2_PASS_STEIN) {
         const float2 dq = *reinterpret_cast<const float2 *>(&dsl[(size_t)j * 4 + q0]);  // the distances of pass PRIOR
@@ -191,7 +195,7 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
           v2f d2 = z[0] * z[0];
 #pragma unroll
           for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
-          const float dd = quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
+          const float dd = t2_quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
           dk[q] = dd;
           const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
           accL[q] += e;
@@ -601,7 +605,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      t2_pair_pass<MODE, T2_PASS_PRIOR>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
+      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
 #pragma unroll
       for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
       T2_TL(8, 16 * k + 3);
@@ -708,7 +713,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
       float rb[4];
-      t2_pair_pass<MODE, T2_PASS_STEIN>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
+      else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
       rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
     }
     if (wave == 10) {
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
-    t2_pair_pass<MODE, T2_PASS_LOGP>(f, kf, th, dsl, ksl, wave, lane, lm_ref, red);
+    t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, dsl, ksl, wave, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;
