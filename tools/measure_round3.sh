@@ -1,0 +1,32 @@
+# One gpurun call: the round's bench lines (driver's command and the default), rocprofv3 kernel stats, PMC passes (each in its own
+# run), derived summaries.  Results land in gpurun_out/r3m/ ; the summaries to be judged are copied to profiles/round3_* afterwards.
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3m; mkdir -p $O
+cd $R
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o b -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o b -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o b -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 40 --warmup 5 > /dev/null 2>&1
+cd $R
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write "particle_states_kernel<2>" $O/rollout_states_traffic.json
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write "svmpc_tick2_kernel" $O/tick_traffic.json
+python tools/pmc_summary.py $O/pmc_sq.json $O/pmc_sq > /dev/null
+python - <<PY
+import json
+d = json.load(open("$O/pmc_sq.json"))
+for k, e in d.items():
+    if "svmpc_tick2_kernel" in k:
+        json.dump({"kernel": k, "SQ_INSTS_VALU_per_tick": e["SQ_INSTS_VALU_mean"], "counters": e,
+                   "source": "rocprofv3 --pmc SQ_* --kernel-trace -- python3 bench.py --no-cpu-baseline --no-roofline --steps 40 --warmup 5"},
+                  open("$O/tick_pmc.json", "w"), indent=1)
+PY
+timeout 900 python tools/configs_bench.py $O/configs.json > $O/configs.log 2>&1
+timeout 200 python tools/coldstart.py > $O/coldstart.txt 2>&1
+timeout 200 python tools/bench_timing_probe.py > $O/bench_timing_probe.txt 2>&1
+timeout 100 tools/_allgather_probe > $O/allgather_probe.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq
+find $O/stats -name "*kernel_trace*" -delete
+tail -c 1200 $O/bench_driver_cmd.json; head -6 $O/stats/*/b_kernel_stats.csv 2>/dev/null | cut -c1-160 || find $O/stats -name "*kernel_stats.csv" | head
