@@ -2376,6 +2376,10 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   f.roll_strategy = c->cfg.roll_strategy;
   f.weighted_prior = c->cfg.weighted_prior;
   f.coef_given = ra.coef_given;
+  if (const char *ta = getenv("DUST_TICK2_TEST_ABORT")) {  // test hook: exercises the replay path without a second tenant on the device
+    const int every = atoi(ta);
+    f.test_abort = every > 0 && ((c->n_tick2 + 1) % every) == 0;
+  }
   f.grid_words = c->cfg.model == DUST_MODEL_PARTICLE ? ra.grid_words : 0;
   f.coef_host[0] = ra.coef_host[0];
   f.coef_host[1] = ra.coef_host[1];

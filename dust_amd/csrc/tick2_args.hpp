@@ -24,6 +24,7 @@ struct Tick2Args {
   int steps;             // ceil(N / 64) rounded up to a multiple of 16: 16-key steps of a pair wave in the theta-only pass (4 waves share the keys)
   int lik, update_a_mat, eps_base_mode, optimizer, roll_strategy, weighted_prior;
   int coef_given;
+  int test_abort;        // test hook (DUST_TICK2_TEST_ABORT=k: every k-th launch): workgroup 0 publishes "abort" as if a peer were missing
   int grid_words;        // Particle: words of the bit-packed occupancy grid staged in LDS (multiple of 4) or 0
   float coef_host[2];
   float alpha, temp;

@@ -189,3 +189,69 @@ def test_tick2_long_run_stays_consistent():
     assert s0["tick2"] == 399 and s0["replayed"] == 0 and s1["tick2"] == 0
     for t in range(2):
         assert elemerr(h0[t][0], h1[t][0]) < 1e-3, t
+
+
+def test_tick2_aborted_ticks_are_replayed():
+    """A tick whose workgroups are not all resident does not start (start barrier) and is replayed by the library on the
+    launch-per-iteration path: the caller sees DUST_OK, the same results, and `tick_stats()['replayed']` counts it.  The test hook
+    DUST_TICK2_TEST_ABORT=3 makes workgroup 0 publish "abort" on every third launch."""
+    N, S, H = 256, 128, 30
+    st = _state("pendulum")
+    outs = []
+    for env in ({"DUST_TICK2_TEST_ABORT": "3"}, {}):
+        saved = os.environ.pop("DUST_TICK2_TEST_ABORT", None)
+        os.environ.update(env)
+        try:
+            c, _ = _make("pendulum", N, S, H)
+            hist = []
+            for t in range(8):
+                a_seq, pw = c.svmpc_tick(st, 3)
+                hist.append((a_seq.copy(), pw.copy(), c.get_theta()))
+            outs.append((hist, c.tick_stats()))
+            c.close()
+        finally:
+            os.environ.pop("DUST_TICK2_TEST_ABORT", None)
+            if saved is not None:
+                os.environ["DUST_TICK2_TEST_ABORT"] = saved
+    (h0, s0), (h1, s1) = outs
+    assert s0["tick2"] == 7 and s0["replayed"] == 2, s0   # launches 3 and 6 of the 7 owner-computes ticks
+    assert s1["replayed"] == 0
+    for t in range(4):  # the replayed tick (t = 3: third tick2 launch) sums in another order; later ticks amplify
+        assert elemerr(h0[t][0], h1[t][0]) < 2e-3, (t, elemerr(h0[t][0], h1[t][0]))
+        assert np.abs(h0[t][1] - h1[t][1]).max() < 5e-3
+    for t in range(8):
+        assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
+
+
+def test_two_contexts_tick_concurrently():
+    """Two contexts on one device ticking from two host threads: each needs its 256 workgroups co-resident, so
+    some launches find the device taken.  No tick may be lost or fail: every call returns, results stay finite and normalised, and
+    tick2 + replayed account for every tick."""
+    import threading
+
+    N, S, H, T = 1024, 128, 30, 150
+    st = _state("pendulum")
+    ctxs = [_make("pendulum", N, S, H, seed=s)[0] for s in (0, 1)]
+    errs, stats = [], [None, None]
+
+    def run(i):
+        try:
+            c = ctxs[i]
+            for t in range(T):
+                a_seq, pw = c.svmpc_tick(st, 5)
+                assert np.isfinite(a_seq).all() and abs(float(pw.sum()) - 1.0) < 1e-3, (i, t)
+            stats[i] = c.tick_stats()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in (0, 1):
+        assert stats[i]["tick2"] == T - 1, stats[i]
+        assert np.isfinite(ctxs[i].get_theta()).all()
+        ctxs[i].close()
+    print("replayed ticks:", stats[0]["replayed"], stats[1]["replayed"])
