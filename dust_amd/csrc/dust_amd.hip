@@ -21,6 +21,7 @@
 #include "tick2_args.hpp"
 #include "rollout_states.hpp"
 #include "pairwise_fused.hpp"
+#include "pairwise_logp_mfma.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -1336,6 +1337,50 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
+// log p(theta) only, large aliased sets (SVMPC.forward): product-form distances on the matrix cores + log-sum-exp
+// (pairwise_logp_mfma.hpp).  DUST_LOGP_MFMA=0 keeps the exact-difference pass of pairwise_fused.hpp (development switch).
+static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
+  const int dpb = std::max(16, ((a.D + 15) / 16) * 16);
+  TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb + 2 * (size_t)c->N));
+  LogpMfmaArgs b;
+  memset(&b, 0, sizeof b);
+  b.N = c->N;
+  b.D = a.D;
+  b.i0 = a.i0;
+  b.n_local = a.n_local;
+  const int tiles = (a.n_local + 255) / 256, chunks = (c->N + 63) / 64;
+  // key slices: one resident round of two workgroups per CU when the set allows it
+  int js = std::max(1, std::min(chunks, (2 * device_cus(c)) / tiles));
+  const int cps = (chunks + js - 1) / js;
+  b.slice = cps * 64;
+  b.JS = (c->N + b.slice - 1) / b.slice;
+  TRY(ensure_partials(c, b.JS));
+  c->prior_js = b.JS;
+  b.X = a.X;
+  b.logmix = a.logmix;
+  b.sw[0] = a.inv_s[0] * 1.2011224087864498f;  // sqrt(log2 e) / sigma_p
+  b.sw[1] = a.da == 2 ? a.inv_s[1] * 1.2011224087864498f : b.sw[0];
+  b.Z = c->xpad;
+  b.hq = c->xpad + (size_t)c->N * dpb;
+  b.hj = b.hq + c->N;
+  b.pM = c->pM;
+  b.pL = c->pL;
+  dim3 grid(tiles, b.JS);
+#define DUST_LAUNCH_LOGPM(DPB)                                                                                                 \
+  do {                                                                                                                          \
+    logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                       \
+    pairwise_logp_mfma_kernel<DPB><<<grid, 256, pairwise_logp_mfma_lds_bytes<DPB>(), c->pair_stream>>>(b);                      \
+  } while (0)
+  if (dpb == 16) DUST_LAUNCH_LOGPM(16);
+  else if (dpb == 32) DUST_LAUNCH_LOGPM(32);
+  else if (dpb == 48) DUST_LAUNCH_LOGPM(48);
+  else if (dpb == 64) DUST_LAUNCH_LOGPM(64);
+  else DUST_LAUNCH_LOGPM(80);
+#undef DUST_LAUNCH_LOGPM
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
 // log p(theta) only, large aliased sets (SVMPC.forward): the distance pass + log-sum-exp of pairwise_fused.hpp
 static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
   const int dpb = fused_dpb(a.D);
@@ -1443,7 +1488,11 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
   c->prior_js = 0;  // (launch_pair_fused sets its own slice count)
-  if (logp_only && pair_fused_ok(c)) return launch_pair_logp_big(c, a, tiles);            // large aliased set: distance pass + log-sum-exp
+  if (logp_only && pair_fused_ok(c)) {  // large aliased set
+    const char *env = getenv("DUST_LOGP_MFMA");
+    if (!(env && atoi(env) == 0)) return launch_pair_logp_mfma(c, a);  // product-form distances on the matrix cores + log-sum-exp
+    return launch_pair_logp_big(c, a, tiles);                         // exact-difference distance pass + log-sum-exp
+  }
   if (logp_only && !pair_big_kernel(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
   if (!logp_only && pair_fused_ok(c)) return launch_pair_fused(c, a, tiles);              // + repulsion + Gram matrix (pairwise_fused.hpp)
   return launch_pair<PAIR_PRIOR>(c, a, tiles);

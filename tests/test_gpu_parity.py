@@ -1009,3 +1009,57 @@ def test_full_size_rollouts_sampled_vs_oracle(name, N, S, M, H):
     ref = o.rollout_cost(state, actions, params)
     assert elemerr(costs[:, idx], ref) < TOL, name
     c.close()
+
+
+@pytest.mark.parametrize("model,N,H,spread,offset", [("particle", 2048, 40, 1.0, 0.0), ("particle", 2100, 40, 0.25, 6.0),
+                                                     ("pendulum", 4096, 30, 0.5, -3.0), ("pendulum", 2200, 17, 2.0, 0.0),
+                                                     ("pendulum", 2048, 12, 0.05, 1.0), ("particle", 16384, 40, 1.0, 2.0)])
+def test_large_aliased_logp_mfma_vs_oracle(model, N, H, spread, offset):
+    """SVMPC.forward's log p(theta) (svmpc.py:128-140) for N >= 2048 with the prior means aliasing theta runs the product-form
+    distance on the matrix cores (pairwise_logp_mfma.hpp; rows centred on particle 0, so a common `offset` of the cloud costs no
+    accuracy).  Against the oracle (exact differences, double accumulation) and against the exact-difference device pass
+    (DUST_LOGP_MFMA=0): log p element-wise at 1e-5, particle weights at 1e-5 absolute.  Ragged N, D = 80 / 30 / 17 / 12,
+    anisotropic sigma_p, non-uniform mixture weights, a nearly collapsed set (spread 0.05: every key matters), the cfg4 shape."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(5 * N + H)
+    S = 8
+    theta = (offset + spread * rng.standard_normal((N, H, da))).astype(np.float32)
+    mixw = rng.random(N).astype(np.float32) + 0.05
+    mixw /= mixw.sum()
+    grid = grid_4x4_map() if model == "particle" else None
+    sg = np.full(da, 1.5, np.float32)
+    sp = np.array([1.5, 0.8], np.float32)[:da]
+    o = Oracle(model=model, N=N, S=S, M=1, H=H, grid=grid)
+    alpha = 1.0 if model == "pendulum" else 1e-4
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    got = {}
+    for mfma in ("1", "0"):
+        os.environ["DUST_LOGP_MFMA"] = mfma
+        try:
+            c = Context(model=model, N=N, S=S, M=1, H=H, kernel="K1", lr=0.0, alpha=alpha, sigma_a=sg, sigma_p=sp, grid=grid, weighted_prior=True,
+                        seed=11)
+            c.set_theta(theta)
+            c.set_prior(theta)
+            c.set_a_mat(theta)
+            c.svmpc_update_prior(mixw)  # the means alias theta from here on
+            c.svmpc_optimize(state, 1)  # lr = 0: the particles stay, the rollouts leave the costs the likelihood half needs
+            assert np.array_equal(c.get_theta(), theta)
+            pw = c.svmpc_get_weights()
+            ll, lp = c.get_log_weights()
+            got[mfma] = (lp, pw, c.get_costs())
+            c.close()
+        finally:
+            os.environ.pop("DUST_LOGP_MFMA", None)
+    lp, pw, costs = got["1"]
+    lp0, pw0, costs0 = got["0"]
+    assert np.array_equal(costs, costs0)
+    fw = o.forward(costs, theta, theta, mixw, sp, alpha, weighted_prior=True)
+    assert elemerr(lp0, fw["log_p"]) < 1e-5
+    assert elemerr(lp, fw["log_p"]) < 1e-5, elemerr(lp, fw["log_p"])
+    assert np.abs(lp - fw["log_p"]).max() < 2e-4, np.abs(lp - fw["log_p"]).max()   # absolute, on values of O(10-300)
+    assert np.abs(pw - pw0).max() < 1e-6 + 3e-4 * pw0.max()  # same costs on both sides: only log p differs
+    assert np.abs(pw - fw["p_weights"]).max() < 2e-3
+    assert abs(float(pw.sum()) - 1.0) < 5e-4  # (log-weights of O(1e3): one fp32 ulp there is 1e-4 relative on a weight)
