@@ -91,6 +91,9 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
+  size_t nzf_cap;
+  int nz_ld;                 // 0: the last fused pass ran dense
   int prior_js;  // slices of the prior partials when pairwise_fused_kernel wrote them (its own split); 0 = pair_geometry's
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
@@ -298,7 +301,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->mw_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1296,6 +1299,14 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   b.ldK = ldK;
   b.tiles = tiles;
   b.chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
+  c->nz_ld = 0;
+  if (!getenv("DUST_DENSE")) {  // flags of the all-zero Gram blocks (development switch: evaluate everything)
+    const int rows = std::max(tiles * fused_tq(a.D), ((c->nloc + 63) / 64) * 64);
+    c->nz_ld = ((rows + 63) / 64) * 64;
+    TRY(ensure(&c->nzf, &c->nzf_cap, ((size_t)b.chunks * c->nz_ld + 3) / 4));
+    b.nz = reinterpret_cast<unsigned char *>(c->nzf);
+    b.ldnz = c->nz_ld;
+  }
   int W, tl;
   fused_geometry(c, &tl, &W, &b.p.JS);  // (a.JS / a.slice describe the regular grid of the other kernels)
   int jsg, slg;
@@ -1433,6 +1444,8 @@ static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
   g.ldp = 8 * cpt_for(a.D);
   g.ldK = ((c->N + 63) / 64) * 64;
   g.K = c->kmat;
+  g.nz = c->nz_ld ? reinterpret_cast<const unsigned char *>(c->nzf) : nullptr;
+  g.ldnz = c->nz_ld;
   g.V = c->score;
   g.pA = c->pA;
   dim3 grid((c->nloc + 63) / 64, g.JS);

@@ -35,7 +35,18 @@ struct PairFusedArgs {
   float *K;         // [tiles * TQ][ldK] Stein kernel values (tiles * TQ >= n_local: whole query tiles)
   int ldK;
   int tiles, chunks;  // query tiles of TQ rows, key chunks of 64: the launch covers tiles * chunks units (see fused_balance)
+  unsigned char *nz;  // [chunks][ldnz] 1 = the 64 Stein kernel values of (key chunk, query row) are not all exactly 0 (see below); ldnz >= rows, multiple of 64
+  int ldnz;
 };
+
+// Exact zeros.  K1's lengthscale is fixed at ln 2 (svmpc.py:78), so k_ij = exp(-d2 / 0.96) UNDERFLOWS to exactly 0 in fp32 once
+// d2 > ~84 - in H d_a = 80 dimensions at sigma = 5 that is every pair except near-duplicates (tools/kernel_sparsity.py: 8 615 of
+// 16.8 M sampled pairs at cfg4 after 100 ticks; a clustered Pendulum set has 33 % non-zeros).  A zero kernel value contributes
+// exactly nothing to the repulsion sum and to K x score, so (query row, 64-key chunk) blocks whose kernel values are all zero are
+// flagged by pass A (one ballot per row and chunk) and skipped: pass B drops the repulsion FMAs of a chunk that is zero for the
+// whole tile, the Gram rows of a zero block are not stored, and gram_score_kernel skips the blocks of its tile that are zero.
+// Results are bit-identical to the dense evaluation for finite inputs (0 x finite = 0; DUST_DENSE=1 evaluates everything, and the
+// tests compare the two bitwise); the time is data dependent: a dense (clustered) set runs as before.
 
 // Work split of pairwise_fused_kernel.  A unit is (query tile, 64-key chunk), units ordered tile-major; workgroup s of W takes the
 // contiguous run [s T / W, (s + 1) T / W) of the T = tiles * chunks units: every workgroup does the same work to within one
@@ -70,7 +81,7 @@ struct FusedGeom {
 template <int DPB>
 static inline size_t pairwise_fused_lds_bytes() {
   using G = FusedGeom<DPB>;
-  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 3 * (size_t)G::TQ);
+  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 3 * (size_t)G::TQ + 4);
 }
 
 #ifndef DUST_FUSED_WGS
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
   float *mrow = kvf + 2 * TQ * KS;  // [TQ] running max
   float *scl = mrow + TQ;           // [TQ] rescale factor of this chunk
   float *lrow = scl + TQ;           // [TQ] running sum of the softmax terms (relative to mrow)
+  unsigned int *wany = reinterpret_cast<unsigned int *>(lrow + TQ);  // [4] per wave: some Stein kernel value of this chunk is non-zero
   const int tid = threadIdx.x, D = a.D, N = a.N;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), jA = tid & 63;
   const int qg = tid / LCG, cg = tid - qg * LCG, c0 = CB * cg;  // pass-B ownership: queries qg + QS r, columns c0 .. c0 + CB - 1
@@ -169,6 +181,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         y[2 * p + 1] = v2f{t.z, t.w};
       }
       const bool kval = jA < jc;
+      bool wave_any = (MODE != PAIR_K1) || b.nz == nullptr;
       for (int qi = 0; qi < QW; qi += 2) {
         const int i = wave * QW + qi;  // wave-uniform
         // uniform addresses -> scalar loads.  The kernel also STORES to global memory inside this loop (the Gram rows), so a plain
@@ -220,14 +233,28 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         // columns behind N exist (the latter receive 0)
         const int il = tile * TQ + i;
         float *ka_p = &b.K[(size_t)il * b.ldK + j0 + jA], *kb_p = ka_p + b.ldK;
-        if (STREAM_K) {
-          __builtin_nontemporal_store(ka, ka_p);
-          __builtin_nontemporal_store(kb, kb_p);
-        } else {
-          *ka_p = ka;
-          *kb_p = kb;
+        // exact zeros (see PairFusedArgs): a row of 64 zero kernel values is flagged, not stored
+        bool anya = true, anyb = true;
+        if (MODE == PAIR_K1 && b.nz) {
+          anya = __ballot(ka != 0.f) != 0ull;
+          anyb = __ballot(kb != 0.f) != 0ull;
+          wave_any = wave_any || anya || anyb;
+        }
+        if (b.nz && jA == 0) {
+          unsigned char *fz = b.nz + (size_t)(j0 >> 6) * b.ldnz + il;  // (QW is even: the two rows are adjacent bytes of one chunk row)
+          fz[0] = anya ? 1 : 0;
+          fz[1] = anyb ? 1 : 0;
+        }
+        if (anya) {
+          if (STREAM_K) __builtin_nontemporal_store(ka, ka_p);
+          else *ka_p = ka;
+        }
+        if (anyb) {
+          if (STREAM_K) __builtin_nontemporal_store(kb, kb_p);
+          else *kb_p = kb;
         }
       }
+      if (jA == 0) wany[wave] = wave_any ? 1u : 0u;
     }
     wg_sync();
     {
@@ -268,7 +295,10 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
     const bool more = j0 + JC < jend;
     if (more) keys_issue(j0 + JC);  // in flight during pass B
     // ---- pass B: lane = 4 queries x CB columns; the difference y_j - x_i feeds the prior sum and the repulsion sum ----
-    if (pb) {
+    // (a chunk whose Stein kernel values are zero for the whole tile runs without the repulsion FMAs: they would add exact zeros)
+    const bool tile_any = (wany[0] | wany[1] | wany[2] | wany[3]) != 0u;
+    auto pass_b = [&](auto with_k) {
+      constexpr bool WK = decltype(with_k)::value;
 #pragma unroll 2
       for (int jj = 0; jj < JC; ++jj) {
         v4f yv[NV];
@@ -284,10 +314,14 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
           for (int u = 0; u < NV; ++u) {
             const v4f diff = yv[u] + xB[r][u];  // y_j - x_i
             accA[r][u] = __builtin_elementwise_fma(v4f{wp, wp, wp, wp}, diff, accA[r][u]);
-            accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
+            if (WK) accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
           }
         }
       }
+    };
+    if (pb) {
+      if (tile_any) pass_b(std::true_type{});
+      else pass_b(std::false_type{});
     }
     wg_sync();  // pass B is done with Ys / kv
     if (more) keys_commit(j0 + JC);
@@ -488,11 +522,13 @@ struct GramScoreArgs {
   const float *K;  // [n_local][ldK]
   const float *V;  // [N][D] score
   float *pA;       // [JS][n_local][ldp]
+  const unsigned char *nz;  // [chunks][ldnz] non-zero flags of (key chunk, query row) written by pass 1, or nullptr: dense
+  int ldnz;
 };
 
 template <int DPB>
 static inline size_t gram_score_lds_bytes() {
-  return sizeof(float) * ((size_t)PAIR_JC * (DPB + 4) + 64 * (size_t)(PAIR_JC + 4));
+  return sizeof(float) * ((size_t)PAIR_JC * (DPB + 4) + 64 * (size_t)(PAIR_JC + 4) + 64);  // + 2 048-chunk bitmap
 }
 
 // Tile: 64 queries x DPB columns per workgroup (wave w owns queries 16 w .. 16 w + 15 and all DPB / 16 column tiles), keys in
@@ -525,21 +561,49 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[t], bq, acc[t], 0, 0, 0);
     }
   };
+  unsigned int *nzm = reinterpret_cast<unsigned int *>(Kt + 64 * KS2);  // [64] bitmap: chunks of this slice with a non-zero block
+  const int ch0 = jbeg >> 6, nch = (jend - jbeg + JC - 1) >> 6;
+  const bool sparse = a.nz != nullptr && nch <= 2048;
+  if (sparse) {
+    if (tid < 64) nzm[tid] = 0u;
+    wg_sync();
+    for (int ci = tid >> 4; ci < nch; ci += NT / 16) {  // 16 lanes x 4 flag bytes = the tile's 64 rows of one chunk
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(a.nz + (size_t)(ch0 + ci) * a.ldnz + il0 + 4 * (tid & 15));
+      if (w) atomicOr(&nzm[ci >> 5], 1u << (ci & 31));
+    }
+    wg_sync();
+  }
+  auto next_chunk = [&](int ci) {  // first chunk >= ci with a non-zero block (nch: none); uniform
+    if (!sparse) return ci;
+    while (ci < nch) {
+      const uint32_t w = nzm[ci >> 5] >> (ci & 31);
+      if (w) return ci + __builtin_ctz(w);
+      ci = (ci | 31) + 1;
+    }
+    return nch;
+  };
+  uint32_t kfl = 0xffffffffu;  // row flags of the K tile in flight (byte u: row kr + 16 u)
   auto k_issue = [&](const int j0, v4f (&kt)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int il = min(il0 + kr + 16 * u, a.n_local - 1);
       kt[u] = *reinterpret_cast<const v4f *>(a.K + (size_t)il * a.ldK + j0 + kc);  // (ldK is a multiple of 64: in bounds; the tail is masked)
     }
+    if (sparse) {  // rows whose block is zero were not stored by pass 1: what the load returned for them is stale
+      kfl = 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kfl |= (uint32_t)a.nz[(size_t)(j0 >> 6) * a.ldnz + il0 + kr + 16 * u] << (8 * u);
+    }
   };
   auto k_commit = [&](const int jc, const v4f (&kt)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       v4f t = kt[u];
-      t.x = kc + 0 < jc ? t.x : 0.f;
-      t.y = kc + 1 < jc ? t.y : 0.f;
-      t.z = kc + 2 < jc ? t.z : 0.f;
-      t.w = kc + 3 < jc ? t.w : 0.f;
+      const bool rz = ((kfl >> (8 * u)) & 0xffu) != 0u;
+      t.x = (rz && kc + 0 < jc) ? t.x : 0.f;
+      t.y = (rz && kc + 1 < jc) ? t.y : 0.f;
+      t.z = (rz && kc + 2 < jc) ? t.z : 0.f;
+      t.w = (rz && kc + 3 < jc) ? t.w : 0.f;
       *reinterpret_cast<v4f *>(&Kt[(kr + 16 * u) * KS2 + kc]) = t;
     }
   };
@@ -572,9 +636,13 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
         }
       }
     };
-    v_issue(jbeg);
-    k_issue(jbeg, kt);
-    for (int j0 = jbeg; j0 < jend; j0 += JC) {
+    int ci = next_chunk(0);  // chunks whose block is zero for all 64 rows are skipped: they would add exact zeros
+    if (ci < nch) {
+      v_issue(jbeg + ci * JC);
+      k_issue(jbeg + ci * JC, kt);
+    }
+    while (ci < nch) {
+      const int j0 = jbeg + ci * JC;
       const int jc = min(JC, jend - j0);
       wg_sync();  // the previous chunk's products are done with Vs / Kt
 #pragma unroll
@@ -593,9 +661,10 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
       }
       k_commit(jc, kt);
       wg_sync();
-      if (j0 + JC < jend) {  // in flight during the products
-        v_issue(j0 + JC);
-        k_issue(j0 + JC, kt);
+      ci = next_chunk(ci + 1);
+      if (ci < nch) {  // in flight during the products
+        v_issue(jbeg + ci * JC);
+        k_issue(jbeg + ci * JC, kt);
       }
       products();
     }

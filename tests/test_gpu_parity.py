@@ -1063,3 +1063,61 @@ def test_large_aliased_logp_mfma_vs_oracle(model, N, H, spread, offset):
     assert np.abs(pw - pw0).max() < 1e-6 + 3e-4 * pw0.max()  # same costs on both sides: only log p differs
     assert np.abs(pw - fw["p_weights"]).max() < 2e-3
     assert abs(float(pw.sum()) - 1.0) < 5e-4  # (log-weights of O(1e3): one fp32 ulp there is 1e-4 relative on a weight)
+
+
+@pytest.mark.parametrize("model,N,H,kind", [("particle", 2048, 40, "spread"), ("particle", 2100, 40, "mixed"), ("pendulum", 4096, 30, "mixed"),
+                                            ("pendulum", 2304, 30, "clustered"), ("pendulum", 2200, 17, "spread"),
+                                            ("particle", 16384, 40, "mixed")])
+def test_fused_pairwise_zero_blocks_bitwise(model, N, H, kind):
+    """K1's kernel values underflow to exactly 0 in fp32 beyond d^2 ~ 84; pairwise_fused.hpp flags the (query row, 64-key chunk)
+    blocks that are all zero and skips them in pass B, in the Gram store and in the Gram x score GEMM.  The result must be
+    BIT-IDENTICAL to the dense evaluation (DUST_DENSE=1): phi / grad_pri of the stage-wise call and the particles after two whole
+    ticks, for a spread set (only the diagonal survives), a clustered one (everything survives) and a mixed one (a cluster of
+    near-duplicates inside a spread set: blocks with a few non-zero rows - the rows of such a block that were NOT stored must read
+    as zeros, not as stale Gram values of an earlier pass)."""
+    from dust_amd import Context
+    from oracle import grid_4x4_map
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(7 * N + H)
+    S = 8
+    sig = 2.0 if model == "pendulum" else 5.0
+    theta = (sig * rng.standard_normal((N, H, da))).astype(np.float32)
+    if kind == "clustered":
+        theta = (0.05 * rng.standard_normal((N, H, da))).astype(np.float32)
+    elif kind == "mixed":  # every 7th particle sits next to particle 3; a run of neighbours in index space as well
+        theta[::7] = theta[3] + (0.3 * rng.standard_normal((len(theta[::7]), H, da))).astype(np.float32)
+        theta[100:180] = theta[100] + (0.2 * rng.standard_normal((80, H, da))).astype(np.float32)
+    costs = (30.0 * rng.random((S, N))).astype(np.float32)
+    actions = (theta[None] + rng.standard_normal((S, N, H, da))).astype(np.float32)
+    mixw = rng.random(N).astype(np.float32) + 0.05
+    grid = grid_4x4_map() if model == "particle" else None
+    state = np.array([3.0, 0.0] if da == 1 else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    got = {}
+    for dense in ("", "1"):
+        if dense:
+            os.environ["DUST_DENSE"] = dense
+        try:
+            c = Context(model=model, N=N, S=S, M=1, H=H, kernel="K1", lr=0.5, alpha=1.0 if da == 1 else 1e-4, sigma_a=sig, sigma_p=sig,
+                        grid=grid, weighted_prior=True, seed=3)
+            c.set_theta(theta)
+            c.set_prior(theta)
+            c.set_a_mat(theta)
+            c.svmpc_update_prior(mixw)
+            phi_d, _, gp_d = c.svmpc_phi(costs, actions)
+            # the same call again after a pass over OTHER particles has left its Gram rows in the buffer
+            c.set_theta(theta[::-1].copy())
+            c.svmpc_phi(costs, actions)
+            c.set_theta(theta)
+            phi_2, _, gp_2 = c.svmpc_phi(costs, actions)
+            assert np.array_equal(phi_2, phi_d) and np.array_equal(gp_2, gp_d)
+            for _ in range(2):
+                a_seq, pw = c.svmpc_tick(state, 1)
+            got[dense] = (phi_d, gp_d, c.get_theta(), pw)
+            c.close()
+        finally:
+            os.environ.pop("DUST_DENSE", None)
+    for x, y in zip(got[""], got["1"]):
+        assert np.array_equal(x, y)
+    nzfrac = float((np.abs(got[""][0]) > 0).mean())
+    assert nzfrac > 0.5  # (phi itself is dense: K_ii = 1 carries the score)
