@@ -2031,7 +2031,9 @@ extern "C" int dust_svmpc_step(dust_ctx *c, const float *state, const float *eps
 static int forward_device(dust_ctx *c) {
   if (!c->have_sample) return fail(DUST_ERR_STATE, "forward(fast_pred=True) needs the costs of a previous optimize step");
   TRY(launch_prior(c, /*logp_only=*/true));
-  if (c->nloc == c->N) return DUST_OK;  // unsharded: finalize_kernel combines the partials itself
+  // unsharded small sets: finalize_kernel combines the partials itself (one launch less); from 4 096 particles on the merge of the
+  // slice partials is spread over many workgroups first (the single finalize workgroup took 40 us at N = 16 384 with it, 14 without)
+  if (c->nloc == c->N && c->N < 4096) return DUST_OK;
   TRY(launch_prior_finish(c, false, true));
   Prof p(c, DUST_K_FORWARD);
   logw_kernel<<<(c->nloc + 255) / 256, 256, 0, c->stream>>>(c->logl, c->logp, c->lw, c->n0, c->nloc);
@@ -2055,7 +2057,7 @@ static FinalizeArgs finalize_args(dust_ctx *c, bool keep_prior) {
   f.mixw = c->mixw;
   f.weighted_prior = c->cfg.weighted_prior;
   f.keep_prior = keep_prior ? 1 : 0;
-  if (c->nloc == c->N) {
+  if (c->nloc == c->N && c->N < 4096) {  // (forward_device: larger sets arrive with lw formed)
     f.merge_logp = 1;
     f.logp_out = c->logp;
     f.pm = prior_merge_args(c);
