@@ -147,6 +147,8 @@ SYMBOLS = {
     "dust_mpf_get_particles": (C.c_int, [VP, FP]),
     "dust_mpf_set_particles": (C.c_int, [VP, FP]),
     "dust_mpf_get_prior": (C.c_int, [VP, FP, FP]),
+    "dust_mpf_set_prior_bw": (C.c_int, [VP, FP, C.c_int]),
+    "dust_mpf_get_prior_bw": (C.c_int, [VP, FP]),
     "dust_mpf_prior_sample": (C.c_int, [VP, C.c_int, C.c_uint64, FP]),
     "dust_mpf_prior_log_prob": (C.c_int, [VP, C.c_int, FP, FP]),
 }

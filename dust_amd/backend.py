@@ -471,6 +471,16 @@ class MpfContext:
         L.check(L.load().dust_mpf_get_prior(self._h, _p(means), C.cast(C.byref(bw), L.FP)))
         return means, bw.value
 
+    def set_prior_bw(self, bw):
+        """Per-dimension bandwidths of the current prior (MPF(bw=None): bw_silverman of the particle columns, mpf.py:31-36)."""
+        b = np.ascontiguousarray(np.asarray(bw, np.float32).reshape(-1))
+        L.check(L.load().dust_mpf_set_prior_bw(self._h, _p(b), int(b.size)))
+
+    def get_prior_bw(self):
+        out = np.empty(self.P, np.float32)
+        L.check(L.load().dust_mpf_get_prior_bw(self._h, _p(out)))
+        return out
+
     def prior_sample(self, n, seed=0):
         out = np.empty((n, self.P), np.float32)
         L.check(L.load().dust_mpf_prior_sample(self._h, n, seed, _p(out)))

@@ -19,7 +19,8 @@ namespace dust {
 struct MpfArgs {
   DevModel dm;
   int Mp, P, ds, da, n_steps, log_space, have_past;
-  float prior_bw, bw, lr, obs_std;
+  float prior_bwv[4];  // prior bandwidth per parameter dimension (equal after the first update_prior; MPF(bw=None) starts per-dimension)
+  float bw, lr, obs_std;
   float past_obs[4], past_action[2], obs[4];
   float *x;           // [Mp][P] in/out
   float *grad_norms;  // [n_steps] or nullptr
@@ -117,7 +118,11 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
     _Pragma("unroll") for (int p = 0; p < P; ++p) xs[i * P + p] = a.x[i * P + p];
   wg_sync();
   const float bw2 = (float)((double)a.bw * (double)a.bw);
-  const double inv_pbw = 1.0 / (double)a.prior_bw, inv_pbw2 = inv_pbw * inv_pbw;
+  double inv_pbw[4], inv_pbw2[4];
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {
+    inv_pbw[p] = 1.0 / (double)a.prior_bwv[p < P ? p : 0];
+    inv_pbw2[p] = inv_pbw[p] * inv_pbw[p];
+  }
   const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw), inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
   float am[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};  // Adam moments of this lane's particle (registers for the whole launch)
   const bool adam = a.optimizer == DUST_OPT_ADAM;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
       for (int k = k0; k < k1; ++k) {
         double q = 0.0;
         _Pragma("unroll") for (int p = 0; p < P; ++p) {
-          const double z = ((double)xi[p] - (double)xs[k * P + p]) * inv_pbw;
+          const double z = ((double)xi[p] - (double)xs[k * P + p]) * inv_pbw[p];
           q += z * z;
         }
         const double w = (double)expf((float)(-0.5 * q));
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
         _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] += d[1 + p];
       }
       double s[4];
-      _Pragma("unroll") for (int p = 0; p < P; ++p) s[p] = acc[p] / zs * inv_pbw2;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) s[p] = acc[p] / zs * inv_pbw2[p];
       // likelihood score (mpf.py:46-50, likelihoods.py:30-49)
       float pred[4];
       for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
@@ -238,14 +243,17 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
   }
 }
 
-__global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, int K, int P, float bw, float *out) {
+struct MpfBw {
+  float v[4];
+};
+__global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, int K, int P, const MpfBw bw, float *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double mx = -INFINITY;
   for (int k = 0; k < K; ++k) {
     double q = 0.0;
     for (int p = 0; p < P; ++p) {
-      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw;
+      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw.v[p];
       q += z * z;
     }
     mx = fmax(mx, -0.5 * q);
@@ -254,16 +262,18 @@ __global__ void mpf_log_prob_kernel(const float *x, const float *means, int n, i
   for (int k = 0; k < K; ++k) {
     double q = 0.0;
     for (int p = 0; p < P; ++p) {
-      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw;
+      const double z = ((double)x[i * P + p] - (double)means[k * P + p]) / (double)bw.v[p];
       q += z * z;
     }
     zs += exp(-0.5 * q - mx);
   }
-  out[i] = (float)(mx + log(zs) - log((double)K) - P * log((double)bw) - 0.5 * P * log(2.0 * M_PI));
+  double ld = 0.0;
+  for (int p = 0; p < P; ++p) ld += log((double)bw.v[p]);
+  out[i] = (float)(mx + log(zs) - log((double)K) - ld - 0.5 * P * log(2.0 * M_PI));
 }
 
 // mpf.prior.sample([n]): categorical over the M_p components (uniform), then N(mean, bw^2 I)
-__global__ void mpf_sample_kernel(const float *means, int K, int P, float bw, uint64_t seed, int n, float *out) {
+__global__ void mpf_sample_kernel(const float *means, int K, int P, const MpfBw bw, uint64_t seed, int n, float *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t r[4];
@@ -271,7 +281,7 @@ __global__ void mpf_sample_kernel(const float *means, int K, int P, float bw, ui
   const int k = (int)(((unsigned long long)r[0] * (unsigned long long)K) >> 32);
   float z[4];
   philox_normal4(seed, (uint32_t)i, 0x6d7067u, 1u, 0u, z);
-  for (int p = 0; p < P; ++p) out[i * P + p] = means[k * P + p] + bw * z[p];
+  for (int p = 0; p < P; ++p) out[i * P + p] = means[k * P + p] + bw.v[p] * z[p];
 }
 
 }  // namespace dust
@@ -288,7 +298,7 @@ struct dust_mpf {
   uint32_t *grid_bits;
   int nx, ny;
   float off_x, off_y;
-  float prior_bw;
+  float prior_bwv[4];          // per parameter dimension; equal once update_prior(bw) has run (mpf.py:85)
   float loc[4], past_obs[4], past_action[2];
   bool have_past;
 };
@@ -344,7 +354,7 @@ extern "C" int dust_mpf_create(const dust_mpf_config *cfg, const float *init_par
   TRY(dalloc(&m->gn, (size_t)4096));
   HIP_TRY(hipMemcpyAsync(m->x, init_particles, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyHostToDevice, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  m->prior_bw = cfg->init_bw;
+  for (int p = 0; p < 4; ++p) m->prior_bwv[p] = cfg->init_bw;
   for (int k = 0; k < cfg->dim_s && k < 4; ++k) m->loc[k] = initial_obs[k];
   m->have_past = false;
   return DUST_OK;
@@ -398,7 +408,7 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   HIP_TRY(hipMemcpy(x.data(), src->x, x.size() * sizeof(float), hipMemcpyDeviceToHost));
   TRY(dust_mpf_create(&src->cfg, x.data(), src->loc, out));
   dust_mpf *m = *out;
-  m->prior_bw = src->prior_bw;
+  memcpy(m->prior_bwv, src->prior_bwv, sizeof m->prior_bwv);
   memcpy(m->loc, src->loc, sizeof m->loc);
   memcpy(m->past_obs, src->past_obs, sizeof m->past_obs);
   memcpy(m->past_action, src->past_action, sizeof m->past_action);
@@ -434,7 +444,7 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.da = m->cfg.dim_a;
   a.n_steps = n_steps;
   a.log_space = m->cfg.log_space;
-  a.prior_bw = m->prior_bw;
+  for (int p = 0; p < 4; ++p) a.prior_bwv[p] = m->prior_bwv[p];
   a.bw = bw;
   a.lr = lr;
   a.obs_std = m->cfg.obs_std;
@@ -487,7 +497,7 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr));
   if (m->optimizer == DUST_OPT_ADAM) m->adam_t += n_steps;
-  m->prior_bw = bw;  // update_prior(bw) mpf.py:85
+  for (int p = 0; p < 4; ++p) m->prior_bwv[p] = bw;  // update_prior(bw) mpf.py:85
   if (grad_norms && n_steps > 0) {
     HIP_TRY(hipMemcpyAsync(grad_norms, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   }
@@ -531,17 +541,40 @@ extern "C" int dust_mpf_set_particles(dust_mpf *m, const float *x) {
   HIP_TRY(hipStreamSynchronize(m->stream));
   return DUST_OK;
 }
+static dust::MpfBw mpf_bw(const dust_mpf *m) {
+  dust::MpfBw b;
+  for (int p = 0; p < 4; ++p) b.v[p] = m->prior_bwv[p];
+  return b;
+}
+
+// MPF(bw=None) with P > 1: bw_silverman of the particle columns is a [P] vector and `bw ** 2 * torch.eye(P)` (mpf.py:31-36) turns it
+// into the covariance diag(bw_p^2) of the FIRST prior; every later update_prior(bw) (mpf.py:85) is scalar again.
+extern "C" int dust_mpf_set_prior_bw(dust_mpf *m, const float *bw, int n) {
+  if (!m || !bw) return fail(DUST_ERR_INVALID, "null argument");
+  if (n != 1 && n != m->P) return fail(DUST_ERR_INVALID, "prior bandwidths: 1 or P = %d values, got %d", m->P, n);
+  for (int p = 0; p < n; ++p)
+    if (!(bw[p] > 0.f)) return fail(DUST_ERR_INVALID, "prior bandwidth %d must be > 0", p);
+  for (int p = 0; p < 4; ++p) m->prior_bwv[p] = bw[n == 1 ? 0 : (p < n ? p : 0)];
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_get_prior_bw(dust_mpf *m, float *bw) {
+  if (!m || !bw) return fail(DUST_ERR_INVALID, "null argument");
+  for (int p = 0; p < m->P; ++p) bw[p] = m->prior_bwv[p];
+  return DUST_OK;
+}
+
 extern "C" int dust_mpf_get_prior(dust_mpf *m, float *means, float *bw) {
   if (!m) return fail(DUST_ERR_INVALID, "null mpf");
   if (means) TRY(dust_mpf_get_particles(m, means));
-  if (bw) *bw = m->prior_bw;
+  if (bw) *bw = m->prior_bwv[0];  // (per-dimension bandwidths: dust_mpf_get_prior_bw)
   return DUST_OK;
 }
 extern "C" int dust_mpf_prior_sample(dust_mpf *m, int n, uint64_t seed, float *samples) {
   if (!m || !samples || n < 1) return fail(DUST_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(m->cfg.device));
   TRY(ensure(&m->tmp, &m->tmp_cap, (size_t)n * m->P));
-  mpf_sample_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->x, m->Mp, m->P, m->prior_bw, seed, n, m->tmp);
+  mpf_sample_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->x, m->Mp, m->P, mpf_bw(m), seed, n, m->tmp);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(samples, m->tmp, (size_t)n * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
@@ -552,7 +585,7 @@ extern "C" int dust_mpf_prior_log_prob(dust_mpf *m, int n, const float *x, float
   HIP_TRY(hipSetDevice(m->cfg.device));
   TRY(ensure(&m->tmp, &m->tmp_cap, (size_t)n * (m->P + 1)));
   HIP_TRY(hipMemcpyAsync(m->tmp, x, (size_t)n * m->P * sizeof(float), hipMemcpyHostToDevice, m->stream));
-  mpf_log_prob_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->tmp, m->x, n, m->Mp, m->P, m->prior_bw, m->tmp + (size_t)n * m->P);
+  mpf_log_prob_kernel<<<(n + 255) / 256, 256, 0, m->stream>>>(m->tmp, m->x, n, m->Mp, m->P, mpf_bw(m), m->tmp + (size_t)n * m->P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(log_prob, m->tmp + (size_t)n * m->P, n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));

@@ -64,11 +64,12 @@ class MPF:
         if extra:
             raise NotImplementedError("optimiser options %s are not implemented on the device" % sorted(extra))
         self.likelihood, self.bw_scale = likelihood, bw_scale
-        if bw is None:
-            b = bw_silverman(init_particles.flatten(1, -1), bw_scale)
-            if torch.as_tensor(b).numel() != 1:
-                raise NotImplementedError("per-dimension initial bandwidths (bw=None with P > 1) are not supported; pass bw")
-            bw = float(b)
+        bw_vec = None
+        if bw is None:  # mpf.py:31-32: a scalar (IQR branch of _select_sigma) or one value per particle column
+            b = torch.as_tensor(bw_silverman(init_particles.flatten(1, -1), bw_scale), dtype=torch.float).reshape(-1)
+            if b.numel() != 1:
+                bw_vec = b.numpy().copy()  # `bw ** 2 * torch.eye(P)` (mpf.py:36) -> covariance diag(bw_p^2)
+            bw = float(b[0])
         model = likelihood.model
         kw = dict(model=model.family, uncertain_params=tuple(model.uncertain_params), log_space=bool(likelihood.log_space),
                   obs_std=float(likelihood.sigma), lr=float(opt_args.get("lr", 1e-3)), bw_scale=float(bw_scale), init_bw=float(bw), dt=model.dt)
@@ -82,6 +83,8 @@ class MPF:
             grid = model.obst_map.map.astype(np.float32) if model.obst_map is not None else None
         kw.update(opt_kw)
         self._dev = MpfContext(init_particles.numpy(), likelihood.loc.numpy(), grid=grid, **kw)
+        if bw_vec is not None:
+            self._dev.set_prior_bw(bw_vec)
         self.prior = _DevicePrior(self)
 
     def __deepcopy__(self, memo):

@@ -283,6 +283,11 @@ int dust_mpf_set_grid(dust_mpf *mpf, const float *grid, int nx, int ny, float of
 int dust_mpf_get_particles(dust_mpf *mpf, float *x);
 int dust_mpf_set_particles(dust_mpf *mpf, const float *x);
 int dust_mpf_get_prior(dust_mpf *mpf, float *means, float *bw);
+/* MPF(bw=None) with P > 1 parameters (mpf.py:29-38): bw_silverman (svgd.py:55-81) of the particle columns is a [P] vector and
+ * `bw ** 2 * torch.eye(P)` makes it the covariance diag(bw_p^2) of the FIRST prior; n = 1 or P values.  Every later
+ * update_prior(bw) (mpf.py:85, at the end of optimize) is scalar again.  dust_mpf_get_prior reports bw[0]; _get_prior_bw all P. */
+int dust_mpf_set_prior_bw(dust_mpf *mpf, const float *bw, int n);
+int dust_mpf_get_prior_bw(dust_mpf *mpf, float *bw);
 /* mpf.prior.sample([n]) / .log_prob(x): the controller draws its dynamics samples here (disco.py:171-172) */
 int dust_mpf_prior_sample(dust_mpf *mpf, int n, uint64_t seed, float *samples);
 int dust_mpf_prior_log_prob(dust_mpf *mpf, int n, const float *x, float *log_prob);

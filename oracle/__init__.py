@@ -296,6 +296,29 @@ class Oracle:
                           C.c_float(obs_std), C.c_int(int(log_space)), C.c_float(bw), _p(phi))
         return phi
 
+    def mpf_phi_v(self, x, prior_means, prior_bwv, past_obs, past_action, obs, obs_std, log_space, bw):
+        """MPF.phi with a per-dimension prior bandwidth (the first prior of MPF(bw=None), mpf.py:31-32)."""
+        x, pm, po, pa, ob, bv = _f(x), _f(prior_means), _f(past_obs), _f(past_action).reshape(-1), _f(obs), _f(prior_bwv)
+        phi = np.empty_like(x)
+        lib().orc_mpf_phi_v(C.byref(self.c), C.c_int(x.shape[0]), _p(x), _p(pm), _p(bv), _p(po), _p(pa), _p(ob),
+                            C.c_float(obs_std), C.c_int(int(log_space)), C.c_float(bw), _p(phi))
+        return phi
+
+    def mpf_optimize_v(self, x, prior_means, prior_bwv, past_obs, past_action, obs, obs_std, log_space, bw, lr, n_steps):
+        x, pm, po, pa, ob = _f(x).copy(), _f(prior_means).copy(), _f(past_obs), _f(past_action).reshape(-1), _f(obs)
+        bv = _f(prior_bwv).copy()
+        gn = np.empty(n_steps, np.float32)
+        lib().orc_mpf_optimize_v(C.byref(self.c), C.c_int(x.shape[0]), _p(x), _p(pm), _p(bv), _p(po), _p(pa), _p(ob),
+                                 C.c_float(obs_std), C.c_int(int(log_space)), C.c_float(bw), C.c_float(lr), C.c_int(n_steps), _p(gn))
+        return x, pm, bv, gn
+
+    @staticmethod
+    def gmm_log_prob_v(x, means, bwv):
+        x, means, bv = _f(x), _f(means), _f(bwv)
+        out = np.empty(x.shape[0], np.float32)
+        lib().orc_gmm_log_prob_v(C.c_int(x.shape[0]), C.c_int(means.shape[0]), C.c_int(x.shape[1]), _p(x), _p(means), _p(bv), _p(out))
+        return out
+
     def mpf_optimize(self, x, prior_means, prior_bw, past_obs, past_action, obs, obs_std, log_space, bw, lr, n_steps):
         x, pm, po, pa, ob = _f(x).copy(), _f(prior_means).copy(), _f(past_obs), _f(past_action).reshape(-1), _f(obs)
         gn = np.empty(n_steps, np.float32)

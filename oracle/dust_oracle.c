@@ -690,9 +690,11 @@ static void step_jacobian(const orc_cfg *c, const float *x, const float *a, cons
   }
 }
 
-void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_means, float prior_bw,
-                 const float *past_obs, const float *past_action, const float *obs, float obs_std, int log_space,
-                 float bw, float *phi) {
+/* prior_bwv: one bandwidth per parameter dimension - MPF(bw=None) builds its FIRST prior from bw_silverman of the particle columns
+ * (mpf.py:31-32, svgd.py:55-81: a [P] vector; `bw ** 2 * torch.eye(P)` broadcasts it over the columns: covariance diag(bw_p^2)). */
+void orc_mpf_phi_v(const orc_cfg *c, int Mp, const float *x, const float *prior_means, const float *prior_bwv,
+                   const float *past_obs, const float *past_action, const float *obs, float obs_std, int log_space,
+                   float bw, float *phi) {
   const int P = c->P, ds = c->ds;
   double *score = (double *)malloc(sizeof(double) * (size_t)Mp * P);
   double *lg = (double *)malloc(sizeof(double) * Mp);
@@ -703,7 +705,7 @@ void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_me
     for (int k = 0; k < Mp; ++k) {
       double q = 0.0;
       for (int p = 0; p < P; ++p) {
-        double z = ((double)x[(size_t)i * P + p] - (double)prior_means[(size_t)k * P + p]) / (double)prior_bw;
+        double z = ((double)x[(size_t)i * P + p] - (double)prior_means[(size_t)k * P + p]) / (double)prior_bwv[p];
         q += z * z;
       }
       lg[k] = -0.5 * q;
@@ -713,7 +715,7 @@ void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_me
       double acc = 0.0;
       for (int k = 0; k < Mp; ++k)
         acc += exp(lg[k] - z) * ((double)prior_means[(size_t)k * P + p] - (double)x[(size_t)i * P + p]) /
-               ((double)prior_bw * (double)prior_bw);
+               ((double)prior_bwv[p] * (double)prior_bwv[p]);
       score[(size_t)i * P + p] = acc;
     }
     /* likelihood score, mpf.py:46-50 + likelihoods.py:30-49 */
@@ -753,6 +755,50 @@ void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_me
     }
   free(nrm);
   free(score);
+  free(lg);
+}
+
+void orc_mpf_phi(const orc_cfg *c, int Mp, const float *x, const float *prior_means, float prior_bw,
+                 const float *past_obs, const float *past_action, const float *obs, float obs_std, int log_space,
+                 float bw, float *phi) {
+  const float v[4] = {prior_bw, prior_bw, prior_bw, prior_bw};
+  orc_mpf_phi_v(c, Mp, x, prior_means, v, past_obs, past_action, obs, obs_std, log_space, bw, phi);
+}
+
+/* MPF.optimize from a per-dimension prior (the state right after MPF(bw=None)): SGD steps, then update_prior(bw) - scalar again */
+void orc_mpf_optimize_v(const orc_cfg *c, int Mp, float *x, float *prior_means, float *prior_bwv /* [P] in/out */, const float *past_obs,
+                        const float *past_action, const float *obs, float obs_std, int log_space, float bw, float lr,
+                        int n_steps, float *grad_norms) {
+  const int P = c->P;
+  float *phi = (float *)malloc(sizeof(float) * (size_t)Mp * P);
+  for (int it = 0; it < n_steps; ++it) {
+    orc_mpf_phi_v(c, Mp, x, x, prior_bwv, past_obs, past_action, obs, obs_std, log_space, bw, phi);
+    double nn = 0.0;
+    for (int i = 0; i < Mp * P; ++i) nn += (double)phi[i] * (double)phi[i];
+    if (grad_norms) grad_norms[it] = (float)sqrt(nn);
+    orc_sgd(Mp * P, lr, phi, x);
+  }
+  memcpy(prior_means, x, sizeof(float) * (size_t)Mp * P);
+  for (int p = 0; p < P; ++p) prior_bwv[p] = bw;
+  free(phi);
+}
+
+/* log prob of the diagonal-covariance uniform GMM (the first prior of MPF(bw=None)) */
+void orc_gmm_log_prob_v(int n, int K, int P, const float *x, const float *means, const float *bwv, float *out) {
+  double *lg = (double *)malloc(sizeof(double) * K);
+  double ld = 0.0;
+  for (int p = 0; p < P; ++p) ld += log((double)bwv[p]);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < K; ++k) {
+      double q = 0.0;
+      for (int p = 0; p < P; ++p) {
+        double z = ((double)x[(size_t)i * P + p] - (double)means[(size_t)k * P + p]) / (double)bwv[p];
+        q += z * z;
+      }
+      lg[k] = -log((double)K) - 0.5 * q - ld - 0.5 * P * log(2.0 * M_PI);
+    }
+    out[i] = (float)lse(lg, K);
+  }
   free(lg);
 }
 

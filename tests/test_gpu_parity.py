@@ -1121,3 +1121,44 @@ def test_fused_pairwise_zero_blocks_bitwise(model, N, H, kind):
         assert np.array_equal(x, y)
     nzfrac = float((np.abs(got[""][0]) > 0).mean())
     assert nzfrac > 0.5  # (phi itself is dense: K_ii = 1 carries the score)
+
+
+@pytest.mark.parametrize("name", ["mpf_bwvec", "mpf_bwiqr"])
+def test_mpf_initial_prior_from_bw_silverman(golden, name):
+    """MPF(bw=None) with P = 2 (mpf.py:29-38): the first prior is diag(bw_silverman(columns)^2) - per-dimension bandwidths on the
+    device (`dust_mpf_set_prior_bw`), through the raw context and through the mirror class `dust_amd.inference.mpf.MPF(bw=None)`;
+    golden = the reference's own MPF (tests/golden/make_golden_r3.py)."""
+    import torch
+
+    from dust_amd import MpfContext
+    from dust_amd.inference.likelihoods import GaussianLikelihood
+    from dust_amd.inference.mpf import MPF
+    from dust_amd.inference.svgd import bw_silverman
+    from dust_amd.models import PendulumModel
+
+    g = golden(name)
+    P, bw, lr, n = int(g["P"]), float(g["bw_opt"]), float(g["lr"]), int(g["n_steps"])
+    bwv = np.broadcast_to(np.asarray(bw_silverman(g["x0"], 1.0), np.float32).reshape(-1), (P,)).astype(np.float32)
+    tol_x = TOL * (1.0 + lr / float(bwv.min()) ** 2) ** n  # (stiff attraction of the prior: tests/test_oracle_golden.py, same test)
+    up = ("length", "mass")
+    m = MpfContext(g["x0"], g["obs0"], model="pendulum", uncertain_params=up, log_space=False, obs_std=float(g["obs_std"]), lr=lr,
+                   init_bw=float(bwv[0]))
+    m.set_prior_bw(bwv)
+    assert np.array_equal(m.get_prior_bw(), bwv)
+    assert relerr(m.prior_log_prob(g["probe"]), g["probe_log_prob0"]) < TOL
+    smp = m.prior_sample(40000, seed=5)
+    spread = smp.std(0) ** 2 - g["x0"].std(0) ** 2  # mixture variance = variance of the means + bw_p^2
+    assert np.all(np.abs(spread - bwv ** 2) < 0.15 * bwv ** 2 + 0.05 * g["x0"].std(0) ** 2)
+    m.condition(g["action"], g["obs1"])
+    assert elemerr(m.phi(bw), g["phi0"]) < TOL
+    m.close()
+    # the mirror class: bw=None evaluates bw_silverman on the host and hands the vector over
+    model = PendulumModel(uncertain_params=up)
+    lik = GaussianLikelihood(initial_obs=torch.tensor(g["obs0"]), obs_std=float(g["obs_std"]), model=model, log_space=False)
+    mp = MPF(init_particles=torch.tensor(g["x0"]), likelihood=lik, optimizer_class=torch.optim.SGD, lr=lr, bw=None, bw_scale=1.0)
+    assert relerr(mp.prior.log_prob(torch.tensor(g["probe"])).numpy(), g["probe_log_prob0"]) < TOL
+    grads, _ = mp.optimize(torch.tensor(g["action"]), torch.tensor(g["obs1"]), bw=bw, n_steps=n)
+    assert relerr(mp.x.numpy(), g["x_final"]) < tol_x and relerr(grads.numpy(), g["grad_norms"]) < TOL
+    assert relerr(mp.prior.log_prob(torch.tensor(g["probe"])).numpy(), g["probe_log_prob1"]) < TOL  # isotropic again (mpf.py:85)
+    grads2, _ = mp.optimize(torch.tensor(g["action2"]), torch.tensor(g["obs2"]), bw=bw, n_steps=n)
+    assert relerr(mp.x.numpy(), g["x_final2"]) < 2 * tol_x and relerr(grads2.numpy(), g["grad_norms2"]) < 2e-4

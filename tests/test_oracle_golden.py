@@ -251,3 +251,37 @@ def test_unscented_transform_costs_vs_reference(golden):
     spT = np.ascontiguousarray(g["sigma_points"].T)
     assert relerr(o.rollout_cost_ut(g["state"], g["actions"], spT, g["loc_weights"]), g["costs"]) < 1e-5
     assert relerr(o.rollout_cost_ut(g["state"], g["ext_actions"], spT, g["loc_weights"]), g["costs_ext"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["mpf_bwvec", "mpf_bwiqr"])
+def test_mpf_initial_prior_from_bw_silverman(golden, name):
+    """MPF(bw=None) (mpf.py:29-38): the first prior's covariance is diag(bw_silverman(columns)^2) - one bandwidth per parameter
+    when `_select_sigma` (svgd.py:10-25) takes its per-column std branch (`mpf_bwvec`), a scalar on the pooled-IQR branch
+    (`mpf_bwiqr`).  The host mirror of bw_silverman, the oracle's prior density and phi under that prior, and two optimize() calls
+    (the prior is isotropic again after the first: update_prior(bw), mpf.py:85) against the reference's own MPF."""
+    from dust_amd.inference.svgd import bw_silverman
+    from oracle import Oracle
+
+    g = golden(name)
+    P = int(g["P"])
+    bw0 = np.asarray(bw_silverman(g["x0"], 1.0), np.float32).reshape(-1)
+    assert bw0.size == g["bw_init"].size and relerr(bw0, g["bw_init"]) < 1e-6
+    bwv = np.broadcast_to(bw0, (P,)).astype(np.float32)
+    assert relerr(bwv ** 2, g["prior_cov_diag"]) < 1e-6 and float(g["prior_cov_offdiag_max"]) == 0.0
+    o = Oracle(model="pendulum", uncertain_params=("length", "mass"))
+    assert relerr(Oracle.gmm_log_prob_v(g["probe"], g["x0"], bwv), g["probe_log_prob0"]) < TOL
+    bw, lr, n = float(g["bw_opt"]), float(g["lr"]), int(g["n_steps"])
+    phi0 = o.mpf_phi_v(g["x0"], g["x0"], bwv, g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), False, bw)
+    assert relerr(phi0, g["phi0"]) < TOL
+    x, pm, bv, gn = o.mpf_optimize_v(g["x0"], g["x0"], bwv, g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), False, bw, lr, n)
+    # the prior attracts with stiffness 1 / bw_min^2 (1 450 at bw_0 = 0.026): an SGD step multiplies a difference in x by up to
+    # 1 + lr / bw_min^2 = 2.45, so n steps carry the fp32 noise of phi (TOL) to TOL * 2.45^n on x
+    tol_x = TOL * (1.0 + lr / float(bwv.min()) ** 2) ** n
+    assert relerr(x, g["x_final"]) < tol_x and relerr(gn, g["grad_norms"]) < TOL
+    assert np.all(bv == np.float32(bw))
+    assert relerr(Oracle.gmm_log_prob(g["probe"], pm, bw), g["probe_log_prob1"]) < TOL
+    x2, _, _, gn2 = o.mpf_optimize(x, pm, bw, g["obs1"], g["action2"], g["obs2"], float(g["obs_std"]), False, bw, lr, n)
+    assert relerr(x2, g["x_final2"]) < 2 * tol_x and relerr(gn2, g["grad_norms2"]) < 2e-4
+    if name == "mpf_bwvec":  # a scalar prior bandwidth must NOT reproduce the reference here
+        bad = o.mpf_phi(g["x0"], g["x0"], float(bwv[0]), g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), False, bw)
+        assert relerr(bad, g["phi0"]) > 100 * TOL
