@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("DUST_AMD_LIB", os.path.join(_HERE, "libdust_amd.so"))
 
 ABI_VERSION = 1
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)
-MODEL_PENDULUM, MODEL_PARTICLE = 0, 1
-COST_PENDULUM_QUADCOS, COST_PARTICLE_DEFAULT = 0, 1
+MODEL_PENDULUM, MODEL_PARTICLE, MODEL_SKID_STEER = 0, 1, 2
+COST_PENDULUM_QUADCOS, COST_PARTICLE_DEFAULT, COST_QUADRATIC = 0, 1, 2
 KERNEL_K1_RBF, KERNEL_K2_IIDMP, KERNEL_K2_SHARED, KERNEL_IMQ = 0, 1, 2, 3
 LIK_EXP_UTILITY, LIK_EXPECTED_COST = 0, 1
 OPT_SGD, OPT_ADAM = 0, 1
@@ -32,6 +32,12 @@ class DustError(RuntimeError):
 
 class Param(C.Structure):
     _fields_ = [("kind", C.c_int32), ("column", C.c_int32), ("value", C.c_double)]
+
+
+class SkidConfig(C.Structure):  # dust_skid_config
+    _fields_ = [("x_icr", Param), ("wheel_radius", Param), ("axial_distance", Param), ("min_wheel_speed", C.c_float * 2),
+                ("max_wheel_speed", C.c_float * 2), ("goal", C.c_float * 5), ("w_state", C.c_float * 5), ("w_term", C.c_float * 5),
+                ("w_ctrl", C.c_float * 2)]
 
 
 class Config(C.Structure):
@@ -147,6 +153,7 @@ SYMBOLS = {
     "dust_mpf_get_particles": (C.c_int, [VP, FP]),
     "dust_mpf_set_particles": (C.c_int, [VP, FP]),
     "dust_mpf_get_prior": (C.c_int, [VP, FP, FP]),
+    "dust_set_skid_steer": (C.c_int, [VP, C.POINTER(SkidConfig)]),
     "dust_mpf_set_prior_bw": (C.c_int, [VP, FP, C.c_int]),
     "dust_mpf_get_prior_bw": (C.c_int, [VP, FP]),
     "dust_mpf_prior_sample": (C.c_int, [VP, C.c_int, C.c_uint64, FP]),

@@ -48,10 +48,13 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     c.abi_version = L.ABI_VERSION
     c.device = device
     pend = model == "pendulum"
-    c.model = L.MODEL_PENDULUM if pend else L.MODEL_PARTICLE
-    c.cost = L.COST_PENDULUM_QUADCOS if pend else L.COST_PARTICLE_DEFAULT
+    skid = model == "skid_steer"
+    if model not in ("pendulum", "particle", "skid_steer"):
+        raise ValueError("unknown model family %r" % (model,))
+    c.model = L.MODEL_PENDULUM if pend else (L.MODEL_SKID_STEER if skid else L.MODEL_PARTICLE)
+    c.cost = L.COST_PENDULUM_QUADCOS if pend else (L.COST_QUADRATIC if skid else L.COST_PARTICLE_DEFAULT)
     c.n_policies, c.n_samples, c.n_params, c.horizon = N, S, M, H
-    c.dim_a, c.dim_s = (1, 2) if pend else (2, 4)
+    c.dim_a, c.dim_s = (1, 2) if pend else ((2, 5) if skid else (2, 4))
     up = list(uncertain_params) if uncertain_params else []
     use_params = bool(up) if sampling is None else bool(sampling)
     c.dim_p = len(up) if use_params else 0
@@ -75,11 +78,13 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     for d in range(c.dim_a):
         c.sigma_a[d], c.sigma_p[d], c.chol_a[d], c.a_pre[d] = sa[d], sp[d], ch[d], ap[d]
     c.bw_scale, c.imq_ell = bw_scale, imq_ell
-    lo = np.broadcast_to(np.asarray((-2.0 if pend else -max_accel) if min_a is None else min_a, np.float32), (c.dim_a,))
-    hi = np.broadcast_to(np.asarray((2.0 if pend else max_accel) if max_a is None else max_a, np.float32), (c.dim_a,))
+    lo = np.broadcast_to(np.asarray((-2.0 if pend else (-0.5 if skid else -max_accel)) if min_a is None else min_a, np.float32), (c.dim_a,))
+    hi = np.broadcast_to(np.asarray((2.0 if pend else (0.5 if skid else max_accel)) if max_a is None else max_a, np.float32), (c.dim_a,))
     for d in range(c.dim_a):
         c.min_a[d], c.max_a[d] = lo[d], hi[d]
     c.seed = seed
+    if skid and dt is None:
+        raise ValueError("SkidSteerRobot(delta_t=...) has no default: pass dt")
     c.dt = (0.05 if pend else 0.015) if dt is None else dt
 
     def par(name, value):
@@ -90,7 +95,7 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     c.g, c.mass, c.length = par("g", g), par("mass", mass), par("length", length)
     c.max_torque, c.max_speed_pend, c.w_cos, c.w_vel = 2.0, 8.0, w_cos, w_vel
     c.max_speed, c.max_accel = max_speed, max_accel
-    c.can_crash, c.with_obstacle = int(can_crash), int(with_obstacle and not pend)
+    c.can_crash, c.with_obstacle = int(can_crash), int(with_obstacle and not pend and not skid)
     c.cell_size = cell_size
     c.target[:] = list(target)
     c.w_state[:] = list(w_state)
@@ -105,6 +110,8 @@ class Context:
         self._h = None
         lib = L.load()
         k2_bw, k2_min = kw.pop("k2_bandwidth", None), kw.pop("k2_minimum_bw", 1e-5)
+        skid_kw = {k: kw.pop(k) for k in ("x_icr", "wheel_radius", "axial_distance", "goal", "w_quad_state", "w_quad_term", "w_quad_ctrl")
+                   if k in kw}
         if _handle is not None:
             self._h = _handle
         else:
@@ -120,6 +127,8 @@ class Context:
         self.D = self.H * self.da
         if grid is not None:
             self.set_grid(grid)
+        if _handle is None and got.model == L.MODEL_SKID_STEER:
+            self.set_skid_steer(uncertain_params=kw.get("uncertain_params"), sampling=kw.get("sampling"), **skid_kw)
         if k2_bw is not None and float(k2_bw) >= 0:  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth instead of the median trick
             L.check(lib.dust_set_k2_bandwidth(self._h, float(k2_bw), float(k2_min)))
 
@@ -177,6 +186,28 @@ class Context:
         nx, ny = g.shape
         ox, oy = (int(nx / 2), int(ny / 2)) if off is None else off
         L.check(L.load().dust_set_grid(self._h, _p(g), nx, ny, float(ox), float(oy)))
+
+    def set_skid_steer(self, x_icr=0.2, wheel_radius=0.0625, axial_distance=0.475, goal=(0, 0, 0, 0, 0), w_quad_state=(1, 1, 1, 1, 1),
+                       w_quad_term=(1, 1, 1, 1, 1), w_quad_ctrl=(0, 0), uncertain_params=None, sampling=None):
+        """SkidSteerRobot parameters (skid_steer_robot.py:19-45; `uncertain_params` name the sampled ones, in column order) and the
+        quadratic cost family (dust_amd.costs.QuadraticCost).  Wheel-speed bounds are the context's min_a / max_a."""
+        up = list(uncertain_params) if uncertain_params else []
+        use = bool(up) if sampling is None else bool(sampling)
+        g = L.SkidConfig()
+
+        def par(name, value):
+            if use and name in up:
+                return L.Param(L.PARAM_SAMPLED, up.index(name), float(value))
+            return L.Param(L.PARAM_PYFLOAT, 0, float(value))
+
+        g.x_icr, g.wheel_radius, g.axial_distance = par("x_icr", x_icr), par("wheel_radius", wheel_radius), par("axial_distance", axial_distance)
+        for d in range(2):
+            g.min_wheel_speed[d], g.max_wheel_speed[d] = self.cfg.min_a[d], self.cfg.max_a[d]
+        g.goal[:] = [float(v) for v in goal]
+        g.w_state[:] = [float(v) for v in w_quad_state]
+        g.w_term[:] = [float(v) for v in w_quad_term]
+        g.w_ctrl[:] = [float(v) for v in w_quad_ctrl]
+        L.check(L.load().dust_set_skid_steer(self._h, C.byref(g)))
 
     def set_param_weights(self, w):
         """Unscented-transform weights of the n_params dynamics samples (None: plain mean)."""

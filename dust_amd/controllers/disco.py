@@ -70,8 +70,8 @@ class MultiDISCO:
 
     # ------------------------------------------------------------------ context management
     def _config(self, model, params_dist):
-        if model.family not in ("pendulum", "particle"):
-            raise NotImplementedError("no rollout kernel family for %s (the reference ships no cost functions for it either)" % type(model).__name__)
+        if model.family not in ("pendulum", "particle", "skid_steer"):
+            raise NotImplementedError("no rollout kernel family for %s" % type(model).__name__)
         chol = torch.linalg.cholesky(self.a_dist.covariance_matrix).diag()
         sigma = self.a_dist.covariance_matrix.diag().sqrt()  # svmpc.py:107-111
         cfg = dict(model=model.family, N=self.n_pol, S=self.n_actions, M=self._tf.pts if self._tf is not None else self.n_params, H=self.hz_len,
@@ -89,6 +89,9 @@ class MultiDISCO:
             cfg["uncertain_params"] = tuple(model.uncertain_params)
             cfg["params_scalar_event"] = self._scalar_event
         pd = model.params_dict
+        for k in ("x_icr", "wheel_radius", "axial_distance"):  # SkidSteerRobot (skid_steer_robot.py:40-44)
+            if k in pd:
+                cfg[k] = float(pd[k])
         for k in ("g", "mass", "length"):
             if k in pd:
                 v = pd[k]

@@ -24,6 +24,30 @@ class PendulumQuadCos:
         return self.inst_cost(states).squeeze()
 
 
+class QuadraticCost:
+    """Quadratic state / control cost for any model (the skid-steer family uses it: the reference ships no cost for that model and
+    its MultiDISCO takes any callable with this signature, disco.py:294-346):
+        inst(x, a) = sum_k w_state[k] (x_k - goal_k)^2 + sum_d w_ctrl[d] a_d^2        term(x) = sum_k w_term[k] (x_k - goal_k)^2
+    `inst_cost` / `term_cost` are plain torch, so the same object drives the reference's controller and this one's kernels."""
+
+    family = "quadratic"
+
+    def __init__(self, goal, w_state, w_term=None, w_ctrl=None):
+        self.goal = torch.as_tensor(goal, dtype=torch.float).reshape(-1)
+        self.w_state = torch.as_tensor(w_state, dtype=torch.float).reshape(-1)
+        self.w_term = self.w_state.clone() if w_term is None else torch.as_tensor(w_term, dtype=torch.float).reshape(-1)
+        self.w_ctrl = None if w_ctrl is None else torch.as_tensor(w_ctrl, dtype=torch.float).reshape(-1)
+
+    def inst_cost(self, states, controls=None, n_pol=1, debug=None):
+        c = (((states - self.goal) ** 2) * self.w_state).sum(-1)
+        if controls is not None and self.w_ctrl is not None:
+            c = c + ((controls ** 2) * self.w_ctrl).sum(-1)
+        return c
+
+    def term_cost(self, states, n_pol=1, debug=None):
+        return (((states - self.goal) ** 2) * self.w_term).sum(-1)
+
+
 def _probe_quadcos(fn):
     pts = torch.tensor([[0.3, 0.0], [0.0, 1.7], [2.1, -0.4], [-1.2, 3.3], [5.9, -7.1], [3.14159, 0.5]])
     try:
@@ -66,4 +90,14 @@ def recognise(model, inst_cost_fn, term_cost_fn):
         m = inst_cost_fn.__self__
         return dict(target=tuple(float(v) for v in m.target), w_state=tuple(float(v) for v in m.w_state),
                     w_term=tuple(float(v) for v in m.w_term), w_ctrl=tuple(float(v) for v in m.w_ctrl), w_obs=float(m.w_obs))
+    if fam == "skid_steer":
+        owner = getattr(inst_cost_fn, "__self__", None)
+        if not isinstance(owner, QuadraticCost) or getattr(term_cost_fn, "__self__", None) is not owner:
+            raise NotImplementedError("SkidSteerRobot runs with dust_amd.costs.QuadraticCost(...).inst_cost / .term_cost (the reference ships "
+                                      "no cost for this model; an opaque callable cannot run on the device and there is no CPU fallback)")
+        if owner.goal.numel() != 5 or owner.w_state.numel() != 5 or owner.w_term.numel() != 5:
+            raise ValueError("QuadraticCost for SkidSteerRobot needs 5 state entries (x, y, theta, v, omega)")
+        wc = owner.w_ctrl if owner.w_ctrl is not None else torch.zeros(2)
+        return dict(goal=tuple(float(v) for v in owner.goal), w_quad_state=tuple(float(v) for v in owner.w_state),
+                    w_quad_term=tuple(float(v) for v in owner.w_term), w_quad_ctrl=tuple(float(v) for v in wc))
     raise NotImplementedError("model family %r has no HIP kernel" % (fam,))

@@ -22,6 +22,7 @@
 #include "rollout_states.hpp"
 #include "pairwise_fused.hpp"
 #include "pairwise_logp_mfma.hpp"
+#include "skid.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -91,6 +92,7 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
   float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
   size_t nzf_cap;
   int nz_ld;                 // 0: the last fused pass ran dense
@@ -276,6 +278,10 @@ static int validate(const dust_config *g) {
   } else if (g->model == DUST_MODEL_PARTICLE) {
     if (g->dim_a != 2 || g->dim_s != 4) return fail(DUST_ERR_INVALID, "Particle (acceleration control) has dim_a=2, dim_s=4");
     if (g->cost != DUST_COST_PARTICLE_DEFAULT) return fail(DUST_ERR_UNSUPPORTED, "particle model needs Particle.default_*_cost");
+  } else if (g->model == DUST_MODEL_SKID_STEER) {
+    if (g->dim_a != 2 || g->dim_s != 5) return fail(DUST_ERR_INVALID, "SkidSteerRobot has dim_a=2, dim_s=5");
+    if (g->cost != DUST_COST_QUADRATIC) return fail(DUST_ERR_UNSUPPORTED, "the skid-steer model runs with the quadratic cost family (DUST_COST_QUADRATIC)");
+    if (g->dim_p > 3) return fail(DUST_ERR_INVALID, "SkidSteerRobot has 3 parameters");
   } else {
     return fail(DUST_ERR_UNSUPPORTED, "unknown model id %d", g->model);
   }
@@ -360,6 +366,17 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   c->H = cfg->horizon;
   c->da = cfg->dim_a;
   c->ds = cfg->dim_s;
+  if (cfg->model == DUST_MODEL_SKID_STEER) {  // SkidSteerRobot.__init__ defaults (skid_steer_robot.py:19-28); unit state weights, no goal
+    memset(&c->skid, 0, sizeof c->skid);
+    c->skid.x_icr = DevParam{DUST_PARAM_PYFLOAT, 0, 0.2};
+    c->skid.wheel_radius = DevParam{DUST_PARAM_PYFLOAT, 0, 0.0625};
+    c->skid.axial_distance = DevParam{DUST_PARAM_PYFLOAT, 0, 0.475};
+    for (int d = 0; d < 2; ++d) {
+      c->skid.lo[d] = -0.5f;
+      c->skid.hi[d] = 0.5f;
+    }
+    for (int k = 0; k < 5; ++k) c->skid.w_state[k] = c->skid.w_term[k] = 1.0f;
+  }
   c->P = cfg->dim_p > 0 ? cfg->dim_p : 1;
   c->D = c->H * c->da;
   c->n0 = cfg->shard_offset;
@@ -533,6 +550,7 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
   TRY(d2d(c, c->ctr_dev, src->ctr_dev, 4 * sizeof(uint32_t)));
   c->mu_aliased = src->mu_aliased;
   c->have_sample = src->have_sample;
+  c->skid = src->skid;
   if (src->grid_bits) {
     const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
     TRY(dalloc(&c->grid_bits, words));
@@ -709,6 +727,7 @@ struct SampleOpts {
   int eps_base_mode;
   int update_a_mat;
   const float *costs_in;   // device [S][N]: skip the rollouts and use these costs (stage-wise phi)
+  bool costs_own;          // costs_in came from a first pass of this very sample (stored-states / skid-steer forms)
   bool want_actions, want_states, want_omega;
   bool store_f16;          // states / actions are stored as binary16 (DUST_STORE_F16)
   int merge_prior;         // a prior pass ran just before: fold its partials into grad_pri / score
@@ -855,6 +874,7 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
   a.a_mat = c->a_mat;
   a.costsT = c->costsT;
   a.costs_in = o.costs_in;
+  a.costs_own = o.costs_own ? 1 : 0;
   a.grad_lik = c->grad_lik;
   a.logl = c->logl;
   a.eta = c->eta;
@@ -955,6 +975,47 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
   int nt;
   size_t lds;
   TRY(rollout_args(c, o, a, &nt, &lds));
+  if (c->cfg.model == DUST_MODEL_SKID_STEER) {
+    // pass 1 (skid.hpp): rollouts + costs (+ states); pass 2 (below): the regular kernel in its injected-costs mode
+    if (a.noise_f16 || o.store_f16) return fail(DUST_ERR_UNSUPPORTED, "binary16 storage is not implemented for the skid-steer family");
+    if (a.mw) return fail(DUST_ERR_UNSUPPORTED, "sigma-point weights are not implemented for the skid-steer family");
+    if (o.costs_in == nullptr) {
+      Prof ps(c, DUST_K_ROLLOUT_STATES);
+      SkidArgs k;
+      memset(&k, 0, sizeof k);
+      k.sk = c->skid;
+      k.N_total = c->N;
+      k.n0 = c->n0;
+      k.n_local = c->nloc;
+      k.S = c->S;
+      k.M = c->M;
+      k.H = c->H;
+      k.D = c->D;
+      k.P = c->P;
+      k.noise_mode = a.noise_mode;
+      k.log_space = c->cfg.params_log_space;
+      k.interleave = c->cfg.params_interleave;
+      k.dt = (float)c->cfg.dt;
+      k.chol_a[0] = a.chol_a[0];
+      k.chol_a[1] = a.chol_a[1];
+      k.seed = a.seed;
+      k.ctr = a.ctr;
+      k.noise = a.noise;
+      k.theta = a.theta;
+      k.state = a.state;
+      k.params = a.params;
+      k.costs_sn = c->costs_stage;
+      k.costsT = c->costsT;
+      k.states_out = a.states_out;
+      const int nthr = c->nloc * c->S;
+      skid_rollout_kernel<<<(nthr + 255) / 256, 256, 0, c->stream>>>(k);
+      HIP_TRY(hipGetLastError());
+      o.want_states = false;
+      o.costs_in = c->costs_stage;
+      o.costs_own = true;
+      TRY(rollout_args(c, o, a, &nt, &lds));
+    }
+  }
   {
     int gw;
     size_t lds_s;
@@ -979,6 +1040,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       }
       o.want_states = false;
       o.costs_in = c->costs_stage;
+      o.costs_own = true;
       TRY(rollout_args(c, o, a, &nt, &lds));
     } else if (states_whole_lines_pend(c, o, a, &lds_s)) {
       {
@@ -996,6 +1058,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       }
       o.want_states = false;
       o.costs_in = c->costs_stage;
+      o.costs_own = true;
       TRY(rollout_args(c, o, a, &nt, &lds));
     }
   }
@@ -1041,7 +1104,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
 }
 
 struct StateWord {
-  float v[4];
+  float v[8];
 };
 __global__ void set_state_kernel(float *dst, const StateWord w) { dst[threadIdx.x] = w.v[threadIdx.x]; }
 
@@ -1050,8 +1113,8 @@ static int upload_state_params(dust_ctx *c, const float *state, const float *par
     // the 16-byte plant state travels as a kernel ARGUMENT of a 4-lane launch (the runtime copies arguments at launch
     // time: nothing to keep alive, no host wait); measured 2 us on the stream against 4 us for a 16-byte hipMemcpyAsync
     StateWord w;
-    for (int k = 0; k < 4; ++k) w.v[k] = k < c->ds ? state[k] : 0.f;
-    set_state_kernel<<<1, 4, 0, c->stream>>>(c->state_dev, w);
+    for (int k = 0; k < 8; ++k) w.v[k] = k < c->ds ? state[k] : 0.f;
+    set_state_kernel<<<1, 8, 0, c->stream>>>(c->state_dev, w);
     HIP_TRY(hipGetLastError());
   }
   if (c->cfg.dim_p > 0 && c->M >= 1) {
@@ -1514,6 +1577,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
 // Fused prior pass + rollout kernel (fused.hpp).  Returns DUST_OK with *done = false when the shape does not qualify.
 static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
+  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
   if (off || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
   FusedArgs f;
@@ -1855,6 +1919,7 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
 // the caller runs the two-launch form.
 static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool *done) {
   *done = false;
+  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_ITER") != nullptr;  // development switches
   if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -2227,6 +2292,7 @@ static int tick_occupancy(size_t lds, int *occ) {
 
 static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
+  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;  // development switches (read per call)
   if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -2400,6 +2466,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 // *done stays false when the shape / configuration does not qualify (persist.hpp's form or the launch-per-iteration path run).
 static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
+  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return DUST_OK;  // development switches (read per call)
   if (c->prof || c->nloc != c->N || c->theta_pinned || c->capturing || !c->mu_aliased) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -2791,6 +2858,32 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
     c->t2_replays++;
   }
   *replayed = true;
+  return DUST_OK;
+}
+
+extern "C" int dust_set_skid_steer(dust_ctx *c, const dust_skid_config *g) {
+  if (!c || !g) return fail(DUST_ERR_INVALID, "null argument");
+  if (c->cfg.model != DUST_MODEL_SKID_STEER) return fail(DUST_ERR_STATE, "the context's model is not DUST_MODEL_SKID_STEER");
+  const dust_param *ps[3] = {&g->x_icr, &g->wheel_radius, &g->axial_distance};
+  for (const dust_param *p : ps) {
+    if (p->kind < 0 || p->kind > DUST_PARAM_TENSOR0D) return fail(DUST_ERR_INVALID, "bad parameter kind %d", p->kind);
+    if (p->kind == DUST_PARAM_SAMPLED && (p->column < 0 || p->column >= c->P)) return fail(DUST_ERR_INVALID, "sampled parameter column %d outside dim_p = %d", p->column, c->P);
+  }
+  c->skid.x_icr = dev_param(g->x_icr);
+  c->skid.wheel_radius = dev_param(g->wheel_radius);
+  c->skid.axial_distance = dev_param(g->axial_distance);
+  for (int d = 0; d < 2; ++d) {
+    if (!(g->min_wheel_speed[d] <= g->max_wheel_speed[d])) return fail(DUST_ERR_INVALID, "wheel speed bounds: min > max");
+    c->skid.lo[d] = g->min_wheel_speed[d];
+    c->skid.hi[d] = g->max_wheel_speed[d];
+    c->skid.w_ctrl[d] = g->w_ctrl[d];
+  }
+  for (int k = 0; k < 5; ++k) {
+    c->skid.goal[k] = g->goal[k];
+    c->skid.w_state[k] = g->w_state[k];
+    c->skid.w_term[k] = g->w_term[k];
+  }
+  if (c->graph_exec) graph_drop(c);  // (the captured kernel arguments hold the old model)
   return DUST_OK;
 }
 

@@ -69,6 +69,8 @@ struct RolloutArgs {
   float *a_mat;         // [N_total][D]
   float *costsT;        // [N_total][S]
   const float *costs_in; // [S][N_total] or nullptr: stage-wise mode (SVMPC.phi with a user log_p): skip the rollouts
+  int costs_own;         // costs_in holds THIS sample's costs (a first pass of the same call rolled them out: rollout_states.hpp,
+                         // skid.hpp): the likelihood record (logl, eta) is refreshed as after a one-pass sample
   float *grad_lik;      // [N_total][D]
   float *grad_pri;      // [N_total][D] (merge_prior)
   float *score;         // [N_total][D] (merge_prior)
@@ -582,7 +584,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const float *wom = same_w ? cst : omg;
   if (f_omegaT)
     for (int s = tid; s < S; s += nt) f_omegaT[(size_t)n * S + s] = wom[s] / zo;
-  if (tid == 0 && !f_costs_in) {
+  if (tid == 0 && (!f_costs_in || a.costs_own)) {
     if (a.lik == DUST_LIK_EXP_UTILITY)  // likelihoods.py:127-135
       a.logl[n] = ((-cmin * a.alpha) + logf(zw)) - logf((float)S);
     else  // likelihoods.py:113-119

@@ -146,9 +146,9 @@ class Particle(BaseModel):
 
 
 class SkidSteerRobot(BaseModel):
-    """dust/models/skid_steer_robot.py:9-122 (Kozlowski & Pazderski's simplified kinematic model).  Plant-side only: the reference
-    ships no cost family and no demo for it, so there is no rollout kernel family - handing it to MultiDISCO raises.  State
-    (x, y, theta, v, omega), action (right, left) wheel speeds [rot/s]."""
+    """dust/models/skid_steer_robot.py:9-122 (Kozlowski & Pazderski's simplified kinematic model).  State (x, y, theta, v, omega),
+    action (right, left) wheel speeds [rot/s].  The reference ships no cost family and no demo for it; batched rollouts run on the
+    device (csrc/skid.hpp) with `dust_amd.costs.QuadraticCost` as the cost family; `step` below is the plant-side host form."""
 
     family = "skid_steer"
 

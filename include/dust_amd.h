@@ -38,9 +38,9 @@ enum dust_status {
   DUST_ERR_STATE = 5 /* call order (e.g. phi before any likelihood sample) */
 };
 
-enum dust_model { DUST_MODEL_PENDULUM = 0, DUST_MODEL_PARTICLE = 1 };
+enum dust_model { DUST_MODEL_PENDULUM = 0, DUST_MODEL_PARTICLE = 1, DUST_MODEL_SKID_STEER = 2 };
 /* cost families: pendulum demo cost (demo/pendulum_example.py:21-28), Particle.default_*_cost (particle.py:170-225) */
-enum dust_cost { DUST_COST_PENDULUM_QUADCOS = 0, DUST_COST_PARTICLE_DEFAULT = 1 };
+enum dust_cost { DUST_COST_PENDULUM_QUADCOS = 0, DUST_COST_PARTICLE_DEFAULT = 1, DUST_COST_QUADRATIC = 2 };
 /* K1: gpytorch RBFKernel semantics, lengthscale ln 2 (svmpc.py:76-83); K2: iid_mp(RBF) per-dimension median bandwidth
  * (svmpc.py:64-74, composite_kernels.py:33-64); K2_SHARED: indep_controls=False; IMQ: new, no reference. */
 enum dust_kernel { DUST_KERNEL_K1_RBF = 0, DUST_KERNEL_K2_IIDMP = 1, DUST_KERNEL_K2_SHARED = 2, DUST_KERNEL_IMQ = 3 };
@@ -107,6 +107,18 @@ typedef struct dust_config {
   float target[4], w_state[4], w_term[4], w_ctrl[2], w_obs;
 } dust_config;
 
+/* SkidSteerRobot (dust/models/skid_steer_robot.py:19-52, step :73-122; model = DUST_MODEL_SKID_STEER, dim_s = 5: x, y, theta, v,
+ * omega; dim_a = 2: right / left wheel speed) with the quadratic cost family DUST_COST_QUADRATIC - the reference ships no cost for
+ * this model, its MultiDISCO takes any callable (disco.py:294-346); the family is what dust_amd.costs.QuadraticCost evaluates:
+ *   inst(x, a) = sum_k w_state[k] (x_k - goal_k)^2 + sum_d w_ctrl[d] a_d^2 ,   term(x) = sum_k w_term[k] (x_k - goal_k)^2 .
+ * dust_create gives the reference's constructor defaults; dust_set_skid_steer replaces them.  Sampled parameters
+ * (kind DUST_PARAM_SAMPLED) name columns of the `params` rows in the order of `uncertain_params`. */
+typedef struct dust_skid_config {
+  dust_param x_icr, wheel_radius, axial_distance;
+  float min_wheel_speed[2], max_wheel_speed[2]; /* action_space bounds: the step clamps the wheel speeds to them */
+  float goal[5], w_state[5], w_term[5], w_ctrl[2];
+} dust_skid_config;
+
 typedef struct dust_ctx dust_ctx;
 typedef struct dust_mpf dust_mpf;
 
@@ -132,6 +144,7 @@ int dust_set_model_param(dust_ctx *ctx, const char *name, double value, int kind
  * combination with `w[n_params]` (utf.py loc_weights; the reference's (sigma, step) weight pattern is reproduced) instead
  * of the mean.  NULL switches back to the mean over sampled parameters. */
 int dust_set_param_weights(dust_ctx *ctx, const float *w);
+int dust_set_skid_steer(dust_ctx *ctx, const dust_skid_config *cfg);
 /* ObstacleMap occupancy grid [nx][ny] (obstacle_map.py:13-43); offsets are the map centre in cells */
 int dust_set_grid(dust_ctx *ctx, const float *grid, int nx, int ny, float off_x, float off_y);
 

@@ -347,6 +347,26 @@ class Oracle:
         lib().orc_gmm_log_prob(C.c_int(x.shape[0]), C.c_int(means.shape[0]), C.c_int(x.shape[1]), _p(x), _p(means), C.c_float(bw), _p(out))
         return out
 
+    # -- skid-steer family (f.4)
+    @staticmethod
+    def skid_rollout_cost(state, actions, params=None, uncertain_params=(), x_icr=0.2, wheel_radius=0.0625, axial_distance=0.475, dt=0.05,
+                          lo=(-0.5, -0.5), hi=(0.5, 0.5), goal=(0, 0, 0, 0, 0), w_state=(1, 1, 1, 1, 1), w_term=(1, 1, 1, 1, 1), w_ctrl=(0, 0),
+                          log_space=False, interleave=False, want_states=False):
+        """SkidSteerRobot rollouts + the quadratic cost family: costs [S][N] (and states [M][S][N][H+1][5])."""
+        actions = _f(actions)
+        S, N, H = actions.shape[:3]
+        names = ("x_icr", "wheel_radius", "axial_distance")
+        cols = (C.c_int * 3)(*[list(uncertain_params).index(k) if k in uncertain_params else -1 for k in names])
+        dflt = (C.c_double * 3)(x_icr, wheel_radius, axial_distance)
+        pr = None if params is None else _f(params)
+        M, P = (1, 0) if pr is None else pr.shape
+        costs = np.empty((S, N), np.float32)
+        st = np.empty((M, S, N, H + 1, 5), np.float32) if want_states else None
+        lib().orc_skid_rollout_cost(C.c_int(N), C.c_int(S), C.c_int(M), C.c_int(H), C.c_int(P), _p(_f(state)), _p(actions), _p(pr), dflt, cols,
+                                    C.c_int(int(log_space)), C.c_int(int(interleave)), C.c_double(dt), _p(_f(lo)), _p(_f(hi)), _p(_f(goal)),
+                                    _p(_f(w_state)), _p(_f(w_term)), _p(_f(w_ctrl)), _p(costs), _p(st))
+        return (costs, st) if want_states else costs
+
     # -- whole tick (cpu_baseline timing)
     def tick_k1(self, state, theta, mu, mix, sigma_p, sigma_a, eps, n_iters, alpha, lr, a_mat):
         c = self.c

@@ -873,3 +873,72 @@ void orc_tick_k1(const orc_cfg *c, const float *state, float *theta, float *mu, 
   free(logmix);
   free(zero_seq);
 }
+
+/* ------------------------------------------------------------------ skid-steer family
+ * SkidSteerRobot.step skid_steer_robot.py:73-122 under MultiDISCO._rollout / _compute_cost (disco.py:139-209, 294-346) with the
+ * quadratic cost family of dust_amd.costs.QuadraticCost (the reference ships no cost for this model; its controller takes any
+ * callable): inst(x, a) = sum_k w_state[k] (x_k - goal_k)^2 + sum_d w_ctrl[d] a_d^2 on the state BEFORE the action and the raw
+ * action, term(x) = sum_k w_term[k] (x_k - goal_k)^2.  fp32 operation order of the reference's tensor expressions; cos / sin in
+ * double rounded to fp32 (torch's are <= 1 ulp).  cols[3]: column of `params` for (x_icr, wheel_radius, axial_distance) or -1. */
+void orc_skid_rollout_cost(int N, int S, int M, int H, int P, const float *state /* [5] */, const float *actions /* [S][N][H][2] */,
+                           const float *params /* [M][P] or NULL */, const double *defaults /* [3] */, const int *cols /* [3] */,
+                           int log_space, int interleave, double dt, const float *lo, const float *hi, const float *goal,
+                           const float *w_state, const float *w_term, const float *w_ctrl, float *costs /* [S][N] */,
+                           float *states /* [M][S][N][H+1][5] or NULL */) {
+  const float dtf = (float)dt, pif = (float)M_PI;
+  for (int s = 0; s < S; ++s)
+    for (int n = 0; n < N; ++n) {
+      const float *act = actions + ((size_t)s * N + n) * H * 2;
+      double acc = 0.0;
+      for (int m = 0; m < M; ++m) {
+        const int mi = interleave ? (int)((((long)m * S + s) * N + n) % M) : m;
+        float pv[3];
+        for (int q = 0; q < 3; ++q) {
+          if (cols[q] >= 0 && params) {
+            float v = params[(size_t)mi * P + cols[q]];
+            pv[q] = log_space ? expf(v) : v;
+          } else {
+            pv[q] = (float)defaults[q];
+          }
+        }
+        const float xicr = pv[0], wr = pv[1], ad = pv[2];
+        float x[5];
+        for (int k = 0; k < 5; ++k) x[k] = state[k];
+        float *so = states ? states + ((((size_t)m * S + s) * N + n) * (size_t)(H + 1)) * 5 : NULL;
+        if (so)
+          for (int k = 0; k < 5; ++k) so[k] = x[k];
+        double tot = 0.0;
+        for (int t = 0; t < H; ++t) {
+          const float a0 = act[2 * t], a1 = act[2 * t + 1];
+          double sc = 0.0;
+          for (int k = 0; k < 5; ++k) {
+            float d = x[k] - goal[k];
+            sc += (double)((d * d) * w_state[k]);
+          }
+          double cc = (double)((a0 * a0) * w_ctrl[0]) + (double)((a1 * a1) * w_ctrl[1]);
+          tot += (double)((float)sc + (float)cc);
+          float r = clampf(a0, lo[0], hi[0]), l = clampf(a1, lo[1], hi[1]);
+          float lin = ((r + l) * pif) * wr;
+          float ang = ((((r - l) * 2.0f) * pif) * wr) / ad;
+          float fwd = lin * dtf, lat = ((-ang) * xicr) * dtf;
+          float cs = (float)cos((double)x[2]), sn = (float)sin((double)x[2]);
+          float nx = (x[0] + fwd * cs) - lat * sn;
+          float ny = (x[1] + fwd * sn) + lat * cs;
+          x[2] = x[2] + ang * dtf;
+          x[0] = nx;
+          x[1] = ny;
+          x[3] = lin;
+          x[4] = ang;
+          if (so)
+            for (int k = 0; k < 5; ++k) so[(size_t)(t + 1) * 5 + k] = x[k];
+        }
+        double tc = 0.0;
+        for (int k = 0; k < 5; ++k) {
+          float d = x[k] - goal[k];
+          tc += (double)((d * d) * w_term[k]);
+        }
+        acc += (double)((float)tot + (float)tc);
+      }
+      costs[(size_t)s * N + n] = M == 1 ? (float)acc : (float)(acc / M);
+    }
+}

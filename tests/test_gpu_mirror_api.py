@@ -483,3 +483,34 @@ def test_particle_episode_vs_reference_driver(golden, tag):
             assert int(np.argmax(rec["p_weights"][k])) == int(np.argmax(ref_pw)), k
             assert np.abs(rec["p_weights"][k] - ref_pw).max() < 5e-3, k  # exp of O(1e3) log-weights (tests/test_gpu_parity.py)
             assert elemerr(rec["a_seq"][k], g["a_seq"][k]) < 2e-3, k
+
+
+def test_skid_steer_through_the_mirror_classes(golden):
+    """`MultiDISCO(...).forward(state, SkidSteerRobot(...), ext_actions=...)` with `QuadraticCost` as the cost callables -
+    the call the reference's controller accepts (disco.py:348-394) - against the reference's own result; an opaque callable raises."""
+    import torch
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.costs import QuadraticCost
+    from dust_amd.models import SkidSteerRobot
+
+    g = golden("skid_nominal")
+    N, H, S = int(g["N"]), int(g["H"]), int(g["S"])
+    model = SkidSteerRobot(delta_t=float(g["dt"]))
+    cost = QuadraticCost(g["goal"], g["w_state"], g["w_term"], g["w_ctrl"])
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=float(g["temperature"]), ctrl_penalty=1.0,
+                      a_cov=float(g["sigma_a"]) ** 2 * torch.eye(2), inst_cost_fn=cost.inst_cost, term_cost_fn=cost.term_cost, params_sampling=None)
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    costs, states, actions, omega, _ = ctrl.forward(torch.tensor(g["state"]), model, None, ext_actions=torch.tensor(g["ext_actions"]))
+    assert elemerr(costs.numpy(), g["costs"]) < 1e-5
+    assert np.abs(states.numpy() - g["states"]).max() < 1e-5 * max(1.0, np.abs(g["states"]).max())
+    assert relerr(ctrl.a_mat.numpy(), g["a_mat1"]) < 1e-4
+    # the host-side cost object evaluates the same family (what a user would hand to the reference)
+    x = torch.tensor(g["states"][0, :, :, :-1].reshape(-1, 5))
+    a = torch.tensor(g["ext_actions"].reshape(-1, 2))
+    tot = cost.inst_cost(x, a).reshape(S, N, H).sum(-1) + cost.term_cost(torch.tensor(g["states"][0, :, :, -1].reshape(-1, 5))).reshape(S, N)
+    assert relerr(tot.numpy(), g["costs"]) < 1e-5
+    bad = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=1.0, a_cov=0.09 * torch.eye(2),
+                     inst_cost_fn=lambda s, a, **k: s.sum(-1), term_cost_fn=lambda s, **k: s.sum(-1), params_sampling=None)
+    with pytest.raises(NotImplementedError):
+        bad.forward(torch.tensor(g["state"]), model, None, ext_actions=torch.tensor(g["ext_actions"]))

@@ -1162,3 +1162,77 @@ def test_mpf_initial_prior_from_bw_silverman(golden, name):
     assert relerr(mp.prior.log_prob(torch.tensor(g["probe"])).numpy(), g["probe_log_prob1"]) < TOL  # isotropic again (mpf.py:85)
     grads2, _ = mp.optimize(torch.tensor(g["action2"]), torch.tensor(g["obs2"]), bw=bw, n_steps=n)
     assert relerr(mp.x.numpy(), g["x_final2"]) < 2 * tol_x and relerr(grads2.numpy(), g["grad_norms2"]) < 2e-4
+
+
+def _skid_ctx(g, N, S, M, H, up=(), **kw):
+    from dust_amd import Context
+
+    return Context(model="skid_steer", N=N, S=S, M=M, H=H, dt=float(g["dt"]), sigma_a=float(g["sigma_a"]), sigma_p=float(g["sigma_a"]),
+                   uncertain_params=up or None, params_log_space=bool(int(g["params_log_space"])), goal=g["goal"], w_quad_state=g["w_state"],
+                   w_quad_term=g["w_term"], w_quad_ctrl=g["w_ctrl"], **kw)
+
+
+@pytest.mark.parametrize("name", ["skid_nominal", "skid_params", "skid_params_log"])
+def test_skid_steer_family_vs_reference(golden, name):
+    """the skid-steer rollout family on the device (csrc/skid.hpp + the regular kernel's weights stage) against the
+    reference's own MultiDISCO.forward on SkidSteerRobot with the quadratic cost: costs, all states, omega, the a_mat update, a_mix."""
+    g = golden(name)
+    N, H, S, M = int(g["N"]), int(g["H"]), int(g["S"]), int(g["M"])
+    up = ("x_icr", "wheel_radius") if "params" in g else ()
+    temp = float(g["temperature"])
+    c = _skid_ctx(g, N, S, M, H, up, temperature=temp, alpha=1.0 / temp)
+    c.set_a_mat(g["a_mat0"])
+    costs, states, _, omega = c.disco_forward(g["state"], g["ext_actions"], params=g["params"] if up else None, want_states=True)
+    assert elemerr(costs, g["costs"]) < TOL
+    assert np.abs(states - g["states"]).max() < 1e-5 * max(1.0, np.abs(g["states"]).max())
+    assert relerr(omega, g["omega"]) < 2e-4
+    assert relerr(c.get_a_mat(), g["a_mat1"]) < 1e-4
+    assert relerr(c.get_a_mix(), g["a_mix"]) < 2e-4
+    c.close()
+
+
+def test_skid_steer_svmpc_ticks_vs_oracle(golden):
+    """Whole SVGD-MPC ticks on the skid-steer family (launch-per-iteration path): caller-supplied noise and sampled parameters
+    against the oracle's composition (skid rollouts -> score -> K1 phi -> SGD -> forward); the device Philox draws fetched as actions
+    and replayed through the oracle; a clone continues identically."""
+    from oracle import Oracle
+
+    g = golden("skid_params")
+    N, S, H, M, K = 12, 32, 10, 3, 2
+    rng = np.random.default_rng(3)
+    up = ("x_icr", "wheel_radius")
+    sig, lr, alpha = 0.3, 0.05, 0.5
+    mu = (0.2 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    theta = (mu + 0.1 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    state = g["state"]
+    c = _skid_ctx(g, N, S, M, H, up, kernel="K1", lr=lr, alpha=alpha, seed=9)
+    c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+    eps = rng.standard_normal((K, S, N, H, 2)).astype(np.float32)
+    params = np.stack([rng.uniform([0.1, 0.05], [0.3, 0.08], (M, 2)) for _ in range(K)]).astype(np.float32)
+    a_seq, pw = c.svmpc_tick(state, K, eps=eps, params=params)
+    assert c.tick_stats()["tick2"] == 0 and c.tick_stats()["tick1"] == 0
+    o = Oracle(model="particle", N=N, S=S, M=1, H=H)  # (score / phi / forward do not touch the model)
+    sg = np.full(2, sig, np.float32)
+    kw = dict(uncertain_params=up, dt=float(g["dt"]), goal=g["goal"], w_state=g["w_state"], w_term=g["w_term"], w_ctrl=g["w_ctrl"])
+    th, mix = theta.copy(), np.ones(N, np.float32)
+    for k in range(K):
+        actions = o.sample_actions(th, eps[k], sg)
+        costs = Oracle.skid_rollout_cost(state, actions, params=params[k], **kw)
+        if k == K - 1:
+            assert elemerr(c.get_costs(), costs) < TOL
+        _, _, sc = o.score(th, mu, mix, sg, costs, actions, alpha, sg)
+        th = o.sgd(th, o.phi_k1(th, sc), lr)
+    r = o.forward(costs, th, mu, mix, sg, alpha)
+    assert elemerr(c.get_theta(), r["theta"]) < 1e-4
+    assert np.abs(pw - r["p_weights"]).max() < 2e-3
+    # device Philox noise: fetch the draws as actions, replay the rollouts through the oracle
+    cc = c.clone()
+    costs_dev, actions = c.likelihood_sample(state, None, params[0], want_actions=True)
+    assert elemerr(costs_dev, Oracle.skid_rollout_cost(state, actions, params=params[0], **kw)) < TOL
+    z = (actions - c.get_theta()[None]) / sig
+    assert abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1.0) < 0.05
+    a1, p1 = c.svmpc_tick(state, 2, params=params)
+    cc.likelihood_sample(state, None, params[0])  # (the same stream position as c)
+    a2, p2 = cc.svmpc_tick(state, 2, params=params)
+    assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
+    c.close(); cc.close()

@@ -39,10 +39,12 @@ def _run(N, S, M, H, can_crash, with_obstacle, poison=None, state=None, seed=0):
             c.profile(True)
             costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True)
             used = "states_kernel" in c.profile_get()
+            amix = c.get_a_mix()
             c.close()
         finally:
             os.environ.pop("DUST_STATES_FORM", None)
         out[form] = (costs, states, omega, used)
+        out[form + "_amix"] = amix
     return ref_costs, ref_states, out
 
 
@@ -62,6 +64,9 @@ def test_whole_line_states_vs_oracle_and_staged_kernel(N, S, M, H, can_crash, wi
     assert np.array_equal(states, states0)  # every byte of every line, heads and tails included
     assert np.array_equal(costs, costs0)
     assert np.array_equal(omega, omega0)
+    # the two-pass form hands its costs to the regular kernel: the likelihood record (a_mix = softmax(eta), disco.py:393) must be
+    # refreshed as after a one-pass sample (round 3: it was left stale)
+    assert np.allclose(out["1_amix"], out["0_amix"], rtol=1e-4, atol=1e-7) and abs(float(out["1_amix"].sum()) - 1.0) < 1e-4
 
 
 def test_whole_line_states_general_path_on_nan_action():

@@ -285,3 +285,20 @@ def test_mpf_initial_prior_from_bw_silverman(golden, name):
     if name == "mpf_bwvec":  # a scalar prior bandwidth must NOT reproduce the reference here
         bad = o.mpf_phi(g["x0"], g["x0"], float(bwv[0]), g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), False, bw)
         assert relerr(bad, g["phi0"]) > 100 * TOL
+
+
+@pytest.mark.parametrize("name", ["skid_nominal", "skid_params", "skid_params_log"])
+def test_skid_steer_rollouts_vs_reference(golden, name):
+    """SkidSteerRobot.step (skid_steer_robot.py:73-122) under MultiDISCO._rollout / _compute_cost with a quadratic cost:
+    the oracle's restatement against the reference's own MultiDISCO.forward - costs and every state of every rollout, nominal
+    parameters, sampled (x_icr, wheel_radius) and log-space samples; ~20 % of the actions are clamped by the step."""
+    from oracle import Oracle
+
+    g = golden(name)
+    up = ("x_icr", "wheel_radius") if "params" in g else ()
+    costs, states = Oracle.skid_rollout_cost(g["state"], g["ext_actions"], params=g["params"] if up else None, uncertain_params=up, dt=float(g["dt"]),
+                                             goal=g["goal"], w_state=g["w_state"], w_term=g["w_term"], w_ctrl=g["w_ctrl"],
+                                             log_space=bool(int(g["params_log_space"])), want_states=True)
+    assert float(g["clamped_fraction"]) > 0.1
+    assert relerr(costs, g["costs"]) < TOL
+    assert np.abs(states - g["states"]).max() < 1e-5 * max(1.0, np.abs(g["states"]).max())
