@@ -2755,18 +2755,54 @@ extern "C" int dust_comm_probe(dust_ctx *c, int n_steps, int reps, double *us_pe
 // + update of the rank's rows -> all-gather(theta) (the prior means alias theta: the next prior pass needs every rank's new
 // particles) ... -> local log-weights -> all-gather -> finalize + roll of ALL rows (strategy "resample": roll of the rank's rows ->
 // all-gather(theta)).  Kernels and collectives share the context's stream: no host synchronisation inside the tick.
+// The particle all-gather of iteration k runs on the side stream UNDER the rollouts of iteration k + 1, which read only the rank's own
+// rows (an in-place all-gather writes the other ranks' rows of the same buffer); the prior pass - the first consumer of the other
+// ranks' particles - waits for it.  Collectives of one communicator never overlap each other: the particle gather starts after the
+// update (which follows the score gather) and the next score gather follows the prior pass that waited for it.  After the LAST
+// iteration nothing local is left to run beside the gather (forward's log p needs every particle), so it stays on the main stream.
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags) {
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
   TRY(upload_state_params(c, state, params, n_steps));
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
   const size_t shard = (size_t)c->nloc * c->D;
+  const bool overlap = !c->prof && c->stream2 && !getenv("DUST_NO_COMM_OVERLAP");  // (development switch)
+  bool gather_in_flight = false;
   for (int k = 0; k < n_steps; ++k) {
     const float *nd = nullptr;
     TRY(stage_noise(c, eps ? eps + (size_t)k * slice : nullptr, flags, &nd));
-    TRY(local_score_device(c, nd, k));
+    if (gather_in_flight) {
+      // rollouts first (own rows only, no merge of prior partials), then the prior pass once every rank's particles have landed
+      SampleOpts o;
+      memset(&o, 0, sizeof o);
+      o.noise_mode = nd ? NOISE_EPS : NOISE_PHILOX;
+      o.noise_dev = nd;
+      o.base = c->theta;
+      o.update_a_mat = 1;
+      o.bump_adam = 1;
+      float *save = c->params_dev;
+      if (c->params_dev) c->params_dev += (size_t)k * c->M * c->P;
+      const int st = launch_rollout(c, o);
+      c->params_dev = save;
+      TRY(st);
+      c->have_sample = true;
+      HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      gather_in_flight = false;
+      TRY(launch_prior(c));
+      TRY(launch_prior_finish(c, true, false));
+    } else {
+      TRY(local_score_device(c, nd, k));
+    }
     TRY(gather_inplace(c, c->score, shard));
     TRY(launch_stein_update(c, 1));
-    TRY(gather_inplace(c, c->theta, shard));
+    if (overlap && k + 1 < n_steps) {
+      HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      TRY(rccl::check(rccl::all_gather(c->theta + (size_t)c->comm_rank * shard, c->theta, shard, rccl::ncclFloat32, c->comm, c->stream2), "ncclAllGather"));
+      HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+      gather_in_flight = true;
+    } else {
+      TRY(gather_inplace(c, c->theta, shard));
+    }
   }
   return DUST_OK;
 }

@@ -336,6 +336,8 @@ extern "C" int dust_mpf_create(const dust_mpf_config *cfg, const float *init_par
   if (cfg->n_particles < 1 || cfg->n_particles > 1024) return fail(DUST_ERR_UNSUPPORTED, "MPF supports 1..1024 particles (one workgroup)");
   if (cfg->dim_p < 1 || cfg->dim_p > 4) return fail(DUST_ERR_INVALID, "dim_p must be 1..4");
   if (!(cfg->init_bw > 0.f)) return fail(DUST_ERR_INVALID, "init_bw must be > 0 (the host layer evaluates bw_silverman)");
+  if (cfg->model_cfg.model != DUST_MODEL_PENDULUM && cfg->model_cfg.model != DUST_MODEL_PARTICLE)
+    return fail(DUST_ERR_UNSUPPORTED, "MPF's one-step prediction and its Jacobian exist for the Pendulum and Particle models only");
   if (!(cfg->obs_std > 0.f)) return fail(DUST_ERR_INVALID, "obs_std must be > 0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DUST_ERR_NO_DEVICE, "no HIP device: libdust_amd has no CPU fallback");
