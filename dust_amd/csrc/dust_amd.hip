@@ -92,6 +92,7 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  unsigned long persist_declined;  // key of the (shape, state) for which the one-launch ticks last declined: no staging for it again
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
   float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
   size_t nzf_cap;
@@ -2651,6 +2652,14 @@ static int load() {
     all_gather = nullptr;
     return fail(DUST_ERR_UNSUPPORTED, "librccl.so lacks the NCCL entry points");
   }
+  // the binding assumes the NCCL 2.x ABI (ncclFloat32 = 7, a 128-byte ncclUniqueId passed by value)
+  if (int (*get_version)(int *) = (int (*)(int *))dlsym(handle, "ncclGetVersion")) {
+    int v = 0;
+    if (get_version(&v) == 0 && v > 0 && (v < 20000 ? v / 1000 : v / 10000) != 2) {
+      all_gather = nullptr;
+      return fail(DUST_ERR_UNSUPPORTED, "RCCL reports version code %d: the binding is written against the NCCL 2.x ABI", v);
+    }
+  }
   return DUST_OK;
 }
 static int check(int r, const char *what) {
@@ -2824,8 +2833,13 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
   const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;
   if (off || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
-  if (c->N > 4096 || c->D > 64 || pair_is_big(c)) return DUST_OK;
+  if (c->N > 4096 || c->D > 64 || pair_is_big(c) || c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  // The launchers decide eligibility (slice counts, occupancy, rollout form ...) only after the inputs are staged; what they decline
+  // is static for a context in a given state, so a decline is remembered and the same call is not staged twice again
+  const unsigned long key = 1ul + (unsigned long)n_steps * 16ul + (do_forward ? 8ul : 0ul) + (c->mu_aliased ? 4ul : 0ul) + (eps ? 2ul : 0ul) +
+                            (c->have_sample ? 1ul : 0ul) * 1000003ul;
+  if (c->persist_declined == key) return DUST_OK;
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, nullptr, params, n_steps));
   const float *eps_dev = eps;
@@ -2838,7 +2852,9 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
   }
   TRY(launch_tick2(c, state, n_steps, eps_dev, do_forward, done));
   if (*done) return DUST_OK;
-  return launch_tick(c, state, n_steps, eps_dev, do_forward, done);
+  TRY(launch_tick(c, state, n_steps, eps_dev, do_forward, done));
+  if (!*done) c->persist_declined = key;
+  return DUST_OK;
 }
 
 // a_seq / p_weights of the tick (or forward) just enqueued -> host: ONE device-to-host copy into pinned memory and ONE stream
