@@ -299,7 +299,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *gpl = lds + T2_L_GP, *rpart = lds + T2_L_RP;
   float *dsl = lds + L.dsl;
   float *wpart = lds + T2_L_WPART;
-  float *kpart = lds + T2_L_KPART;
   float *scl = lds + T2_L_SCL;
   unsigned int *cnt_start = f->cnt;
   unsigned int *cnt_theta = f->cnt + (size_t)1 * T2_NSH * T2_CNT_STRIDE;
@@ -729,27 +728,27 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     wg_sync();  // B4
     f = t2_args();
     T2_TL(0, 16 * k + 10);
-    // ================= phase 5: sum_j k_ij s_j (P waves stream the score rows) =================
-    if (wave >= 8) {
-      const int pw = wave - 8, u = lane >> 2, c = lane & 3;
+    // ================= phase 5: sum_j k_ij s_j (all 16 waves stream the score rows) =================
+    {  // (the R waves have drawn their noise in phase 4 and would idle here: 16 waves instead of the 8 P waves, -1.1 us per tick)
+      const int pw = wave, u = lane >> 2, c = lane & 3;
       const __amdgpu_buffer_rsrc_t rsq = t2_rsrc(f->sq + (size_t)k * N * T2_ROW, N * T2_ROW);
       v2f acc[T2_PW][4];
 #pragma unroll
       for (int q = 0; q < T2_PW; ++q)
 #pragma unroll
         for (int h = 0; h < 4; ++h) acc[q][h] = v2f{0.f, 0.f};
-      constexpr int NB = 8;  // steps per chunk (f->steps / 2 is a multiple of 8): 16 loads = every row of a 1024-key set in flight at once
-      for (int t0 = 0; t0 < f->steps / 2; t0 += NB) {
+      constexpr int NB = 4;
+      for (int t0 = 0; t0 < f->steps / 4; t0 += NB) {
         v4f sa[NB], sb[NB];
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-          const int j = min(((t0 + p) * 8 + pw) * 16 + u, N - 1);
+          const int j = min(((t0 + p) * 16 + pw) * 16 + u, N - 1);
           sa[p] = t2_ld16(rsq, (j * T2_ROW + 8 * c) * 4);
           sb[p] = t2_ld16(rsq, (j * T2_ROW + 8 * c + 4) * 4);
         }
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-          const int j = ((t0 + p) * 8 + pw) * 16 + u;
+          const int j = ((t0 + p) * 16 + pw) * 16 + u;
           const float4 kq = *reinterpret_cast<const float4 *>(&ksl[(size_t)j * 4]);  // (keys past N hold k = 0)
           const v2f sv[4] = {{sa[p][0], sa[p][1]}, {sa[p][2], sa[p][3]}, {sb[p][0], sb[p][1]}, {sb[p][2], sb[p][3]}};
           const float kk[T2_PW] = {kq.x, kq.y, kq.z, kq.w};
@@ -770,8 +769,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           v[q * 8 + 2 * h + 1] = acc[q][h].y;
         }
       reduce_u16<32>(v, r2, lane);
+      float *kp16 = lds + T2_L_WPART;  // (the weighted-sum partials are dead by now: [16 waves][32][4] fits their 2 x 4 x 8 x 32 floats)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) kpart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + c] = r2[i];
+      for (int i = 0; i < 2; ++i) kp16[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + c] = r2[i];
     }
     wg_sync();  // B5
     f = t2_args();
@@ -779,8 +779,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     // ================= phase 6: phi, optimiser step, theta rows out (waves 8-9) =================
     if (isown) {
       float sa = 0.f;
+      {
+        const float *kp16 = lds + T2_L_WPART;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) sa += kpart[(w * 32 + op * 8 + (od & 7)) * 4 + (od >> 3)];
+        for (int w = 0; w < 16; ++w) sa += kp16[(w * 32 + op * 8 + (od & 7)) * 4 + (od >> 3)];
+      }
+
       float sb = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) sb += rpart[(((op >> 1) * 4 + w) * 16 + (op & 1) * 8 + (od & 7)) * 4 + (od >> 3)];
