@@ -374,11 +374,13 @@ def main():
         if rank == 0 and (n_gpus > 1 or os.environ.get("DUST_BENCH_FORCE_DIST")):
             one = Context(**dict(common))
             one.set_theta(theta); one.set_prior(mu); one.set_a_mat(theta)
-            for _ in range(3):
+            # (the same number of warm-up and timed ticks as the sharded run: the particle set - and with it the share of exactly-zero
+            #  kernel blocks the fused pairwise pass can skip - evolves with the ticks, so the two rates must be taken at the same age)
+            for _ in range(n_warm):
                 one.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
             one.sync()
             t1 = time.perf_counter()
-            n1 = 10
+            n1 = args.steps
             for _ in range(n1):
                 one.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
             one.sync()

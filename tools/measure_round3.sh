@@ -30,3 +30,11 @@ timeout 100 tools/_allgather_probe > $O/allgather_probe.txt 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq
 find $O/stats -name "*kernel_trace*" -delete
 tail -c 1200 $O/bench_driver_cmd.json; head -6 $O/stats/*/b_kernel_stats.csv 2>/dev/null | cut -c1-160 || find $O/stats -name "*kernel_stats.csv" | head
+# --- appended: cfg4 sharding projection, world-1 forced-collective bench, pair probe, sparsity, states probe
+cd $R
+timeout 600 python tools/shard_time.py cfg4 > $O/shard_time.txt 2>&1
+timeout 300 python tools/states_probe.py > $O/states_probe.txt 2>&1
+timeout 300 python tools/kernel_sparsity.py > $O/kernel_sparsity.txt 2>&1
+timeout 300 python tools/pair_probe.py cfg4 > $O/pair_probe.txt 2>&1
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 DUST_BENCH_FORCE_DIST=1 timeout 400 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline > $O/sharded_world1_bench.json 2> $O/sharded_world1_bench.err
+tail -3 $O/shard_time.txt; tail -c 600 $O/sharded_world1_bench.json

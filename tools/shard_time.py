@@ -49,7 +49,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
         th = (mu + rng.standard_normal((N, H, 2))).astype(np.float32)
         sh = DeviceShard(cfg, 0, G, use_torch_stream=False)
         sh.set_state(th, th)
-        sh.ctx.svmpc_update_prior(np.full(N, 1.0 / N, np.float32))  # the prior means alias theta, as after every forward()
+        # the prior means alias theta, as after every forward(): one rank-local forward (a sharded context refreshes its prior there)
+        sh.local_score(np.array([-9.0, -9.0, 0.0, 0.0], np.float32), params=(1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32))
+        sh.apply_phi()
+        sh.forward_local()
+        sh.forward_finish()
         state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
         params = (1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
         for rep in range(2):
