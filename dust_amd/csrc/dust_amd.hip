@@ -11,6 +11,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
 
 #include "bandwidth.hpp"
 #include "common.hpp"
@@ -341,13 +343,53 @@ static void comm_release(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
 static int sharded_forward(dust_ctx *c);
 
+// One-launch ticks (persist.hpp, tick2.hpp) spin on their own workgroups: every workgroup of the launch must be resident.  Two contexts
+// of ONE process ticking on the same device from two threads would interleave their grids (tick2.hpp then aborts and replays - late
+// but correct; persist.hpp has no such protocol and would time out).  So as soon as a second context lives on a device, the one-launch
+// kernels of that device are chained across streams with an event: launch k + 1 waits for launch k, whichever context issued it.  A
+// single context (the common case, the bench) pays nothing.  Other PROCESSES on the device remain tick2.hpp's start barrier's business.
+enum { DUST_MAX_DEV = 64 };
+static std::atomic<int> g_live_ctx[DUST_MAX_DEV];
+static std::mutex g_persist_mu[DUST_MAX_DEV];
+static hipEvent_t g_persist_ev[DUST_MAX_DEV];
+static hipStream_t g_persist_last[DUST_MAX_DEV];
+struct PersistChain {  // RAII around ONE one-launch kernel launch on c->stream
+  dust_ctx *c;
+  int dev;
+  bool on;
+  explicit PersistChain(dust_ctx *c_);
+  ~PersistChain();
+};
+
 extern "C" void dust_destroy(dust_ctx *c) {
   if (!c) return;
+  if (c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV) g_live_ctx[c->cfg.device].fetch_sub(1);
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   comm_release(c);
   free_all(c);
   delete c;
+}
+
+PersistChain::PersistChain(dust_ctx *c_) : c(c_), dev(c_->cfg.device), on(false) {
+  static const bool off = getenv("DUST_NO_CHAIN") != nullptr;  // development switch
+  if (off || dev < 0 || dev >= DUST_MAX_DEV || g_live_ctx[dev].load() < 2) return;
+  g_persist_mu[dev].lock();
+  on = true;
+  if (!g_persist_ev[dev] && hipEventCreateWithFlags(&g_persist_ev[dev], hipEventDisableTiming) != hipSuccess) {
+    g_persist_ev[dev] = nullptr;
+    (void)hipGetLastError();
+    return;
+  }
+  if (g_persist_last[dev] && g_persist_last[dev] != c->stream) (void)hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0);
+}
+PersistChain::~PersistChain() {
+  if (!on) return;
+  if (g_persist_ev[dev]) {
+    (void)hipEventRecord(g_persist_ev[dev], c->stream);
+    g_persist_last[dev] = c->stream;
+  }
+  g_persist_mu[dev].unlock();
 }
 
 static int create_impl(const dust_config *cfg, dust_ctx **out) {
@@ -445,6 +487,8 @@ extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
   if (!out) return fail(DUST_ERR_INVALID, "null out");
   *out = nullptr;
   int s = create_impl(cfg, out);
+  if (s == DUST_OK && cfg->device >= 0 && cfg->device < DUST_MAX_DEV && g_live_ctx[cfg->device].fetch_add(1) + 1 == 2)
+    (void)hipDeviceSynchronize();  // a second tenant: one-launch kernels are chained from here on (PersistChain); none may be in flight unchained
   if (s != DUST_OK && *out) {
     std::string keep = g_err;
     free_all(*out);
@@ -1621,6 +1665,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   do {                                                                                                                                  \
     if (lds > 64 * 1024 && !c->capturing)                                                                                               \
       HIP_TRY(hipFuncSetAttribute((const void *)fused_prior_rollout_kernel<MODEL, CPT, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    PersistChain chain(c);                                                                                                              \
     fused_prior_rollout_kernel<MODEL, CPT, GR><<<grid, PAIR_NT, lds, c->stream>>>(f);                                                  \
   } while (0)
 #define DUST_LAUNCH_FUSED(MODEL, CPT)                   \
@@ -1793,7 +1838,11 @@ static int launch_stein_update(dust_ctx *c, int apply) {
       f.cnt = c->stein_cnt;
       f.timeout_flag = c->stein_cnt + ((size_t)tiles + 1) * CNT_STRIDE;
       const int grid = f.n_pair_blocks + (n + PAIR_NT - 1) / PAIR_NT;
-#define DUST_LAUNCH_SU(MODE, CPT) stein_update_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
+#define DUST_LAUNCH_SU(MODE, CPT)                                            \
+  do {                                                                        \
+    PersistChain chain(c);                                                    \
+    stein_update_kernel<MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f);     \
+  } while (0)
       if (c->cfg.kernel == DUST_KERNEL_IMQ) {
         if (cpt == 4) DUST_LAUNCH_SU(PAIR_IMQ, 4);
         else DUST_LAUNCH_SU(PAIR_IMQ, 8);
@@ -2012,7 +2061,11 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   f.tl = c->tl_dev;
   const int n = c->nloc * c->D;
   const int grid = 2 * f.n_pair_blocks + f.n_roll_blocks + (n + PAIR_NT - 1) / PAIR_NT;
-#define DUST_LAUNCH_ITER(MODEL, MODE, CPT) svgd_iter_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
+#define DUST_LAUNCH_ITER(MODEL, MODE, CPT)                                          \
+  do {                                                                              \
+    PersistChain chain(c);                                                          \
+    svgd_iter_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f);       \
+  } while (0)
 #define DUST_PICK_ITER(MODEL)                                       \
   do {                                                              \
     if (c->cfg.kernel == DUST_KERNEL_IMQ) {                         \
@@ -2445,11 +2498,14 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
       else DUST_LAUNCH_TICK(MODEL, PAIR_K1, 8);                     \
     }                                                               \
   } while (0)
-  if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_TICK(DUST_MODEL_PENDULUM);
-  else DUST_PICK_TICK(DUST_MODEL_PARTICLE);
+  {
+    PersistChain chain(c);
+    if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_TICK(DUST_MODEL_PENDULUM);
+    else DUST_PICK_TICK(DUST_MODEL_PARTICLE);
+    HIP_TRY(hipGetLastError());
+  }
 #undef DUST_PICK_TICK
 #undef DUST_LAUNCH_TICK
-  HIP_TRY(hipGetLastError());
   c->n_tick1++;
   c->tick_set ^= 1;
   if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
@@ -2600,7 +2656,10 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   f.zero_base = c->t2_cnt + (size_t)(1 - c->t2_set) * T2_SETS * T2_CNT_STRIDE;
   f.status = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
   f.tl = c->tl_dev;
-  HIP_TRY((hipError_t)tick2_launch(f, c->cfg.model, mode, grid, lds, c->stream));
+  {
+    PersistChain chain(c);
+    HIP_TRY((hipError_t)tick2_launch(f, c->cfg.model, mode, grid, lds, c->stream));
+  }
   c->t2_set ^= 1;
   c->n_tick2++;
   c->t2_inflight = true;
@@ -2980,8 +3039,11 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     }
   }
   static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
+  // (a second context on the device: the in-launch hand-off kernels are chained across streams at every launch - PersistChain - which a
+  //  replayed capture would not be)
+  const bool tenants = c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV && g_live_ctx[c->cfg.device].load() >= 2;
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
-                         c->mu_aliased && c->own_stream;
+                         c->mu_aliased && c->own_stream && !tenants;
   if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || c->graph_flags != flags ||
       (c->graph_exec && c->graph_theta != c->theta)) {
     if (c->graph_exec) graph_drop(c);

@@ -62,9 +62,9 @@ enum {
   T2_L_PPART = T2_L_MISC + 192,               // [8 waves][32 sums][4 column groups] partials of the prior pass
   T2_L_GP = T2_L_PPART + 8 * 32 * 4,          // [4][32] grad_pri
   T2_L_RP = T2_L_GP + T2_PW * T2_ROW,         // [8 waves][16 sums][4 column groups] partials of the Stein repulsion
-  T2_L_WPART = T2_L_RP + 8 * 16 * 4,          // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update)
-  T2_L_KPART = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [8 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
-  T2_L_SCL = T2_L_KPART + 8 * 32 * 4,         // [4][32] score rows on their way out
+  T2_L_WPART = T2_L_RP + 8 * 16 * 4,          // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update); after barrier B4 the
+                                              // same 2 048 floats hold [16 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
+  T2_L_SCL = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [4][32] score rows on their way out
   T2_L_COEFS = T2_L_SCL + T2_PW * T2_ROW,     // [T2_MAXM][2] dynamics coefficients of the iteration
   T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | dsl | grid | tile
 };

@@ -223,35 +223,47 @@ def test_tick2_aborted_ticks_are_replayed():
         assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
 
 
-def test_two_contexts_tick_concurrently():
-    """Two contexts on one device ticking from two host threads: each needs its 256 workgroups co-resident, so
-    some launches find the device taken.  No tick may be lost or fail: every call returns, results stay finite and normalised, and
-    tick2 + replayed account for every tick."""
+@pytest.mark.parametrize("env", [{}, {"DUST_NO_TICK2": "1"}, {"DUST_NO_PERSIST": "1"}], ids=["tick2", "tiled-tick", "launch-per-iteration"])
+def test_contexts_tick_concurrently(env):
+    """Three contexts on one device ticking from three host threads.  Every one-launch form spins on its own
+    workgroups and needs them co-resident; with a second context on the device the library chains those launches across the
+    contexts' streams (and the owner-computes tick additionally proves residency at its start and is replayed otherwise).  No
+    tick may be lost or fail: every call returns, results stay finite and normalised.  All three tick forms: the owner-computes
+    kernel, the tiled one-launch kernel (also every context's FIRST tick), the launch-per-iteration forms with in-launch hand-offs."""
     import threading
 
-    N, S, H, T = 1024, 128, 30, 150
+    N, S, H, T, C = 1024, 128, 30, 120, 3
     st = _state("pendulum")
-    ctxs = [_make("pendulum", N, S, H, seed=s)[0] for s in (0, 1)]
-    errs, stats = [], [None, None]
+    saved = {k: os.environ.pop(k, None) for k in ("DUST_NO_TICK2", "DUST_NO_PERSIST")}
+    os.environ.update(env)
+    try:
+        ctxs = [_make("pendulum", N, S, H, seed=s)[0] for s in range(C)]
+        errs, stats = [], [None] * C
 
-    def run(i):
-        try:
-            c = ctxs[i]
-            for t in range(T):
-                a_seq, pw = c.svmpc_tick(st, 5)
-                assert np.isfinite(a_seq).all() and abs(float(pw.sum()) - 1.0) < 1e-3, (i, t)
-            stats[i] = c.tick_stats()
-        except Exception as e:  # noqa: BLE001
-            errs.append((i, repr(e)))
+        def run(i):
+            try:
+                c = ctxs[i]
+                for t in range(T):
+                    a_seq, pw = c.svmpc_tick(st, 5)
+                    assert np.isfinite(a_seq).all() and abs(float(pw.sum()) - 1.0) < 1e-3, (i, t)
+                stats[i] = c.tick_stats()
+            except Exception as e:  # noqa: BLE001
+                errs.append((i, repr(e)))
 
-    th = [threading.Thread(target=run, args=(i,)) for i in (0, 1)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errs, errs
-    for i in (0, 1):
-        assert stats[i]["tick2"] == T - 1, stats[i]
-        assert np.isfinite(ctxs[i].get_theta()).all()
-        ctxs[i].close()
-    print("replayed ticks:", stats[0]["replayed"], stats[1]["replayed"])
+        th = [threading.Thread(target=run, args=(i,)) for i in range(C)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(C):
+            if not env:
+                assert stats[i]["tick2"] == T - 1, stats[i]
+            assert np.isfinite(ctxs[i].get_theta()).all()
+            ctxs[i].close()
+        print("replayed ticks:", [s["replayed"] for s in stats])
+    finally:
+        for k in ("DUST_NO_TICK2", "DUST_NO_PERSIST"):
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
