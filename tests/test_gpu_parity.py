@@ -1241,3 +1241,38 @@ def test_skid_steer_svmpc_ticks_vs_oracle(golden):
     a2, p2 = cc.svmpc_tick(state, 2, params=params)
     assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
     c.close(); cc.close()
+
+
+def test_skid_steer_sharded_equals_unsharded(golden):
+    """The skid-steer family under particle sharding (2 and 4 sharded contexts in one process, all-gathers as slice copies): its
+    rollout kernel takes (shard offset, local count) like every other kernel."""
+    from dust_amd.parallel import DeviceShard, LocalComm, tick
+
+    g = golden("skid_params")
+    N, S, H, M, K, T = 64, 32, 10, 3, 2, 2
+    rng = np.random.default_rng(5)
+    up = ("x_icr", "wheel_radius")
+    mu = (0.2 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    th = (mu + 0.1 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    state = g["state"]
+    eps = rng.standard_normal((T, K, S, N, H, 2)).astype(np.float32)
+    params = np.stack([[rng.uniform([0.1, 0.05], [0.3, 0.08], (M, 2)) for _ in range(K)] for _ in range(T)]).astype(np.float32)
+    kw = dict(model="skid_steer", N=N, S=S, M=M, H=H, dt=float(g["dt"]), sigma_a=0.3, sigma_p=0.3, uncertain_params=up, goal=g["goal"],
+              w_quad_state=g["w_state"], w_quad_term=g["w_term"], w_quad_ctrl=g["w_ctrl"], kernel="K1", lr=0.05, alpha=0.5, seed=11)
+    ref = _skid_ctx(g, N, S, M, H, up, kernel="K1", lr=0.05, alpha=0.5, seed=11)
+    ref.set_theta(th); ref.set_prior(mu); ref.set_a_mat(th)
+    outs = [ref.svmpc_tick(state, K, eps[t], params[t]) for t in range(T)]
+    rt = ref.get_theta()
+    for world in (2, 4):
+        shards = tuple(DeviceShard(dict(kw), r, world) for r in range(world))
+        for sh in shards:
+            sh.set_state(th, mu, th)
+        for t in range(T):
+            a_seq, pw = tick(shards, LocalComm(), state, K, eps[t], params[t], want_outputs=True, final_gather=(world == 2))
+            assert np.array_equal(a_seq, outs[t][0]), (world, t)
+            assert relerr(pw, outs[t][1]) < 1e-5
+        for sh in shards:
+            sh.sync()
+            assert elemerr(sh.ctx.get_theta(), rt) < 2e-6, (world, sh.rank)
+            sh.ctx.close()
+    ref.close()
