@@ -6,7 +6,7 @@
 N = 1 (the contract's workload): BASELINE.json configs[1] - Pendulum, 1024 Stein particles, S=128 action samples, M=1, H=30,
 5 SVGD iterations per tick, gpytorch-RBF ("K1") kernel, SGD lr 2, fp32, synthetic seeded inputs resident in HBM.  One "step" =
 one control tick = SVMPC.optimize(5 iterations) + SVMPC.forward (weights, argmax, roll, prior refresh): ONE persistent kernel
-launch (dust_amd/csrc/tick2.hpp; the first tick of a context, whose prior does not alias the particles yet, runs persist.hpp).  Policy noise is drawn on the device inside the timed region (Philox, in registers) - the
+launch (dust_amd/csrc/tick2.hpp; the first tick of a context, whose prior does not alias the particles yet, runs plain kernels).  Policy noise is drawn on the device inside the timed region (Philox, in registers) - the
 reference also draws its noise inside the tick - so no work is skipped.  `value` is the open-loop rate (ticks enqueued back to
 back, plant state constant); `closed_loop_ticks_per_s` is the rate when every tick's first action is read back (one pinned
 device-to-host copy + one stream synchronisation), stepped through a host plant model and fed to the next tick - the loop order

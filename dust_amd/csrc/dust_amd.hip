@@ -94,6 +94,7 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  bool no_handoff;           // replay of a tick that found the device shared: plain kernels only, nothing that spins on its own grid
   unsigned long persist_declined;  // key of the (shape, state) for which the one-launch ticks last declined: no staging for it again
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
   float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
@@ -341,6 +342,7 @@ static void free_all(dust_ctx *c) {
 static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || getenv("DUST_COMM_FORCE") != nullptr); }
 static void comm_release(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
+static bool tick2_shape_ok(dust_ctx *c, int n_steps);
 static int sharded_forward(dust_ctx *c);
 
 // One-launch ticks (persist.hpp, tick2.hpp) spin on their own workgroups: every workgroup of the launch must be resident.  Two contexts
@@ -1624,7 +1626,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
-  if (off || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
+  if (off || c->no_handoff || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
   FusedArgs f;
   memset(&f, 0, sizeof f);
   int nt;
@@ -1809,7 +1811,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     static const bool no_fuse = getenv("DUST_NO_FUSE") != nullptr;  // development switch
     const int cpt = cpt_for(a.D);
     const size_t lds = pairwise_lds_bytes(PAIR_K1, cpt);
-    bool fuse = apply && !c->prof && !no_fuse && cpt <= 8 && !pair_is_big(c);  // D <= 64: >= 2 workgroups per CU co-resident
+    bool fuse = apply && !c->prof && !c->no_handoff && !no_fuse && cpt <= 8 && !pair_is_big(c);  // D <= 64: >= 2 workgroups per CU co-resident
     if (fuse && (!c->stein_cnt || c->stein_tiles != tiles)) {
       if (c->capturing) fuse = false;
       else {
@@ -1971,7 +1973,7 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_ITER") != nullptr;  // development switches
-  if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
+  if (off || c->no_handoff || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   const int cpt = cpt_for(c->D);
   if (cpt > 8) return DUST_OK;
@@ -2521,6 +2523,26 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 // ---------------------------------------------------------------------------------------------------------------
 // One launch per control tick, owner-computes form (tick2.hpp): two all-to-all hand-offs per SVGD iteration instead of four.
 // *done stays false when the shape / configuration does not qualify (persist.hpp's form or the launch-per-iteration path run).
+// the static part of launch_tick2's eligibility (everything but "the prior means alias the particles")
+static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
+  if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return false;
+  if (c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 1) return false;
+  if (c->cfg.model != DUST_MODEL_PENDULUM && c->cfg.model != DUST_MODEL_PARTICLE) return false;
+  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return false;
+  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE || c->cfg.a_reg != 0.0f || c->mw_dev) return false;
+  if (c->N % T2_PW || c->D > T2_ROW || c->N / T2_PW > device_cus(c) || c->M > T2_MAXM) return false;
+  for (int d = 1; d < c->da; ++d)
+    if (c->cfg.sigma_p[d] != c->cfg.sigma_p[0]) return false;
+  const int steps = (((c->N + 63) / 64) + 15) & ~15;
+  int gw = 0;
+  if (c->cfg.model == DUST_MODEL_PARTICLE && c->cfg.with_obstacle && c->grid_bits) {
+    const int words = (c->nx * c->ny + 31) / 32;
+    if (words > 4096) return false;
+    gw = (words + 3) & ~3;
+  }
+  return (size_t)tick2_lds(c->S, c->D, steps, gw).total * sizeof(float) <= 160 * 1024;
+}
+
 static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
@@ -2890,7 +2912,7 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
                           bool *done) {
   *done = false;
   const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;
-  if (off || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
+  if (off || c->no_handoff || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (c->N > 4096 || c->D > 64 || pair_is_big(c) || c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
@@ -2958,16 +2980,22 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
   if (!n) return DUST_OK;
   if (!c->t2_replayable)
     return fail(DUST_ERR_HIP, "%u control tick(s) with caller-supplied noise did not start (device shared with another context): repeat them", n);
-  for (unsigned int i = 0; i < n; ++i) {
-    TRY(upload_state_params(c, c->t2_state, nullptr, c->t2_steps));
+  // (the device is shared - that is why the tick did not start - so the replay uses plain kernels only: the fused launch forms spin on
+  //  their own workgroups too and could meet the same tenant)
+  c->no_handoff = true;
+  int st = DUST_OK;
+  for (unsigned int i = 0; i < n && st == DUST_OK; ++i) {
+    st = upload_state_params(c, c->t2_state, nullptr, c->t2_steps);
     c->noise_f16 = false;
-    for (int k = 0; k < c->t2_steps; ++k) TRY(step_device(c, nullptr, k));
-    if (c->t2_fwd) {
-      TRY(forward_device(c));
-      TRY(forward_finish_device(c));
+    for (int k = 0; k < c->t2_steps && st == DUST_OK; ++k) st = step_device(c, nullptr, k);
+    if (c->t2_fwd && st == DUST_OK) {
+      st = forward_device(c);
+      if (st == DUST_OK) st = forward_finish_device(c);
     }
-    c->t2_replays++;
+    if (st == DUST_OK) c->t2_replays++;
   }
+  c->no_handoff = false;
+  TRY(st);
   *replayed = true;
   return DUST_OK;
 }
@@ -3027,6 +3055,20 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(sharded_steps(c, state, n_steps, eps, params, flags));
     TRY(sharded_forward(c));
+    if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+    return DUST_OK;
+  }
+  // The FIRST tick of a context whose later ticks the owner-computes kernel will serve (tick2.hpp needs the prior means aliased to the
+  // particles, which this tick's forward establishes): plain kernels, nothing that spins on its own grid.  The tiled one-launch kernel
+  // would serve it 0.4 ms faster - once per context - but has no residency proof: with another process on the device it would time
+  // out; from the second tick on tick2.hpp's start barrier covers that case.
+  if (!c->mu_aliased && tick2_shape_ok(c, n_steps)) {
+    c->no_handoff = true;
+    int st = dust_svmpc_optimize(c, state, n_steps, eps, params, flags);
+    if (st == DUST_OK) st = forward_device(c);
+    if (st == DUST_OK) st = forward_finish_device(c);
+    c->no_handoff = false;
+    TRY(st);
     if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
     return DUST_OK;
   }
