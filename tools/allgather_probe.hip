@@ -7,6 +7,8 @@
 //   2  plain loads after an agent-scope acquire (buffer_inv sc1) by every wave
 //   3  form 0 with the row order rotated per workgroup (no two CUs stream the same lines at the same time)
 //   4  nothing read (hop only: publish + counter + poll + barrier)
+//   5  DATA-POLLED: no counter, no polling wave - all 16 waves load their pieces (sc1) right after publishing and re-load the pieces whose
+//      generation tag (first word) is not this round's yet
 //   hipcc --offload-arch=gfx950 -O3 tools/allgather_probe.hip -o tools/_allgather_probe && tools/_allgather_probe
 #include <hip/hip_runtime.h>
 
@@ -43,11 +45,13 @@ __global__ __launch_bounds__(1024, 4) void probe(float *buf0, float *buf1, unsig
         v4f v = {(float)(r + 1), (float)row, 1.f, 2.f};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (row * 32 + 4 * (lane & 7)) * 4, 0, 16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)(b % NSH) * STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (FORM != 5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)(b % NSH) * STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-    if (wave == 10 && lane < NSH) {
+    if (FORM != 5 && wave == 10 && lane < NSH) {
       const unsigned int target = (unsigned int)(NWG / NSH) * 2u * (unsigned int)(r + 1);
       while ((int)(__hip_atomic_load(cnt + (size_t)lane * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
     }
@@ -71,6 +75,23 @@ __global__ __launch_bounds__(1024, 4) void probe(float *buf0, float *buf1, unsig
       v4f sv[8];
 #pragma unroll
       for (int p = 0; p < 8; ++p) sv[p] = ld16<16>(rs, ((((p * 16 + wave) * 8 + u) * 32) + 4 * c) * 4);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc += sv[p];
+    } else if (FORM == 5) {
+      v4f sv[8];
+      const float tag = (float)(r + 1);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) sv[p] = ld16<16>(rs, ((((p * 16 + wave) * 8 + u) * 32) + 4 * c) * 4);
+      for (int tries = 0; tries < 100000; ++tries) {
+        bool miss = false;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) miss |= sv[p][0] != tag;
+        if (!__any(miss)) break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          if (sv[p][0] != tag) sv[p] = ld16<16>(rs, ((((p * 16 + wave) * 8 + u) * 32) + 4 * c) * 4);
+      }
 #pragma unroll
       for (int p = 0; p < 8; ++p) acc += sv[p];
     } else if (FORM == 2) {
@@ -268,6 +289,7 @@ int main() {
   run<1>("sc1 loads, 16 waves x 8 steps");
   run<2>("agent acquire + plain loads, 16 waves x 8 steps");
   run<3>("sc1 loads, 8 waves x 16 steps, rotated per workgroup");
+  run<5>("DATA-POLLED sc1 loads, 16 waves x 8 steps, no counter");
   run_stream<1, false>("stream 16 steps x 2 KB per wave, 1 step in flight");
   run_stream<2, false>("stream, 2 steps in flight");
   run_stream<2, true>("stream, 2 steps in flight, lines touched first");
