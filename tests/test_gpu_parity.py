@@ -644,14 +644,30 @@ def test_k2_bandwidth_is_the_exact_order_statistic(N):
     c.set_a_mat(theta)
     c.svmpc_optimize(np.array([3.0, 0.0], np.float32), 1)
     h = c.get_bandwidths()
-    c.close()
-    X = theta.reshape(N, H)
+
+    def exact(X):
+        out = []
+        for d in range(H):
+            x = X[:, d]
+            pw = (x[:, None] - x[None, :]) ** 2  # fp32, as the sorted-coordinate kernel forms it
+            v = np.partition(pw.ravel(), (N * N - 1) // 2)[(N * N - 1) // 2]
+            out.append(max(np.float32(v) / np.float32(np.log(N + 1.0)), np.float32(1e-5)))
+        return out
+
+    ref = exact(theta.reshape(N, H))
     for d in range(H):
-        x = X[:, d]
-        pw = (x[:, None] - x[None, :]) ** 2  # fp32, as the sorted-coordinate kernel forms it
-        v = np.partition(pw.ravel(), (N * N - 1) // 2)[(N * N - 1) // 2]
-        ref = max(np.float32(v) / np.float32(np.log(N + 1.0)), np.float32(1e-5))
-        assert np.float32(h[d]) == np.float32(ref), (d, h[d], ref)
+        assert np.float32(h[d]) == np.float32(ref[d]), (d, h[d], ref[d])
+    # later calls start the bisection from the previous bandwidth (warm start, N <= 1024): nudged particles (the bracket holds),
+    # the same particles again (the answer sits ON the previous value), and a jump (the bracket misses: full range)
+    for scale, shift in ((1.002, 0.0), (1.0, 0.0), (1.7, 0.3)):
+        theta = (theta * np.float32(scale) + np.float32(shift) * rng.standard_normal(theta.shape).astype(np.float32)).astype(np.float32)
+        c.set_theta(theta)
+        c.svmpc_optimize(np.array([3.0, 0.0], np.float32), 1)
+        h = c.get_bandwidths()
+        ref = exact(theta.reshape(N, H))
+        for d in range(H):
+            assert np.float32(h[d]) == np.float32(ref[d]), (scale, d, h[d], ref[d])
+    c.close()
 
 
 @pytest.mark.parametrize("model,N,H,kernel", [("pendulum", 2048, 30, "K1"), ("pendulum", 2200, 17, "IMQ"), ("particle", 2048, 20, "K1"),
