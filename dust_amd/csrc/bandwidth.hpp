@@ -50,23 +50,27 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [npow2]
   __shared__ unsigned redc[16 * 8];
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
-  for (int i = tid; i < npow2; i += nt) xs[i] = i < N ? a.thetaT[(size_t)c * N + i] : INFINITY;
-  wg_sync();
-  for (int k = 2; k <= npow2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npow2; i += nt) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float u = xs[i], v = xs[ixj];
-          const bool up = (i & k) == 0;
-          if ((u > v) == up) {
-            xs[i] = v;
-            xs[ixj] = u;
-          }
+  // bitonic sort, one element per lane (npow2 <= 1024 = blockDim): partners inside a wave (j < 64) are exchanged with a lane
+  // shuffle - no barrier - and only the 10 stages with j >= 64 go through LDS (55 barrier-separated LDS passes before: ~30 of 76 us)
+  {
+    float v = tid < N ? a.thetaT[(size_t)c * N + tid] : INFINITY;
+    for (int k = 2; k <= npow2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        float other;
+        if (j < 64) {
+          other = __shfl_xor(v, j, 64);
+        } else {
+          if (tid < npow2) xs[tid] = v;
+          wg_sync();
+          other = tid < npow2 ? xs[tid ^ j] : v;
+          wg_sync();  // (everyone has read before the next stage overwrites)
         }
+        const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+        v = (lower == up) ? fminf(v, other) : fmaxf(v, other);
       }
-      wg_sync();
-    }
+    if (tid < npow2) xs[tid] = v;
+    wg_sync();
+  }
   const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
   const float span = xs[N - 1] - xs[0];
   unsigned lo = 0u, hi = __float_as_uint(span * span);
@@ -78,9 +82,10 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   const bool has = tid < N;
   const float xi = has ? xs[tid] : 0.f;
   int bl = tid, br = N - 1;
+  int round = 0;
   // Warm start (round 3): between two SVGD iterations the particles move by lr * phi, so the median moves by a fraction of a
   // percent.  a.h[c] still holds the previous bandwidth: two probes at v_prev (1 -+ 2^-7) - if they bracket the rank, the bisection
-  // starts from 2^17 bit patterns instead of 2^31 (17 rounds instead of 31: 76 -> ~50 us per iteration at N = 1024, D = 30); if
+  // starts from 2^17 bit patterns instead of 2^31 (17 rounds instead of 31; the median moves 0.2-0.8 % per iteration at cfg2: +-2^-9 misses too often, +-2^-5 costs two more rounds); if
   // not (first call, a jump), nothing is lost but the two probes.  The answer is the same exact order statistic either way.
   {
     const float hp = a.h[c];
@@ -116,6 +121,8 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
       }
     }
   }
+  if (tid < 24) redc[tid] = 0u;
+  wg_sync();
   while (lo < hi) {
     unsigned mid[NC];
     int b[NC];
@@ -135,26 +142,27 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
       b[c] = l;
       cnt[c] = has ? (unsigned)(l - tid) : 0u;
     }
-    // block sums of the NC counters (2 sum + N <= 2 N^2 < 2^32)
+    // block sums of the NC counters (2 sum + N <= 2 N^2 < 2^32): wave sums, one LDS atomic per wave into the round's slot, ONE barrier
+    // (three slots in rotation: the one re-armed here was last READ before the previous round's barrier, which every wave has passed)
     {
-      const int lane = tid & 63, wid = tid >> 6, nw = (nt + 63) >> 6;
+      const int lane = tid & 63;
+      unsigned *slot = redc + (round % 3) * 8, *other = redc + ((round + 1) % 3) * 8;
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt[c] += __shfl_xor(cnt[c], o, 64);
-      wg_sync();
       if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) redc[wid * 8 + c] = cnt[c];
+        for (int c = 0; c < NC; ++c) atomicAdd(&slot[c], cnt[c]);
+      }
+      if (tid == 64) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) other[c] = 0u;
       }
       wg_sync();
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        unsigned t = lane < nw ? redc[lane * 8 + c] : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        cnt[c] = t;
-      }
+      for (int c = 0; c < NC; ++c) cnt[c] = slot[c];
+      ++round;
     }
     // counts are monotone in the threshold
     unsigned nlo = lo, nhi = hi;
