@@ -94,6 +94,9 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
+  unsigned int *tick1_start;  // {start counter, go word} of the tiled one-launch tick's start barrier (persist.hpp)
+  unsigned int tick1_seq;     // ticks launched through it (the go word's value)
+  bool t2_mu_aliased;        // the prior means aliased the particles BEFORE the last one-launch tick (its replay starts from that state)
   bool no_handoff;           // replay of a tick that found the device shared: plain kernels only, nothing that spins on its own grid
   unsigned long persist_declined;  // key of the (shape, state) for which the one-launch ticks last declined: no staging for it again
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
@@ -326,6 +329,7 @@ static void free_all(dust_ctx *c) {
   if (c->t2_xq) (void)hipFree(c->t2_xq);
   if (c->t2_sq) (void)hipFree(c->t2_sq);
   if (c->t2_lwq) (void)hipFree(c->t2_lwq);
+  if (c->tick1_start) (void)hipFree(c->tick1_start);
   if (c->out_pinned) (void)hipHostFree(c->out_pinned);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
@@ -2428,7 +2432,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
     const size_t nd = (size_t)f.JS * c->nloc * 8 * cpt;
     TRY(ensure(&c->pS, &c->pS_cap, nd));
   }
-  const int lines = 5 * f.tiles + 1;  // + the global log-weight line
+  const int lines = 5 * f.tiles + 1 + 16;  // + the global log-weight line + the 16 arrival lines of the start barrier
   if (!c->tick_cnt || c->tick_tiles != f.tiles) {
     if (c->tick_cnt) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2481,6 +2485,24 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   f.zero_base = c->tick_cnt + (size_t)(1 - c->tick_set) * lines * CNT_STRIDE;
   f.zero_lines = lines;
   f.timeout_flag = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
+  const bool mu_aliased_before = c->mu_aliased;
+  if (do_forward && !getenv("DUST_NO_TICK1_BARRIER")) {  // whole ticks only: an aborted optimize-only call would leave the host's particle-buffer bookkeeping ahead of the device
+    if (!c->tick1_start) {
+      TRY(dalloc(&c->tick1_start, (size_t)CNT_STRIDE));
+      HIP_TRY(hipMemsetAsync(c->tick1_start, 0, (size_t)CNT_STRIDE * sizeof(unsigned int), c->stream));
+      c->tick1_seq = 0u;
+    }
+    c->tick1_seq = (c->tick1_seq + 1u) & 0x7fffffffu;
+    if (c->tick1_seq == 0u) c->tick1_seq = 1u;  // (the go word only has to differ from the previous tick's)
+    f.start_cnt = set + (size_t)(5 * f.tiles + 1) * CNT_STRIDE;
+    f.go = c->tick1_start;
+    f.abort_cnt = f.timeout_flag + 1;
+    f.seq = c->tick1_seq;
+    if (const char *ta = getenv("DUST_TICK1_TEST_ABORT")) {  // test hook, as DUST_TICK2_TEST_ABORT
+      const int every = atoi(ta);
+      f.test_abort = every > 0 && ((c->n_tick1 + 1) % every) == 0;
+    }
+  }
   f.logp = c->logp;
   f.lw = c->lw;
   f.pw = c->pw;
@@ -2510,6 +2532,14 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 #undef DUST_LAUNCH_TICK
   c->n_tick1++;
   c->tick_set ^= 1;
+  if (do_forward && f.start_cnt) {  // replay information (t2_settle): the state this tick started from
+    c->t2_inflight = true;
+    for (int k = 0; k < 4; ++k) c->t2_state[k] = k < c->ds ? state[k] : 0.f;
+    c->t2_steps = n_steps;
+    c->t2_fwd = true;
+    c->t2_replayable = eps_dev == nullptr;
+    c->t2_mu_aliased = mu_aliased_before;
+  }
   if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
   if (do_forward) c->mu_aliased = true;
   c->actions_valid = false;
@@ -2689,6 +2719,7 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   c->t2_steps = n_steps;
   c->t2_fwd = do_forward;
   c->t2_replayable = eps_dev == nullptr;
+  c->t2_mu_aliased = true;
   if (do_forward) c->mu_aliased = true;
   c->actions_valid = false;
   c->have_sample = true;
@@ -2983,6 +3014,7 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
   // (the device is shared - that is why the tick did not start - so the replay uses plain kernels only: the fused launch forms spin on
   //  their own workgroups too and could meet the same tenant)
   c->no_handoff = true;
+  if (!c->t2_mu_aliased) c->mu_aliased = false;  // (a context's first tick: its prior means are still c->mu; the replay's forward aliases them)
   int st = DUST_OK;
   for (unsigned int i = 0; i < n && st == DUST_OK; ++i) {
     st = upload_state_params(c, c->t2_state, nullptr, c->t2_steps);

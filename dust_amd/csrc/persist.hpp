@@ -70,6 +70,13 @@ struct TickArgs {
   unsigned int *zero_base;  // the other set ...
   int zero_lines;           // ... of this many lines
   unsigned int *timeout_flag;
+  // start barrier (round 3; as tick2.hpp's): every workgroup arrives on start_cnt (monotonic: start_target = seq x grid), workgroup 0 waits
+  // a bounded time for all of them and publishes go (seq) or abort (seq | 2^31) in *go; nothing is written before go, so a launch whose
+  // workgroups cannot all be resident leaves the state untouched and the host replays the tick on plain kernels.  nullptr: no barrier.
+  unsigned int *start_cnt, *go, *abort_cnt;  // start_cnt: 16 lines of THIS tick's counter set (workgroup b arrives on line b % 16; re-armed
+                                             // with the set by the next tick) - no running totals, no per-lane index into this block
+  unsigned int seq;
+  int test_abort;
   // forward outputs
   float *logp, *lw, *pw, *a_seq_out, *logmix, *mixw;
   int *istar;
@@ -884,6 +891,57 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svmpc_tick_kernel
   if (__hip_atomic_load(f.timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if (b0 == 0)
     for (int t = threadIdx.x; t < f.zero_lines; t += PAIR_NT) f.zero_base[t * CNT_STRIDE] = 0u;
+  if (f.start_cnt) {  // residency proof (see TickArgs): the other counter set is re-armed above whether or not the tick starts
+    // (arrivals are spread over 16 lines - 1 024 same-address atomics take ~9 us - and the waiters poll `go` sparsely: a thousand lanes
+    //  polling one line every 60 ns starve the arrivals on their way to the same L2)
+    unsigned int &s_go = *reinterpret_cast<unsigned int *>(lds);  // (the roles stage into the dynamic region only after this barrier)
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      if (lane == 0) __hip_atomic_fetch_add(f.start_cnt + (size_t)(b0 & 15) * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned int g = 0u;
+      if (b0 == 0) {
+        bool ok = true;
+        if (lane < 16) {
+          const unsigned int G = gridDim.x, mine = G / 16u + ((unsigned int)lane < G % 16u ? 1u : 0u);
+          const unsigned int target = mine;
+          const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+          while ((int)(__hip_atomic_load(f.start_cnt + (size_t)lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t_start > 20000ull) {  // 200 us
+              ok = false;
+              break;
+            }
+          }
+        }
+        const bool all_ok = __all(ok ? 1 : 0) && !f.test_abort;
+        g = all_ok ? f.seq : (f.seq | 0x80000000u);
+        if (lane == 0) {
+          if (!all_ok) __hip_atomic_fetch_add(f.abort_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(f.go, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (lane == 0) {
+        unsigned int spins = 0u;
+        unsigned long long t0 = 0ull;
+        for (;;) {
+          g = __hip_atomic_load(f.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((g & 0x7fffffffu) == f.seq) break;
+          __builtin_amdgcn_s_sleep(12);
+          if ((++spins & 63u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (!t0) t0 = now;
+            else if (now - t0 > 5000000ull) {  // workgroup 0 never came: give up (reported as a time-out)
+              __hip_atomic_store(f.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              g = f.seq | 0x80000000u;
+              break;
+            }
+          }
+        }
+      }
+      if (lane == 0) s_go = g == f.seq ? 1u : 0u;
+    }
+    wg_sync();
+    if (s_go == 0u) return;
+  }
   if (b0 < f.n_pair_blocks) {
 #ifndef DUST_X_NOPAIR
     tick_pair<MODE, CPT>(f, lds, b0);

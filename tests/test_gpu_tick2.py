@@ -267,3 +267,37 @@ def test_contexts_tick_concurrently(env):
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+
+
+@pytest.mark.parametrize("model,N,S,H,kw", [("pendulum", 256, 128, 30, {}), ("pendulum", 512, 64, 40, {}), ("particle", 128, 64, 24, {})])
+def test_tiled_tick_aborted_ticks_are_replayed(model, N, S, H, kw):
+    """The tiled one-launch tick (persist.hpp) proves residency with the same start barrier as the owner-computes kernel: a tick
+    that does not start changes nothing and is replayed on plain kernels - including a context's FIRST tick, whose prior means do
+    not alias the particles yet.  DUST_TICK1_TEST_ABORT=2 aborts every second launch; DUST_NO_TICK2 keeps every tick on the tiled
+    kernel (shapes 2 and 3 are not the owner-computes kernel's anyway: H d_a > 32)."""
+    st = _state(model)
+    outs = []
+    for env in ({"DUST_TICK1_TEST_ABORT": "2", "DUST_NO_TICK2": "1"}, {"DUST_NO_TICK2": "1"}):
+        saved = {k: os.environ.pop(k, None) for k in ("DUST_TICK1_TEST_ABORT", "DUST_NO_TICK2")}
+        os.environ.update(env)
+        try:
+            c, _ = _make(model, N, S, H, **kw)
+            hist = []
+            for t in range(6):
+                a_seq, pw = c.svmpc_tick(st, 3)
+                hist.append((a_seq.copy(), pw.copy(), c.get_theta()))
+            outs.append((hist, c.tick_stats()))
+            c.close()
+        finally:
+            for k in ("DUST_TICK1_TEST_ABORT", "DUST_NO_TICK2"):
+                os.environ.pop(k, None)
+                if saved[k] is not None:
+                    os.environ[k] = saved[k]
+    (h0, s0), (h1, s1) = outs
+    assert s0["tick1"] == 6 and s0["replayed"] == 3 and s0["tick2"] == 0, s0
+    assert s1["tick1"] == 6 and s1["replayed"] == 0, s1
+    for t in range(3):  # (replayed ticks take the separate prior / Stein tiles: one rounding apart; later ticks amplify)
+        assert elemerr(h0[t][2], h1[t][2]) < 2e-3 * (1 + 4 * t), (t, elemerr(h0[t][2], h1[t][2]))
+        assert np.abs(h0[t][1] - h1[t][1]).max() < 5e-3 * (1 + 4 * t)
+    for t in range(6):
+        assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
