@@ -97,6 +97,7 @@ struct dust_ctx {
   unsigned int *tick1_start;  // {start counter, go word} of the tiled one-launch tick's start barrier (persist.hpp)
   unsigned int tick1_seq;     // ticks launched through it (the go word's value)
   bool t2_mu_aliased;        // the prior means aliased the particles BEFORE the last one-launch tick (its replay starts from that state)
+  bool handoff_banned;       // an in-launch wait timed out once (the device is shared with another process): plain kernels from then on
   bool no_handoff;           // replay of a tick that found the device shared: plain kernels only, nothing that spins on its own grid
   unsigned long persist_declined;  // key of the (shape, state) for which the one-launch ticks last declined: no staging for it again
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
@@ -146,6 +147,8 @@ struct dust_ctx {
   size_t t2_occ_lds;
   unsigned int t2_aborts_seen;  // value of the device-side "did not start" counter already accounted for
   bool t2_inflight;             // a tick2 launch was enqueued since the last check
+  int t2_grid;                  // workgroups of the last tick2 launch
+  bool t2_transactional;        // ... of the owner-computes kernel, which commits nothing when one of its waits gives up
   float t2_state[4];            // inputs of the last tick2 launch (replayed on the launch-per-iteration path if it did not start)
   int t2_steps;
   bool t2_fwd, t2_replayable;
@@ -511,12 +514,40 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
 static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights);
 static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed);
 
+// A wait inside a launch gave up.  The tick it belonged to is lost (its results are invalid and the particles may be partly updated);
+// what can be saved is the future: no kernel of this context spins on its own grid any more (handoff.hpp DUST_SPIN_TIMEOUT_TICKS).
+static void handoff_ban(dust_ctx *c) {
+  c->handoff_banned = true;
+  if (c->graph_exec) graph_drop(c);  // (a captured tick replays the fused launches)
+}
+// A wait of the owner-computes kernel gave up: clear the report, take the context off the spinning kernels, and tell whether the tick
+// is whole - committed by every workgroup or by none (tick2.hpp t2_commit; a tick nobody committed is replayed by t2_settle).
+#define T2_TORN_MSG "persistent tick kernel: a hand-off wait timed out while some workgroups were committing (results of this tick are invalid: re-seed the particles); the device seems to be shared with another process: this context runs plain kernels from here on"
+static int t2_timed_out(dust_ctx *c, bool *whole) {
+  unsigned int w[3] = {0u, 0u, 0u};
+  HIP_TRY(hipMemcpy(w, c->outblk + c->out_floats - 32, sizeof w, hipMemcpyDeviceToHost));
+  const unsigned int zero[3] = {0u, w[1], 0u};
+  HIP_TRY(hipMemcpy(c->outblk + c->out_floats - 32, zero, sizeof zero, hipMemcpyHostToDevice));
+  handoff_ban(c);
+  *whole = c->t2_grid > 0 && (w[2] % (unsigned int)c->t2_grid) == 0u;
+  return DUST_OK;
+}
+static int handoff_timeout(dust_ctx *c, const char *msg) {
+  handoff_ban(c);
+  return fail(DUST_ERR_HIP, "%s", msg);
+}
+
 extern "C" int dust_sync(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->t2_inflight) {  // owner-computes ticks that did not start (device shared with another context) run now, on the other path
     unsigned int w[2] = {0u, 0u};
     HIP_TRY(hipMemcpy(w, c->outblk + c->out_floats - 32, sizeof w, hipMemcpyDeviceToHost));
+    if (w[0] && c->t2_transactional) {  // ... and so do ticks whose waits gave up: tick2.hpp commits nothing then (w[1] counts them too)
+      bool whole = false;
+      TRY(t2_timed_out(c, &whole));
+      if (!whole) return fail(DUST_ERR_HIP, "%s", T2_TORN_MSG);
+    }
     bool replayed = false;
     TRY(t2_settle(c, w[1], &replayed));
     if (replayed) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -529,19 +560,19 @@ extern "C" int dust_sync(dust_ctx *c) {
   if (c->stein_cnt) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) return fail(DUST_ERR_HIP, "Stein+update launch: hand-off spin timed out (results of that tick are invalid)");
+    if (flag) return handoff_timeout(c, "Stein+update launch: hand-off spin timed out (results of that tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
   }
   if (c->iter_cnt) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) return fail(DUST_ERR_HIP, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid)");
+    if (flag) return handoff_timeout(c, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
   }
   if (c->tick_cnt || c->t2_cnt) {
     unsigned int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->outblk + c->out_floats - 32, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
       HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, sizeof flag));  // reported: clear
-      return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid)");
+      return handoff_timeout(c, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
     }
   }
   return DUST_OK;
@@ -1630,7 +1661,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
-  if (off || c->no_handoff || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
+  if (off || c->no_handoff || c->handoff_banned || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
   FusedArgs f;
   memset(&f, 0, sizeof f);
   int nt;
@@ -1815,7 +1846,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
     static const bool no_fuse = getenv("DUST_NO_FUSE") != nullptr;  // development switch
     const int cpt = cpt_for(a.D);
     const size_t lds = pairwise_lds_bytes(PAIR_K1, cpt);
-    bool fuse = apply && !c->prof && !c->no_handoff && !no_fuse && cpt <= 8 && !pair_is_big(c);  // D <= 64: >= 2 workgroups per CU co-resident
+    bool fuse = apply && !c->prof && !c->no_handoff && !c->handoff_banned && !no_fuse && cpt <= 8 && !pair_is_big(c);  // D <= 64: >= 2 workgroups per CU co-resident
     if (fuse && (!c->stein_cnt || c->stein_tiles != tiles)) {
       if (c->capturing) fuse = false;
       else {
@@ -1977,7 +2008,7 @@ static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool 
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_ITER") != nullptr;  // development switches
-  if (off || c->no_handoff || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
+  if (off || c->no_handoff || c->handoff_banned || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   const int cpt = cpt_for(c->D);
   if (cpt > 8) return DUST_OK;
@@ -2534,6 +2565,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   c->tick_set ^= 1;
   if (do_forward && f.start_cnt) {  // replay information (t2_settle): the state this tick started from
     c->t2_inflight = true;
+    c->t2_transactional = false;
     for (int k = 0; k < 4; ++k) c->t2_state[k] = k < c->ds ? state[k] : 0.f;
     c->t2_steps = n_steps;
     c->t2_fwd = true;
@@ -2556,7 +2588,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 // the static part of launch_tick2's eligibility (everything but "the prior means alias the particles")
 static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
   if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return false;
-  if (c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 1) return false;
+  if (c->prof || c->handoff_banned || c->nloc != c->N || c->theta_pinned || n_steps < 1) return false;
   if (c->cfg.model != DUST_MODEL_PENDULUM && c->cfg.model != DUST_MODEL_PARTICLE) return false;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return false;
   if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE || c->cfg.a_reg != 0.0f || c->mw_dev) return false;
@@ -2619,6 +2651,10 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   if (const char *ta = getenv("DUST_TICK2_TEST_ABORT")) {  // test hook: exercises the replay path without a second tenant on the device
     const int every = atoi(ta);
     f.test_abort = every > 0 && ((c->n_tick2 + 1) % every) == 0;
+  }
+  if (const char *ta = getenv("DUST_TICK2_TEST_TIMEOUT")) {  // test hook: a tick whose last wait "gives up" - not committed, replayed, context banned
+    const int every = atoi(ta);
+    if (every > 0 && ((c->n_tick2 + 1) % every) == 0) f.test_abort = 2;
   }
   f.grid_words = c->cfg.model == DUST_MODEL_PARTICLE ? ra.grid_words : 0;
   f.coef_host[0] = ra.coef_host[0];
@@ -2715,6 +2751,8 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   c->t2_set ^= 1;
   c->n_tick2++;
   c->t2_inflight = true;
+  c->t2_transactional = true;
+  c->t2_grid = grid;
   for (int k = 0; k < 4; ++k) c->t2_state[k] = f.x0[k];
   c->t2_steps = n_steps;
   c->t2_fwd = do_forward;
@@ -2943,7 +2981,7 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
                           bool *done) {
   *done = false;
   const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;
-  if (off || c->no_handoff || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
+  if (off || c->no_handoff || c->handoff_banned || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (c->N > 4096 || c->D > 64 || pair_is_big(c) || c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
@@ -2983,17 +3021,29 @@ static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights) {
       HIP_TRY(hipMemcpyAsync(lf + 2, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const unsigned int *st = reinterpret_cast<const unsigned int *>(c->out_pinned + c->out_floats - 32);
-    if (st[0]) {
+    if (st[0] && c->t2_inflight && c->t2_transactional) {  // the owner-computes kernel commits nothing when a wait gave up (tick2.hpp COMMIT): replayed below
+      bool whole = false;
+      TRY(t2_timed_out(c, &whole));
+      if (!whole) {
+        c->t2_inflight = false;
+        return fail(DUST_ERR_HIP, "%s", T2_TORN_MSG);
+      }
+    } else if (st[0]) {
       HIP_TRY(hipMemset(c->outblk + c->out_floats - 32, 0, 4));
       c->t2_inflight = false;
-      return fail(DUST_ERR_HIP, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid)");
+      return handoff_timeout(c, "persistent tick kernel: a hand-off wait timed out (results of this tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
     }
     // an owner-computes tick whose workgroups were not all resident left the state untouched: run it on the other path, read again
     bool replayed = false;
     TRY(t2_settle(c, st[1], &replayed));
     if (!replayed) break;
   }
-  if (lf[0] | lf[1] | lf[2]) return fail(DUST_ERR_HIP, "a fused launch's in-kernel hand-off timed out (results of this tick are invalid)");
+  if (lf[0] | lf[1] | lf[2]) {  // reported once: clear the device words (the kernels that set them are not launched again)
+    if (c->fused_cnt) (void)hipMemsetAsync(c->fused_cnt + (size_t)c->fused_tiles * CNT_STRIDE, 0, 4, c->stream);
+    if (c->stein_cnt) (void)hipMemsetAsync(c->stein_cnt + ((size_t)c->stein_tiles + 1) * CNT_STRIDE, 0, 4, c->stream);
+    if (c->iter_cnt) (void)hipMemsetAsync(c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, 0, 4, c->stream);
+  }
+  if (lf[0] | lf[1] | lf[2]) return handoff_timeout(c, "a fused launch's in-kernel hand-off timed out (results of this tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
   if (a_seq) memcpy(a_seq, c->out_pinned, c->D * sizeof(float));
   if (p_weights) memcpy(p_weights, c->out_pinned + (c->pw - c->outblk), c->N * sizeof(float));
   return DUST_OK;

@@ -9,7 +9,17 @@ namespace dust {
 enum { PAIR_PRIOR = 0, PAIR_K1 = 1, PAIR_IMQ = 2, PAIR_LOGP = 3 };  // LOGP: the prior pass of SVMPC.forward - log p only, no gradient
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Bounded wait of ONE lane on a monotonic arrival counter (wrap-safe compare).  A spin gives up after ~50 ms of wall clock
+// Wall-clock bound of every in-launch wait (s_memrealtime ticks, 100 MHz): 50 ms.  The start barriers prove that a grid IS resident, not
+// that it STAYS resident: when another PROCESS computes on the device the hardware scheduler time-slices the two processes' queues with
+// wave save / restore, and a partially restored grid spins on peers that are still saved while the other process's grid does the same
+// (tools/two_process_ticks.py: two processes ticking the product shape deadlock within a second; raising this bound to 2 s only
+// delays the report).  Giving up is what resolves it - the other process's grid can then be restored whole - so the bound stays short;
+// the host turns the time-out into an error for that tick and takes the context off every kernel that spins on its own grid.
+#ifndef DUST_SPIN_TIMEOUT_TICKS
+#define DUST_SPIN_TIMEOUT_TICKS 5000000ull
+#endif
+
+// Bounded wait of ONE lane on a monotonic arrival counter (wrap-safe compare).  A spin gives up after DUST_SPIN_TIMEOUT_TICKS of wall clock
 // (s_memrealtime, 100 MHz) or as soon as another waiter has given up, and raises the flag: the host reports it as an error.
 __device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned int target, unsigned int *flag) {
   unsigned int spins = 0;
@@ -22,7 +32,10 @@ __device__ __forceinline__ bool spin_until(const unsigned int *p, const unsigned
     if ((++spins & 255u) == 0u) {
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (!t0) t0 = now;
-      else if (now - t0 > 5000000ull || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      else if (now - t0 > DUST_SPIN_TIMEOUT_TICKS || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        // (one more look: a wait that is complete by now has not failed, whatever the clock says - a wave can find its time gone
+        //  because its process was switched out, with every arrival in)
+        if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;
         __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }

@@ -929,7 +929,7 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svmpc_tick_kernel
           if ((++spins & 63u) == 0u) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (!t0) t0 = now;
-            else if (now - t0 > 5000000ull) {  // workgroup 0 never came: give up (reported as a time-out)
+            else if (now - t0 > DUST_SPIN_TIMEOUT_TICKS) {  // workgroup 0 never came: give up (reported as a time-out)
               __hip_atomic_store(f.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               g = f.seq | 0x80000000u;
               break;

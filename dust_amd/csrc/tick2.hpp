@@ -81,6 +81,20 @@ __device__ __forceinline__ unsigned int t2_lds_ld(const unsigned int *p) { retur
 __device__ __forceinline__ void t2_lds_st(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ unsigned int t2_shard_wgs(const int sh, const int G) { return (unsigned int)(G / T2_NSH + (sh < G % T2_NSH ? 1 : 0)); }
 
+// COMMIT of a tick.  A workgroup that has passed the tick's last wait reads the time-out flag ONCE (one lane, handed round through
+// LDS) and writes persistent state only if it is clear; otherwise it counts itself in status[2].  The host replays a tick nobody
+// committed.  This read is not a linearisation point - a wait can give up a moment before the arrival it was waiting for while
+// another workgroup sees that arrival and commits - but the host SEES that case (0 < status[2] < workgroups) and reports the tick lost,
+// as it did every timed-out tick before.  One compare-and-swap word deciding for everybody closes the window and costs 2.4 us per
+// tick (256 agent-scope RMWs on one line: 118.9 against 116.5 us); the window is ~1 us wide at the end of a 50 ms wait.
+__device__ __forceinline__ bool t2_commit(unsigned int *status, const int b) {
+  const bool ok = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  if (!ok) {
+    __hip_atomic_fetch_add(status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b == 0) __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the host replays it
+  }
+  return ok;
+}
 // lanes [0, T2_NSH) of the calling wave wait until every shard has seen `per_wg * phase` arrivals of each of its workgroups
 __device__ __forceinline__ void t2_poll(const unsigned int *lines, const unsigned int per_wg, const unsigned int phase, const int G, const int lane,
                                         unsigned int *flag) {
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *flag_th = misc + 44;    // [4] non-finite particle
   float *flag_eps = misc + 48;   // [4] non-finite caller-supplied noise
   // (misc[56..59] unused)
-  unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived
+  unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived  [2] COMMIT (1) / not (0)
   float *wred = misc + 64;       // [128] block-reduction scratch
   float *coefs = lds + T2_L_COEFS;
   float *ksl = lds + L.ksl;
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           }
         }
       }
-      const bool all_ok = __all(ok ? 1 : 0) && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && !f->test_abort;
+      const bool all_ok = __all(ok ? 1 : 0) && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1;
       if (lane == 0) {
         if (!all_ok) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(go, all_ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         if ((++spins & 255u) == 0u) {
           const unsigned long long now = __builtin_amdgcn_s_memrealtime();
           if (!t_start) t_start = now;
-          else if (now - t_start > 5000000ull) {  // workgroup 0 never came: give up (reported as a time-out)
+          else if (now - t_start > DUST_SPIN_TIMEOUT_TICKS) {  // workgroup 0 never came: give up (reported as a time-out)
             __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             g = 2u;
             break;
@@ -707,7 +721,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         f->score[no] = gs_keep + gp_keep;
         f->grad_lik[no] = gs_keep;
         f->grad_pri[no] = gp_keep;
-        if (f->update_a_mat) f->a_mat[no] = amv;
       }
     }
     if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
@@ -806,9 +819,17 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
 
   const int kf = f->n_iters;
   const int lane = tid0 & 63;
+  // COMMIT (t2_commit above).  Everything persistent - particles, a_mat, optimiser moments, prior mixture, stream counters - is written
+  // only from here on, behind the tick's last wait, and only if no wait of the launch has given up: a workgroup that has passed the last
+  // wait knows that every workgroup published its last hand-off, i.e. passed every earlier wait.  A tick whose waits timed out (another
+  // process's compute on the device: handoff.hpp) therefore leaves the state untouched and the host replays it on plain kernels.
   if (!f->do_forward) {  // SVMPC.optimize alone: particles and optimiser state stay (svmpc.py:97-126)
+    if (tid0 == 0) t2_lds_st(sig + 2, t2_commit(f->status, b) ? 1u : 0u);
+    wg_sync();
+    if (sig[2] == 0u) return;
     if (ownv) {
       f->theta[no] = thv;
+      if (f->update_a_mat) f->a_mat[no] = amv;
       if (adam) {
         f->adam_m[no] = adm;
         f->adam_v[no] = adv;
@@ -857,11 +878,16 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       f->lw[n] = lwv;
       st_sc1(f->lwq + n, lwv);
     }
+    if (f->test_abort == 2 && b == G - 1 && lane == 0) {  // test hook: "a wait of this workgroup gave up"
+      __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     t2_arrive_wave(cnt_lw + (size_t)sh * T2_CNT_STRIDE, lane);
     t2_poll(cnt_lw, 1u, 1u, G, lane, tflag);
+    if (lane == 0) t2_lds_st(sig + 2, t2_commit(f->status, b) ? 1u : 0u);
   }
   wg_sync();
   T2_TL(0, 16 * kf + 1);
+  if (sig[2] == 0u) return;  // no COMMIT (see above)
   // softmax over all particles, first-index argmax (finalize_body), computed by every workgroup for itself
   {
     const int t = tid0;
@@ -936,6 +962,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       float out = (od + DA < D) ? th[op * T2_ROW + od + DA] : thv;
       if (f->roll_strategy == DUST_ROLL_MEAN && od + DA >= D) out = outv;
       f->theta[no] = out;
+      if (f->update_a_mat) f->a_mat[no] = amv;
       if (adam) {  // SVMPC.roll makes a NEW parameter tensor: torch's optimiser state restarts
         f->adam_m[no] = 0.f;
         f->adam_v[no] = 0.f;

@@ -24,7 +24,8 @@ struct Tick2Args {
   int steps;             // ceil(N / 64) rounded up to a multiple of 16: 16-key steps of a pair wave in the theta-only pass (4 waves share the keys)
   int lik, update_a_mat, eps_base_mode, optimizer, roll_strategy, weighted_prior;
   int coef_given;
-  int test_abort;        // test hook (DUST_TICK2_TEST_ABORT=k: every k-th launch): workgroup 0 publishes "abort" as if a peer were missing
+  int test_abort;        // test hooks, every k-th launch.  1 (DUST_TICK2_TEST_ABORT=k): workgroup 0 publishes "abort" as if a peer were missing;
+                         // 2 (DUST_TICK2_TEST_TIMEOUT=k): the last workgroup behaves as if its last wait had given up (no COMMIT)
   int grid_words;        // Particle: words of the bit-packed occupancy grid staged in LDS (multiple of 4) or 0
   float coef_host[2];
   float alpha, temp;
@@ -49,7 +50,8 @@ struct Tick2Args {
   int *istar;
   unsigned int *cnt;        // this tick's counter set (T2_SETS lines)
   unsigned int *zero_base;  // the other set, zeroed by workgroup 0 for the next tick
-  unsigned int *status;     // [0] a hand-off wait timed out (sticky until the host clears it) [1] ticks that did not start (not all workgroups resident)
+  unsigned int *status;     // [0] a hand-off wait timed out (sticky until the host clears it) [1] ticks to replay: did not start (not all workgroups
+                            // resident) or not committed (a wait gave up) [2] workgroups that did not commit
   unsigned long long *tl;   // diagnostic build only: [grid][128] wall-clock stamps
 };
 

@@ -191,6 +191,42 @@ def test_tick2_long_run_stays_consistent():
         assert elemerr(h0[t][0], h1[t][0]) < 1e-3, t
 
 
+def test_tick2_timed_out_ticks_commit_nothing_and_are_replayed():
+    """A tick of the owner-computes kernel one of whose in-launch waits gives up (another PROCESS computing on the device:
+    tools/two_process_ticks.py) writes no persistent state - particles, a_mat, optimiser moments, stream counters are committed
+    behind the last wait under ONE verdict word - and is replayed by the library on plain kernels; afterwards the context stays off
+    every kernel that spins on its own grid.  DUST_TICK2_TEST_TIMEOUT=3: the last workgroup of the third launch acts as if its last
+    wait had given up."""
+    N, S, H = 256, 128, 30
+    st = _state("pendulum")
+    outs = []
+    for env in ({"DUST_TICK2_TEST_TIMEOUT": "3"}, {}):
+        saved = os.environ.pop("DUST_TICK2_TEST_TIMEOUT", None)
+        os.environ.update(env)
+        try:
+            c, _ = _make("pendulum", N, S, H)
+            hist = []
+            for t in range(7):
+                a_seq, pw = c.svmpc_tick(st, 3)
+                hist.append((a_seq.copy(), pw.copy(), c.get_theta()))
+            outs.append((hist, c.tick_stats()))
+            c.close()
+        finally:
+            os.environ.pop("DUST_TICK2_TEST_TIMEOUT", None)
+            if saved is not None:
+                os.environ["DUST_TICK2_TEST_TIMEOUT"] = saved
+    (h0, s0), (h1, s1) = outs
+    assert s0["tick2"] == 3 and s0["replayed"] == 1, s0   # launches 1-3 of the owner-computes kernel, then plain kernels for good
+    assert s1["tick2"] == 6 and s1["replayed"] == 0, s1
+    for t in range(5):  # t = 3 is the replayed tick; from then on the two runs sum in different orders, later ticks amplify
+        assert elemerr(h0[t][0], h1[t][0]) < 2e-3, (t, elemerr(h0[t][0], h1[t][0]))
+        assert np.abs(h0[t][1] - h1[t][1]).max() < 5e-3
+        if t < 3:
+            assert np.array_equal(h0[t][2], h1[t][2]), t
+    for t in range(7):
+        assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
+
+
 def test_tick2_aborted_ticks_are_replayed():
     """A tick whose workgroups are not all resident does not start (start barrier) and is replayed by the library on the
     launch-per-iteration path: the caller sees DUST_OK, the same results, and `tick_stats()['replayed']` counts it.  The test hook
