@@ -156,6 +156,7 @@ SYMBOLS = {
     "dust_set_skid_steer": (C.c_int, [VP, C.POINTER(SkidConfig)]),
     "dust_mpf_set_prior_bw": (C.c_int, [VP, FP, C.c_int]),
     "dust_mpf_get_prior_bw": (C.c_int, [VP, FP]),
+    "dust_mpf_stats": (C.c_int, [VP, C.POINTER(C.c_longlong)]),
     "dust_mpf_prior_sample": (C.c_int, [VP, C.c_int, C.c_uint64, FP]),
     "dust_mpf_prior_log_prob": (C.c_int, [VP, C.c_int, FP, FP]),
 }

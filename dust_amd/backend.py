@@ -512,6 +512,13 @@ class MpfContext:
         L.check(L.load().dust_mpf_get_prior_bw(self._h, _p(out)))
         return out
 
+    def stats(self):
+        """{'grid': optimize() calls served by the multi-workgroup kernel, 'fallback': those re-run by the single-workgroup one}."""
+        import ctypes as C
+        n = (C.c_longlong * 2)()
+        L.check(L.load().dust_mpf_stats(self._h, n))
+        return {"grid": int(n[0]), "fallback": int(n[1])}
+
     def prior_sample(self, n, seed=0):
         out = np.empty((n, self.P), np.float32)
         L.check(L.load().dust_mpf_prior_sample(self._h, n, seed, _p(out)))

@@ -828,9 +828,14 @@ static int fused_dpb(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : 80); }
 static int fused_tq(int D) { return D <= 32 ? FusedGeom<32>::TQ : (D <= 64 ? FusedGeom<64>::TQ : FusedGeom<80>::TQ); }
 // "large key set": none of the small-N launch fusions (fused.hpp, persist.hpp) applies
 static bool pair_is_big(const dust_ctx *c) {
-  const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel
+  const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel, 1 the large-set path from N = 2048 on
   if (env && atoi(env) == 0) return false;
+  const bool forced = env && atoi(env) == 1;
   // (a rank of a sharded run qualifies from 512 local particles on: the fused pass slices the keys finely enough to fill the chip)
+  // Just above the threshold the 32 x 64 kernels inside the fused launches (2 launches per iteration) still win while the rows are
+  // short - measured, us per 5-iteration tick, large-set / small-set path: Pendulum N = 2048 D = 30: 434 / 355 (M = 8, cfg5: 742 / 620);
+  // Particle N = 2048 D = 32: 467 / 376, D = 80: 946 / 1129; Pendulum N = 3072 D = 30: 722 / 725; N = 4096: 871 / 1044.
+  if (!forced && c->nloc == c->N && (long)c->N * c->D <= 65536) return false;
   return c->N >= 2048 && c->D <= 80 && (c->nloc == c->N || c->nloc >= 512);
 }
 static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64 && c->nloc == c->N; }  // pairwise_big.hpp (unfused passes)

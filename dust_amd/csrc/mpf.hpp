@@ -243,6 +243,237 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
   }
 }
 
+// ---- the same optimisation spread over the chip -------------------------------------------------------------------------------------
+// The single-workgroup kernel above is bound by the VALU issue rate of ONE compute unit: 2 M_p^2 pair terms of ~40 (mostly fp64)
+// instructions per step - 40 us per step at M_p = 256, 815 us for the 20 steps of a filter update (profiles/round3_cfg5_kernel_stats.txt),
+// longer than the control tick it runs beside.  Here ONE WAVE owns one particle i (4 waves per workgroup, M_p / 4 workgroups): its lanes
+// stride over the other particles, the partial sums are combined by a fixed xor-shuffle tree in fp64 (reproducible), lane 0 adds the
+// likelihood score and takes the optimiser step.  Per step the waves exchange the scores and the new particles through global memory
+// (write-through stores, one arrival per wave on a counter sharded over 16 lines, one polling wave per workgroup) - two grid-wide
+// hand-offs of ~3 us; the arithmetic per particle is the kernel's above, summed in another (fixed) order.
+// The grid must be co-resident.  Protocol of tick2.hpp: a START BARRIER (workgroup 0 waits <= 200 us for every workgroup, then
+// publishes go / abort; nothing is written before "go"), bounded waits, and a COMMIT - particles and optimiser moments are written
+// behind the last hand-off by waves that find the time-out flag clear.  The host runs an aborted or uncommitted call on the kernel
+// above, which needs no co-residency.
+struct MpfGridArgs {
+  MpfArgs a;
+  float *xg;             // [2][Mp][P] particle generations (step parity)
+  float *scg;            // [2][Mp][P] scores
+  float *n2g;            // [n_steps][Mp] |phi_i|^2
+  unsigned int *cnt;     // 16 lines of score arrivals | 16 lines of particle arrivals | start arrivals | go   (zeroed by the host per launch)
+  unsigned int *status;  // [0] a wait timed out [1] calls that did not start [2] waves that did not commit
+  int test;              // test hook: 1 abort at the start barrier, 2 "a wait gave up" before the last hand-off
+};
+enum { MPF_G_WAVES = 4, MPF_G_NT = 64 * MPF_G_WAVES, MPF_G_NSH = 16, MPF_G_LINE = 32 /* words: one 128-byte line per counter */ };
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int P>
+__global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGridArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const MpfArgs &a = g.a;
+  const int Mp = a.Mp, tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = (int)gridDim.x, b = (int)blockIdx.x, i = b * MPF_G_WAVES + wave;
+  float *xs = sm;             // [Mp][P] current particles
+  float *sc = xs + Mp * P;    // [Mp][P] scores
+  float *nrm = sc + Mp * P;   // [Mp] squared norms
+  unsigned int *sig = reinterpret_cast<unsigned int *>(nrm + Mp);
+  unsigned int *cnt_sc = g.cnt, *cnt_x = g.cnt + MPF_G_NSH * MPF_G_LINE, *cnt_start = g.cnt + 2 * MPF_G_NSH * MPF_G_LINE, *go = cnt_start + MPF_G_LINE;
+  unsigned int *tflag = g.status;
+  const bool on = i < Mp, lead = on && lane == 0;
+  // ---- start barrier
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt_start, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int v = 0u;
+    if (b == 0) {
+      const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+      bool ok = true;
+      while ((int)(__hip_atomic_load(cnt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned int)G) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t_start > 20000ull) {
+          ok = false;
+          break;
+        }
+      }
+      ok = ok && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && g.test != 1;
+      if (!ok) __hip_atomic_fetch_add(g.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = ok ? 1u : 2u;
+      __hip_atomic_store(go, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned int spins = 0u;
+      unsigned long long t_start = 0;
+      for (;;) {
+        v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0u) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (!t_start) t_start = now;
+          else if (now - t_start > DUST_SPIN_TIMEOUT_TICKS) {  // workgroup 0 never came
+            __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = 2u;
+            break;
+          }
+        }
+      }
+    }
+    sig[0] = v;
+  }
+  for (int t = tid; t < Mp * P; t += MPF_G_NT) xs[t] = a.x[t];
+  wg_sync();
+  if (sig[0] != 1u) return;
+  for (int j = tid; j < Mp; j += MPF_G_NT) {
+    float nn = 0.f;
+    _Pragma("unroll") for (int p = 0; p < P; ++p) nn = nn + xs[j * P + p] * xs[j * P + p];
+    nrm[j] = nn;
+  }
+  wg_sync();
+
+  const float bw2 = (float)((double)a.bw * (double)a.bw);
+  double inv_pbw[4], inv_pbw2[4];
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {
+    inv_pbw[p] = 1.0 / (double)a.prior_bwv[p < P ? p : 0];
+    inv_pbw2[p] = inv_pbw[p] * inv_pbw[p];
+  }
+  const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw), inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
+  float am[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool adam = a.optimizer == DUST_OPT_ADAM;
+  if (adam && lead)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      am[p] = a.adam_m[i * P + p];
+      av[p] = a.adam_v[i * P + p];
+    }
+  // lanes [0, 16) of wave 0 wait for the arrivals of every particle's wave on their shard line
+  auto poll = [&](unsigned int *lines, const unsigned int phase) {
+    if (wave == 0 && lane < MPF_G_NSH) {
+      const unsigned int target = (unsigned int)((Mp >> 4) + ((Mp & 15) > lane ? 1 : 0)) * phase;
+      if (target) spin_until(lines + lane * MPF_G_LINE, target, tflag);
+    }
+    wg_sync();
+  };
+  auto arrive = [&](unsigned int *lines) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lead) __hip_atomic_fetch_add(lines + (i & 15) * MPF_G_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  for (int it = 0; it < a.n_steps; ++it) {
+    float xi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      _Pragma("unroll") for (int p = 0; p < P; ++p) xi[p] = xs[i * P + p];
+      // prior score (mpf.py:45), as in the kernel above
+      double zs = 0.0, acc[4] = {0, 0, 0, 0};
+      for (int k = lane; k < Mp; k += 64) {
+        double q = 0.0;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          const double z = ((double)xi[p] - (double)xs[k * P + p]) * inv_pbw[p];
+          q += z * z;
+        }
+        const double w = (double)expf((float)(-0.5 * q));
+        zs += w;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] += w * ((double)xs[k * P + p] - (double)xi[p]);
+      }
+      zs = wave_sum_f64(zs);
+      _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] = wave_sum_f64(acc[p]);
+      if (lane == 0) {
+        double s[4];
+        _Pragma("unroll") for (int p = 0; p < P; ++p) s[p] = acc[p] / zs * inv_pbw2[p];
+        float pred[4];
+        for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
+        const Coef cf = make_coef(a.dm, xi);
+        if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
+        else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+        double J[4][4];
+        step_jacobian<P>(a.dm, a.past_obs, a.past_action, xi, J);
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          double gl = 0.0;
+          _Pragma("unroll") for (int k = 0; k < 4; ++k)
+            if (k < a.ds) gl += J[k][p] * ((double)a.obs[k] - (double)pred[k]);
+          s[p] += gl * inv_obs2;
+          st_sc1(g.scg + ((size_t)(it & 1) * Mp + i) * P + p, (float)s[p]);
+        }
+      }
+    }
+    arrive(cnt_sc);
+    poll(cnt_sc, (unsigned int)(it + 1));
+    for (int t = tid; t < Mp * P; t += MPF_G_NT) sc[t] = ld_sc1(g.scg + (size_t)(it & 1) * Mp * P + t);
+    wg_sync();
+    // kernel + phi (svgd.py:92-99, mpf.py:52-56), as in the kernel above
+    if (on) {
+      double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
+      const float ni = nrm[i];
+      for (int j = lane; j < Mp; j += 64) {
+        float dot = xi[0] * xs[j * P];
+        _Pragma("unroll") for (int q = 1; q < P; ++q) dot = fmaf(xi[q], xs[j * P + q], dot);
+        float q = (nrm[j] + (-2.0f * dot)) + ni;
+        q = fmaxf(q, 0.f);
+        const double k = (double)expf(((-q) / bw2) / 2.0f);
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          gk[p] -= k * ((double)xi[p] - (double)xs[j * P + p]);
+          ks[p] += k * (double)sc[j * P + p];
+        }
+      }
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        gk[p] = wave_sum_f64(gk[p]);
+        ks[p] = wave_sum_f64(ks[p]);
+      }
+      if (lane == 0) {
+        float ph[4] = {0.f, 0.f, 0.f, 0.f}, n2 = 0.f;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          ph[p] = (float)(gk[p] * inv_bw2 + ks[p] / Mp);
+          n2 += ph[p] * ph[p];
+        }
+        if (g.n2g) st_sc1(g.n2g + (size_t)it * Mp + i, n2);
+        if (it == 0 && a.phi_out)
+          _Pragma("unroll") for (int p = 0; p < P; ++p) a.phi_out[i * P + p] = ph[p];
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          xn[p] = adam ? adam_step(xi[p], -ph[p], am[p], av[p], a.lr, a.beta1, a.beta2, a.eps, (float)(a.t0 + it + 1)) : fmaf(a.lr, ph[p], xi[p]);
+          st_sc1(g.xg + ((size_t)((it + 1) & 1) * Mp + i) * P + p, xn[p]);
+        }
+      }
+    }
+    if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrive(cnt_x);
+    poll(cnt_x, (unsigned int)(it + 1));
+    if (it + 1 < a.n_steps) {
+      for (int j = tid; j < Mp; j += MPF_G_NT) {
+        float nn = 0.f;
+        _Pragma("unroll") for (int p = 0; p < P; ++p) {
+          const float v = ld_sc1(g.xg + ((size_t)((it + 1) & 1) * Mp + j) * P + p);
+          xs[j * P + p] = v;
+          nn = nn + v * v;
+        }
+        nrm[j] = nn;
+      }
+      wg_sync();
+    }
+  }
+  // COMMIT: one look at the flag per workgroup, behind the last hand-off
+  if (tid == 0) sig[1] = __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wg_sync();
+  if (sig[1] != 0u) {
+    if (lead) __hip_atomic_fetch_add(g.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (lead) {
+    _Pragma("unroll") for (int p = 0; p < P; ++p) a.x[i * P + p] = xn[p];
+    if (adam)
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        a.adam_m[i * P + p] = am[p];
+        a.adam_v[i * P + p] = av[p];
+      }
+  }
+  if (b == 0 && a.grad_norms)  // ||phi|| of every step: the per-particle squares in particle order
+    for (int it = tid; it < a.n_steps; it += MPF_G_NT) {
+      double n2 = 0.0;
+      for (int j = 0; j < Mp; ++j) n2 += (double)ld_sc1(g.n2g + (size_t)it * Mp + j);
+      a.grad_norms[it] = sqrtf((float)n2);
+    }
+}
+
 struct MpfBw {
   float v[4];
 };
@@ -301,6 +532,12 @@ struct dust_mpf {
   float prior_bwv[4];          // per parameter dimension; equal once update_prior(bw) has run (mpf.py:85)
   float loc[4], past_obs[4], past_action[2];
   bool have_past;
+  // the multi-workgroup form of the optimisation (mpf_optimize_grid_kernel): exchange buffers, counters, status; lazily allocated
+  float *gbuf;            // xg [2][Mp][P] | scg [2][Mp][P] | n2g [gsteps][Mp]
+  unsigned int *gcnt;     // counters (zeroed per launch) followed by the 4 status words
+  int gsteps;             // rows of n2g allocated
+  bool grid_banned;       // a wait of the grid form timed out once (device shared with another process): single-workgroup kernel from then on
+  long long n_grid, n_grid_fallback;
 };
 
 static DevModel mpf_dev_model(const dust_mpf *m) {
@@ -321,7 +558,7 @@ extern "C" void dust_mpf_destroy(dust_mpf *m) {
   if (!m) return;
   (void)hipSetDevice(m->cfg.device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  float *fp[] = {m->x, m->gn, m->phi, m->tmp, m->adam_m, m->adam_v};
+  float *fp[] = {m->x, m->gn, m->phi, m->tmp, m->adam_m, m->adam_v, m->gbuf, reinterpret_cast<float *>(m->gcnt)};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (m->grid_bits) (void)hipFree(m->grid_bits);
@@ -434,7 +671,19 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   return DUST_OK;
 }
 
-static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true) {
+enum { MPF_GCNT_WORDS = (2 * dust::MPF_G_NSH + 2) * dust::MPF_G_LINE };
+// Whether this call takes the multi-workgroup kernel: an optimisation of >= 2 steps over >= 192 particles - measured, us per 20-step
+// call, grid / single workgroup: M_p = 128: 378 / 284, 256: 413 / 797, 512: 562 / 2 927, 1024: 885 / 11 433 (the grid form pays
+// ~7 us per step for its two hand-offs and 2.5 us for the likelihood term on one lane; the single workgroup ~M_p^2).
+// DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests).
+static bool mpf_grid_ok(const dust_mpf *m, int n_steps, bool optimise) {
+  if (!optimise || n_steps < 2 || m->grid_banned) return false;
+  const char *env = getenv("DUST_MPF_GRID");
+  if (env && atoi(env) == 0) return false;
+  return m->Mp >= ((env && atoi(env) == 1) ? 8 : 192);
+}
+
+static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true, bool grid = false) {
   if (m->cfg.model_cfg.model == DUST_MODEL_PARTICLE && m->cfg.model_cfg.with_obstacle && m->cfg.model_cfg.can_crash && !m->grid_bits)
     return fail(DUST_ERR_STATE, "Particle model with obstacles: call dust_mpf_set_grid first");
   MpfArgs a;
@@ -466,6 +715,37 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.eps = m->adam_eps;
   a.adam_m = m->adam_m;
   a.adam_v = m->adam_v;
+  if (grid) {
+    const size_t np = (size_t)m->Mp * m->P;
+    if (!m->gbuf || m->gsteps < n_steps) {
+      if (m->gbuf) HIP_TRY(hipFree(m->gbuf));
+      m->gbuf = nullptr;
+      m->gsteps = std::max(n_steps, 32);
+      TRY(dalloc(&m->gbuf, 4 * np + (size_t)m->gsteps * m->Mp));
+    }
+    if (!m->gcnt) {
+      TRY(dalloc(&m->gcnt, (size_t)MPF_GCNT_WORDS + 4));
+      HIP_TRY(hipMemsetAsync(m->gcnt, 0, ((size_t)MPF_GCNT_WORDS + 4) * sizeof(unsigned int), m->stream));
+    }
+    HIP_TRY(hipMemsetAsync(m->gcnt, 0, (size_t)MPF_GCNT_WORDS * sizeof(unsigned int), m->stream));
+    MpfGridArgs g;
+    memset(&g, 0, sizeof g);
+    g.a = a;
+    g.xg = m->gbuf;
+    g.scg = m->gbuf + 2 * np;
+    g.n2g = m->gbuf + 4 * np;
+    g.cnt = m->gcnt;
+    g.status = m->gcnt + MPF_GCNT_WORDS;
+    if (const char *t = getenv("DUST_MPF_GRID_TEST")) g.test = atoi(t);
+    const int G = (m->Mp + MPF_G_WAVES - 1) / MPF_G_WAVES;
+    const size_t lds = sizeof(float) * ((size_t)2 * np + m->Mp + 8);
+    if (m->P == 1) mpf_optimize_grid_kernel<1><<<G, MPF_G_NT, lds, m->stream>>>(g);
+    else if (m->P == 2) mpf_optimize_grid_kernel<2><<<G, MPF_G_NT, lds, m->stream>>>(g);
+    else if (m->P == 3) mpf_optimize_grid_kernel<3><<<G, MPF_G_NT, lds, m->stream>>>(g);
+    else mpf_optimize_grid_kernel<4><<<G, MPF_G_NT, lds, m->stream>>>(g);
+    HIP_TRY(hipGetLastError());
+    return DUST_OK;
+  }
   const int mpad = ((m->Mp + 63) / 64) * 64;
   int R = 1;
   while (mpad * R * 2 <= 1024) R *= 2;
@@ -497,13 +777,37 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
     m->have_past = true;
   }
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
-  TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr));
+  const bool grid = mpf_grid_ok(m, n_steps, true);
+  TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, grid));
+  if (grid) {  // did the grid form start, and did it commit?  (tick2.hpp's protocol; this call is synchronous anyway)
+    unsigned int st[3] = {0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(st, m->gcnt + MPF_GCNT_WORDS, sizeof st, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->n_grid++;
+    if (st[0] | st[1] | st[2]) {
+      HIP_TRY(hipMemsetAsync(m->gcnt + MPF_GCNT_WORDS, 0, 4 * sizeof(unsigned int), m->stream));
+      if (st[0]) m->grid_banned = true;  // (a wait gave up: another process computes on the device - handoff.hpp)
+      if (st[2] != 0u && st[2] != (unsigned int)m->Mp)
+        return fail(DUST_ERR_HIP, "MPF: a hand-off wait timed out while some waves were committing (particles invalid: re-seed them); the device seems to be shared with another process");
+      if (st[1] || st[2]) {  // nothing was written: the single-workgroup kernel runs the call
+        m->n_grid_fallback++;
+        TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, false));
+      }
+    }
+  }
   if (m->optimizer == DUST_OPT_ADAM) m->adam_t += n_steps;
   for (int p = 0; p < 4; ++p) m->prior_bwv[p] = bw;  // update_prior(bw) mpf.py:85
   if (grad_norms && n_steps > 0) {
     HIP_TRY(hipMemcpyAsync(grad_norms, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   }
   HIP_TRY(hipStreamSynchronize(m->stream));
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_stats(dust_mpf *m, long long out[2]) {
+  if (!m || !out) return fail(DUST_ERR_INVALID, "null argument");
+  out[0] = m->n_grid;
+  out[1] = m->n_grid_fallback;
   return DUST_OK;
 }
 

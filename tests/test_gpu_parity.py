@@ -672,10 +672,11 @@ def test_k2_bandwidth_is_the_exact_order_statistic(N):
 
 @pytest.mark.parametrize("model,N,H,kernel", [("pendulum", 2048, 30, "K1"), ("pendulum", 2200, 17, "IMQ"), ("particle", 2048, 20, "K1"),
                                               ("particle", 2048, 40, "K1"), ("pendulum", 4096, 30, "K1")])
-def test_large_key_set_pairwise_vs_oracle(model, N, H, kernel):
+def test_large_key_set_pairwise_vs_oracle(model, N, H, kernel, monkeypatch):
     """N >= 2048 takes the register-blocked pairwise kernel (pairwise_big.hpp): prior score, log p and phi against the
     oracle for both padded widths (D = 30 / 17 -> 32, 40 -> 64), D = 80 (which stays on the 32 x 64 kernel), ragged N, and
     log p through a forward pass."""
+    monkeypatch.setenv("DUST_PAIR_BIG", "1")  # (N D <= 65536 runs the small-set launches by default: this test is about the large-set kernels)
     from dust_amd import Context
     from oracle import Oracle, grid_4x4_map
 
@@ -855,10 +856,11 @@ def test_cfg5_shaped_sharded_equals_unsharded():
     ("particle", 2048, 40, "K1", 1.2),    # far-apart particles: almost every Stein kernel value underflows to 0
     ("pendulum", 4096, 30, "K1", 2.0),
     ("particle", 2048, 40, "K1", 0.02)])  # nearly collapsed set: every kernel value ~ 1
-def test_fused_large_pairwise_vs_oracle(model, N, H, kernel, spread):
+def test_fused_large_pairwise_vs_oracle(model, N, H, kernel, spread, monkeypatch):
     """Prior means aliasing theta + N >= 2048: ONE distance pass serves the prior score, the Stein repulsion and the Gram matrix,
     then Gram x score runs as a GEMM (pairwise_fused.hpp) - D = 80 / 30 / 40 / 17 (tile widths 80 / 32 / 64 / 32), ragged N,
     non-uniform mixture weights.  grad_pri and phi against the oracle, and against the two unfused passes (DUST_PAIR_FUSED=0)."""
+    monkeypatch.setenv("DUST_PAIR_BIG", "1")  # (N D <= 65536 runs the small-set launches by default: this test is about the large-set kernels)
     from dust_amd import Context
     from oracle import Oracle, grid_4x4_map
 
@@ -1035,12 +1037,13 @@ def test_full_size_rollouts_sampled_vs_oracle(name, N, S, M, H):
 @pytest.mark.parametrize("model,N,H,spread,offset", [("particle", 2048, 40, 1.0, 0.0), ("particle", 2100, 40, 0.25, 6.0),
                                                      ("pendulum", 4096, 30, 0.5, -3.0), ("pendulum", 2200, 17, 2.0, 0.0),
                                                      ("pendulum", 2048, 12, 0.05, 1.0), ("particle", 16384, 40, 1.0, 2.0)])
-def test_large_aliased_logp_mfma_vs_oracle(model, N, H, spread, offset):
+def test_large_aliased_logp_mfma_vs_oracle(model, N, H, spread, offset, monkeypatch):
     """SVMPC.forward's log p(theta) (svmpc.py:128-140) for N >= 2048 with the prior means aliasing theta runs the product-form
     distance on the matrix cores (pairwise_logp_mfma.hpp; rows centred on particle 0, so a common `offset` of the cloud costs no
     accuracy).  Against the oracle (exact differences, double accumulation) and against the exact-difference device pass
     (DUST_LOGP_MFMA=0): log p element-wise at 1e-5, particle weights at 1e-5 absolute.  Ragged N, D = 80 / 30 / 17 / 12,
     anisotropic sigma_p, non-uniform mixture weights, a nearly collapsed set (spread 0.05: every key matters), the cfg4 shape."""
+    monkeypatch.setenv("DUST_PAIR_BIG", "1")  # (N D <= 65536 runs the small-set launches by default: this test is about the large-set kernels)
     from dust_amd import Context
     from oracle import Oracle, grid_4x4_map
 
@@ -1089,13 +1092,14 @@ def test_large_aliased_logp_mfma_vs_oracle(model, N, H, spread, offset):
 @pytest.mark.parametrize("model,N,H,kind", [("particle", 2048, 40, "spread"), ("particle", 2100, 40, "mixed"), ("pendulum", 4096, 30, "mixed"),
                                             ("pendulum", 2304, 30, "clustered"), ("pendulum", 2200, 17, "spread"),
                                             ("particle", 16384, 40, "mixed")])
-def test_fused_pairwise_zero_blocks_bitwise(model, N, H, kind):
+def test_fused_pairwise_zero_blocks_bitwise(model, N, H, kind, monkeypatch):
     """K1's kernel values underflow to exactly 0 in fp32 beyond d^2 ~ 84; pairwise_fused.hpp flags the (query row, 64-key chunk)
     blocks that are all zero and skips them in pass B, in the Gram store and in the Gram x score GEMM.  The result must be
     BIT-IDENTICAL to the dense evaluation (DUST_DENSE=1): phi / grad_pri of the stage-wise call and the particles after two whole
     ticks, for a spread set (only the diagonal survives), a clustered one (everything survives) and a mixed one (a cluster of
     near-duplicates inside a spread set: blocks with a few non-zero rows - the rows of such a block that were NOT stored must read
     as zeros, not as stale Gram values of an earlier pass)."""
+    monkeypatch.setenv("DUST_PAIR_BIG", "1")  # (N D <= 65536 runs the small-set launches by default: this test is about the large-set kernels)
     from dust_amd import Context
     from oracle import grid_4x4_map
 
@@ -1183,6 +1187,75 @@ def test_mpf_initial_prior_from_bw_silverman(golden, name):
     assert relerr(mp.prior.log_prob(torch.tensor(g["probe"])).numpy(), g["probe_log_prob1"]) < TOL  # isotropic again (mpf.py:85)
     grads2, _ = mp.optimize(torch.tensor(g["action2"]), torch.tensor(g["obs2"]), bw=bw, n_steps=n)
     assert relerr(mp.x.numpy(), g["x_final2"]) < 2 * tol_x and relerr(grads2.numpy(), g["grad_norms2"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["mpf_pend", "mpf_part_log", "mpf_pend_adam", "mpf_part_log_adam"])
+def test_mpf_multi_workgroup_kernel_vs_reference(golden, name, monkeypatch):
+    """The multi-workgroup form of MPF.optimize (mpf.hpp mpf_optimize_grid_kernel: one wave per particle, two grid-wide hand-offs per
+    step; the default from 192 particles on) against the reference's own filter updates - DUST_MPF_GRID=1 sends these small golden
+    cases through it."""
+    from dust_amd import MpfContext
+    from oracle import grid_4x4_map
+
+    monkeypatch.setenv("DUST_MPF_GRID", "1")
+    g = golden(name)
+    kind = str(g["model_kind"])
+    up = ("length", "mass") if kind == "pendulum" else ("mass",)
+    bw, ls, n = float(g["bw"]), bool(int(g["log_space"])), int(g["n_steps"])
+    m = MpfContext(g["x0"], g["obs0"], model=kind, uncertain_params=up, log_space=ls, obs_std=float(g["obs_std"]), lr=float(g["lr"]),
+                   init_bw=bw, grid=grid_4x4_map() if kind == "particle" else None, mass=2.0 if kind == "particle" else 1.0,
+                   optimizer="Adam" if name.endswith("adam") else "SGD")
+    gn = m.optimize(g["action"], g["obs1"], bw, n)
+    assert elemerr(m.get_particles(), g["x_final"]) < TOL
+    assert relerr(gn, g["grad_norms"]) < 2e-4
+    gn2 = m.optimize(g["action2"], g["obs2"], bw, n)
+    assert elemerr(m.get_particles(), g["x_final2"]) < TOL
+    assert relerr(gn2, g["grad_norms2"]) < 2e-4
+    assert m.stats() == {"grid": 2, "fallback": 0}
+
+
+@pytest.mark.parametrize("kind,Mp,opt,hook", [("pendulum", 256, "SGD", None), ("pendulum", 130, "Adam", None), ("particle", 128, "SGD", None),
+                                              ("pendulum", 1024, "SGD", None), ("pendulum", 1021, "Adam", None),
+                                              ("pendulum", 256, "Adam", "1"), ("pendulum", 200, "SGD", "2")])
+def test_mpf_multi_workgroup_kernel_vs_single(kind, Mp, opt, hook, monkeypatch):
+    """From 192 particles on MPF.optimize runs spread over the chip; the single-workgroup kernel (DUST_MPF_GRID=0) does the same
+    arithmetic per particle and sums in another fixed order.  Two filter updates each; ragged particle counts; both optimisers.
+    hook 1 / 2: the grid form aborts at its start barrier / one of its waits "gives up" before the last hand-off - nothing is
+    committed, the single-workgroup kernel runs the call, the caller sees DUST_OK and the same numbers."""
+    from dust_amd import MpfContext
+    from oracle import grid_4x4_map
+
+    rng = np.random.default_rng(Mp)
+    pend = kind == "pendulum"
+    up = ("length", "mass") if pend else ("mass",)
+    x0 = (1.0 + 0.2 * rng.standard_normal((Mp, len(up)))).astype(np.float32)
+    obs = [np.array([3.0, 0.0], np.float32), np.array([3.02, 0.41], np.float32), np.array([3.08, 0.93], np.float32)] if pend else \
+          [np.array([0.0, 0.0, 0.0, 0.0], np.float32), np.array([0.001, 0.002, 0.05, 0.1], np.float32), np.array([0.004, 0.01, 0.1, 0.2], np.float32)]
+    acts = [np.array([1.0], np.float32), np.array([-0.5], np.float32)] if pend else [np.array([1.0, 2.0], np.float32), np.array([1.0, 2.0], np.float32)]
+    out = []
+    for grid in ("0", None):
+        monkeypatch.delenv("DUST_MPF_GRID", raising=False)
+        monkeypatch.delenv("DUST_MPF_GRID_TEST", raising=False)
+        monkeypatch.setenv("DUST_MPF_GRID", grid or "1")  # (1: the grid form whatever the particle count; its default starts at 192)
+        if grid is None and hook:
+            monkeypatch.setenv("DUST_MPF_GRID_TEST", hook)
+        m = MpfContext(x0, obs[0], model=kind, uncertain_params=up, obs_std=0.1, lr=1e-3, init_bw=0.1, optimizer=opt,
+                       grid=None if pend else grid_4x4_map(), mass=1.0)
+        gn1 = m.optimize(acts[0], obs[1], 0.1, 20)
+        x1 = m.get_particles()
+        gn2 = m.optimize(acts[1], obs[2], 0.12, 7)
+        out.append((x1, m.get_particles(), gn1, gn2, m.stats()))
+        m.close()
+    (a1, a2, ga1, ga2, sa), (b1, b2, gb1, gb2, sb) = out
+    assert sa == {"grid": 0, "fallback": 0}
+    # hook 2 ("a wait gave up") takes the context off the grid form for good: the second call does not try it again
+    assert sb == ({"grid": 2, "fallback": 0} if hook is None else {"grid": 2, "fallback": 2} if hook == "1" else {"grid": 1, "fallback": 1}), sb
+    if hook:
+        assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(ga1, gb1)
+    else:
+        assert np.isfinite(b2).all()
+        assert elemerr(b1, a1) < 1e-5 and elemerr(b2, a2) < 1e-5, (elemerr(b1, a1), elemerr(b2, a2))
+        assert relerr(gb1, ga1) < 1e-5 and relerr(gb2, ga2) < 1e-5
 
 
 def _skid_ctx(g, N, S, M, H, up=(), **kw):
