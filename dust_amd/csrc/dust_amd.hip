@@ -1056,6 +1056,19 @@ static bool states_whole_lines_pend(const dust_ctx *c, const SampleOpts &o, cons
   return true;
 }
 
+// ... and the binary16 form of the Pendulum states (DUST_STORE_F16): 32-particle groups of 4 (H+1)-byte rows
+static bool states_whole_lines_pend_f16(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, size_t *lds_out) {
+  const char *env = getenv("DUST_STATES_FORM");
+  if (env && atoi(env) == 0) return false;
+  if (c->cfg.model != DUST_MODEL_PENDULUM || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
+  if (!o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
+  if ((c->N % 32) || (c->n0 % 32) || (c->nloc % 32)) return false;
+  const size_t lds = pendulum_states_f16_lds_bytes(c->D, c->M, c->H);
+  if (lds > 80 * 1024) return false;
+  *lds_out = lds;
+  return true;
+}
+
 static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
   SampleOpts o = o_in;
   RolloutArgs a;
@@ -1141,6 +1154,24 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
         }
         pendulum_states_kernel<false><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);
         pendulum_states_kernel<true><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);  // flagged workgroups only
+        HIP_TRY(hipGetLastError());
+      }
+      o.want_states = false;
+      o.costs_in = c->costs_stage;
+      o.costs_own = true;
+      TRY(rollout_args(c, o, a, &nt, &lds));
+    } else if (states_whole_lines_pend_f16(c, o, a, &lds_s)) {
+      {
+        Prof ps(c, DUST_K_ROLLOUT_STATES);
+        const int blocks = (c->nloc / 32) * ((c->S + 7) / 8);
+        TRY(ensure(&c->wg_flags, &c->wg_flags_cap, (size_t)blocks));
+        unsigned int *fl = reinterpret_cast<unsigned int *>(c->wg_flags);
+        if (lds_s > 64 * 1024 && !c->capturing) {
+          HIP_TRY(hipFuncSetAttribute((const void *)pendulum_states_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+          HIP_TRY(hipFuncSetAttribute((const void *)pendulum_states_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+        }
+        pendulum_states_f16_kernel<false><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);
+        pendulum_states_f16_kernel<true><<<blocks, 256, lds_s, c->stream>>>(a, c->costs_stage, fl);  // flagged workgroups only
         HIP_TRY(hipGetLastError());
       }
       o.want_states = false;

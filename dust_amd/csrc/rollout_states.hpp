@@ -462,6 +462,137 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
   }
 }
 
+// =====================================================================================================================
+// Pendulum family, binary16 states (DUST_STORE_F16; the arithmetic stays fp32): a state is 4 bytes and a trajectory 4 (H+1) bytes
+// (124 at H = 30) - SHORTER than a line, so no line of the output is complete before the trajectories end and there is nothing to
+// stream.  A wave rolls out 2 samples x 32 ADJACENT particles: per sample 32 rows of 4 (H+1) bytes = H+1 whole lines, line-aligned
+// because N and the group's first particle are multiples of 32.  Every lane writes its rows into an LDS IMAGE of that output block
+// (row stride H+1 words: conflict-free when H+1 is odd) and the wave copies the image out in whole-wave 16-byte stores: 2 (H+1)
+// whole lines per dynamics sample, nothing partial, nothing written twice.  A workgroup = 8 samples x 32 particles.
+// GENERAL as above.
+template <bool GENERAL>
+__global__ void __launch_bounds__(256, 2) pendulum_states_f16_kernel(const RolloutArgs a, float *costs_sn, unsigned int *wg_flags) {
+  if (GENERAL && wg_flags[blockIdx.x] == 0u) return;
+  extern __shared__ float lds[];
+  const int S = a.S, D = a.D, H = a.H, N = a.N_total, M = a.M, Hp1 = H + 1;
+  const int Dp = D | 1;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+  const int nblk = (int)gridDim.x / ((S + 7) >> 3);
+  const int nb = blockIdx.x % nblk, sb = blockIdx.x / nblk;
+  const int n_first = a.n0 + nb * 32;
+  float *tile = lds;               // [256][Dp] action rows, row = tid
+  float *coefs = tile + 256 * Dp;  // [M][2]
+  float *flags = coefs + 2 * M;    // [4]
+  const int off_img = ((int)((flags + 4) - lds) + 3) & ~3;
+  uint32_t *const img = reinterpret_cast<uint32_t *>(lds + off_img) + (size_t)w * 64 * Hp1;  // [2 samples][32 particles][H+1] packed states
+  if (tid == 0) flags[0] = 0.f;
+  const float x0[2] = {a.state[0], a.state[1]};
+  wg_sync();
+  bool bad = false;
+  for (int m = tid; m < M; m += nt) {
+    Coef cf;
+    if (a.coef_given) {
+      cf.c0 = a.coef_host[0];
+      cf.c1 = a.coef_host[1];
+    } else {
+      cf = make_coef(a.dm, a.params ? a.params + (size_t)m * a.dm.P : nullptr);
+    }
+    coefs[2 * m] = cf.c0;
+    coefs[2 * m + 1] = cf.c1;
+    bad |= !(fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f);
+  }
+  for (int idx = tid; idx < 256 * D; idx += nt) {
+    const int row = (int)__umulhi((uint32_t)idx, a.magicD), k = idx - row * D;
+    const int s = min(sb * 8 + (row >> 6) * 2 + ((row & 63) >> 5), S - 1), n = n_first + (row & 31);
+    const float e = a.noise[((size_t)s * N + n) * D + k];
+    const float thk = a.noise_mode == NOISE_EPS ? a.theta[(size_t)n * D + k] : 0.f;
+    const float lk = a.noise_mode == NOISE_EPS ? a.chol_a[0] : 1.f;
+    const float av = thk + lk * e;
+    tile[row * Dp + k] = av;
+    bad |= av != av;
+  }
+  if (bad) flags[0] = 1.f;
+  wg_sync();
+  const bool fast = flags[0] == 0.f && fabsf(x0[1]) <= 3.0e38f && (fabsf(x0[0]) + a.dm.max_speed_pend * (float)a.dm.dt * (float)H < 5.0e4f);
+  if (!GENERAL) {
+    if (tid == 0) wg_flags[blockIdx.x] = fast ? 0u : 1u;
+    if (!fast) return;
+  }
+  const int j = lane & 31, ssub = lane >> 5;
+  const int s = sb * 8 + w * 2 + ssub;
+  const bool live = s < S;
+  uint32_t *const my = img + lane * Hp1;
+  const float *actl = tile + tid * Dp;
+  const float dt = (float)a.dm.dt, mt = a.dm.max_torque, ms = a.dm.max_speed_pend;
+  const v2f W = {a.dm.w_cos, a.dm.w_vel};
+  const uint32_t rowb = 4u * (uint32_t)Hp1;
+  const int pieces = 16 * Hp1;  // 16-byte pieces of the wave's image: 2 samples x (H+1) lines x 8
+  double acc = 0.0;
+  for (int m = 0; m < M; ++m) {
+    Coef cf;
+    cf.c0 = coefs[2 * m];
+    cf.c1 = coefs[2 * m + 1];
+    float x[2] = {x0[0], x0[1]};
+    double tot = 0.0;
+    auto emit = [&](const int row) {
+      const _Float16 h[2] = {(_Float16)x[0], (_Float16)x[1]};
+      my[row] = *reinterpret_cast<const uint32_t *>(h);
+    };
+    emit(0);
+#pragma unroll 2
+    for (int t = 0; t < H; ++t) {
+      const float at[1] = {actl[t]};
+      if (GENERAL) {
+        tot += (double)step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+      } else {
+        float sn, cs;
+        pendulum_trig(x[0], &sn, &cs);
+        v2f qv = {cs - 1.0f, x[1]};
+        qv = W * (qv * qv);
+        tot += (double)(qv.x + qv.y);
+        const float u = __builtin_amdgcn_fmed3f(at[0], -mt, mt);
+        float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
+        thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
+        x[0] = x[0] + thd * dt;
+        x[1] = thd;
+      }
+      emit(t + 1);
+    }
+    float traj;
+    if (GENERAL) {
+      traj = (float)tot + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
+    } else {
+      float sn, cs;
+      pendulum_trig(x[0], &sn, &cs);
+      v2f qv = {cs - 1.0f, x[1]};
+      qv = W * (qv * qv);
+      traj = (float)tot + (qv.x + qv.y);
+    }
+    acc += (double)traj;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int P = lane; P < pieces; P += 64) {
+      const int ss = P >= 8 * Hp1 ? 1 : 0, pc = P - ss * 8 * Hp1;
+      const int sg = sb * 8 + w * 2 + ss;
+      const v4f pv = *reinterpret_cast<const v4f *>(img + 4 * P);
+      if (sg < S)
+        *reinterpret_cast<v4f *>(reinterpret_cast<char *>(a.states_out) + (((size_t)m * S + sg) * N + n_first) * rowb + (size_t)pc * 16) = pv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (live) {
+    const float cost = M == 1 ? (float)acc : (float)(acc / M);
+    costs_sn[(size_t)s * N + n_first + j] = cost;
+    a.costsT[(size_t)(n_first + j) * S + s] = cost;
+  }
+}
+
+static inline size_t pendulum_states_f16_lds_bytes(int D, int M, int H) {
+  const size_t floats = (size_t)256 * (D | 1) + 2 * (size_t)M + 4 + 4;
+  return floats * sizeof(float) + (size_t)4 * 64 * (H + 1) * 4 + 16;
+}
+
 static inline size_t pendulum_states_lds_bytes(int D, int M) {
   const size_t floats = (size_t)256 * (D | 1) + 2 * (size_t)M + 4 + 4;
   return floats * sizeof(float) + (size_t)4 * 64 * SG_ROW + 16;

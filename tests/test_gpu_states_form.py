@@ -156,3 +156,75 @@ def test_pendulum_whole_line_states_general_path_and_fallbacks():
         costs, states, _, used, _ = out["1"]
         assert not used
         assert relerr(states, ref_states) < TOL and relerr(costs, ref_costs) < TOL
+
+
+def _run_pend_f16(N, S, M, H, poison=None, seed=0):
+    from dust_amd import Context
+    from oracle import Oracle
+
+    rng = np.random.default_rng(seed + 7 * N + S)
+    up = ("length", "mass") if M > 1 else None
+    kw = dict(model="pendulum", N=N, S=S, M=M, H=H, uncertain_params=up)
+    actions = (1.5 * rng.standard_normal((S, N, H, 1))).astype(np.float32)
+    if poison is not None:
+        actions[poison] = np.nan
+    params = None if up is None else rng.uniform(0.6, 1.4, (M, 2)).astype(np.float32)
+    st = np.array([3.0, -0.4], np.float32)
+    ref_costs, ref_states = Oracle(**kw).rollout_cost(st, actions, params, want_states=True)
+    out = {}
+    for form in ("1", "0"):
+        os.environ["DUST_STATES_FORM"] = form
+        try:
+            c = Context(kernel="K1", sigma_a=2.0, sigma_p=2.0, **kw)
+            c.set_a_mat(np.zeros((N, H, 1), np.float32))
+            c.profile(True)
+            costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True, store_f16=True)
+            used = "states_kernel" in c.profile_get()
+            c.set_a_mat(np.zeros((N, H, 1), np.float32))
+            lean_costs = c.disco_forward(st, actions, params, want_states=False)[0]
+            c.close()
+        finally:
+            os.environ.pop("DUST_STATES_FORM", None)
+        out[form] = (costs, states, omega, used, lean_costs)
+    return ref_costs, ref_states, out
+
+
+@pytest.mark.parametrize("N,S,M,H", [
+    (32, 8, 1, 30),    # cfg2's horizon: 124-byte rows, 31 lines per 32-particle group
+    (64, 21, 3, 16),   # ragged S, three dynamics samples in sequence
+    (64, 128, 8, 30),  # cfg5's S / M / H ("fp16 rollout")
+    (32, 5, 2, 37),    # H + 1 even: two-way LDS conflicts in the image, same bytes
+    (96, 9, 1, 5),
+])
+def test_pendulum_binary16_whole_line_states_vs_oracle_and_staged_kernel(N, S, M, H):
+    """DUST_STORE_F16 (cfg5's "fp16 rollout": storage only, fp32 arithmetic) through the whole-line form: a trajectory is 4 (H+1)
+    bytes, shorter than a line, so a wave images 2 samples x 32 adjacent particles in LDS and copies H+1 whole lines per sample out.
+    States: the oracle's fp32 states rounded to binary16 (one ulp of slack, plus the fp32 difference underneath), and the staged
+    kernel's halves up to the same; costs bit-equal to the rollout kernel without stored states."""
+    ref_costs, ref_states, out = _run_pend_f16(N, S, M, H)
+    costs, states, omega, used, lean = out["1"]
+    costs0, states0, omega0, used0, _ = out["0"]
+    assert used and not used0
+    assert states.dtype == np.float16 and states.shape == ref_states.shape
+    assert relerr(costs, ref_costs) < TOL and np.array_equal(costs, lean)
+    ref16 = ref_states.astype(np.float16).astype(np.float32)
+    s32, s032 = states.astype(np.float32), states0.astype(np.float32)
+    # one binary16 ulp, plus the fp32 difference underneath (branch-free trig path vs reference-order steps: 2e-6 of the largest
+    # state, the bound of the fp32 test above - it shows where a velocity passes through zero)
+    ulp16 = np.maximum(np.abs(ref16), 2.0 ** -14) * 2.0 ** -10 + 2e-6 * np.abs(ref_states).max()
+    assert np.all(np.abs(s32 - ref16) <= ulp16) and np.mean(s32 != ref16) < 1e-3
+    assert np.all(np.abs(s32 - s032) <= ulp16) and np.mean(s32 != s032) < 1e-3
+    assert relerr(costs, costs0) < 2e-6 and relerr(omega, omega0) < 1e-4
+
+
+def test_pendulum_binary16_whole_line_states_general_path_and_fallbacks():
+    ref_costs, ref_states, out = _run_pend_f16(32, 8, 2, 20, poison=(2, 7, 3, 0))  # one workgroup: all of it takes the general instance
+    costs, states, _, used, _ = out["1"]
+    costs0, states0, _, _, _ = out["0"]
+    assert used
+    assert np.array_equal(np.isnan(states), np.isnan(ref_states))
+    assert np.array_equal(states, states0, equal_nan=True) and np.array_equal(costs, costs0, equal_nan=True)
+    ref_costs, ref_states, out = _run_pend_f16(48, 8, 1, 30)  # N % 32 != 0: the staged kernel
+    costs, states, _, used, _ = out["1"]
+    assert not used
+    assert relerr(states.astype(np.float32), ref_states) < 2e-3 and relerr(costs, ref_costs) < TOL

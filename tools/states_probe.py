@@ -42,4 +42,5 @@ if __name__ == "__main__":
     run("particle", 4096, 64, 64, 40, True)
     run("particle", 4096, 64, 64, 40, True, f16=True)
     run("pendulum", 8192, 128, 8, 30, True)
+    run("pendulum", 8192, 128, 8, 30, True, f16=True)
     run("pendulum", 8192, 128, 8, 30, False)
