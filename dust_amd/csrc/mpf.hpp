@@ -360,6 +360,30 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
     if (lead) __hip_atomic_fetch_add(lines + (i & 15) * MPF_G_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+  // likelihood score of this wave's particle (mpf.py:46-50, likelihoods.py:30-49): one model step and its Jacobian, on lane 0 - 2.5 us.
+  // It depends on the particle alone, so the term of step it + 1 is computed behind the particle store of step it, under the hop.
+  double glik[4] = {0, 0, 0, 0};
+  auto lik = [&](const float *xp) {
+    float pred[4];
+    for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
+    const Coef cf = make_coef(a.dm, xp);
+    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
+    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+    double J[4][4];
+    step_jacobian<P>(a.dm, a.past_obs, a.past_action, xp, J);
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      double gl = 0.0;
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)
+        if (k < a.ds) gl += J[k][p] * ((double)a.obs[k] - (double)pred[k]);
+      glik[p] = gl * inv_obs2;
+    }
+  };
+  if (lead) {
+    float x0v[4] = {0.f, 0.f, 0.f, 0.f};
+    _Pragma("unroll") for (int p = 0; p < P; ++p) x0v[p] = xs[i * P + p];
+    lik(x0v);
+  }
+
   for (int it = 0; it < a.n_steps; ++it) {
     float xi[4] = {0.f, 0.f, 0.f, 0.f};
     if (on) {
@@ -378,24 +402,9 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
       }
       zs = wave_sum_f64(zs);
       _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] = wave_sum_f64(acc[p]);
-      if (lane == 0) {
-        double s[4];
-        _Pragma("unroll") for (int p = 0; p < P; ++p) s[p] = acc[p] / zs * inv_pbw2[p];
-        float pred[4];
-        for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
-        const Coef cf = make_coef(a.dm, xi);
-        if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
-        else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
-        double J[4][4];
-        step_jacobian<P>(a.dm, a.past_obs, a.past_action, xi, J);
-        _Pragma("unroll") for (int p = 0; p < P; ++p) {
-          double gl = 0.0;
-          _Pragma("unroll") for (int k = 0; k < 4; ++k)
-            if (k < a.ds) gl += J[k][p] * ((double)a.obs[k] - (double)pred[k]);
-          s[p] += gl * inv_obs2;
-          st_sc1(g.scg + ((size_t)(it & 1) * Mp + i) * P + p, (float)s[p]);
-        }
-      }
+      if (lane == 0)
+        _Pragma("unroll") for (int p = 0; p < P; ++p)
+            st_sc1(g.scg + ((size_t)(it & 1) * Mp + i) * P + p, (float)(acc[p] / zs * inv_pbw2[p] + glik[p]));
     }
     arrive(cnt_sc);
     poll(cnt_sc, (unsigned int)(it + 1));
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
     }
     if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     arrive(cnt_x);
+    if (lead && it + 1 < a.n_steps) lik(xn);
     poll(cnt_x, (unsigned int)(it + 1));
     if (it + 1 < a.n_steps) {
       for (int j = tid; j < Mp; j += MPF_G_NT) {
@@ -536,6 +546,7 @@ struct dust_mpf {
   float *gbuf;            // xg [2][Mp][P] | scg [2][Mp][P] | n2g [gsteps][Mp]
   unsigned int *gcnt;     // counters (zeroed per launch) followed by the 4 status words
   int gsteps;             // rows of n2g allocated
+  float *hpin;            // pinned host staging: gradient norms [4096] + status words
   bool grid_banned;       // a wait of the grid form timed out once (device shared with another process): single-workgroup kernel from then on
   long long n_grid, n_grid_fallback;
 };
@@ -562,6 +573,7 @@ extern "C" void dust_mpf_destroy(dust_mpf *m) {
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (m->grid_bits) (void)hipFree(m->grid_bits);
+  if (m->hpin) (void)hipHostFree(m->hpin);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -673,8 +685,8 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
 
 enum { MPF_GCNT_WORDS = (2 * dust::MPF_G_NSH + 2) * dust::MPF_G_LINE };
 // Whether this call takes the multi-workgroup kernel: an optimisation of >= 2 steps over >= 192 particles - measured, us per 20-step
-// call, grid / single workgroup: M_p = 128: 378 / 284, 256: 413 / 797, 512: 562 / 2 927, 1024: 885 / 11 433 (the grid form pays
-// ~7 us per step for its two hand-offs and 2.5 us for the likelihood term on one lane; the single workgroup ~M_p^2).
+// call, grid / single workgroup: M_p = 128: 378 / 284, 256: 363 / 797, 512: 498 / 2 927, 1024: 757 / 11 433 (the grid form pays
+// ~7 us per step for its two hand-offs; the single workgroup ~M_p^2).
 // DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests).
 static bool mpf_grid_ok(const dust_mpf *m, int n_steps, bool optimise) {
   if (!optimise || n_steps < 2 || m->grid_banned) return false;
@@ -779,10 +791,16 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   const bool grid = mpf_grid_ok(m, n_steps, true);
   TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, grid));
+  const bool want_gn = grad_norms && n_steps > 0;
+  if (!m->hpin) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->hpin), (4096 + 8) * sizeof(float), hipHostMallocDefault));
+  bool gn_read = false;
   if (grid) {  // did the grid form start, and did it commit?  (tick2.hpp's protocol; this call is synchronous anyway)
-    unsigned int st[3] = {0u, 0u, 0u};
-    HIP_TRY(hipMemcpyAsync(st, m->gcnt + MPF_GCNT_WORDS, sizeof st, hipMemcpyDeviceToHost, m->stream));
+    // status and gradient norms come back through pinned memory behind ONE synchronisation
+    unsigned int *st = reinterpret_cast<unsigned int *>(m->hpin + 4096);
+    HIP_TRY(hipMemcpyAsync(st, m->gcnt + MPF_GCNT_WORDS, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, m->stream));
+    if (want_gn) HIP_TRY(hipMemcpyAsync(m->hpin, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    gn_read = want_gn;
     m->n_grid++;
     if (st[0] | st[1] | st[2]) {
       HIP_TRY(hipMemsetAsync(m->gcnt + MPF_GCNT_WORDS, 0, 4 * sizeof(unsigned int), m->stream));
@@ -792,15 +810,17 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
       if (st[1] || st[2]) {  // nothing was written: the single-workgroup kernel runs the call
         m->n_grid_fallback++;
         TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, false));
+        gn_read = false;
       }
     }
   }
   if (m->optimizer == DUST_OPT_ADAM) m->adam_t += n_steps;
   for (int p = 0; p < 4; ++p) m->prior_bwv[p] = bw;  // update_prior(bw) mpf.py:85
-  if (grad_norms && n_steps > 0) {
-    HIP_TRY(hipMemcpyAsync(grad_norms, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  if (!gn_read) {
+    if (want_gn) HIP_TRY(hipMemcpyAsync(m->hpin, m->gn, n_steps * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
   }
-  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (want_gn) memcpy(grad_norms, m->hpin, n_steps * sizeof(float));
   return DUST_OK;
 }
 
