@@ -484,6 +484,287 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
     }
 }
 
+// ---- the same grid with a DATA-POLLED exchange (up to 512 particles; DUST_MPF_POLL=0 switches it off) --------------------------------
+// Rows cross as 16-byte pieces {tag, v0, v1, tag}: the owner's lane 0 writes each with ONE write-through store; every lane re-loads
+// the pieces of ITS keys (sc1 loads, all in flight at once) until both tag words are this step's.  A piece is written by one aligned
+// 16-byte store and the tag sits in its first AND last word, so a reader that finds both has the words between them.  No counters, no
+// polling wave, no LDS copy, no workgroup barrier in the loop - a hop costs one store-to-load round trip (2.4 us against 5.0 for
+// counter + data in tools/allgather_probe.hip); keys live in registers (KC = 4 or 8 per lane).  Tags are unique per launch and step
+// (launch number x 8192 + 2 step + 1 | 2, kept to bit patterns of normal floats), pieces alternate between two buffers by step
+// parity: an owner overwrites the piece of two steps ago only after it has seen every other owner's piece of the step in between,
+// i.e. after everybody finished reading the old one.  The likelihood term of the NEXT step is computed behind the particle store,
+// under the hop.  Start barrier (monotonic counter, no memset per call), bounded waits, commit and fallback as above.
+// Two traps met on the way: (i) scalars kept live across the one-lane start code came out wrong in the wave that ran it - everything
+// below the barrier is derived from opaque copies of the arguments; (ii) `.y` / `.z` of the loaded vector were folded to `.x` by the
+// compiler inside the `x == tag && w == tag` branch (ISA: v_mov v3, v2) - the words are taken out through memcpy.
+struct MpfPollArgs {
+  MpfArgs a;
+  float *xpc;            // [2][Mp][NP + 1] pieces: NP pieces of particle values, then {tag, |phi_i|^2, 0, tag}
+  float *scp;            // [2][Mp][NP] pieces of scores
+  unsigned int *cnt;     // [0] start arrivals (monotonic over launches) [32] go word = launch << 2 | 1 (go) / 2 (abort)
+  unsigned int *status;
+  unsigned int tag0, seq;
+  int test;
+};
+
+template <int P, int KC>
+__global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPollArgs g) {
+  constexpr int NP = (P + 1) / 2, NX = NP + 1;
+  __shared__ unsigned int sig[2];
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  // ---- start barrier (one lane per workgroup)
+  if (tid == 0) {
+    const int G = (int)gridDim.x;
+    unsigned int *cnt_start = g.cnt, *go = g.cnt + MPF_G_LINE;
+    __hip_atomic_fetch_add(cnt_start, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int v = 0u;
+    if (blockIdx.x == 0) {
+      const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+      bool ok = true;
+      while ((int)(__hip_atomic_load(cnt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq * (unsigned int)G) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t_start > 20000ull) {
+          ok = false;
+          break;
+        }
+      }
+      ok = ok && __hip_atomic_load(g.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && g.test != 1;
+      if (!ok) __hip_atomic_fetch_add(g.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = ok ? 1u : 2u;
+      __hip_atomic_store(go, (g.seq << 2) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned int spins = 0u;
+      unsigned long long t_start = 0;
+      for (;;) {
+        const unsigned int w = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((w >> 2) == g.seq) {
+          v = w & 3u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0u) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (!t_start) t_start = now;
+          else if (now - t_start > DUST_SPIN_TIMEOUT_TICKS) {
+            __hip_atomic_store(g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = 2u;
+            break;
+          }
+        }
+      }
+    }
+    sig[0] = v;
+  }
+  wg_sync();
+  if (sig[0] != 1u) return;
+  // everything below is derived AFTER the barrier from opaque copies of the arguments (nothing scalar lives across the start code)
+  const MpfArgs &a = g.a;
+  const int Mp = opaque_s(a.Mp), wave = opaque_s(__builtin_amdgcn_readfirstlane(tid >> 6));
+  const int G = (int)gridDim.x, b = (int)blockIdx.x, i = b * MPF_G_WAVES + wave;
+  unsigned int *tflag = g.status;
+  const unsigned int tag0 = (unsigned int)opaque_s((int)g.tag0);
+  const bool on = i < Mp;
+  const int io = on ? i : 0;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(g.xpc, 0, 2 * Mp * NX * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(g.scp, 0, 2 * Mp * NP * 16, 0x00020000);
+  typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+  float xk[KC][P], sk[KC][P], nk[KC], n2k[KC];
+  // poll NQ pieces per key of buffer r (row stride RS pieces) until both tag words match; values land in o0 / o1
+  auto poll = [&](const __amdgpu_buffer_rsrc_t r, const int rs_pieces, const int nq, const int parity, const unsigned int tag, float (*o0)[NX],
+                  float (*o1)[NX]) {
+    unsigned int pt[KC][NX];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int q = 0; q < NX; ++q) pt[c][q] = (q < nq && lane + 64 * c < Mp) ? 0u : 1u;  // 1: done / nothing to see
+    unsigned int spins = 0u;
+    unsigned long long t0 = 0;
+    for (;;) {
+      bool miss = false;
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+          if (pt[c][q] == 0u) {
+            const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(r, ((parity * Mp + lane + 64 * c) * rs_pieces + q) * 16, 0, 16);
+            unsigned int w[4];
+            __builtin_memcpy(w, &t, sizeof w);
+            if (w[0] == tag && w[3] == tag) {
+              o0[c][q] = __builtin_bit_cast(float, w[1]);
+              o1[c][q] = __builtin_bit_cast(float, w[2]);
+              pt[c][q] = 1u;
+            } else {
+              miss = true;
+            }
+          }
+      if (!__any(miss ? 1 : 0)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0u) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!t0) t0 = now;
+        else if (now - t0 > DUST_SPIN_TIMEOUT_TICKS || __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  };
+  auto put = [&](const __amdgpu_buffer_rsrc_t r, const int piece, const unsigned int tag, const float v0, const float v1) {
+    const v4u_t t = {tag, __builtin_bit_cast(unsigned int, v0), __builtin_bit_cast(unsigned int, v1), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, piece * 16, 0, 16);
+  };
+  auto norms = [&]() {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float nn = 0.f;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) nn = nn + xk[c][p] * xk[c][p];
+      nk[c] = nn;
+    }
+  };
+  const double inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
+  double glik[4] = {0, 0, 0, 0};
+  auto lik = [&](const float *xp) {
+    float pred[4];
+    for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
+    const Coef cf = make_coef(a.dm, xp);
+    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
+    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+    double J[4][4];
+    step_jacobian<P>(a.dm, a.past_obs, a.past_action, xp, J);
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      double gl = 0.0;
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)
+        if (k < a.ds) gl += J[k][p] * ((double)a.obs[k] - (double)pred[k]);
+      glik[p] = gl * inv_obs2;
+    }
+  };
+  float xi[4] = {0.f, 0.f, 0.f, 0.f};
+  _Pragma("unroll") for (int p = 0; p < P; ++p) xi[p] = a.x[io * P + p];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k = lane + 64 * c;
+    _Pragma("unroll") for (int p = 0; p < P; ++p) xk[c][p] = k < Mp ? a.x[k * P + p] : 0.f;
+    n2k[c] = 0.f;
+  }
+  norms();
+  const float bw2 = (float)((double)a.bw * (double)a.bw);
+  double inv_pbw[4], inv_pbw2[4];
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {
+    inv_pbw[p] = 1.0 / (double)a.prior_bwv[p < P ? p : 0];
+    inv_pbw2[p] = inv_pbw[p] * inv_pbw[p];
+  }
+  const double inv_bw2 = 1.0 / ((double)a.bw * (double)a.bw);
+  float am[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool adam = a.optimizer == DUST_OPT_ADAM;
+  if (adam && on)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      am[p] = a.adam_m[io * P + p];
+      av[p] = a.adam_v[io * P + p];
+    }
+  lik(xi);
+
+  for (int it = 0; it < a.n_steps; ++it) {
+    const unsigned int tag_s = 0x40000000u | ((tag0 + 2u * (unsigned int)it + 1u) & 0x3fffffffu), tag_x = 0x40000000u | ((tag0 + 2u * (unsigned int)it + 2u) & 0x3fffffffu);
+    {
+      double zs = 0.0, acc[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if (lane + 64 * c < Mp) {
+          double q = 0.0;
+          _Pragma("unroll") for (int p = 0; p < P; ++p) {
+            const double z = ((double)xi[p] - (double)xk[c][p]) * inv_pbw[p];
+            q += z * z;
+          }
+          const double w = (double)expf((float)(-0.5 * q));
+          zs += w;
+          _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] += w * ((double)xk[c][p] - (double)xi[p]);
+        }
+      zs = wave_sum_f64(zs);
+      _Pragma("unroll") for (int p = 0; p < P; ++p) acc[p] = wave_sum_f64(acc[p]);
+      float sv[4] = {0.f, 0.f, 0.f, 0.f};
+      _Pragma("unroll") for (int p = 0; p < P; ++p) sv[p] = (float)(acc[p] / zs * inv_pbw2[p] + glik[p]);
+      if (on && lane == 0)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) put(rs_s, ((it & 1) * Mp + i) * NP + q, tag_s, sv[2 * q], sv[2 * q + 1]);
+    }
+    {
+      float o0[KC][NX], o1[KC][NX];
+      poll(rs_s, NP, NP, it & 1, tag_s, o0, o1);
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        _Pragma("unroll") for (int p = 0; p < P; ++p) sk[c][p] = (p & 1) ? o1[c][p >> 1] : o0[c][p >> 1];
+    }
+    float xn[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
+      float ni = 0.f;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) ni = ni + xi[p] * xi[p];
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if (lane + 64 * c < Mp) {
+          float dot = xi[0] * xk[c][0];
+          _Pragma("unroll") for (int q = 1; q < P; ++q) dot = fmaf(xi[q], xk[c][q], dot);
+          float q = (nk[c] + (-2.0f * dot)) + ni;
+          q = fmaxf(q, 0.f);
+          const double k = (double)expf(((-q) / bw2) / 2.0f);
+          _Pragma("unroll") for (int p = 0; p < P; ++p) {
+            gk[p] -= k * ((double)xi[p] - (double)xk[c][p]);
+            ks[p] += k * (double)sk[c][p];
+          }
+        }
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        gk[p] = wave_sum_f64(gk[p]);
+        ks[p] = wave_sum_f64(ks[p]);
+      }
+      float ph[4] = {0.f, 0.f, 0.f, 0.f}, n2 = 0.f;
+      _Pragma("unroll") for (int p = 0; p < P; ++p) {
+        ph[p] = (float)(gk[p] * inv_bw2 + ks[p] / Mp);
+        n2 += ph[p] * ph[p];
+      }
+      _Pragma("unroll") for (int p = 0; p < P; ++p)
+        xn[p] = adam ? adam_step(xi[p], -ph[p], am[p], av[p], a.lr, a.beta1, a.beta2, a.eps, (float)(a.t0 + it + 1)) : fmaf(a.lr, ph[p], xi[p]);
+      if (on && lane == 0) {
+        const int row = (((it + 1) & 1) * Mp + i) * NX;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) put(rs_x, row + q, tag_x, xn[2 * q], xn[2 * q + 1]);
+        put(rs_x, row + NP, tag_x, n2, 0.f);
+        if (it == 0 && a.phi_out)
+          _Pragma("unroll") for (int p = 0; p < P; ++p) a.phi_out[i * P + p] = ph[p];
+      }
+    }
+    _Pragma("unroll") for (int p = 0; p < P; ++p) xi[p] = xn[p];
+    if (it + 1 < a.n_steps) lik(xi);  // (under the hop)
+    if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      float o0[KC][NX], o1[KC][NX];
+      poll(rs_x, NX, NX, (it + 1) & 1, tag_x, o0, o1);
+      double n2s = 0.0;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        _Pragma("unroll") for (int p = 0; p < P; ++p) xk[c][p] = lane + 64 * c < Mp ? ((p & 1) ? o1[c][p >> 1] : o0[c][p >> 1]) : 0.f;
+        if (lane + 64 * c < Mp) n2s += (double)o0[c][NP];
+      }
+      norms();
+      if (i == 0 && a.grad_norms) {
+        n2s = wave_sum_f64(n2s);
+        if (lane == 0) a.grad_norms[it] = sqrtf((float)n2s);
+      }
+    }
+  }
+  const unsigned int fl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (!on || lane != 0) return;
+  if (fl != 0u) {
+    __hip_atomic_fetch_add(g.status + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  _Pragma("unroll") for (int p = 0; p < P; ++p) a.x[i * P + p] = xi[p];
+  if (adam)
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {
+      a.adam_m[i * P + p] = am[p];
+      a.adam_v[i * P + p] = av[p];
+    }
+}
+
 struct MpfBw {
   float v[4];
 };
@@ -546,6 +827,9 @@ struct dust_mpf {
   float *gbuf;            // xg [2][Mp][P] | scg [2][Mp][P] | n2g [gsteps][Mp]
   unsigned int *gcnt;     // counters (zeroed per launch) followed by the 4 status words
   int gsteps;             // rows of n2g allocated
+  float *pbuf;            // data-polled form (experimental): particle pieces | score pieces
+  unsigned int *pcnt;     // ... its start counter and go word (monotonic over launches)
+  unsigned int pseq;
   float *hpin;            // pinned host staging: gradient norms [4096] + status words
   bool grid_banned;       // a wait of the grid form timed out once (device shared with another process): single-workgroup kernel from then on
   long long n_grid, n_grid_fallback;
@@ -569,7 +853,7 @@ extern "C" void dust_mpf_destroy(dust_mpf *m) {
   if (!m) return;
   (void)hipSetDevice(m->cfg.device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  float *fp[] = {m->x, m->gn, m->phi, m->tmp, m->adam_m, m->adam_v, m->gbuf, reinterpret_cast<float *>(m->gcnt)};
+  float *fp[] = {m->x, m->gn, m->phi, m->tmp, m->adam_m, m->adam_v, m->gbuf, reinterpret_cast<float *>(m->gcnt), m->pbuf, reinterpret_cast<float *>(m->pcnt)};
   for (float *p : fp)
     if (p) (void)hipFree(p);
   if (m->grid_bits) (void)hipFree(m->grid_bits);
@@ -684,15 +968,15 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
 }
 
 enum { MPF_GCNT_WORDS = (2 * dust::MPF_G_NSH + 2) * dust::MPF_G_LINE };
-// Whether this call takes the multi-workgroup kernel: an optimisation of >= 2 steps over >= 192 particles - measured, us per 20-step
-// call, grid / single workgroup: M_p = 128: 378 / 284, 256: 363 / 797, 512: 498 / 2 927, 1024: 757 / 11 433 (the grid form pays
-// ~7 us per step for its two hand-offs; the single workgroup ~M_p^2).
-// DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests).
+// Whether this call takes a multi-workgroup kernel: an optimisation of >= 2 steps over >= 96 particles - measured, us per 20-step call
+// (profiles/round3_mpf_time.txt): single workgroup 64: 151, 96: 231, 128: 270, 256: 797, 512: 2 927, 1024: 11 433; data-polled grid
+// (up to 512 particles) 64: 163, 96: 185, 128: 182, 256: 208, 512: 408; counter grid 256: 363, 512: 498, 1024: 757.
+// DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests); DUST_MPF_POLL=0: the counter form at every size.
 static bool mpf_grid_ok(const dust_mpf *m, int n_steps, bool optimise) {
   if (!optimise || n_steps < 2 || m->grid_banned) return false;
   const char *env = getenv("DUST_MPF_GRID");
   if (env && atoi(env) == 0) return false;
-  return m->Mp >= ((env && atoi(env) == 1) ? 8 : 192);
+  return m->Mp >= ((env && atoi(env) == 1) ? 8 : 96);
 }
 
 static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true, bool grid = false) {
@@ -727,6 +1011,46 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.eps = m->adam_eps;
   a.adam_m = m->adam_m;
   a.adam_v = m->adam_v;
+  // the data-polled form (keys in registers: up to 512 particles) unless DUST_MPF_POLL=0; above that the counter form
+  if (grid && m->Mp <= 512 && !(getenv("DUST_MPF_POLL") && atoi(getenv("DUST_MPF_POLL")) == 0)) {
+    const int NP = (m->P + 1) / 2, NX = NP + 1;
+    const size_t fx = (size_t)2 * m->Mp * NX * 4, fs = (size_t)2 * m->Mp * NP * 4;  // floats
+    if (!m->pbuf) {
+      TRY(dalloc(&m->pbuf, fx + fs));
+      HIP_TRY(hipMemsetAsync(m->pbuf, 0, (fx + fs) * sizeof(float), m->stream));  // (tag 0 is never waited for)
+    }
+    if (!m->pcnt) {
+      TRY(dalloc(&m->pcnt, (size_t)2 * MPF_G_LINE));
+      HIP_TRY(hipMemsetAsync(m->pcnt, 0, (size_t)2 * MPF_G_LINE * sizeof(unsigned int), m->stream));
+    }
+    if (!m->gcnt) {
+      TRY(dalloc(&m->gcnt, (size_t)MPF_GCNT_WORDS + 4));
+      HIP_TRY(hipMemsetAsync(m->gcnt, 0, ((size_t)MPF_GCNT_WORDS + 4) * sizeof(unsigned int), m->stream));
+    }
+    MpfPollArgs g;
+    memset(&g, 0, sizeof g);
+    g.a = a;
+    g.xpc = m->pbuf;
+    g.scp = m->pbuf + fx;
+    g.cnt = m->pcnt;
+    g.status = m->gcnt + MPF_GCNT_WORDS;
+    g.seq = ++m->pseq;
+    g.tag0 = g.seq * 8192u;  // (n_steps <= 4096: 2 tags per step)
+    if (const char *t = getenv("DUST_MPF_GRID_TEST")) g.test = atoi(t);
+    const int G = (m->Mp + MPF_G_WAVES - 1) / MPF_G_WAVES;
+#define DUST_LAUNCH_MPFP(PP)                                                                       \
+  do {                                                                                              \
+    if (m->Mp <= 256) mpf_optimize_poll_kernel<PP, 4><<<G, MPF_G_NT, 0, m->stream>>>(g);            \
+    else mpf_optimize_poll_kernel<PP, 8><<<G, MPF_G_NT, 0, m->stream>>>(g);                         \
+  } while (0)
+    if (m->P == 1) DUST_LAUNCH_MPFP(1);
+    else if (m->P == 2) DUST_LAUNCH_MPFP(2);
+    else if (m->P == 3) DUST_LAUNCH_MPFP(3);
+    else DUST_LAUNCH_MPFP(4);
+#undef DUST_LAUNCH_MPFP
+    HIP_TRY(hipGetLastError());
+    return DUST_OK;
+  }
   if (grid) {
     const size_t np = (size_t)m->Mp * m->P;
     if (!m->gbuf || m->gsteps < n_steps) {

@@ -1189,15 +1189,17 @@ def test_mpf_initial_prior_from_bw_silverman(golden, name):
     assert relerr(mp.x.numpy(), g["x_final2"]) < 2 * tol_x and relerr(grads2.numpy(), g["grad_norms2"]) < 2e-4
 
 
+@pytest.mark.parametrize("form", ["poll", "counter"])
 @pytest.mark.parametrize("name", ["mpf_pend", "mpf_part_log", "mpf_pend_adam", "mpf_part_log_adam"])
-def test_mpf_multi_workgroup_kernel_vs_reference(golden, name, monkeypatch):
+def test_mpf_multi_workgroup_kernel_vs_reference(golden, name, form, monkeypatch):
     """The multi-workgroup form of MPF.optimize (mpf.hpp mpf_optimize_grid_kernel: one wave per particle, two grid-wide hand-offs per
-    step; the default from 192 particles on) against the reference's own filter updates - DUST_MPF_GRID=1 sends these small golden
+    step; the default from 96 particles on) against the reference's own filter updates - DUST_MPF_GRID=1 sends these small golden
     cases through it."""
     from dust_amd import MpfContext
     from oracle import grid_4x4_map
 
     monkeypatch.setenv("DUST_MPF_GRID", "1")
+    monkeypatch.setenv("DUST_MPF_POLL", "1" if form == "poll" else "0")
     g = golden(name)
     kind = str(g["model_kind"])
     up = ("length", "mass") if kind == "pendulum" else ("mass",)
@@ -1214,11 +1216,14 @@ def test_mpf_multi_workgroup_kernel_vs_reference(golden, name, monkeypatch):
     assert m.stats() == {"grid": 2, "fallback": 0}
 
 
-@pytest.mark.parametrize("kind,Mp,opt,hook", [("pendulum", 256, "SGD", None), ("pendulum", 130, "Adam", None), ("particle", 128, "SGD", None),
-                                              ("pendulum", 1024, "SGD", None), ("pendulum", 1021, "Adam", None),
-                                              ("pendulum", 256, "Adam", "1"), ("pendulum", 200, "SGD", "2")])
-def test_mpf_multi_workgroup_kernel_vs_single(kind, Mp, opt, hook, monkeypatch):
-    """From 192 particles on MPF.optimize runs spread over the chip; the single-workgroup kernel (DUST_MPF_GRID=0) does the same
+@pytest.mark.parametrize("kind,Mp,opt,hook,form", [
+    ("pendulum", 256, "SGD", None, "poll"), ("pendulum", 130, "Adam", None, "poll"), ("particle", 128, "SGD", None, "poll"),
+    ("pendulum", 500, "Adam", None, "poll"), ("pendulum", 41, "SGD", None, "poll"),
+    ("pendulum", 256, "SGD", None, "counter"), ("pendulum", 1024, "SGD", None, "counter"), ("pendulum", 1021, "Adam", None, "counter"),
+    ("pendulum", 256, "Adam", "1", "poll"), ("pendulum", 200, "SGD", "2", "poll"), ("pendulum", 200, "Adam", "2", "counter")])
+def test_mpf_multi_workgroup_kernel_vs_single(kind, Mp, opt, hook, form, monkeypatch):
+    """From 96 particles on MPF.optimize runs spread over the chip (up to 512 particles with the data-polled exchange, above with
+    arrival counters; `form` pins one of them); the single-workgroup kernel (DUST_MPF_GRID=0) does the same
     arithmetic per particle and sums in another fixed order.  Two filter updates each; ragged particle counts; both optimisers.
     hook 1 / 2: the grid form aborts at its start barrier / one of its waits "gives up" before the last hand-off - nothing is
     committed, the single-workgroup kernel runs the call, the caller sees DUST_OK and the same numbers."""
@@ -1236,7 +1241,8 @@ def test_mpf_multi_workgroup_kernel_vs_single(kind, Mp, opt, hook, monkeypatch):
     for grid in ("0", None):
         monkeypatch.delenv("DUST_MPF_GRID", raising=False)
         monkeypatch.delenv("DUST_MPF_GRID_TEST", raising=False)
-        monkeypatch.setenv("DUST_MPF_GRID", grid or "1")  # (1: the grid form whatever the particle count; its default starts at 192)
+        monkeypatch.setenv("DUST_MPF_GRID", grid or "1")  # (1: the grid form whatever the particle count; its default starts at 96)
+        monkeypatch.setenv("DUST_MPF_POLL", "1" if form == "poll" else "0")
         if grid is None and hook:
             monkeypatch.setenv("DUST_MPF_GRID_TEST", hook)
         m = MpfContext(x0, obs[0], model=kind, uncertain_params=up, obs_std=0.1, lr=1e-3, init_bw=0.1, optimizer=opt,
