@@ -494,9 +494,9 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
 // parity: an owner overwrites the piece of two steps ago only after it has seen every other owner's piece of the step in between,
 // i.e. after everybody finished reading the old one.  The likelihood term of the NEXT step is computed behind the particle store,
 // under the hop.  Start barrier (monotonic counter, no memset per call), bounded waits, commit and fallback as above.
-// Two traps met on the way: (i) scalars kept live across the one-lane start code came out wrong in the wave that ran it - everything
-// below the barrier is derived from opaque copies of the arguments; (ii) `.y` / `.z` of the loaded vector were folded to `.x` by the
-// compiler inside the `x == tag && w == tag` branch (ISA: v_mov v3, v2) - the words are taken out through memcpy.
+// A trap met on the way: `.y` / `.z` of the loaded vector were folded to `.x` by the compiler inside the `x == tag && w == tag` branch
+// (ISA: v_mov v3, v2) - the words are taken out through memcpy.  (Everything below the one-lane start code is derived from opaque
+// copies of the arguments; that was part of the same rewrite and is kept.)
 struct MpfPollArgs {
   MpfArgs a;
   float *xpc;            // [2][Mp][NP + 1] pieces: NP pieces of particle values, then {tag, |phi_i|^2, 0, tag}
