@@ -484,12 +484,12 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
     }
 }
 
-// ---- the same grid with a DATA-POLLED exchange (up to 512 particles; DUST_MPF_POLL=0 switches it off) --------------------------------
+// ---- the same grid with a DATA-POLLED exchange (the default; DUST_MPF_POLL=0 switches it off) ------------------------------------------
 // Rows cross as 16-byte pieces {tag, v0, v1, tag}: the owner's lane 0 writes each with ONE write-through store; every lane re-loads
 // the pieces of ITS keys (sc1 loads, all in flight at once) until both tag words are this step's.  A piece is written by one aligned
 // 16-byte store and the tag sits in its first AND last word, so a reader that finds both has the words between them.  No counters, no
 // polling wave, no LDS copy, no workgroup barrier in the loop - a hop costs one store-to-load round trip (2.4 us against 5.0 for
-// counter + data in tools/allgather_probe.hip); keys live in registers (KC = 4 or 8 per lane).  Tags are unique per launch and step
+// counter + data in tools/allgather_probe.hip); keys live in registers (KC = 4 / 8 / 16 per lane).  Tags are unique per launch and step
 // (launch number x 8192 + 2 step + 1 | 2, kept to bit patterns of normal floats), pieces alternate between two buffers by step
 // parity: an owner overwrites the piece of two steps ago only after it has seen every other owner's piece of the step in between,
 // i.e. after everybody finished reading the old one.  The likelihood term of the NEXT step is computed behind the particle store,
@@ -569,35 +569,42 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
   const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(g.scp, 0, 2 * Mp * NP * 16, 0x00020000);
   typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
   float xk[KC][P], sk[KC][P], nk[KC], n2k[KC];
-  // poll NQ pieces per key of buffer r (row stride RS pieces) until both tag words match; values land in o0 / o1
-  auto poll = [&](const __amdgpu_buffer_rsrc_t r, const int rs_pieces, const int nq, const int parity, const unsigned int tag, float (*o0)[NX],
-                  float (*o1)[NX]) {
-    unsigned int pt[KC][NX];
+  // poll the pieces of this lane's keys until both tag words match; the values go straight to their registers (SCORES: sk; else xk
+  // and, from the extra piece of a particle row, n2k); `done` is a bit mask over (key, piece)
+  auto poll = [&](auto scores, const __amdgpu_buffer_rsrc_t r, const int parity, const unsigned int tag) {
+    constexpr bool SC = decltype(scores)::value;
+    constexpr int RS = SC ? NP : NX;  // pieces per row
+    unsigned long long done = 0ull;
 #pragma unroll
     for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int q = 0; q < NX; ++q) pt[c][q] = (q < nq && lane + 64 * c < Mp) ? 0u : 1u;  // 1: done / nothing to see
+      if (!(lane + 64 * c < Mp)) done |= ((1ull << RS) - 1ull) << (c * RS);  // (nothing to see)
+    constexpr unsigned long long all = KC * RS >= 64 ? ~0ull : ((1ull << (KC * RS)) - 1ull);
     unsigned int spins = 0u;
     unsigned long long t0 = 0;
     for (;;) {
-      bool miss = false;
 #pragma unroll
       for (int c = 0; c < KC; ++c)
 #pragma unroll
-        for (int q = 0; q < NX; ++q)
-          if (pt[c][q] == 0u) {
-            const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(r, ((parity * Mp + lane + 64 * c) * rs_pieces + q) * 16, 0, 16);
+        for (int q = 0; q < RS; ++q)
+          if (!((done >> (c * RS + q)) & 1ull)) {
+            const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(r, ((parity * Mp + lane + 64 * c) * RS + q) * 16, 0, 16);
             unsigned int w[4];
             __builtin_memcpy(w, &t, sizeof w);
             if (w[0] == tag && w[3] == tag) {
-              o0[c][q] = __builtin_bit_cast(float, w[1]);
-              o1[c][q] = __builtin_bit_cast(float, w[2]);
-              pt[c][q] = 1u;
-            } else {
-              miss = true;
+              const float v0 = __builtin_bit_cast(float, w[1]), v1 = __builtin_bit_cast(float, w[2]);
+              if (SC) {
+                sk[c][2 * q < P ? 2 * q : 0] = v0;
+                if (2 * q + 1 < P) sk[c][2 * q + 1] = v1;
+              } else if (q < NP) {
+                xk[c][2 * q < P ? 2 * q : 0] = v0;
+                if (2 * q + 1 < P) xk[c][2 * q + 1] = v1;
+              } else {
+                n2k[c] = v0;
+              }
+              done |= 1ull << (c * RS + q);
             }
           }
-      if (!__any(miss ? 1 : 0)) break;
+      if (!__any(done != all ? 1 : 0)) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0u) {
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -687,13 +694,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
 #pragma unroll
         for (int q = 0; q < NP; ++q) put(rs_s, ((it & 1) * Mp + i) * NP + q, tag_s, sv[2 * q], sv[2 * q + 1]);
     }
-    {
-      float o0[KC][NX], o1[KC][NX];
-      poll(rs_s, NP, NP, it & 1, tag_s, o0, o1);
-#pragma unroll
-      for (int c = 0; c < KC; ++c)
-        _Pragma("unroll") for (int p = 0; p < P; ++p) sk[c][p] = (p & 1) ? o1[c][p >> 1] : o0[c][p >> 1];
-    }
+    poll(std::true_type{}, rs_s, it & 1, tag_s);
     float xn[4] = {0.f, 0.f, 0.f, 0.f};
     {
       double gk[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0};
@@ -736,14 +737,11 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
     if (it + 1 < a.n_steps) lik(xi);  // (under the hop)
     if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
-      float o0[KC][NX], o1[KC][NX];
-      poll(rs_x, NX, NX, (it + 1) & 1, tag_x, o0, o1);
+      poll(std::false_type{}, rs_x, (it + 1) & 1, tag_x);
       double n2s = 0.0;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        _Pragma("unroll") for (int p = 0; p < P; ++p) xk[c][p] = lane + 64 * c < Mp ? ((p & 1) ? o1[c][p >> 1] : o0[c][p >> 1]) : 0.f;
-        if (lane + 64 * c < Mp) n2s += (double)o0[c][NP];
-      }
+      for (int c = 0; c < KC; ++c)
+        if (lane + 64 * c < Mp) n2s += (double)n2k[c];
       norms();
       if (i == 0 && a.grad_norms) {
         n2s = wave_sum_f64(n2s);
@@ -967,11 +965,12 @@ extern "C" int dust_mpf_clone(const dust_mpf *src, dust_mpf **out) {
   return DUST_OK;
 }
 
+enum { MPF_POLL_MAX = 1024 };  // particles up to which the data-polled form is taken (A/B: 512 = counter form above)
 enum { MPF_GCNT_WORDS = (2 * dust::MPF_G_NSH + 2) * dust::MPF_G_LINE };
 // Whether this call takes a multi-workgroup kernel: an optimisation of >= 2 steps over >= 96 particles - measured, us per 20-step call
 // (profiles/round3_mpf_time.txt): single workgroup 64: 151, 96: 231, 128: 270, 256: 797, 512: 2 927, 1024: 11 433; data-polled grid
-// (up to 512 particles) 64: 163, 96: 185, 128: 182, 256: 208, 512: 408; counter grid 256: 363, 512: 498, 1024: 757.
-// DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests); DUST_MPF_POLL=0: the counter form at every size.
+// 64: 163, 96: 185, 128: 176, 256: 195, 512: 259, 1024: 400; counter grid 256: 363, 512: 498, 1024: 730.
+// DUST_MPF_GRID=0 / 1: never / from 8 particles on (tests); DUST_MPF_POLL=0: the counter form.
 static bool mpf_grid_ok(const dust_mpf *m, int n_steps, bool optimise) {
   if (!optimise || n_steps < 2 || m->grid_banned) return false;
   const char *env = getenv("DUST_MPF_GRID");
@@ -1012,7 +1011,7 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.adam_m = m->adam_m;
   a.adam_v = m->adam_v;
   // the data-polled form (keys in registers: up to 512 particles) unless DUST_MPF_POLL=0; above that the counter form
-  if (grid && m->Mp <= 512 && !(getenv("DUST_MPF_POLL") && atoi(getenv("DUST_MPF_POLL")) == 0)) {
+  if (grid && m->Mp <= MPF_POLL_MAX && !(getenv("DUST_MPF_POLL") && atoi(getenv("DUST_MPF_POLL")) == 0)) {
     const int NP = (m->P + 1) / 2, NX = NP + 1;
     const size_t fx = (size_t)2 * m->Mp * NX * 4, fs = (size_t)2 * m->Mp * NP * 4;  // floats
     if (!m->pbuf) {
@@ -1041,7 +1040,8 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
 #define DUST_LAUNCH_MPFP(PP)                                                                       \
   do {                                                                                              \
     if (m->Mp <= 256) mpf_optimize_poll_kernel<PP, 4><<<G, MPF_G_NT, 0, m->stream>>>(g);            \
-    else mpf_optimize_poll_kernel<PP, 8><<<G, MPF_G_NT, 0, m->stream>>>(g);                         \
+    else if (m->Mp <= 512) mpf_optimize_poll_kernel<PP, 8><<<G, MPF_G_NT, 0, m->stream>>>(g);       \
+    else mpf_optimize_poll_kernel<PP, 16><<<G, MPF_G_NT, 0, m->stream>>>(g);                        \
   } while (0)
     if (m->P == 1) DUST_LAUNCH_MPFP(1);
     else if (m->P == 2) DUST_LAUNCH_MPFP(2);

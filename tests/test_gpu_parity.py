@@ -1218,12 +1218,13 @@ def test_mpf_multi_workgroup_kernel_vs_reference(golden, name, form, monkeypatch
 
 @pytest.mark.parametrize("kind,Mp,opt,hook,form", [
     ("pendulum", 256, "SGD", None, "poll"), ("pendulum", 130, "Adam", None, "poll"), ("particle", 128, "SGD", None, "poll"),
-    ("pendulum", 500, "Adam", None, "poll"), ("pendulum", 41, "SGD", None, "poll"),
+    ("pendulum", 500, "Adam", None, "poll"), ("pendulum", 41, "SGD", None, "poll"), ("pendulum", 1024, "SGD", None, "poll"),
+    ("pendulum", 1021, "Adam", None, "poll"), ("particle", 600, "Adam", None, "poll"), ("pendulum", 700, "SGD", "2", "poll"),
     ("pendulum", 256, "SGD", None, "counter"), ("pendulum", 1024, "SGD", None, "counter"), ("pendulum", 1021, "Adam", None, "counter"),
     ("pendulum", 256, "Adam", "1", "poll"), ("pendulum", 200, "SGD", "2", "poll"), ("pendulum", 200, "Adam", "2", "counter")])
 def test_mpf_multi_workgroup_kernel_vs_single(kind, Mp, opt, hook, form, monkeypatch):
-    """From 96 particles on MPF.optimize runs spread over the chip (up to 512 particles with the data-polled exchange, above with
-    arrival counters; `form` pins one of them); the single-workgroup kernel (DUST_MPF_GRID=0) does the same
+    """From 96 particles on MPF.optimize runs spread over the chip (data-polled exchange by default, arrival counters with DUST_MPF_POLL=0;
+    `form` pins one of them); the single-workgroup kernel (DUST_MPF_GRID=0) does the same
     arithmetic per particle and sums in another fixed order.  Two filter updates each; ragged particle counts; both optimisers.
     hook 1 / 2: the grid form aborts at its start barrier / one of its waits "gives up" before the last hand-off - nothing is
     committed, the single-workgroup kernel runs the call, the caller sees DUST_OK and the same numbers."""
