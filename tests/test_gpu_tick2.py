@@ -337,3 +337,32 @@ def test_tiled_tick_aborted_ticks_are_replayed(model, N, S, H, kw):
         assert np.abs(h0[t][1] - h1[t][1]).max() < 5e-3 * (1 + 4 * t)
     for t in range(6):
         assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("model,N,S,H,iters,M,kw", [("pendulum", 2048, 16, 30, 2, 1, {}), ("pendulum", 2048, 16, 12, 2, 2, dict(kernel="IMQ")),
+                                                    ("particle", 2048, 16, 16, 2, 1, {})])
+def test_n2048_short_rows_default_path_equals_the_other_paths(model, N, S, H, iters, M, kw):
+    """N = 2048 with N D <= 65 536 runs the small-set kernels by default since round 3 (dust_amd.hip pair_is_big) - whichever launch form
+    that is for the shape (tiled one-launch tick, fused launches): the same two ticks through the launch-per-iteration kernels
+    (DUST_NO_FUSE) and through the large-set path (DUST_PAIR_BIG=1, the default until then and the one the oracle tests of
+    test_gpu_parity.py pin at this size) must agree."""
+    outs = {}
+    for name, env in (("default", {}), ("plain", {"DUST_NO_FUSE": "1"}), ("large", {"DUST_PAIR_BIG": "1"})):
+        saved = {k: os.environ.pop(k, None) for k in ("DUST_PAIR_BIG", "DUST_NO_FUSE")}
+        try:
+            outs[name] = _run(env, model, N, S, H, iters, 2, True, M=M, **kw)
+        finally:
+            for k in ("DUST_PAIR_BIG", "DUST_NO_FUSE"):
+                os.environ.pop(k, None)
+                if saved[k] is not None:
+                    os.environ[k] = saved[k]
+    (a, sa), (b, _), (c, _) = outs["default"], outs["plain"], outs["large"]
+    assert sa["tick2"] == 0, sa
+    for other in (b, c):
+        for t in range(2):
+            for k in ("costs", "score", "phi", "theta", "a_mat", "ll", "lp", "a_seq"):
+                # (different kernels from the first tick on: everything downstream of exp(-alpha cost) carries the summation order)
+                tol = TOL * (25 if k in ("score", "phi", "theta", "a_mat", "a_seq", "ll") else 1) * (1 if t == 0 else 4)
+                assert elemerr(a[t][k], other[t][k]) < tol, (t, k, elemerr(a[t][k], other[t][k]))
+            assert np.abs(a[t]["pw"] - other[t]["pw"]).max() < 4e-3
+    print("paths at N = 2048:", sa)
