@@ -1010,7 +1010,7 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   a.eps = m->adam_eps;
   a.adam_m = m->adam_m;
   a.adam_v = m->adam_v;
-  // the data-polled form (keys in registers: up to 512 particles) unless DUST_MPF_POLL=0; above that the counter form
+  // the data-polled form (keys in registers) unless DUST_MPF_POLL=0, which selects the counter form
   if (grid && m->Mp <= MPF_POLL_MAX && !(getenv("DUST_MPF_POLL") && atoi(getenv("DUST_MPF_POLL")) == 0)) {
     const int NP = (m->P + 1) / 2, NX = NP + 1;
     const size_t fx = (size_t)2 * m->Mp * NX * 4, fs = (size_t)2 * m->Mp * NP * 4;  // floats

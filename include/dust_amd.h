@@ -301,7 +301,7 @@ int dust_mpf_get_prior(dust_mpf *mpf, float *means, float *bw);
  * update_prior(bw) (mpf.py:85, at the end of optimize) is scalar again.  dust_mpf_get_prior reports bw[0]; _get_prior_bw all P. */
 int dust_mpf_set_prior_bw(dust_mpf *mpf, const float *bw, int n);
 int dust_mpf_get_prior_bw(dust_mpf *mpf, float *bw);
-/* How dust_mpf_optimize calls ran: out[0] calls served by the multi-workgroup kernel (>= 128 particles, >= 2 steps; mpf.hpp), out[1]
+/* How dust_mpf_optimize calls ran: out[0] calls served by a multi-workgroup kernel (>= 96 particles, >= 2 steps; mpf.hpp), out[1]
  * those among them that did not start or did not commit (the grid was not co-resident / a wait gave up) and were run by the
  * single-workgroup kernel instead - the caller saw DUST_OK either way. */
 int dust_mpf_stats(dust_mpf *mpf, long long out[2]);
