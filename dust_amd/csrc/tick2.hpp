@@ -104,9 +104,9 @@ __device__ __forceinline__ void t2_poll(const unsigned int *lines, const unsigne
   }
 }
 // every storing wave for itself: drain its write-through stores, then one agent-scope add
-__device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lane) {
+__device__ __forceinline__ void t2_arrive_wave(unsigned int *line /* the workgroup's shard in replica 0 */, const int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane < T2_NREP) __hip_atomic_fetch_add(line + (size_t)lane * T2_NSH * T2_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees only the kernel's signature: it cannot read through constant-address-space pointers)
@@ -117,9 +117,9 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line, const int lan
 // 150 against 130 us per tick, although the 8 x 8 form reads whole lines and every row once).
 // The theta-only half of SVMPC.phi (svmpc.py:38-41, 76-83) is cut in two at the point the SCORE needs:
 //   T2_PASS_PRIOR  (phase 1, underneath the rollouts; needed for the score rows): prior softmax mass L, weighted sum
-//                  a = sum_j e_ij (y_j - x_i); the squared distances go to LDS (dsl[key][4]).
+//                  a = sum_j e_ij (y_j - x_i); the squared distances go to LDS (dk[key][4]).
 //   T2_PASS_STEIN  (phase 4, while the score rows of the other workgroups are in flight - the CU has nothing else to do then but
-//                  draw the next noise): k_ij from the kept distances -> LDS (ksl[key][4]), repulsion b = sum_j k'_ij (y_j - x_i)
+//                  draw the next noise): k_ij from the kept distances -> LDS (the same dk[key][4], in place), repulsion b = sum_j k'_ij (y_j - x_i)
 //                  with k' = k (K1) or k^3 (IMQ).  Re-reads the key rows and re-forms the differences: ~15 % more work in
 //                  all, a third of it off the path that the score rows wait for (146 -> 130 us per tick).
 //   In both a wave takes TWO of the workgroup's four queries (waves 8-11: queries 0-1, waves 12-15: queries 2-3) and a quarter of
@@ -132,12 +132,30 @@ __device__ __forceinline__ float t2_quad_sum(float v) {  // quad permutes never 
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
 }
+// LDS accesses the compiler must not see while LDS-DMA loads are in flight: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS access
+// it cannot prove disjoint from an outstanding DMA's destination (seen in the ISA in front of the ds_write of the distances: one full
+// drain per step).  LDS operations of one wave execute in order, so a later compiler-issued read of the same words still sees the data;
+// the workgroup barriers drain lgkmcnt explicitly (wg_sync).
+__device__ __forceinline__ unsigned int t2_lds_addr(const float *p) { return (unsigned int)(size_t)(const __attribute__((address_space(3))) float *)p; }
+__device__ __forceinline__ void t2_lds_st64(float *p, const float a, const float b) {
+  const v2f v = {a, b};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(t2_lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ v2f t2_lds_ld64_issue(const float *p) {  // the caller waits (t2_lds_wait) before it uses the value
+  v2f v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(t2_lds_addr(p)) : "memory");
+  return v;
+}
+__device__ __forceinline__ void t2_lds_wait(v2f &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); }
 template <int MODE, int PASS, bool MASK /* the steps cover more than the N keys: those past the last one carry no weight */>
 __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* theta generation */, const float *thq /* LDS [4][32] own query rows */,
-                                             float *dsl, float *ksl, const int pw, const int lane, const float lm_ref,
+                                             float *dk /* LDS [keys][4]: |y_j - x_q|^2 (PRIOR) -> k_qj (STEIN) */, const float *lml /* LDS [keys] log pi_j */,
+                                             float *ring /* LDS: this wave's key ring [T2_NS][2][64][4] (PRIOR / STEIN) */, const int pw, const int lane,
+                                             const float lm_ref,
                                              float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */) {
   constexpr int NQ = PASS == T2_PASS_LOGP ? 4 : 2;   // queries per wave
   constexpr int NKW = PASS == T2_PASS_LOGP ? 16 : 4;  // waves that share the keys (forward: all 16 waves of the workgroup)
+  constexpr bool RING = T2_NS > 0 && PASS != T2_PASS_LOGP;
   const int u = lane >> 2, c = lane & 3, N = f->N;
   const int kw = PASS == T2_PASS_LOGP ? pw : (pw & 3), q0 = PASS == T2_PASS_LOGP ? 0 : (pw >> 2) * 2;
   v2f xq[NQ][4];
@@ -159,67 +177,106 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
     accL[q] = 0.f;
   }
   const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq + (size_t)gen * N * T2_ROW, N * T2_ROW);
-  constexpr int PF = 2;  // key steps in flight (4 spill the prefetched rows themselves into the loop: 17 us per pass instead of 6)
-  v4f ya[PF], yb[PF];
-  float lbuf[PF];
-  auto issue = [&](const int t, v4f &y0, v4f &y1, float &lm) {
-    const int j = min((t * NKW + kw) * 16 + u, N - 1);
-    y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
-    y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
-    if (PASS != T2_PASS_STEIN) lm = f->logmix[j];
-  };
   const int steps = PASS == T2_PASS_LOGP ? f->steps / 4 : f->steps;
-#pragma unroll
-  for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p], lbuf[p]);
   const float cP = f->cP, cS = f->cS;
-  for (int t0 = 0; t0 < steps; t0 += PF) {
+  // one 16-key step of the pass on the lane's 8 columns (y0 | y1) of key row j
+  auto step = [&](const int t, const v4f y0, const v4f y1, const v2f dq /* STEIN: the distances of pass PRIOR */) {
+    const int j = (t * NKW + kw) * 16 + u;
+    const bool valid = !MASK || j < N;
+    const v2f yv[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
+    if (PASS == T2_PASS_STEIN) {
+      const float dd[2] = {dq.x, dq.y};
+      float kq[2];
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const int t = t0 + p;
-      const v4f y0 = ya[p], y1 = yb[p];
-      const float lm = lbuf[p];
-      issue(min(t + PF, steps - 1), ya[p], yb[p], lbuf[p]);  // (the last group re-reads its last rows: no branch in the loop)
-      const int j = (t * NKW + kw) * 16 + u;
-      const bool valid = !MASK || j < N;
-      const v2f yv[4] = {{y0[0], y0[1]}, {y0[2], y0[3]}, {y1[0], y1[1]}, {y1[2], y1[3]}};
-      if (PASS == T2_PASS_STEIN) {
-        const float2 dq = *reinterpret_cast<const float2 *>(&dsl[(size_t)j * 4 + q0]);  // the distances of pass PRIOR
-        const float dd[2] = {dq.x, dq.y};
-        float kq[2];
+      for (int q = 0; q < 2; ++q) {
+        float k;
+        if (MODE == PAIR_K1) k = valid ? __builtin_amdgcn_exp2f(dd[q] * cS) : 0.f;
+        else k = valid ? __builtin_amdgcn_rsqf(fmaf(dd[q], cS, 1.0f)) : 0.f;
+        kq[q] = k;
+        const float kp = MODE == PAIR_K1 ? k : (k * k) * k;
+        const v2f kk = {kp, kp};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float k;
-          if (MODE == PAIR_K1) k = valid ? __builtin_amdgcn_exp2f(dd[q] * cS) : 0.f;
-          else k = valid ? __builtin_amdgcn_rsqf(fmaf(dd[q], cS, 1.0f)) : 0.f;
-          kq[q] = k;
-          const float kp = MODE == PAIR_K1 ? k : (k * k) * k;
-          const v2f kk = {kp, kp};
+        for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(kk, yv[h] - xq[q][h], acc[q][h]);
+      }
+      if (c == 0) t2_lds_st64(&dk[(size_t)j * 4 + q0], kq[0], kq[1]);  // (in place: the quad has read its distances)
+    } else {
+      const float lm2 = (lml[j] - lm_ref) * 1.44269504088896340736f;
+      float dsq[NQ];
 #pragma unroll
-          for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(kk, yv[h] - xq[q][h], acc[q][h]);
+      for (int q = 0; q < NQ; ++q) {
+        v2f z[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) z[h] = yv[h] - xq[q][h];
+        v2f d2 = z[0] * z[0];
+#pragma unroll
+        for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
+        const float dd = t2_quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
+        dsq[q] = dd;
+        const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
+        accL[q] += e;
+        if (PASS == T2_PASS_PRIOR) {
+          const v2f ee = {e, e};
+#pragma unroll
+          for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(ee, z[h], acc[q][h]);
         }
-        if (c == 0) *reinterpret_cast<float2 *>(&ksl[(size_t)j * 4 + q0]) = float2{kq[0], kq[1]};
-      } else {
-        const float lm2 = (lm - lm_ref) * 1.44269504088896340736f;
-        float dk[NQ];
+      }
+      if (PASS == T2_PASS_PRIOR && c == 0) t2_lds_st64(&dk[(size_t)j * 4 + q0], dsq[0], dsq[1]);
+    }
+  };
+  if (RING) {
+    // Keys through an LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds: no destination registers): T2_NS steps - 2 KB each - are in
+    // flight per wave whatever the register budget says.  The register form (below, still used by the log-density pass) holds two steps in
+    // 18 registers, the compiler rotates them through copies at the loop's back edge and waits there for EVERY outstanding load
+    // (s_waitcnt vmcnt(0)): one exposed L2 round trip per two steps - a pass of a wave pair alone on its SIMD took 4.5 us for ~0.9 k
+    // instructions (tools/tick2_timeline.py with the R waves' work compiled out), and four steps in registers spill.
+    // Order per step: wait until the step's two DMA pieces have landed (the T2_NS - 1 younger steps stay in flight) -> read them
+    // (the lane's own 2 x 16 bytes: a wave reads only what it loaded itself, no barrier) -> refill the slot -> arithmetic.
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto dma = [&](const int t, const int slot) {
+      const int j = min((t * NKW + kw) * 16 + u, N - 1);
+      const int voff = (j * T2_ROW + 8 * c) * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(ring + slot * 512), 16, voff, 0, 0, 0);
+      // (the instruction offset moves the LDS address as well as the memory address - tools/ldsdma_probe.hip -, hence 252 = 256 - 16 / 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(ring + slot * 512 + 252), 16, voff, 0, 16, 0);
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the query rows are in registers before the first DMA is issued (see t2_lds_st64)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          v2f z[4];
+    for (int sl = 0; sl < T2_NS; ++sl) dma(min(sl, steps - 1), sl);
+    int slot = 0;
+    for (int t = 0; t < steps; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (T2_NS - 1)) : "memory");
+      const v4f y0 = *reinterpret_cast<const v4f *>(ring + slot * 512 + lane * 4);
+      const v4f y1 = *reinterpret_cast<const v4f *>(ring + slot * 512 + 256 + lane * 4);
+      v2f dq = {0.f, 0.f};
+      if (PASS == T2_PASS_STEIN) dq = t2_lds_ld64_issue(&dk[(size_t)((t * NKW + kw) * 16 + u) * 4 + q0]);
+      t2_lds_wait(dq);                                      // the slot is read: it may be refilled
+      dma(min(t + T2_NS, steps - 1), slot);                // (past the end: the last rows again - the in-flight count stays uniform)
+      step(t, y0, y1, dq);
+      slot = slot + 1 == T2_NS ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills: nothing may land in the ring after the pass
+  } else {
+    constexpr int PF = 2;  // key steps in flight
+    v4f ya[PF], yb[PF];
+    auto issue = [&](const int t, v4f &y0, v4f &y1) {
+      const int j = min((t * NKW + kw) * 16 + u, N - 1);
+      y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
+      y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
+    };
 #pragma unroll
-          for (int h = 0; h < 4; ++h) z[h] = yv[h] - xq[q][h];
-          v2f d2 = z[0] * z[0];
+    for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p]);
+    for (int t0 = 0; t0 < steps; t0 += PF) {
 #pragma unroll
-          for (int h = 1; h < 4; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
-          const float dd = t2_quad_sum(d2.x + d2.y);  // |y_j - x_q|^2 over all columns, in every lane of the 4
-          dk[q] = dd;
-          const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
-          accL[q] += e;
-          if (PASS == T2_PASS_PRIOR) {
-            const v2f ee = {e, e};
-#pragma unroll
-            for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(ee, z[h], acc[q][h]);
-          }
+      for (int p = 0; p < PF; ++p) {
+        const int t = t0 + p;
+        const v4f y0 = ya[p], y1 = yb[p];
+        issue(min(t + PF, steps - 1), ya[p], yb[p]);  // (the last group re-reads its last rows: no branch in the loop)
+        v2f dq = {0.f, 0.f};
+        if (PASS == T2_PASS_STEIN) {
+          const float2 d = *reinterpret_cast<const float2 *>(&dk[(size_t)((t * NKW + kw) * 16 + u) * 4 + q0]);
+          dq = v2f{d.x, d.y};
         }
-        if (PASS == T2_PASS_PRIOR && c == 0) *reinterpret_cast<float2 *>(&dsl[(size_t)j * 4 + q0]) = float2{dk[0], dk[1]};
+        step(t, y0, y1, dq);
       }
     }
   }
@@ -300,25 +357,27 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *th = lds + T2_L_TH;     // [4][32] the workgroup's particles, zero padded
   float *misc = lds + T2_L_MISC;
   float *red_w = misc;           // [4][2][4] per (particle, wave): cost min, sum exp, sum exp (omega), cost sum
-  float *zfin = misc + 32;       // [4][2] softmax masses
   float *ll = misc + 40;         // [4] log-likelihood of the last sample (SVMPC.forward, fast_pred)
   float *flag_th = misc + 44;    // [4] non-finite particle
-  float *flag_eps = misc + 48;   // [4] non-finite caller-supplied noise
-  // (misc[56..59] unused)
+  float *flag_eps = misc + 48;   // [2][4] non-finite caller-supplied noise, by iteration parity (iteration k + 1's noise is staged while
+                                 // iteration k's flags are still to be cleared: phase 6)
+  // (misc[32..39], misc[56..59] unused)
   unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived  [2] COMMIT (1) / not (0)
   float *wred = misc + 64;       // [128] block-reduction scratch
   float *coefs = lds + T2_L_COEFS;
   float *ksl = lds + L.ksl;
   float *ppart = lds + T2_L_PPART;
-  float *gpl = lds + T2_L_GP, *rpart = lds + T2_L_RP;
-  float *dsl = lds + L.dsl;
+  float *rpart = lds + T2_L_RP;
+  float *lml = lds + L.lml;      // [steps * 64] log pi_j of the tick's prior (read by every pair pass; constant over the tick)
+  float *ring = lds + L.ring;    // [8 P waves][T2_NS][2][64][4] key rings of the pair passes (t2_pair_pass)
   float *wpart = lds + T2_L_WPART;
   float *scl = lds + T2_L_SCL;
-  unsigned int *cnt_start = f->cnt;
-  unsigned int *cnt_theta = f->cnt + (size_t)1 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *cnt_score = f->cnt + (size_t)2 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *cnt_lw = f->cnt + (size_t)3 * T2_NSH * T2_CNT_STRIDE;
-  unsigned int *go = f->cnt + (size_t)4 * T2_NSH * T2_CNT_STRIDE;
+  unsigned int *cnt_start = f->cnt;  // (replica 0 only: one arrival per workgroup, polled by workgroup 0)
+  unsigned int *cnt_theta = f->cnt + (size_t)1 * T2_KIND * T2_CNT_STRIDE;
+  unsigned int *cnt_score = f->cnt + (size_t)2 * T2_KIND * T2_CNT_STRIDE;
+  unsigned int *cnt_lw = f->cnt + (size_t)3 * T2_KIND * T2_CNT_STRIDE;
+  unsigned int *go = f->cnt + (size_t)4 * T2_KIND * T2_CNT_STRIDE;
+  const size_t rep_off = (size_t)(b % T2_NREP) * T2_NSH * T2_CNT_STRIDE;  // the replica this workgroup polls
   unsigned int *tflag = f->status;
 
   if (b == 0)
@@ -353,7 +412,11 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float ll0 = 0.f;
   if (tid0 >= 32 && tid0 < 32 + T2_PW) ll0 = f->logl[n_first + tid0 - 32];
   float lm_max = -INFINITY;  // max_j log pi_j: an upper bound of every prior logit (the exponent reference of the pair passes)
-  for (int i = tid0; i < N; i += T2_NT) lm_max = fmaxf(lm_max, f->logmix[i]);
+  for (int i = tid0; i < f->steps * 64; i += T2_NT) {
+    const float lmi = f->logmix[min(i, N - 1)];
+    lml[i] = lmi;
+    lm_max = fmaxf(lm_max, lmi);
+  }
   if (MODEL == DUST_MODEL_PARTICLE) {  // occupancy grid -> LDS
     uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + L.grid);
     const int words = f->dm.with_obstacle ? (f->dm.nx * f->dm.ny + 31) >> 5 : 0;
@@ -392,6 +455,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   // rows two lanes split a row's Philox blocks.  Same counter layout as rollout.hpp / persist.hpp: element (s, n, j).
   auto draw_noise = [&](const T2ArgPtr f, const int k, const int lid, const int nl) {
     const int rows = T2_PW * S;
+#ifdef T2_ABL_NOISE  // timing ablation (results invalid): the tile keeps the first draw
+    if (k > 0) return;
+#endif
     if (f->eps == nullptr) {
       const int split = nl >= 2 * rows ? 2 : 1;
       const int half = split == 2 ? (lid & 1) : 0;
@@ -423,7 +489,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           if (e < total) {
             const int r = e / D, j = e - r * D;
             tile[(size_t)r * Dp + j] = v[q];
-            if (!(fabsf(v[q]) <= 3.0e38f)) flag_eps[r / S] = 1.f;
+            if (!(fabsf(v[q]) <= 3.0e38f)) flag_eps[(k & 1) * T2_PW + r / S] = 1.f;
           }
         }
       }
@@ -446,8 +512,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   if (tid0 >= 32 && tid0 < 32 + T2_PW) ll[tid0 - 32] = ll0;
   lm_max = wave_max(lm_max);
   if ((tid0 & 63) == 0) wred[wave] = lm_max;
-  // start barrier (wave 15, underneath the first rollouts): workgroup 0 collects the arrivals - bounded: ~200 us - and publishes
-  // go / abort
+  // start barrier of a launch WITHOUT iterations (SVMPC.forward alone; wave 15): workgroup 0 collects the arrivals - bounded: ~200 us -
+  // and publishes go / abort
   auto start_protocol = [&]() {
     const int lane = tid0 & 63;
     if (b == 0) {
@@ -470,6 +536,65 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         t2_lds_st(sig, all_ok ? 1u : 2u);
       }
     } else if (lane == 0) {
+      unsigned int g = 0u, spins = 0u;
+      unsigned long long t_start = 0;
+      for (;;) {
+        g = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0u) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (!t_start) t_start = now;
+          else if (now - t_start > DUST_SPIN_TIMEOUT_TICKS) {  // workgroup 0 never came: give up (reported as a time-out)
+            __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = 2u;
+            break;
+          }
+        }
+      }
+      t2_lds_st(sig, g);
+    }
+  };
+  // With SVGD iterations in the launch the FIRST HAND-OFF is the start barrier: every workgroup publishes its particles (generation 0)
+  // before anything else, so "all generation-0 rows have arrived" proves that all workgroups are resident.  Workgroup 0 decides - it
+  // waits (bounded: ~200 us) for the arrivals and publishes go / abort; the others start their pair pass over generation 0 as soon as
+  // THEY see the arrivals complete (the pass reads the exchange buffer and writes LDS only) and pick the go word up behind it, in front
+  // of barrier B1, the first point where a workgroup writes anything another one reads.  Against a start barrier of its own in front of
+  // the first hand-off (round 3) this takes two round trips out of the head of the tick (~3 us).
+  auto gen0_wait = [&]() {  // wave 15
+    const int lane = tid0 & 63;
+    bool ok = true;
+    if (lane < T2_NSH) {
+      const unsigned int target = t2_shard_wgs(lane, G) * 2u;
+      const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+      unsigned int spins = 0u;
+      while (target && (int)(__hip_atomic_load(cnt_theta + rep_off + (size_t)lane * T2_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 15u) == 0u) {
+          const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_start;
+          if (b == 0 ? waited > 20000ull
+                     : (waited > DUST_SPIN_TIMEOUT_TICKS || __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)) {
+            ok = false;
+            break;
+          }
+        }
+      }
+    }
+    const bool all_in = __all(ok ? 1 : 0);
+    if (b == 0) {
+      const bool all_ok = all_in && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1;
+      if (lane == 0) {
+        if (!all_ok) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(go, all_ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2_lds_st(sig, all_ok ? 1u : 2u);
+      }
+    } else if (!all_in && lane == 0) {  // workgroup 0 said abort, or nothing came for 50 ms (reported as a time-out)
+      if (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t2_lds_st(sig, 2u);
+    }
+  };
+  auto go_wait = [&]() {  // wave 15 of workgroups 1 ..: the go word, published by workgroup 0 when it saw generation 0 complete
+    if ((tid0 & 63) == 0 && t2_lds_ld(sig) == 0u) {
       unsigned int g = 0u, spins = 0u;
       unsigned long long t_start = 0;
       for (;;) {
@@ -517,7 +642,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       const float *tile_p = tile + (size_t)rp * S * Dp;
       float *cst_p = cst + rp * S, *omg_p = omg + rp * S;
       const float *th_p = th + rp * T2_ROW;
-      const bool bad = flag_th[rp] != 0.f || flag_eps[rp] != 0.f;
+      const bool bad = flag_th[rp] != 0.f || flag_eps[(k & 1) * T2_PW + rp] != 0.f;
       const long SN = (long)S * N;
       const bool fast_trig = MODEL == DUST_MODEL_PENDULUM && !bad && fabsf(x0[1]) <= 3.0e38f &&
                              (fabsf(x0[0]) + f->dm.max_speed_pend * (float)f->dm.dt * (float)H < 5.0e4f);
@@ -539,6 +664,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
             const float dt = (float)f->dm.dt, mt = f->dm.max_torque, ms = f->dm.max_speed_pend, chol0 = f->chol_a[0];
             const v2f W = {f->dm.w_cos, f->dm.w_vel};
             float sn, cs;
+#ifdef T2_ABL_ROLL  // timing ablation (results invalid): one step instead of H
+            const int H = 1;
+#endif
 #pragma unroll 2
             for (int t = 0; t < H; ++t) {
               pendulum_trig(x[0], &sn, &cs);
@@ -571,14 +699,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         cst_p[s] = cost;
       }
       T2_TL(0, 16 * k + 1);
-      {  // nothing leaves the workgroup before "go" (known long before the first rollouts end)
-        unsigned int g = 1u;
-        if (k == 0)
-          while ((g = t2_lds_ld(sig)) == 0u) __builtin_amdgcn_s_sleep(1);
-        if (g == 1u)
-          for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
-      }
-      // wave-local softmax pieces (merged after the barrier: one exchange instead of two)
+      // (the costs are an output of the tick's last iteration only, rewritten by the replay of a tick that does not start: they may leave
+      //  the workgroup before "go" is known)
+      for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
+      // wave-local softmax pieces over the wave's own samples, and the wave's share of the weighted sums over them (likelihoods.py:127-135,
+      // svmpc.py:50-53, disco.py:387-392): nothing here needs the partner wave or the prior pass, so it runs underneath the P waves' pass
+      // instead of behind barrier B1; the owner lanes merge the two waves' pieces of a particle (scale factors exp(-alpha (m_w - min)))
       float m_w = INFINITY, cs_w = 0.f;
       for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
         m_w = fminf(m_w, cst_p[s]);
@@ -608,32 +734,58 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         rw[3] = cs_w;
       }
       DUST_PRIO(0);
+      {  // lane = (sample parity q, column j): 32 of the wave's 64 samples each (its own LDS writes: in order, no barrier)
+        const int q = lane >> 5, j = lane & 31;
+        float g = 0.f, am = 0.f;
+        if (j < D) {
+          const float thj = th_p[j], lj = pick_da<DA>(f->chol_a, j);
+          const float is2 = 1.0f / (pick_da<DA>(f->sigma_a, j) * pick_da<DA>(f->sigma_a, j));
+          const float base = f->eps_base_mode ? thj : f->a_seq[j];
+          const float *tp = tile_p + j;
+          const float *op_ = same_w ? cst_p : omg_p;
+          for (int s0 = (wave & 1) * 64; s0 < S; s0 += 128) {
+            const int s1 = min(s0 + 64, S);
+#pragma unroll 4
+            for (int s = s0 + q; s < s1; s += 2) {
+              const float av = thj + lj * tp[s * Dp];
+              g = fmaf(cst_p[s], (av - thj) * is2, g);
+              am = fmaf(op_[s], av - base, am);
+            }
+          }
+        }
+        wpart[((rp * 2 + (wave & 1)) * 2 + q) * T2_ROW + j] = g;
+        wpart[(T2_PW * 4 + (rp * 2 + (wave & 1)) * 2 + q) * T2_ROW + j] = am;
+      }
+      T2_TL(0, 16 * k + 5);
     } else {
       // ================= P waves, phase 1: the theta-only half of SVMPC.phi against all N keys =================
       const int pw = wave - 8;
       if (wave == 15) {  // theta generation k: published at the start of the tick (k = 0) or by iteration k - 1
-        if (k == 0) start_protocol();
-        t2_poll(cnt_theta, 2u, (unsigned int)(k + 1), G, lane, tflag);
+        if (k == 0) gen0_wait();
+        else t2_poll(cnt_theta + rep_off, 2u, (unsigned int)(k + 1), G, lane, tflag);
         if (lane == 0) t2_lds_st(sig + 1, (unsigned int)(k + 1));
       }
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
-      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, dsl, ksl, pw, lane, lm_ref, red);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, ksl, lml, ring + pw * (T2_NS * 512), pw, lane, lm_ref, red);
+      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, ksl, lml, ring + pw * (T2_NS * 512), pw, lane, lm_ref, red);
 #pragma unroll
       for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
       T2_TL(8, 16 * k + 3);
+      T2_TL(15, 16 * k + 15);
+      if (k == 0 && wave == 15) go_wait();  // (the pass above read and wrote nothing outside the workgroup)
     }
     wg_sync();  // B1
     f = t2_args();
     T2_TL(0, 16 * k + 4);
     if (sig[0] == 2u) return;  // (uniform: no workgroup wrote anything)
-    // ================= phase 2: merge the softmax pieces (R) | finish grad_pri / repulsion (P) =================
-    if (wave < 8) {
-      const int rp = wave >> 1;
-      float *cst_p = cst + rp * S, *omg_p = omg + rp * S;
-      const float *r0 = red_w + (rp * 2) * 4, *r1 = r0 + 4;
+    // ================= phase 4: score rows out (waves 8-9) | score arrivals (wave 10) | next noise (R) =================
+    // The owner lanes finish both halves of the score themselves (no barrier between the prior pass and the published row): grad_pri from
+    // the pass partials of the four waves that hold the query, grad_lik from the two R waves' pieces of the particle's sample softmax.
+    float gs_keep = 0.f, gp_keep = 0.f;
+    if (isown) {
+      const float *r0 = red_w + (op * 2) * 4, *r1 = r0 + 4;
       const float m0 = r0[0], m1 = r1[0], cmin = fminf(m0, m1);
       const float f0 = expf(-m0 * f->alpha - (-cmin * f->alpha)), f1 = expf(-m1 * f->alpha - (-cmin * f->alpha));
       const float zw = r0[1] * f0 + r1[1] * f1;
@@ -643,77 +795,32 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         g1 = expf((-1.0f * (m1 - cmin)) / f->temp);
         zo = r0[2] * g0 + r1[2] * g1;
       }
-      const float fw = (wave & 1) ? f1 : f0, go_w = (wave & 1) ? g1 : g0;
-      for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
-        cst_p[s] = cst_p[s] * fw;
-        if (!same_w) omg_p[s] = omg_p[s] * go_w;
-      }
-      if ((wave & 1) == 0 && lane == 0) {
-        const int n = n_first + rp;
-        zfin[rp * 2] = zw;
-        zfin[rp * 2 + 1] = zo;
+      if (od == 0) {
+        const int n = n_first + op;
         float last_logl;
         if (f->lik == DUST_LIK_EXP_UTILITY) last_logl = ((-cmin * f->alpha) + logf(zw)) - logf((float)S);
         else last_logl = -f->alpha * ((r0[3] + r1[3]) / (float)S);
-        ll[rp] = last_logl;
+        ll[op] = last_logl;
         f->logl[n] = last_logl;
         f->eta[n] = (-cmin / f->temp) + logf(zo);
       }
-    } else {
-      const int v = tid - 512;  // 0..511: [0,128) grad_pri (q, d)
-      if (v < 128) {
-        const int q = (v >> 5) & 3, d = v & 31, c = d >> 3, cc = d & 7;
-        float s = 0.f, l = 0.f;
+      const float *wg = wpart + (op * 4) * T2_ROW + od, *wa = wpart + (T2_PW * 4 + op * 4) * T2_ROW + od;
+      const float g = (wg[0] + wg[T2_ROW]) * f0 + (wg[2 * T2_ROW] + wg[3 * T2_ROW]) * f1;
+      const float am = (wa[0] + wa[T2_ROW]) * g0 + (wa[2 * T2_ROW] + wa[3 * T2_ROW]) * g1;
+      const float gs = g / zw;
+      const float as = am / zo;
+      if (f->update_a_mat) amv = amv + as;
+      {
+        const int c = od >> 3, cc = od & 7;
+        float sp = 0.f, l = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {  // the four waves that hold this query's half: their key quarters, in order
-          const int pwq = (q >> 1) * 4 + w;
-          s += ppart[(pwq * 32 + (q & 1) * 8 + cc) * 4 + c];
-          l += ppart[(pwq * 32 + 16 + (q & 1)) * 4 + c];
+          const int pwq = (op >> 1) * 4 + w;
+          sp += ppart[(pwq * 32 + (op & 1) * 8 + cc) * 4 + c];
+          l += ppart[(pwq * 32 + 16 + (op & 1)) * 4 + c];
         }
-        gpl[q * T2_ROW + d] = (s / l) * f->inv_sp2;
-      } else if (v < 128 + T2_PW) {
-        flag_eps[v - 128] = 0.f;  // consumed by this iteration's rollouts; the next noise is staged after barrier B3
+        gp_keep = (sp / l) * f->inv_sp2;
       }
-    }
-    wg_sync();  // B2
-    f = t2_args();
-    T2_TL(0, 16 * k + 5);
-    // ================= phase 3: weighted sums over the samples, all lanes: lane = (particle, sample slice, column) =================
-    {
-      const int p = tid >> 8, q = (tid >> 5) & 7, j = tid & 31;
-      float g = 0.f, am = 0.f;
-      if (j < D) {
-        const float thj = th[p * T2_ROW + j], lj = pick_da<DA>(f->chol_a, j);
-        const float is2 = 1.0f / (pick_da<DA>(f->sigma_a, j) * pick_da<DA>(f->sigma_a, j));
-        const float base = f->eps_base_mode ? thj : f->a_seq[j];
-        const float *tp = tile + (size_t)p * S * Dp + j;
-        const float *wp = cst + p * S, *op_ = same_w ? wp : omg + p * S;
-#pragma unroll 4
-        for (int s = q; s < S; s += 8) {
-          const float av = thj + lj * tp[s * Dp];
-          g = fmaf(wp[s], (av - thj) * is2, g);
-          am = fmaf(op_[s], av - base, am);
-        }
-      }
-      wpart[(p * 8 + q) * T2_ROW + j] = g;
-      wpart[(T2_PW * 8 + p * 8 + q) * T2_ROW + j] = am;
-    }
-    wg_sync();  // B3
-    f = t2_args();
-    T2_TL(0, 16 * k + 6);
-    // ================= phase 4: score rows out (waves 8-9) | score arrivals (wave 10) | next noise (R) =================
-    float gs_keep = 0.f, gp_keep = 0.f;
-    if (isown) {
-      float g = 0.f, am = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        g += wpart[(op * 8 + q) * T2_ROW + od];
-        am += wpart[(T2_PW * 8 + op * 8 + q) * T2_ROW + od];
-      }
-      const float gs = g / zfin[op * 2];
-      const float as = am / zfin[op * 2 + 1];
-      if (f->update_a_mat) amv = amv + as;
-      gp_keep = gpl[op * T2_ROW + od];
       gs_keep = gs;
       scl[op * T2_ROW + od] = ownv ? gs + gp_keep : 0.f;
       publish_rows(scl, f->sq + (size_t)k * N * T2_ROW, cnt_score);
@@ -726,12 +833,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
       float rb[4];
-      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
-      else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, dsl, ksl, wave - 8, lane, lm_ref, rb);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
+      else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
       rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
+      T2_TL(8, 16 * k + 11);
+      T2_TL(15, 16 * k + 6);
     }
     if (wave == 10) {
-      t2_poll(cnt_score, 2u, (unsigned int)(k + 1), G, lane, tflag);
+      t2_poll(cnt_score + rep_off, 2u, (unsigned int)(k + 1), G, lane, tflag);
       T2_TL(10, 16 * k + 8);
     } else if (wave < 8) {
       if (k + 1 < f->n_iters) draw_noise(f, k + 1, tid, 512);
@@ -809,7 +918,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       if (!ownv) thv = 0.f;
       th[op * T2_ROW + od] = thv;
       const unsigned long long badm = __ballot(ownv && !(fabsf(thv) <= 3.0e38f));
-      if ((lane & 31) == 0) flag_th[op] = ((badm >> (lane & 32)) & 0xffffffffull) ? 1.f : 0.f;
+      if ((lane & 31) == 0) {
+        flag_th[op] = ((badm >> (lane & 32)) & 0xffffffffull) ? 1.f : 0.f;
+        flag_eps[(k & 1) * T2_PW + op] = 0.f;  // read by this iteration's rollouts; iteration k + 2 stages its noise behind barrier B6
+      }
       if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq + (size_t)(k + 1) * N * T2_ROW, cnt_theta);
       T2_TL(8, 16 * k + 13);
       if (ownv) f->phi[no] = phi;
@@ -851,12 +963,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   }
   {  // log p(theta_n) under the tick's prior, whose means ARE the particles (svmpc.py:137; svgd.py:87): all 16 waves
     if (wave == 15) {
-      t2_poll(cnt_theta, 2u, (unsigned int)(kf + 1), G, lane, tflag);
+      t2_poll(cnt_theta + rep_off, 2u, (unsigned int)(kf + 1), G, lane, tflag);
       if (lane == 0) t2_lds_st(sig + 1, (unsigned int)(kf + 1));
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
-    t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, dsl, ksl, wave, lane, lm_ref, red);
+    t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, ksl, lml, ring, wave, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;
@@ -883,7 +995,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     t2_arrive_wave(cnt_lw + (size_t)sh * T2_CNT_STRIDE, lane);
-    t2_poll(cnt_lw, 1u, 1u, G, lane, tflag);
+    t2_poll(cnt_lw + rep_off, 1u, 1u, G, lane, tflag);
     if (lane == 0) t2_lds_st(sig + 2, t2_commit(f->status, b) ? 1u : 0u);
   }
   wg_sync();

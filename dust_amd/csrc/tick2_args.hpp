@@ -8,13 +8,20 @@ namespace dust {
 #ifndef T2_NSH_N
 #define T2_NSH_N 16
 #endif
+#ifndef T2_NREP_N
+#define T2_NREP_N 8
+#endif
 enum {
   T2_PW = 4,      // Stein particles per workgroup (4 x 128 action samples = 8 rollout waves)
   T2_NT = 1024,   // lanes per workgroup: waves 0-7 roll out, waves 8-15 run the pairwise passes
   T2_NSH = T2_NSH_N,  // shards of every arrival counter (workgroup b signals shard b % T2_NSH; one 128-byte line each)
   T2_ROW = 32,    // floats per row of the exchange buffers (D <= 32 padded to one 128-byte line)
+  T2_NREP = T2_NREP_N,  // replicas of every arrival counter: an arriving wave adds to all of them (one lane each), workgroup b polls replica
+                        // b % T2_NREP only - 256 workgroups polling the SAME 16 lines took 2 us per poll round (agent-scope loads of one
+                        // line are served one after the other); with 8 replicas a line has 32 pollers
   T2_CNT_STRIDE = 32,
-  T2_SETS = 4 * T2_NSH + 1  // lines of one counter set: start | theta | score | lw shards, then the go word
+  T2_KIND = T2_NSH * T2_NREP,  // lines of one counter kind: [replica][shard]
+  T2_SETS = 4 * T2_KIND + 1    // lines of one counter set: start | theta | score | lw counters, then the go word
 };
 
 struct Tick2Args {
@@ -68,19 +75,24 @@ enum {
                                               // same 2 048 floats hold [16 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
   T2_L_SCL = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [4][32] score rows on their way out
   T2_L_COEFS = T2_L_SCL + T2_PW * T2_ROW,     // [T2_MAXM][2] dynamics coefficients of the iteration
-  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | dsl | grid | tile
+  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | lml | ring | grid | tile
 };
+#ifndef T2_NS
+#define T2_NS 0   // key steps (2 KB each) a pair wave keeps in flight through an LDS ring (tick2.hpp t2_pair_pass); 0: register form
+#endif
 struct Tick2Lds {
-  int cst, omg, ksl, dsl, grid, tile, total;
+  int cst, omg, ksl, lml, ring, grid, tile, total;
 };
 __host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_words) {
   Tick2Lds l;
   const int Dp = D | 1, ps = (T2_PW * S + 3) & ~3;
   l.cst = T2_L_VAR;               // [4][S] costs -> softmax weights
   l.omg = l.cst + ps;             // [4][S] omega weights
-  l.ksl = l.omg + ps;             // [steps * 64][4] Stein kernel values k_ij of the workgroup's 4 queries
-  l.dsl = l.ksl + steps * 64 * 4;   // [steps * 64][4] squared distances |y_j - x_q|^2 (prior pass -> Stein pass)
-  l.grid = l.dsl + steps * 64 * 4;
+  l.ksl = l.omg + ps;             // [steps * 64][4] squared distances |y_j - x_q|^2 of the workgroup's 4 queries (prior pass), replaced in
+                                  // place by the Stein kernel values k_qj (Stein pass)
+  l.lml = l.ksl + steps * 64 * 4;   // [steps * 64] log pi_j of the tick's prior
+  l.ring = l.lml + steps * 64;      // [8 pair waves][T2_NS][2][64][4] key rows on their way in (LDS-DMA)
+  l.grid = l.ring + 8 * T2_NS * 512;
   l.tile = l.grid + grid_words;   // [4][S][Dp] standard normals of the current iteration
   l.total = l.tile + T2_PW * S * Dp;
   return l;

@@ -36,10 +36,10 @@ lib.dust_debug_stamps(c._h, -(2048 * 32), buf.ctypes.data_as(C.c_void_p))
 t = buf.reshape(2048, 128).astype(np.int64)[:W]
 t0 = t[:, 120][t[:, 120] > 0].min()
 us = lambda x: (x - t0) / 100.0
-names = {0: "iteration start (w0)", 1: "rollouts done (w0)", 2: "theta arrived (w8)", 3: "pair pass done (w8)", 4: "after B1", 5: "after B2: softmax merged",
-         6: "after B3: weighted sums", 7: "score rows published (w8)", 8: "score arrivals seen (w10)", 9: "next noise drawn (w0)",
-         10: "after B4", 12: "after B5: K x score", 13: "theta rows published (w8)", 14: "after B6"}
-order = [0, 2, 1, 3, 4, 5, 6, 7, 9, 8, 10, 12, 13, 14]
+names = {0: "iteration start (w0)", 1: "rollouts done (w0)", 2: "theta arrived (w8)", 3: "prior pass done (w8)", 15: "prior pass done (w15)", 4: "after B1",
+         5: "weighted sums done (w0)", 7: "score rows published (w8)", 8: "score arrivals seen (w10)", 9: "next noise drawn (w0)",
+         11: "Stein pass done (w8)", 6: "Stein pass done (w15)", 10: "after B4", 12: "after B5: K x score", 13: "theta rows published (w8)", 14: "after B6"}
+order = [0, 2, 1, 5, 3, 15, 4, 7, 9, 11, 6, 8, 10, 12, 13, 14]
 def show(label, col):
     v = t[:, col]
     v = v[v > 0]
