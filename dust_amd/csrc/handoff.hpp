@@ -64,14 +64,53 @@ __device__ __forceinline__ float adam_step(float th, const float g, float &m, fl
 // sin(fl(theta + pi_f)) and cos(theta) from ONE Cody-Waite reduction of theta.  fl(theta + pi_f) = theta + pi + e with
 // e = (pi_f - pi) - err, err the rounding error of the fp32 add recovered exactly by TwoSum; then
 // sin(theta + pi + e) = -(sin theta cos e + cos theta sin e) = -(sin theta + e cos theta) up to e^2 < 1e-13.
+// Round 4: the reduction is by PI, not pi / 2 - theta = k pi + r, |r| <= pi / 2: sin theta = (-1)^k S(r), cos theta = (-1)^k C(r) with an
+// odd degree-11 / even degree-12 polynomial pair (tools/trig_fit.py: fitted to 2e-11 / 1e-12, evaluated in fp32 they stay within
+// 1.2e-7 / 1.5e-7 ABSOLUTE of sin / cos for |theta| <= 5e4 - the [-pi/4, pi/4] pair of rounds 1-3: 7e-8; one fp32 ulp of the angular
+// velocity the value feeds is 1.2e-7 .. 4.8e-7).  Gone with it: the two polynomial swaps and three selects on the quadrant
+// (v_cmp / v_cndmask / VOP3 negations: 41 of the step's 171 issue cycles, tools/valu_rate_probe.hip) - the sign is the parity bit of
+// k, taken from the mantissa of fl(theta / pi + 1.5 * 2^23), which is also how k is rounded (no v_rndne / v_cvt).  The rollout step of the
+// product tick: 56 -> 47 instructions, 171 -> 134 issue cycles.  Valid for |theta| < 2^22 pi (the callers hold |theta| <= 5e4).
 __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
-  int q;
-  const float r = trig_reduce(th, &q);
-  const float ps = poly_sin(r), pc = poly_cos(r);
-  float sn = (q & 1) ? pc : ps;
-  float cs = (q & 1) ? ps : pc;
-  sn = (q & 2) ? -sn : sn;
-  cs = ((q + 1) & 2) ? -cs : cs;
+#ifdef DUST_OLD_TRIG  // A/B only: the pi / 2 reduction of rounds 1-3
+  int q_;
+  const float r_ = trig_reduce(th, &q_);
+  const float ps = poly_sin(r_), pc = poly_cos(r_);
+  float sn_ = (q_ & 1) ? pc : ps;
+  float cs_ = (q_ & 1) ? ps : pc;
+  sn_ = (q_ & 2) ? -sn_ : sn_;
+  cs_ = ((q_ + 1) & 2) ? -cs_ : cs_;
+  const float tp_ = th + PI_F;
+  const float bb_ = tp_ - th;
+  const float err_ = (th - (tp_ - bb_)) + (PI_F - bb_);
+  const float e_ = 8.742278000372485e-8f - err_;
+  *sin_tp = -fmaf(e_, cs_, sn_);
+  *cos_th = cs_;
+  return;
+#endif
+  const float magic = 12582912.0f;  // 1.5 * 2^23: fl(x + magic) - magic = rint(x), and bit 0 of fl(x + magic) is the parity of rint(x)
+  const float t = fmaf(th, 0.318309886183790671538f, magic);
+  const float kf = t - magic;
+  const unsigned int sgn = __float_as_uint(t) << 31;
+  float r = fmaf(kf, -(2.0f * 1.57079601e+00f), th);  // the three-term pi / 2 of trig_reduce, doubled (exact)
+  r = fmaf(kf, -(2.0f * 3.13916473e-07f), r);
+  r = fmaf(kf, -(2.0f * 5.39030253e-15f), r);
+  const float s = r * r;
+  float p = -2.381653097e-08f;
+  p = fmaf(p, s, 2.752084583e-06f);
+  p = fmaf(p, s, -1.984076807e-04f);
+  p = fmaf(p, s, 8.333330043e-03f);
+  p = fmaf(p, s, -1.666666716e-01f);
+  float sn = fmaf(p, r * s, r);
+  float q = 1.989598042e-09f;
+  q = fmaf(q, s, -2.752404384e-07f);
+  q = fmaf(q, s, 2.480102921e-05f);
+  q = fmaf(q, s, -1.388888457e-03f);
+  q = fmaf(q, s, 4.166666791e-02f);
+  q = fmaf(q, s, -5.000000000e-01f);
+  float cs = fmaf(q, s, 1.0f);
+  sn = __uint_as_float(__float_as_uint(sn) ^ sgn);
+  cs = __uint_as_float(__float_as_uint(cs) ^ sgn);
   const float tp = th + PI_F;
   const float bb = tp - th;
   const float err = (th - (tp - bb)) + (PI_F - bb);  // exact: th + PI_F = tp + err

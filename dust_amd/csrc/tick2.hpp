@@ -661,7 +661,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           double tot = 0.0;
           float traj;
           if (fast_trig && fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f) {
-            const float dt = (float)f->dm.dt, mt = f->dm.max_torque, ms = f->dm.max_speed_pend, chol0 = f->chol_a[0];
+            const float dt = (float)f->dm.dt, mt = f->dm.max_torque, ms = f->dm.max_speed_pend;
+            float chol0 = f->chol_a[0];
+            asm volatile("" : "+v"(chol0));  // (a vector register: a VOP2 with a scalar operand issues in 4.3 cycles instead of 2.6)
             const v2f W = {f->dm.w_cos, f->dm.w_vel};
             float sn, cs;
 #ifdef T2_ABL_ROLL  // timing ablation (results invalid): one step instead of H
@@ -743,13 +745,15 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           const float base = f->eps_base_mode ? thj : f->a_seq[j];
           const float *tp = tile_p + j;
           const float *op_ = same_w ? cst_p : omg_p;
-          for (int s0 = (wave & 1) * 64; s0 < S; s0 += 128) {
-            const int s1 = min(s0 + 64, S);
+          {
+            for (int s0 = (wave & 1) * 64; s0 < S; s0 += 128) {
+              const int s1 = min(s0 + 64, S);
 #pragma unroll 4
-            for (int s = s0 + q; s < s1; s += 2) {
-              const float av = thj + lj * tp[s * Dp];
-              g = fmaf(cst_p[s], (av - thj) * is2, g);
-              am = fmaf(op_[s], av - base, am);
+              for (int s = s0 + q; s < s1; s += 2) {
+                const float av = thj + lj * tp[s * Dp];
+                g = fmaf(cst_p[s], (av - thj) * is2, g);
+                am = fmaf(op_[s], av - base, am);
+              }
             }
           }
         }
