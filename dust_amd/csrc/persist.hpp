@@ -385,12 +385,12 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
     if (f.eps == nullptr) {
       for (int s = tid; s < S; s += nt) {
         float *row = tile + s * Dp;
-        for (int j4 = 0; j4 * 4 < D; ++j4) {
-          float z[4];
-          philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), ctr_iter0 + (uint32_t)k, ctr_tick, z);
+        for (int j8 = 0; j8 * 8 < D; ++j8) {
+          float z[8];
+          philox_normal8(a.seed, (uint32_t)j8, (uint32_t)(s * N + n), ctr_iter0 + (uint32_t)k, ctr_tick, z);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (j4 * 4 + q < D) row[j4 * 4 + q] = z[q];
+          for (int q = 0; q < 8; ++q)
+            if (j8 * 8 + q < D) row[j8 * 8 + q] = z[q];
         }
       }
     } else {

@@ -242,15 +242,15 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   const int G = ONE ? 1 : a.G, sub = ONE ? nt : nt / a.G;
   const int mg = ONE ? 0 : __builtin_amdgcn_readfirstlane(tid / sub);  // sub is a multiple of 64: a wave belongs to one group
   const int ts = ONE ? tid : tid - mg * sub;
-  if (a.noise_mode == NOISE_PHILOX) {  // the lanes of a sample fill ITS row (4-element blocks dealt over the groups)
+  if (a.noise_mode == NOISE_PHILOX) {  // the lanes of a sample fill ITS row (8-element blocks dealt over the groups)
     for (int s = ts; s < S; s += sub) {
       float *act = tile + s * Dp;
-      for (int j4 = mg; j4 * 4 < D; j4 += G) {
-        float z[4];
-        philox_normal4(a.seed, (uint32_t)j4, (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);
+      for (int j8 = mg; j8 * 8 < D; j8 += G) {
+        float z[8];
+        philox_normal8(a.seed, (uint32_t)j8, (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = j4 * 4 + q;
+        for (int q = 0; q < 8; ++q) {
+          const int j = j8 * 8 + q;
           if (j < D) act[j] = th[j] + pick_da<DA>(a.chol_a, j) * z[q];
         }
       }

@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256) void skid_rollout_kernel(const SkidArgs a) {
   auto action = [&](const int j) -> float {
     if (a.noise_mode == NOISE_ACTIONS) return nz[j];
     if (a.noise_mode == NOISE_EPS) return th[j] + a.chol_a[j & 1] * nz[j];
-    float z[4];
-    philox_normal4(a.seed, (uint32_t)(j >> 2), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
-    return th[j] + a.chol_a[j & 1] * z[j & 3];
+    float z[8];
+    philox_normal8(a.seed, (uint32_t)(j >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
+    return th[j] + a.chol_a[j & 1] * z[j & 7];
   };
   if (a.actions_out)
     for (int j = 0; j < D; ++j) a.actions_out[((size_t)s * N + n) * D + j] = action(j);

@@ -262,6 +262,12 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
       const int j = min((t * NKW + kw) * 16 + u, N - 1);
       y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
       y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
+#ifdef T2_ABL_EXTRA  // timing ablation (results unchanged): a third 16-byte piece per lane and step, from another line
+      {
+        const v4f yx = t2_ld16(rx, (min(j + 16, N - 1) * T2_ROW + 8 * c) * 4);
+        asm volatile("" ::"v"(yx));
+      }
+#endif
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p]);
@@ -464,12 +470,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       for (int r = split == 2 ? (lid >> 1) : lid; r < rows; r += nl / split) {
         const int p = r / S, s = r - p * S;
         float *row = tile + (size_t)r * Dp;
-        for (int j4 = half; j4 * 4 < D; j4 += split) {
-          float z[4];
-          philox_normal4(f->seed, (uint32_t)j4, (uint32_t)(s * N + n_first + p), ctr_iter0 + (uint32_t)k, ctr_tick, z);
+        for (int j8 = half; j8 * 8 < D; j8 += split) {
+          float z[8];
+          philox_normal8(f->seed, (uint32_t)j8, (uint32_t)(s * N + n_first + p), ctr_iter0 + (uint32_t)k, ctr_tick, z);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (j4 * 4 + q < D) row[j4 * 4 + q] = z[q];
+          for (int q = 0; q < 8; ++q)
+            if (j8 * 8 + q < D) row[j8 * 8 + q] = z[q];
         }
       }
     } else {
