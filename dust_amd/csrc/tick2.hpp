@@ -128,6 +128,12 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line /* the workgro
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
 // f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
 enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
+#ifndef T2_PRIO_OWNERSTAGE
+#define T2_PRIO_OWNERSTAGE 3
+#endif
+#ifndef T2_PRIO_OWNERSTEIN
+#define T2_PRIO_OWNERSTEIN 0
+#endif
 __device__ __forceinline__ float t2_quad_sum(float v) {  // quad permutes never read an invalid lane: bound_ctrl spares the `old` operand
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
@@ -795,6 +801,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     // the pass partials of the four waves that hold the query, grad_lik from the two R waves' pieces of the particle's sample softmax.
     float gs_keep = 0.f, gp_keep = 0.f;
     if (isown) {
+      DUST_PRIO(T2_PRIO_OWNERSTAGE);  // the score rows are what every other workgroup waits for: ahead of the Stein pass and the noise draw
       const float *r0 = red_w + (op * 2) * 4, *r1 = r0 + 4;
       const float m0 = r0[0], m1 = r1[0], cmin = fminf(m0, m1);
       const float f0 = expf(-m0 * f->alpha - (-cmin * f->alpha)), f1 = expf(-m1 * f->alpha - (-cmin * f->alpha));
@@ -834,6 +841,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       gs_keep = gs;
       scl[op * T2_ROW + od] = ownv ? gs + gp_keep : 0.f;
       publish_rows(scl, f->sq + (size_t)k * N * T2_ROW, cnt_score);
+      DUST_PRIO(T2_PRIO_OWNERSTEIN);  // (these two waves start their share of the Stein pass last)
       T2_TL(8, 16 * k + 7);
       if (ownv) {
         f->score[no] = gs_keep + gp_keep;
@@ -846,6 +854,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
       else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
       rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
+      DUST_PRIO(0);
       T2_TL(8, 16 * k + 11);
       T2_TL(15, 16 * k + 6);
     }
@@ -910,6 +919,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     f = t2_args();
     T2_TL(0, 16 * k + 12);
     // ================= phase 6: phi, optimiser step, theta rows out (waves 8-9) =================
+    float phi_keep = 0.f;
     if (isown) {
       float sa = 0.f;
       {
@@ -932,11 +942,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         flag_th[op] = ((badm >> (lane & 32)) & 0xffffffffull) ? 1.f : 0.f;
         flag_eps[(k & 1) * T2_PW + op] = 0.f;  // read by this iteration's rollouts; iteration k + 2 stages its noise behind barrier B6
       }
+      phi_keep = phi;
+    }
+    if (isown) {
       if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq + (size_t)(k + 1) * N * T2_ROW, cnt_theta);
       T2_TL(8, 16 * k + 13);
-      if (ownv) f->phi[no] = phi;
+      if (ownv) f->phi[no] = phi_keep;
     }
-    wg_sync();  // B6
+    wg_sync();  // B6  (tried: the barrier in front of the publish, so that the rollout waves start ~1 us earlier - +1.3 us per tick, A/B)
     T2_TL(0, 16 * k + 14);
   }
 

@@ -22,7 +22,7 @@ for rep in range(5):
 print("%.2f" % best)
 '''
 libs = sys.argv[1:]
-for rnd in range(3):
+for rnd in range(int(os.environ.get('AB_ROUNDS', '3'))):
     row = []
     for lib in libs:
         env = dict(os.environ, DUST_AMD_LIB=os.path.abspath(lib))
