@@ -507,6 +507,22 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
     }
   };
+  // device noise of iteration k, by the rollout waves: every wave draws the rows of ITS OWN samples (particle wave >> 1, samples
+  // (wave & 1) * 64 + lane + 128 i), so a wave may go from its draw into its rollouts - and from its weighted sums into the next draw -
+  // without a barrier in between
+  auto draw_own_rows = [&](const T2ArgPtr f, const int k, const int wave, const int lane) {
+    const int rp = wave >> 1;
+    for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
+      float *row = tile + (size_t)(rp * S + s) * Dp;
+      for (int j8 = 0; j8 * 8 < D; ++j8) {
+        float z[8];
+        philox_normal8(f->seed, (uint32_t)j8, (uint32_t)(s * N + n_first + rp), ctr_iter0 + (uint32_t)k, ctr_tick, z);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (j8 * 8 + q < D) row[j8 * 8 + q] = z[q];
+      }
+    }
+  };
   // the workgroup's particles into LDS and out to the other workgroups FIRST (generation 0; the exchange buffer is scratch: harmless if
   // the tick does not start): their hop runs under the first noise draw (116.35 -> 115.8 us per tick, A/B)
   if (isown) {
@@ -516,8 +532,9 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     publish_rows(th, f->xq, cnt_theta);
   }
   T2_TL(0, 122);
+  const bool own_first = f->n_iters > 0 && f->eps == nullptr;  // device noise: drawn behind the barrier, each rollout wave its own rows
   if (f->n_iters > 0) {
-    draw_noise(f, 0, tid0, T2_NT);
+    if (!own_first) draw_noise(f, 0, tid0, T2_NT);
     if (wave == 11) make_coefs(f, 0);
   }
   // ... and now what the other loads brought: the likelihood of the last sample, the logit reference
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   const float lm_ref = wave_max((tid0 & 63) < T2_NT / 64 ? wred[tid0 & 63] : -INFINITY);
   const bool same_w = (f->alpha * f->temp == 1.0f);
   const int lane0 = tid0 & 63;
+  if (own_first && wave < 8) draw_own_rows(f, 0, wave, lane0);  // (the pair waves are on their way to the first hand-off meanwhile)
 
   const int wave0 = wave;
   for (int k = 0; k < f->n_iters; ++k) {
@@ -862,7 +880,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       t2_poll(cnt_score + rep_off, 2u, (unsigned int)(k + 1), G, lane, tflag);
       T2_TL(10, 16 * k + 8);
     } else if (wave < 8) {
-      if (k + 1 < f->n_iters) draw_noise(f, k + 1, tid, 512);
+      if (k + 1 < f->n_iters) {
+        if (f->eps == nullptr) draw_own_rows(f, k + 1, wave, lane);
+        else draw_noise(f, k + 1, tid, 512);
+      }
       T2_TL(0, 16 * k + 9);
     } else if (wave == 11) {
       if (k + 1 < f->n_iters) make_coefs(f, k + 1);
