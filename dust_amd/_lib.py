@@ -119,6 +119,7 @@ SYMBOLS = {
     "dust_get_actions": (C.c_int, [VP, FP]),
     "dust_get_score": (C.c_int, [VP, FP]),
     "dust_get_phi": (C.c_int, [VP, FP]),
+    "dust_get_score_parts": (C.c_int, [VP, FP, FP]),
     "dust_get_log_weights": (C.c_int, [VP, FP, FP]),
     "dust_get_bandwidths": (C.c_int, [VP, FP]),
     "dust_gather_buffers": (C.c_int, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(C.c_size_t)]),

@@ -377,6 +377,12 @@ class Context:
     def get_phi(self):
         return self._get(L.load().dust_get_phi, (self.N, self.H, self.da))
 
+    def get_score_parts(self):
+        """(grad_lik, grad_pri) of the last SVGD iteration (svmpc.py:38-53)."""
+        gl, gp = (np.empty((self.N, self.H, self.da), np.float32) for _ in range(2))
+        L.check(L.load().dust_get_score_parts(self._h, _p(gl), _p(gp)))
+        return gl, gp
+
     def get_log_weights(self):
         ll, lp = np.empty(self.N, np.float32), np.empty(self.N, np.float32)
         L.check(L.load().dust_get_log_weights(self._h, _p(ll), _p(lp)))

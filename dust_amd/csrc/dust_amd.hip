@@ -152,6 +152,24 @@ struct dust_ctx {
   float t2_state[4];            // inputs of the last tick2 launch (replayed on the launch-per-iteration path if it did not start)
   int t2_steps;
   bool t2_fwd, t2_replayable;
+  // One entry per one-launch tick enqueued since the last settle: the inputs its replay needs.  A launch that does not start - or does
+  // not commit - makes every LATER one-launch tick of the context abort at its start as well (the kernels compare the device's abort
+  // count with the value the host knew when it launched them: `expect_aborts`), so the ticks that have to be replayed are always the
+  // tail of this queue and are replayed in their order, each with its own inputs.
+  // Development switches and test hooks (environment variables), read ONCE when the context is created or cloned - the tick entry
+  // points called getenv() several times per control tick before.  -1: unset, otherwise atoi of the value.
+  struct EnvSw {
+    int comm_force, pair_big, pair_fused, states_form, dense, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
+        tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+  } env;
+  struct T2Replay {
+    float state[4];
+    int steps;
+    bool fwd, replayable, mu_aliased;
+    std::vector<float> params;  // host copy of the caller's [steps][M][P] dynamics samples (empty: none)
+  };
+  std::vector<T2Replay> *t2_queue;  // (a pointer: the context block is zero-filled as a whole when it is created)
+  const float *t2_params_host;  // the caller's params of the call being staged (valid inside try_persistent only)
   long long t2_replays;         // sticky: ticks replayed so far (dust_tick_stats)
   long long n_tick2, n_tick1, n_tick_other;  // sticky: optimize / tick calls served by tick2.hpp, persist.hpp, the other paths
   // hipGraph replay of a whole tick (dust_svmpc_tick)
@@ -346,7 +364,29 @@ static void free_all(dust_ctx *c) {
 
 // a communicator of one rank is the unsharded problem: it runs the single-GPU path (DUST_COMM_FORCE=1: development switch that
 // sends a world-1 context through the sharded tick and its RCCL calls, for tests and per-collective latency measurements)
-static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || getenv("DUST_COMM_FORCE") != nullptr); }
+static int env_int(const char *name) {  // -1: unset; a set but empty / non-numeric value counts as 1 ("switch on")
+  const char *v = getenv(name);
+  if (!v) return -1;
+  return (*v >= '0' && *v <= '9') ? atoi(v) : 1;
+}
+static void env_read(dust_ctx *c) {
+  c->env.comm_force = env_int("DUST_COMM_FORCE");
+  c->env.pair_big = env_int("DUST_PAIR_BIG");
+  c->env.pair_fused = env_int("DUST_PAIR_FUSED");
+  c->env.states_form = env_int("DUST_STATES_FORM");
+  c->env.dense = env_int("DUST_DENSE");
+  c->env.logp_mfma = env_int("DUST_LOGP_MFMA");
+  c->env.no_fuse = env_int("DUST_NO_FUSE");
+  c->env.no_persist = env_int("DUST_NO_PERSIST");
+  c->env.no_share = env_int("DUST_NO_SHARE");
+  c->env.no_tick1_barrier = env_int("DUST_NO_TICK1_BARRIER");
+  c->env.tick1_test_abort = env_int("DUST_TICK1_TEST_ABORT");
+  c->env.no_tick2 = env_int("DUST_NO_TICK2");
+  c->env.tick2_test_abort = env_int("DUST_TICK2_TEST_ABORT");
+  c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
+  c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
+}
+static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || c->env.comm_force >= 0); }
 static void comm_release(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
 static bool tick2_shape_ok(dust_ctx *c, int n_steps);
@@ -377,6 +417,7 @@ extern "C" void dust_destroy(dust_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   comm_release(c);
   free_all(c);
+  delete c->t2_queue;
   delete c;
 }
 
@@ -411,6 +452,12 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   dust_ctx *c = new (std::nothrow) dust_ctx();
   if (!c) return fail(DUST_ERR_HIP, "out of host memory");
   memset((void *)c, 0, sizeof *c);
+  env_read(c);
+  c->t2_queue = new (std::nothrow) std::vector<dust_ctx::T2Replay>();
+  if (!c->t2_queue) {
+    delete c;
+    return fail(DUST_ERR_HIP, "out of host memory");
+  }
   c->cfg = *cfg;
   c->N = cfg->n_policies;
   c->S = cfg->n_samples;
@@ -513,11 +560,13 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
                           bool *done);
 static int tick_outputs(dust_ctx *c, float *a_seq, float *p_weights);
 static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed);
+static void t2_queue_push(dust_ctx *c, const float *state4, int steps, bool fwd, bool replayable, bool mu_aliased);
 
 // A wait inside a launch gave up.  The tick it belonged to is lost (its results are invalid and the particles may be partly updated);
 // what can be saved is the future: no kernel of this context spins on its own grid any more (handoff.hpp DUST_SPIN_TIMEOUT_TICKS).
 static void handoff_ban(dust_ctx *c) {
   c->handoff_banned = true;
+  c->persist_declined = 0;
   if (c->graph_exec) graph_drop(c);  // (a captured tick replays the fused launches)
 }
 // A wait of the owner-computes kernel gave up: clear the report, take the context off the spinning kernels, and tell whether the tick
@@ -585,6 +634,7 @@ extern "C" int dust_get_config(const dust_ctx *c, dust_config *out) {
 }
 
 extern "C" int dust_set_stream(dust_ctx *c, void *s) {
+  if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->graph_exec) graph_drop(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -599,12 +649,21 @@ static int d2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return DUST_OK;
 }
+// A one-launch tick enqueued earlier may not have started, or not committed (device shared): it - and every one-launch tick enqueued
+// behind it, which then aborted as well (`expect_aborts`) - is replayed when the pending launches are SETTLED (dust_sync: stream
+// synchronisation, status words, t2_settle).  Everything that reads or changes the particle / prior / optimiser state from the host, or
+// runs plain kernels on it, settles first (a forward on un-optimised particles, getters ahead of the replay); the one-launch
+// ticks themselves need no host round trip for that - the device-side chain keeps them in order.
+static int settle_pending(dust_ctx *c) { return (c && c->t2_inflight) ? dust_sync(c) : DUST_OK; }
+
 static int h2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
+  TRY(settle_pending(c));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the caller owns (and may free/reuse) the host buffer
   return DUST_OK;
 }
 static int d2h(dust_ctx *c, void *dst, const void *src, size_t bytes) {
+  TRY(settle_pending(c));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DUST_OK;
@@ -612,6 +671,7 @@ static int d2h(dust_ctx *c, void *dst, const void *src, size_t bytes) {
 
 extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
   if (!src || !out) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(const_cast<dust_ctx *>(src)));
   TRY(dust_create(&src->cfg, out));
   dust_ctx *c = *out;
   HIP_TRY(hipStreamSynchronize(src->stream));
@@ -664,6 +724,7 @@ extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value,
 }
 
 extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
+  if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
   if (c->graph_exec) graph_drop(c);
@@ -681,6 +742,7 @@ extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
 }
 
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
+  if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
   if (c->graph_exec) graph_drop(c);
   const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
@@ -724,6 +786,7 @@ extern "C" int dust_set_theta(dust_ctx *c, const float *theta) {
 // h = clip(bw_scale * bandwidth^2 / log(N + 1), minimum_bw), evaluated here in double as the reference's Python floats are,
 // then used as an fp32 scalar by the tensor ops (K = exp(-d2 / h), dK = K (x - y) 2 / h).
 extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum_bw) {
+  if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->cfg.kernel != DUST_KERNEL_K2_IIDMP && c->cfg.kernel != DUST_KERNEL_K2_SHARED)
     return fail(DUST_ERR_STATE, "dust_set_k2_bandwidth: the context's kernel is not iid_mp(RBF)");
@@ -785,6 +848,7 @@ extern "C" int dust_get_a_mat(dust_ctx *c, float *a) {
 }
 extern "C" int dust_get_a_mix(dust_ctx *c, float *a) {
   if (!c || !a) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));
   if (c->have_sample) {
     amix_kernel<<<1, 1024, 0, c->stream>>>(c->eta, c->a_mix, c->N);
     HIP_TRY(hipGetLastError());
@@ -828,9 +892,9 @@ static int fused_dpb(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : 80); }
 static int fused_tq(int D) { return D <= 32 ? FusedGeom<32>::TQ : (D <= 64 ? FusedGeom<64>::TQ : FusedGeom<80>::TQ); }
 // "large key set": none of the small-N launch fusions (fused.hpp, persist.hpp) applies
 static bool pair_is_big(const dust_ctx *c) {
-  const char *env = getenv("DUST_PAIR_BIG");  // development switch: 0 forces the 32 x 64 kernel, 1 the large-set path from N = 2048 on
-  if (env && atoi(env) == 0) return false;
-  const bool forced = env && atoi(env) == 1;
+  // development switch DUST_PAIR_BIG: 0 forces the 32 x 64 kernel, 1 the large-set path from N = 2048 on
+  if (c->env.pair_big == 0) return false;
+  const bool forced = c->env.pair_big == 1;
   // (a rank of a sharded run qualifies from 512 local particles on: the fused pass slices the keys finely enough to fill the chip)
   // Just above the threshold the 32 x 64 kernels inside the fused launches (2 launches per iteration) still win while the rows are
   // short - measured, us per 5-iteration tick, large-set / small-set path: Pendulum N = 2048 D = 30: 434 / 355 (M = 8, cfg5: 742 / 620);
@@ -840,8 +904,7 @@ static bool pair_is_big(const dust_ctx *c) {
 }
 static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64 && c->nloc == c->N; }  // pairwise_big.hpp (unfused passes)
 static bool pair_fused_ok(const dust_ctx *c) {
-  const char *env = getenv("DUST_PAIR_FUSED");  // development switch: 0 keeps the two unfused passes
-  if (env && atoi(env) == 0) return false;
+  if (c->env.pair_fused == 0) return false;  // development switch DUST_PAIR_FUSED: 0 keeps the two unfused passes
   return pair_is_big(c) && c->mu_aliased && (c->cfg.kernel == DUST_KERNEL_K1_RBF || c->cfg.kernel == DUST_KERNEL_IMQ);
 }
 // key slices: `tiles` is the query-tile count of the PRIMARY kernel of the current state; a launcher whose kernel has another
@@ -1025,8 +1088,7 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
 
 // The whole-line stored-states form (rollout_states.hpp): Particle, fp32 in and out, 8-particle groups that are whole lines.
 static bool states_whole_lines(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, int *gw_out, size_t *lds_out) {
-  const char *env = getenv("DUST_STATES_FORM");  // development switch: 0 keeps the per-particle staging kernel
-  if (env && atoi(env) == 0) return false;
+  if (c->env.states_form == 0) return false;  // development switch DUST_STATES_FORM: 0 keeps the per-particle staging kernel
   if (c->cfg.model != DUST_MODEL_PARTICLE || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
   if (o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
   if (((c->H + 1) & 1) == 0 || c->H + 1 < 9) return false;
@@ -1044,8 +1106,7 @@ static bool states_whole_lines(const dust_ctx *c, const SampleOpts &o, const Rol
 
 // ... and its Pendulum counterpart: 16-particle groups of 8 (H+1)-byte rows
 static bool states_whole_lines_pend(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, size_t *lds_out) {
-  const char *env = getenv("DUST_STATES_FORM");
-  if (env && atoi(env) == 0) return false;
+  if (c->env.states_form == 0) return false;
   if (c->cfg.model != DUST_MODEL_PENDULUM || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
   if (o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
   if (((c->H + 1) & 1) == 0 || c->H < 16) return false;
@@ -1058,8 +1119,7 @@ static bool states_whole_lines_pend(const dust_ctx *c, const SampleOpts &o, cons
 
 // ... and the binary16 form of the Pendulum states (DUST_STORE_F16): 32-particle groups of 4 (H+1)-byte rows
 static bool states_whole_lines_pend_f16(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, size_t *lds_out) {
-  const char *env = getenv("DUST_STATES_FORM");
-  if (env && atoi(env) == 0) return false;
+  if (c->env.states_form == 0) return false;
   if (c->cfg.model != DUST_MODEL_PENDULUM || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
   if (!o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
   if ((c->N % 32) || (c->n0 % 32) || (c->nloc % 32)) return false;
@@ -1284,6 +1344,12 @@ extern "C" int dust_get_score(dust_ctx *c, float *s) {
   if (!c || !s) return fail(DUST_ERR_INVALID, "null argument");
   return d2h(c, s, c->score, (size_t)c->N * c->D * sizeof(float));
 }
+extern "C" int dust_get_score_parts(dust_ctx *c, float *gl, float *gp) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (gl) TRY(d2h(c, gl, c->grad_lik, (size_t)c->N * c->D * sizeof(float)));
+  if (gp) TRY(d2h(c, gp, c->grad_pri, (size_t)c->N * c->D * sizeof(float)));
+  return DUST_OK;
+}
 extern "C" int dust_get_phi(dust_ctx *c, float *s) {
   if (!c || !s) return fail(DUST_ERR_INVALID, "null argument");
   return d2h(c, s, c->phi, (size_t)c->N * c->D * sizeof(float));
@@ -1308,6 +1374,7 @@ extern "C" int dust_likelihood_log_prob(dust_ctx *c, float *ll) {
 extern "C" int dust_disco_forward(dust_ctx *c, const float *state, const float *actions, const float *params, int flags,
                                   float *costs, float *states, float *actions_out, float *omega) {
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, params, 1));
@@ -1341,6 +1408,7 @@ extern "C" int dust_disco_forward(dust_ctx *c, const float *state, const float *
 extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const float *eps, const float *params, int flags,
                                       float *costs, float *actions_out) {
   if (!c || !state) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, params, 1));
@@ -1367,6 +1435,7 @@ extern "C" int dust_likelihood_sample(dust_ctx *c, const float *state, const flo
 extern "C" int dust_likelihood_sample_at(dust_ctx *c, const float *state, const float *theta, const float *eps, const float *params, int flags,
                                          float *costs, float *actions_out) {
   if (!c || !state || !theta) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));
   if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass the [M][P] parameter samples");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(upload_state_params(c, state, params, 1));
@@ -1481,7 +1550,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   b.tiles = tiles;
   b.chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
   c->nz_ld = 0;
-  if (!getenv("DUST_DENSE")) {  // flags of the all-zero Gram blocks (development switch: evaluate everything)
+  if (c->env.dense < 0) {  // flags of the all-zero Gram blocks (development switch: evaluate everything)
     const int rows = std::max(tiles * fused_tq(a.D), ((c->nloc + 63) / 64) * 64);
     c->nz_ld = ((rows + 63) / 64) * 64;
     TRY(ensure(&c->nzf, &c->nzf_cap, ((size_t)b.chunks * c->nz_ld + 3) / 4));
@@ -1683,8 +1752,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   Prof p(c, DUST_K_PRIOR_SCORE);
   c->prior_js = 0;  // (launch_pair_fused sets its own slice count)
   if (logp_only && pair_fused_ok(c)) {  // large aliased set
-    const char *env = getenv("DUST_LOGP_MFMA");
-    if (!(env && atoi(env) == 0)) return launch_pair_logp_mfma(c, a);  // product-form distances on the matrix cores + log-sum-exp
+    if (c->env.logp_mfma != 0) return launch_pair_logp_mfma(c, a);  // product-form distances on the matrix cores + log-sum-exp
     return launch_pair_logp_big(c, a, tiles);                         // exact-difference distance pass + log-sum-exp
   }
   if (logp_only && !pair_big_kernel(c)) return launch_pair<PAIR_LOGP>(c, a, tiles);  // SVMPC.forward needs log p(theta) only
@@ -1953,6 +2021,7 @@ static int launch_stein_update(dust_ctx *c, int apply) {
 
 extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *actions, float *phi, float *grad_lik, float *grad_pri) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  TRY(settle_pending(c));
   if ((costs == nullptr) != (actions == nullptr)) return fail(DUST_ERR_INVALID, "pass both costs and actions, or neither");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(launch_prior(c));
@@ -2204,6 +2273,7 @@ extern "C" int dust_svmpc_optimize(dust_ctx *c, const float *state, int n_steps,
     TRY(try_persistent(c, state, n_steps, eps, params, flags, /*do_forward=*/false, &done));
     if (done) return DUST_OK;
   }
+  TRY(settle_pending(c));  // (plain kernels from here on)
   TRY(upload_state_params(c, state, params, n_steps));
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);  // in floats (binary16: S*N*D is even or n_steps is 1)
   if ((flags & DUST_EPS_F16) && eps && n_steps > 1 && (((size_t)c->S * c->N * c->D) & 1))
@@ -2326,6 +2396,7 @@ static int resample_rows(dust_ctx *c, const float *host_rows, const float **dev)
 
 extern "C" int dust_svmpc_get_weights(dust_ctx *c, float *p_weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  TRY(settle_pending(c));
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: get_weights is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(forward_device(c));
@@ -2338,6 +2409,7 @@ extern "C" int dust_svmpc_get_weights(dust_ctx *c, float *p_weights) {
 
 extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float *last_row) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  TRY(settle_pending(c));
   if (strategy < DUST_ROLL_REPEAT || strategy > DUST_ROLL_RESAMPLE) return fail(DUST_ERR_INVALID, "%d is an invalid roll strategy.", strategy);
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the roll is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
@@ -2365,6 +2437,7 @@ extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float
 
 extern "C" int dust_svmpc_update_prior(dust_ctx *c, const float *weights) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  TRY(settle_pending(c));
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the prior refresh is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
   if (c->graph_exec) graph_drop(c);
@@ -2396,6 +2469,18 @@ extern "C" int dust_svmpc_forward_ex(dust_ctx *c, int steps, const float *resamp
   }
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context without a communicator: dust_comm_init, or use dust_svmpc_forward_local / _finish");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (steps == -1 && !resample_last_row && c->t2_inflight) {
+    // behind a one-launch optimize(): the forward as a one-launch tick without iterations - it stays in the device-side order of the
+    // one-launch ticks (an optimize() that did not start takes this forward with it into the replay) and needs no host round trip
+    bool done = false;
+    const float zero_state[4] = {0.f, 0.f, 0.f, 0.f};
+    TRY(try_persistent(c, zero_state, 0, nullptr, nullptr, 0, /*do_forward=*/true, &done));
+    if (done) {
+      if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+      return DUST_OK;
+    }
+  }
+  TRY(settle_pending(c));  // (plain kernels from here on)
   if (steps != -1 && c->graph_exec) graph_drop(c);
   const float *lr = nullptr;
   TRY(resample_rows(c, resample_last_row, &lr));
@@ -2420,7 +2505,7 @@ static int tick_occupancy(size_t lds, int *occ) {
 static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
-  const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;  // development switches (read per call)
+  const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;  // development switches
   if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
@@ -2456,7 +2541,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   {
     bool iso = true;
     for (int d = 1; d < c->da; ++d) iso = iso && c->cfg.sigma_p[d] == c->cfg.sigma_p[0];
-    const bool no_share = getenv("DUST_NO_SHARE") != nullptr;  // development switch
+    const bool no_share = c->env.no_share >= 0;  // development switch
     f.share_pair = (c->mu_aliased && iso && !no_share) ? 1 : 0;
     const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
     const float r = c->cfg.sigma_p[0] / ell;
@@ -2553,7 +2638,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
   f.zero_lines = lines;
   f.timeout_flag = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
   const bool mu_aliased_before = c->mu_aliased;
-  if (do_forward && !getenv("DUST_NO_TICK1_BARRIER")) {  // whole ticks only: an aborted optimize-only call would leave the host's particle-buffer bookkeeping ahead of the device
+  if (do_forward && c->env.no_tick1_barrier < 0) {  // whole ticks only: an aborted optimize-only call would leave the host's particle-buffer bookkeeping ahead of the device
     if (!c->tick1_start) {
       TRY(dalloc(&c->tick1_start, (size_t)CNT_STRIDE));
       HIP_TRY(hipMemsetAsync(c->tick1_start, 0, (size_t)CNT_STRIDE * sizeof(unsigned int), c->stream));
@@ -2564,9 +2649,10 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
     f.start_cnt = set + (size_t)(5 * f.tiles + 1) * CNT_STRIDE;
     f.go = c->tick1_start;
     f.abort_cnt = f.timeout_flag + 1;
+    f.expect_aborts = c->t2_aborts_seen;
     f.seq = c->tick1_seq;
-    if (const char *ta = getenv("DUST_TICK1_TEST_ABORT")) {  // test hook, as DUST_TICK2_TEST_ABORT
-      const int every = atoi(ta);
+    {  // test hook DUST_TICK1_TEST_ABORT, as DUST_TICK2_TEST_ABORT
+      const int every = c->env.tick1_test_abort;
       f.test_abort = every > 0 && ((c->n_tick1 + 1) % every) == 0;
     }
   }
@@ -2607,6 +2693,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
     c->t2_fwd = true;
     c->t2_replayable = eps_dev == nullptr;
     c->t2_mu_aliased = mu_aliased_before;
+    t2_queue_push(c, c->t2_state, n_steps, true, eps_dev == nullptr, mu_aliased_before);
   }
   if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
   if (do_forward) c->mu_aliased = true;
@@ -2623,7 +2710,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 // *done stays false when the shape / configuration does not qualify (persist.hpp's form or the launch-per-iteration path run).
 // the static part of launch_tick2's eligibility (everything but "the prior means alias the particles")
 static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
-  if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return false;
+  if (c->env.no_tick2 >= 0 || c->env.no_fuse >= 0 || c->env.no_persist >= 0) return false;
   if (c->prof || c->handoff_banned || c->nloc != c->N || c->theta_pinned || n_steps < 1) return false;
   if (c->cfg.model != DUST_MODEL_PENDULUM && c->cfg.model != DUST_MODEL_PARTICLE) return false;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return false;
@@ -2644,7 +2731,7 @@ static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
 static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
   if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
-  if (getenv("DUST_NO_TICK2") || getenv("DUST_NO_FUSE") || getenv("DUST_NO_PERSIST")) return DUST_OK;  // development switches (read per call)
+  if (c->env.no_tick2 >= 0 || c->env.no_fuse >= 0 || c->env.no_persist >= 0) return DUST_OK;  // development switches
   if (c->prof || c->nloc != c->N || c->theta_pinned || c->capturing || !c->mu_aliased) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
@@ -2684,14 +2771,15 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   f.roll_strategy = c->cfg.roll_strategy;
   f.weighted_prior = c->cfg.weighted_prior;
   f.coef_given = ra.coef_given;
-  if (const char *ta = getenv("DUST_TICK2_TEST_ABORT")) {  // test hook: exercises the replay path without a second tenant on the device
-    const int every = atoi(ta);
+  {  // test hook DUST_TICK2_TEST_ABORT: exercises the replay path without a second tenant on the device
+    const int every = c->env.tick2_test_abort;
     f.test_abort = every > 0 && ((c->n_tick2 + 1) % every) == 0;
   }
-  if (const char *ta = getenv("DUST_TICK2_TEST_TIMEOUT")) {  // test hook: a tick whose last wait "gives up" - not committed, replayed, context banned
-    const int every = atoi(ta);
+  {  // test hook DUST_TICK2_TEST_TIMEOUT: a tick whose last wait "gives up" - not committed, replayed, context banned
+    const int every = c->env.tick2_test_timeout;
     if (every > 0 && ((c->n_tick2 + 1) % every) == 0) f.test_abort = 2;
   }
+  f.expect_aborts = c->t2_aborts_seen;
   f.grid_words = c->cfg.model == DUST_MODEL_PARTICLE ? ra.grid_words : 0;
   f.coef_host[0] = ra.coef_host[0];
   f.coef_host[1] = ra.coef_host[1];
@@ -2794,6 +2882,7 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   c->t2_fwd = do_forward;
   c->t2_replayable = eps_dev == nullptr;
   c->t2_mu_aliased = true;
+  t2_queue_push(c, c->t2_state, n_steps, do_forward, eps_dev == nullptr, true);
   if (do_forward) c->mu_aliased = true;
   c->actions_valid = false;
   c->have_sample = true;
@@ -2960,7 +3049,7 @@ static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const flo
   TRY(upload_state_params(c, state, params, n_steps));
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
   const size_t shard = (size_t)c->nloc * c->D;
-  const bool overlap = !c->prof && c->stream2 && !getenv("DUST_NO_COMM_OVERLAP");  // (development switch)
+  const bool overlap = !c->prof && c->stream2 && c->env.no_comm_overlap < 0;  // (development switch)
   bool gather_in_flight = false;
   for (int k = 0; k < n_steps; ++k) {
     const float *nd = nullptr;
@@ -3012,22 +3101,36 @@ static int sharded_forward(dust_ctx *c) {
   return gather_inplace(c, c->theta, (size_t)c->nloc * c->D);  // the other ranks' rolled rows
 }
 
+// the replay inputs of the one-launch tick just enqueued (t2_settle)
+static void t2_queue_push(dust_ctx *c, const float *state4, int steps, bool fwd, bool replayable, bool mu_aliased) {
+  dust_ctx::T2Replay r;
+  for (int k = 0; k < 4; ++k) r.state[k] = state4[k];
+  r.steps = steps;
+  r.fwd = fwd;
+  r.replayable = replayable;
+  r.mu_aliased = mu_aliased;
+  if (c->t2_params_host && c->cfg.dim_p > 0) r.params.assign(c->t2_params_host, c->t2_params_host + (size_t)steps * c->M * c->cfg.dim_p);
+  c->t2_queue->push_back(std::move(r));
+}
+
 // stage the caller's inputs and try the persistent launch; *done = false -> nothing was launched
 static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
                           bool *done) {
   *done = false;
-  const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_PERSIST") != nullptr;
+  const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;
   if (off || c->no_handoff || c->handoff_banned || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (c->N > 4096 || c->D > 64 || pair_is_big(c) || c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;
-  if (c->cfg.dim_p > 0 && !params) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
+  if (c->cfg.dim_p > 0 && !params && n_steps > 0) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
   // The launchers decide eligibility (slice counts, occupancy, rollout form ...) only after the inputs are staged; what they decline
   // is static for a context in a given state, so a decline is remembered and the same call is not staged twice again
   const unsigned long key = 1ul + (unsigned long)n_steps * 16ul + (do_forward ? 8ul : 0ul) + (c->mu_aliased ? 4ul : 0ul) + (eps ? 2ul : 0ul) +
                             (c->have_sample ? 1ul : 0ul) * 1000003ul;
   if (c->persist_declined == key) return DUST_OK;
   HIP_TRY(hipSetDevice(c->cfg.device));
+  if (c->t2_queue->size() >= 4096) TRY(dust_sync(c));  // (an open-loop caller that never reads outputs: settle now and then)
   TRY(upload_state_params(c, nullptr, params, n_steps));
+  c->t2_params_host = params;
   const float *eps_dev = eps;
   c->noise_f16 = false;
   if (eps && !(flags & DUST_PTR_DEVICE)) {
@@ -3039,7 +3142,7 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
   TRY(launch_tick2(c, state, n_steps, eps_dev, do_forward, done));
   if (*done) return DUST_OK;
   TRY(launch_tick(c, state, n_steps, eps_dev, do_forward, done));
-  if (!*done) c->persist_declined = key;
+  if (!*done && !c->capturing) c->persist_declined = key;  // (a decline during graph capture says nothing about the eager call)
   return DUST_OK;
 }
 
@@ -3094,19 +3197,25 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
   c->t2_inflight = false;
   const unsigned int n = aborts_now - c->t2_aborts_seen;
   c->t2_aborts_seen = aborts_now;
+  std::vector<dust_ctx::T2Replay> q;
+  q.swap(*c->t2_queue);
   if (!n) return DUST_OK;
-  if (!c->t2_replayable)
-    return fail(DUST_ERR_HIP, "%u control tick(s) with caller-supplied noise did not start (device shared with another context): repeat them", n);
+  // every one-launch tick behind the first one that did not start (or commit) aborted as well (`expect_aborts`): the last n entries
+  if (n > q.size()) return fail(DUST_ERR_STATE, "%u one-launch tick(s) reported as not started, %zu on record", n, q.size());
+  for (size_t i = q.size() - n; i < q.size(); ++i)
+    if (!q[i].replayable)
+      return fail(DUST_ERR_HIP, "%u control tick(s) did not start (device shared with another context), one of them with caller-supplied noise: repeat them", n);
   // (the device is shared - that is why the tick did not start - so the replay uses plain kernels only: the fused launch forms spin on
   //  their own workgroups too and could meet the same tenant)
   c->no_handoff = true;
-  if (!c->t2_mu_aliased) c->mu_aliased = false;  // (a context's first tick: its prior means are still c->mu; the replay's forward aliases them)
   int st = DUST_OK;
-  for (unsigned int i = 0; i < n && st == DUST_OK; ++i) {
-    st = upload_state_params(c, c->t2_state, nullptr, c->t2_steps);
+  for (size_t i = q.size() - n; i < q.size() && st == DUST_OK; ++i) {
+    const dust_ctx::T2Replay &r = q[i];
+    if (!r.mu_aliased) c->mu_aliased = false;  // (a context's first tick: its prior means are still c->mu; the replay's forward aliases them)
+    st = upload_state_params(c, r.state, r.params.empty() ? nullptr : r.params.data(), r.steps);
     c->noise_f16 = false;
-    for (int k = 0; k < c->t2_steps && st == DUST_OK; ++k) st = step_device(c, nullptr, k);
-    if (c->t2_fwd && st == DUST_OK) {
+    for (int k = 0; k < r.steps && st == DUST_OK; ++k) st = step_device(c, nullptr, k);
+    if (r.fwd && st == DUST_OK) {
       st = forward_device(c);
       if (st == DUST_OK) st = forward_finish_device(c);
     }
@@ -3198,6 +3307,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
       return DUST_OK;
     }
   }
+  TRY(settle_pending(c));  // (plain kernels / a captured graph from here on)
   static const bool no_graph = getenv("DUST_NO_GRAPH") != nullptr;  // development switch
   // (a second context on the device: the in-launch hand-off kernels are chained across streams at every launch - PersistChain - which a
   //  replayed capture would not be)
@@ -3271,6 +3381,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
 
 extern "C" int dust_disco_step(dust_ctx *c, int strategy, int steps, const float *ext, float *next) {
   if (!c || !next) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));
   if (strategy < 0 || strategy > 2 || (strategy == DUST_STEP_EXTERNAL && !ext)) return fail(DUST_ERR_INVALID, "Invalid value for strategy.");
   if (steps < 1 || steps > c->H) return fail(DUST_ERR_INVALID, "steps out of range");
   HIP_TRY(hipSetDevice(c->cfg.device));
@@ -3384,6 +3495,7 @@ extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_wei
 
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int dust_profile_enable(dust_ctx *c, int on) {
+  if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->graph_exec) graph_drop(c);
   c->prof = on != 0;

@@ -77,6 +77,7 @@ struct TickArgs {
                                              // with the set by the next tick) - no running totals, no per-lane index into this block
   unsigned int seq;
   int test_abort;
+  unsigned int expect_aborts;  // *abort_cnt as the host knew it at launch: a larger value = an earlier one-launch tick awaits its replay, abort too
   // forward outputs
   float *logp, *lw, *pw, *a_seq_out, *logmix, *mixw;
   int *istar;
@@ -913,7 +914,8 @@ __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void svmpc_tick_kernel
             }
           }
         }
-        const bool all_ok = __all(ok ? 1 : 0) && !f.test_abort;
+        const bool all_ok = __all(ok ? 1 : 0) && !f.test_abort &&
+                            __hip_atomic_load(f.abort_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.expect_aborts;
         g = all_ok ? f.seq : (f.seq | 0x80000000u);
         if (lane == 0) {
           if (!all_ok) __hip_atomic_fetch_add(f.abort_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

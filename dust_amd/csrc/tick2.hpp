@@ -558,7 +558,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           }
         }
       }
-      const bool all_ok = __all(ok ? 1 : 0) && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1;
+      const bool all_ok = __all(ok ? 1 : 0) && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1 &&
+                          __hip_atomic_load(f->status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f->expect_aborts;  // (an earlier tick awaits its replay)
       if (lane == 0) {
         if (!all_ok) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(go, all_ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -611,7 +612,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     const bool all_in = __all(ok ? 1 : 0);
     if (b == 0) {
-      const bool all_ok = all_in && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1;
+      const bool all_ok = all_in && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && f->test_abort != 1 &&
+                          __hip_atomic_load(f->status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f->expect_aborts;  // (an earlier tick awaits its replay)
       if (lane == 0) {
         if (!all_ok) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(go, all_ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

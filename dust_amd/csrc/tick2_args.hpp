@@ -33,6 +33,9 @@ struct Tick2Args {
   int coef_given;
   int test_abort;        // test hooks, every k-th launch.  1 (DUST_TICK2_TEST_ABORT=k): workgroup 0 publishes "abort" as if a peer were missing;
                          // 2 (DUST_TICK2_TEST_TIMEOUT=k): the last workgroup behaves as if its last wait had given up (no COMMIT)
+  unsigned int expect_aborts;  // value of status[1] the host knew when it enqueued this launch: a different value on the device means an
+                         // EARLIER one-launch tick of the context did not start or did not commit and will be replayed - this one must not
+                         // run ahead of that replay: it aborts at its start as well and is replayed behind it, in order
   int grid_words;        // Particle: words of the bit-packed occupancy grid staged in LDS (multiple of 4) or 0
   float coef_host[2];
   float alpha, temp;

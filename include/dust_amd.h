@@ -212,6 +212,9 @@ int dust_get_costs(dust_ctx *ctx, float *costs);
 int dust_get_actions(dust_ctx *ctx, float *actions);
 int dust_get_score(dust_ctx *ctx, float *score);
 int dust_get_phi(dust_ctx *ctx, float *phi);
+/* the two halves of the score of the last SVGD iteration: grad_lik (svmpc.py:50-53) and grad_pri (svmpc.py:38-41), [N][H][da] each;
+   either pointer may be NULL */
+int dust_get_score_parts(dust_ctx *ctx, float *grad_lik, float *grad_pri);
 int dust_get_log_weights(dust_ctx *ctx, float *log_l, float *log_p);
 int dust_get_bandwidths(dust_ctx *ctx, float *h); /* K2: [H*da] or [H] */
 

@@ -259,6 +259,107 @@ def test_tick2_aborted_ticks_are_replayed():
         assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("model,N,S,H,M,kernel,optimizer", [
+    ("pendulum", 1024, 128, 30, 1, "K1", "SGD"),    # BASELINE configs[1], the shape bench.py times
+    ("pendulum", 1024, 128, 30, 1, "K1", "Adam"),
+    ("pendulum", 512, 128, 30, 1, "IMQ", "SGD"),
+    ("particle", 256, 64, 16, 4, "K1", "SGD"),      # sampled dynamics (mass), occupancy grid in LDS
+    ("particle", 256, 64, 16, 4, "IMQ", "Adam"),
+])
+def test_tick2_stage_parity_vs_oracle(model, N, S, H, M, kernel, optimizer):
+    """the kernel the bench times, held to the ORACLE stage by stage at 1e-5.  From an aliased state one optimize()
+    of ONE iteration through `svmpc_tick2_kernel` with caller-supplied noise: a one-iteration launch is stage-local - the costs depend
+    on theta and eps only, the score on the costs, phi on the score - so every stage is compared with the oracle fed the stage before it
+    (the policy of DESIGN.md section 2: one ulp of a cost of 1e3 is 1e-4 on a softmax weight).  Reference path: SVMPC.step svmpc.py:87-95
+    -> likelihood.sample likelihoods.py:81-101 -> MultiDISCO._rollout / _compute_cost disco.py:139-346 -> SVMPC.phi svmpc.py:38-83."""
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+    from test_oracle_golden import k1_tolerance
+
+    da = 1 if model == "pendulum" else 2
+    rng = np.random.default_rng(1234 + N + H)
+    sig = 2.0 if model == "pendulum" else 5.0
+    alpha = 1.0 if model == "pendulum" else 1e-4
+    lr = 2.0 if model == "pendulum" else 100.0
+    kw = {}
+    P = 0
+    if model == "particle":
+        kw["grid"] = grid_4x4_map()
+        kw["uncertain_params"] = ("mass",)
+        P = 1
+    mu = rng.standard_normal((N, H, da)).astype(np.float32)
+    th0 = (mu + sig * rng.standard_normal((N, H, da))).astype(np.float32)
+    c = Context(model=model, N=N, S=S, M=M, H=H, kernel=kernel, imq_ell=0.9, lr=lr, alpha=alpha, sigma_a=sig, sigma_p=sig,
+                optimizer=optimizer, seed=5, **kw)
+    c.set_theta(th0)
+    c.set_prior(mu)
+    c.set_a_mat(th0)
+    st = _state(model)
+    par = lambda: (1.0 + 0.1 * rng.standard_normal((1, M, P))).astype(np.float32) if P else None
+    c.svmpc_tick(st, 1, eps=rng.standard_normal((1, S, N, H, da)).astype(np.float32), params=par())  # aliases the prior
+    th, (mu1, mix), am = c.get_theta(), c.get_prior(), c.get_a_mat()
+    assert np.array_equal(mu1, th)
+    eps = rng.standard_normal((1, S, N, H, da)).astype(np.float32)
+    params = par()
+    before = c.tick_stats()["tick2"]
+    c.svmpc_optimize(st, 1, eps=eps, params=params)
+    assert c.tick_stats()["tick2"] == before + 1 and c.tick_stats()["replayed"] == 0, c.tick_stats()
+    costs, (gl, gp), score, phi, th1 = c.get_costs(), c.get_score_parts(), c.get_score(), c.get_phi(), c.get_theta()
+    c.close()
+
+    o = Oracle(model=model, N=N, S=S, M=M, H=H, grid=kw.get("grid"), uncertain_params=kw.get("uncertain_params"))
+    sv = np.full(da, sig, np.float32)
+    actions = o.sample_actions(th, eps[0], sv)
+    costs_ref = o.rollout_cost(st, actions, None if params is None else params[0])
+    assert elemerr(costs, costs_ref) < 1e-5, elemerr(costs, costs_ref)                      # a1-a5: rollouts + costs
+    gl_ref, gp_ref, sc_ref = o.score(th, th, mix, sv, costs, actions, alpha, sv)            # a9, fed the DEVICE costs
+    assert elemerr(gl, gl_ref) < 1e-5 and elemerr(gp, gp_ref) < 1e-5, (elemerr(gl, gl_ref), elemerr(gp, gp_ref))
+    assert elemerr(score, sc_ref) < 1e-5
+    phi_ref = o.phi_k1(th, score) if kernel == "K1" else o.phi_imq(th, score, 0.9)          # a10 / IMQ, fed the DEVICE score
+    assert elemerr(phi, phi_ref) < (k1_tolerance(th) if kernel == "K1" else 1e-5), elemerr(phi, phi_ref)
+    if optimizer == "SGD":                                                                  # a8, fed the DEVICE phi
+        th_ref = o.sgd(th, phi, lr)
+    else:
+        th_ref, _, _ = o.adam(th, phi, np.zeros_like(th), np.zeros_like(th), 1, lr)
+    assert elemerr(th1, th_ref) < 1e-6, elemerr(th1, th_ref)
+
+
+def test_tick2_open_loop_queue_aborts_in_order():
+    """ticks enqueued WITHOUT reading their outputs, each with another plant state.  The third launch does not
+    start (hook); every one-launch tick enqueued behind it must not run ahead of its replay - the kernels compare the device's abort
+    count with the value the host knew at launch (`expect_aborts`) and abort too - and the library replays the whole tail in order,
+    each tick with its own inputs.  Also: an optimize() that did not start followed by forward() - the forward stays behind it."""
+    N, S, H = 256, 128, 30
+    states = [np.array([3.0 - 0.4 * t, 0.2 * t], np.float32) for t in range(6)]
+    outs = []
+    for env in ({"DUST_TICK2_TEST_ABORT": "3"}, {}):
+        saved = os.environ.pop("DUST_TICK2_TEST_ABORT", None)
+        os.environ.update(env)
+        try:
+            c, _ = _make("pendulum", N, S, H)
+            c.svmpc_tick(states[0], 2)                      # tiled form: aliases the prior
+            for t in range(1, 6):                          # launches 1-5 of the owner-computes kernel, nothing read back in between
+                c.svmpc_tick(states[t], 2, want_outputs=False)
+            c.sync()
+            th = c.get_theta()
+            stats = c.tick_stats()
+            # optimize() alone (launch 6: aborted by the hook in the first run) and a separate forward()
+            c.svmpc_optimize(states[1], 2)
+            a_seq, pw = c.svmpc_forward()
+            outs.append((th, stats, a_seq, pw, c.get_theta(), c.tick_stats()))
+            c.close()
+        finally:
+            os.environ.pop("DUST_TICK2_TEST_ABORT", None)
+            if saved is not None:
+                os.environ["DUST_TICK2_TEST_ABORT"] = saved
+    (t0, s0, a0, p0, e0, f0), (t1, s1, a1, p1, e1, f1) = outs
+    assert s0["replayed"] == 3 and s1["replayed"] == 0, (s0, s1)   # launch 3 did not start; launches 4 and 5 went with it
+    assert f0["replayed"] == 5, f0                                   # launch 6 (the optimize) and the forward behind it
+    assert elemerr(t0, t1) < 5e-3, elemerr(t0, t1)                   # (replays sum in another order; three ticks amplify)
+    assert elemerr(e0, e1) < 2e-2 and np.abs(p0 - p1).max() < 2e-2
+    assert np.isfinite(e0).all() and abs(float(p0.sum()) - 1.0) < 1e-3
+
+
 @pytest.mark.parametrize("env", [{}, {"DUST_NO_TICK2": "1"}, {"DUST_NO_PERSIST": "1"}], ids=["tick2", "tiled-tick", "launch-per-iteration"])
 def test_contexts_tick_concurrently(env):
     """Three contexts on one device ticking from three host threads.  Every one-launch form spins on its own
