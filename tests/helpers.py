@@ -44,3 +44,15 @@ def scenario_kwargs(g):
 def is_adam(name):
     """Golden scenarios run with the reference's class-default optimiser (tests/golden/make_golden_r2.py)."""
     return name.endswith("_adam")
+
+
+def tick2_ticks_expected(g, name, calls_per_tick=1):
+    """How many of a golden scenario's optimize() / tick() calls the owner-computes one-launch kernel (dust_amd/csrc/tick2.hpp) serves:
+    every call after the first forward() - from then on the prior means alias the particles (svgd.py:87) - when the shape is one the
+    kernel takes (K1 / IMQ, N % 4 == 0, H * d_a <= 32, isotropic prior scale, no control cost).  The golden chain tests assert this
+    count, so that which kernel produced the compared numbers is on record."""
+    T = int(g["eps"].shape[0])
+    N, D = int(g["N"]), int(g["H"]) * int(g["da"])
+    sp = np.atleast_1d(np.asarray(g["sigma_p"], np.float64)).reshape(-1)
+    eligible = "k2" not in name and N % 4 == 0 and D <= 32 and "ctrlpen" not in name and bool(np.all(sp == sp[0]))
+    return (T - 1) * calls_per_tick if eligible else 0
