@@ -190,6 +190,34 @@ __device__ __forceinline__ float fast_cosf(float x) {
   return ((q + 1) & 2) ? -v : v;
 }
 
+// Sum of a trajectory's instantaneous costs.  The oracle - and rounds 1-3 here - add every step's cost to a double: a v_cvt_f64_f32 and
+// a v_add_f64 per step, 9 of the 134 issue cycles of the Pendulum step (tools/valu_rate_probe.hip).  The Pendulum kernels now add FOUR
+// consecutive steps in fp32 and that partial sum to the double: 4.2 instead of 8.9 cycles per step.  Three fp32 additions of
+// non-negative terms inside a group of four: the group's relative error is <= 1.5 eps, the sum's <= 1.5 eps * (4 / H) of the total plus
+// the final rounding - indistinguishable from the double sum at the 1e-5 the costs are held to, and small enough for the tests that
+// watch the softmax amplify cost ulps (a plain fp32 sum over H = 30 steps - the reference's own torch.sum, disco.py:325-330 - was
+// tried: -2 us per cfg2 tick instead of -1.5, but 2-3 ulp of cost error pushed two amplification-limited checks over their bounds).
+// Every Pendulum rollout kernel, and both its trig paths, sums this way: their costs still agree bit for bit.  Particle / skid-steer keep
+// the plain double sum (obstacle weights of 1e6 beside terms of 1e-2).
+template <int MODEL>
+struct CostSum {
+  double tot = 0.0;
+  float part = 0.f;
+  __device__ __forceinline__ void add(const float c, const int t) {
+    if (MODEL == DUST_MODEL_PENDULUM) {
+      part += c;
+      if ((t & 3) == 3) {
+        tot += (double)part;
+        part = 0.f;
+      }
+    } else {
+      tot += (double)c;
+    }
+  }
+  __device__ __forceinline__ void add_weighted(const double w, const float c) { tot += w * (double)c; }  // (sigma-point rollouts: rare)
+  __device__ __forceinline__ double total() const { return MODEL == DUST_MODEL_PENDULUM ? tot + (double)part : tot; }
+};
+
 template <int MODEL>
 __device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, float *x, const float *a) {
   const float dt = (float)dm.dt;

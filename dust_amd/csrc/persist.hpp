@@ -459,18 +459,18 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
         float x[DS];
 #pragma unroll
         for (int q = 0; q < DS; ++q) x[q] = x0[q];
-        double tot = 0.0;
+        CostSum<MODEL> tot;
         float traj;
         if (fast_trig && fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f) {
           const float dt = (float)a.dm.dt, mt = a.dm.max_torque, ms = a.dm.max_speed_pend, chol0 = a.chol_a[0];
           const v2f W = {a.dm.w_cos, a.dm.w_vel};
           float sn, cs;
-#pragma unroll 2
+#pragma unroll 4
           for (int t = 0; t < H; ++t) {
             pendulum_trig(x[0], &sn, &cs);
             v2f q = {cs - 1.0f, x[1]};
             q = W * (q * q);
-            tot += (double)(q.x + q.y);
+            tot.add(q.x + q.y, t);
             const float u = __builtin_amdgcn_fmed3f(th[t] + chol0 * act[t], -mt, mt);
             float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
             thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
@@ -480,16 +480,16 @@ __device__ __forceinline__ void tick_owner(const TickArgs &f, float *lds_all, co
           pendulum_trig(x[0], &sn, &cs);
           v2f q = {cs - 1.0f, x[1]};
           q = W * (q * q);
-          traj = (float)tot + (q.x + q.y);
+          traj = (float)tot.total() + (q.x + q.y);
         } else {
           for (int t = 0; t < H; ++t) {
             float at[DA];
 #pragma unroll
             for (int q = 0; q < DA; ++q) at[q] = th[t * DA + q] + a.chol_a[q] * act[t * DA + q];
             const float ci = step_with_cost<MODEL>(a.dm, cf, x, at);
-            tot += (double)ci;
+            tot.add(ci, t);
           }
-          traj = (float)tot + term_cost<MODEL>(a.dm, x);
+          traj = (float)tot.total() + term_cost<MODEL>(a.dm, x);
         }
         acc_m += (double)traj;
       }

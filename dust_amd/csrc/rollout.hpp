@@ -419,7 +419,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       float x[DS];
 #pragma unroll
       for (int k = 0; k < DS; ++k) x[k] = x0[k];
-      double tot = 0.0;
+      CostSum<MODEL> tot;
       float traj;
       if (fast_trig && fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f) {
         // PendulumModel.step + demo cost, same fp32 operation order as model_step / inst_cost.  All operands are finite
@@ -428,12 +428,12 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         const v2f W = {a.dm.w_cos, a.dm.w_vel};
         const float *actl = lds + s * Dp;
         float sn, cs;
-#pragma unroll 2
+#pragma unroll 4
         for (int t = 0; t < H; ++t) {
           pendulum_trig(x[0], &sn, &cs);
           v2f q = {cs - 1.0f, x[1]};
           q = W * (q * q);
-          tot += (double)(q.x + q.y);
+          tot.add(q.x + q.y, t);
           const float u = __builtin_amdgcn_fmed3f(actl[t], -mt, mt);
           float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
           thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
@@ -443,7 +443,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         pendulum_trig(x[0], &sn, &cs);
         v2f q = {cs - 1.0f, x[1]};
         q = W * (q * q);
-        traj = (float)tot + (q.x + q.y);
+        traj = (float)tot.total() + (q.x + q.y);
       } else {
         const bool so = f_states != nullptr;
         // trajectory j of this wave (lane j's) is row r_first + j N of the [M][S][N] rollout index
@@ -469,16 +469,17 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
           const float ci = step_with_cost<MODEL>(dml, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
-          tot += f_mw ? (double)f_mw[((long)m * H + t) % a.M] * (double)ci : (double)ci;
+          if (f_mw) tot.add_weighted((double)f_mw[((long)m * H + t) % a.M], ci);
+          else tot.add(ci, t);
           if (so) put_and_flush(t + 1);
         }
         if (f_mw) {  // weighted instantaneous and terminal parts are summed separately over the sigma points (disco.py:314-321)
           ut_term += (double)f_mw[m] * (double)term_cost<MODEL>(dml, x);
-          traj = (float)tot;  // unused
-          acc_m += tot;
+          traj = (float)tot.total();  // unused
+          acc_m += tot.total();
           continue;
         }
-        traj = (float)tot + term_cost<MODEL>(dml, x);
+        traj = (float)tot.total() + term_cost<MODEL>(dml, x);
       }
       acc_m += (double)traj;
     }

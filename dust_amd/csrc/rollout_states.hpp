@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
     v2f head[15];  // rows 0 .. 14
     v4f pv = {0.f, 0.f, 0.f, 0.f};  // a line read by the first half of the wave, stored together with the second half's next step
     uint32_t pline = 0u;
-    double tot = 0.0;
+    CostSum<DUST_MODEL_PENDULUM> tot;
     auto emit = [&](const int q /* row % 16, static */, const int row) {
       *reinterpret_cast<v2f *>(my_row + (((q + pj) & 15) << 3)) = (v2f){x[0], x[1]};
       if (row < 15) {  // (lines completing before row 15 are heads)
@@ -397,13 +397,13 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
     auto step = [&](const int t) {
       const float at[1] = {actl[t]};
       if (GENERAL) {
-        tot += (double)step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+        tot.add(step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at), t);  // cost of the state BEFORE the action (disco.py:306)
       } else {
         float sn, cs;
         pendulum_trig(x[0], &sn, &cs);
         v2f qv = {cs - 1.0f, x[1]};
         qv = W * (qv * qv);
-        tot += (double)(qv.x + qv.y);
+        tot.add(qv.x + qv.y, t);
         const float u = __builtin_amdgcn_fmed3f(at[0], -mt, mt);
         float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
         thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
@@ -422,13 +422,13 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_kernel(const RolloutAr
     }
     float traj;
     if (GENERAL) {
-      traj = (float)tot + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
+      traj = (float)tot.total() + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
     } else {
       float sn, cs;
       pendulum_trig(x[0], &sn, &cs);
       v2f qv = {cs - 1.0f, x[1]};
       qv = W * (qv * qv);
-      traj = (float)tot + (qv.x + qv.y);
+      traj = (float)tot.total() + (qv.x + qv.y);
     }
     acc += (double)traj;
     if (((H - 15) & 1) == 0 && !half1 && flive) *reinterpret_cast<v4f *>(g + (size_t)pline * 128u) = pv;  // an unpaired last line
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_f16_kernel(const Rollo
     cf.c0 = coefs[2 * m];
     cf.c1 = coefs[2 * m + 1];
     float x[2] = {x0[0], x0[1]};
-    double tot = 0.0;
+    CostSum<DUST_MODEL_PENDULUM> tot;
     auto emit = [&](const int row) {
       const _Float16 h[2] = {(_Float16)x[0], (_Float16)x[1]};
       my[row] = *reinterpret_cast<const uint32_t *>(h);
@@ -543,13 +543,13 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_f16_kernel(const Rollo
     for (int t = 0; t < H; ++t) {
       const float at[1] = {actl[t]};
       if (GENERAL) {
-        tot += (double)step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+        tot.add(step_with_cost<DUST_MODEL_PENDULUM>(a.dm, cf, x, at), t);  // cost of the state BEFORE the action (disco.py:306)
       } else {
         float sn, cs;
         pendulum_trig(x[0], &sn, &cs);
         v2f qv = {cs - 1.0f, x[1]};
         qv = W * (qv * qv);
-        tot += (double)(qv.x + qv.y);
+        tot.add(qv.x + qv.y, t);
         const float u = __builtin_amdgcn_fmed3f(at[0], -mt, mt);
         float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * u);
         thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
@@ -560,13 +560,13 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_f16_kernel(const Rollo
     }
     float traj;
     if (GENERAL) {
-      traj = (float)tot + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
+      traj = (float)tot.total() + term_cost<DUST_MODEL_PENDULUM>(a.dm, x);
     } else {
       float sn, cs;
       pendulum_trig(x[0], &sn, &cs);
       v2f qv = {cs - 1.0f, x[1]};
       qv = W * (qv * qv);
-      traj = (float)tot + (qv.x + qv.y);
+      traj = (float)tot.total() + (qv.x + qv.y);
     }
     acc += (double)traj;
     __builtin_amdgcn_wave_barrier();

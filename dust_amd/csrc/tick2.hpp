@@ -690,7 +690,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           float x[DS];
 #pragma unroll
           for (int q = 0; q < DS; ++q) x[q] = x0[q];
-          double tot = 0.0;
+          CostSum<MODEL> tot;  // (Pendulum: fp32 within groups of four steps - common.hpp)
           float traj;
           if (fast_trig && fabsf(cf.c0) <= 3.0e38f && fabsf(cf.c1) <= 3.0e38f) {
             const float dt = (float)f->dm.dt, mt = f->dm.max_torque, ms = f->dm.max_speed_pend;
@@ -701,12 +701,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
 #ifdef T2_ABL_ROLL  // timing ablation (results invalid): one step instead of H
             const int H = 1;
 #endif
-#pragma unroll 2
+#pragma unroll 4
             for (int t = 0; t < H; ++t) {
               pendulum_trig(x[0], &sn, &cs);
               v2f q = {cs - 1.0f, x[1]};
               q = W * (q * q);
-              tot += (double)(q.x + q.y);
+              tot.add(q.x + q.y, t);
               const float uu = __builtin_amdgcn_fmed3f(th_p[t] + chol0 * act[t], -mt, mt);
               float thd = x[1] + dt * (cf.c0 * sn + cf.c1 * uu);
               thd = __builtin_amdgcn_fmed3f(thd, -ms, ms);
@@ -716,16 +716,16 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
             pendulum_trig(x[0], &sn, &cs);
             v2f q = {cs - 1.0f, x[1]};
             q = W * (q * q);
-            traj = (float)tot + (q.x + q.y);
+            traj = (float)tot.total() + (q.x + q.y);
           } else {
             for (int t = 0; t < H; ++t) {
               float at[DA];
 #pragma unroll
               for (int q = 0; q < DA; ++q) at[q] = th_p[t * DA + q] + f->chol_a[q] * act[t * DA + q];
               const float ci = t2_step_with_cost<MODEL>(f, lds + L.grid, cf, x, at);
-              tot += (double)ci;
+              tot.add(ci, t);
             }
-            traj = (float)tot + t2_term_cost<MODEL>(f, lds + L.grid, x);
+            traj = (float)tot.total() + t2_term_cost<MODEL>(f, lds + L.grid, x);
           }
           acc_m += (double)traj;
         }

@@ -444,7 +444,9 @@ def test_sharded_equals_unsharded(golden, world, overlap):
         rt = ref.get_theta()
         for s in shards:
             assert relerr(s.ctx.get_theta(), rt) < (2e-6 if overlap else 1e-6), (world, t, s.rank)  # split: other merge rounding
-        assert relerr(pw, rp) < 1e-5 and np.array_equal(a_seq, ra)
+        # (from its second tick on the unsharded context runs the owner-computes one-launch kernel, which sums over samples and keys in
+        #  another order than the shards' launch-per-iteration kernels: the chosen row agrees to an ulp, not bit for bit)
+        assert relerr(pw, rp) < 1e-5 and relerr(a_seq, ra) < 1e-6
 
 
 def _synthetic_case(model, N, S, M, H, seed=3):

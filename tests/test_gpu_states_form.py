@@ -214,7 +214,10 @@ def test_pendulum_binary16_whole_line_states_vs_oracle_and_staged_kernel(N, S, M
     ulp16 = np.maximum(np.abs(ref16), 2.0 ** -14) * 2.0 ** -10 + 2e-6 * np.abs(ref_states).max()
     assert np.all(np.abs(s32 - ref16) <= ulp16) and np.mean(s32 != ref16) < 1e-3
     assert np.all(np.abs(s32 - s032) <= ulp16) and np.mean(s32 != s032) < 1e-3
-    assert relerr(costs, costs0) < 2e-6 and relerr(omega, omega0) < 1e-4
+    # omega = softmax_S(-costs / temp): one fp32 ulp of a cost of 6e3 is 5e-4 in a logit, so the weights of two kernels whose costs
+    # differ in the last place (branch-free trig path vs reference-order steps) can only be held to a few of those
+    ulp_logit = float(np.spacing(np.float32(np.abs(costs0).max())))
+    assert relerr(costs, costs0) < 2e-6 and relerr(omega, omega0) < max(1e-4, 2.0 * ulp_logit)
 
 
 def test_pendulum_binary16_whole_line_states_general_path_and_fallbacks():
