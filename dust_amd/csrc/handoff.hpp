@@ -65,12 +65,13 @@ __device__ __forceinline__ float adam_step(float th, const float g, float &m, fl
 // e = (pi_f - pi) - err, err the rounding error of the fp32 add recovered exactly by TwoSum; then
 // sin(theta + pi + e) = -(sin theta cos e + cos theta sin e) = -(sin theta + e cos theta) up to e^2 < 1e-13.
 // Round 4: the reduction is by PI, not pi / 2 - theta = k pi + r, |r| <= pi / 2: sin theta = (-1)^k S(r), cos theta = (-1)^k C(r) with an
-// odd degree-11 / even degree-12 polynomial pair (tools/trig_fit.py: fitted to 2e-11 / 1e-12, evaluated in fp32 they stay within
+// odd degree-9 / even degree-10 polynomial pair (tools/trig_fit.py: fitted to 5e-9 / 3e-10 - a term more in each changes nothing once the
+// polynomials are evaluated in fp32 -, they stay within
 // 1.2e-7 / 1.5e-7 ABSOLUTE of sin / cos for |theta| <= 5e4 - the [-pi/4, pi/4] pair of rounds 1-3: 7e-8; one fp32 ulp of the angular
 // velocity the value feeds is 1.2e-7 .. 4.8e-7).  Gone with it: the two polynomial swaps and three selects on the quadrant
 // (v_cmp / v_cndmask / VOP3 negations: 41 of the step's 171 issue cycles, tools/valu_rate_probe.hip) - the sign is the parity bit of
 // k, taken from the mantissa of fl(theta / pi + 1.5 * 2^23), which is also how k is rounded (no v_rndne / v_cvt).  The rollout step of the
-// product tick: 56 -> 47 instructions, 171 -> 134 issue cycles.  Valid for |theta| < 2^22 pi (the callers hold |theta| <= 5e4).
+// product tick: 56 -> 45 instructions, 171 -> 129 issue cycles.  Valid for |theta| < 2^22 pi (the callers hold |theta| <= 5e4).
 __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
 #ifdef DUST_OLD_TRIG  // A/B only: the pi / 2 reduction of rounds 1-3
   int q_;
@@ -96,17 +97,15 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   r = fmaf(kf, -(2.0f * 3.13916473e-07f), r);
   r = fmaf(kf, -(2.0f * 5.39030253e-15f), r);
   const float s = r * r;
-  float p = -2.381653097e-08f;
-  p = fmaf(p, s, 2.752084583e-06f);
-  p = fmaf(p, s, -1.984076807e-04f);
-  p = fmaf(p, s, 8.333330043e-03f);
-  p = fmaf(p, s, -1.666666716e-01f);
+  float p = 2.596175364e-06f;
+  p = fmaf(p, s, -1.980484958e-04f);
+  p = fmaf(p, s, 8.332992904e-03f);
+  p = fmaf(p, s, -1.666665673e-01f);
   float sn = fmaf(p, r * s, r);
-  float q = 1.989598042e-09f;
-  q = fmaf(q, s, -2.752404384e-07f);
-  q = fmaf(q, s, 2.480102921e-05f);
-  q = fmaf(q, s, -1.388888457e-03f);
-  q = fmaf(q, s, 4.166666791e-02f);
+  float q = -2.604016061e-07f;
+  q = fmaf(q, s, 2.475986184e-05f);
+  q = fmaf(q, s, -1.388836536e-03f);
+  q = fmaf(q, s, 4.166663811e-02f);
   q = fmaf(q, s, -5.000000000e-01f);
   float cs = fmaf(q, s, 1.0f);
   sn = __uint_as_float(__float_as_uint(sn) ^ sgn);

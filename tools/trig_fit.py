@@ -82,8 +82,8 @@ def eval_old(th):
 
 if __name__ == "__main__":
     hi = np.pi / 2 + 0.02
-    es, S = fit("sin", 5, hi)
-    ec, C = fit("cos", 6, hi)
+    es, S = fit("sin", 4, hi)
+    ec, C = fit("cos", 5, hi)
     S32, C32 = [f32(c) for c in S], [f32(c) for c in C]
     print("sin fit error (float64 coefficients) %.3e   cos %.3e" % (es, ec))
     print("S =", ", ".join("%.9ef" % c for c in S32))
