@@ -131,37 +131,19 @@ enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
 #ifndef T2_PRIO_OWNERSTAGE
 #define T2_PRIO_OWNERSTAGE 3
 #endif
-#ifndef T2_PRIO_OWNERSTEIN
-#define T2_PRIO_OWNERSTEIN 0
-#endif
+
 __device__ __forceinline__ float t2_quad_sum(float v) {  // quad permutes never read an invalid lane: bound_ctrl spares the `old` operand
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
 }
-// LDS accesses the compiler must not see while LDS-DMA loads are in flight: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS access
-// it cannot prove disjoint from an outstanding DMA's destination (seen in the ISA in front of the ds_write of the distances: one full
-// drain per step).  LDS operations of one wave execute in order, so a later compiler-issued read of the same words still sees the data;
-// the workgroup barriers drain lgkmcnt explicitly (wg_sync).
-__device__ __forceinline__ unsigned int t2_lds_addr(const float *p) { return (unsigned int)(size_t)(const __attribute__((address_space(3))) float *)p; }
-__device__ __forceinline__ void t2_lds_st64(float *p, const float a, const float b) {
-  const v2f v = {a, b};
-  asm volatile("ds_write_b64 %0, %1" ::"v"(t2_lds_addr(p)), "v"(v) : "memory");
-}
-__device__ __forceinline__ v2f t2_lds_ld64_issue(const float *p) {  // the caller waits (t2_lds_wait) before it uses the value
-  v2f v;
-  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(t2_lds_addr(p)) : "memory");
-  return v;
-}
-__device__ __forceinline__ void t2_lds_wait(v2f &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); }
 template <int MODE, int PASS, bool MASK /* the steps cover more than the N keys: those past the last one carry no weight */>
 __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* theta generation */, const float *thq /* LDS [4][32] own query rows */,
                                              float *dk /* LDS [keys][4]: |y_j - x_q|^2 (PRIOR) -> k_qj (STEIN) */, const float *lml /* LDS [keys] log pi_j */,
-                                             float *ring /* LDS: this wave's key ring [T2_NS][2][64][4] (PRIOR / STEIN) */, const int pw, const int lane,
-                                             const float lm_ref,
-                                             float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */) {
+                                             const int pw /* unit: (query half, key quarter), or the wave (LOGP) */, const int lane, const float lm_ref,
+                                             float (&red)[4] /* PRIOR: reduce_u16<32> of a | L; STEIN: reduce_u16<16> of b; LOGP: L of the 4 queries */,
+                                             const int t_begin = 0, const int t_end = -1 /* the unit's steps [t_begin, t_end): even bounds; -1: all */) {
   constexpr int NQ = PASS == T2_PASS_LOGP ? 4 : 2;   // queries per wave
   constexpr int NKW = PASS == T2_PASS_LOGP ? 16 : 4;  // waves that share the keys (forward: all 16 waves of the workgroup)
-  constexpr bool RING = T2_NS > 0 && PASS != T2_PASS_LOGP;
   const int u = lane >> 2, c = lane & 3, N = f->N;
   const int kw = PASS == T2_PASS_LOGP ? pw : (pw & 3), q0 = PASS == T2_PASS_LOGP ? 0 : (pw >> 2) * 2;
   v2f xq[NQ][4];
@@ -204,7 +186,7 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
 #pragma unroll
         for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(kk, yv[h] - xq[q][h], acc[q][h]);
       }
-      if (c == 0) t2_lds_st64(&dk[(size_t)j * 4 + q0], kq[0], kq[1]);  // (in place: the quad has read its distances)
+      if (c == 0) *reinterpret_cast<float2 *>(&dk[(size_t)j * 4 + q0]) = float2{kq[0], kq[1]};  // (in place: the quad has read its distances)
     } else {
       const float lm2 = (lml[j] - lm_ref) * 1.44269504088896340736f;
       float dsq[NQ];
@@ -226,63 +208,26 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
           for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(ee, z[h], acc[q][h]);
         }
       }
-      if (PASS == T2_PASS_PRIOR && c == 0) t2_lds_st64(&dk[(size_t)j * 4 + q0], dsq[0], dsq[1]);
+      if (PASS == T2_PASS_PRIOR && c == 0) *reinterpret_cast<float2 *>(&dk[(size_t)j * 4 + q0]) = float2{dsq[0], dsq[1]};
     }
   };
-  if (RING) {
-    // Keys through an LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds: no destination registers): T2_NS steps - 2 KB each - are in
-    // flight per wave whatever the register budget says.  The register form (below, still used by the log-density pass) holds two steps in
-    // 18 registers, the compiler rotates them through copies at the loop's back edge and waits there for EVERY outstanding load
-    // (s_waitcnt vmcnt(0)): one exposed L2 round trip per two steps - a pass of a wave pair alone on its SIMD took 4.5 us for ~0.9 k
-    // instructions (tools/tick2_timeline.py with the R waves' work compiled out), and four steps in registers spill.
-    // Order per step: wait until the step's two DMA pieces have landed (the T2_NS - 1 younger steps stay in flight) -> read them
-    // (the lane's own 2 x 16 bytes: a wave reads only what it loaded itself, no barrier) -> refill the slot -> arithmetic.
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    auto dma = [&](const int t, const int slot) {
-      const int j = min((t * NKW + kw) * 16 + u, N - 1);
-      const int voff = (j * T2_ROW + 8 * c) * 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(ring + slot * 512), 16, voff, 0, 0, 0);
-      // (the instruction offset moves the LDS address as well as the memory address - tools/ldsdma_probe.hip -, hence 252 = 256 - 16 / 4)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(ring + slot * 512 + 252), 16, voff, 0, 16, 0);
-    };
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the query rows are in registers before the first DMA is issued (see t2_lds_st64)
-#pragma unroll
-    for (int sl = 0; sl < T2_NS; ++sl) dma(min(sl, steps - 1), sl);
-    int slot = 0;
-    for (int t = 0; t < steps; ++t) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (T2_NS - 1)) : "memory");
-      const v4f y0 = *reinterpret_cast<const v4f *>(ring + slot * 512 + lane * 4);
-      const v4f y1 = *reinterpret_cast<const v4f *>(ring + slot * 512 + 256 + lane * 4);
-      v2f dq = {0.f, 0.f};
-      if (PASS == T2_PASS_STEIN) dq = t2_lds_ld64_issue(&dk[(size_t)((t * NKW + kw) * 16 + u) * 4 + q0]);
-      t2_lds_wait(dq);                                      // the slot is read: it may be refilled
-      dma(min(t + T2_NS, steps - 1), slot);                // (past the end: the last rows again - the in-flight count stays uniform)
-      step(t, y0, y1, dq);
-      slot = slot + 1 == T2_NS ? 0 : slot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing refills: nothing may land in the ring after the pass
-  } else {
-    constexpr int PF = 2;  // key steps in flight
-    v4f ya[PF], yb[PF];
+  {
+    constexpr int PF = 2;  // key steps in flight (deeper prefetch - four steps in registers, an LDS-DMA ring of three: tools/ldsdma_probe.hip -
+    v4f ya[PF], yb[PF];    // was measured and bought nothing: the passes follow the bytes they pull through the CU's vector memory path)
+    const int tb = t_begin, te = t_end < 0 ? steps : t_end;
     auto issue = [&](const int t, v4f &y0, v4f &y1) {
       const int j = min((t * NKW + kw) * 16 + u, N - 1);
       y0 = t2_ld16(rx, (j * T2_ROW + 8 * c) * 4);
       y1 = t2_ld16(rx, (j * T2_ROW + 8 * c + 4) * 4);
-#ifdef T2_ABL_EXTRA  // timing ablation (results unchanged): a third 16-byte piece per lane and step, from another line
-      {
-        const v4f yx = t2_ld16(rx, (min(j + 16, N - 1) * T2_ROW + 8 * c) * 4);
-        asm volatile("" ::"v"(yx));
-      }
-#endif
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) issue(p, ya[p], yb[p]);
-    for (int t0 = 0; t0 < steps; t0 += PF) {
+    for (int p = 0; p < PF; ++p) issue(min(tb + p, te - 1), ya[p], yb[p]);
+    for (int t0 = tb; t0 < te; t0 += PF) {
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
         const int t = t0 + p;
         const v4f y0 = ya[p], y1 = yb[p];
-        issue(min(t + PF, steps - 1), ya[p], yb[p]);  // (the last group re-reads its last rows: no branch in the loop)
+        issue(min(t + PF, te - 1), ya[p], yb[p]);  // (the last group re-reads its last rows: no branch in the loop)
         v2f dq = {0.f, 0.f};
         if (PASS == T2_PASS_STEIN) {
           const float2 d = *reinterpret_cast<const float2 *>(&dk[(size_t)((t * NKW + kw) * 16 + u) * 4 + q0]);
@@ -381,7 +326,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *ppart = lds + T2_L_PPART;
   float *rpart = lds + T2_L_RP;
   float *lml = lds + L.lml;      // [steps * 64] log pi_j of the tick's prior (read by every pair pass; constant over the tick)
-  float *ring = lds + L.ring;    // [8 P waves][T2_NS][2][64][4] key rings of the pair passes (t2_pair_pass)
   float *wpart = lds + T2_L_WPART;
   float *scl = lds + T2_L_SCL;
   unsigned int *cnt_start = f->cnt;  // (replica 0 only: one arrival per workgroup, polled by workgroup 0)
@@ -804,8 +748,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, ksl, lml, ring + pw * (T2_NS * 512), pw, lane, lm_ref, red);
-      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, ksl, lml, ring + pw * (T2_NS * 512), pw, lane, lm_ref, red);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, ksl, lml, pw, lane, lm_ref, red);
+      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, ksl, lml, pw, lane, lm_ref, red);
 #pragma unroll
       for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
       T2_TL(8, 16 * k + 3);
@@ -861,7 +805,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       gs_keep = gs;
       scl[op * T2_ROW + od] = ownv ? gs + gp_keep : 0.f;
       publish_rows(scl, f->sq + (size_t)k * N * T2_ROW, cnt_score);
-      DUST_PRIO(T2_PRIO_OWNERSTEIN);  // (these two waves start their share of the Stein pass last)
+      DUST_PRIO(0);
       T2_TL(8, 16 * k + 7);
       if (ownv) {
         f->score[no] = gs_keep + gp_keep;
@@ -870,11 +814,13 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
     }
     if (wave >= 8) {  // the Stein half of the theta-only work, while the score rows travel
+      // (tried: the owner waves' two units - they start 1.7 us late and finish last - cut in four and handed to the rollout waves behind
+      //  their noise draw, with the owner waves idle: +4.5 us per tick, the workgroups drift apart; an idle wave polling the score
+      //  counters from the moment the rows are published: the hop takes 5.8 instead of 2.5 us - the polls sit on the arrivals' lines)
       float rb[4];
-      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
-      else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, ksl, lml, ring + (wave - 8) * (T2_NS * 512), wave - 8, lane, lm_ref, rb);
+      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_STEIN, true>(f, k, th, ksl, lml, wave - 8, lane, lm_ref, rb);
+      else t2_pair_pass<MODE, T2_PASS_STEIN, false>(f, k, th, ksl, lml, wave - 8, lane, lm_ref, rb);
       rpart[((wave - 8) * 16 + reduce_u16_index<16>(0, lane)) * 4 + (lane & 3)] = rb[0];
-      DUST_PRIO(0);
       T2_TL(8, 16 * k + 11);
       T2_TL(15, 16 * k + 6);
     }
@@ -1014,7 +960,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
-    t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, ksl, lml, ring, wave, lane, lm_ref, red);
+    t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, ksl, lml, wave, lane, lm_ref, red);
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;

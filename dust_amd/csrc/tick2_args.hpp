@@ -72,19 +72,15 @@ enum {
   T2_L_TH = 0,                                // [4][32] the workgroup's particles, zero padded
   T2_L_MISC = T2_L_TH + T2_PW * T2_ROW,       // [192] small words (see tick2.hpp)
   T2_L_PPART = T2_L_MISC + 192,               // [8 waves][32 sums][4 column groups] partials of the prior pass
-  T2_L_GP = T2_L_PPART + 8 * 32 * 4,          // [4][32] grad_pri
-  T2_L_RP = T2_L_GP + T2_PW * T2_ROW,         // [8 waves][16 sums][4 column groups] partials of the Stein repulsion
+  T2_L_RP = T2_L_PPART + 8 * 32 * 4,          // [8 waves][16 sums][4 column groups] partials of the Stein repulsion
   T2_L_WPART = T2_L_RP + 8 * 16 * 4,          // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update); after barrier B4 the
                                               // same 2 048 floats hold [16 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
   T2_L_SCL = T2_L_WPART + 2 * T2_PW * 8 * T2_ROW,  // [4][32] score rows on their way out
   T2_L_COEFS = T2_L_SCL + T2_PW * T2_ROW,     // [T2_MAXM][2] dynamics coefficients of the iteration
-  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | lml | ring | grid | tile
+  T2_L_VAR = T2_L_COEFS + 2 * T2_MAXM         // cst | omg | ksl | lml | grid | tile
 };
-#ifndef T2_NS
-#define T2_NS 0   // key steps (2 KB each) a pair wave keeps in flight through an LDS ring (tick2.hpp t2_pair_pass); 0: register form
-#endif
 struct Tick2Lds {
-  int cst, omg, ksl, lml, ring, grid, tile, total;
+  int cst, omg, ksl, lml, grid, tile, total;
 };
 __host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_words) {
   Tick2Lds l;
@@ -94,8 +90,7 @@ __host__ __device__ inline Tick2Lds tick2_lds(int S, int D, int steps, int grid_
   l.ksl = l.omg + ps;             // [steps * 64][4] squared distances |y_j - x_q|^2 of the workgroup's 4 queries (prior pass), replaced in
                                   // place by the Stein kernel values k_qj (Stein pass)
   l.lml = l.ksl + steps * 64 * 4;   // [steps * 64] log pi_j of the tick's prior
-  l.ring = l.lml + steps * 64;      // [8 pair waves][T2_NS][2][64][4] key rows on their way in (LDS-DMA)
-  l.grid = l.ring + 8 * T2_NS * 512;
+  l.grid = l.lml + steps * 64;
   l.tile = l.grid + grid_words;   // [4][S][Dp] standard normals of the current iteration
   l.total = l.tile + T2_PW * S * Dp;
   return l;
