@@ -918,7 +918,8 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       T2_TL(8, 16 * k + 13);
       if (ownv) f->phi[no] = phi_keep;
     }
-    wg_sync();  // B6  (tried: the barrier in front of the publish, so that the rollout waves start ~1 us earlier - +1.3 us per tick, A/B)
+    wg_sync();  // B6  (tried twice: the barrier in front of the publish, so that the rollout waves start ~1 us earlier - +1.3 us per tick; with the
+                // publish at wave priority 3: no gain either)
     T2_TL(0, 16 * k + 14);
   }
 
