@@ -1,5 +1,6 @@
 """Per-iteration GPU time of ONE rank's share of the weak-scaled bench (1024 particles per GPU, N = 1024 * G in the joint
 problem), measured on a single GPU without collectives: what each rank computes between the all-gathers."""
+import gc
 import os
 import sys
 import time
@@ -73,7 +74,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
         pk = {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}
         print("cfg4 G=%d n_local=%d: %.0f us per iteration (local score + Stein/update), kernels: %s" % (G, N // G, el * 1e6, pk), flush=True)
         sh.ctx.profile(False)
-        for rep in range(2):  # the whole tick of one rank without its collectives: iteration + forward (local log p, finalize over all N, roll)
+        # The whole tick of one rank without its collectives: iteration + forward (local log p, finalize over all N, roll).  The MEDIAN of three
+        # repetitions (the particle set evolves from repetition to repetition, and with it the share of exactly-zero kernel blocks: the
+        # minimum would pick the sparsest set) with the collector off: round 3's profile (and this round's first pass) showed 2 690 us at 8 shards against 630 us in
+        # every other run - in the kernel trace ONE 44 ms gap on the host side between a roll_kernel and the next set_state_kernel
+        # (the fourth context of the process: the three before it had just released ~3 GB of device and host buffers), i.e. 2.2 ms
+        # when averaged over the 20 ticks of the timed loop; every kernel of those ticks ran at its usual time.
+        gc.collect()
+        gc.disable()
+        reps2 = []
+        for rep in range(3):
             sh.ctx.sync()
             t0 = time.perf_counter()
             for _ in range(iters):
@@ -82,6 +92,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
                 sh.forward_local()
                 sh.forward_finish()
             sh.ctx.sync()
-            el2 = (time.perf_counter() - t0) / iters
+            reps2.append((time.perf_counter() - t0) / iters)
+        gc.enable()
+        el2 = sorted(reps2)[1]
         print("        whole tick of the rank (collectives excluded): %.0f us -> forward %.0f us" % (el2 * 1e6, (el2 - el) * 1e6), flush=True)
+        sh.ctx.profile(True)  # per-kernel times of the whole tick (profiling mode: one event pair per launch)
+        for _ in range(5):
+            sh.local_score(state, params=params)
+            sh.apply_phi()
+            sh.forward_local()
+            sh.forward_finish()
+        sh.ctx.sync()
+        print("        per kernel, whole tick: %s" % {k: round(1e3 * ms / n, 1) for k, (ms, n) in sh.ctx.profile_get().items()}, flush=True)
         sh.ctx.close()
