@@ -130,6 +130,7 @@ SYMBOLS = {
     "dust_svmpc_forward_local": (C.c_int, [VP, C.POINTER(VP), C.POINTER(C.c_size_t)]),
     "dust_svmpc_forward_finish": (C.c_int, [VP, FP, FP]),
     "dust_comm_unique_id": (C.c_int, [VP]),
+    "dust_comm_validate": (C.c_int, [VP, C.c_int, C.c_int]),
     "dust_comm_init": (C.c_int, [VP, VP, C.c_int, C.c_int]),
     "dust_comm_destroy": (C.c_int, [VP]),
     "dust_comm_probe": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),

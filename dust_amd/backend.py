@@ -141,6 +141,10 @@ class Context:
         L.check(L.load().dust_comm_unique_id(C.cast(buf, L.VP)))
         return buf.raw
 
+    def comm_validate(self, rank, world):
+        """The local (non-collective) checks of comm_init; raises on failure.  Call it on every rank and let the ranks agree before comm_init."""
+        L.check(L.load().dust_comm_validate(self._h, int(rank), int(world)))
+
     def comm_init(self, unique_id, rank, world):
         """ncclCommInitRank (collective over the ranks).  Afterwards svmpc_tick / svmpc_optimize / svmpc_forward run the sharded tick."""
         buf = C.create_string_buffer(bytes(unique_id), 128)

@@ -2954,13 +2954,18 @@ extern "C" int dust_comm_unique_id(void *id) {
   return rccl::check(rccl::get_unique_id(id), "ncclGetUniqueId");
 }
 
-extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) {
-  if (!c || !id) return fail(DUST_ERR_INVALID, "null argument");
+extern "C" int dust_comm_validate(dust_ctx *c, int rank, int world) {
+  if (!c) return fail(DUST_ERR_INVALID, "null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(DUST_ERR_INVALID, "bad rank %d of %d", rank, world);
   if (c->N % world || c->nloc != c->N / world || c->n0 != rank * (c->N / world))
     return fail(DUST_ERR_INVALID, "context shard [%d,+%d) is not rank %d's equal share of %d particles over %d ranks", c->n0, c->nloc, rank, c->N, world);
   if (c->comm) return fail(DUST_ERR_STATE, "the context already has a communicator");
-  TRY(rccl::load());
+  return rccl::load();
+}
+
+extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) {
+  if (!c || !id) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(dust_comm_validate(c, rank, world));  // (every rank's launcher has agreed on this beforehand: include/dust_amd.h, ABORT RULE)
   HIP_TRY(hipSetDevice(c->cfg.device));
   rccl::UniqueId uid;
   memcpy(uid.internal, id, sizeof uid.internal);

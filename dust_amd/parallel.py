@@ -229,8 +229,21 @@ class ShardedSVMPC:
         self.c_side = bool(c_side)
         self.rank, self.world = rank, world
         if self.c_side:
-            off, n_loc = shard_bounds(common_cfg["N"], rank, world)
-            self.ctx = Context(**dict(common_cfg, shard_offset=off, shard_size=n_loc))
+            # ncclCommInitRank is a collective without a time-out: a rank that fails BEFORE it (bad shard, no device, no librccl) would
+            # leave the others hanging inside it.  Every rank therefore runs the local checks first, the ranks exchange the outcome over
+            # torch.distributed, and either all of them go on to the communicator or all of them raise (include/dust_amd.h, ABORT RULE).
+            err = None
+            try:
+                off, n_loc = shard_bounds(common_cfg["N"], rank, world)
+                self.ctx = Context(**dict(common_cfg, shard_offset=off, shard_size=n_loc))
+                self.ctx.comm_validate(rank, world)
+            except Exception as e:  # noqa: BLE001 - whatever went wrong, the other ranks must hear of it
+                err = "rank %d: %s" % (rank, e)
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, err)
+            bad = [v for v in verdicts if v]
+            if bad:
+                raise RuntimeError("sharded context not created on every rank - no rank enters ncclCommInitRank: " + "; ".join(bad))
             ids = [Context.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             self.ctx.comm_init(ids[0], rank, world)

@@ -240,6 +240,12 @@ int dust_svmpc_forward_finish(dust_ctx *ctx, float *a_seq, float *p_weights);
  * (dlopen of librccl.so): single-GPU hosts need none. */
 #define DUST_COMM_ID_BYTES 128
 int dust_comm_unique_id(void *id /* DUST_COMM_ID_BYTES */);
+/* dust_comm_validate: the LOCAL checks of dust_comm_init (rank / world sane, the context's shard is rank's equal share, no communicator
+ * yet, librccl loadable) and nothing else - no collective.  ABORT RULE: ncclCommInitRank has no time-out, so a rank that fails its checks
+ * while the others enter it leaves them hanging; a launcher therefore calls dust_comm_validate on every rank, lets the ranks AGREE on the
+ * result out of band (an all-gather of the status over the same channel that carries the id), and calls dust_comm_init only when every
+ * rank passed (dust_amd/parallel.py ShardedSVMPC does exactly that). */
+int dust_comm_validate(dust_ctx *ctx, int rank, int world);
 int dust_comm_init(dust_ctx *ctx, const void *id, int rank, int world);
 int dust_comm_destroy(dust_ctx *ctx);
 /* The all-gathers of one sharded tick alone (per SVGD iteration: score rows and particles; per tick: the log-weights), `reps` times

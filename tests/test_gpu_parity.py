@@ -984,6 +984,44 @@ def test_sharded_large_set_takes_fused_pairwise():
     ref.close()
 
 
+def test_cfg4_rank_of_eight_runs_the_large_set_kernels():
+    """one rank's share of BASELINE configs[3] on 8 GPUs (N = 16384 Particle particles, 2 048 of them local) - the
+    shape whose last round-3 profile showed a 4x slower tick.  That reading was one 44 ms host-side gap inside a 20-tick timed loop
+    (tools/shard_time.py, profiles/round4_shard_time.txt); this test pins what the rank's tick consists of instead: in profiling mode
+    (one event pair per kernel) the passes of a whole tick must stay where the fused large-set kernels put them - against 1.1 ms and
+    1.0 ms for the two pairwise passes alone through the small-set kernels."""
+    from dust_amd.parallel import DeviceShard
+    from oracle import grid_4x4_map
+
+    N, S, M, H = 16384, 64, 4, 40
+    rng = np.random.default_rng(0)
+    mu = rng.standard_normal((N, H, 2)).astype(np.float32)
+    th = (mu + rng.standard_normal((N, H, 2))).astype(np.float32)
+    cfg = dict(model="particle", N=N, S=S, M=M, H=H, kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0, uncertain_params=("mass",),
+               grid=grid_4x4_map(), seed=3)
+    sh = DeviceShard(cfg, 0, 8, use_torch_stream=False)
+    sh.set_state(th, th)
+    state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    params = (1.0 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+
+    def one_tick():
+        sh.local_score(state, params=params)
+        sh.apply_phi()
+        sh.forward_local()
+        sh.forward_finish()
+
+    one_tick()  # the forward aliases the prior means to the particles: from here on the fused pass serves prior + Stein
+    sh.ctx.profile(True)
+    for _ in range(4):
+        one_tick()
+    sh.ctx.sync()
+    pk = {k: 1e3 * ms / n for k, (ms, n) in sh.ctx.profile_get().items()}
+    sh.ctx.close()
+    assert np.isfinite(list(pk.values())).all()
+    # measured: rollouts 89, fused pairwise pass 145, Gram x score 58, update 16, finalize + roll 17 us (profiles/round4_shard_time.txt)
+    assert pk["pairwise_kernel<PRIOR>"] < 450 and pk["pairwise_kernel<STEIN>"] < 200 and sum(pk.values()) < 1000, pk
+
+
 def test_particle_m64_small_n_vs_oracle():
     """BASELINE configs[2]'s dynamics-sample count (M = 64, S = 64, H = 40: the lane-group split of the M loop at its real trip
     counts) at a particle count the oracle finishes in seconds: every cost, then score and phi, element-wise."""

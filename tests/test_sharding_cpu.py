@@ -109,3 +109,40 @@ def test_gloo_world2_equals_unsharded(family):
     for rank, theta, pw in got:
         assert np.allclose(theta, ref_theta, atol=1e-6), rank
         assert np.allclose(pw, ref_outs[-1][1], atol=1e-6), rank
+
+
+def _abort_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dust_amd.parallel import ShardedSVMPC
+
+    cfg = dict(model="pendulum", N=64, S=8, M=1, H=6, kernel="K1")
+    if rank == 1:
+        cfg["N"] = 63  # this rank's share is not a whole shard: its context is never created
+    try:
+        ShardedSVMPC(cfg, rank, world, dist, c_side=True)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_comm_init_abort_rule():
+    """ADVICE r2 / VERDICT r3 item 3d: ncclCommInitRank is a collective without a time-out, so a rank that fails its local checks must
+    not leave the others hanging inside it.  ShardedSVMPC (C-side form) validates on every rank, the ranks exchange the outcome, and
+    EVERY rank raises the agreed error before any of them touches the communicator - here: no HIP device in this container (both
+    ranks), one rank with a particle count that does not shard."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_abort_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert "no rank enters ncclCommInitRank" in got[rank] and "rank 1:" in got[rank], got
