@@ -201,11 +201,11 @@ def roofline_section(local, state_pend):
                  "launch pair includes the (idle) general-path launch behind it)")
     ach = b_alg / avg_s / 1e9
     traffic, traffic_src = None, None
-    tf = os.path.join(ROOT, "profiles", "round3_rollout_states_traffic.json")
+    tf = os.path.join(ROOT, "profiles", "round4_rollout_states_traffic.json")
     if os.path.exists(tf):
         with open(tf) as fh:
             tj = json.load(fh)
-        traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round3_rollout_states_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/round4_rollout_states_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
     out.update(kernel=kname, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                algorithmic_bytes_per_launch=b_alg, avg_launch_us=avg_s * 1e6, launches=reps,
                launch_us_median=(float(np.median(samples)) if samples else None),
@@ -241,6 +241,31 @@ def roofline_section(local, state_pend):
                                   note="131072 rollouts = 2 waves per SIMD: one resident wave of workgroups, latency-bound (DESIGN.md section 5)")
     c1.device_free(p2)
     c1.close()
+    # ---- (3) the other stored-states forms, with what BOUNDS them: HBM fraction from tools/states_probe.py and the
+    # VALU issue fraction from a rocprofv3 --pmc SQ_INSTS_VALU pass of the same probe (tools/measure_round4.sh -> committed summaries).
+    # The Pendulum forms write 8 (fp32) / 4 (binary16) bytes per ~45 vector instructions per lane: they are VALU-issue bound, not HBM bound.
+    hf, vf = os.path.join(ROOT, "profiles", "round4_states_hbm.json"), os.path.join(ROOT, "profiles", "round4_states_forms.json")
+    if os.path.exists(hf) and os.path.exists(vf):
+        with open(hf) as fh:
+            hb = json.load(fh)
+        with open(vf) as fh:
+            vj = json.load(fh)
+
+        def issue(sub):
+            for k, e in vj.items():
+                if sub in k:
+                    return e["valu_issue_frac"]
+            return None
+
+        for key, kern, bound in (("pendulum_store_f32", "pendulum_states_kernel<false>", "valu"),
+                                 ("pendulum_store_f16", "pendulum_states_f16_kernel<false>", "valu"),
+                                 ("particle_store_f16", "rollout_stream_kernel<1, true, false, true>", "valu (per-particle staging kernel; whole-line form not built)")):
+            if key in hb:
+                e = hb[key]
+                forms[key] = dict(kernel="dust::" + kern, bound=bound, avg_launch_us=e["total_us"], hbm_frac=e["hbm_frac"], achieved_gbs=e["achieved_gbs"],
+                                  valu_issue_frac=issue(kern), workload="%s N=%d S=%d M=%d H=%d" % (e["model"], e["N"], e["S"], e["M"], e["H"]),
+                                  source="profiles/round4_states_probe.txt, profiles/round4_states_forms.json (fraction of one wave64 VALU instruction per 2 "
+                                         "cycles per SIMD; tools/valu_rate_probe.hip prices the mix at 2.6-8.2 cycles per instruction)")
     out["forms"] = forms
     return out
 
@@ -428,7 +453,7 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline and dist is None:
         roofline = roofline_section(local, state)
-        pf = os.path.join(ROOT, "profiles", "round3_tick_pmc.json")
+        pf = os.path.join(ROOT, "profiles", "round4_tick_pmc.json")
         if os.path.exists(pf):  # VALU issue fraction of the persistent tick kernel from the committed SQ counter pass
             with open(pf) as fh:
                 pj = json.load(fh)
@@ -438,7 +463,9 @@ def main():
                 roofline["product_kernel"] = dict(
                     kernel=pj.get("kernel", "dust::svmpc_tick2_kernel<0,1>") + " (one launch = one control tick)", bound="valu-issue / hand-off latency",
                     valu_wave_instructions_per_tick=insts, valu_issue_floor_us=issue_s * 1e6, measured_us=1e6 * el / args.steps,
-                    frac=issue_s / (el / args.steps), source="profiles/round3_tick_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)")
+                    frac=issue_s / (el / args.steps), source="profiles/round4_tick_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)",
+                    note="the floor prices every vector instruction at the 2-cycle issue peak; measured on this chip (tools/valu_rate_probe.hip, "
+                         "profiles/round4_valu_rate_probe.txt) plain VOP2 issue in 2.6, VOP3 / packed / DPP in 4.3, transcendentals in 8.2 cycles")
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -458,7 +485,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "parallelism": par},
+            "config": {"workload": workload, "parallelism": par,
+                       "other_configs": "BASELINE configs[4] (cfg5) is run with M = 8 dynamics samples per rollout (the yaml's params_samples), drawn from "
+                                        "the 256-particle MPF: 1 635 ticks/s on one GPU (profiles/round4_configs.json).  SURVEY 8d's alternative, M = 256 "
+                                        "(every dynamics particle once), is accepted by the launch-per-iteration rollout kernels (any M; parity 9e-8 vs the "
+                                        "oracle) but not by the one-launch tick (T2_MAXM = 64): 114 ticks/s (tools/cfg5_m256.py)"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

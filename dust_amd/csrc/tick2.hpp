@@ -679,7 +679,11 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       T2_TL(0, 16 * k + 1);
       // (the costs are an output of the tick's last iteration only, rewritten by the replay of a tick that does not start: they may leave
       //  the workgroup before "go" is known)
-      for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
+      // Stage outputs (costs, log-likelihood, score halves, phi) are what the getters return for the LAST iteration: only that one
+      // stores them - the stores of the other iterations sat in front of the barriers' vmcnt waits (phi: right in front of B6)
+      const bool last_iter = k + 1 == f->n_iters;
+      if (last_iter)
+        for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
       // wave-local softmax pieces over the wave's own samples, and the wave's share of the weighted sums over them (likelihoods.py:127-135,
       // svmpc.py:50-53, disco.py:387-392): nothing here needs the partner wave or the prior pass, so it runs underneath the P waves' pass
       // instead of behind barrier B1; the owner lanes merge the two waves' pieces of a particle (scale factors exp(-alpha (m_w - min)))
@@ -782,8 +786,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
         if (f->lik == DUST_LIK_EXP_UTILITY) last_logl = ((-cmin * f->alpha) + logf(zw)) - logf((float)S);
         else last_logl = -f->alpha * ((r0[3] + r1[3]) / (float)S);
         ll[op] = last_logl;
-        f->logl[n] = last_logl;
-        f->eta[n] = (-cmin / f->temp) + logf(zo);
+        if (k + 1 == f->n_iters) {
+          f->logl[n] = last_logl;
+          f->eta[n] = (-cmin / f->temp) + logf(zo);
+        }
       }
       const float *wg = wpart + (op * 4) * T2_ROW + od, *wa = wpart + (T2_PW * 4 + op * 4) * T2_ROW + od;
       const float g = (wg[0] + wg[T2_ROW]) * f0 + (wg[2 * T2_ROW] + wg[3 * T2_ROW]) * f1;
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       publish_rows(scl, f->sq + (size_t)k * N * T2_ROW, cnt_score);
       DUST_PRIO(0);
       T2_TL(8, 16 * k + 7);
-      if (ownv) {
+      if (ownv && k + 1 == f->n_iters) {
         f->score[no] = gs_keep + gp_keep;
         f->grad_lik[no] = gs_keep;
         f->grad_pri[no] = gp_keep;
@@ -916,7 +922,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     if (isown) {
       if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq + (size_t)(k + 1) * N * T2_ROW, cnt_theta);
       T2_TL(8, 16 * k + 13);
-      if (ownv) f->phi[no] = phi_keep;
+      if (ownv && k + 1 == f->n_iters) f->phi[no] = phi_keep;
     }
     wg_sync();  // B6  (tried twice: the barrier in front of the publish, so that the rollout waves start ~1 us earlier - +1.3 us per tick; with the
                 // publish at wave priority 3: no gain either)
