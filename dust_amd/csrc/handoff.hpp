@@ -72,7 +72,19 @@ __device__ __forceinline__ float adam_step(float th, const float g, float &m, fl
 // (v_cmp / v_cndmask / VOP3 negations: 41 of the step's 171 issue cycles, tools/valu_rate_probe.hip) - the sign is the parity bit of
 // k, taken from the mantissa of fl(theta / pi + 1.5 * 2^23), which is also how k is rounded (no v_rndne / v_cvt).  The rollout step of the
 // product tick: 56 -> 45 instructions, 171 -> 129 issue cycles.  Valid for |theta| < 2^22 pi (the callers hold |theta| <= 5e4).
-__device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th) {
+// The constants that sit in the ADDEND slot beside a literal multiplier (v_fmamk takes one literal): a caller whose translation unit is
+// built without machine LICM (tick2.hip) pins them in registers in front of its step loop - trig_consts_pinned() - instead of
+// re-creating them in every step.
+struct TrigConsts {
+  float magic, s1, c1, pif;
+};
+__device__ __forceinline__ TrigConsts trig_consts() { return TrigConsts{12582912.0f, -1.980484958e-04f, 2.475986184e-05f, PI_F}; }
+__device__ __forceinline__ TrigConsts trig_consts_pinned() {
+  TrigConsts k = trig_consts();
+  asm volatile("" : "+v"(k.magic), "+v"(k.s1), "+v"(k.c1), "+v"(k.pif));
+  return k;
+}
+__device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *cos_th, const TrigConsts K = trig_consts()) {
 #ifdef DUST_OLD_TRIG  // A/B only: the pi / 2 reduction of rounds 1-3
   int q_;
   const float r_ = trig_reduce(th, &q_);
@@ -89,7 +101,7 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   *cos_th = cs_;
   return;
 #endif
-  const float magic = 12582912.0f;  // 1.5 * 2^23: fl(x + magic) - magic = rint(x), and bit 0 of fl(x + magic) is the parity of rint(x)
+  const float magic = K.magic;  // 1.5 * 2^23: fl(x + magic) - magic = rint(x), and bit 0 of fl(x + magic) is the parity of rint(x)
   const float t = fmaf(th, 0.318309886183790671538f, magic);
   const float kf = t - magic;
   const unsigned int sgn = __float_as_uint(t) << 31;
@@ -97,21 +109,21 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   r = fmaf(kf, -(2.0f * 3.13916473e-07f), r);         // 1.1e-14 k, stays below 2e-10 for |theta| <= 5e4 (tools/trig_fit.py)
   const float s = r * r;
   float p = 2.596175364e-06f;
-  p = fmaf(p, s, -1.980484958e-04f);
+  p = fmaf(p, s, K.s1);
   p = fmaf(p, s, 8.332992904e-03f);
   p = fmaf(p, s, -1.666665673e-01f);
   float sn = fmaf(p, r * s, r);
   float q = -2.604016061e-07f;
-  q = fmaf(q, s, 2.475986184e-05f);
+  q = fmaf(q, s, K.c1);
   q = fmaf(q, s, -1.388836536e-03f);
   q = fmaf(q, s, 4.166663811e-02f);
   q = fmaf(q, s, -5.000000000e-01f);
   float cs = fmaf(q, s, 1.0f);
   sn = __uint_as_float(__float_as_uint(sn) ^ sgn);
   cs = __uint_as_float(__float_as_uint(cs) ^ sgn);
-  const float tp = th + PI_F;
+  const float tp = th + K.pif;
   const float bb = tp - th;
-  const float err = (th - (tp - bb)) + (PI_F - bb);  // exact: th + PI_F = tp + err
+  const float err = (th - (tp - bb)) + (K.pif - bb);  // exact: th + PI_F = tp + err
   const float e = 8.742278000372485e-8f - err;       // pi_f - pi
   *sin_tp = -fmaf(e, cs, sn);
   *cos_th = cs;

@@ -117,7 +117,8 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line /* the workgro
 // 150 against 130 us per tick, although the 8 x 8 form reads whole lines and every row once).
 // The theta-only half of SVMPC.phi (svmpc.py:38-41, 76-83) is cut in two at the point the SCORE needs:
 //   T2_PASS_PRIOR  (phase 1, underneath the rollouts; needed for the score rows): prior softmax mass L, weighted sum
-//                  a = sum_j e_ij (y_j - x_i); the squared distances go to LDS (dk[key][4]).
+//                  a = sum_j e_ij (y_j - x_i); the squared distances go to LDS (dk[key][4]).  The tick runs this pass in the
+//                  wide layout since round 4 - t2_prior_pass_w below; the form here is the A/B partner.
 //   T2_PASS_STEIN  (phase 4, while the score rows of the other workgroups are in flight - the CU has nothing else to do then but
 //                  draw the next noise): k_ij from the kept distances -> LDS (the same dk[key][4], in place), repulsion b = sum_j k'_ij (y_j - x_i)
 //                  with k' = k (K1) or k^3 (IMQ).  Re-reads the key rows and re-forms the differences: ~15 % more work in
@@ -274,6 +275,120 @@ __device__ __forceinline__ void t2_pair_pass(const T2ArgPtr f, const int gen /* 
       s += __shfl_xor(s, 32, 64);
       red[q] = s;
     }
+  }
+}
+
+// The PRIOR pass in the WIDE layout: lane = (key u = lane >> 1, column half c = lane & 1) - a step is 32 key rows, a lane holds 16
+// columns of its key row.  The per-(query, key) scalar chain (the column sum of the squared distance, the exponential, the mask) is
+// shared by 2 lanes instead of 4 and covers twice the columns: 109 instructions per (32 keys, 2 queries) against 139 in the 16 x 4
+// layout (98.5 -> 95.5 us per tick; phase 1 is bound by vector issue - tools/valu_rate_probe.hip - and this pass shares it with the
+// rollouts).  Registers: 32 of accumulators, two key steps of 16 (one in flight), 16 of differences; the query rows do NOT fit beside
+// them (128 registers at 16 waves per CU) and are read from LDS for every (step, query) - two broadcast addresses per read.
+// The Stein pass stays in the 16 x 4 layout: it runs in phase 4, where vector issue is not the bound - the wide form of it (correct,
+// with the query rows in registers) cost +9 us, a four-query form that loads every key row once per workgroup +1.3 us; so did a
+// prefetch of the next query row here (+1.5 .. 4 us: one spilled register puts a scratch load, i.e. a vmcnt(0), into the key loop).
+// Results: red[0] = the complete sum over the unit's keys of value index (lane >> 2 & 1) * 16 + t2_wide_col(lane) of column half c
+// (value index = query * 16 + column within the half); red[1] = L of query (lane >> 1) & 1 (every lane).
+__device__ __forceinline__ int t2_wide_col(const int lane) {
+  return ((lane >> 1) & 1) + 2 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 8 * ((lane >> 3) & 1);
+}
+template <int MODE, bool MASK>
+__device__ __forceinline__ void t2_prior_pass_w(const T2ArgPtr f, const int gen, const float *thq, float *dk, const float *lml, const int pw, const int lane,
+                                                const float lm_ref, float (&red)[2]) {
+  const int u = lane >> 1, c = lane & 1, N = f->N;
+  const int kw = pw & 3, q0 = (pw >> 2) * 2;
+  const int xoff = opaque((q0 * T2_ROW + 16 * c) * 4);
+  auto xrow = [&](const int q, v2f (&x)[8]) {  // (opaque offset: re-read for every (step, query), not hoisted into 32 registers)
+    const char *b = reinterpret_cast<const char *>(thq) + opaque(xoff) + q * T2_ROW * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 xa = *reinterpret_cast<const float4 *>(b + 16 * i);
+      x[2 * i] = v2f{xa.x, xa.y};
+      x[2 * i + 1] = v2f{xa.z, xa.w};
+    }
+  };
+  v2f acc[2][8];
+  float accL[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int h = 0; h < 8; ++h) acc[q][h] = v2f{0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq + (size_t)gen * N * T2_ROW, N * T2_ROW);
+  const int steps = f->steps / 2;
+  const float cP = f->cP;
+  auto step = [&](const int t, const v4f (&y)[4]) {
+    const int j = (t * 4 + kw) * 32 + u;
+    const bool valid = !MASK || j < N;
+    v2f yv[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      yv[2 * i] = v2f{y[i][0], y[i][1]};
+      yv[2 * i + 1] = v2f{y[i][2], y[i][3]};
+    }
+    const float lm2 = (lml[j] - lm_ref) * 1.44269504088896340736f;
+    float dsq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      v2f z[8];
+      xrow(q, z);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) z[h] = yv[h] - z[h];
+      v2f d2 = z[0] * z[0];
+#pragma unroll
+      for (int h = 1; h < 8; ++h) d2 = __builtin_elementwise_fma(z[h], z[h], d2);
+      float dd = d2.x + d2.y;
+      asm volatile("" : "+v"(dd));  // (keeps the two queries' chains apart: fused into packed operations they are live together)
+      dd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dd), 0xB1, 0xf, 0xf, true));  // the other column half
+      dsq[q] = dd;
+      const float e = valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;  // prior weight pi_j N(x_q; y_j) / exp(lm_ref)
+      accL[q] += e;
+      const v2f ee = {e, e};
+#pragma unroll
+      for (int h = 0; h < 8; ++h) acc[q][h] = __builtin_elementwise_fma(ee, z[h], acc[q][h]);
+      // one (step, query) after the other - left alone, the compiler sinks the accumulation of both steps and both queries behind the
+      // four distance chains: 64 registers of differences, the accumulators in scratch
+#pragma unroll
+      for (int h = 0; h < 8; ++h) asm volatile("" : "+v"(acc[q][h]));
+    }
+    if (c == 0) *reinterpret_cast<float2 *>(&dk[(size_t)j * 4 + q0]) = float2{dsq[0], dsq[1]};
+  };
+  auto issue = [&](const int t, v4f (&y)[4]) {
+    const int j = min((t * 4 + kw) * 32 + u, N - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = t2_ld16(rx, (j * T2_ROW + 16 * c + 4 * i) * 4);
+  };
+  {
+    v4f ya[4], yb[4];
+    issue(0, ya);
+    for (int t = 0; t < steps; t += 2) {  // (steps is a multiple of 8; the last group re-reads its last rows: no branch in the loop)
+      issue(t + 1, yb);
+      step(t, ya);
+      issue(min(t + 2, steps - 1), ya);
+      step(t + 1, yb);
+    }
+  }
+  float v[32], r2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      v[q * 16 + 2 * h] = acc[q][h].x;
+      v[q * 16 + 2 * h + 1] = acc[q][h].y;
+    }
+  reduce_u16<32>(v, r2, lane);  // over lane bits 2-5 ...
+  const bool b1 = (lane & 2) != 0;
+  {  // ... and over lane bit 1 (partner 2 lanes away: no bank mask tells them apart - the select form, on the last element pair only)
+    const float keep = b1 ? r2[1] : r2[0], give = b1 ? r2[0] : r2[1];
+    red[0] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0x4E, 0xf, 0xf, true));
+  }
+  {
+    const float keep = b1 ? accL[1] : accL[0], give = b1 ? accL[0] : accL[1];
+    float sL = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0x4E, 0xf, 0xf, true));
+    sL += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sL), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    sL += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sL), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    sL += __shfl_xor(sL, 16, 64);
+    sL += __shfl_xor(sL, 32, 64);
+    red[1] = sL;
   }
 }
 
@@ -642,12 +757,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
             asm volatile("" : "+v"(chol0));  // (a vector register: a VOP2 with a scalar operand issues in 4.3 cycles instead of 2.6)
             const v2f W = {f->dm.w_cos, f->dm.w_vel};
             float sn, cs;
-#ifdef T2_ABL_ROLL  // timing ablation (results invalid): one step instead of H
-            const int H = 1;
-#endif
+            const TrigConsts K = trig_consts_pinned();
 #pragma unroll 4
             for (int t = 0; t < H; ++t) {
-              pendulum_trig(x[0], &sn, &cs);
+              pendulum_trig(x[0], &sn, &cs, K);
               v2f q = {cs - 1.0f, x[1]};
               q = W * (q * q);
               tot.add(q.x + q.y, t);
@@ -657,7 +770,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
               x[0] = x[0] + thd * dt;
               x[1] = thd;
             }
-            pendulum_trig(x[0], &sn, &cs);
+            pendulum_trig(x[0], &sn, &cs, K);
             v2f q = {cs - 1.0f, x[1]};
             q = W * (q * q);
             traj = (float)tot.total() + (q.x + q.y);
@@ -752,10 +865,11 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
       float red[4];
-      if (N != f->steps * 64) t2_pair_pass<MODE, T2_PASS_PRIOR, true>(f, k, th, ksl, lml, pw, lane, lm_ref, red);
-      else t2_pair_pass<MODE, T2_PASS_PRIOR, false>(f, k, th, ksl, lml, pw, lane, lm_ref, red);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) ppart[(pw * 32 + reduce_u16_index<32>(i, lane)) * 4 + (lane & 3)] = red[i];
+      float rw[2];
+      if (N != f->steps * 64) t2_prior_pass_w<MODE, true>(f, k, th, ksl, lml, pw, lane, lm_ref, rw);
+      else t2_prior_pass_w<MODE, false>(f, k, th, ksl, lml, pw, lane, lm_ref, rw);
+      ppart[(pw * 2 + ((lane >> 2) & 1)) * 32 + 16 * (lane & 1) + t2_wide_col(lane)] = rw[0];  // [unit][query][column]
+      if ((lane & ~2) == 0) ppart[512 + pw * 2 + (lane >> 1)] = rw[1];                            // [unit][query] L
       T2_TL(8, 16 * k + 3);
       T2_TL(15, 16 * k + 15);
       if (k == 0 && wave == 15) go_wait();  // (the pass above read and wrote nothing outside the workgroup)
@@ -798,13 +912,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       const float as = am / zo;
       if (f->update_a_mat) amv = amv + as;
       {
-        const int c = od >> 3, cc = od & 7;
         float sp = 0.f, l = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {  // the four waves that hold this query's half: their key quarters, in order
           const int pwq = (op >> 1) * 4 + w;
-          sp += ppart[(pwq * 32 + (op & 1) * 8 + cc) * 4 + c];
-          l += ppart[(pwq * 32 + 16 + (op & 1)) * 4 + c];
+          sp += ppart[(pwq * 2 + (op & 1)) * 32 + od];
+          l += ppart[512 + pwq * 2 + (op & 1)];
         }
         gp_keep = (sp / l) * f->inv_sp2;
       }

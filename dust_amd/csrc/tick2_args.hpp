@@ -71,7 +71,7 @@ enum {
   T2_MAXM = 64,                               // dynamics samples per rollout (coefficient pairs in LDS)
   T2_L_TH = 0,                                // [4][32] the workgroup's particles, zero padded
   T2_L_MISC = T2_L_TH + T2_PW * T2_ROW,       // [192] small words (see tick2.hpp)
-  T2_L_PPART = T2_L_MISC + 192,               // [8 waves][32 sums][4 column groups] partials of the prior pass
+  T2_L_PPART = T2_L_MISC + 192,               // [8 units][2 queries][32 columns] partials of the prior pass, then [8][2] of L (forward: [16][4])
   T2_L_RP = T2_L_PPART + 8 * 32 * 4,          // [8 waves][16 sums][4 column groups] partials of the Stein repulsion
   T2_L_WPART = T2_L_RP + 8 * 16 * 4,          // [2][4][8][32] weighted-sum partials (likelihood score, a_mat update); after barrier B4 the
                                               // same 2 048 floats hold [16 waves][32 sums][4 column groups] partials of sum_j k_ij s_j
