@@ -392,6 +392,70 @@ __device__ __forceinline__ void t2_prior_pass_w(const T2ArgPtr f, const int gen,
   }
 }
 
+// The log-density pass of SVMPC.forward in the same wide layout (lane = (key of a 32-key step, column half)): L only - no accumulators,
+// so the four query rows stay in registers.  All 16 waves share the keys: f->steps / 8 steps per wave.  red[q] = L of query q, every lane.
+template <bool MASK>
+__device__ __forceinline__ void t2_logp_pass_w(const T2ArgPtr f, const int gen, const float *thq, const float *lml, const int wave, const int lane,
+                                               const float lm_ref, float (&red)[4]) {
+  const int u = lane >> 1, c = lane & 1, N = f->N;
+  v2f xq[T2_PW][8];
+#pragma unroll
+  for (int q = 0; q < T2_PW; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 xa = *reinterpret_cast<const float4 *>(&thq[q * T2_ROW + 16 * c + 4 * i]);
+      xq[q][2 * i] = v2f{xa.x, xa.y};
+      xq[q][2 * i + 1] = v2f{xa.z, xa.w};
+    }
+  float accL[T2_PW] = {0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rx = t2_rsrc(f->xq + (size_t)gen * N * T2_ROW, N * T2_ROW);
+  const int steps = f->steps / 8;
+  const float cP = f->cP;
+  auto issue = [&](const int t, v4f (&y)[4]) {
+    const int j = min((t * 16 + wave) * 32 + u, N - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = t2_ld16(rx, (j * T2_ROW + 16 * c + 4 * i) * 4);
+  };
+  auto step = [&](const int t, const v4f (&y)[4]) {
+    const int j = (t * 16 + wave) * 32 + u;
+    const bool valid = !MASK || j < N;
+    const float lm2 = (lml[j] - lm_ref) * 1.44269504088896340736f;
+#pragma unroll
+    for (int q = 0; q < T2_PW; ++q) {
+      v2f d2 = v2f{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v2f z0 = v2f{y[i][0], y[i][1]} - xq[q][2 * i], z1 = v2f{y[i][2], y[i][3]} - xq[q][2 * i + 1];
+        d2 = i == 0 ? z0 * z0 : __builtin_elementwise_fma(z0, z0, d2);
+        d2 = __builtin_elementwise_fma(z1, z1, d2);
+      }
+      float dd = d2.x + d2.y;
+      dd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dd), 0xB1, 0xf, 0xf, true));  // the other column half
+      accL[q] += valid ? __builtin_amdgcn_exp2f(fmaf(dd, cP, lm2)) : 0.f;
+    }
+  };
+  {
+    v4f ya[4], yb[4];
+    issue(0, ya);
+    for (int t = 0; t < steps; t += 2) {  // (steps is even: f->steps is a multiple of 16)
+      issue(t + 1, yb);
+      step(t, ya);
+      issue(min(t + 2, steps - 1), ya);
+      step(t + 1, yb);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < T2_PW; ++q) {  // all-reduce over the 32 keys of the lanes (the two column halves hold the same value)
+    float sL = accL[q];
+    sL += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sL), 0x4E, 0xf, 0xf, true));
+    sL += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sL), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    sL += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sL), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    sL += __shfl_xor(sL, 16, 64);
+    sL += __shfl_xor(sL, 32, 64);
+    red[q] = sL;
+  }
+}
+
 // the general (reference-order) step / terminal cost with the Particle's occupancy grid read from LDS: the model block is copied
 // only inside the Particle instance, where it is used
 template <int MODEL>
@@ -1080,7 +1144,11 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     }
     while (t2_lds_ld(sig + 1) < (unsigned int)(kf + 1)) __builtin_amdgcn_s_sleep(1);
     float red[4];
+#ifdef T2_LOGP_NARROW
     t2_pair_pass<MODE, T2_PASS_LOGP, true>(f, kf, th, ksl, lml, wave, lane, lm_ref, red);
+#else
+    t2_logp_pass_w<true>(f, kf, th, lml, wave, lane, lm_ref, red);
+#endif
     if (lane < T2_PW) {
       float s = red[0];
       s = lane == 1 ? red[1] : s;
