@@ -26,6 +26,7 @@ PY
 timeout 900 python tools/configs_bench.py $O/configs.json > $O/configs.log 2>&1
 timeout 200 python tools/coldstart.py > $O/coldstart.txt 2>&1
 timeout 200 python tools/bench_timing_probe.py > $O/bench_timing_probe.txt 2>&1
+timeout 200 python tools/closed_loop_probe.py > $O/closed_loop_probe.txt 2>&1
 timeout 100 tools/_valu_rate_probe > $O/valu_rate_probe.txt 2>&1
 timeout 100 tools/_ldsdma_probe > $O/ldsdma_probe.txt 2>&1
 DUST_AMD_LIB=tools/_libdust_stamps.so timeout 200 python tools/tick2_timeline.py > $O/tick2_timeline.txt 2>&1
@@ -36,6 +37,7 @@ tail -c 1200 $O/bench_driver_cmd.json; head -6 $O/stats/*/b_kernel_stats.csv 2>/
 cd $R
 timeout 600 python tools/shard_time.py cfg4 > $O/shard_time.txt 2>&1
 timeout 300 python tools/states_probe.py > $O/states_probe.txt 2>&1
+python tools/states_hbm.py $O/states_probe.txt $O/states_hbm.json > /dev/null
 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 DUST_BENCH_FORCE_DIST=1 timeout 400 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline > $O/sharded_world1_bench.json 2> $O/sharded_world1_bench.err
 tail -3 $O/shard_time.txt; tail -c 600 $O/sharded_world1_bench.json
 # --- round 4: what bounds each stored-states form and the cfg3 / cfg5 rollout launches: kernel durations from a

@@ -43,13 +43,14 @@ def run(model, N, S, M, H, ticks, kernel="K1", optimizer="SGD", check_every=500)
         for _ in range(n - 1):
             c.svmpc_tick(state, 5, want_outputs=False)
         c.sync()  # raises if a hand-off spin timed out
-        twin = c.clone()
-        a_seq, pw = c.svmpc_tick(state, 5)
-        os.environ["DUST_NO_TICK2"] = "1"
+        os.environ["DUST_NO_TICK2"] = "1"  # (development switches are read once per context, when it is created: the clone is a new context)
         try:
-            b_seq, qw = twin.svmpc_tick(state, 5)
+            twin = c.clone()
         finally:
             os.environ.pop("DUST_NO_TICK2", None)
+        a_seq, pw = c.svmpc_tick(state, 5)
+        b_seq, qw = twin.svmpc_tick(state, 5)
+        assert twin.tick_stats()["tick2"] == 0, twin.tick_stats()
         e = max(elemerr(c.get_theta(), twin.get_theta()), elemerr(c.get_phi(), twin.get_phi()))
         worst = max(worst, e)
         assert np.isfinite(c.get_theta()).all() and abs(float(pw.sum()) - 1.0) < 1e-3
