@@ -1285,8 +1285,29 @@ struct StateWord {
   float v[8];
 };
 __global__ void set_state_kernel(float *dst, const StateWord w) { dst[threadIdx.x] = w.v[threadIdx.x]; }
+// the same with the tick's dynamics samples ([n_sets][M][P], up to 240 floats) behind the state: one 256-lane launch instead of a launch
+// and a host-to-device copy (4 us on the stream, and a staging copy on the host when the caller's array is pageable)
+struct StateParamsWord {
+  float v[8];
+  float p[240];
+};
+__global__ void set_state_params_kernel(float *dst, float *pdst, const StateParamsWord w, int ns, int np) {
+  const int t = threadIdx.x;
+  if (t < ns) dst[t] = w.v[t];
+  if (t < np) pdst[t] = w.p[t];
+}
 
 static int upload_state_params(dust_ctx *c, const float *state, const float *params, int n_sets) {
+  const size_t np = (c->cfg.dim_p > 0 && c->M >= 1 && params) ? (size_t)n_sets * c->M * c->P : 0;
+  if (np > 0 && np <= 240) {
+    TRY(ensure(&c->params_dev, &c->params_cap, np));
+    StateParamsWord w;
+    for (int k = 0; k < 8; ++k) w.v[k] = (state && k < c->ds) ? state[k] : 0.f;
+    memcpy(w.p, params, np * sizeof(float));
+    set_state_params_kernel<<<1, 256, 0, c->stream>>>(c->state_dev, c->params_dev, w, state ? 8 : 0, (int)np);
+    HIP_TRY(hipGetLastError());
+    return DUST_OK;
+  }
   if (state) {
     // the 16-byte plant state travels as a kernel ARGUMENT of a 4-lane launch (the runtime copies arguments at launch
     // time: nothing to keep alive, no host wait); measured 2 us on the stream against 4 us for a 16-byte hipMemcpyAsync
@@ -1531,7 +1552,8 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
   const int ldK = ((c->N + 63) / 64) * 64;
   TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)tiles * fused_tq(a.D) * ldK));  // whole query tiles: the kernel stores rows unconditionally
-  {
+  const bool whole_rows = a.D == dpb;  // (D = 80: the rows are their own padded copy - no pad_rows launch, 7 us per pass at N = 16 384)
+  if (!whole_rows) {
     const int n = c->N * dpb;
     pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
     HIP_TRY(hipGetLastError());
@@ -1539,7 +1561,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   PairFusedArgs b;
   memset(&b, 0, sizeof b);
   b.p = a;
-  b.Xp = c->xpad;
+  b.Xp = whole_rows ? a.X : c->xpad;
   b.ldp = 8 * cpt_for(a.D);
   b.wP[0] = a.inv_s[0] * a.inv_s[0];
   b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
@@ -1646,7 +1668,8 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
 static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
   const int dpb = fused_dpb(a.D);
   TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
-  {
+  const bool whole_rows = a.D == dpb;  // (D = 80: the rows are their own padded copy - no pad_rows launch, 7 us per pass at N = 16 384)
+  if (!whole_rows) {
     const int n = c->N * dpb;
     pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
     HIP_TRY(hipGetLastError());
@@ -1654,7 +1677,7 @@ static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
   PairFusedArgs b;
   memset(&b, 0, sizeof b);
   b.p = a;
-  b.Xp = c->xpad;
+  b.Xp = whole_rows ? a.X : c->xpad;
   b.ldp = 8 * cpt_for(a.D);
   b.wP[0] = a.inv_s[0] * a.inv_s[0];
   b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
@@ -1831,7 +1854,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   return DUST_OK;
 }
 
-static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp) {
+static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp, bool want_lw = false) {
   PriorFinishArgs f;
   memset(&f, 0, sizeof f);
   f.pm = prior_merge_args(c);
@@ -1843,6 +1866,8 @@ static int launch_prior_finish(dust_ctx *c, bool want_grad, bool want_logp) {
   f.grad_pri = want_grad ? c->grad_pri : nullptr;
   f.score = want_grad ? c->score : nullptr;
   f.logp = want_logp ? c->logp : nullptr;
+  f.logl = want_lw ? c->logl : nullptr;
+  f.lw = want_lw ? c->lw : nullptr;
   const int n = c->nloc * c->D;
   Prof p(c, DUST_K_PRIOR_SCORE);
   prior_finish_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(f);
@@ -2296,11 +2321,7 @@ static int forward_device(dust_ctx *c) {
   // unsharded small sets: finalize_kernel combines the partials itself (one launch less); from 4 096 particles on the merge of the
   // slice partials is spread over many workgroups first (the single finalize workgroup took 40 us at N = 16 384 with it, 14 without)
   if (c->nloc == c->N && c->N < 4096) return DUST_OK;
-  TRY(launch_prior_finish(c, false, true));
-  Prof p(c, DUST_K_FORWARD);
-  logw_kernel<<<(c->nloc + 255) / 256, 256, 0, c->stream>>>(c->logl, c->logp, c->lw, c->n0, c->nloc);
-  HIP_TRY(hipGetLastError());
-  return DUST_OK;
+  return launch_prior_finish(c, false, true, /*want_lw=*/true);  // log p and the log-weights logl + logp in one launch (logw_kernel's sum)
 }
 
 static FinalizeArgs finalize_args(dust_ctx *c, bool keep_prior) {

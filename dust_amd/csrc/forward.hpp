@@ -26,12 +26,6 @@ struct FinalizeArgs {
   PriorMerge pm;
 };
 
-// lw = logl + logp for the local shard (separate tiny kernel so a sharded caller can all-gather lw in between)
-__global__ void logw_kernel(const float *logl, const float *logp, float *lw, int i0, int n_local) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_local) lw[i0 + i] = logl[i0 + i] + logp[i0 + i];
-}
-
 // block-wide reduction of TWO values at once (one barrier pair instead of two)
 __device__ __forceinline__ void block_reduce2(float &mx, float &sm, float *scratch /* >= 32 */) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -573,6 +573,8 @@ struct PriorFinishArgs {
   float *grad_pri;        // [N][D] or nullptr
   float *score;           // [N][D] or nullptr
   float *logp;            // [N] or nullptr
+  const float *logl;      // [N] with lw: the log-likelihoods
+  float *lw;              // [N] or nullptr: log-weights logl + logp out (SVMPC.forward, svmpc.py:190)
 };
 __global__ void prior_finish_kernel(const PriorFinishArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,7 +588,11 @@ __global__ void prior_finish_kernel(const PriorFinishArgs a) {
     if (a.grad_pri) a.grad_pri[o] = gp;
     if (a.score) a.score[o] = a.grad_lik[o] + gp;
   }
-  if (a.logp && d == 0) a.logp[a.i0 + il] = (m + logf(l)) + a.pm.log_norm;
+  if (a.logp && d == 0) {
+    const float lp = (m + logf(l)) + a.pm.log_norm;
+    a.logp[a.i0 + il] = lp;
+    if (a.lw) a.lw[a.i0 + il] = a.logl[a.i0 + il] + lp;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
