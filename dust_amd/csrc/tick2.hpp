@@ -129,6 +129,12 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line /* the workgro
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
 // f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
 enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
+#ifndef T2_NOISE_SPLIT
+#define T2_NOISE_SPLIT 1
+#endif
+#ifndef T2_NOISE_P4
+#define T2_NOISE_P4 2  // quarters of a row's Philox blocks drawn in phase 4 (the rest: phase 6)
+#endif
 #ifndef T2_PRIO_OWNERSTAGE
 #define T2_PRIO_OWNERSTAGE 3
 #endif
@@ -633,11 +639,13 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   // device noise of iteration k, by the rollout waves: every wave draws the rows of ITS OWN samples (particle wave >> 1, samples
   // (wave & 1) * 64 + lane + 128 i), so a wave may go from its draw into its rollouts - and from its weighted sums into the next draw -
   // without a barrier in between
-  auto draw_own_rows = [&](const T2ArgPtr f, const int k, const int wave, const int lane) {
+  auto draw_own_rows = [&](const T2ArgPtr f, const int k, const int wave, const int lane, const int part = 2 /* 0 / 1: the first / second half of the row's Philox blocks; 2: all */) {
     const int rp = wave >> 1;
+    const int nb = (D + 7) >> 3, nh = T2_NOISE_SPLIT ? (nb * T2_NOISE_P4) >> 2 : nb;
+    const int jb = part == 1 ? nh : 0, je = part == 0 ? nh : nb;
     for (int s = (wave & 1) * 64 + lane; s < S; s += 128) {
       float *row = tile + (size_t)(rp * S + s) * Dp;
-      for (int j8 = 0; j8 * 8 < D; ++j8) {
+      for (int j8 = jb; j8 < je; ++j8) {
         float z[8];
         philox_normal8(f->seed, (uint32_t)j8, (uint32_t)(s * N + n_first + rp), ctr_iter0 + (uint32_t)k, ctr_tick, z);
 #pragma unroll
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       T2_TL(10, 16 * k + 8);
     } else if (wave < 8) {
       if (k + 1 < f->n_iters) {
-        if (f->eps == nullptr) draw_own_rows(f, k + 1, wave, lane);
+        if (f->eps == nullptr) draw_own_rows(f, k + 1, wave, lane, 0);  // (the second half: phase 6)
         else draw_noise(f, k + 1, tid, 512);
       }
       T2_TL(0, 16 * k + 9);
@@ -1100,6 +1108,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       if (k + 1 < f->n_iters || f->do_forward) publish_rows(th, f->xq + (size_t)(k + 1) * N * T2_ROW, cnt_theta);
       T2_TL(8, 16 * k + 13);
       if (ownv && k + 1 == f->n_iters) f->phi[no] = phi_keep;
+    } else if (T2_NOISE_SPLIT && wave < 8 && k + 1 < f->n_iters && f->eps == nullptr) {
+      // the second half of the next iteration's noise, by the rollout waves, while the owner lanes update and publish: in phase 4 the whole
+      // draw competed with the Stein pass for issue slots, here nothing else runs
+      draw_own_rows(f, k + 1, wave, lane, 1);
     }
     wg_sync();  // B6  (tried twice: the barrier in front of the publish, so that the rollout waves start ~1 us earlier - +1.3 us per tick; with the
                 // publish at wave priority 3: no gain either)
