@@ -129,6 +129,12 @@ __device__ __forceinline__ void t2_arrive_wave(unsigned int *line /* the workgro
 // Keys: the padded rows of the exchange buffer (sc1 loads); every workgroup publishes its particles there at the start of the tick.
 // f->steps (a multiple of 16, the host rounds up) = steps of a two-query pass; steps past the last key run on clamped rows, weight 0.
 enum { T2_PASS_PRIOR = 0, T2_PASS_STEIN = 1, T2_PASS_LOGP = 2 };
+#ifndef T2_PRIO_ROLL
+#define T2_PRIO_ROLL 1
+#endif
+#ifndef T2_PRIO_PPASS
+#define T2_PRIO_PPASS 0
+#endif
 #ifndef T2_NOISE_SPLIT
 #define T2_NOISE_SPLIT 1
 #endif
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     T2_TL(0, 16 * k + 0);
     if (wave < 8) {
       // ================= R waves, phase 1: rollouts (tick_owner stage 2; lane = sample) =================
-      DUST_PRIO(DUST_PRIO_OWNER);
+      DUST_PRIO(T2_PRIO_ROLL);
       const int rp = wave >> 1;
       const int n = n_first + rp;
       const float *tile_p = tile + (size_t)rp * S * Dp;
@@ -938,10 +944,12 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       T2_TL(8, 16 * k + 2);
       float red[4];
       float rw[2];
+      DUST_PRIO(T2_PRIO_PPASS);
       if (N != f->steps * 64) t2_prior_pass_w<MODE, true>(f, k, th, ksl, lml, pw, lane, lm_ref, rw);
       else t2_prior_pass_w<MODE, false>(f, k, th, ksl, lml, pw, lane, lm_ref, rw);
       ppart[(pw * 2 + ((lane >> 2) & 1)) * 32 + 16 * (lane & 1) + t2_wide_col(lane)] = rw[0];  // [unit][query][column]
       if ((lane & ~2) == 0) ppart[512 + pw * 2 + (lane >> 1)] = rw[1];                            // [unit][query] L
+      DUST_PRIO(0);
       T2_TL(8, 16 * k + 3);
       T2_TL(15, 16 * k + 15);
       if (k == 0 && wave == 15) go_wait();  // (the pass above read and wrote nothing outside the workgroup)
