@@ -11,6 +11,11 @@ __global__ void k(float *out, long long *cyc, int iters) {
   const float x = out[threadIdx.x & 7], y = out[8 + (threadIdx.x & 7)];
   for (int i = 0; i < 8; ++i) { a[i] = x + i; p[i] = v2f{x + i, y - i}; }
   const v2f xv = {x, y}, yv = {y, x};
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  v4f_ m4[4] = {{x, y, x, y}, {y, x, y, x}, {x, x, y, y}, {y, y, x, x}};
+  v2f xs;
+  xs.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+  xs.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)));
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -50,10 +55,14 @@ __global__ void k(float *out, long long *cyc, int iters) {
         if (KIND == 29) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
         if (KIND == 30) asm volatile("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(xv));
         if (KIND == 31) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(xv), "v"(yv));
+        if (KIND == 32) asm volatile("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "s"(xs));   // packed, one operand a scalar register pair
+        if (KIND == 33) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "s"(xs), "v"(yv));
+        if (KIND == 34) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(m4[i & 3]) : "v"(x), "v"(y));
+        if (KIND == 35) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(m4[i & 3]) : "v"(x), "v"(y));
       }
   }
   const long long t1 = __builtin_readcyclecounter();
-  float s = 0;
+  float s = m4[0].x + m4[1].y + m4[2].z + m4[3].w;
   for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
   out[64 + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
@@ -87,5 +96,6 @@ int main() {
   run<20>("v_fmaak_f32", o, c); run<21>("v_mul_f32", o, c); run<22>("v_add_f32_dpp", o, c); run<23>("v_add_f32 sgpr", o, c);
   run<24>("cndmask+add", o, c); run<25>("v_rndne_f32", o, c); run<26>("v_cvt_i32_f32", o, c); run<27>("v_and_b32", o, c);
   run<28>("v_bfi_b32", o, c); run<29>("v_max_f32", o, c); run<30>("v_pk_add neg", o, c); run<31>("v_pk_fma opsel", o, c);
+  run<32>("v_pk_add sgpr pair", o, c); run<33>("v_pk_fma sgpr pair", o, c); run<34>("v_mfma_f32_16x16x4_f32", o, c); run<35>("v_mfma_f32_4x4x1_16b", o, c);
   return 0;
 }
