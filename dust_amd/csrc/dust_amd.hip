@@ -412,7 +412,11 @@ struct PersistChain {  // RAII around ONE one-launch kernel launch on c->stream
 
 extern "C" void dust_destroy(dust_ctx *c) {
   if (!c) return;
-  if (c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV) g_live_ctx[c->cfg.device].fetch_sub(1);
+  if (c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV) {
+    std::lock_guard<std::mutex> lk(g_persist_mu[c->cfg.device]);
+    g_live_ctx[c->cfg.device].fetch_sub(1);
+    if (g_persist_last[c->cfg.device] == c->stream) g_persist_last[c->cfg.device] = nullptr;  // (a later stream may reuse the address)
+  }
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   comm_release(c);
@@ -423,8 +427,14 @@ extern "C" void dust_destroy(dust_ctx *c) {
 
 PersistChain::PersistChain(dust_ctx *c_) : c(c_), dev(c_->cfg.device), on(false) {
   static const bool off = getenv("DUST_NO_CHAIN") != nullptr;  // development switch
-  if (off || dev < 0 || dev >= DUST_MAX_DEV || g_live_ctx[dev].load() < 2) return;
+  if (off || dev < 0 || dev >= DUST_MAX_DEV) return;
+  // (the tenant count is tested UNDER the device's mutex, which dust_create holds while it counts itself in and drains the device:
+  //  a launch cannot slip unchained between another thread's increment and its first kernel - ADVICE r3)
   g_persist_mu[dev].lock();
+  if (g_live_ctx[dev].load() < 2) {
+    g_persist_mu[dev].unlock();
+    return;
+  }
   on = true;
   if (!g_persist_ev[dev] && hipEventCreateWithFlags(&g_persist_ev[dev], hipEventDisableTiming) != hipSuccess) {
     g_persist_ev[dev] = nullptr;
@@ -543,8 +553,12 @@ extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
   if (!out) return fail(DUST_ERR_INVALID, "null out");
   *out = nullptr;
   int s = create_impl(cfg, out);
-  if (s == DUST_OK && cfg->device >= 0 && cfg->device < DUST_MAX_DEV && g_live_ctx[cfg->device].fetch_add(1) + 1 == 2)
-    (void)hipDeviceSynchronize();  // a second tenant: one-launch kernels are chained from here on (PersistChain); none may be in flight unchained
+  if (s == DUST_OK && cfg->device >= 0 && cfg->device < DUST_MAX_DEV) {
+    // counted in under the device's mutex (PersistChain tests the count under it, and holds it across its launch): a one-launch kernel
+    // is either enqueued before this point - and drained here - or sees the second tenant and is chained
+    std::lock_guard<std::mutex> lk(g_persist_mu[cfg->device]);
+    if (g_live_ctx[cfg->device].fetch_add(1) + 1 == 2) (void)hipDeviceSynchronize();
+  }
   if (s != DUST_OK && *out) {
     std::string keep = g_err;
     free_all(*out);

@@ -90,6 +90,13 @@ __global__ __launch_bounds__(256, 2) void pairwise_logp_mfma_kernel(const LogpMf
     m[t] = -3.0e38f;  // (finite: a lane whose first keys are all masked must not form inf - inf)
     sm[t] = 0.f;
   }
+  // The query's OWN term - the dominant one of a spread-out set - is exact in the exact-difference pass (distance 0: logit = log w_i),
+  // and here it would carry the product form's whole cancellation error, 4 eps |z_i|^2: the one key step of a wave that
+  // holds its own queries (a wave-uniform test) puts hj_i + |z_i|^2 / 2 + |z_i|^2 / 2 = hj_i - 2 hq_i in the accumulator's place.
+  const int qg0 = a.i0 + q0;  // the wave's first query (global index)
+  float hq2[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) hq2[t] = 2.0f * a.hq[min(qg0 + 16 * t + r16, N - 1)];
   // key chunk staging: 64 rows x DPB floats = NP 16-byte pieces per lane
   v4f ky[NP];
   float hjn = 0.f;
@@ -132,9 +139,16 @@ __global__ __launch_bounds__(256, 2) void pairwise_logp_mfma_kernel(const LogpMf
       }
       // the lane holds (keys 16 kt + 4 g + r, query r16 of tile t): online log-sum-exp in base 2
       const v4f h = *reinterpret_cast<const v4f *>(&hs[buf * JC + 16 * kt + 4 * g]);
+      const int kb = j0 + 16 * kt;
+      const bool diag = kb < qg0 + 16 * QT && kb + 16 > qg0;  // (wave-uniform: 4 of a wave's key steps at most)
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        const v4f x = acc[t] + h;
+        v4f x = acc[t] + h;
+        if (diag) {
+          const int d = (qg0 + 16 * t + r16) - (kb + 4 * g);  // the lane's query is key r = d of its four
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = d == r ? h[r] - hq2[t] : x[r];
+        }
         const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
         const float mn = fmaxf(m[t], mx);
         const float e = (__builtin_amdgcn_exp2f(x.x - mn) + __builtin_amdgcn_exp2f(x.y - mn)) +
