@@ -1118,6 +1118,24 @@ static bool states_whole_lines(const dust_ctx *c, const SampleOpts &o, const Rol
   return true;
 }
 
+// ... its binary16 form (DUST_STORE_F16): 8-byte states, 16-particle groups (rollout_states.hpp particle_states_f16_kernel)
+static bool states_whole_lines_f16(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, int *gw_out, size_t *lds_out) {
+  if (c->env.states_form == 0) return false;
+  if (c->cfg.model != DUST_MODEL_PARTICLE || !a.states_out || a.costs_in || a.mw || a.tile_scratch) return false;
+  if (!o.store_f16 || a.noise_f16 || a.noise_mode == NOISE_PHILOX || !a.noise || a.a_reg != 0.0f || a.dm.interleave) return false;
+  if (((c->H + 1) & 1) == 0 || c->H < 16) return false;
+  if ((c->N % 16) || (c->n0 % 16) || (c->nloc % 16)) return false;
+  if (a.dm.with_obstacle && a.grid_words == 0) return false;
+  int gw = 4;
+  while (gw > 1 && c->M % (2 * gw)) gw >>= 1;
+  if (c->M % (2 * gw)) return false;
+  const size_t lds = particle_states_f16_lds_bytes(c->D, c->M, a.grid_words, gw);
+  if (lds > 80 * 1024) return false;
+  *gw_out = gw;
+  *lds_out = lds;
+  return true;
+}
+
 // ... and its Pendulum counterpart: 16-particle groups of 8 (H+1)-byte rows
 static bool states_whole_lines_pend(const dust_ctx *c, const SampleOpts &o, const RolloutArgs &a, size_t *lds_out) {
   if (c->env.states_form == 0) return false;
@@ -1204,6 +1222,28 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
     if (lds_s > 64 * 1024 && !c->capturing)                                                                                                  \
       HIP_TRY(hipFuncSetAttribute((const void *)particle_states_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));      \
     particle_states_kernel<MODE><<<blocks, 64 * gw, lds_s, c->stream>>>(a, c->costs_stage, gw, reinterpret_cast<unsigned int *>(c->wg_flags));                                 \
+  } while (0)
+        if (!a.dm.with_obstacle) DUST_LAUNCH_STATES(SP_FAST_FREE);
+        else if (a.dm.can_crash) DUST_LAUNCH_STATES(SP_FAST_CRASH);
+        else DUST_LAUNCH_STATES(SP_FAST_OBST);
+        DUST_LAUNCH_STATES(SP_GENERAL);  // only the workgroups the fast kernel flagged (non-finite operands) do any work here
+#undef DUST_LAUNCH_STATES
+        HIP_TRY(hipGetLastError());
+      }
+      o.want_states = false;
+      o.costs_in = c->costs_stage;
+      o.costs_own = true;
+      TRY(rollout_args(c, o, a, &nt, &lds));
+    } else if (states_whole_lines_f16(c, o, a, &gw, &lds_s)) {
+      {
+        Prof ps(c, DUST_K_ROLLOUT_STATES);
+        const int blocks = (c->nloc / 16) * ((c->S + 3) / 4);
+        TRY(ensure(&c->wg_flags, &c->wg_flags_cap, (size_t)blocks));
+#define DUST_LAUNCH_STATES(MODE)                                                                                                                 \
+  do {                                                                                                                                           \
+    if (lds_s > 64 * 1024 && !c->capturing)                                                                                                      \
+      HIP_TRY(hipFuncSetAttribute((const void *)particle_states_f16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));      \
+    particle_states_f16_kernel<MODE><<<blocks, 64 * gw, lds_s, c->stream>>>(a, c->costs_stage, gw, reinterpret_cast<unsigned int *>(c->wg_flags)); \
   } while (0)
         if (!a.dm.with_obstacle) DUST_LAUNCH_STATES(SP_FAST_FREE);
         else if (a.dm.can_crash) DUST_LAUNCH_STATES(SP_FAST_CRASH);

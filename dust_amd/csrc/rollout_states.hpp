@@ -588,6 +588,208 @@ __global__ void __launch_bounds__(256, 2) pendulum_states_f16_kernel(const Rollo
   }
 }
 
+// =====================================================================================================================
+// Particle family, binary16 states (DUST_STORE_F16; the arithmetic stays fp32): a state is 8 bytes, a trajectory 8 (H+1) bytes (328 at
+// H = 40) - the geometry of the Pendulum's fp32 rows above: groups of 16 ADJACENT particles are H+1 whole lines, 16 slots per line.
+// Rollouts as in particle_states_kernel (two dynamics samples (m, m + GW) side by side per lane in packed fp32, the workgroup's waves
+// split the dynamics samples and share 64 action rows), storage as in pendulum_states_kernel: lane = (sample lane / 16, particle
+// lane % 16), a workgroup = 4 samples x 16 particles; trajectory A is staged in the lane's own LDS line (slot (row + p) % 16),
+// trajectory B's last 16 states ride in a register ring and are dumped into a transient line when a line of its group completes; at
+// every step from row 15 on lanes 0-31 fetch the 4 completed lines of A, lanes 32-63 those of B, and the wave stores 8 whole lines.
+// Heads (rows 0 .. 14 of both trajectories) stay in registers; the 15 straddling lines per group are assembled at the end.
+// MODE as particle_states_kernel (SP_GENERAL: the flagged workgroups, reference-order step functions).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const RolloutArgs a, float *costs_sn, const int GW, unsigned int *wg_flags) {
+  if (MODE == SP_GENERAL && wg_flags[blockIdx.x] == 0u) return;
+  extern __shared__ float lds[];
+  const int S = a.S, D = a.D, H = a.H, N = a.N_total, M = a.M, Hp1 = H + 1;
+  const int Dp = D | 1;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+  const int nblk = (int)gridDim.x / ((S + 3) >> 2);  // particle groups of 16
+  const int nb = blockIdx.x % nblk, sb = blockIdx.x / nblk;
+  const int n_first = a.n0 + nb * 16;
+  float *tile = lds;                         // [64][Dp] action rows, row = lane
+  float *coefs = tile + 64 * Dp;             // [M][2]
+  float *flags = coefs + 2 * M;              // [4]
+  const int off_grid = ((int)((flags + 4) - lds) + 3) & ~3;
+  uint32_t *gridl = reinterpret_cast<uint32_t *>(lds + off_grid);
+  const int off_acc = (off_grid + a.grid_words + 3) & ~3;
+  double *accp = reinterpret_cast<double *>(lds + off_acc);                  // [GW][64]
+  char *areas = reinterpret_cast<char *>(lds + off_acc + 2 * GW * 64);        // [GW][68][SG_ROW]: 64 staged lines + 4 transient lines per wave
+  if (tid == 0) flags[0] = 0.f;
+  float x0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x0[k] = a.state[k];
+  wg_sync();
+  bool bad = false;
+  for (int m = tid; m < M; m += nt) {
+    float c0;
+    if (a.coef_given) c0 = a.coef_host[0];
+    else c0 = make_coef(a.dm, a.params ? a.params + (size_t)m * a.dm.P : nullptr).c0;
+    coefs[2 * m] = c0;
+    coefs[2 * m + 1] = 0.f;
+    bad |= !(fabsf(c0) >= 1.0e-30f && fabsf(c0) <= 1.0e30f);
+  }
+  {
+    const int words = a.dm.with_obstacle ? (a.dm.nx * a.dm.ny + 31) >> 5 : 0;
+    for (int i = tid; i < words; i += nt) gridl[i] = a.dm.grid_bits[i];
+  }
+  for (int idx = tid; idx < 64 * D; idx += nt) {  // the 16 particles of a sample are one contiguous 16 D run
+    const int row = (int)__umulhi((uint32_t)idx, a.magicD), k = idx - row * D;
+    const int s = min(sb * 4 + (row >> 4), S - 1), n = n_first + (row & 15);
+    const float e = a.noise[((size_t)s * N + n) * D + k];
+    const float thk = a.noise_mode == NOISE_EPS ? a.theta[(size_t)n * D + k] : 0.f;
+    const float lk = a.noise_mode == NOISE_EPS ? ((k & 1) ? a.chol_a[1] : a.chol_a[0]) : 1.f;
+    const float av = thk + lk * e;
+    tile[row * Dp + k] = av;
+    bad |= av != av;
+  }
+  if (bad) flags[0] = 1.f;
+  wg_sync();
+  const bool fast = flags[0] == 0.f && fabsf(x0[0]) <= 3.0e38f && fabsf(x0[1]) <= 3.0e38f && fabsf(x0[2]) <= 3.0e38f && fabsf(x0[3]) <= 3.0e38f &&
+                    (fabsf(x0[0]) + fabsf(x0[1]) + (fabsf(x0[2]) + fabsf(x0[3]) + a.dm.max_speed * (float)H) * fabsf((float)a.dm.dt)) * fabsf(a.dm.inv_cell) +
+                                fabsf(a.dm.off_x) + fabsf(a.dm.off_y) <
+                        1.0e17f;
+  if (MODE != SP_GENERAL) {
+    if (tid == 0) wg_flags[blockIdx.x] = fast ? 0u : 1u;
+    if (!fast) return;
+  }
+  const int j = lane & 15, ssub = lane >> 4;
+  const int s = sb * 4 + ssub;
+  const bool live = s < S;
+  // flusher role: lanes 0-31 take trajectory A's lines, lanes 32-63 B's: (sample sf_sub, 16-byte piece)
+  const int sf_sub = (lane >> 3) & 3, piece = lane & 7;
+  const bool halfB = lane >= 32;
+  const bool flive = sb * 4 + sf_sub < S;
+  const uint32_t rowb = 8u * (uint32_t)Hp1;
+  const size_t mstride = (size_t)S * N * rowb;  // bytes between consecutive dynamics samples
+  char *const gF = reinterpret_cast<char *>(a.states_out) + ((size_t)min(sb * 4 + sf_sub, S - 1) * N + n_first) * rowb + piece * 16;
+  const int pj = (Hp1 * j) & 15;
+  int inv16 = 1;
+  for (int c = 1; c < 16; c += 2)
+    if (((Hp1 * c) & 15) == 1) inv16 = c;
+  char *const area = areas + (size_t)w * 68 * SG_ROW;
+  char *const my_row = area + lane * SG_ROW;
+  char *const prev_row = area + (lane - 1) * SG_ROW;
+  char *const tr_w = area + (64 + ssub) * SG_ROW;  // transient line of this lane's sample (B's dumps)
+  const char *const fl_r = halfB ? area + (64 + sf_sub) * SG_ROW + piece * 16 : area + (sf_sub * 16) * SG_ROW + piece * 16;  // (A: + jn * SG_ROW)
+  const float *actl = tile + lane * Dp;
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  auto pack = [](const float x, const float y, const float z, const float v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 lo = {(_Float16)x, (_Float16)y}, hi = {(_Float16)z, (_Float16)v};
+    return u2{__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi)};
+  };
+  PairK pk;
+  pk.load(a.dm);
+  pk.pin();
+  double acc = 0.0;
+  for (int m = w; m + GW < M; m += 2 * GW) {
+    const float ma = coefs[2 * m], mb = coefs[2 * (m + GW)];
+    const v2f m2 = {ma, mb}, r2 = {1.0f / ma, 1.0f / mb};
+    char *const gA = gF + (size_t)m * mstride, *const gB = gA + (size_t)GW * mstride;
+    char *const gX = halfB ? gB : gA;
+    v2f xp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
+    u2 cB[16];            // trajectory B's ring (row % 16)
+    u2 hA[15], hB[15];    // rows 0 .. 14 of both
+    double ta = 0.0, tb = 0.0;
+    auto emit = [&](const int q /* row % 16, static */, const int row) {
+      const u2 sa = pack(xp[0].x, xp[1].x, xp[2].x, xp[3].x), sbv = pack(xp[0].y, xp[1].y, xp[2].y, xp[3].y);
+      *reinterpret_cast<u2 *>(my_row + (((q + pj) & 15) << 3)) = sa;
+      cB[q] = sbv;
+      if (row < 15) {  // (lines completing before row 15 are heads)
+        hA[q < 15 ? q : 0] = sa;
+        hB[q < 15 ? q : 0] = sbv;
+        return;
+      }
+      const int ph = (15 - q) & 15;
+      const int jn = (ph * inv16) & 15;
+      const uint32_t line = (rowb * (uint32_t)jn + 8u * (uint32_t)(row + 1)) / 128u - 1u;
+      __builtin_amdgcn_wave_barrier();
+      if (pj == ph) {  // (ph is static: the 16 slots are 8 static 16-byte pairs - ring entries (u, u + 1) with u + ph even)
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const int u0 = (2 * v + (ph & 1)) & 15, u1 = (u0 + 1) & 15;
+          *reinterpret_cast<u4 *>(tr_w + (((u0 + ph) & 15) << 3)) = u4{cB[u0].x, cB[u0].y, cB[u1].x, cB[u1].y};
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const v4f pv = *reinterpret_cast<const v4f *>(fl_r + (halfB ? 0 : jn * SG_ROW));
+      __builtin_amdgcn_wave_barrier();
+      if (flive) *reinterpret_cast<v4f *>(gX + (size_t)line * 128u) = pv;
+    };
+    float a0 = actl[0], a1 = actl[1];
+    v2f coll = {0.f, 0.f};
+    if (MODE == SP_FAST_OBST || MODE == SP_FAST_CRASH) coll = collision_pair(a.dm, gridl, xp[0], xp[1]);
+    auto step = [&](const int i /* static */, const int t) {
+      const v2f c = sg_pair_step<MODE>(a.dm, pk, gridl, m2, r2, xp, a0, a1, &coll);
+      const int tn = min(t + 1, H - 1);
+      a0 = actl[2 * tn];
+      a1 = actl[2 * tn + 1];
+      ta += (double)c.x;
+      tb += (double)c.y;
+      emit((i + 1) & 15, t + 1);
+    };
+    emit(0, 0);
+    for (int base = 0; base < H; base += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (base + i < H) step(i, base + i);
+    }
+    const v2f tc = sg_pair_term<MODE>(a.dm, gridl, xp, &coll);
+    acc += (double)((float)ta + tc.x);
+    acc += (double)((float)tb + tc.y);
+    // ---- the 15 straddling lines of each group: tail of row j (slots 0 .. t-1) + head of row j+1 (slots t .. 15) ----
+    auto assemble = [&](const bool ring /* B: the tails are in the register ring */, const u2 *head, char *g0 /* + m stride, piece 0 of sample 0's group */) {
+      __builtin_amdgcn_wave_barrier();
+      if (ring && j < 15) {  // (row 15 of a group ends on a line boundary: no tail)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) *reinterpret_cast<u2 *>(my_row + (((u + pj) & 15) << 3)) = cB[u];  // tail slots valid, the rest overwritten below
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (j >= 1) {  // pj >= 1: rows 0 .. 15-pj of this trajectory complete the previous row's last line
+#pragma unroll
+        for (int q = 0; q < 15; ++q)
+          if (q + pj <= 15) *reinterpret_cast<u2 *>(prev_row + (q + pj) * 8) = head[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      // 4 samples x 15 lines x 8 pieces = 480 pieces over the wave's 64 lanes
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int P = it * 64 + lane, ln = P >> 3, pc = P & 7;
+        const int ss = ln / 15, jb = ln - ss * 15;
+        if (ln < 60) {
+          const v4f pv = *reinterpret_cast<const v4f *>(area + (ss * 16 + jb) * SG_ROW + pc * 16);
+          const int sg = sb * 4 + ss;
+          if (sg < S)
+            *reinterpret_cast<v4f *>(g0 + ((size_t)sg * N + n_first) * rowb + (size_t)((rowb * (uint32_t)(jb + 1)) / 128u) * 128u + pc * 16) = pv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    char *const base_out = reinterpret_cast<char *>(a.states_out);
+    assemble(false, hA, base_out + (size_t)m * mstride);
+    assemble(true, hB, base_out + (size_t)(m + GW) * mstride);
+  }
+  accp[w * 64 + lane] = acc;
+  wg_sync();
+  if (w == 0 && live) {  // fixed-order sum of the wave partials, then the mean over the dynamics samples (rollout_body finish_cost)
+    double t = accp[lane];
+    for (int g = 1; g < GW; ++g) t += accp[g * 64 + lane];
+    const float cost = M == 1 ? (float)t : (float)(t / M);
+    costs_sn[(size_t)s * N + n_first + j] = cost;
+    a.costsT[(size_t)(n_first + j) * S + s] = cost;
+  }
+}
+
+static inline size_t particle_states_f16_lds_bytes(int D, int M, int grid_words, int GW) {
+  const size_t floats = (size_t)64 * (D | 1) + 2 * (size_t)M + 4 + 4 + (size_t)grid_words + 4 + 2 * (size_t)GW * 64;
+  return floats * sizeof(float) + (size_t)GW * 68 * SG_ROW + 16;
+}
+
 static inline size_t pendulum_states_f16_lds_bytes(int D, int M, int H) {
   const size_t floats = (size_t)256 * (D | 1) + 2 * (size_t)M + 4 + 4;
   return floats * sizeof(float) + (size_t)4 * 64 * (H + 1) * 4 + 16;

@@ -231,3 +231,71 @@ def test_pendulum_binary16_whole_line_states_general_path_and_fallbacks():
     costs, states, _, used, _ = out["1"]
     assert not used
     assert relerr(states.astype(np.float32), ref_states) < 2e-3 and relerr(costs, ref_costs) < TOL
+
+
+def _run_particle_f16(N, S, M, H, can_crash, with_obstacle, poison=None, seed=0):
+    from dust_amd import Context
+    from oracle import Oracle, grid_4x4_map
+
+    rng = np.random.default_rng(seed + 11 * N + S)
+    grid = grid_4x4_map() if with_obstacle else None
+    up = ("mass",) if M > 1 else None
+    kw = dict(model="particle", N=N, S=S, M=M, H=H, uncertain_params=up, can_crash=can_crash, with_obstacle=with_obstacle)
+    actions = (1.5 * rng.standard_normal((S, N, H, 2))).astype(np.float32)
+    if poison is not None:
+        actions[poison] = np.nan
+    params = None if up is None else rng.uniform(0.6, 1.6, (M, 1)).astype(np.float32)
+    st = np.array([-5.2, -7.3, 4.0, 3.0], np.float32)
+    ref_costs, ref_states = Oracle(grid=grid, **kw).rollout_cost(st, actions, params, want_states=True)
+    out = {}
+    for form in ("1", "0"):
+        os.environ["DUST_STATES_FORM"] = form
+        try:
+            c = Context(grid=grid, kernel="K1", alpha=1e-4, sigma_a=5.0, sigma_p=5.0, **kw)
+            c.set_a_mat(np.zeros((N, H, 2), np.float32))
+            c.profile(True)
+            costs, states, _, omega = c.disco_forward(st, actions, params, want_states=True, store_f16=True)
+            used = "states_kernel" in c.profile_get()
+            c.close()
+        finally:
+            os.environ.pop("DUST_STATES_FORM", None)
+        out[form] = (costs, states, omega, used)
+    return ref_costs, ref_states, out
+
+
+@pytest.mark.parametrize("N,S,M,H,can_crash,with_obstacle", [
+    (16, 4, 2, 16, False, False),    # smallest legal shape: one group, one pair, 17 rows (two lines complete in the loop)
+    (32, 9, 4, 40, True, True),      # cfg3's H, ragged S (9 = 4 + 4 + 1), two waves, crash semantics
+    (48, 64, 8, 40, False, True),    # cfg3's S / H, four waves, three groups
+    (16, 6, 16, 18, True, True),     # two pair iterations per wave
+])
+def test_particle_binary16_whole_line_states_vs_oracle_and_staged_kernel(N, S, M, H, can_crash, with_obstacle):
+    """DUST_STORE_F16 for the Particle family through a whole-line kernel of its own (round 4): 8-byte states, groups of 16 adjacent
+    particles = H + 1 whole lines.  States: the oracle's fp32 states rounded to binary16 and the staged kernel's halves BIT FOR BIT
+    (same step functions, same conversions); costs bit-equal to the staged kernel's."""
+    ref_costs, ref_states, out = _run_particle_f16(N, S, M, H, can_crash, with_obstacle)
+    costs, states, omega, used = out["1"]
+    costs0, states0, omega0, used0 = out["0"]
+    assert used and not used0
+    assert states.dtype == np.float16 and states.shape == ref_states.shape
+    assert relerr(costs, ref_costs) < TOL
+    assert np.array_equal(states, states0)  # every byte of every line, heads and tails included
+    assert np.array_equal(costs, costs0) and np.array_equal(omega, omega0)
+    ref16 = ref_states.astype(np.float16).astype(np.float32)
+    s32 = states.astype(np.float32)
+    ulp16 = np.maximum(np.abs(ref16), 2.0 ** -14) * 2.0 ** -10 + 2e-6 * np.abs(ref_states).max()
+    assert np.all(np.abs(s32 - ref16) <= ulp16) and np.mean(s32 != ref16) < 1e-3
+
+
+def test_particle_binary16_whole_line_states_general_path_and_fallbacks():
+    ref_costs, ref_states, out = _run_particle_f16(16, 8, 4, 20, True, True, poison=(3, 5, 2, 1))  # a NaN action: the general instance
+    costs, states, _, used = out["1"]
+    costs0, states0, _, _ = out["0"]
+    assert used
+    assert np.array_equal(np.isnan(states), np.isnan(ref_states))
+    assert np.array_equal(states, states0, equal_nan=True) and np.array_equal(costs, costs0, equal_nan=True)
+    for N, H in ((24, 20), (16, 21), (16, 10)):  # N % 16 != 0, H + 1 even, H < 16: the staged kernel
+        ref_costs, ref_states, out = _run_particle_f16(N, 8, 2, H, True, True)
+        costs, states, _, used = out["1"]
+        assert not used
+        assert relerr(states.astype(np.float32), ref_states) < 2e-3 and relerr(costs, ref_costs) < TOL
