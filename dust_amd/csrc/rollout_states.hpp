@@ -692,13 +692,20 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
     v2f xp[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
-    u2 cB[16];            // trajectory B's ring (row % 16)
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 cB2[8];            // trajectory B's ring (row % 16): entries (2 v, 2 v + 1) share a register quad - half of the dumps are 16-byte writes
     u2 hA[15], hB[15];    // rows 0 .. 14 of both
     double ta = 0.0, tb = 0.0;
     auto emit = [&](const int q /* row % 16, static */, const int row) {
       const u2 sa = pack(xp[0].x, xp[1].x, xp[2].x, xp[3].x), sbv = pack(xp[0].y, xp[1].y, xp[2].y, xp[3].y);
       *reinterpret_cast<u2 *>(my_row + (((q + pj) & 15) << 3)) = sa;
-      cB[q] = sbv;
+      if (q & 1) {
+        cB2[q >> 1].z = sbv.x;
+        cB2[q >> 1].w = sbv.y;
+      } else {
+        cB2[q >> 1].x = sbv.x;
+        cB2[q >> 1].y = sbv.y;
+      }
       if (row < 15) {  // (lines completing before row 15 are heads)
         hA[q < 15 ? q : 0] = sa;
         hB[q < 15 ? q : 0] = sbv;
@@ -708,12 +715,17 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
       const int jn = (ph * inv16) & 15;
       const uint32_t line = (rowb * (uint32_t)jn + 8u * (uint32_t)(row + 1)) / 128u - 1u;
       __builtin_amdgcn_wave_barrier();
-      if (pj == ph) {  // (ph is static: the 16 slots are 8 static 16-byte pairs - ring entries (u, u + 1) with u + ph even)
-        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      if (pj == ph) {  // (ph is static: ring entry u goes to the static slot (u + ph) % 16; with ph even the entry pairs of a register quad are
+                       //  aligned 16-byte pairs of slots - 8 writes -, with ph odd they straddle: 16 writes of 8 bytes)
+        if ((ph & 1) == 0) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          const int u0 = (2 * v + (ph & 1)) & 15, u1 = (u0 + 1) & 15;
-          *reinterpret_cast<u4 *>(tr_w + (((u0 + ph) & 15) << 3)) = u4{cB[u0].x, cB[u0].y, cB[u1].x, cB[u1].y};
+          for (int v = 0; v < 8; ++v) *reinterpret_cast<u4 *>(tr_w + (((2 * v + ph) & 15) << 3)) = cB2[v];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            *reinterpret_cast<u2 *>(tr_w + (((2 * v + ph) & 15) << 3)) = u2{cB2[v].x, cB2[v].y};
+            *reinterpret_cast<u2 *>(tr_w + (((2 * v + 1 + ph) & 15) << 3)) = u2{cB2[v].z, cB2[v].w};
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -747,7 +759,8 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
       __builtin_amdgcn_wave_barrier();
       if (ring && j < 15) {  // (row 15 of a group ends on a line boundary: no tail)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) *reinterpret_cast<u2 *>(my_row + (((u + pj) & 15) << 3)) = cB[u];  // tail slots valid, the rest overwritten below
+        for (int u = 0; u < 16; ++u)  // tail slots valid, the rest overwritten below
+          *reinterpret_cast<u2 *>(my_row + (((u + pj) & 15) << 3)) = (u & 1) ? u2{cB2[u >> 1].z, cB2[u >> 1].w} : u2{cB2[u >> 1].x, cB2[u >> 1].y};
       }
       __builtin_amdgcn_wave_barrier();
       if (j >= 1) {  // pj >= 1: rows 0 .. 15-pj of this trajectory complete the previous row's last line
