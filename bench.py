@@ -259,7 +259,7 @@ def roofline_section(local, state_pend):
 
         for key, kern, bound in (("pendulum_store_f32", "pendulum_states_kernel<false>", "valu"),
                                  ("pendulum_store_f16", "pendulum_states_f16_kernel<false>", "valu"),
-                                 ("particle_store_f16", "particle_states_f16_kernel<1>", "valu (whole-line kernel of round 4: 160 instructions per step and pair at 2 waves per SIMD)")):
+                                 ("particle_store_f16", "particle_states_f16_kernel", "valu (whole-line kernel of round 4: 160 instructions per step and pair at 2 waves per SIMD)")):
             if key in hb:
                 e = hb[key]
                 forms[key] = dict(kernel="dust::" + kern, bound=bound, avg_launch_us=e["total_us"], hbm_frac=e["hbm_frac"], achieved_gbs=e["achieved_gbs"],
