@@ -602,9 +602,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   // rows two lanes split a row's Philox blocks.  Same counter layout as rollout.hpp / persist.hpp: element (s, n, j).
   auto draw_noise = [&](const T2ArgPtr f, const int k, const int lid, const int nl) {
     const int rows = T2_PW * S;
-#ifdef T2_ABL_NOISE  // timing ablation (results invalid): the tile keeps the first draw
-    if (k > 0) return;
-#endif
     if (f->eps == nullptr) {
       const int split = nl >= 2 * rows ? 2 : 1;
       const int half = split == 2 ? (lid & 1) : 0;
