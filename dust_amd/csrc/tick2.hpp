@@ -12,23 +12,29 @@
 // pair distances) and every particle's score (for sum_j k_ij s_j).  Here the workgroup that OWNS 4 particles also computes their
 // rows of every pairwise sum against all N keys, so nothing but "theta published" and "score published" crosses workgroups:
 //   * one 1024-lane workgroup per CU, N / 4 workgroups, all resident (start barrier below);
-//   * waves 0-7 (R): rollouts of the 4 particles, lane = action sample (tick_owner's arithmetic), policy noise kept in an LDS
-//     tile and redrawn (Philox) while the score hop is in flight;
-//   * waves 8-15 (P): lane = (key sub-slice u, column group c): a wave streams 8 key rows (one coalesced 1 KB load) per step,
-//     forms exact differences to the 4 query rows, reduces the squared distances over the 8 column lanes (DPP), and accumulates
-//     the prior's softmax-weighted sum, the Stein repulsion and the softmax mass in registers - the whole theta-only half of
-//     SVMPC.phi - underneath the rollouts; k_ij goes to LDS.  Sums over u leave the wave through reduce_u (tick2_reduce.hpp);
-//   * after the score hop the P waves stream the score rows the same way: sum_j k_ij s_j, then phi and the optimiser step.
+//   * waves 0-7 (R): rollouts of the 4 particles, lane = action sample (tick_owner's arithmetic), then - wave-locally - their
+//     samples' softmax pieces and weighted sums; policy noise kept in an LDS tile, every wave redrawing the rows of its own samples
+//     (Philox) half while the score hop is in flight and half while the owner lanes update the particles;
+//   * waves 8-15 (P): the theta-only half of SVMPC.phi in two passes over all N keys (exact differences to two query rows per
+//     wave): the PRIOR pass underneath the rollouts - lane = (key of a 32-key step, column half), squared distances -> LDS, the
+//     prior's softmax-weighted sum and mass in registers (t2_prior_pass_w) - and, while the score rows travel, the STEIN pass -
+//     lane = (key of 16, column quarter), k_ij -> LDS in place of the distances, repulsion in registers (t2_pair_pass).  Sums over
+//     the key lanes leave a wave through the butterflies of tick2_reduce.hpp;
+//   * the owner lanes (waves 8-9, lane = (particle, column)) finish the score rows behind the prior pass (at wave priority 3:
+//     every other workgroup waits for them) and publish them; after the score hop all 16 waves stream the score rows:
+//     sum_j k_ij s_j, then phi and the optimiser step by the owner lanes, who publish the new particles.
 //   The theta hop of iteration k+1 hides under its rollouts (which need only the workgroup's own particles): ONE exposed hop
-//   per iteration.
+//   per iteration.  DESIGN.md 4.R has the timeline (15.9 us per iteration at cfg2) and what was tried around it.
 // Hand-offs: write-through rows (one 128-byte line per particle, 16-byte sc1 stores) -> every storing wave drains vmcnt -> one
-// agent-scope add per storing wave on the workgroup's counter shard; consumers: one wave polls the T2_NSH shard lines with sc1
-// loads, then a workgroup barrier (or an LDS word), then sc1 loads only (cdna_hip_programming.md Guideline 16).  The exchange
+// agent-scope add per storing wave on the workgroup's counter shard (in each of T2_NREP replicas); consumers: one wave polls the
+// T2_NSH shard lines of ITS replica with sc1 loads, then a workgroup barrier (or an LDS word) (cdna_hip_programming.md Guideline 16).  The exchange
 // buffers hold one [N][32] block PER GENERATION (particles: n_iters + 1, score rows: n_iters), which is what lets the consumers
 // use plain (L1 / L2-cached) loads - see t2_ld16.
-// Start barrier: every workgroup arrives on a counter; workgroup 0 waits (bounded) for all of them and publishes go / no-go.
-// Nothing is written before "go", so a launch whose workgroups cannot all be resident (another context on the device) leaves the
-// state untouched and the host runs that tick on the launch-per-iteration path instead.
+// Start barrier: the first hand-off (the particles of generation 0) doubles as it: workgroup 0 waits (bounded) for every
+// workgroup's arrival and publishes go / no-go; the others start their first pass on their own observation and pick "go" up in
+// front of barrier B1.  Nothing outside the exchange buffers is written before "go", so a launch whose workgroups cannot all be
+// resident (another context on the device) - or that stands behind an earlier launch awaiting its replay (expect_aborts) -
+// leaves the state untouched and the host runs that tick, in order, on the launch-per-iteration path instead.
 // Arithmetic: element-wise the operations of rollout.hpp / stein.hpp; sums over keys and samples are taken in a different order
 // and the sample softmax is merged from two wave-local pieces, so a tick agrees with the other paths to ~1e-6, not bitwise.
 #pragma once
