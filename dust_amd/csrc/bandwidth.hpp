@@ -15,6 +15,7 @@
 // an O(N^2) count per step; no demo uses that mode.
 #pragma once
 #include "common.hpp"
+#include "handoff.hpp"
 
 namespace dust {
 
@@ -29,6 +30,16 @@ struct K2Args {
   const float *score;   // [N][D]
   float *h;             // [G] bandwidths out (G = D, or H when shared)
   float *phi;           // [N][D]
+  // optimiser step folded into k2_phi_kernel (apply != 0): what update_from_phi_kernel does in a launch of its own otherwise.  The phi
+  // kernel reads the particles through the TRANSPOSED copy only, so the row-major theta may be updated in place while other
+  // workgroups are still summing.
+  int apply, optimizer;
+  float lr, beta1, beta2, eps;
+  float *theta_rw;      // [N][D] row-major particles (updated in place)
+  float *adam_m, *adam_v;
+  uint32_t *ctr;        // {tick, iter, adam_step}
+  unsigned int *fused_cnt;
+  int fused_tiles;
 };
 
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *scratch) {
@@ -307,6 +318,10 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
   const bool on = il < a.n_local;
   const int i = a.i0 + (on ? il : 0);
   const float h = a.h[g];
+  // k = exp(-d2 / h) as exp2(d2 * ce) with ce = -log2(e) / h formed once: a division per PAIR (v_div_scale / v_rcp / 4 FMAs /
+  // v_div_fmas / v_div_fixup) was half of this kernel's instructions (26 -> 14 us at cfg2 / K2); the argument differs from the
+  // divided one by <= 1.2e-7 relative, i.e. the kernel value by <= |arg| 1.2e-7 - inside what the bare v_exp_f32 already leaves
+  const float ce = -1.44269504088896340736f / h;
   float xi[2] = {0.f, 0.f}, g1[2] = {0.f, 0.f}, g2[2] = {0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
           df[q] = xi[q] - xcol[q][j];
           d2 = fmaf(df[q], df[q], d2);
         }
-      const float k = __builtin_amdgcn_exp2f((-d2 / h) * 1.44269504088896340736f);
+      const float k = __builtin_amdgcn_exp2f(d2 * ce);
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (q < gd) {
@@ -354,8 +369,27 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
           s1 += part[r][ii][q];
           s2 += part[r][ii][2 + q];
         }
-        a.phi[(size_t)i * D + c0 + q] = s1 / (float)N + ((s2 * 2.0f) / h) / (float)N;
+        const size_t o = (size_t)i * D + c0 + q;
+        const float phi = s1 / (float)N + ((s2 * 2.0f) / h) / (float)N;
+        a.phi[o] = phi;
+        if (a.apply) {  // (update_from_phi_kernel's element)
+          float th = a.theta_rw[o];
+          const float gr = -phi;
+          if (a.optimizer == DUST_OPT_SGD) {
+            th = fmaf(-a.lr, gr, th);
+          } else {
+            float m = a.adam_m[o], v = a.adam_v[o];
+            th = adam_step(th, gr, m, v, a.lr, a.beta1, a.beta2, a.eps, (float)a.ctr[2]);
+            a.adam_m[o] = m;
+            a.adam_v[o] = v;
+          }
+          a.theta_rw[o] = th;
+        }
       }
+  }
+  if (a.apply && blockIdx.x == 0 && blockIdx.y == 0) {  // (... and its bookkeeping: the fused launches' counters re-armed, the iteration counted)
+    for (int t = threadIdx.x; t < a.fused_tiles; t += 256) a.fused_cnt[t * 32] = 0u;
+    if (threadIdx.x == 0) a.ctr[1] += 1u;
   }
 }
 

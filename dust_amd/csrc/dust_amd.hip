@@ -2006,15 +2006,25 @@ static int launch_stein_update(dust_ctx *c, int apply) {
         TRY(launch_k2_bandwidth(c->stream, k));
       }
       c->k2_bw_ahead = false;
-      TRY(launch_k2_phi(c->stream, k));
+      K2Args kp = k;
+      if (apply) {  // the optimiser step rides in the phi kernel (no update_from_phi launch)
+        const UpdateArgs u = update_args(c, 1);
+        kp.apply = 1;
+        kp.optimizer = u.optimizer;
+        kp.lr = u.lr;
+        kp.beta1 = u.beta1;
+        kp.beta2 = u.beta2;
+        kp.eps = u.eps;
+        kp.theta_rw = u.theta;
+        kp.adam_m = u.adam_m;
+        kp.adam_v = u.adam_v;
+        kp.ctr = u.ctr;
+        kp.fused_cnt = u.fused_cnt;
+        kp.fused_tiles = u.fused_tiles;
+      }
+      TRY(launch_k2_phi(c->stream, kp));
     }
-    if (apply) {
-      UpdateArgs u = update_args(c, 1);
-      Prof p(c, DUST_K_UPDATE);
-      update_from_phi_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
-      HIP_TRY(hipGetLastError());
-      c->fused_dirty = false;
-    }
+    if (apply) c->fused_dirty = false;
     return DUST_OK;
   }
   {
