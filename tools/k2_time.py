@@ -1,3 +1,4 @@
+"""cfg2 with the K2 (iid_mp, per-dimension median bandwidth) kernel: us per tick (python tools/k2_time.py [K2 K2shared])."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
@@ -5,7 +6,7 @@ import bench
 from dust_amd import Context
 w = bench.WORKLOAD
 mu, theta = bench.synth(w["N"], w["H"], 1)
-for kern in ("K2", "K2shared"):
+for kern in (sys.argv[1:] or ["K2"]):
     try:
         ctx = Context(model="pendulum", N=w["N"], S=w["S"], M=1, H=w["H"], kernel=kern, lr=w["lr"], alpha=w["alpha"], sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=0, seed=1234)
     except Exception as e:
