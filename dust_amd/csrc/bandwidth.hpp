@@ -36,6 +36,8 @@ struct K2Args {
   int apply, optimizer;
   float lr, beta1, beta2, eps;
   float *theta_rw;      // [N][D] row-major particles (updated in place)
+  float *thetaT_out;    // [D][N] or nullptr: the updated particles, transposed, for the NEXT iteration's bandwidth and phi kernels (a second
+                        // buffer: this launch's other workgroups still read the current transposed copy) - no transpose launch between iterations
   float *adam_m, *adam_v;
   uint32_t *ctr;        // {tick, iter, adam_step}
   unsigned int *fused_cnt;
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
             a.adam_v[o] = v;
           }
           a.theta_rw[o] = th;
+          if (a.thetaT_out) a.thetaT_out[(size_t)(c0 + q) * N + i] = th;
         }
       }
   }

@@ -78,6 +78,8 @@ struct dust_ctx {
   hipStream_t pair_stream;  // stream the next pairwise launch goes to (stream or stream2)
   // particles / prior / controller state
   float *theta, *thetaT, *mu, *muT, *logmix, *mixw;
+  float *thetaT_alt;     // K2: the transposed particles of the next iteration, written by the phi + update launch (ping-pong with thetaT)
+  bool k2_thetaT_fresh;  // thetaT is the transpose of theta as the last K2 update left it (valid from one iteration to the next of ONE loop only)
   bool mu_aliased;  // reference quirk: after update_prior the GMM means alias theta's storage (svgd.py:87, svmpc.py:160-170)
   float *a_mat, *a_seq, *a_mix, *eta;
   // per-iteration products
@@ -332,7 +334,7 @@ static int validate(const dust_config *g) {
 
 static void free_all(dust_ctx *c) {
   // {theta, theta_alt} are always the two particle buffers, whichever is current
-  float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
+  float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
                   &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev};
@@ -506,6 +508,7 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
     HIP_TRY(hipMemsetAsync(*p, 0, ND * sizeof(float), c->stream));
   }
   TRY(dalloc(&c->theta_alt, ND));
+  if (cfg->kernel == DUST_KERNEL_K2_IIDMP || cfg->kernel == DUST_KERNEL_K2_SHARED) TRY(dalloc(&c->thetaT_alt, ND));
   c->theta_home = c->theta;
   float **nn[] = {&c->logmix, &c->mixw, &c->a_mix, &c->eta, &c->logl, &c->logp, &c->lw};
   for (auto p : nn) {
@@ -2021,8 +2024,16 @@ static int launch_stein_update(dust_ctx *c, int apply) {
         kp.ctr = u.ctr;
         kp.fused_cnt = u.fused_cnt;
         kp.fused_tiles = u.fused_tiles;
+        if (c->nloc == c->N && c->k2_fixed_h <= 0.f) {  // (unsharded: every column of the transposed copy is written here)
+          kp.thetaT_out = c->thetaT_alt;  // (allocated with the context for the K2 kernels: nothing may be allocated inside a graph capture)
+        }
       }
       TRY(launch_k2_phi(c->stream, kp));
+      c->k2_thetaT_fresh = false;
+      if (kp.thetaT_out) {
+        std::swap(c->thetaT, c->thetaT_alt);
+        c->k2_thetaT_fresh = true;
+      }
     }
     if (apply) c->fused_dirty = false;
     return DUST_OK;
@@ -2344,8 +2355,12 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     const int n = c->N * c->D;
-    transpose_kernel<<<(n + 255) / 256, 256, 0, c->stream2>>>(c->theta, c->thetaT, c->N, c->D);
-    HIP_TRY(hipGetLastError());
+    if (param_set == 0) c->k2_thetaT_fresh = false;  // (a new loop: whatever happened to theta since the last K2 update is not in thetaT)
+    if (!c->k2_thetaT_fresh) {
+      transpose_kernel<<<(n + 255) / 256, 256, 0, c->stream2>>>(c->theta, c->thetaT, c->N, c->D);
+      HIP_TRY(hipGetLastError());
+    }
+    c->k2_thetaT_fresh = false;
     TRY(launch_k2_bandwidth(c->stream2, k2_args(c)));
     HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
     int s = local_score_device(c, noise_dev, param_set);
