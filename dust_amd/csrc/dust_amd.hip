@@ -1997,15 +1997,15 @@ static K2Args k2_args(dust_ctx *c) {
 }
 
 // Stein pass (+ optimiser step when apply != 0).  K1 / IMQ: tiled partials -> update_kernel; K2: bandwidths + phi, then update.
-static int launch_stein_update(dust_ctx *c, int apply) {
+static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K2: called by step_device - thetaT may be fresh from iteration k - 1 */) {
   const int n = c->nloc * c->D;
   int jsa = 0;  // slices of pA when pass 2 of the fused pair wrote it
   if (c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED) {
     {
       Prof p(c, DUST_K_BANDWIDTH);
       const K2Args k = k2_args(c);
-      if (!c->k2_bw_ahead) {  // (else: the bandwidths of this theta were computed beside the rollouts, step_device)
-        TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
+      if (!c->k2_bw_ahead) {  // (else: the bandwidths of this theta were computed beside the rollouts, step_device's forked form)
+        if (!(in_loop && c->k2_thetaT_fresh)) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));  // (fresh: the last update launch wrote it)
         TRY(launch_k2_bandwidth(c->stream, k));
       }
       c->k2_bw_ahead = false;
@@ -2347,15 +2347,17 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
   bool done = false;
   TRY(launch_iter(c, noise_dev, param_set, &done));
   if (done) return DUST_OK;
-  // K2: the per-dimension median bandwidths read theta only (a few dozen single-workgroup sorts, 60 us on 30 CUs): they run on
-  // the side stream beside the prior + rollout launch and join before the phi kernel
-  static const bool k2_serial = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_K2_SERIAL") != nullptr;  // development switches
+  // K2: the per-dimension median bandwidths read theta only.  Rounds 2-3 ran them on a side stream beside the prior + rollout launch;
+  // the kernel trace of round 4 (profiles/round4_k2_kernel_stats.csv) shows what that bought: both kernels 30-40 % slower
+  // side by side (24 / 24 us against 22 / 17 alone) and 10 us of cross-queue join in front of every phi launch - 55 us per iteration
+  // either way.  One stream, launches back to back, is the default now (DUST_K2_FORK=1: the forked form).
+  static const bool k2_fork = getenv("DUST_K2_FORK") != nullptr && getenv("DUST_NO_FUSE") == nullptr;  // development switch
   const bool k2 = c->cfg.kernel == DUST_KERNEL_K2_IIDMP || c->cfg.kernel == DUST_KERNEL_K2_SHARED;
-  if (k2 && !k2_serial && !c->prof && c->stream2 && c->own_stream) {
+  if (k2 && param_set == 0) c->k2_thetaT_fresh = false;  // (a new loop: whatever happened to theta since the last K2 update is not in thetaT)
+  if (k2 && k2_fork && !c->prof && c->stream2 && c->own_stream) {
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     const int n = c->N * c->D;
-    if (param_set == 0) c->k2_thetaT_fresh = false;  // (a new loop: whatever happened to theta since the last K2 update is not in thetaT)
     if (!c->k2_thetaT_fresh) {
       transpose_kernel<<<(n + 255) / 256, 256, 0, c->stream2>>>(c->theta, c->thetaT, c->N, c->D);
       HIP_TRY(hipGetLastError());
@@ -2367,10 +2369,10 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // (join even on failure: the capture, if any, must see the side stream return)
     TRY(s);
     c->k2_bw_ahead = true;
-    return launch_stein_update(c, 1);
+    return launch_stein_update(c, 1, true);
   }
   TRY(local_score_device(c, noise_dev, param_set));
-  TRY(launch_stein_update(c, 1));
+  TRY(launch_stein_update(c, 1, true));
   return DUST_OK;
 }
 
