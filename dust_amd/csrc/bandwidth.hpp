@@ -161,9 +161,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
       const int lane = tid & 63;
       unsigned *slot = redc + (round % 3) * 8, *other = redc + ((round + 1) % 3) * 8;
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt[c] += __shfl_xor(cnt[c], o, 64);
+      for (int c = 0; c < NC; ++c) cnt[c] = (unsigned)wave_sum((float)cnt[c]);  // (per-lane counts < 2^10: the sums are exact in fp32; DPP, not 6 LDS-crossbar shuffles)
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) atomicAdd(&slot[c], cnt[c]);
