@@ -61,7 +61,7 @@ enum { K2_NC = 1 };  // candidate thresholds per bisection round (measured at N 
 // one workgroup per independent scalar dimension c
 __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args a, int npow2) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [npow2]
-  __shared__ unsigned redc[16 * 8];
+  __shared__ unsigned redc[16 * 8];  // [3][8] rotating count slots, [24] the gathered answer
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
   // bitonic sort, one element per lane (npow2 <= 1024 = blockDim): partners inside a wave (j < 64) are exchanged with a lane
   // shuffle - no barrier - and only the 10 stages with j >= 64 go through LDS (55 barrier-separated LDS passes before: ~30 of 76 us)
@@ -96,6 +96,10 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   const float xi = has ? xs[tid] : 0.f;
   int bl = tid, br = N - 1;
   int round = 0;
+  // pair counts (j > i) at the ends of the bracket: Clo = #{d2 <= float(lo - 1)} (0 below the smallest float), Chi = #{d2 <= float(hi)}; the
+  // answer is the (Wc - Clo)-th smallest of the Chi - Clo pair distances in between (Wc: the rank in pairs - count(v) = N + 2 C(v))
+  const unsigned Wc = (unsigned)((want - (unsigned long long)N + 1ull) / 2ull);
+  unsigned Clo = 0u, Chi = (unsigned)(((unsigned long long)N * (N - 1)) / 2ull);
   // Warm start (round 3): between two SVGD iterations the particles move by lr * phi, so the median moves by a fraction of a
   // percent.  a.h[c] still holds the previous bandwidth: two probes at v_prev (1 -+ 2^-7) - if they bracket the rank, the bisection
   // starts from 2^17 bit patterns instead of 2^31 (17 rounds instead of 31; the median moves 0.2-0.8 % per iteration at cfg2: +-2^-9 misses too often, +-2^-5 costs two more rounds); if
@@ -131,66 +135,84 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
         hi = phi_;
         bl = bb[0];
         br = bb[1];
+        Clo = (unsigned)c_lo;
+        Chi = (unsigned)c_hi;
       }
     }
   }
   if (tid < 24) redc[tid] = 0u;
+  __shared__ float cand[64];
+  __shared__ unsigned ncand;
+  if (tid == 0) ncand = 0u;
   wg_sync();
+  // Narrowing (round 4).  Every probe keeps the invariant C(lo - 1) < Wc <= C(hi), so ANY threshold inside the bracket is a legal probe:
+  // while the pair count is locally linear in the threshold (it is, to ~ 1 / sqrt(K) over the K candidates of a warm-started bracket) the
+  // interpolated threshold leaves a few dozen candidates after one or two rounds instead of halving them 17 times; a probe that does
+  // not at least halve the candidates is followed by a plain bit-pattern midpoint (termination as before).  With <= 64 candidates
+  // left they are gathered and sorted by one wave: the (Wc - Clo)-th smallest IS the order statistic - no more rounds.
+  bool interp = true;
   while (lo < hi) {
-    unsigned mid[NC];
-    int b[NC];
-    unsigned cnt[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      mid[c] = lo + (unsigned)(((unsigned long long)(hi - lo) * (unsigned)(c + 1)) / (unsigned)(NC + 1));
-      const float v = __uint_as_float(mid[c]);
-      int l = (c == 0) ? bl : b[c - 1], r = br;  // candidates ascend: b of the previous one is a lower bound
-      if (has)
-        while (l < r) {
-          const int m = (l + r + 1) >> 1;
-          const float dlt = xs[m] - xi;
-          if (dlt * dlt <= v) l = m;
-          else r = m - 1;
-        }
-      b[c] = l;
-      cnt[c] = has ? (unsigned)(l - tid) : 0u;
+    const unsigned K = Chi - Clo;
+    if (K <= 64u) break;
+    unsigned mid = lo + ((hi - lo) >> 1);
+    if (interp) {
+      const float vlo = lo ? __uint_as_float(lo - 1u) : 0.f, vhi = __uint_as_float(hi);
+      const float fr = ((float)(Wc - Clo) - 0.5f) / (float)K;
+      const unsigned mi = __float_as_uint(fmaf(vhi - vlo, fr, vlo));
+      mid = min(max(mi, lo), hi - 1u);
     }
-    // block sums of the NC counters (2 sum + N <= 2 N^2 < 2^32): wave sums, one LDS atomic per wave into the round's slot, ONE barrier
-    // (three slots in rotation: the one re-armed here was last READ before the previous round's barrier, which every wave has passed)
+    const float v = __uint_as_float(mid);
+    int l = bl, r = br;
+    if (has)
+      while (l < r) {
+        const int m = (l + r + 1) >> 1;
+        const float dlt = xs[m] - xi;
+        if (dlt * dlt <= v) l = m;
+        else r = m - 1;
+      }
+    unsigned cnt = has ? (unsigned)(l - tid) : 0u;
     {
       const int lane = tid & 63;
       unsigned *slot = redc + (round % 3) * 8, *other = redc + ((round + 1) % 3) * 8;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) cnt[c] = (unsigned)wave_sum((float)cnt[c]);  // (per-lane counts < 2^10: the sums are exact in fp32; DPP, not 6 LDS-crossbar shuffles)
-      if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) atomicAdd(&slot[c], cnt[c]);
-      }
-      if (tid == 64) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) other[c] = 0u;
-      }
+      cnt = (unsigned)wave_sum((float)cnt);  // (per-lane counts < 2^10: exact in fp32; DPP, not 6 LDS-crossbar shuffles)
+      if (lane == 0) atomicAdd(&slot[0], cnt);
+      if (tid == 64) other[0] = 0u;
       wg_sync();
-#pragma unroll
-      for (int c = 0; c < NC; ++c) cnt[c] = slot[c];
+      cnt = slot[0];
       ++round;
     }
-    // counts are monotone in the threshold
-    unsigned nlo = lo, nhi = hi;
-    int nbl = bl, nbr = br;
-#pragma unroll
-    for (int c = NC - 1; c >= 0; --c) {
-      const bool below = 2ull * cnt[c] + (unsigned long long)N < want;
-      nhi = below ? nhi : mid[c];  // smallest candidate that reaches the rank
-      nbr = below ? nbr : b[c];
-      const bool raise = below && nlo <= mid[c];
-      nlo = raise ? mid[c] + 1u : nlo;  // largest candidate below the rank, + 1
-      nbl = raise ? b[c] : nbl;
+    if (cnt >= Wc) {  // the answer is <= mid
+      interp = (cnt - Clo) * 2u <= K;
+      hi = mid;
+      Chi = cnt;
+      br = l;
+    } else {
+      interp = (Chi - cnt) * 2u <= K;
+      lo = mid + 1u;
+      Clo = cnt;
+      bl = l;
     }
-    lo = nlo;
-    hi = nhi < nlo ? nlo : nhi;
-    bl = nbl;
-    br = nbr;
+  }
+  if (lo < hi) {  // <= 64 candidates: lane i's are the pairs (i, j), bl < j <= br
+    if (has)
+      for (int j = bl + 1; j <= br; ++j) {
+        const float dlt = xs[j] - xi;
+        cand[atomicAdd(&ncand, 1u)] = dlt * dlt;
+      }
+    wg_sync();
+    if (tid < 64) {
+      float x = tid < (int)ncand ? cand[tid] : INFINITY;
+      for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const float o = __shfl_xor(x, j, 64);
+          const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+          x = (lower == up) ? fminf(x, o) : fmaxf(x, o);
+        }
+      const float ans = __shfl(x, (int)(Wc - Clo) - 1, 64);
+      if (tid == 0) redc[24] = __float_as_uint(ans);
+    }
+    wg_sync();
+    lo = redc[24];
   }
   if (tid == 0) {
     float h = __uint_as_float(lo);
