@@ -65,22 +65,38 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
   // bitonic sort, one element per lane (npow2 <= 1024 = blockDim): partners inside a wave (j < 64) are exchanged with a lane
   // shuffle - no barrier - and only the 10 stages with j >= 64 go through LDS (55 barrier-separated LDS passes before: ~30 of 76 us)
+  // (round 4: the partner at distance 1 / 2 / 8 comes through one DPP move, at distance 4 through two - 34 of the 45 in-wave stages - and
+  //  the LDS stages alternate between two buffers, so one barrier per stage suffices: a wave that passes the barrier of stage s has seen
+  //  every wave finish its reads of stage s - 1, whose buffer stage s + 1 writes.  8.5 -> 5 us of the kernel's 20.)
   {
     float v = tid < N ? a.thetaT[(size_t)c * N + tid] : INFINITY;
-    for (int k = 2; k <= npow2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        float other;
-        if (j < 64) {
-          other = __shfl_xor(v, j, 64);
-        } else {
-          if (tid < npow2) xs[tid] = v;
-          wg_sync();
-          other = tid < npow2 ? xs[tid ^ j] : v;
-          wg_sync();  // (everyone has read before the next stage overwrites)
-        }
-        const bool up = (tid & k) == 0, lower = (tid & j) == 0;
-        v = (lower == up) ? fminf(v, other) : fmaxf(v, other);
+    float *const xs2 = xs + npow2;  // (the host allocates 2 npow2 floats)
+    int pp = 0;
+    auto cmpx = [&](const int k, const int j, const float other) {
+      const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+      v = (lower == up) ? fminf(v, other) : fmaxf(v, other);
+    };
+    for (int k = 2; k <= npow2; k <<= 1) {
+      for (int j = k >> 1; j >= 64; j >>= 1) {  // LDS stages
+        float *const buf = pp ? xs2 : xs;
+        pp ^= 1;
+        if (tid < npow2) buf[tid] = v;
+        wg_sync();
+        cmpx(k, j, tid < npow2 ? buf[tid ^ j] : v);
       }
+      // in-wave stages: j is a compile-time constant in each statement (scalar branches on k only)
+      if (k > 32) cmpx(k, 32, __shfl_xor(v, 32, 64));
+      if (k > 16) cmpx(k, 16, __shfl_xor(v, 16, 64));
+      if (k > 8) cmpx(k, 8, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false)));
+      if (k > 4) {
+        int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104 /* row_shl:4 */, 0xf, 0x5, false);  // banks 0 / 2: the lane 4 up
+        o = __builtin_amdgcn_update_dpp(o, __builtin_bit_cast(int, v), 0x114 /* row_shr:4 */, 0xf, 0xa, false);      // banks 1 / 3: the lane 4 down
+        cmpx(k, 4, __builtin_bit_cast(float, o));
+      }
+      if (k > 2) cmpx(k, 2, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true)));
+      cmpx(k, 1, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true)));
+    }
+    wg_sync();  // (the last LDS stage's reads of xs, if it was the buffer in use, are done)
     if (tid < npow2) xs[tid] = v;
     wg_sync();
   }
@@ -125,10 +141,17 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
         bb[q] = l;
         cc[q] = has ? (unsigned)(l - tid) : 0u;
       }
-      unsigned long long packed = ((unsigned long long)cc[1] << 32) | cc[0];  // (each total < 2^21: no carry between the halves)
-      __shared__ unsigned long long red2[16];
-      packed = block_sum_u64(packed, red2);
-      const unsigned long long c_lo = packed & 0xffffffffull, c_hi = packed >> 32;
+      // block sums of the two counts: wave sums by DPP (per-lane counts < 2^10: exact in fp32), one LDS atomic per wave and count
+      __shared__ unsigned red2[2];
+      if (tid < 2) red2[tid] = 0u;
+      wg_sync();
+      const unsigned w0 = (unsigned)wave_sum((float)cc[0]), w1 = (unsigned)wave_sum((float)cc[1]);
+      if ((tid & 63) == 0) {
+        atomicAdd(&red2[0], w0);
+        atomicAdd(&red2[1], w1);
+      }
+      wg_sync();
+      const unsigned long long c_lo = red2[0], c_hi = red2[1];
       const bool lo_below = 2ull * c_lo + (unsigned long long)N < want, hi_reaches = !(2ull * c_hi + (unsigned long long)N < want);
       if (lo_below && hi_reaches && plo < phi_ && phi_ <= hi) {
         lo = plo + 1u;
@@ -434,7 +457,7 @@ static inline int launch_k2_bandwidth(hipStream_t stream, const K2Args &a) {
   } else {
     int np = 1;
     while (np < a.N) np <<= 1;
-    if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
+    if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)2 * np * sizeof(float), stream>>>(a, np);  // (two buffers: the sort's LDS stages alternate)
     else k2_bandwidth_sorted_big_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
   }
   return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
