@@ -153,13 +153,64 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
       wg_sync();
       const unsigned long long c_lo = red2[0], c_hi = red2[1];
       const bool lo_below = 2ull * c_lo + (unsigned long long)N < want, hi_reaches = !(2ull * c_hi + (unsigned long long)N < want);
-      if (lo_below && hi_reaches && plo < phi_ && phi_ <= hi) {
-        lo = plo + 1u;
-        hi = phi_;
-        bl = bb[0];
-        br = bb[1];
-        Clo = (unsigned)c_lo;
-        Chi = (unsigned)c_hi;
+      if (plo < phi_ && phi_ <= hi) {
+        // a probe that misses still halves the problem: it becomes one end of the bracket, and up to two wider probes on the open side
+        // (v_prev (1 -+ 2^-4), (1 -+ 2^-2): the first iteration of a tick follows the roll, which moves the median by a few per cent)
+        // close it - a round each instead of the ~ 12 that a bracket ending at 0 or at the span costs
+        if (lo_below) {
+          lo = plo + 1u;
+          bl = bb[0];
+          Clo = (unsigned)c_lo;
+        }
+        if (hi_reaches) {
+          hi = phi_;
+          br = bb[1];
+          Chi = (unsigned)c_hi;
+        } else {  // the answer lies above both probes
+          lo = phi_ + 1u;
+          bl = bb[1];
+          Clo = (unsigned)c_hi;
+        }
+        if (!lo_below) {  // ... or below both
+          hi = plo;
+          br = bb[0];
+          Chi = (unsigned)c_lo;
+        }
+        const bool open_hi = !hi_reaches, open_lo = !lo_below;
+        if (open_hi || open_lo) {
+#pragma unroll 1
+          for (int e = 4; e >= 2; e -= 2) {
+            const float wv = open_hi ? vp * (1.0f + 1.0f / (float)(1 << e)) : vp * (1.0f - 1.0f / (float)(1 << e));
+            const unsigned pv = __float_as_uint(wv);
+            if (!(pv >= lo && pv < hi)) break;  // (wave-uniform)
+            int l = bl, r = br;
+            if (has)
+              while (l < r) {
+                const int m = (l + r + 1) >> 1;
+                const float dlt = xs[m] - xi;
+                if (dlt * dlt <= wv) l = m;
+                else r = m - 1;
+              }
+            if (tid == 0) red2[0] = 0u;
+            wg_sync();
+            const unsigned ws = (unsigned)wave_sum(has ? (float)(l - tid) : 0.f);
+            if ((tid & 63) == 0) atomicAdd(&red2[0], ws);
+            wg_sync();
+            const unsigned cw = red2[0];
+            wg_sync();  // (red2 is re-armed by the next probe)
+            if (cw >= Wc) {
+              hi = pv;
+              br = l;
+              Chi = cw;
+              if (open_hi) break;  // closed
+            } else {
+              lo = pv + 1u;
+              bl = l;
+              Clo = cw;
+              if (open_lo) break;  // closed
+            }
+          }
+        }
       }
     }
   }
