@@ -490,6 +490,82 @@ __global__ __launch_bounds__(256) void k2_phi_kernel(const K2Args a) {
   }
 }
 
+// The same for one dimension per kernel group (indep_controls = True: every demo) with TWO queries per lane (i and i + 64 of a 128-query
+// tile) in packed fp32: per key one packed subtract, two packed multiplies, two exponentials and two packed FMAs serve both queries
+// (19 instead of 25 issue cycles per pair, tools/valu_rate_probe.hip) and the broadcast reads of the key and its score are shared.
+// Element for element the operations of k2_phi_kernel<1>, in its order: the same bits.
+__global__ __launch_bounds__(256) void k2_phi2_kernel(const K2Args a) {
+  __shared__ float xcol[K2_JT], scol[K2_JT];
+  __shared__ float part[4][128][2];
+  const int N = a.N, D = a.D;
+  const int g = blockIdx.y;
+  const int ii = threadIdx.x & 63, js = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ila = blockIdx.x * 128 + ii, ilb = ila + 64;
+  const bool ona = ila < a.n_local, onb = ilb < a.n_local;
+  const int ia = a.i0 + (ona ? ila : 0), ib = a.i0 + (onb ? ilb : 0);
+  const float h = a.h[g];
+  const float ce = -1.44269504088896340736f / h;
+  const v2f ce2 = {ce, ce};
+  const v2f xi = {a.thetaT[(size_t)g * N + ia], a.thetaT[(size_t)g * N + ib]};
+  v2f g1 = {0.f, 0.f}, g2 = {0.f, 0.f};
+  for (int jb = 0; jb < N; jb += K2_JT) {
+    const int jn = min(K2_JT, N - jb);
+    wg_sync();
+    for (int j = threadIdx.x; j < jn; j += 256) {
+      xcol[j] = a.thetaT[(size_t)g * N + jb + j];
+      scol[j] = a.score[(size_t)(jb + j) * D + g];
+    }
+    wg_sync();
+    const int per = (jn + 3) >> 2, j0 = js * per, j1 = min(jn, j0 + per);
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      const float xc = xcol[j], sc = scol[j];
+      const v2f df = xi - v2f{xc, xc};
+      const v2f arg = (df * df) * ce2;
+      const v2f k = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+      g1 = __builtin_elementwise_fma(k, v2f{sc, sc}, g1);
+      g2 = __builtin_elementwise_fma(k, df, g2);
+    }
+  }
+  part[js][ii][0] = g1.x;
+  part[js][ii][1] = g2.x;
+  part[js][ii + 64][0] = g1.y;
+  part[js][ii + 64][1] = g2.y;
+  wg_sync();
+  if (threadIdx.x < 128) {
+    const int q = threadIdx.x, il = blockIdx.x * 128 + q;
+    if (il < a.n_local) {
+      const int i = a.i0 + il;
+      float s1 = part[0][q][0], s2 = part[0][q][1];
+      for (int r = 1; r < 4; ++r) {
+        s1 += part[r][q][0];
+        s2 += part[r][q][1];
+      }
+      const size_t o = (size_t)i * D + g;
+      const float phi = s1 / (float)N + ((s2 * 2.0f) / h) / (float)N;
+      a.phi[o] = phi;
+      if (a.apply) {  // (update_from_phi_kernel's element)
+        float th = a.theta_rw[o];
+        const float gr = -phi;
+        if (a.optimizer == DUST_OPT_SGD) {
+          th = fmaf(-a.lr, gr, th);
+        } else {
+          float m = a.adam_m[o], v = a.adam_v[o];
+          th = adam_step(th, gr, m, v, a.lr, a.beta1, a.beta2, a.eps, (float)a.ctr[2]);
+          a.adam_m[o] = m;
+          a.adam_v[o] = v;
+        }
+        a.theta_rw[o] = th;
+        if (a.thetaT_out) a.thetaT_out[(size_t)g * N + i] = th;
+      }
+    }
+  }
+  if (a.apply && blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int t = threadIdx.x; t < a.fused_tiles; t += 256) a.fused_cnt[t * 32] = 0u;
+    if (threadIdx.x == 0) a.ctr[1] += 1u;
+  }
+}
+
 __global__ void k2_bandwidth_fixed_kernel(float *h, int G, float v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < G) h[i] = v;
@@ -517,8 +593,13 @@ static inline int launch_k2_phi(hipStream_t stream, const K2Args &a) {
   const int G = a.shared ? a.H : a.D;
   if (a.da > 2) return DUST_ERR_UNSUPPORTED;
   dim3 grid((a.n_local + 63) / 64, G);
-  if (a.shared && a.da == 2) k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
-  else k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
+  if (a.shared && a.da == 2) {
+    k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
+  } else {
+    static const bool one_q = getenv("DUST_K2_PHI1") != nullptr;  // development switch: one query per lane (k2_phi_kernel<1>)
+    if (one_q) k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
+    else k2_phi2_kernel<<<dim3((a.n_local + 127) / 128, G), 256, 0, stream>>>(a);
+  }
   return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
 }
 static inline int launch_k2(hipStream_t stream, const K2Args &a) {
