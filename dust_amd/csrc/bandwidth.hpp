@@ -56,7 +56,8 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   return r;
 }
 
-enum { K2_NC = 1 };  // candidate thresholds per bisection round (measured at N = 1024: 1 -> 43 us, 2 -> 50, 3 -> 54, 7 -> 77)
+// (several candidate thresholds per bisection round were measured at N = 1024 and lost: 1 -> 43 us, 2 -> 50, 3 -> 54, 7 -> 77; again in round 4
+//  behind the warm start: 282 / 291 / 297 us per cfg2 tick)
 
 // one workgroup per independent scalar dimension c
 __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args a, int npow2) {
@@ -103,11 +104,10 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
   const float span = xs[N - 1] - xs[0];
   unsigned lo = 0u, hi = __float_as_uint(span * span);
-  // Bisection with NC candidate thresholds per round (their counts share one block reduction).  b_v(i) = largest j >= i with
+  // Bisection on the bit pattern, one threshold per round.  b_v(i) = largest j >= i with
   // (x_j - x_i)^2 <= v is monotone in v, so every lane keeps a bracket [bl, br] of b for the current [lo, hi] and only
   // searches inside it: the per-lane searches shrink from log2 N steps to 1-2 as the bisection narrows.
   // (blockDim >= N is required: one particle per lane - the host launches 1024 lanes and N <= 1024 takes this kernel.)
-  constexpr int NC = K2_NC;
   const bool has = tid < N;
   const float xi = has ? xs[tid] : 0.f;
   int bl = tid, br = N - 1;

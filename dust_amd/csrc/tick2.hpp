@@ -945,7 +945,6 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       }
       while (t2_lds_ld(sig + 1) < (unsigned int)(k + 1)) __builtin_amdgcn_s_sleep(1);
       T2_TL(8, 16 * k + 2);
-      float red[4];
       float rw[2];
       DUST_PRIO(T2_PRIO_PPASS);
       if (N != f->steps * 64) t2_prior_pass_w<MODE, true>(f, k, th, ksl, lml, pw, lane, lm_ref, rw);
