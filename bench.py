@@ -285,6 +285,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import __graft_entry__ as entry
 
+    # Exactly ONE line on stdout: the JSON.  Libraries in the process write to the C-level stdout as well (RCCL prints its version banner
+    # there when NCCL_DEBUG asks for it - it landed BEHIND the JSON line in the world-1 runs of this round): file descriptor 1 is pointed
+    # at stderr for the run, and the JSON line goes out through a duplicate of the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     if rank == 0:  # (before anything initialises the GPU in this process: a stale library would compile in a child process)
         entry.build()
     import torch
@@ -494,7 +501,8 @@ def main():
             "cpu_baseline": cpu,
         }
         out.update(extra)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
