@@ -56,3 +56,9 @@ python tools/forms_summary.py $O/cf_stats $O/configs_pmc.json $O/configs_forms.j
 find $O/st_stats $O/cf_stats -name "*kernel_trace*" -delete
 rm -rf $O/st_pmc $O/cf_pmc
 cat $O/states_forms.json | head -60
+# --- K2 (iid_mp) tick: time and kernels
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k2_stats -o b -- python3 $R/tools/k2_time.py > $O/k2_time_under_rocprof.txt 2>&1
+cd $R
+timeout 200 python tools/k2_time.py > $O/k2_time.txt 2>&1
+find $O/k2_stats -name "*kernel_trace*" -delete
