@@ -10,7 +10,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DUST_AMD_LIB", os.path.join(_HERE, "libdust_amd.so"))  # override: diagnostic builds only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_STATE = range(6)
 MODEL_PENDULUM, MODEL_PARTICLE, MODEL_SKID_STEER = 0, 1, 2
 COST_PENDULUM_QUADCOS, COST_PARTICLE_DEFAULT, COST_QUADRATIC = 0, 1, 2
@@ -20,6 +20,7 @@ OPT_SGD, OPT_ADAM = 0, 1
 ROLL_REPEAT, ROLL_MEAN, ROLL_RESAMPLE = 0, 1, 2
 STEP_ARGMAX, STEP_AVERAGE, STEP_EXTERNAL = 0, 1, 2
 PARAM_PYFLOAT, PARAM_SAMPLED, PARAM_TENSOR0D = 0, 1, 2
+CONTROL_ACCELERATION, CONTROL_VELOCITY = 0, 1
 PTR_DEVICE, STORE_STATES, EPS_AROUND_A_MAT, EPS_F16, STORE_F16 = 1, 2, 4, 8, 16
 K_ROLLOUT, K_PRIOR_SCORE, K_STEIN, K_UPDATE, K_FORWARD, K_BANDWIDTH, K_MPF, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 
@@ -63,6 +64,7 @@ class Config(C.Structure):
         ("cell_size", C.c_double),
         ("target", C.c_float * 4), ("w_state", C.c_float * 4), ("w_term", C.c_float * 4), ("w_ctrl", C.c_float * 2),
         ("w_obs", C.c_float),
+        ("control_type", C.c_int32), ("ctrl_noise", C.c_int32), ("dyn_std", C.c_float * 2),
     ]
 
 
@@ -92,6 +94,8 @@ SYMBOLS = {
     "dust_set_model_param": (C.c_int, [VP, C.c_char_p, C.c_double, C.c_int]),
     "dust_set_param_weights": (C.c_int, [VP, FP]),
     "dust_set_grid": (C.c_int, [VP, FP, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "dust_set_ctrl_noise": (C.c_int, [VP, FP, C.c_int]),
+    "dust_mpf_set_ctrl_noise": (C.c_int, [VP, FP, C.c_int]),
     "dust_set_theta": (C.c_int, [VP, FP]),
     "dust_get_theta": (C.c_int, [VP, FP]),
     "dust_set_prior": (C.c_int, [VP, FP, FP]),

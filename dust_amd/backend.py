@@ -43,7 +43,8 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
                 shard_offset=0, shard_size=0, dt=None, g=9.8, mass=1.0, length=1.0, mass_0dim=False, w_cos=50.0, w_vel=1.0,
                 max_speed=5.0, max_accel=10.0, can_crash=True, with_obstacle=True, cell_size=0.1,
                 target=(9.0, 9.0, 0.0, 0.0), w_state=(0.5, 0.5, 0.25, 0.25), w_term=(1e3, 1e3, 0.1, 0.1), w_ctrl=(0.2, 0.2),
-                w_obs=1e6, min_a=None, max_a=None, adam=(0.9, 0.999, 1e-8), sampling=None, **_ignored):
+                w_obs=1e6, min_a=None, max_a=None, adam=(0.9, 0.999, 1e-8), sampling=None, control_type="acceleration",
+                deterministic=True, noise_std=(0.0, 0.0), **_ignored):
     c = L.Config()
     c.abi_version = L.ABI_VERSION
     c.device = device
@@ -54,7 +55,15 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     c.model = L.MODEL_PENDULUM if pend else (L.MODEL_SKID_STEER if skid else L.MODEL_PARTICLE)
     c.cost = L.COST_PENDULUM_QUADCOS if pend else (L.COST_QUADRATIC if skid else L.COST_PARTICLE_DEFAULT)
     c.n_policies, c.n_samples, c.n_params, c.horizon = N, S, M, H
-    c.dim_a, c.dim_s = (1, 2) if pend else ((2, 5) if skid else (2, 4))
+    if control_type not in ("acceleration", "velocity"):
+        raise IOError('control_type "{}" not recognized'.format(control_type))  # particle.py:59-60
+    vel = control_type == "velocity" and not pend and not skid
+    c.dim_a, c.dim_s = (1, 2) if pend else ((2, 5) if skid else ((2, 2) if vel else (2, 4)))
+    if not pend and not skid:  # Particle(control_type=, deterministic=, noise_std=) particle.py:13-31
+        c.control_type = L.CONTROL_VELOCITY if vel else L.CONTROL_ACCELERATION
+        c.ctrl_noise = int(not deterministic)
+        ns = np.broadcast_to(np.asarray(noise_std, np.float32).reshape(-1), (2,))
+        c.dyn_std[0], c.dyn_std[1] = float(ns[0]), float(ns[1])
     up = list(uncertain_params) if uncertain_params else []
     use_params = bool(up) if sampling is None else bool(sampling)
     c.dim_p = len(up) if use_params else 0
@@ -97,9 +106,10 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     c.max_speed, c.max_accel = max_speed, max_accel
     c.can_crash, c.with_obstacle = int(can_crash), int(with_obstacle and not pend and not skid)
     c.cell_size = cell_size
-    c.target[:] = list(target)
-    c.w_state[:] = list(w_state)
-    c.w_term[:] = list(w_term)
+    pad4 = lambda v: (list(np.asarray(v, np.float32).reshape(-1)) + [0.0] * 4)[:4]  # (velocity control: two-entry target / weights)
+    c.target[:] = pad4(target)
+    c.w_state[:] = pad4(w_state)
+    c.w_term[:] = pad4(w_term)
     c.w_ctrl[:] = list(w_ctrl)
     c.w_obs = w_obs
     return c
@@ -219,6 +229,16 @@ class Context:
         g.w_term[:] = [float(v) for v in w_quad_term]
         g.w_ctrl[:] = [float(v) for v in w_quad_ctrl]
         L.check(L.load().dust_set_skid_steer(self._h, C.byref(g)))
+
+    def set_ctrl_noise(self, z):
+        """Recorded control-channel noise for the next rollouts of a Particle(deterministic=False) context (particle.py:145-148):
+        z [n_sets][H][M*S*N][da] standard-normal draws in the reference's own order (one randn_like per model.step call); None: back
+        to the device Philox stream."""
+        if z is None:
+            L.check(L.load().dust_set_ctrl_noise(self._h, None, 0))
+            return
+        z = _f(z, (-1, self.H, self.M * self.S * self.N, self.da))
+        L.check(L.load().dust_set_ctrl_noise(self._h, _p(z), int(z.shape[0])))
 
     def set_param_weights(self, w):
         """Unscented-transform weights of the n_params dynamics samples (None: plain mean)."""
@@ -501,6 +521,15 @@ class MpfContext:
     def condition(self, action, new_obs):
         a = None if action is None else _f(action).reshape(-1)
         L.check(L.load().dust_mpf_condition(self._h, _p(a), _p(_f(new_obs, (self.ds,)))))
+
+    def set_ctrl_noise(self, z):
+        """Recorded control-noise draws [n][da] for the next phi / optimize steps (one per SVGD step; likelihoods.py:30-46 ->
+        particle.py:145-148); None: the library's own generator."""
+        if z is None:
+            L.check(L.load().dust_mpf_set_ctrl_noise(self._h, None, 0))
+            return
+        z = _f(z, (-1, self.da))
+        L.check(L.load().dust_mpf_set_ctrl_noise(self._h, _p(z), int(z.shape[0])))
 
     def phi(self, bw):
         out = np.empty((self.Mp, self.P), np.float32)

@@ -67,6 +67,12 @@ class MultiDISCO:
         self._svmpc_cfg = {}
         self._device = kwargs.get("device", 0)
         self._seed = kwargs.get("seed", 0)
+        # Reproducible runs: an object whose next_eps() / next_params() / next_ctrl_noise() return the next recorded draw (or None:
+        # draw as usual) - policy noise [S,N,H,da] per SVGD step, dynamics samples [M,P] per sampling call, control-channel noise
+        # [H, M*S*N, da] per rollout launch (Particle(deterministic=False), particle.py:145-148).  None (default): every draw is
+        # fresh - policy / control noise from the device Philox stream, dynamics samples from params_dist.  The parity tests replay
+        # the reference's own recorded draws through it (tests/helpers.py RecordedDraws).
+        self.draw_source = None
 
     # ------------------------------------------------------------------ context management
     def _config(self, model, params_dist):
@@ -100,7 +106,10 @@ class MultiDISCO:
                     cfg["mass_0dim"] = True
         if model.family == "particle":
             cfg.update(max_speed=float(model._max_speed), max_accel=float(model._max_acc), can_crash=bool(model.can_crash),
-                       with_obstacle=bool(model.with_obstacle), cell_size=float(model.map_cell_size or 0.1))
+                       with_obstacle=bool(model.with_obstacle), cell_size=float(model.map_cell_size or 0.1),
+                       # particle.py:13-31, 145-153: control-channel noise and the control type reach the device rollouts
+                       control_type=str(model.control_type), deterministic=bool(model.deterministic),
+                       noise_std=tuple(float(v) for v in torch.as_tensor(model.dyn_std, dtype=torch.float).reshape(-1).expand(2)))
         cfg.update(recognise(model, self.inst_cost_fn, self.term_cost_fn))
         cfg.update(self._svmpc_cfg)
         return cfg
@@ -184,15 +193,25 @@ class MultiDISCO:
         if self._tf is not None:
             sp, lp = self._sigma_params(params_dist)
             return np.repeat(sp, n_sets, axis=0), lp
-        from ..utils import replay
-
         ps, lps = [], []
         for _ in range(n_sets):
-            rec = replay.next_params()  # recorded dynamics samples of a reference run (parity tests), else a fresh draw
+            rec = self._recorded("params")  # recorded dynamics samples (draw_source), else a fresh draw
             p = params_dist.sample([self.n_params]) if rec is None else torch.as_tensor(rec, dtype=torch.float)
             lps.append(params_dist.log_prob(p))
             ps.append(p.reshape(self.n_params, -1))
         return torch.stack(ps).numpy(), lps[-1]
+
+    def _recorded(self, kind):
+        src = self.draw_source
+        return None if src is None else getattr(src, "next_" + kind)()
+
+    def _feed_ctrl_noise(self, ctx, n_sets=1):
+        """Recorded control-channel noise for the next n_sets rollout launches, when the draw source has it."""
+        if self.draw_source is None or not ctx.cfg.ctrl_noise:
+            return
+        rec = [self._recorded("ctrl_noise") for _ in range(n_sets)]
+        if rec and rec[0] is not None:
+            ctx.set_ctrl_noise(np.stack([np.asarray(r, np.float32) for r in rec]))
 
     def forward(self, state, model, params_dist=None, ext_actions=None, debug=False):
         ctx = self._ensure_ctx(model, params_dist)
@@ -200,6 +219,7 @@ class MultiDISCO:
         params, params_log_p = self._sample_params(params_dist)
         acts = None if ext_actions is None else torch.as_tensor(ext_actions, dtype=torch.float).numpy()
         want = bool(self.return_rollouts)
+        self._feed_ctrl_noise(ctx)
         costs, states, actions, omega = ctx.disco_forward(state.numpy(), acts, None if params is None else params[0],
                                                           want_states=want, want_actions=want)
         if not want:

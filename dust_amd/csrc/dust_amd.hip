@@ -9,6 +9,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 #include <atomic>
@@ -25,6 +26,7 @@
 #include "pairwise_fused.hpp"
 #include "pairwise_logp_mfma.hpp"
 #include "skid.hpp"
+#include "particle_general.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -91,6 +93,9 @@ struct dust_ctx {
   float *pS;                 // Gram x score partials of the one-launch iteration (pA still holds the prior's while its Stein tiles run)
   size_t pS_cap;
   float *mw_dev;             // [M] unscented-transform weights of the dynamics samples (nullptr: mean)
+  float *cz_dev;             // recorded control-noise draws [cz_sets][H][M*S*N][da] (dust_set_ctrl_noise), consumed one set per rollout launch
+  size_t cz_cap;
+  int cz_sets, cz_next;
   float *xpad;               // [N][DPB] zero-padded query rows of the large-N pairwise kernel
   size_t xpad_cap;
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
@@ -306,8 +311,11 @@ static int validate(const dust_config *g) {
     if (g->dim_a != 1 || g->dim_s != 2) return fail(DUST_ERR_INVALID, "PendulumModel has dim_a=1, dim_s=2");
     if (g->cost != DUST_COST_PENDULUM_QUADCOS) return fail(DUST_ERR_UNSUPPORTED, "pendulum model needs the quad-cos cost family");
   } else if (g->model == DUST_MODEL_PARTICLE) {
-    if (g->dim_a != 2 || g->dim_s != 4) return fail(DUST_ERR_INVALID, "Particle (acceleration control) has dim_a=2, dim_s=4");
+    if (g->control_type != DUST_CONTROL_ACCELERATION && g->control_type != DUST_CONTROL_VELOCITY) return fail(DUST_ERR_INVALID, "bad control_type %d", g->control_type);
+    const int want_ds = g->control_type == DUST_CONTROL_VELOCITY ? 2 : 4;  // particle.py:41-60
+    if (g->dim_a != 2 || g->dim_s != want_ds) return fail(DUST_ERR_INVALID, "Particle has dim_a=2 and dim_s=4 (acceleration control) / 2 (velocity control)");
     if (g->cost != DUST_COST_PARTICLE_DEFAULT) return fail(DUST_ERR_UNSUPPORTED, "particle model needs Particle.default_*_cost");
+    if (g->ctrl_noise && (!(g->dyn_std[0] >= 0.f) || !(g->dyn_std[1] >= 0.f))) return fail(DUST_ERR_INVALID, "noise_std must be >= 0");
   } else if (g->model == DUST_MODEL_SKID_STEER) {
     if (g->dim_a != 2 || g->dim_s != 5) return fail(DUST_ERR_INVALID, "SkidSteerRobot has dim_a=2, dim_s=5");
     if (g->cost != DUST_COST_QUADRATIC) return fail(DUST_ERR_UNSUPPORTED, "the skid-steer model runs with the quadratic cost family (DUST_COST_QUADRATIC)");
@@ -315,6 +323,8 @@ static int validate(const dust_config *g) {
   } else {
     return fail(DUST_ERR_UNSUPPORTED, "unknown model id %d", g->model);
   }
+  if (g->model != DUST_MODEL_PARTICLE && (g->control_type != 0 || g->ctrl_noise != 0))
+    return fail(DUST_ERR_UNSUPPORTED, "control_type / ctrl_noise are Particle fields (particle.py:13-31); the other models have no control-channel noise");
   const int D = g->horizon * g->dim_a;
   if (D > 128) return fail(DUST_ERR_UNSUPPORTED, "H*da = %d > 128 not supported by the kernels", D);
   if ((double)g->n_samples * g->n_policies * D >= 1073741824.0)
@@ -337,7 +347,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev, &c->cz_dev};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -388,6 +398,15 @@ static void env_read(dust_ctx *c) {
   c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
   c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
 }
+// Particle configurations the specialised rollout kernels do not take (particle_general.hpp): velocity control, and control-channel noise
+// that is not identically zero (the reference's constructor default is deterministic=False with noise_std = zeros(2): draws are made and
+// multiplied by 0, which leaves every action as it is - that default runs on the fast kernels).
+static bool particle_general(const dust_ctx *c) {
+  if (c->cfg.model != DUST_MODEL_PARTICLE) return false;
+  return c->cfg.control_type == DUST_CONTROL_VELOCITY || (c->cfg.ctrl_noise && (c->cfg.dyn_std[0] != 0.f || c->cfg.dyn_std[1] != 0.f));
+}
+// families whose rollouts are a launch of their own followed by the regular kernel in its injected-costs mode: launch-per-iteration path only
+static bool two_pass_family(const dust_ctx *c) { return c->cfg.model == DUST_MODEL_SKID_STEER || particle_general(c); }
 static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || c->env.comm_force >= 0); }
 static void comm_release(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
@@ -665,6 +684,7 @@ extern "C" int dust_get_config(const dust_ctx *c, dust_config *out) {
 extern "C" int dust_set_stream(dust_ctx *c, void *s) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->t2_inflight) TRY(dust_sync(c));  // (settle one-launch ticks on the stream they were enqueued on, replays included)
   if (c->graph_exec) graph_drop(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->own_stream) HIP_TRY(hipStreamDestroy(c->stream));
@@ -741,6 +761,7 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
 
 extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value, int kind) {
   if (!c || !name) return fail(DUST_ERR_INVALID, "null argument");
+  TRY(settle_pending(c));  // (a one-launch tick that did not start is replayed with the dynamics it was enqueued with)
   if (c->graph_exec) graph_drop(c);
   dust_param *p = nullptr;
   if (!strcmp(name, "g")) p = &c->cfg.g;
@@ -756,6 +777,7 @@ extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(settle_pending(c));  // (... and with the weights it was enqueued with)
   if (c->graph_exec) graph_drop(c);
   if (!w) {
     if (c->mw_dev) {
@@ -768,6 +790,22 @@ extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
   if (c->cfg.dim_p <= 0) return fail(DUST_ERR_STATE, "parameter weights need sampled parameters (dim_p > 0)");
   if (!c->mw_dev) TRY(dalloc(&c->mw_dev, (size_t)c->M));
   return h2d(c, c->mw_dev, w, (size_t)c->M * sizeof(float));
+}
+
+extern "C" int dust_set_ctrl_noise(dust_ctx *c, const float *z, int n_sets) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (c->cfg.model != DUST_MODEL_PARTICLE || !c->cfg.ctrl_noise)
+    return fail(DUST_ERR_STATE, "control noise belongs to a Particle(deterministic=False) context (dust_config.ctrl_noise)");
+  TRY(settle_pending(c));
+  if (c->graph_exec) graph_drop(c);
+  c->cz_sets = c->cz_next = 0;
+  if (!z || n_sets <= 0) return DUST_OK;
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  const size_t n = (size_t)n_sets * c->H * c->M * c->S * c->N * 2;
+  TRY(ensure(&c->cz_dev, &c->cz_cap, n));
+  TRY(h2d(c, c->cz_dev, z, n * sizeof(float)));
+  c->cz_sets = n_sets;
+  return DUST_OK;
 }
 
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
@@ -1222,6 +1260,56 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       o.costs_own = true;
       TRY(rollout_args(c, o, a, &nt, &lds));
     }
+  }
+  if (particle_general(c) && o.costs_in == nullptr) {
+    // pass 1 (particle_general.hpp): rollouts with control noise / velocity control + costs (+ states); pass 2: the regular kernel in
+    // its injected-costs mode
+    if (a.mw) return fail(DUST_ERR_UNSUPPORTED, "sigma-point weights are not implemented for Particle rollouts with control noise / velocity control");
+    Prof ps(c, DUST_K_ROLLOUT_STATES);
+    PartGenArgs k;
+    memset(&k, 0, sizeof k);
+    k.dm = a.dm;
+    k.N_total = c->N;
+    k.n0 = c->n0;
+    k.n_local = c->nloc;
+    k.S = c->S;
+    k.M = c->M;
+    k.H = c->H;
+    k.D = c->D;
+    k.noise_mode = a.noise_mode;
+    k.noise_f16 = a.noise_f16;
+    k.store_f16 = a.store_f16;
+    k.velocity = c->cfg.control_type == DUST_CONTROL_VELOCITY;
+    k.ctrl_noise = c->cfg.ctrl_noise && (c->cfg.dyn_std[0] != 0.f || c->cfg.dyn_std[1] != 0.f);
+    for (int d = 0; d < 2; ++d) {
+      k.dyn_std[d] = c->cfg.dyn_std[d];
+      k.chol_a[d] = a.chol_a[d];
+      k.a_pre[d] = a.a_pre[d];
+    }
+    k.a_reg = a.a_reg;
+    k.seed = a.seed;
+    k.ctr = a.ctr;
+    k.noise = a.noise;
+    k.theta = a.theta;
+    k.state = a.state;
+    k.params = a.params;
+    if (k.ctrl_noise && c->cz_dev && c->cz_next < c->cz_sets) {  // recorded draws: one set per rollout launch
+      if (c->capturing) return fail(DUST_ERR_STATE, "recorded control noise cannot be replayed from a captured graph");
+      k.cz = c->cz_dev + (size_t)c->cz_next * c->H * c->M * c->S * c->N * 2;
+      c->cz_next++;
+    }
+    k.a_seq = a.a_seq;
+    k.a_mat = a.a_mat;
+    k.costs_sn = c->costs_stage;
+    k.costsT = c->costsT;
+    k.states_out = a.states_out;
+    const int nthr = c->nloc * c->S;
+    particle_general_kernel<<<(nthr + 255) / 256, 256, 0, c->stream>>>(k);
+    HIP_TRY(hipGetLastError());
+    o.want_states = false;
+    o.costs_in = c->costs_stage;
+    o.costs_own = true;
+    TRY(rollout_args(c, o, a, &nt, &lds));
   }
   {
     int gw;
@@ -1855,7 +1943,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
 // Fused prior pass + rollout kernel (fused.hpp).  Returns DUST_OK with *done = false when the shape does not qualify.
 static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
-  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
+  if (two_pass_family(c)) return DUST_OK;  // (these families run on the launch-per-iteration path: skid.hpp, particle_general.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr;  // development switch
   if (off || c->no_handoff || c->handoff_banned || c->prof || o.want_actions || o.want_states || o.want_omega || o.costs_in || pair_is_big(c)) return DUST_OK;
   FusedArgs f;
@@ -2223,7 +2311,7 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
 // the caller runs the two-launch form.
 static int launch_iter(dust_ctx *c, const float *noise_dev, int param_set, bool *done) {
   *done = false;
-  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
+  if (two_pass_family(c)) return DUST_OK;  // (these families run on the launch-per-iteration path: skid.hpp, particle_general.hpp)
   static const bool off = getenv("DUST_NO_FUSE") != nullptr || getenv("DUST_NO_ITER") != nullptr;  // development switches
   if (off || c->no_handoff || c->handoff_banned || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -2618,7 +2706,7 @@ static int tick_occupancy(size_t lds, int *occ) {
 
 static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
-  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
+  if (two_pass_family(c)) return DUST_OK;  // (these families run on the launch-per-iteration path: skid.hpp, particle_general.hpp)
   const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;  // development switches
   if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -2826,7 +2914,7 @@ static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float
 static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
   if (c->env.no_tick2 >= 0 || c->env.no_fuse >= 0 || c->env.no_persist >= 0) return false;
   if (c->prof || c->handoff_banned || c->nloc != c->N || c->theta_pinned || n_steps < 1) return false;
-  if (c->cfg.model != DUST_MODEL_PENDULUM && c->cfg.model != DUST_MODEL_PARTICLE) return false;
+  if ((c->cfg.model != DUST_MODEL_PENDULUM && c->cfg.model != DUST_MODEL_PARTICLE) || two_pass_family(c)) return false;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return false;
   if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE || c->cfg.a_reg != 0.0f || c->mw_dev) return false;
   if (c->N % T2_PW || c->D > T2_ROW || c->N / T2_PW > device_cus(c) || c->M > T2_MAXM) return false;
@@ -2844,7 +2932,7 @@ static bool tick2_shape_ok(dust_ctx *c, int n_steps) {
 
 static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
   *done = false;
-  if (c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;  // (this family runs on the launch-per-iteration path: skid.hpp)
+  if (two_pass_family(c)) return DUST_OK;  // (these families run on the launch-per-iteration path: skid.hpp, particle_general.hpp)
   if (c->env.no_tick2 >= 0 || c->env.no_fuse >= 0 || c->env.no_persist >= 0) return DUST_OK;  // development switches
   if (c->prof || c->nloc != c->N || c->theta_pinned || c->capturing || !c->mu_aliased) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
@@ -3239,7 +3327,7 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
   const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;
   if (off || c->no_handoff || c->handoff_banned || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
-  if (c->N > 4096 || c->D > 64 || pair_is_big(c) || c->cfg.model == DUST_MODEL_SKID_STEER) return DUST_OK;
+  if (c->N > 4096 || c->D > 64 || pair_is_big(c) || two_pass_family(c)) return DUST_OK;
   if (c->cfg.dim_p > 0 && !params && n_steps > 0) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
   // The launchers decide eligibility (slice counts, occupancy, rollout form ...) only after the inputs are staged; what they decline
   // is static for a context in a given state, so a decline is remembered and the same call is not staged twice again
@@ -3432,7 +3520,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
   //  replayed capture would not be)
   const bool tenants = c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV && g_live_ctx[c->cfg.device].load() >= 2;
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
-                         c->mu_aliased && c->own_stream && !tenants;
+                         c->mu_aliased && c->own_stream && !tenants && c->cz_next >= c->cz_sets /* no recorded control noise pending */;
   if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || c->graph_flags != flags ||
       (c->graph_exec && c->graph_theta != c->theta)) {
     if (c->graph_exec) graph_drop(c);

@@ -22,6 +22,10 @@ struct MpfArgs {
   float prior_bwv[4];  // prior bandwidth per parameter dimension (equal after the first update_prior; MPF(bw=None) starts per-dimension)
   float bw, lr, obs_std;
   float past_obs[4], past_action[2], obs[4];
+  // control-channel noise of the one-step prediction (Particle(deterministic=False), particle.py:145-148 reached through
+  // likelihoods.py:30-46): `acts` there is the bare action vector, so ONE d_a-vector is drawn per phi() call - i.e. per SVGD step -
+  // and shared by all filter particles.  act_seq[step][2] = fl(past_action + fl(dyn_std * z_step)), prepared by the host, or nullptr
+  const float *act_seq;
   float *x;           // [Mp][P] in/out
   float *grad_norms;  // [n_steps] or nullptr
   float *phi_out;     // [Mp][P] or nullptr (phi of the first step, when n_steps == 0 semantics are wanted use n_steps=1, lr=0)
@@ -166,10 +170,11 @@ __global__ __launch_bounds__(1024) void mpf_optimize_kernel(const MpfArgs a) {
       float pred[4];
       for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
       const Coef cf = make_coef(a.dm, xi);
-      if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
-      else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+      const float pa[2] = {a.act_seq ? a.act_seq[2 * it] : a.past_action[0], a.act_seq ? a.act_seq[2 * it + 1] : a.past_action[1]};
+      if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, pa);
+      else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, pa);
       double J[4][4];
-      step_jacobian<P>(a.dm, a.past_obs, a.past_action, xi, J);
+      step_jacobian<P>(a.dm, a.past_obs, pa, xi, J);
       _Pragma("unroll") for (int p = 0; p < P; ++p) {
         double g = 0.0;
         _Pragma("unroll") for (int k = 0; k < 4; ++k)
@@ -363,14 +368,15 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
   // likelihood score of this wave's particle (mpf.py:46-50, likelihoods.py:30-49): one model step and its Jacobian, on lane 0 - 2.5 us.
   // It depends on the particle alone, so the term of step it + 1 is computed behind the particle store of step it, under the hop.
   double glik[4] = {0, 0, 0, 0};
-  auto lik = [&](const float *xp) {
+  auto lik = [&](const float *xp, const int step) {
     float pred[4];
     for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
     const Coef cf = make_coef(a.dm, xp);
-    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
-    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+    const float pa[2] = {a.act_seq ? a.act_seq[2 * step] : a.past_action[0], a.act_seq ? a.act_seq[2 * step + 1] : a.past_action[1]};
+    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, pa);
+    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, pa);
     double J[4][4];
-    step_jacobian<P>(a.dm, a.past_obs, a.past_action, xp, J);
+    step_jacobian<P>(a.dm, a.past_obs, pa, xp, J);
     _Pragma("unroll") for (int p = 0; p < P; ++p) {
       double gl = 0.0;
       _Pragma("unroll") for (int k = 0; k < 4; ++k)
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
   if (lead) {
     float x0v[4] = {0.f, 0.f, 0.f, 0.f};
     _Pragma("unroll") for (int p = 0; p < P; ++p) x0v[p] = xs[i * P + p];
-    lik(x0v);
+    lik(x0v, 0);
   }
 
   for (int it = 0; it < a.n_steps; ++it) {
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_grid_kernel(const MpfGr
     }
     if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     arrive(cnt_x);
-    if (lead && it + 1 < a.n_steps) lik(xn);
+    if (lead && it + 1 < a.n_steps) lik(xn, it + 1);
     poll(cnt_x, (unsigned int)(it + 1));
     if (it + 1 < a.n_steps) {
       for (int j = tid; j < Mp; j += MPF_G_NT) {
@@ -630,14 +636,15 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
   };
   const double inv_obs2 = 1.0 / ((double)a.obs_std * (double)a.obs_std);
   double glik[4] = {0, 0, 0, 0};
-  auto lik = [&](const float *xp) {
+  auto lik = [&](const float *xp, const int step) {
     float pred[4];
     for (int k = 0; k < 4; ++k) pred[k] = k < a.ds ? a.past_obs[k] : 0.f;
     const Coef cf = make_coef(a.dm, xp);
-    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, a.past_action);
-    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, a.past_action);
+    const float pa[2] = {a.act_seq ? a.act_seq[2 * step] : a.past_action[0], a.act_seq ? a.act_seq[2 * step + 1] : a.past_action[1]};
+    if (a.dm.model == DUST_MODEL_PENDULUM) model_step<DUST_MODEL_PENDULUM>(a.dm, cf, pred, pa);
+    else model_step<DUST_MODEL_PARTICLE>(a.dm, cf, pred, pa);
     double J[4][4];
-    step_jacobian<P>(a.dm, a.past_obs, a.past_action, xp, J);
+    step_jacobian<P>(a.dm, a.past_obs, pa, xp, J);
     _Pragma("unroll") for (int p = 0; p < P; ++p) {
       double gl = 0.0;
       _Pragma("unroll") for (int k = 0; k < 4; ++k)
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
       am[p] = a.adam_m[io * P + p];
       av[p] = a.adam_v[io * P + p];
     }
-  lik(xi);
+  lik(xi, 0);
 
   for (int it = 0; it < a.n_steps; ++it) {
     const unsigned int tag_s = 0x40000000u | ((tag0 + 2u * (unsigned int)it + 1u) & 0x3fffffffu), tag_x = 0x40000000u | ((tag0 + 2u * (unsigned int)it + 2u) & 0x3fffffffu);
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(MPF_G_NT) void mpf_optimize_poll_kernel(const MpfPo
       }
     }
     _Pragma("unroll") for (int p = 0; p < P; ++p) xi[p] = xn[p];
-    if (it + 1 < a.n_steps) lik(xi);  // (under the hop)
+    if (it + 1 < a.n_steps) lik(xi, it + 1);  // (under the hop)
     if (g.test == 2 && it == a.n_steps - 1 && b == G - 1 && tid == 0) __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
       poll(std::false_type{}, rs_x, (it + 1) & 1, tag_x);
@@ -821,6 +828,12 @@ struct dust_mpf {
   float prior_bwv[4];          // per parameter dimension; equal once update_prior(bw) has run (mpf.py:85)
   float loc[4], past_obs[4], past_action[2];
   bool have_past;
+  // control-channel noise of the one-step prediction (model_cfg.ctrl_noise; particle.py:145-148 through likelihoods.py:30-46)
+  std::vector<float> *cz;   // recorded draws [n][da] (dust_mpf_set_ctrl_noise), consumed one per SVGD step
+  size_t cz_next;
+  std::mt19937_64 *rng;     // draws once the recorded ones are used up
+  float *act_seq;           // device: effective action per step of the current launch [steps][2]
+  int act_seq_cap;
   // the multi-workgroup form of the optimisation (mpf_optimize_grid_kernel): exchange buffers, counters, status; lazily allocated
   float *gbuf;            // xg [2][Mp][P] | scg [2][Mp][P] | n2g [gsteps][Mp]
   unsigned int *gcnt;     // counters (zeroed per launch) followed by the 4 status words
@@ -856,7 +869,10 @@ extern "C" void dust_mpf_destroy(dust_mpf *m) {
     if (p) (void)hipFree(p);
   if (m->grid_bits) (void)hipFree(m->grid_bits);
   if (m->hpin) (void)hipHostFree(m->hpin);
+  if (m->act_seq) (void)hipFree(m->act_seq);
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m->cz;
+  delete m->rng;
   delete m;
 }
 
@@ -870,6 +886,10 @@ extern "C" int dust_mpf_create(const dust_mpf_config *cfg, const float *init_par
   if (cfg->model_cfg.model != DUST_MODEL_PENDULUM && cfg->model_cfg.model != DUST_MODEL_PARTICLE)
     return fail(DUST_ERR_UNSUPPORTED, "MPF's one-step prediction and its Jacobian exist for the Pendulum and Particle models only");
   if (!(cfg->obs_std > 0.f)) return fail(DUST_ERR_INVALID, "obs_std must be > 0");
+  if (cfg->model_cfg.model == DUST_MODEL_PARTICLE && cfg->model_cfg.control_type != DUST_CONTROL_ACCELERATION)
+    return fail(DUST_ERR_UNSUPPORTED, "MPF over Particle(control_type='velocity'): the mass does not enter that model's step (particle.py:152-153), there is nothing to filter");
+  if (cfg->model_cfg.model != DUST_MODEL_PARTICLE && cfg->model_cfg.ctrl_noise)
+    return fail(DUST_ERR_UNSUPPORTED, "ctrl_noise is a Particle field (particle.py:145-148)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DUST_ERR_NO_DEVICE, "no HIP device: libdust_amd has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(DUST_ERR_NO_DEVICE, "device %d of %d", cfg->device, ndev);
@@ -978,7 +998,50 @@ static bool mpf_grid_ok(const dust_mpf *m, int n_steps, bool optimise) {
   return m->Mp >= ((env && atoi(env) == 1) ? 8 : 96);
 }
 
-static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true, bool grid = false) {
+// Effective action of every SVGD step of the coming launch when the model carries control noise: acts = past_action + dyn_std * z, one
+// z [da] per phi() call (particle.py:145-148; `acts` is the bare action vector at likelihoods.py:44), in fp32 as the reference adds it.
+static int mpf_noisy_actions(dust_mpf *m, int n_steps, const float **dev) {
+  *dev = nullptr;
+  const dust_config &g = m->cfg.model_cfg;
+  if (g.model != DUST_MODEL_PARTICLE || !g.ctrl_noise || (g.dyn_std[0] == 0.f && g.dyn_std[1] == 0.f) || n_steps < 1) return DUST_OK;
+  if (!m->act_seq || m->act_seq_cap < n_steps) {
+    if (m->act_seq) HIP_TRY(hipFree(m->act_seq));
+    m->act_seq = nullptr;
+    m->act_seq_cap = std::max(n_steps, 64);
+    TRY(dalloc(&m->act_seq, (size_t)2 * m->act_seq_cap));
+  }
+  std::vector<float> h((size_t)2 * n_steps);
+  for (int it = 0; it < n_steps; ++it)
+    for (int d = 0; d < 2; ++d) {
+      float z;
+      if (m->cz && m->cz_next < m->cz->size()) {
+        z = (*m->cz)[m->cz_next++];
+      } else {
+        if (!m->rng) m->rng = new std::mt19937_64(g.seed ^ 0x6d70666e6f697365ull);
+        z = std::normal_distribution<float>(0.f, 1.f)(*m->rng);
+      }
+      const float nz = g.dyn_std[d] * z;
+      h[(size_t)2 * it + d] = m->past_action[d] + nz;
+    }
+  HIP_TRY(hipMemcpyAsync(m->act_seq, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));  // (h is a local; the filter's calls are synchronous anyway)
+  *dev = m->act_seq;
+  return DUST_OK;
+}
+
+extern "C" int dust_mpf_set_ctrl_noise(dust_mpf *m, const float *z, int n) {
+  if (!m) return fail(DUST_ERR_INVALID, "null mpf");
+  if (m->cfg.model_cfg.model != DUST_MODEL_PARTICLE || !m->cfg.model_cfg.ctrl_noise)
+    return fail(DUST_ERR_STATE, "control noise belongs to a Particle(deterministic=False) model (model_cfg.ctrl_noise)");
+  if (!m->cz) m->cz = new std::vector<float>();
+  m->cz->clear();
+  m->cz_next = 0;
+  if (z && n > 0) m->cz->assign(z, z + (size_t)n * m->cfg.dim_a);
+  return DUST_OK;
+}
+
+static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true, bool grid = false,
+                      const float *act_seq_dev = nullptr) {
   if (m->cfg.model_cfg.model == DUST_MODEL_PARTICLE && m->cfg.model_cfg.with_obstacle && m->cfg.model_cfg.can_crash && !m->grid_bits)
     return fail(DUST_ERR_STATE, "Particle model with obstacles: call dust_mpf_set_grid first");
   MpfArgs a;
@@ -1000,6 +1063,7 @@ static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_de
   }
   a.past_action[0] = m->past_action[0];
   a.past_action[1] = m->past_action[1];
+  a.act_seq = act_seq_dev;
   a.x = m->x;
   a.grad_norms = gn_dev;
   a.phi_out = phi_dev;
@@ -1114,7 +1178,9 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
   }
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   const bool grid = mpf_grid_ok(m, n_steps, true);
-  TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, grid));
+  const float *acts = nullptr;
+  TRY(mpf_noisy_actions(m, n_steps, &acts));
+  TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, grid, acts));
   const bool want_gn = grad_norms && n_steps > 0;
   if (!m->hpin) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->hpin), (4096 + 8) * sizeof(float), hipHostMallocDefault));
   bool gn_read = false;
@@ -1133,7 +1199,7 @@ extern "C" int dust_mpf_optimize(dust_mpf *m, const float *action, const float *
         return fail(DUST_ERR_HIP, "MPF: a hand-off wait timed out while some waves were committing (particles invalid: re-seed them); the device seems to be shared with another process");
       if (st[1] || st[2]) {  // nothing was written: the single-workgroup kernel runs the call
         m->n_grid_fallback++;
-        TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, false));
+        TRY(mpf_launch(m, bw, m->cfg.lr, n_steps, m->gn, nullptr, true, false, acts));  // (the same draws: nothing was committed)
         gn_read = false;
       }
     }
@@ -1159,7 +1225,9 @@ extern "C" int dust_mpf_phi(dust_mpf *m, float bw, float *phi) {
   if (!m || !phi) return fail(DUST_ERR_INVALID, "null argument");
   if (!m->have_past) return fail(DUST_ERR_STATE, "Previous action is None. Need at least one observation to start sampling.");
   HIP_TRY(hipSetDevice(m->cfg.device));
-  TRY(mpf_launch(m, bw, 0.0f, 1, nullptr, m->phi, false));  // lr = 0, SGD form: particles and optimiser state unchanged
+  const float *acts = nullptr;
+  TRY(mpf_noisy_actions(m, 1, &acts));
+  TRY(mpf_launch(m, bw, 0.0f, 1, nullptr, m->phi, false, false, acts));  // lr = 0, SGD form: particles and optimiser state unchanged
   HIP_TRY(hipMemcpyAsync(phi, m->phi, (size_t)m->Mp * m->P * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return DUST_OK;

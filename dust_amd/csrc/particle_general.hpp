@@ -1,0 +1,172 @@
+// particle_general.hpp - the Particle rollouts the specialised kernels (rollout.hpp packed pairs, rollout_states.hpp whole lines,
+// persist.hpp) do not take: control-channel noise and velocity control.
+//
+// Replaces (reference file:line): Particle.step particle.py:117-166 in full -
+//   * `if not self.deterministic: acts += self.dyn_std * torch.randn_like(acts)` (particle.py:145-148; deterministic=False is the
+//     constructor DEFAULT, particle.py:31): every model.step call of MultiDISCO._rollout (disco.py:193-200) draws one [M*S*N, d_a]
+//     normal tensor, so rollout r = (m*S + s)*N + n at step t uses draw [t][r].  The noise moves the DYNAMICS only: the costs see
+//     the raw actions (disco.py:306-310);
+//   * `control_type == "velocity"` (particle.py:41-48, 152-153): a TWO-state model (x, y): acts.clamp_(+-max_speed), x_dot = acts,
+//     next = states + x_dot * dt * (1 - mask), and the closing `next_states[..., -2:].clamp_` (particle.py:165) then lands on the
+//     POSITIONS (reproduced: it is what the reference computes);
+// under MultiDISCO._rollout / _compute_cost (disco.py:139-209, 294-346) with Particle.default_inst_cost / default_term_cost
+// (particle.py:170-225; w_state / w_term / target have dim_s entries).
+//
+// One lane = one (action sample s, policy n) pair, the M dynamics samples in sequence (the scheme of skid.hpp); costs go to a [S][N]
+// buffer that the regular rollout kernel consumes in its injected-costs mode (weights, likelihood score, a_mat update).  Control noise:
+// recorded draws `cz` [H][M*S*N][d_a] (parity runs: the reference's own torch.randn_like tensors, dust_set_ctrl_noise) or a Philox
+// stream of its own, keyed (tick, iter, r, t) - in registers, never in HBM.  A completeness row, not a tuned one: plain loads.
+#pragma once
+#include "rollout.hpp"
+
+namespace dust {
+
+struct PartGenArgs {
+  DevModel dm;
+  int N_total, n0, n_local, S, M, H, D;
+  int noise_mode;  // policy noise: NOISE_EPS / NOISE_ACTIONS / NOISE_PHILOX (rollout.hpp)
+  int noise_f16;   // caller's eps / actions are binary16
+  int store_f16;   // states_out is binary16
+  int velocity;    // control_type == "velocity": dim_s = 2
+  int ctrl_noise;  // Particle(deterministic=False)
+  float dyn_std[2];
+  float chol_a[2], a_pre[2];
+  float a_reg;
+  uint64_t seed;
+  const uint32_t *ctr;  // {tick, iter, ..}: Philox stream position, as the regular kernel reads it
+  const float *noise;   // [S][N][D] eps or actions
+  const float *theta;   // [N][D]
+  const float *state;   // [ds]
+  const float *params;  // [M][P] raw samples or nullptr
+  const float *cz;      // [H][M*S*N][2] recorded control-noise draws, or nullptr: Philox
+  const float *a_seq;   // [D]
+  const float *a_mat;   // [N][D]
+  float *costs_sn;      // [S][N]
+  float *costsT;        // [N][S]
+  void *states_out;     // [M][S][N][H+1][ds] or nullptr
+};
+
+__global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.n_local * a.S) return;
+  const int s = idx / a.n_local, n = a.n0 + (idx - s * a.n_local);  // (n fastest: the rows of one sample are adjacent)
+  const int D = a.D, H = a.H, N = a.N_total;
+  const int DSm = a.velocity ? 2 : 4;
+  const size_t row = ((size_t)s * N + n) * D;
+  const float *nz = (a.noise && !a.noise_f16) ? a.noise + row : nullptr;
+  const _Float16 *nzh = (a.noise && a.noise_f16) ? reinterpret_cast<const _Float16 *>(a.noise) + row : nullptr;
+  const float *th = a.theta + (size_t)n * D;
+  const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
+  auto action = [&](const int j) -> float {
+    const float v = nzh ? (float)nzh[j] : (nz ? nz[j] : 0.f);
+    if (a.noise_mode == NOISE_ACTIONS) return v;
+    if (a.noise_mode == NOISE_EPS) return th[j] + a.chol_a[j & 1] * v;
+    float z[8];
+    philox_normal8(a.seed, (uint32_t)(j >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
+    return th[j] + a.chol_a[j & 1] * z[j & 7];
+  };
+  const DevModel &dm = a.dm;
+  const float dt = (float)dm.dt;
+  const bool obst = dm.with_obstacle != 0, crash = dm.can_crash && dm.with_obstacle;
+  float x0[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < DSm; ++k) x0[k] = a.state[k];
+  const size_t SN = (size_t)a.S * N;
+  double acc = 0.0;
+  for (int m = 0; m < a.M; ++m) {
+    const size_t r = (size_t)m * SN + (size_t)s * N + n;
+    // scalar-event params_dist quirk (disco.py:177-179): rollout r = (m, s, n) flattened uses params[r % M]
+    const int mi = dm.interleave ? (int)(r % (size_t)a.M) : m;
+    const Coef cf = make_coef(dm, a.params ? a.params + (size_t)mi * dm.P : nullptr);
+    float x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x0[k];
+    const size_t so = r * (size_t)(H + 1) * DSm;
+    auto put = [&](const int t) {
+      if (!a.states_out) return;
+      for (int k = 0; k < DSm; ++k) {
+        if (a.store_f16) reinterpret_cast<_Float16 *>(a.states_out)[so + (size_t)t * DSm + k] = (_Float16)x[k];
+        else reinterpret_cast<float *>(a.states_out)[so + (size_t)t * DSm + k] = x[k];
+      }
+    };
+    put(0);
+    double tot = 0.0;
+    for (int t = 0; t < H; ++t) {
+      const float a0 = action(2 * t), a1 = action(2 * t + 1);
+      // cost of the state BEFORE the action, raw action (disco.py:306; particle.py:170-198)
+      const float coll = obst ? collision(dm, x[0], x[1]) : 0.f;
+      double sc = 0.0;
+      for (int k = 0; k < DSm; ++k) {
+        const float d = x[k] - dm.target[k];
+        sc += (double)((d * d) * dm.w_state[k]);
+      }
+      const double cc = (double)((a0 * a0) * dm.w_ctrl[0]) + (double)((a1 * a1) * dm.w_ctrl[1]);
+      const float ob = obst ? dm.w_obs * coll : 0.0f;
+      tot += (double)(((float)sc + (float)cc) + ob);
+      // the action that drives the dynamics (particle.py:144-153)
+      float u0 = a0, u1 = a1;
+      if (a.ctrl_noise) {
+        float z0, z1;
+        if (a.cz) {
+          const float *zp = a.cz + ((size_t)t * a.M * SN + r) * 2;
+          z0 = zp[0];
+          z1 = zp[1];
+        } else {  // a stream of its own: key word 0x63747264 ("ctrd") apart from the policy noise
+          float z[4];
+          philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)(r >> 32) ^ ((uint32_t)t << 8), ctr_iter, ctr_tick, z);
+          z0 = z[0];
+          z1 = z[1];
+        }
+        u0 = u0 + a.dyn_std[0] * z0;
+        u1 = u1 + a.dyn_std[1] * z1;
+      }
+      const float om = crash ? 1.0f - coll : 1.0f;
+      if (a.velocity) {
+        u0 = clampf(u0, -dm.max_speed, dm.max_speed);
+        u1 = clampf(u1, -dm.max_speed, dm.max_speed);
+        if (crash) {
+          x[0] = x[0] + (u0 * dt) * om;
+          x[1] = x[1] + (u1 * dt) * om;
+        } else {
+          x[0] = x[0] + u0 * dt;
+          x[1] = x[1] + u1 * dt;
+        }
+        x[0] = clampf(x[0], -dm.max_speed, dm.max_speed);  // particle.py:165 on a two-state row: the positions
+        x[1] = clampf(x[1], -dm.max_speed, dm.max_speed);
+      } else {
+        u0 = clampf(u0 / cf.c0, -dm.max_acc, dm.max_acc);
+        u1 = clampf(u1 / cf.c0, -dm.max_acc, dm.max_acc);
+        const float xd[4] = {x[2], x[3], u0, u1};
+        if (crash) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = x[k] + (xd[k] * dt) * om;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = x[k] + xd[k] * dt;
+        }
+        x[2] = clampf(x[2], -dm.max_speed, dm.max_speed);
+        x[3] = clampf(x[3], -dm.max_speed, dm.max_speed);
+      }
+      put(t + 1);
+    }
+    double tc = 0.0;
+    for (int k = 0; k < DSm; ++k) {
+      const float d = x[k] - dm.target[k];
+      tc += (double)((d * d) * dm.w_term[k]);
+    }
+    const float tob = obst ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
+    acc += (double)((float)tot + ((float)tc + tob));
+  }
+  float cost = a.M == 1 ? (float)acc : (float)(acc / a.M);
+  if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
+    double cc = 0.0;
+    for (int j = 0; j < D; ++j) {
+      const float e = action(j) - a.a_seq[j];
+      cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j & 1]);
+    }
+    cost = cost + a.a_reg * (float)cc;
+  }
+  a.costs_sn[(size_t)s * N + n] = cost;
+  a.costsT[(size_t)n * a.S + s] = cost;
+}
+
+}  // namespace dust

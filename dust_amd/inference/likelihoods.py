@@ -21,6 +21,7 @@ class CostLikelihood:
         ctx = c._ensure_ctx(self.model, params_dist)
         params, self.params_log_p = c._sample_params(params_dist)
         st = torch.as_tensor(state, dtype=torch.float).reshape(-1).numpy()
+        c._feed_ctrl_noise(ctx)
         # theta is an ARGUMENT here (the reference never writes SVMPC.theta or the optimiser state from sample())
         costs, actions = ctx.likelihood_sample_at(st, torch.as_tensor(theta, dtype=torch.float).detach().numpy(),
                                                   None if eps is None else np.asarray(eps, np.float32),

@@ -79,13 +79,19 @@ class MPF:
         grid = None
         if model.family == "particle":
             kw.update(max_speed=float(model._max_speed), max_accel=float(model._max_acc), can_crash=bool(model.can_crash),
-                      with_obstacle=bool(model.with_obstacle), cell_size=float(model.map_cell_size or 0.1))
+                      with_obstacle=bool(model.with_obstacle), cell_size=float(model.map_cell_size or 0.1),
+                      # the one-step prediction runs Particle.step in full (likelihoods.py:30-46 -> particle.py:145-153)
+                      control_type=str(model.control_type), deterministic=bool(model.deterministic),
+                      noise_std=tuple(float(v) for v in torch.as_tensor(model.dyn_std, dtype=torch.float).reshape(-1).expand(2)))
             grid = model.obst_map.map.astype(np.float32) if model.obst_map is not None else None
         kw.update(opt_kw)
         self._dev = MpfContext(init_particles.numpy(), likelihood.loc.numpy(), grid=grid, **kw)
         if bw_vec is not None:
             self._dev.set_prior_bw(bw_vec)
         self.prior = _DevicePrior(self)
+        # recorded control-noise draws for reproducible runs: an object whose next_mpf_noise() returns the next [da] draw or None
+        # (see MultiDISCO.draw_source); None: the library's own generator
+        self.draw_source = None
 
     def __deepcopy__(self, memo):
         import copy
@@ -101,7 +107,15 @@ class MPF:
     def x(self):
         return torch.from_numpy(self._dev.get_particles())
 
+    def _feed_ctrl_noise(self, n):
+        if self.draw_source is None:
+            return
+        rec = [self.draw_source.next_mpf_noise() for _ in range(n)]
+        if rec and rec[0] is not None:
+            self._dev.set_ctrl_noise(np.stack([np.asarray(r, np.float32).reshape(-1) for r in rec]))
+
     def phi(self, bw):
+        self._feed_ctrl_noise(1)
         return torch.from_numpy(self._dev.phi(float(bw)))
 
     def optimize(self, action, new_obs, bw=None, n_steps=100, debug=False):  # mpf.py:64-86
@@ -111,5 +125,6 @@ class MPF:
             bw = silvermans_rule(self.x.view(-1, 1).numpy()) * self.bw_scale
         a = None if action is None else torch.as_tensor(action, dtype=torch.float).reshape(-1).numpy()
         o = None if new_obs is None else torch.as_tensor(new_obs, dtype=torch.float).reshape(-1).numpy()
+        self._feed_ctrl_noise(int(n_steps))
         grads = self._dev.optimize(a, o, float(bw), int(n_steps))
         return torch.as_tensor(grads), bw

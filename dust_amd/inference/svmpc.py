@@ -108,16 +108,16 @@ class SVMPC:
 
     def optimize(self, state, params_dist, bw=None, n_steps=None, debug=False, eps=None):
         """`bw` is accepted and ignored, as in the reference (dead value on both kernel branches)."""
-        from ..utils import replay
-
         ctx = self._ctx(params_dist)
+        ctrl = self.likelihood.controller
         n_steps = self.n_steps if n_steps is None else n_steps
-        if eps is None:  # recorded draws of a reference run, when a replay feed is active (parity tests)
-            rec = [replay.next_eps() for _ in range(n_steps)]
+        if eps is None and ctrl.draw_source is not None:  # recorded draws (MultiDISCO.draw_source), e.g. of a reference run
+            rec = [ctrl._recorded("eps") for _ in range(n_steps)]
             if rec and rec[0] is not None:
                 eps = np.stack([np.asarray(r, np.float32) for r in rec])
-        params, lp = self.likelihood.controller._sample_params(params_dist, n_steps)
+        params, lp = ctrl._sample_params(params_dist, n_steps)
         self.likelihood.params_log_p = lp
+        ctrl._feed_ctrl_noise(ctx, n_steps)
         ctx.svmpc_optimize(self._state(state), n_steps, eps, params)
 
     # -- svmpc.py:128-200

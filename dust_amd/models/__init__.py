@@ -76,7 +76,8 @@ class PendulumModel(BaseModel):
 
 
 class Particle(BaseModel):
-    """dust/models/particle.py:11-334 (acceleration control; `render` is out of scope)."""
+    """dust/models/particle.py:11-334 (`render` is out of scope).  `deterministic=False` with a non-zero `noise_std` and
+    `control_type="velocity"` run on the device through csrc/particle_general.hpp."""
 
     family = "particle"
 
@@ -85,18 +86,23 @@ class Particle(BaseModel):
                  init_state=None, target_state=None, can_crash=False, max_speed=None, max_accel=None, verbose=False,
                  deterministic=False, euler_steps=1, **kwargs):
         super().__init__(params_dict={"mass": mass}, **kwargs)
-        if control_type != "acceleration":
-            raise NotImplementedError("only control_type='acceleration' has a HIP kernel (no CPU fallback)")
         self._max_speed = float("inf") if max_speed is None else max_speed
         self._max_acc = float("inf") if max_accel is None else max_accel
-        bounds = torch.tensor([float("inf"), float("inf"), float(self._max_speed), float(self._max_speed)])
-        self._observation_space = Box(dim=4, low=-bounds, high=bounds, dtype=torch.float)
-        self._action_space = Box(dim=2, low=-float(self._max_acc), high=float(self._max_acc), dtype=torch.float)
-        self.target = torch.zeros(4) if target_state is None else torch.as_tensor(target_state, dtype=torch.float)
+        if control_type == "velocity":  # particle.py:41-48: a TWO-state model (x, y)
+            bounds = torch.tensor([float("inf"), float("inf")])
+            self._observation_space = Box(dim=2, low=-bounds, high=bounds, dtype=torch.float)
+            self._action_space = Box(dim=2, low=-float(self._max_speed), high=float(self._max_speed), dtype=torch.float)
+        elif control_type == "acceleration":
+            bounds = torch.tensor([float("inf"), float("inf"), float(self._max_speed), float(self._max_speed)])
+            self._observation_space = Box(dim=4, low=-bounds, high=bounds, dtype=torch.float)
+            self._action_space = Box(dim=2, low=-float(self._max_acc), high=float(self._max_acc), dtype=torch.float)
+        else:
+            raise IOError('control_type "{}" not recognized'.format(control_type))  # particle.py:59-60
+        self.target = torch.zeros(self._observation_space.dim) if target_state is None else torch.as_tensor(target_state, dtype=torch.float)
         self.dyn_std = noise_std
         self.init_state = None if init_state is None else torch.as_tensor(init_state)
         self.euler_steps = euler_steps
-        self.control_type = control_type
+        self.control_type = control_type  # (set before init_cost_weights, which reads it - as particle.py:68-91 orders them)
         self.with_obstacle, self.can_crash = with_obstacle, can_crash
         self.map_cell_size, self.map_size = map_cell_size, map_size
         self.verbose, self.deterministic = verbose, deterministic
@@ -112,9 +118,10 @@ class Particle(BaseModel):
     def init_cost_weights(self, params):  # particle.py:292-326
         if params is None:
             params = dict.fromkeys(["w_qpos", "w_qvel", "w_qpos_T", "w_qvel_T", "w_ctrl", "w_obs"], 1.0)
-        self.w_state = torch.as_tensor([params["w_qpos"]] * 2 + [params["w_qvel"]] * 2, dtype=torch.float)
+        vel = self.control_type == "velocity"  # two-state model: position weights only (particle.py:307-322)
+        self.w_state = torch.as_tensor([params["w_qpos"]] * 2 + ([] if vel else [params["w_qvel"]] * 2), dtype=torch.float)
         self.w_ctrl = torch.as_tensor([params["w_ctrl"]] * 2, dtype=torch.float)
-        self.w_term = torch.as_tensor([params["w_qpos_T"]] * 2 + [params["w_qvel_T"]] * 2, dtype=torch.float)
+        self.w_term = torch.as_tensor([params["w_qpos_T"]] * 2 + ([] if vel else [params["w_qvel_T"]] * 2), dtype=torch.float)
         self.w_obs = torch.as_tensor([params["w_obs"]], dtype=torch.float)
 
     def step(self, states, actions, params_dict=None):  # particle.py:117-166, plant-side
@@ -123,7 +130,10 @@ class Particle(BaseModel):
         acts = torch.as_tensor(actions, dtype=torch.float).clone()
         if not self.deterministic:
             acts = acts + torch.as_tensor(self.dyn_std, dtype=torch.float) * torch.randn_like(acts)
-        acts = torch.clamp(acts / m, min=-self._max_acc, max=self._max_acc)
+        if self.control_type == "acceleration":
+            acts = torch.clamp(acts / m, min=-self._max_acc, max=self._max_acc)
+        else:  # particle.py:152-153
+            acts = acts.clamp(min=-self._max_speed, max=self._max_speed)
         x_dot = torch.cat((states[..., 2:], acts), dim=-1)
         if self.can_crash and self.with_obstacle:
             mask = self.obst_map.get_collisions(states[..., 0:2]).unsqueeze(-1)

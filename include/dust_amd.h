@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DUST_ABI_VERSION 1
+#define DUST_ABI_VERSION 2
 
 enum dust_status {
   DUST_OK = 0,
@@ -50,6 +50,9 @@ enum dust_roll { DUST_ROLL_REPEAT = 0, DUST_ROLL_MEAN = 1, DUST_ROLL_RESAMPLE = 
 enum dust_step_strategy { DUST_STEP_ARGMAX = 0, DUST_STEP_AVERAGE = 1, DUST_STEP_EXTERNAL = 2 }; /* disco.py:396-417 */
 /* how a model parameter enters the arithmetic: a Python float (double), a 0-dim fp32 tensor, or a sampled column */
 enum dust_param_kind { DUST_PARAM_PYFLOAT = 0, DUST_PARAM_SAMPLED = 1, DUST_PARAM_TENSOR0D = 2 };
+/* Particle(control_type=) particle.py:41-60, 149-153.  Velocity control is a TWO-state model (x, y; dim_s = 2): the action is clamped to
+ * +-max_speed and integrated directly, and the closing clamp of the step (particle.py:165) lands on the positions. */
+enum dust_control_type { DUST_CONTROL_ACCELERATION = 0, DUST_CONTROL_VELOCITY = 1 };
 /* DUST_EPS_AROUND_A_MAT: the external actions were drawn around a_mat (MultiDISCO's own sampling, disco.py:155-160) */
 enum dust_flags {
   DUST_PTR_DEVICE = 1,
@@ -105,6 +108,13 @@ typedef struct dust_config {
   int32_t can_crash, with_obstacle;
   double cell_size;
   float target[4], w_state[4], w_term[4], w_ctrl[2], w_obs;
+  /* ABI 2: Particle(control_type=, deterministic=, noise_std=) particle.py:13-31.  ctrl_noise = `not deterministic` (the reference's
+   * constructor default is deterministic=False with noise_std = zeros(2)): every model step adds dyn_std * N(0, I) to the actions that
+   * drive the dynamics (particle.py:145-148; the costs see the raw actions).  Draws: a device Philox stream, or the recorded tensors
+   * handed to dust_set_ctrl_noise / dust_mpf_set_ctrl_noise (parity runs). */
+  int32_t control_type; /* dust_control_type */
+  int32_t ctrl_noise;
+  float dyn_std[2];
 } dust_config;
 
 /* SkidSteerRobot (dust/models/skid_steer_robot.py:19-52, step :73-122; model = DUST_MODEL_SKID_STEER, dim_s = 5: x, y, theta, v,
@@ -145,6 +155,12 @@ int dust_set_model_param(dust_ctx *ctx, const char *name, double value, int kind
  * of the mean.  NULL switches back to the mean over sampled parameters. */
 int dust_set_param_weights(dust_ctx *ctx, const float *w);
 int dust_set_skid_steer(dust_ctx *ctx, const dust_skid_config *cfg);
+/* Recorded control-channel noise for the NEXT rollouts of a Particle(deterministic=False) context (particle.py:145-148): z holds n_sets
+ * tensors [H][M*S*N][da] of standard-normal draws in the reference's own order - one `torch.randn_like(acts)` per model.step call of
+ * MultiDISCO._rollout (disco.py:193-200), rollout r = (m*S + s)*N + n, N = n_policies (all shards).  Every rollout launch that follows
+ * (one per likelihood sample, i.e. per SVGD iteration) consumes one set; when they are used up - or after z = NULL - the draws come
+ * from the context's Philox stream again.  Host pointer; copied before the call returns. */
+int dust_set_ctrl_noise(dust_ctx *ctx, const float *z, int n_sets);
 /* ObstacleMap occupancy grid [nx][ny] (obstacle_map.py:13-43); offsets are the map centre in cells */
 int dust_set_grid(dust_ctx *ctx, const float *grid, int nx, int ny, float off_x, float off_y);
 
@@ -300,6 +316,11 @@ int dust_mpf_optimize(dust_mpf *mpf, const float *action, const float *new_obs, 
 int dust_mpf_phi(dust_mpf *mpf, float bw, float *phi); /* MPF.phi mpf.py:40-57 */
 /* GaussianLikelihood.condition(action, new_obs) likelihoods.py:51-64 */
 int dust_mpf_condition(dust_mpf *mpf, const float *action, const float *new_obs);
+/* Control-channel noise inside the filter's one-step prediction (likelihoods.py:30-46 -> Particle.step particle.py:145-148 with
+ * model_cfg.ctrl_noise): `acts` there is the bare past action, so ONE da-vector is drawn per MPF.phi call - per SVGD step - and shared
+ * by all filter particles.  z [n][da]: recorded draws consumed one per step by the following dust_mpf_phi / dust_mpf_optimize calls;
+ * when used up (or z = NULL) a host generator seeded from model_cfg.seed draws them. */
+int dust_mpf_set_ctrl_noise(dust_mpf *mpf, const float *z, int n);
 /* occupancy grid for the Particle model's crash mask inside the one-step prediction */
 int dust_mpf_set_grid(dust_mpf *mpf, const float *grid, int nx, int ny, float off_x, float off_y);
 int dust_mpf_get_particles(dust_mpf *mpf, float *x);

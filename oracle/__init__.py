@@ -51,6 +51,7 @@ class _Cfg(C.Structure):
         ("grid", C.POINTER(C.c_float)),
         ("target", C.c_float * 4), ("w_state", C.c_float * 4), ("w_term", C.c_float * 4), ("w_ctrl", C.c_float * 2),
         ("w_obs", C.c_float),
+        ("velocity_ctrl", C.c_int), ("dyn_std", C.c_float * 2), ("ctrl_noise", C.POINTER(C.c_float)),
     ]
 
 
@@ -110,12 +111,15 @@ class Oracle:
                  params_log_space=False, dt=None, g=9.8, mass=1.0, length=1.0, w_cos=50.0, w_vel=1.0,
                  grid=None, cell_size=0.1, max_speed=5.0, max_accel=10.0, can_crash=True, with_obstacle=True,
                  target=(9.0, 9.0, 0.0, 0.0), w_state=(0.5, 0.5, 0.25, 0.25), w_term=(1e3, 1e3, 0.1, 0.1),
-                 w_ctrl=(0.2, 0.2), w_obs=1e6, mass_0dim=False):
+                 w_ctrl=(0.2, 0.2), w_obs=1e6, mass_0dim=False, control_type="acceleration", noise_std=(0.0, 0.0)):
         c = _Cfg()
         self.model = model
         c.model = MODEL_PENDULUM if model == "pendulum" else MODEL_PARTICLE
         c.N, c.S, c.M, c.H = N, S, M, H
-        c.da, c.ds = (1, 2) if model == "pendulum" else (2, 4)
+        vel = model != "pendulum" and control_type == "velocity"  # particle.py:41-48: a two-state model
+        c.da, c.ds = (1, 2) if model == "pendulum" else ((2, 2) if vel else (2, 4))
+        c.velocity_ctrl = int(vel)
+        c.dyn_std[:] = [float(v) for v in np.broadcast_to(np.asarray(noise_std, np.float32).reshape(-1), (2,))]
         up = list(uncertain_params) if uncertain_params else []
         c.P = max(len(up), 1)
         c.params_interleave = int(params_scalar_event)
@@ -138,9 +142,10 @@ class Oracle:
             c.nx, c.ny = self._grid.shape
             c.off_x, c.off_y = int(c.nx / 2), int(c.ny / 2)
             c.grid = _p(self._grid)
-        c.target[:] = target
-        c.w_state[:] = w_state
-        c.w_term[:] = w_term
+        pad4 = lambda v: (list(v) + [0.0] * 4)[:4]
+        c.target[:] = pad4(target)
+        c.w_state[:] = pad4(w_state)
+        c.w_term[:] = pad4(w_term)
         c.w_ctrl[:] = w_ctrl
         c.w_obs = w_obs
         self.c = c
@@ -154,8 +159,12 @@ class Oracle:
         return out
 
     # -- a2..a5
-    def rollout_cost(self, state, actions, params=None, a_reg=0.0, a_mat=None, a_seq=None, a_pre_diag=None, want_states=False):
+    def rollout_cost(self, state, actions, params=None, a_reg=0.0, a_mat=None, a_seq=None, a_pre_diag=None, want_states=False,
+                     ctrl_noise=None):
+        """ctrl_noise: recorded control-channel draws [H][M*S*N][da] of Particle(deterministic=False) (particle.py:145-148), or None."""
         c = self.c
+        cz = None if ctrl_noise is None else _f(ctrl_noise).reshape(c.H, c.M * c.S * c.N, c.da)
+        c.ctrl_noise = _p(cz)
         state, actions = _f(state).reshape(-1), _f(actions)
         params = None if params is None else _f(params).reshape(c.M, -1)
         costs = np.empty((c.S, c.N), np.float32)
@@ -165,6 +174,7 @@ class Oracle:
         a_pre = _f(np.ones(c.da) if a_pre_diag is None else a_pre_diag)
         lib().orc_rollout_cost(C.byref(c), _p(state), _p(actions), _p(params), C.c_float(a_reg), _p(a_mat), _p(a_seq),
                                _p(a_pre), _p(states), _p(costs))
+        c.ctrl_noise = None
         return (costs, states) if want_states else costs
 
     def rollout_cost_ut(self, state, actions, sigma_points, loc_weights, a_reg=0.0, a_mat=None, a_seq=None, a_pre_diag=None):

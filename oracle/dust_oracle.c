@@ -106,22 +106,48 @@ static inline void pendulum_step(const orc_cfg *c, const float *x, const float *
   out[1] = thd;
 }
 
-/* Particle.step particle.py:117-166 (deterministic=True; control noise 145-148 not modelled) */
-static inline void particle_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
+/* Particle.step particle.py:117-166.  z: this call's control-noise draw for this row ([da], standard normal) or NULL
+ * (deterministic=True, or noise_std = 0): acts += dyn_std * z (particle.py:145-148) - the dynamics see the noisy action, the costs the
+ * raw one (disco.py:306-310). */
+static inline void particle_step_z(const orc_cfg *c, const float *x, const float *a, const float *prow, const float *z, float *out) {
   val m = get_param(c, c->pmass, prow);
   float mf = tof(m);
   float dt = (float)c->dt;
-  float ax = clampf(a[0] / mf, -c->max_acc, c->max_acc);
-  float ay = clampf(a[1] / mf, -c->max_acc, c->max_acc);
+  float u0 = a[0], u1 = a[1];
+  if (z) {
+    u0 = u0 + c->dyn_std[0] * z[0];
+    u1 = u1 + c->dyn_std[1] * z[1];
+  }
+  float om = 1.0f;
+  const int crash = c->can_crash && c->with_obstacle;
+  if (crash) om = 1.0f - collision(c, x[0], x[1]);
+  if (c->velocity_ctrl) { /* particle.py:152-153 on a two-state row: x_dot = acts */
+    u0 = clampf(u0, -c->max_speed, c->max_speed);
+    u1 = clampf(u1, -c->max_speed, c->max_speed);
+    if (crash) {
+      out[0] = x[0] + (u0 * dt) * om;
+      out[1] = x[1] + (u1 * dt) * om;
+    } else {
+      out[0] = x[0] + u0 * dt;
+      out[1] = x[1] + u1 * dt;
+    }
+    out[0] = clampf(out[0], -c->max_speed, c->max_speed); /* next_states[..., -2:].clamp_ (particle.py:165): the positions */
+    out[1] = clampf(out[1], -c->max_speed, c->max_speed);
+    return;
+  }
+  float ax = clampf(u0 / mf, -c->max_acc, c->max_acc);
+  float ay = clampf(u1 / mf, -c->max_acc, c->max_acc);
   float xd[4] = {x[2], x[3], ax, ay};
-  if (c->can_crash && c->with_obstacle) {
-    float om = 1.0f - collision(c, x[0], x[1]);
+  if (crash) {
     for (int k = 0; k < 4; ++k) out[k] = x[k] + (xd[k] * dt) * om;
   } else {
     for (int k = 0; k < 4; ++k) out[k] = x[k] + xd[k] * dt;
   }
   out[2] = clampf(out[2], -c->max_speed, c->max_speed);
   out[3] = clampf(out[3], -c->max_speed, c->max_speed);
+}
+static inline void particle_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
+  particle_step_z(c, x, a, prow, NULL, out);
 }
 
 static inline void model_step(const orc_cfg *c, const float *x, const float *a, const float *prow, float *out) {
@@ -148,7 +174,7 @@ static inline float inst_cost(const orc_cfg *c, const float *x, const float *a) 
     return t1 + t2;
   }
   double sc = 0.0, cc = 0.0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < c->ds; ++k) { /* (velocity control: two state entries, particle.py:307-322) */
     float d = x[k] - c->target[k];
     sc += (double)((d * d) * c->w_state[k]);
   }
@@ -159,7 +185,7 @@ static inline float inst_cost(const orc_cfg *c, const float *x, const float *a) 
 static inline float term_cost(const orc_cfg *c, const float *x) {
   if (c->model == ORC_MODEL_PENDULUM) return inst_cost(c, x, NULL);
   double sc = 0.0;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < c->ds; ++k) {
     float d = x[k] - c->target[k];
     sc += (double)((d * d) * c->w_term[k]);
   }
@@ -200,7 +226,10 @@ void orc_rollout_cost(const orc_cfg *c, const float *state, const float *actions
       double tot = 0.0;
       for (int t = 0; t < H; ++t) {
         tot += (double)inst_cost(c, x, act + (size_t)t * da); /* cost of the state BEFORE the action (disco.py:306) */
-        model_step(c, x, act + (size_t)t * da, prow, xn);
+        if (c->model == ORC_MODEL_PARTICLE && c->ctrl_noise) /* draw [t][r] of this rollout (particle.py:145-148) */
+          particle_step_z(c, x, act + (size_t)t * da, prow, c->ctrl_noise + ((size_t)t * M * SN + r) * da, xn);
+        else
+          model_step(c, x, act + (size_t)t * da, prow, xn);
         for (int k = 0; k < ds; ++k) x[k] = xn[k];
         if (so)
           for (int k = 0; k < ds; ++k) so[(size_t)(t + 1) * ds + k] = x[k];

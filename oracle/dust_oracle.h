@@ -54,6 +54,13 @@ typedef struct {
   float off_x, off_y;
   const float *grid; /* [nx][ny] occupancy, row-major (obstacle_map.py:41) */
   float target[4], w_state[4], w_term[4], w_ctrl[2], w_obs;
+  /* Particle(control_type="velocity") particle.py:41-48, 152-153: a two-state model (ds = 2): acts.clamp_(+-max_speed), x_dot = acts,
+   * and the closing clamp (particle.py:165) lands on the positions */
+  int velocity_ctrl;
+  /* Particle(deterministic=False) particle.py:145-148: acts += dyn_std * randn_like(acts) in every model.step call.  ctrl_noise holds
+   * the recorded standard-normal draws [H][M*S*N][da] of one MultiDISCO._rollout (rollout r = (m*S + s)*N + n), or NULL (no noise) */
+  float dyn_std[2];
+  const float *ctrl_noise;
 } orc_cfg;
 
 /* a1  CostLikelihood.sample likelihoods.py:81-101: actions = theta + L eps (diagonal L) */

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import elemerr, relerr
+from helpers import RecordedDraws, elemerr, relerr
 from test_host_mirror_cpu import PARTICLE_ENV
 from test_oracle_golden import k1_tolerance
 
@@ -361,7 +361,7 @@ def test_pendulum_driver_vs_reference_driver(golden):
     """the build's `run_pendulum_simulation` against the REFERENCE's own driver loop
     (dust/utils/simulations.py:13-190, run by tests/golden/make_golden_driver.py with a stand-in plant) over three control ticks of
     the dual-inference configuration: same call order per tick (optimize -> forward unless warming up -> plant step ->
-    mpf.optimize), every random draw of the reference run replayed (dust_amd.utils.replay).  Per-tick products: applied action,
+    mpf.optimize), every random draw of the reference run replayed (MultiDISCO.draw_source).  Per-tick products: applied action,
     plant state, particle weights, the particles' first action after forward, the dynamics filter's particles."""
     import torch.distributions as dist
 
@@ -369,7 +369,6 @@ def test_pendulum_driver_vs_reference_driver(golden):
     from dust_amd.inference import MPF, GaussianLikelihood, get_gmm
     from dust_amd.kernels import RBFKernel
     from dust_amd.models import PendulumModel
-    from dust_amd.utils import replay
     from dust_amd.utils.simulations import run_pendulum_simulation
 
     g = golden("driver_pend_dual")
@@ -387,14 +386,14 @@ def test_pendulum_driver_vs_reference_driver(golden):
                              log_space=False)
     mpf = MPF(init_particles=torch.tensor(g["mpf_init"]), likelihood=lik, optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]),
               bw=float(g["mpf_bw"]), bw_scale=1.0)
-    with replay.feed(eps=list(g["eps"]), params=list(g["params"])):
-        df = run_pendulum_simulation(
-            init_state, init_policies, {"uncertain_params": ("length", "mass")}, dyn_prior,
-            [{"length": float(g["true_length"]), "mass": float(g["true_mass"])}], ctrl, use_exact_model=False, use_svmpc=True,
-            svmpc_kwargs=dict(init_particles=init_policies, prior=prior, kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1,
-                              optimizer_class=torch.optim.SGD, lr=float(g["lr"])),
-            lik_kwargs={"alpha": 1.0, "n_samples": S}, mpf=mpf, mpf_bw=float(g["mpf_bw"]), mpf_steps=int(g["mpf_steps"]), episodes=1,
-            steps=steps, warm_up=warm)
+    ctrl.draw_source = RecordedDraws(eps=list(g["eps"]), params=list(g["params"]))  # (deep-copied with the controller per episode)
+    df = run_pendulum_simulation(
+        init_state, init_policies, {"uncertain_params": ("length", "mass")}, dyn_prior,
+        [{"length": float(g["true_length"]), "mass": float(g["true_mass"])}], ctrl, use_exact_model=False, use_svmpc=True,
+        svmpc_kwargs=dict(init_particles=init_policies, prior=prior, kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1,
+                          optimizer_class=torch.optim.SGD, lr=float(g["lr"])),
+        lik_kwargs={"alpha": 1.0, "n_samples": S}, mpf=mpf, mpf_bw=float(g["mpf_bw"]), mpf_steps=int(g["mpf_steps"]), episodes=1,
+        steps=steps, warm_up=warm)
     assert len(df) == steps
     for t in range(steps):
         # the state each tick started from (tick t+1's input = the plant state after tick t's action)
@@ -428,7 +427,6 @@ def test_particle_episode_vs_reference_driver(golden, tag):
     from dust_amd.inference import SVMPC, ExponentiatedUtility, get_gmm
     from dust_amd.kernels import RBFKernel
     from dust_amd.models import Particle
-    from dust_amd.utils import replay
     from dust_amd.utils.simulations import run_particle_episode
 
     g = golden("episode_part_" + tag)
@@ -460,9 +458,9 @@ def test_particle_episode_vs_reference_driver(golden, tag):
     lik = ExponentiatedUtility(1.0, controller=ctrl, model=model, n_samples=S)
     sv = RecSVMPC(init_particles=torch.tensor(g["init_policies"]), prior=prior, likelihood=lik, kernel=RBFKernel(), n_particles=N,
                   bw_scale=1.0, n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]), weighted_prior=True)
-    with replay.feed(eps=list(g["eps"]), params=list(g["params"])):
-        cum = run_particle_episode(torch.tensor(g["init_state"]), model, dyn, ctrl, use_svmpc=True, warm_up=int(g["warm_up"]), svmpc=sv,
-                                   load=float(g["load"]), steps=int(g["steps"]))
+    ctrl.draw_source = RecordedDraws(eps=list(g["eps"]), params=list(g["params"]))
+    cum = run_particle_episode(torch.tensor(g["init_state"]), model, dyn, ctrl, use_svmpc=True, warm_up=int(g["warm_up"]), svmpc=sv,
+                               load=float(g["load"]), steps=int(g["steps"]))
     n_run = int(g["steps_run"])
     assert len(rec["state_in"]) == n_run, (len(rec["state_in"]), n_run)  # same termination step
     ref_cum = float(g["cum_cost"])
@@ -514,3 +512,83 @@ def test_skid_steer_through_the_mirror_classes(golden):
                      inst_cost_fn=lambda s, a, **k: s.sum(-1), term_cost_fn=lambda s, **k: s.sum(-1), params_sampling=None)
     with pytest.raises(NotImplementedError):
         bad.forward(torch.tensor(g["state"]), model, None, ext_actions=torch.tensor(g["ext_actions"]))
+
+
+@pytest.mark.parametrize("name", ["part_k1_noisy", "part_k1_velocity", "part_k2_noisy_vel"])
+def test_particle_control_noise_and_velocity_through_the_class_api(golden, name):
+    """`Particle(deterministic=False, noise_std=...)` - the reference's constructor default for `deterministic` - and
+    `control_type="velocity"` through the reference's own classes (particle.py:145-153): the controller forwards both to the device
+    rollouts, and the recorded draws of the reference run (policy noise, dynamics samples, control-channel noise) replayed through
+    `MultiDISCO.draw_source` reproduce its costs (1e-5), rollout states (1e-5) and particles after every SVGD step (2e-3, whole chain)."""
+    import torch.distributions as dist
+
+    from dust_amd.controllers import MultiDISCO
+    from dust_amd.inference import SVMPC, ExponentiatedUtility, get_gmm
+    from dust_amd.kernels import RBF, RBFKernel, iid_mp
+    from dust_amd.models import Particle
+
+    g = golden(name)
+    N, H, S, M = (int(g[k]) for k in ("N", "H", "S", "M"))
+    env = dict(PARTICLE_ENV, deterministic=bool(int(g["deterministic"])), noise_std=torch.tensor(g["dyn_std"]), control_type=str(g["control_type"]))
+    if env["control_type"] == "velocity":
+        env.update(init_state=[-4.0, -3.0], target_state=[4.0, 4.5])
+    model = Particle(**env, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    assert model.observation_space.dim == int(g["ds"])
+    scalar = bool(int(g["params_scalar_event"]))
+    if scalar:
+        pdist = dist.Normal(2.0, 0.1)
+    else:
+        pdist = dist.MixtureSameFamily(dist.Categorical(torch.ones(16)),
+                                       dist.Independent(dist.MultivariateNormal(torch.zeros(16, 1), 0.25 * torch.eye(1)), 0))
+    sig = float(g["sigma_a"])
+    ctrl = MultiDISCO(model.observation_space, model.action_space, H, N, S, temperature=float(g["temperature"]), a_cov=sig ** 2 * torch.eye(2),
+                      params_sampling=True, params_samples=M, params_log_space=bool(int(g["params_log_space"])),
+                      inst_cost_fn=model.default_inst_cost, term_cost_fn=model.default_term_cost)
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    kind = str(g["kernel_kind"])
+    kernel = RBFKernel() if kind == "K1" else iid_mp(base_kernel=RBF(bandwidth=-1), ctrl_dim=2, indep_controls=True)
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), float(g["sigma_p"]) ** 2 * torch.eye(2))
+    lik = ExponentiatedUtility(float(g["alpha"]), controller=ctrl, model=model, n_samples=S)
+    sv = SVMPC(init_particles=torch.tensor(g["theta0"]), prior=prior, likelihood=lik, kernel=kernel, n_particles=N, bw_scale=1.0, n_steps=1,
+               optimizer_class=torch.optim.SGD, lr=float(g["lr"]), weighted_prior=bool(int(g["weighted_prior"])))
+    T, K = g["eps"].shape[:2]
+    cz = list(g["ctrl_noise"].reshape((T * K,) + g["ctrl_noise"].shape[2:])) if "ctrl_noise" in g else None
+    # (a) one likelihood sample + one MultiDISCO.forward from the reference's first inputs: costs and states at 1e-5
+    ctrl.draw_source = RecordedDraws(params=[g["params"][0, 0]] * 2, ctrl_noise=None if cz is None else [cz[0]] * 2)
+    state0 = torch.tensor(g["state"][0, 0])
+    costs, actions = lik.sample(torch.tensor(g["theta0"]), state0, pdist, eps=g["eps"][0, 0])
+    assert np.array_equal(actions.numpy(), g["actions"][0, 0])
+    assert elemerr(costs.numpy(), g["costs"][0, 0]) < 1e-5
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    _, states, _, _, _ = ctrl.forward(state0, model, pdist, ext_actions=torch.tensor(g["actions"][0, 0]))
+    assert elemerr(states.numpy(), g["states_iter0"][0]) < 1e-5
+    # (b) the optimisation chain
+    ctrl.a_mat = torch.tensor(g["a_mat0"])
+    ctrl.draw_source = RecordedDraws(eps=list(g["eps"].reshape((T * K,) + g["eps"].shape[2:])),
+                                     params=list(g["params"].reshape((T * K,) + g["params"].shape[2:])), ctrl_noise=cz)
+    for t in range(T):
+        state = torch.tensor(g["state"][t, 0])
+        sv.optimize(state, pdist, n_steps=K)
+        scale = np.abs(g["theta_after"][t, K - 1]).max()
+        assert np.abs(sv.theta.numpy() - g["theta_after"][t, K - 1]).max() / scale < 2e-3, (name, t)
+        sv.forward(state, pdist)
+        sv.theta = torch.tensor(g["tick_theta_rolled"][t])  # re-sync with the reference (stage-local checks)
+    assert ctrl._ctx.tick_stats()["tick2"] == 0  # (these configurations run on the launch-per-iteration path)
+
+
+def test_mpf_control_noise_through_the_class_api(golden):
+    """MPF over `Particle(deterministic=False)` through the reference's classes; recorded draws via `MPF.draw_source`."""
+    from dust_amd.inference import MPF, GaussianLikelihood
+    from dust_amd.models import Particle
+
+    g = golden("mpf_part_noisy")
+    env = dict(PARTICLE_ENV, deterministic=False, noise_std=torch.tensor(g["dyn_std"]))
+    model = Particle(**env, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    lik = GaussianLikelihood(initial_obs=torch.tensor(g["obs0"]), obs_std=float(g["obs_std"]), model=model, log_space=True)
+    mpf = MPF(init_particles=torch.tensor(g["x0"]), likelihood=lik, optimizer_class=torch.optim.SGD, lr=float(g["lr"]), bw=float(g["bw"]))
+    mpf.draw_source = RecordedDraws(mpf_noise=list(g["noise1"]) + list(g["noise2"]))
+    n = int(g["n_steps"])
+    grads, _ = mpf.optimize(torch.tensor(g["action"]), torch.tensor(g["obs1"]), bw=float(g["bw"]), n_steps=n)
+    assert elemerr(mpf.x.numpy(), g["x_final"]) < 1e-5 and relerr(grads.numpy(), g["grad_norms"]) < 2e-4
+    mpf.optimize(torch.tensor(g["action2"]), torch.tensor(g["obs2"]), bw=float(g["bw"]), n_steps=n)
+    assert elemerr(mpf.x.numpy(), g["x_final2"]) < 1e-5

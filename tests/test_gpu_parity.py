@@ -9,7 +9,7 @@ import pytest
 
 import os
 
-from helpers import tick2_ticks_expected, elemerr, is_adam, relerr, scenario_kwargs
+from helpers import feed_ctrl_noise, tick2_ticks_expected, elemerr, is_adam, relerr, scenario_kwargs
 from test_oracle_golden import K1_F64_CASES, SVMPC_CASES, _prior_at, k1_tolerance
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +23,8 @@ def ctx_kwargs(g):
               weighted_prior=bool(int(g["weighted_prior"])), roll_strategy=str(g["roll_strategy"]))
     a_reg, temp = float(g["a_reg"]), float(g["temperature"])
     kw["ctrl_penalty"] = 1.0 - a_reg / temp
+    if "deterministic" in g:  # Particle(deterministic=) particle.py:31 (round-5 fixtures)
+        kw["deterministic"] = bool(int(g["deterministic"]))
     if "k2_bandwidth" in g and float(g["k2_bandwidth"]) >= 0:
         kw["k2_bandwidth"] = float(g["k2_bandwidth"])  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth
     return kw
@@ -63,6 +65,7 @@ def test_rollout_costs_vs_reference(golden, name):
             c.set_theta(theta)
             c.set_a_mat(a_mat)
             params = g["params"][t, k] if "params" in g else None
+            feed_ctrl_noise(c, g, t, k)
             costs, actions = c.likelihood_sample(g["state"][t, k], g["eps"][t, k], params, want_actions=True)
             assert np.array_equal(actions, g["actions"][t, k]), "a1 must be bit-exact"
             assert elemerr(costs, g["costs"][t, k]) < TOL, (name, t, k)
@@ -74,6 +77,7 @@ def test_rollout_costs_vs_reference(golden, name):
             if ulp_logit < 1e-3:
                 assert relerr(c.get_a_mix(), g["a_mix"][t, k], floor=1e-30) < 2e-3
             if k == 0:
+                feed_ctrl_noise(c, g, t, k)
                 _, states, _, _ = c.disco_forward(g["state"][t, k], g["actions"][t, k], params, want_states=True)
                 assert elemerr(states, g["states_iter0"][t]) < TOL
             a_mat = g["omega_amat"][t, k]
@@ -166,6 +170,7 @@ def test_tick_chain_vs_oracle_and_reference(golden, name):
     c.set_a_mat(g["a_mat0"])
     for t in range(T):
         params = g["params"][t] if "params" in g else None
+        feed_ctrl_noise(c, g, t)
         c.svmpc_optimize(g["state"][t, 0], K, g["eps"][t], params)
         th = c.get_theta()
         scale = np.abs(g["theta_after"][t, K - 1]).max()
@@ -198,6 +203,7 @@ def test_forward_vs_reference(golden, name):
         # a_mat as it stood before the last iteration (it enters the costs when ctrl_penalty != 1)
         a_prev = g["omega_amat"][t, K - 2] if K > 1 else (g["a_mat0"] if t == 0 else g["omega_amat"][t - 1, K - 1])
         c.set_a_mat(a_prev)
+        feed_ctrl_noise(c, g, t, K - 1)
         c.likelihood_sample(g["state"][t, K - 1], g["eps"][t, K - 1], params)
         c.set_theta(th)
         c.set_prior(mu, mix)
@@ -272,6 +278,78 @@ def test_mpf(golden, name):
     smp = m2.prior_sample(20000, seed=3)
     means, pbw = m2.get_prior()
     assert abs(float(smp.mean()) - float(means.mean())) < 0.02 and pbw == pytest.approx(bw)
+
+
+def test_mpf_control_noise_vs_reference(golden):
+    """The filter over Particle(deterministic=False) (likelihoods.py:30-46 -> particle.py:145-148): one control-noise vector per SVGD
+    step, shared by all filter particles; the reference's recorded draws replayed through dust_mpf_set_ctrl_noise.  All three forms
+    of the optimisation kernel (single workgroup, data-polled grid, counter grid) take the per-step effective action."""
+    import os
+
+    from dust_amd import MpfContext
+    from oracle import grid_4x4_map
+
+    g = golden("mpf_part_noisy")
+    bw, n = float(g["bw"]), int(g["n_steps"])
+    kw = dict(model="particle", uncertain_params=("mass",), log_space=True, obs_std=float(g["obs_std"]), lr=float(g["lr"]), init_bw=bw,
+              grid=grid_4x4_map(), mass=2.0, deterministic=False, noise_std=tuple(float(v) for v in g["dyn_std"]))
+    m = MpfContext(g["x0"], g["obs0"], **kw)
+    m.condition(g["action"], g["obs1"])
+    m.set_ctrl_noise(g["phi0_noise"][None])
+    assert elemerr(m.phi(bw), g["phi0"]) < TOL
+    for env in ({}, {"DUST_MPF_GRID": "1"}, {"DUST_MPF_GRID": "1", "DUST_MPF_POLL": "0"}):
+        old = {k: os.environ.get(k) for k in ("DUST_MPF_GRID", "DUST_MPF_POLL")}
+        os.environ.update(env)
+        try:
+            m2 = MpfContext(g["x0"], g["obs0"], **kw)
+            m2.set_ctrl_noise(np.concatenate([g["noise1"], g["noise2"]]))
+            gn = m2.optimize(g["action"], g["obs1"], bw, n)
+            assert elemerr(m2.get_particles(), g["x_final"]) < TOL, env
+            assert relerr(gn, g["grad_norms"]) < 2e-4
+            gn2 = m2.optimize(g["action2"], g["obs2"], bw, n)
+            assert elemerr(m2.get_particles(), g["x_final2"]) < TOL, env
+            assert relerr(gn2, g["grad_norms2"]) < 2e-4
+            if env:
+                assert m2.stats()["grid"] == 2 and m2.stats()["fallback"] == 0, (env, m2.stats())
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    # without the recorded draws the library's own generator takes over: a different, finite answer
+    m3 = MpfContext(g["x0"], g["obs0"], **kw)
+    m3.optimize(g["action"], g["obs1"], bw, n)
+    x3 = m3.get_particles()
+    assert np.isfinite(x3).all() and elemerr(x3, g["x_final"]) > 1e-4
+
+
+def test_particle_control_noise_philox_statistics():
+    """Product form of the control noise (no recorded draws): a Philox stream of its own.  With zero policy noise (eps = 0) and a free
+    map the final velocity of a rollout is linear in the H control-noise draws: v_H = v_0 + dt / m * sum_t (a_t + std z_t) - mean and
+    variance over the S * N * M rollouts are checked against their closed forms, and two launches draw different noise."""
+    from dust_amd import Context
+
+    N, S, M, H, std, mass, dt = 64, 64, 2, 20, (0.7, 0.3), 2.0, 0.015
+    c = Context(model="particle", N=N, S=S, M=M, H=H, uncertain_params=("mass",), sampling=True, with_obstacle=False, can_crash=False,
+                max_speed=1e9, max_accel=1e9, deterministic=False, noise_std=std, sigma_a=1.0, mass=mass, dt=dt)
+    theta = np.full((N, H, 2), 0.5, np.float32)
+    c.set_theta(theta)
+    st = np.zeros(4, np.float32)
+    params = np.full((M, 1), mass, np.float32)
+    _, s1, _, _ = c.disco_forward(st, np.broadcast_to(theta, (S, N, H, 2)).copy(), params, want_states=True)
+    _, s2, _, _ = c.disco_forward(st, np.broadcast_to(theta, (S, N, H, 2)).copy(), params, want_states=True)
+    assert not np.array_equal(s1, s2), "every launch draws fresh control noise (the stream position advances)"
+    v = s1[..., H, 2:4].reshape(-1, 2).astype(np.float64)
+    n = v.shape[0]
+    for d in range(2):
+        want_mean, want_std = dt / mass * H * 0.5, dt / mass * std[d] * np.sqrt(H)
+        assert abs(v[:, d].mean() - want_mean) < 5 * want_std / np.sqrt(n)
+        assert abs(v[:, d].std() / want_std - 1.0) < 5 / np.sqrt(2 * n)
+    # the two control channels and the dynamics samples draw independently
+    assert abs(np.corrcoef(v[:, 0], v[:, 1])[0, 1]) < 5 / np.sqrt(n)
+    vm = s1[..., H, 2].reshape(M, -1)
+    assert abs(np.corrcoef(vm[0], vm[1])[0, 1]) < 5 / np.sqrt(vm.shape[1])
 
 
 @pytest.mark.parametrize("name", ["mpf_pend_adam", "mpf_part_log_adam"])

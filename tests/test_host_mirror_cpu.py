@@ -84,6 +84,31 @@ def test_plant_steps_match_reference_rollouts(golden):
         x = p.step(x, torch.tensor(ac[:, t]), {"mass": torch.full((x.shape[0], 1), float(prm[0]))})
         assert np.allclose(x.numpy(), st[:, t + 1], rtol=1e-5, atol=1e-5)
     assert p.params_to_dict(torch.tensor([[1.0], [2.0]]))["mass"].shape == (2, 1)
+    # velocity control (particle.py:41-48, 152-153, 165): a two-state model whose closing clamp lands on the positions
+    g = golden("part_k1_velocity")
+    env = dict(PARTICLE_ENV, control_type="velocity", init_state=[-4.0, -3.0], target_state=[4.0, 4.5])
+    pv = Particle(**env, uncertain_params=["mass"], mass=torch.tensor(2.0))
+    assert pv.observation_space.dim == 2 and pv.w_state.tolist() == [0.5, 0.5] and pv.w_term.tolist() == [1e3, 1e3]
+    assert pv.action_space.high.tolist() == [5.0, 5.0]
+    st, ac = g["states_iter0"][0][1, 3], g["actions"][0, 0][3]  # [N,H+1,2], [N,H,2]
+    x = torch.tensor(st[:, 0])
+    for t in range(ac.shape[1]):
+        x = pv.step(x, torch.tensor(ac[:, t]))
+        assert np.allclose(x.numpy(), st[:, t + 1], rtol=1e-6, atol=1e-6)
+    assert float(np.abs(st).max()) <= 5.0
+    # control-channel noise on the plant side (particle.py:145-148): the recorded draw of the reference's own plant step
+    g = golden("part_k1_noisy")
+    pn = Particle(**dict(PARTICLE_ENV, deterministic=False, noise_std=torch.tensor(g["dyn_std"])), uncertain_params=["mass"], mass=torch.tensor(2.0))
+    x0, a0 = torch.tensor(g["state"][0, 0]).view(1, -1), torch.tensor(g["tick_a_seq"][0][0]).view(1, -1)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: torch.tensor(g["plant_noise"][0])
+    try:
+        nxt = pn.step(x0, a0)
+    finally:
+        torch.randn_like = orig
+    assert np.allclose(nxt.numpy().reshape(-1), g["state"][1, 0], rtol=1e-6, atol=1e-6)
+    with pytest.raises(IOError):
+        Particle(**dict(PARTICLE_ENV, control_type="torque"))
 
 
 def test_skid_steer_plant_step_matches_reference(golden):

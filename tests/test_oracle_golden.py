@@ -9,12 +9,14 @@ import pytest
 
 import oracle
 from oracle import Oracle
-from helpers import elemerr, is_adam, relerr, scenario_kwargs
+from helpers import ctrl_noise_of, elemerr, is_adam, relerr, scenario_kwargs
 
 TOL = 1e-5
 SVMPC_CASES = ["pend_k1", "pend_k1_close", "pend_k2", "pend_k1_params", "pend_k1_expcost", "pend_k1_ctrlpen", "pend_k1_mean",
                "pend_cfg1", "part_k1_gmm", "part_k2_gmm", "part_k2shared", "part_k1_scalar", "part_k1_near_obst",
-               "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64", "pend_k2_fixedbw", "part_k2shared_fixedbw"]
+               "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64", "pend_k2_fixedbw", "part_k2shared_fixedbw",
+               # round 5: control-channel noise (particle.py:145-148) and velocity control (particle.py:152-153)
+               "part_k1_noisy", "part_k1_velocity", "part_k2_noisy_vel", "part_k1_noisy_zero"]
 K1_F64_CASES = ["pend_k1_f64", "pend_k1_mid_f64"]
 
 
@@ -46,11 +48,15 @@ def test_actions_rollout_costs(golden, name):
             params = g["params"][t, k] if "params" in g else None
             a_reg = float(g["a_reg"])
             a_pre = 1.0 / _sig(g, "sigma_a") ** 2
+            cz = ctrl_noise_of(g, t, k)
             if k == 0:
-                costs, states = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre, want_states=True)
+                costs, states = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre, want_states=True, ctrl_noise=cz)
                 assert elemerr(states, g["states_iter0"][t]) < TOL
+                if cz is not None and float(np.abs(g["dyn_std"]).max()) > 0:  # the fixture must notice the noise
+                    _, quiet = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre, want_states=True)
+                    assert elemerr(quiet, g["states_iter0"][t]) > 1e-3
             else:
-                costs = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre)
+                costs = o.rollout_cost(g["state"][t, k], actions, params, a_reg, a_mat, None, a_pre, ctrl_noise=cz)
             assert elemerr(costs, g["costs"][t, k]) < TOL, name
             # a6 side effects (MultiDISCO.forward): a_mat += sum_s omega eps ; a_mix
             _, a_mat, a_mix = o.disco_weights(g["costs"][t, k], actions, np.zeros(o.D), float(g["temperature"]), a_mat)
@@ -233,6 +239,33 @@ def test_mpf_adam(golden, name):
     # restarting the optimiser state at the second call (what SVMPC does at every roll) must NOT reproduce the reference here
     x2r, *_ = o.mpf_optimize_adam(x, pm, pbw, g["obs1"], g["action2"], g["obs2"], float(g["obs_std"]), ls, bw, lr, n)
     assert relerr(x2r, g["x_final2"]) > 10 * TOL
+
+
+def _noisy_actions(action, dyn_std, z):
+    """acts = action + dyn_std * z in fp32, one draw per phi() call (particle.py:145-148 reached through likelihoods.py:30-46)."""
+    return (np.asarray(action, np.float32)[None, :] + (np.asarray(dyn_std, np.float32)[None, :] * np.asarray(z, np.float32))).astype(np.float32)
+
+
+def test_mpf_control_noise(golden):
+    """MPF over Particle(deterministic=False): every phi() call of the reference's filter draws ONE control-noise vector (`acts` is the
+    bare past action at likelihoods.py:44) - the one-step prediction and its Jacobian use action + dyn_std * z for all particles.
+    The recorded draws are replayed step by step through the oracle's phi + SGD."""
+    g = golden("mpf_part_noisy")
+    o = Oracle(model="particle", uncertain_params=("mass",), mass=2.0)
+    bw, lr, n, std = float(g["bw"]), float(g["lr"]), int(g["n_steps"]), g["dyn_std"]
+    a0 = _noisy_actions(g["action"], std, g["phi0_noise"][None])[0]
+    assert relerr(o.mpf_phi(g["x0"], g["x0"], bw, g["obs0"], a0, g["obs1"], float(g["obs_std"]), True, bw), g["phi0"]) < TOL
+    assert relerr(o.mpf_phi(g["x0"], g["x0"], bw, g["obs0"], g["action"], g["obs1"], float(g["obs_std"]), True, bw), g["phi0"]) > 1e-3
+    x = g["x0"].copy()
+    for past, act, obs, zs, want_x, want_gn in ((g["obs0"], g["action"], g["obs1"], g["noise1"], g["x_final"], g["grad_norms"]),
+                                                (g["obs1"], g["action2"], g["obs2"], g["noise2"], g["x_final2"], g["grad_norms2"])):
+        gn = []
+        for a_eff in _noisy_actions(act, std, zs):
+            phi = o.mpf_phi(x, x, bw, past, a_eff, obs, float(g["obs_std"]), True, bw)
+            gn.append(float(np.sqrt((phi.astype(np.float64) ** 2).sum())))
+            x = o.sgd(x, phi, lr)
+        assert relerr(x, want_x) < TOL
+        assert relerr(np.asarray(gn), want_gn) < 2e-4
 
 
 def test_unscented_transform_costs_vs_reference(golden):
