@@ -121,6 +121,7 @@ SYMBOLS = {
     "dust_svmpc_tick": (C.c_int, [VP, FP, C.c_int, VP, FP, C.c_int, FP, FP]),
     "dust_get_costs": (C.c_int, [VP, FP]),
     "dust_get_actions": (C.c_int, [VP, FP]),
+    "dust_get_states_rows": (C.c_int, [VP, C.POINTER(C.c_longlong), C.c_int, VP]),
     "dust_get_score": (C.c_int, [VP, FP]),
     "dust_get_phi": (C.c_int, [VP, FP]),
     "dust_get_score_parts": (C.c_int, [VP, FP, FP]),

@@ -411,6 +411,13 @@ class Context:
     def get_costs(self):
         return self._get(L.load().dust_get_costs, (self.S, self.N))
 
+    def get_states_rows(self, rows, f16=False):
+        """Trajectories [len(rows)][H+1][ds] of the states the last stored-states sample left on the device; rows = (m*S + s)*N + n."""
+        r = np.ascontiguousarray(np.asarray(rows, np.int64).reshape(-1))
+        out = np.empty((r.size, self.H + 1, self.ds), np.float16 if f16 else np.float32)
+        L.check(L.load().dust_get_states_rows(self._h, r.ctypes.data_as(C.POINTER(C.c_longlong)), int(r.size), C.c_void_p(out.ctypes.data)))
+        return out
+
     def get_score(self):
         return self._get(L.load().dust_get_score, (self.N, self.H, self.da))
 

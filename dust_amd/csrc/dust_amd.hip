@@ -187,6 +187,7 @@ struct dust_ctx {
   int graph_seen;     // consecutive eager ticks with the same shape (capture on the 2nd)
   bool capturing;
   bool have_sample, actions_valid;
+  bool states_valid, states_f16;  // the last rollout launch left states [M][S][N][H+1][ds] in `states` (binary16 when states_f16)
   bool k2_bw_ahead;   // K2: transpose + bandwidths of the current theta are already in flight on the side stream
   float k2_fixed_h;   // > 0: fixed-bandwidth RBF (dust_set_k2_bandwidth), else the median trick
   bool noise_f16;     // the eps / actions handed to the current call are binary16 (DUST_EPS_F16), set by the API entry points
@@ -1434,6 +1435,8 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
   HIP_TRY(hipGetLastError());
   c->actions_valid = o.want_actions;
   c->actions_f16 = o.want_actions && o.store_f16;
+  c->states_valid = o_in.want_states;
+  c->states_f16 = o_in.want_states && o_in.store_f16;
   c->stein_dirty = false;
   return DUST_OK;
 }
@@ -1505,6 +1508,36 @@ static int copy_out_SN(dust_ctx *c, const float *srcT, float *host) {  // device
   transpose2_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(srcT, c->tmp, c->N, c->S);
   HIP_TRY(hipGetLastError());
   return d2h(c, host, c->tmp, (size_t)n * sizeof(float));
+}
+
+// rows[i] = (m*S + s)*N + n -> out row i ([H+1][ds] values); 64-bit row indices: the states of BASELINE configs[2] are 2.77 G values
+__global__ void gather_rows_kernel(const void *src, void *dst, const long long *rows, int n_rows, int row_elems, int elem_bytes) {
+  const int i = blockIdx.x;
+  if (i >= n_rows) return;
+  const size_t base = (size_t)rows[i] * (size_t)row_elems;
+  for (int k = threadIdx.x; k < row_elems; k += blockDim.x) {
+    if (elem_bytes == 2) reinterpret_cast<uint16_t *>(dst)[(size_t)i * row_elems + k] = reinterpret_cast<const uint16_t *>(src)[base + k];
+    else reinterpret_cast<uint32_t *>(dst)[(size_t)i * row_elems + k] = reinterpret_cast<const uint32_t *>(src)[base + k];
+  }
+}
+extern "C" int dust_get_states_rows(dust_ctx *c, const long long *rows, int n_rows, void *out) {
+  if (!c || !rows || !out || n_rows < 1) return fail(DUST_ERR_INVALID, "bad argument");
+  TRY(settle_pending(c));
+  if (!c->states_valid || !c->states)
+    return fail(DUST_ERR_STATE, "no stored states on the device: run a sample with DUST_STORE_STATES (or a forward that returns states) first");
+  const long long R = (long long)c->M * c->S * c->N;
+  for (int i = 0; i < n_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= R) return fail(DUST_ERR_INVALID, "row %lld outside [0, M*S*N = %lld)", rows[i], R);
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  const int row_elems = (c->H + 1) * c->ds, eb = c->states_f16 ? 2 : 4;
+  const size_t idx_floats = ((size_t)n_rows * sizeof(long long) + 3) / 4, out_floats = ((size_t)n_rows * row_elems * eb + 3) / 4;
+  TRY(ensure(&c->tmp, &c->tmp_cap, idx_floats + 2 + out_floats));
+  long long *idx_dev = reinterpret_cast<long long *>(c->tmp);  // (hipMalloc'd: 256-byte aligned)
+  void *dst = c->tmp + ((idx_floats + 1) & ~(size_t)1);
+  TRY(h2d(c, idx_dev, rows, (size_t)n_rows * sizeof(long long)));
+  gather_rows_kernel<<<n_rows, 64, 0, c->stream>>>(c->states, dst, idx_dev, n_rows, row_elems, eb);
+  HIP_TRY(hipGetLastError());
+  return d2h(c, out, dst, (size_t)n_rows * row_elems * eb);
 }
 
 extern "C" int dust_get_costs(dust_ctx *c, float *costs) {

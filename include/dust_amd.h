@@ -226,6 +226,11 @@ int dust_svmpc_tick(dust_ctx *ctx, const float *state, int n_steps, const float 
 /* stage outputs of the last call, for parity tests ([S][N] / [N][H][da] / [N]) */
 int dust_get_costs(dust_ctx *ctx, float *costs);
 int dust_get_actions(dust_ctx *ctx, float *actions);
+/* Trajectories of the states the last stored-states sample left on the device (MultiDISCO.forward's `states` [M][S][N][H+1][ds],
+ * disco.py:190-200, 394 - 11 GB at BASELINE configs[2]; kept in HBM by dust_likelihood_sample(flags & DUST_STORE_STATES) and by
+ * dust_disco_forward): rows[i] = (m*S + s)*N + n selects one rollout, out receives n_rows x [H+1][ds] values - fp32, or binary16 when
+ * the sample ran with DUST_STORE_F16.  For callers (and parity tests) that need some rollouts, not an 11 GB copy. */
+int dust_get_states_rows(dust_ctx *ctx, const long long *rows, int n_rows, void *out);
 int dust_get_score(dust_ctx *ctx, float *score);
 int dust_get_phi(dust_ctx *ctx, float *phi);
 /* the two halves of the score of the last SVGD iteration: grad_lik (svmpc.py:50-53) and grad_pri (svmpc.py:38-41), [N][H][da] each;
