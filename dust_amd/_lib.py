@@ -119,6 +119,8 @@ SYMBOLS = {
     "dust_svmpc_forward_ex": (C.c_int, [VP, C.c_int, FP, FP, FP]),
     "dust_likelihood_sample_at": (C.c_int, [VP, FP, FP, VP, FP, C.c_int, FP, FP]),
     "dust_svmpc_tick": (C.c_int, [VP, FP, C.c_int, VP, FP, C.c_int, FP, FP]),
+    "dust_svmpc_serve_start": (C.c_int, [VP, C.c_int, C.c_double]),
+    "dust_svmpc_serve_stop": (C.c_int, [VP]),
     "dust_get_costs": (C.c_int, [VP, FP]),
     "dust_get_actions": (C.c_int, [VP, FP]),
     "dust_get_states_rows": (C.c_int, [VP, C.POINTER(C.c_longlong), C.c_int, VP]),

@@ -200,7 +200,15 @@ class Context:
         ticks, and ticks replayed on the launch-per-iteration path because the device was shared."""
         n = (C.c_longlong * 4)()
         L.check(L.load().dust_tick_stats(self._h, n))
-        return dict(tick2=int(n[0]), tick1=int(n[1]), replayed=int(n[3]))
+        return dict(tick2=int(n[0]), tick1=int(n[1]), served=int(n[2]), replayed=int(n[3]))
+
+    def serve_start(self, n_steps, wait_us=2000.0):
+        """Closed-loop serving (dust_svmpc_serve_start): svmpc_tick(state, n_steps) calls receive their outputs through pinned host
+        memory and launch the next tick ahead of its plant state (it waits at most wait_us for it).  Same results, bit for bit."""
+        L.check(L.load().dust_svmpc_serve_start(self._h, int(n_steps), float(wait_us)))
+
+    def serve_stop(self):
+        L.check(L.load().dust_svmpc_serve_stop(self._h))
 
     def set_grid(self, grid, off=None):
         g = _f(grid)
@@ -391,6 +399,9 @@ class Context:
             # the control loop's call (device noise, nominal dynamics): cached buffers and pointers, the outputs handed back as copies
             self._tick_state[:] = np.asarray(state, np.float32).reshape(self.ds)
             ps, pa, pw_ = self._tick_ptrs
+            if want_outputs == "action":  # the chosen sequence only (what a control loop sends to its plant): p_weights are not fetched
+                L.check(self._tick_fn(self._h, ps, n_steps, None, None, 0, pa, None))
+                return self._tick_aseq.copy(), None
             if want_outputs:
                 L.check(self._tick_fn(self._h, ps, n_steps, None, None, 0, pa, pw_))
                 return self._tick_aseq.copy(), self._tick_pw.copy()
@@ -399,7 +410,7 @@ class Context:
         st = _f(state, (self.ds,))
         pr = self._params(params, n_steps)
         a_seq = np.empty((self.H, self.da), np.float32) if want_outputs else None
-        pw = np.empty(self.N, np.float32) if want_outputs else None
+        pw = np.empty(self.N, np.float32) if want_outputs and want_outputs != "action" else None
         if eps_dev_ptr:
             e, flags = L.VP(eps_dev_ptr), L.PTR_DEVICE
         else:

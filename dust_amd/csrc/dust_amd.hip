@@ -13,7 +13,9 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <emmintrin.h>
 
 #include "bandwidth.hpp"
 #include "common.hpp"
@@ -173,9 +175,25 @@ struct dust_ctx {
     float state[4];
     int steps;
     bool fwd, replayable, mu_aliased;
+    bool cancelled;             // an armed launch the host cancelled (or whose state never came): nobody asked for this tick - dropped, not replayed
     std::vector<float> params;  // host copy of the caller's [steps][M][P] dynamics samples (empty: none)
   };
   std::vector<T2Replay> *t2_queue;  // (a pointer: the context block is zero-filled as a whole when it is created)
+  // closed-loop serving (dust_svmpc_serve_start; tick2_args.hpp): outputs straight to pinned host memory + a done word the host spins on,
+  // and the NEXT tick launched ahead of its plant state ("armed": its rollout waves wait for the state in a pinned mailbox)
+  bool serve_on;
+  int serve_steps;
+  unsigned long long serve_wait_ticks;  // bound of an armed launch's wait for its state (100 MHz ticks)
+  float *serve_host;                    // pinned: [out_floats] output mirror | [32 words] done | [32 words] T2Mbox
+  unsigned int serve_seq;               // sequence number of the last launch that reports to the done word
+  bool serve_pw;                        // the served calls ask for the particle weights as well (decided by the first served call)
+  int t2_launch_mode;                   // what the next launch_tick2 call adds: 0 nothing, 1 outputs + done word in pinned memory, 2 the same, armed
+  bool armed;                           // an armed launch is in flight and its state has not been posted
+  unsigned int armed_seq;
+  bool cancel_unsettled;                // an armed launch was cancelled: the device's abort count runs ahead of t2_aborts_seen until the next settle
+  int serve_misses;                     // consecutive armed launches whose state came too late (the loop is slower than the bound): stop arming at 3
+  double armed_at;                      // host time the armed launch was enqueued (seconds, steady clock)
+  long long n_served, n_armed_hit;      // sticky: ticks answered through the done word; of them, ticks that had been launched ahead
   const float *t2_params_host;  // the caller's params of the call being staged (valid inside try_persistent only)
   long long t2_replays;         // sticky: ticks replayed so far (dust_tick_stats)
   long long n_tick2, n_tick1, n_tick_other;  // sticky: optimize / tick calls served by tick2.hpp, persist.hpp, the other paths
@@ -427,13 +445,64 @@ static hipStream_t g_persist_last[DUST_MAX_DEV];
 struct PersistChain {  // RAII around ONE one-launch kernel launch on c->stream
   dust_ctx *c;
   int dev;
-  bool on;
+  bool on, locked;
   explicit PersistChain(dust_ctx *c_);
   ~PersistChain();
 };
 
+// Armed launches (closed-loop serving) occupy every CU while they wait for their plant state: one per device at most, on record here so
+// that whoever needs the device next - another context being created, the dynamics filter's kernels - can cancel it instead of waiting
+// for its bound.
+static std::mutex g_armed_mu[DUST_MAX_DEV];
+static dust_ctx *g_armed[DUST_MAX_DEV];
+static double host_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static T2Mbox *serve_mbox(dust_ctx *c) { return reinterpret_cast<T2Mbox *>(c->serve_host + c->out_floats + 32); }
+static volatile unsigned int *serve_done(dust_ctx *c) { return reinterpret_cast<volatile unsigned int *>(c->serve_host + c->out_floats); }
+// post a verdict for launch `seq`: half b first, then half a as ONE aligned 16-byte store (tick2_args.hpp T2Mbox)
+static void serve_post(dust_ctx *c, unsigned int seq, unsigned int verdict, const float *state) {
+  T2Mbox *m = serve_mbox(c);
+  alignas(16) unsigned int hb[4] = {0u, 0u, seq, 0u}, ha[4] = {seq, verdict, 0u, 0u};
+  if (state) {
+    memcpy(&ha[2], &state[0], 4);
+    if (c->ds > 1) memcpy(&ha[3], &state[1], 4);
+    if (c->ds > 2) memcpy(&hb[0], &state[2], 4);
+    if (c->ds > 3) memcpy(&hb[1], &state[3], 4);
+  }
+  _mm_store_si128(reinterpret_cast<__m128i *>(&m->x23[0]), _mm_load_si128(reinterpret_cast<const __m128i *>(hb)));
+  std::atomic_thread_fence(std::memory_order_release);
+  _mm_store_si128(reinterpret_cast<__m128i *>(&m->seq_a), _mm_load_si128(reinterpret_cast<const __m128i *>(ha)));
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+// cancel the armed launch of `c` (caller holds g_armed_mu of its device, or is the owning thread of a context that is not registered)
+static void serve_cancel_locked(dust_ctx *c) {
+  if (!c->armed) return;
+  serve_post(c, c->armed_seq, 2u, nullptr);
+  c->armed = false;
+  c->cancel_unsettled = true;
+  if (!c->t2_queue->empty()) c->t2_queue->back().cancelled = true;
+  const int dev = c->cfg.device;
+  if (dev >= 0 && dev < DUST_MAX_DEV && g_armed[dev] == c) g_armed[dev] = nullptr;
+}
+static void serve_cancel(dust_ctx *c) {
+  if (!c || !c->armed) return;
+  const int dev = c->cfg.device;
+  if (dev >= 0 && dev < DUST_MAX_DEV) {
+    std::lock_guard<std::mutex> lk(g_armed_mu[dev]);
+    serve_cancel_locked(c);
+  } else {
+    serve_cancel_locked(c);
+  }
+}
+// whoever is about to need the whole device (see above)
+static void serve_cancel_device(int dev, const dust_ctx *except = nullptr) {
+  if (dev < 0 || dev >= DUST_MAX_DEV) return;
+  std::lock_guard<std::mutex> lk(g_armed_mu[dev]);
+  if (g_armed[dev] && g_armed[dev] != except) serve_cancel_locked(g_armed[dev]);
+}
+
 extern "C" void dust_destroy(dust_ctx *c) {
   if (!c) return;
+  serve_cancel(c);
   if (c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV) {
     std::lock_guard<std::mutex> lk(g_persist_mu[c->cfg.device]);
     g_live_ctx[c->cfg.device].fetch_sub(1);
@@ -443,20 +512,21 @@ extern "C" void dust_destroy(dust_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   comm_release(c);
   free_all(c);
+  if (c->serve_host) (void)hipHostFree(c->serve_host);
   delete c->t2_queue;
   delete c;
 }
 
-PersistChain::PersistChain(dust_ctx *c_) : c(c_), dev(c_->cfg.device), on(false) {
+PersistChain::PersistChain(dust_ctx *c_) : c(c_), dev(c_->cfg.device), on(false), locked(false) {
   static const bool off = getenv("DUST_NO_CHAIN") != nullptr;  // development switch
   if (off || dev < 0 || dev >= DUST_MAX_DEV) return;
   // (the tenant count is tested UNDER the device's mutex, which dust_create holds while it counts itself in and drains the device:
   //  a launch cannot slip unchained between another thread's increment and its first kernel - ADVICE r3)
   g_persist_mu[dev].lock();
-  if (g_live_ctx[dev].load() < 2) {
-    g_persist_mu[dev].unlock();
-    return;
-  }
+  locked = true;
+  // (a single tenant needs no event, but KEEPS the mutex until its kernel is enqueued: released here, a dust_create of another thread
+  //  could count itself in and drain the device between this test and the launch, and the two grids would meet unchained - ADVICE r4)
+  if (g_live_ctx[dev].load() < 2) return;
   on = true;
   if (!g_persist_ev[dev] && hipEventCreateWithFlags(&g_persist_ev[dev], hipEventDisableTiming) != hipSuccess) {
     g_persist_ev[dev] = nullptr;
@@ -466,12 +536,11 @@ PersistChain::PersistChain(dust_ctx *c_) : c(c_), dev(c_->cfg.device), on(false)
   if (g_persist_last[dev] && g_persist_last[dev] != c->stream) (void)hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0);
 }
 PersistChain::~PersistChain() {
-  if (!on) return;
-  if (g_persist_ev[dev]) {
+  if (on && g_persist_ev[dev]) {
     (void)hipEventRecord(g_persist_ev[dev], c->stream);
     g_persist_last[dev] = c->stream;
   }
-  g_persist_mu[dev].unlock();
+  if (locked) g_persist_mu[dev].unlock();
 }
 
 static int create_impl(const dust_config *cfg, dust_ctx **out) {
@@ -575,6 +644,7 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
 extern "C" int dust_create(const dust_config *cfg, dust_ctx **out) {
   if (!out) return fail(DUST_ERR_INVALID, "null out");
   *out = nullptr;
+  if (cfg) serve_cancel_device(cfg->device);  // (an armed launch of another context holds every CU until its state arrives)
   int s = create_impl(cfg, out);
   if (s == DUST_OK && cfg->device >= 0 && cfg->device < DUST_MAX_DEV) {
     // counted in under the device's mutex (PersistChain tests the count under it, and holds it across its launch): a one-launch kernel
@@ -625,6 +695,8 @@ static int handoff_timeout(dust_ctx *c, const char *msg) {
 
 extern "C" int dust_sync(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  serve_cancel(c);  // (an armed launch would wait for its plant state - and this synchronisation for it)
+  c->cancel_unsettled = false;
   bool have_flag = false;
   unsigned int flag0 = 0u;
   if (c->t2_inflight) {  // owner-computes ticks that did not start (device shared with another context) run now, on the other path
@@ -704,7 +776,7 @@ static int d2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
 // synchronisation, status words, t2_settle).  Everything that reads or changes the particle / prior / optimiser state from the host, or
 // runs plain kernels on it, settles first (a forward on un-optimised particles, getters ahead of the replay); the one-launch
 // ticks themselves need no host round trip for that - the device-side chain keeps them in order.
-static int settle_pending(dust_ctx *c) { return (c && c->t2_inflight) ? dust_sync(c) : DUST_OK; }
+static int settle_pending(dust_ctx *c) { return (c && (c->t2_inflight || c->armed || c->cancel_unsettled)) ? dust_sync(c) : DUST_OK; }
 
 static int h2d(dust_ctx *c, void *dst, const void *src, size_t bytes) {
   TRY(settle_pending(c));
@@ -3102,7 +3174,19 @@ static int launch_tick2(dust_ctx *c, const float *state, int n_steps, const floa
   f.cnt = c->t2_cnt + (size_t)c->t2_set * T2_SETS * T2_CNT_STRIDE;
   f.zero_base = c->t2_cnt + (size_t)(1 - c->t2_set) * T2_SETS * T2_CNT_STRIDE;
   f.status = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
-  f.tl = c->tl_dev;
+  f.tl = c->tl_dev ? c->tl_dev + (size_t)(c->n_tick2 & 1) * 1024 * 128 : nullptr;  // (diagnostic build: consecutive launches stamp alternate halves)
+  if (c->t2_launch_mode && c->serve_host && do_forward) {  // closed-loop serving: outputs and the done word go straight to pinned host memory
+    f.host_out = c->serve_host;
+    f.host_done = const_cast<unsigned int *>(serve_done(c));
+    f.host_pw = c->serve_pw ? 1 : 0;
+    f.launch_seq = ++c->serve_seq;
+    if ((f.launch_seq & 0x7fffffffu) == 0u) f.launch_seq = c->serve_seq = 1u;  // (bit 31 is the "did not start" mark; 0 is never a launch)
+    if (c->t2_launch_mode == 2) {  // armed: the state arrives later, through the mailbox
+      f.mbox = reinterpret_cast<const unsigned int *>(serve_mbox(c));
+      f.mbox_wait = c->serve_wait_ticks;
+      for (int k = 0; k < 4; ++k) f.x0[k] = 0.f;
+    }
+  }
   {
     PersistChain chain(c);
     HIP_TRY((hipError_t)tick2_launch(f, c->cfg.model, mode, grid, lds, c->stream));
@@ -3349,6 +3433,7 @@ static void t2_queue_push(dust_ctx *c, const float *state4, int steps, bool fwd,
   r.fwd = fwd;
   r.replayable = replayable;
   r.mu_aliased = mu_aliased;
+  r.cancelled = false;
   if (c->t2_params_host && c->cfg.dim_p > 0) r.params.assign(c->t2_params_host, c->t2_params_host + (size_t)steps * c->M * c->cfg.dim_p);
   c->t2_queue->push_back(std::move(r));
 }
@@ -3443,7 +3528,7 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
   // every one-launch tick behind the first one that did not start (or commit) aborted as well (`expect_aborts`): the last n entries
   if (n > q.size()) return fail(DUST_ERR_STATE, "%u one-launch tick(s) reported as not started, %zu on record", n, q.size());
   for (size_t i = q.size() - n; i < q.size(); ++i)
-    if (!q[i].replayable)
+    if (!q[i].replayable && !q[i].cancelled)
       return fail(DUST_ERR_HIP, "%u control tick(s) did not start (device shared with another context), one of them with caller-supplied noise: repeat them", n);
   // (the device is shared - that is why the tick did not start - so the replay uses plain kernels only: the fused launch forms spin on
   //  their own workgroups too and could meet the same tenant)
@@ -3451,6 +3536,7 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
   int st = DUST_OK;
   for (size_t i = q.size() - n; i < q.size() && st == DUST_OK; ++i) {
     const dust_ctx::T2Replay &r = q[i];
+    if (r.cancelled) continue;  // (an armed launch nobody supplied a state for: that tick was never asked for)
     if (!r.mu_aliased) c->mu_aliased = false;  // (a context's first tick: its prior means are still c->mu; the replay's forward aliases them)
     st = upload_state_params(c, r.state, r.params.empty() ? nullptr : r.params.data(), r.steps);
     c->noise_f16 = false;
@@ -3497,7 +3583,7 @@ extern "C" int dust_tick_stats(dust_ctx *c, long long out[4]) {
   if (!c || !out) return fail(DUST_ERR_INVALID, "null argument");
   out[0] = c->n_tick2;
   out[1] = c->n_tick1;
-  out[2] = c->n_tick_other;
+  out[2] = c->n_served;  // (closed-loop serving: ticks answered through the pinned done word)
   out[3] = c->t2_replays;
   return DUST_OK;
 }
@@ -3508,6 +3594,142 @@ static void graph_drop(dust_ctx *c) {
   c->graph_exec = nullptr;
   c->graph = nullptr;
   c->graph_seen = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Closed-loop serving (include/dust_amd.h dust_svmpc_serve_start).  A control loop is  state -> tick -> first action -> plant -> state:
+// the tick's outputs are needed on the host before the next tick's input exists, so launch latency, the device-to-host copy and the
+// stream synchronisation all sit on the loop's critical path (round 4: 93 us of kernel, 107 us per closed-loop tick).  While serving,
+//  (1) the tick kernel writes a_seq / p_weights straight into pinned host memory and its last workgroup publishes a sequence number
+//      there: the host spins on that word - no copy, no synchronisation, and the kernel's own end-of-launch work leaves the path;
+//  (2) the NEXT tick is launched while the current one computes, "armed": it hands its particles round, draws its noise and runs the
+//      prior pass - none of which needs the plant state - while its rollout waves wait for the state in a pinned mailbox the host
+//      writes as soon as the plant has stepped.  Launch latency and the head of the tick overlap the host's share of the loop.
+// An armed launch holds every CU while it waits, so: it is bounded (serve_wait_ticks; a launch whose state never comes aborts as one that
+// did not start - nothing written), every other entry point of the context cancels it first (settle_pending), and so does whoever
+// needs the device next (serve_cancel_device: dust_create, the dynamics filter).  A loop slower than the bound stops being armed.
+static int serve_alloc(dust_ctx *c) {
+  if (c->serve_host) return DUST_OK;
+  HIP_TRY(hipHostMalloc((void **)&c->serve_host, (c->out_floats + 64) * sizeof(float), hipHostMallocDefault));
+  memset(c->serve_host, 0, (c->out_floats + 64) * sizeof(float));
+  return DUST_OK;
+}
+static bool serve_call_ok(const dust_ctx *c, int n_steps, const float *eps, const float *params, int flags, const float *a_seq, const float *p_weights) {
+  return c->serve_on && n_steps == c->serve_steps && !eps && !params && flags == 0 && (a_seq || p_weights) && c->cfg.dim_p == 0 &&
+         !c->handoff_banned && !c->prof && c->own_stream && c->mu_aliased;
+}
+static int serve_tick(dust_ctx *c, const float *state, float *a_seq, float *p_weights, bool *done) {
+  *done = false;
+  const int dev = c->cfg.device;
+  if (c->cancel_unsettled) TRY(dust_sync(c));  // (the device's abort count must be known before the next launch: expect_aborts)
+  HIP_TRY(hipSetDevice(dev));
+  TRY(serve_alloc(c));
+  if (c->armed && (p_weights != nullptr) && !c->serve_pw) TRY(dust_sync(c));  // (the armed launch will not deliver the weights this call asks for)
+  c->serve_pw = p_weights != nullptr;
+  unsigned int this_seq = 0u;
+  bool was_armed = false;
+  {
+    std::unique_lock<std::mutex> lk(g_armed_mu[dev >= 0 && dev < DUST_MAX_DEV ? dev : 0]);
+    if (c->armed) {  // the tick was launched ahead: hand it its state
+      this_seq = c->armed_seq;
+      serve_post(c, this_seq, 1u, state);
+      c->armed = false;
+      if (g_armed[dev] == c) g_armed[dev] = nullptr;
+      dust_ctx::T2Replay &r = c->t2_queue->back();
+      for (int k = 0; k < 4; ++k) r.state[k] = k < c->ds ? state[k] : 0.f;
+      was_armed = true;
+      // a state that comes after the launch's bound may find it gone (it then reports "did not start" and is replayed below): a loop
+      // that is slower than the bound gains nothing from arming
+      if ((host_now() - c->armed_at) * 1e8 > (double)c->serve_wait_ticks) c->serve_misses++;
+      else c->serve_misses = 0;
+    }
+  }
+  if (!was_armed) {
+    c->t2_launch_mode = 1;
+    c->t2_params_host = nullptr;
+    int st = launch_tick2(c, state, c->serve_steps, nullptr, true, done);
+    c->t2_launch_mode = 0;
+    TRY(st);
+    if (!*done) return DUST_OK;  // (not a shape / state the one-launch kernel takes: the caller goes on to the regular path)
+    this_seq = c->serve_seq;
+  }
+  *done = true;
+  // the next tick, armed, behind this one (single tenant only: a chained launch of another context could stand behind it)
+  const bool tenants = dev >= 0 && dev < DUST_MAX_DEV && g_live_ctx[dev].load() >= 2;
+  if (!tenants && c->serve_misses < 3 && c->serve_wait_ticks > 0 && c->t2_queue->size() < 4000) {
+    bool d2 = false;
+    c->t2_launch_mode = 2;
+    c->t2_params_host = nullptr;
+    const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+    int st = launch_tick2(c, zero, c->serve_steps, nullptr, true, &d2);
+    c->t2_launch_mode = 0;
+    TRY(st);
+    if (d2) {
+      std::lock_guard<std::mutex> lk(g_armed_mu[dev]);
+      c->armed = true;
+      c->armed_seq = c->serve_seq;
+      c->armed_at = host_now();
+      g_armed[dev] = c;
+    }
+  }
+  // wait for this tick's word
+  volatile unsigned int *dw = serve_done(c);
+  const double t0 = host_now();
+  unsigned int spins = 0u, v = 0u;
+  bool ok = false, slow = false;
+  for (;;) {
+    v = *dw;
+    if (v == this_seq) {
+      ok = true;
+      break;
+    }
+    if (v == (this_seq | 0x80000000u)) break;  // did not start
+    _mm_pause();
+    if ((++spins & 1023u) == 0u && host_now() - t0 > 0.25) {  // (no word: a wait inside the launch gave up - 50 ms - or the device is gone)
+      slow = true;
+      break;
+    }
+  }
+  if (ok) {
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (a_seq) memcpy(a_seq, c->serve_host, c->D * sizeof(float));
+    if (p_weights) memcpy(p_weights, c->serve_host + (c->pw - c->outblk), c->N * sizeof(float));
+    // this tick is committed: it leaves the replay queue (everything in front of it committed too - the launches are ordered)
+    const size_t keep = c->armed ? 1u : 0u;
+    if (c->t2_queue->size() > keep) c->t2_queue->erase(c->t2_queue->begin(), c->t2_queue->end() - keep);
+    if (!c->armed) c->t2_inflight = false;
+    c->n_served++;
+    if (was_armed) c->n_armed_hit++;
+    return DUST_OK;
+  }
+  (void)slow;
+  // the launch did not start (device shared, an earlier tick awaits its replay, its state came too late) or did not commit: the armed
+  // launch behind it goes, then the regular machinery reads the status words, replays what has to be replayed and fetches the outputs
+  serve_cancel(c);
+  TRY(tick_outputs(c, a_seq, p_weights));
+  c->cancel_unsettled = false;
+  return DUST_OK;
+}
+
+extern "C" int dust_svmpc_serve_start(dust_ctx *c, int n_steps, double wait_us) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (n_steps < 1) return fail(DUST_ERR_INVALID, "n_steps must be >= 1");
+  if (!(wait_us >= 0.0) || wait_us > 45000.0) return fail(DUST_ERR_INVALID, "wait_us must be in [0, 45000] (below the 50 ms bound of the in-launch hand-offs)");
+  TRY(settle_pending(c));
+  if (c->cfg.dim_p > 0) return fail(DUST_ERR_UNSUPPORTED, "closed-loop serving takes no per-tick dynamics samples (dim_p = %d): they would have to be staged behind the armed launch", c->cfg.dim_p);
+  if (!tick2_shape_ok(c, n_steps)) return fail(DUST_ERR_UNSUPPORTED, "closed-loop serving runs on the one-launch tick (tick2.hpp: K1 / IMQ, N %% 4 == 0, N / 4 <= CUs, H * da <= 32, isotropic prior scale, no control cost, one GPU)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  TRY(serve_alloc(c));
+  c->serve_on = true;
+  c->serve_steps = n_steps;
+  c->serve_wait_ticks = (unsigned long long)(wait_us * 100.0);
+  c->serve_misses = 0;
+  return DUST_OK;
+}
+extern "C" int dust_svmpc_serve_stop(dust_ctx *c) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  c->serve_on = false;
+  return settle_pending(c);
 }
 
 // One whole control tick.  The kernel chain of a tick is static once the context is warm (same kernels, same pointers:
@@ -3538,6 +3760,13 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     TRY(st);
     if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
     return DUST_OK;
+  }
+  if (serve_call_ok(c, n_steps, eps, params, flags, a_seq, p_weights)) {  // closed-loop serving: done word, next tick launched ahead
+    bool done = false;
+    TRY(serve_tick(c, state, a_seq, p_weights, &done));
+    if (done) return DUST_OK;
+  } else if (c->armed || c->cancel_unsettled) {
+    TRY(settle_pending(c));  // (a call the armed launch was not made for)
   }
   {  // one persistent launch for the whole tick when the shape allows it (persist.hpp)
     bool done = false;

@@ -1042,6 +1042,7 @@ extern "C" int dust_mpf_set_ctrl_noise(dust_mpf *m, const float *z, int n) {
 
 static int mpf_launch(dust_mpf *m, float bw, float lr, int n_steps, float *gn_dev, float *phi_dev, bool optimise = true, bool grid = false,
                       const float *act_seq_dev = nullptr) {
+  serve_cancel_device(m->cfg.device);  // (an armed control tick - closed-loop serving - would hold every CU until its plant state arrives)
   if (m->cfg.model_cfg.model == DUST_MODEL_PARTICLE && m->cfg.model_cfg.with_obstacle && m->cfg.model_cfg.can_crash && !m->grid_bits)
     return fail(DUST_ERR_STATE, "Particle model with obstacles: call dust_mpf_set_grid first");
   MpfArgs a;

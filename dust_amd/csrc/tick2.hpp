@@ -515,8 +515,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   float *flag_th = misc + 44;    // [4] non-finite particle
   float *flag_eps = misc + 48;   // [2][4] non-finite caller-supplied noise, by iteration parity (iteration k + 1's noise is staged while
                                  // iteration k's flags are still to be cleared: phase 6)
-  // (misc[32..39], misc[56..59] unused)
+  float *mbx = misc + 32;        // [4] plant state of an armed launch, as it arrived in the mailbox
+  // (misc[36..39], misc[56..59] unused)
   unsigned int *sig = reinterpret_cast<unsigned int *>(misc + 60);  // [0] go (1) / abort (2)  [1] theta generations arrived  [2] COMMIT (1) / not (0)
+                                                                    // [3] armed launch: state arrived (1) / cancelled or never came (2)
   float *wred = misc + 64;       // [128] block-reduction scratch
   float *coefs = lds + T2_L_COEFS;
   float *ksl = lds + L.ksl;
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   if (tid0 == 16) {
     sig[0] = 0u;
     sig[1] = 0u;
+    sig[3] = 0u;
   }
   float ll0 = 0.f;
   if (tid0 >= 32 && tid0 < 32 + T2_PW) ll0 = f->logl[n_first + tid0 - 32];
@@ -806,7 +809,81 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     const bool ownv = isown && od < D;
     const size_t no = (size_t)(n_first + op) * D + (ownv ? od : 0);
     T2_TL(0, 16 * k + 0);
-    if (wave < 8) {
+    bool mb_cancel = false;
+    if (k == 0 && f->mbox != nullptr && wave < 8) {
+      // armed launch (tick2_args.hpp T2Mbox): the plant state comes through the pinned-host mailbox.  Workgroup 0 polls it - one aligned
+      // 16-byte system-scope load per round trip (~2 us over PCIe) - and relays state and verdict through device memory; in every
+      // workgroup wave 0 fetches them and the other rollout waves wait on an LDS word.  Bounded: a host that never supplies the state
+      // leaves the launch as one that did not start.
+      if (wave == 0) {
+        unsigned int verdict = 0u;
+        float xs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) {
+          // relay lines: kind 0 of this launch's counter set uses replica 0 (start arrivals) and line T2_NSH (done arrivals); lines
+          // 2 T2_NSH .. 2 T2_NSH + T2_NREP - 1 carry {verdict, x0..x3} from workgroup 0 to the others, workgroup b reading line b % T2_NREP
+          // (256 workgroups polling the HOST line themselves serialise at the root complex: 121 us per tick instead of 93)
+          unsigned int *relay = cnt_start + (size_t)2 * T2_NSH * T2_CNT_STRIDE;
+          const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+          if (b == 0) {
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int *>(f->mbox), 0, 32, 0x00020000);
+            for (;;) {
+              const t2_v4u a = __builtin_amdgcn_raw_buffer_load_b128(rm, 0, 0, 17);  // sc0 sc1: system scope
+              if (a[0] == f->launch_seq && a[1] != 0u) {
+                verdict = a[1] == 1u ? 1u : 2u;
+                xs[0] = __uint_as_float(a[2]);
+                xs[1] = __uint_as_float(a[3]);
+                if (DS > 2 && verdict == 1u) {
+                  const t2_v4u bq = __builtin_amdgcn_raw_buffer_load_b128(rm, 16, 0, 17);
+                  if (bq[2] != f->launch_seq) continue;  // (the halves of two different posts: look again)
+                  xs[2] = __uint_as_float(bq[0]);
+                  xs[3] = __uint_as_float(bq[1]);
+                }
+                break;
+              }
+              if (__builtin_amdgcn_s_memrealtime() - t_start > f->mbox_wait) {
+                verdict = 2u;
+                break;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < T2_NREP; ++r)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) __hip_atomic_store(relay + (size_t)r * T2_CNT_STRIDE + 1 + q, __float_as_uint(xs[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < T2_NREP; ++r) __hip_atomic_store(relay + (size_t)r * T2_CNT_STRIDE, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            unsigned int *line = relay + (size_t)(b % T2_NREP) * T2_CNT_STRIDE;
+            unsigned int spins = 0u;
+            for (;;) {
+              verdict = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (verdict) break;
+              __builtin_amdgcn_s_sleep(2);
+              if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t_start > f->mbox_wait + 200000ull) {  // (workgroup 0 never came)
+                verdict = 2u;
+                break;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[q] = __uint_as_float(__hip_atomic_load(line + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
+          mbx[0] = xs[0];
+          mbx[1] = xs[1];
+          mbx[2] = xs[2];
+          mbx[3] = xs[3];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          t2_lds_st(sig + 3, verdict);
+        }
+      }
+      while (t2_lds_ld(sig + 3) == 0u) __builtin_amdgcn_s_sleep(1);
+      mb_cancel = t2_lds_ld(sig + 3) == 2u;
+#pragma unroll
+      for (int q = 0; q < DS; ++q) x0[q] = mbx[q];
+      T2_TL(0, 123);
+    }
+    if (wave < 8 && mb_cancel) {
+      // (cancelled: nothing to roll out; the launch ends at barrier B1)
+    } else if (wave < 8) {
       // ================= R waves, phase 1: rollouts (tick_owner stage 2; lane = sample) =================
       DUST_PRIO(T2_PRIO_ROLL);
       const int rp = wave >> 1;
@@ -876,7 +953,28 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
       // Stage outputs (costs, log-likelihood, score halves, phi) are what the getters return for the LAST iteration: only that one
       // stores them - the stores of the other iterations sat in front of the barriers' vmcnt waits (phi: right in front of B6)
       const bool last_iter = k + 1 == f->n_iters;
-      if (last_iter)
+      bool store_costs = last_iter;
+      if (last_iter && k == 0) {
+        // a ONE-iteration tick reaches this store before barrier B1, i.e. possibly before workgroup 0 has decided whether the launch
+        // starts (an aborted launch with caller-supplied noise is not replayed and must leave dust_get_costs' record alone):
+        // wait for the go word (published ~2 us into the launch; the rollouts above took longer) and skip the store on "abort"
+        unsigned int g = 0u;
+        if (lane == 0) {
+          g = t2_lds_ld(sig);
+          unsigned int spins = 0u;
+          while (g == 0u) {
+            g = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0u) g = t2_lds_ld(sig);
+            if (g == 0u) {
+              __builtin_amdgcn_s_sleep(2);
+              if ((++spins & 0xffffu) == 0u && __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) g = 2u;  // (a waiter gave up)
+            }
+          }
+        }
+        g = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+        store_costs = g == 1u;
+      }
+      if (store_costs)
         for (int s = (wave & 1) * 64 + lane; s < S; s += 128) f->costsT[(size_t)n * S + s] = cst_p[s];
       // wave-local softmax pieces over the wave's own samples, and the wave's share of the weighted sums over them (likelihoods.py:127-135,
       // svmpc.py:50-53, disco.py:387-392): nothing here needs the partner wave or the prior pass, so it runs underneath the P waves' pass
@@ -959,7 +1057,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     wg_sync();  // B1
     f = t2_args();
     T2_TL(0, 16 * k + 4);
-    if (sig[0] == 2u) return;  // (uniform: no workgroup wrote anything)
+    if (sig[0] == 2u || (k == 0 && sig[3] == 2u)) {  // (uniform: no workgroup wrote anything)
+      if (b == 0 && tid0 == 0) {
+        // an armed launch whose state never came (cancelled by the host, or the bound ran out) counts as one that did not start
+        if (sig[0] != 2u) __hip_atomic_fetch_add(f->status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f->host_done) __hip_atomic_store(f->host_done, f->launch_seq | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
     // ================= phase 4: score rows out (waves 8-9) | score arrivals (wave 10) | next noise (R) =================
     // The owner lanes finish both halves of the score themselves (no barrier between the prior pass and the published row): grad_pri from
     // the pass partials of the four waves that hold the query, grad_lik from the two R waves' pieces of the particle's sample softmax.
@@ -1157,7 +1262,10 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   if (kf == 0) {
     if (wave == 15) start_protocol();
     while (t2_lds_ld(sig) == 0u) __builtin_amdgcn_s_sleep(1);
-    if (sig[0] == 2u) return;
+    if (sig[0] == 2u) {
+      if (b == 0 && tid0 == 0 && f->host_done) __hip_atomic_store(f->host_done, f->launch_seq | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
   }
   {  // log p(theta_n) under the tick's prior, whose means ARE the particles (svmpc.py:137; svgd.py:87): all 16 waves
     if (wave == 15) {
@@ -1204,6 +1312,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
   T2_TL(0, 16 * kf + 1);
   if (sig[2] == 0u) return;  // no COMMIT (see above)
   // softmax over all particles, first-index argmax (finalize_body), computed by every workgroup for itself
+  bool reports = false;  // closed-loop serving: this workgroup owns the best particle and writes the outputs to pinned host memory
   {
     const int t = tid0;
     const float lwr = t < N ? ld_sc1(f->lwq + t) : -INFINITY;
@@ -1237,6 +1346,15 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     if (bi >= n_first && bi < n_first + T2_PW) {  // the owner of the best particle hands out its action sequence
       if (t == 0) *f->istar = bi;
       if (t < D) f->a_seq_out[t] = th[(bi - n_first) * T2_ROW + t];
+      if (f->host_out) {
+        // closed-loop serving: THIS workgroup - the owner of the best particle - also writes the outputs straight into pinned host
+        // memory: the chosen sequence and, when the caller wants them, all N particle weights (every workgroup computed the whole
+        // softmax: lane t holds p_t).  The stores are posted here and acknowledged ~3 us later; the workgroup goes on with the mixture
+        // and the roll meanwhile and tells the host at its very end (below).  No other workgroup touches host memory.
+        if (t < D) f->host_out[t] = th[(bi - n_first) * T2_ROW + t];
+        if (f->host_pw && t < N) f->host_out[(f->pw - f->a_seq_out) + t] = p;  // (the pinned mirror has outblk's layout: a_seq | p_weights)
+        reports = true;  // (uniform over the workgroup: every wave found the same best particle)
+      }
     }
     // new prior mixture (finalize_body): Categorical(probs) clamps, then log_softmax
     if (!f->weighted_prior) {
@@ -1288,6 +1406,14 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
     f->ctr[0] = ctr_tick + 1u;
     f->ctr[1] = 0u;
     f->ctr[2] = 0u;
+  }
+  if (reports) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to host memory are acknowledged
+    wg_sync();
+    if (tid0 == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(f->host_done, f->launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   T2_TL(0, 16 * kf + 2);
 #endif  // __HIP_DEVICE_COMPILE__

@@ -63,6 +63,28 @@ struct Tick2Args {
   unsigned int *status;     // [0] a hand-off wait timed out (sticky until the host clears it) [1] ticks to replay: did not start (not all workgroups
                             // resident) or not committed (a wait gave up) [2] workgroups that did not commit
   unsigned long long *tl;   // diagnostic build only: [grid][128] wall-clock stamps
+  // Closed-loop serving (dust_svmpc_serve_start): the tick's outputs go STRAIGHT to pinned host memory and the last workgroup to finish
+  // publishes the launch's sequence number there - the host spins on that word instead of a device-to-host copy and a stream
+  // synchronisation; and a tick may be launched AHEAD of its plant state ("armed"): it runs everything that does not need the state
+  // (particle hand-off, noise draw, prior pass) and its rollout waves wait - bounded - for the state to arrive in a pinned-host mailbox.
+  float *host_out;          // pinned host mirror of the output block (a_seq | p_weights, laid out as outblk) or nullptr
+  unsigned int *host_done;  // pinned host word: launch_seq when the tick is committed and its outputs are in host_out (written, like them, by
+                            // the workgroup that owns the best particle), launch_seq | 0x80000000 when the launch did not start (not
+                            // resident, an earlier tick awaits its replay, cancelled, state never came)
+  int host_pw;              // the caller wants the particle weights too (4 N bytes over PCIe; a control loop needs a_seq only)
+  unsigned int launch_seq;
+  const unsigned int *mbox; // pinned host mailbox T2Mbox or nullptr: the plant state is x0 (by value)
+  unsigned long long mbox_wait;  // bound of the wait for the state, s_memrealtime ticks (100 MHz)
+};
+
+// Mailbox of an armed tick, pinned host memory, two 16-byte halves each written / read as ONE aligned 16-byte access:
+//   a = {seq, verdict, x0, x1}   b = {x2, x3, seq, 0}        verdict 1: state of launch `seq`; 2: launch `seq` is cancelled
+// The host writes b, then a (release); the kernel polls a and, for four-entry states, reads b behind it and checks its seq.
+struct T2Mbox {
+  unsigned int seq_a, verdict;
+  float x01[2];
+  float x23[2];
+  unsigned int seq_b, pad;
 };
 
 // LDS layout of one workgroup (float offsets; host and device agree through these).  The fixed-size regions come first, at

@@ -142,7 +142,8 @@ int dust_clone(const dust_ctx *src, dust_ctx **out);
 void dust_destroy(dust_ctx *ctx);
 int dust_sync(dust_ctx *ctx);
 /* Which device path served the SVMPC.optimize / forward calls so far (svmpc.py:97-200; sticky counts since creation):
- * out[0] one-launch ticks, owner-computes form (tick2.hpp); out[1] one-launch ticks, tiled form (persist.hpp); out[2] unused;
+ * out[0] one-launch ticks, owner-computes form (tick2.hpp) - launched-ahead ticks of closed-loop serving included, also cancelled ones;
+ * out[1] one-launch ticks, tiled form (persist.hpp); out[2] ticks answered through the pinned done word of closed-loop serving;
  * out[3] ticks whose one-launch kernel found the device shared with other work (its workgroups were not all resident) and that
  * were therefore run on the launch-per-iteration path instead - late, on unchanged state, never lost. */
 int dust_tick_stats(dust_ctx *ctx, long long out[4]);
@@ -222,6 +223,21 @@ int dust_likelihood_sample_at(dust_ctx *ctx, const float *state, const float *th
 /* one whole control tick = optimize(n_steps) + forward(), enqueued without host round trips (one persistent launch where eligible) */
 int dust_svmpc_tick(dust_ctx *ctx, const float *state, int n_steps, const float *eps, const float *params, int flags,
                     float *a_seq, float *p_weights);
+
+/* Closed-loop serving: the loop of dust/utils/simulations.py:104-123 - optimize, forward, first action to the plant, new state, repeat -
+ * with the host's share off the device's critical path.  Between dust_svmpc_serve_start and dust_svmpc_serve_stop a call
+ *   dust_svmpc_tick(ctx, state, n_steps, NULL, NULL, 0, a_seq, p_weights)        (device noise, the n_steps given here)
+ * (1) receives its outputs through pinned host memory - the kernel writes them there and publishes a sequence number the call spins on:
+ * no device-to-host copy, no stream synchronisation - and (2) launches the NEXT tick ahead of its plant state: that launch exchanges
+ * its particles, draws its noise and runs its prior pass while the caller steps the plant, and its rollouts start when the next call
+ * posts the state to a pinned mailbox.  Results are those of the same calls without serving, bit for bit.
+ * The launched-ahead tick waits at most wait_us microseconds for its state (it occupies the whole device while it waits): a state that
+ * comes later finds a launch that has given up - nothing written - and the tick is run then, late but correctly; after three such
+ * misses in a row the context stops launching ahead.  wait_us = 0: outputs through pinned memory only.  Every other entry point of
+ * the context, dust_create on the same device and the dynamics filter's calls cancel a waiting launch first (it leaves no trace).
+ * Needs the one-launch tick's shape (K1 / IMQ kernel, N % 4 == 0, N / 4 <= CUs, H * da <= 32, one GPU, no sampled dynamics). */
+int dust_svmpc_serve_start(dust_ctx *ctx, int n_steps, double wait_us);
+int dust_svmpc_serve_stop(dust_ctx *ctx);
 
 /* stage outputs of the last call, for parity tests ([S][N] / [N][H][da] / [N]) */
 int dust_get_costs(dust_ctx *ctx, float *costs);

@@ -35,3 +35,15 @@ run("+ host plant (bench.py's closed loop)", c)
 t0 = time.perf_counter()
 for _ in range(20000): bench.pendulum_plant(st, 0.3)
 print("host plant alone %.2f us" % ((time.perf_counter() - t0) / 20000 * 1e6))
+# ---- round 5: closed-loop serving (outputs through pinned memory + the next tick launched ahead of its state)
+for wait in (0.0, 2000.0):
+    ctx.serve_start(5, wait)
+    tag = "served, wait_us=%g" % wait
+    run(tag + ": outputs only (constant state)", lambda: ctx.svmpc_tick(st, 5, want_outputs=True))
+    run(tag + ": + host plant", c)
+    def d():
+        a_seq, _ = ctx.svmpc_tick(state[0], 5, want_outputs="action")
+        state[0] = bench.pendulum_plant(state[0], a_seq[0, 0])
+    run(tag + ": a_seq only + host plant", d)
+    print("   tick paths:", ctx.tick_stats(), flush=True)
+    ctx.serve_stop()
