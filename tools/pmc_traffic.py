@@ -22,11 +22,18 @@ def mean_counter(d, name, kernel_substr):
 
 def main():
     dfetch, dwrite, kernel, out = sys.argv[1:5]
+    family = sys.argv[5] if len(sys.argv) > 5 else None  # tools/srcstamp.py family: the summary is stamped with the sources it was measured on
     fk, nf = mean_counter(dfetch, "FETCH_SIZE", kernel)
     wk, nw = mean_counter(dwrite, "WRITE_SIZE", kernel)
     res = dict(kernel=kernel, launches_fetch_pass=nf, launches_write_pass=nw, FETCH_SIZE_KiB_raw=fk, WRITE_SIZE_KiB_raw=wk,
                fetch_bytes_corrected=2.0 * fk * 1024, write_bytes=wk * 1024, hbm_bytes_per_launch=2.0 * fk * 1024 + wk * 1024,
                corrections="FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE x1; KiB -> bytes")
+    if family:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import srcstamp
+
+        res["source_family"], res["source_stamp"] = family, srcstamp.stamp(family)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
