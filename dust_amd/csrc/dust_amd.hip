@@ -3231,9 +3231,15 @@ enum { ncclFloat32 = 7 };
 static int load() {
   if (all_gather) return DUST_OK;
   const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // DUST_RCCL_LIB: the collective library to bind instead (any library with the NCCL 2.x entry points used here: a site's own RCCL
+  // build - or tests/fake_rccl, which runs the sharded tick of several PROCESSES on one GPU)
+  if (const char *own = getenv("DUST_RCCL_LIB")) {
+    handle = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+    if (!handle) return fail(DUST_ERR_UNSUPPORTED, "DUST_RCCL_LIB=%s: %s", own, dlerror());
+  }
   for (const char *n : names) {  // a copy already mapped into the process first (torch's), then the ROCm installation's
-    handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (handle) break;
+    handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   }
   for (int i = 0; !handle && i < 3; ++i) handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
   if (!handle) return fail(DUST_ERR_UNSUPPORTED, "RCCL not found (librccl.so): %s", dlerror());
