@@ -11,6 +11,7 @@ from copy import deepcopy
 
 import torch
 
+from ..controllers.dual import DualSVMPC
 from ..inference.likelihoods import ExponentiatedUtility
 from ..inference.svmpc import SVMPC
 from ..models import PendulumModel
@@ -54,19 +55,19 @@ def run_pendulum_simulation(init_state, init_policies, model_kwargs, dyn_dist, e
             ep_dyn_dist = sim_mpf.prior
             dyn_particles = _nan(steps, *sim_mpf.x.size())
             dyn_bws = torch.zeros(steps)
+        # the two inferences of the dual loop as one object (controllers/dual.py): forward() = optimize (+ forward once warmed up,
+        # simulations.py:108-123), step() = the filter update (simulations.py:132-138)
+        dual = DualSVMPC(sim_svmpc, sim_mpf, dyn_dist=ep_dyn_dist, mpf_bw=mpf_bw, mpf_steps=mpf_steps, warm_up=warm_up) if use_svmpc else None
         states, actions, costs = _nan(steps, sim_ctrl.dim_s), _nan(steps, sim_ctrl.dim_a), _nan(steps, 1)
         pol_particles = _nan(steps, sim_ctrl.n_pol, sim_ctrl.hz_len, sim_ctrl.dim_a)
         weights = _nan(steps, sim_ctrl.n_pol)
         action, cost = torch.zeros(sim_ctrl.dim_a), torch.zeros(1)
         for step in range(steps):
             if use_svmpc:
-                sim_svmpc.optimize(state, ep_dyn_dist)
-                if step < warm_up:
-                    action = torch.zeros(sim_ctrl.dim_a)
-                else:
-                    a_seq, p_weights = sim_svmpc.forward(state, ep_dyn_dist)
-                    action = a_seq[0]
-                    pol_particles[step] = sim_svmpc.theta.detach().clone()
+                a_seq, p_weights = dual.forward(state)
+                action = a_seq[0]
+                if p_weights is not None:
+                    pol_particles[step] = dual.theta.detach().clone()
                     weights[step] = p_weights
             else:
                 sim_ctrl.forward(state, model, ep_dyn_dist)
@@ -74,7 +75,10 @@ def run_pendulum_simulation(init_state, init_policies, model_kwargs, dyn_dist, e
             actions[step] = action
             state = plant.step(state, torch.as_tensor(action, dtype=torch.float).clamp(-2.0, 2.0).reshape(1, -1)).reshape(1, -1)
             if sim_mpf is not None:
-                _, bw = sim_mpf.optimize(action.squeeze(), state, bw=mpf_bw, n_steps=mpf_steps)
+                if dual is not None:
+                    _, bw = dual.step(action, state)
+                else:
+                    _, bw = sim_mpf.optimize(action.squeeze(), state, bw=mpf_bw, n_steps=mpf_steps)
                 dyn_particles[step] = sim_mpf.x
                 dyn_bws[step] = bw
             cost = sim_ctrl.inst_cost_fn(state.view(1, -1))

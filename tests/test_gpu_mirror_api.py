@@ -592,3 +592,70 @@ def test_mpf_control_noise_through_the_class_api(golden):
     assert elemerr(mpf.x.numpy(), g["x_final"]) < 1e-5 and relerr(grads.numpy(), g["grad_norms"]) < 2e-4
     mpf.optimize(torch.tensor(g["action2"]), torch.tensor(g["obs2"]), bw=float(g["bw"]), n_steps=n)
     assert elemerr(mpf.x.numpy(), g["x_final2"]) < 1e-5
+
+
+def test_dual_svmpc_facade_vs_reference_driver(golden):
+    """BASELINE north_star's named surface, `DualSVMPC` with step() / forward() (the reference composes the two inferences by hand:
+    dust/utils/simulations.py:104-138), held to the golden of the reference's OWN dual loop (`driver_pend_dual`): forward(state) =
+    optimize + forward (zero plan while warming up), step(action, new_state) = the filter update; tick() = forward, plant, step.
+    A deep copy continues identically (the loop deep-copies controller and filter per episode, simulations.py:62,78)."""
+    import copy
+
+    from dust_amd.controllers import DualSVMPC, MultiDISCO
+    from dust_amd.inference import MPF, SVMPC, ExponentiatedUtility, GaussianLikelihood, get_gmm
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import PendulumModel
+
+    g = golden("driver_pend_dual")
+    N, H, S, M = (int(g[k]) for k in ("N", "H", "S", "M"))
+    steps, warm = int(g["steps"]), int(g["warm_up"])
+    env_model = PendulumModel()
+    init_state = torch.tensor(g["init_state"])
+    init_policies = torch.tensor(g["init_policies"])
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), float(g["sigma"]) ** 2 * torch.eye(1))
+    ctrl = MultiDISCO(observation_space=env_model.observation_space, action_space=env_model.action_space, hz_len=H, action_samples=S,
+                      params_samples=M, temperature=1.0, a_cov=float(g["sigma"]) ** 2 * torch.eye(1), inst_cost_fn=inst_cost,
+                      term_cost_fn=term_cost, params_sampling=True, n_policies=N, params_log_space=False)
+    ctrl.a_mat = init_policies.clone()
+    ctrl.return_rollouts = False
+    ctrl.draw_source = RecordedDraws(eps=list(g["eps"]), params=list(g["params"]))
+    mpf_model = PendulumModel(uncertain_params=("length", "mass"))
+    mpf = MPF(init_particles=torch.tensor(g["mpf_init"]), likelihood=GaussianLikelihood(initial_obs=init_state, obs_std=float(g["obs_std"]),
+                                                                                         model=mpf_model, log_space=False),
+              optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]), bw=float(g["mpf_bw"]), bw_scale=1.0)
+    # the model the controller rolls out: the filter prior's mean parameters (use_exact_model=False, simulations.py:45-47)
+    model = PendulumModel(length=mpf.prior.mean[0], mass=mpf.prior.mean[1], uncertain_params=("length", "mass"))
+    sv = SVMPC(likelihood=ExponentiatedUtility(alpha=1.0, n_samples=S, controller=ctrl, model=model), init_particles=init_policies, prior=prior,
+               kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]))
+    dual = DualSVMPC(sv, mpf, mpf_bw=float(g["mpf_bw"]), mpf_steps=int(g["mpf_steps"]), warm_up=warm)
+    assert dual.dyn_dist is mpf.prior and dual.controller is ctrl
+    plant_model = PendulumModel(g=10.0, length=float(g["true_length"]), mass=float(g["true_mass"]))  # the driver's gym stand-in
+
+    def plant(state, action):
+        return plant_model.step(state, torch.as_tensor(action, dtype=torch.float).clamp(-2.0, 2.0).reshape(1, -1)).reshape(1, -1)
+
+    state = init_state.reshape(1, -1)
+    twin = None
+    for t in range(steps):
+        if t == steps - 1:
+            twin = copy.deepcopy(dual)  # (taken before the last tick: it must produce the same last tick)
+            twin_state = state.clone()
+        assert relerr(state.numpy().reshape(-1), g["state_in"][t]) < 1e-4, t
+        action, state, pw = dual.tick(state, plant)
+        assert relerr(dual.dyn_particles.numpy(), g["mpf_x"][t]) < (1e-5 if t == 0 else 1e-3), t
+        if t < warm:
+            assert pw is None and float(action.abs().max()) == 0.0
+            continue
+        k = t - warm
+        assert int(pw.argmax()) == int(np.argmax(g["p_weights"][k])) and relerr(pw.numpy(), g["p_weights"][k]) < 5e-3, t
+        assert abs(float(action[0]) - float(g["a_seq"][k][0, 0])) < 2e-3 * max(1.0, abs(float(g["a_seq"][k][0, 0]))), t
+        assert relerr(dual.theta.numpy()[:, 0, 0], g["theta_fwd"][k][:, 0, 0]) < 2e-3, t
+    # the deep copy: same recorded draws (copied with the controller), same tick
+    a2, s2, pw2 = twin.tick(twin_state, plant)
+    assert torch.equal(a2, action) and torch.equal(s2, state) and torch.equal(pw2, pw)
+    assert twin.controller is not ctrl and twin.mpf is not mpf and twin.dyn_dist is twin.mpf.prior
+    # the control half alone (no filter): forward() works, step() is a no-op
+    solo = DualSVMPC(sv, None, dyn_dist=mpf.prior, warm_up=0)
+    ctrl.draw_source = None
+    a_seq, pw = solo.forward(state)
+    assert a_seq.shape == (H, 1) and abs(float(pw.sum()) - 1.0) < 1e-3 and solo.step(a_seq[0], state) == (None, None)
