@@ -146,8 +146,9 @@ class Context:
             self.set_grid(grid)
         if _handle is None and got.model == L.MODEL_SKID_STEER:
             self.set_skid_steer(uncertain_params=kw.get("uncertain_params"), sampling=kw.get("sampling"), **skid_kw)
-        if k2_bw is not None and float(k2_bw) >= 0:  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth instead of the median trick
-            L.check(lib.dust_set_k2_bandwidth(self._h, float(k2_bw), float(k2_min)))
+        # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth instead of the median trick; RBF(minimum_bw=): the clamp of either (base_kernels.py:44-92)
+        if (k2_bw is not None and float(k2_bw) >= 0) or (_handle is None and float(k2_min) != 1e-5 and got.kernel in (L.KERNEL_K2_IIDMP, L.KERNEL_K2_SHARED)):
+            L.check(lib.dust_set_k2_bandwidth(self._h, float(-1.0 if k2_bw is None else k2_bw), float(k2_min)))
 
     # ---- lifecycle
     # ---- C-side multi-GPU tick (include/dust_amd.h dust_comm_*): one RCCL communicator per sharded context

@@ -24,6 +24,7 @@ struct K2Args {
   int shared;  // 1: one kernel per timestep (indep_controls=False)
   int i0, n_local;
   float bw_scale;
+  float min_bw;         // RBF(minimum_bw=) base_kernels.py:44, 83-89: the clamp of every bandwidth (1e-5 by default)
   float fixed_h;        // > 0: RBF(bandwidth >= 0) base_kernels.py:66-67 - every kernel uses this h (host-evaluated), no median pass
   const float *theta;   // [N][D]
   const float *thetaT;  // [D][N]
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   // not (first call, a jump), nothing is lost but the two probes.  The answer is the same exact order statistic either way.
   {
     const float hp = a.h[c];
-    const float vp = hp > 1.0e-5f && a.bw_scale > 0.f ? (hp / a.bw_scale) * (float)log((double)N + 1.0) : 0.f;
+    const float vp = hp > a.min_bw && a.bw_scale > 0.f ?  /* (a clamped bandwidth says nothing about the median) */ (hp / a.bw_scale) * (float)log((double)N + 1.0) : 0.f;
     if (vp > 0.f && vp < span * span) {  // (wave-uniform: one value per workgroup)
       const unsigned plo = __float_as_uint(vp * (1.0f - 0.0078125f)), phi_ = __float_as_uint(vp * (1.0f + 0.0078125f));
       int bb[2];
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
     float h = __uint_as_float(lo);
     h = h / (float)log((double)N + 1.0);  // base_kernels.py:77
     h = a.bw_scale * h;
-    a.h[c] = fmaxf(h, 1e-5f);
+    a.h[c] = fmaxf(h, a.min_bw);
   }
 }
 
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_big_kernel(const K2A
     float h = __uint_as_float(lo);
     h = h / (float)log((double)N + 1.0);  // base_kernels.py:77
     h = a.bw_scale * h;
-    a.h[c] = fmaxf(h, 1e-5f);
+    a.h[c] = fmaxf(h, a.min_bw);
   }
 }
 
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_pairs_kernel(const K2Args a
     float h = __uint_as_float(lo);
     h = h / (float)log((double)N + 1.0);
     h = a.bw_scale * h;
-    a.h[g] = fmaxf(h, 1e-5f);
+    a.h[g] = fmaxf(h, a.min_bw);
   }
 }
 

@@ -208,6 +208,7 @@ struct dust_ctx {
   bool states_valid, states_f16;  // the last rollout launch left states [M][S][N][H+1][ds] in `states` (binary16 when states_f16)
   bool k2_bw_ahead;   // K2: transpose + bandwidths of the current theta are already in flight on the side stream
   float k2_fixed_h;   // > 0: fixed-bandwidth RBF (dust_set_k2_bandwidth), else the median trick
+  float k2_min_bw;    // RBF(minimum_bw=): clamp of the median-trick bandwidths (0: the reference's default 1e-5)
   bool noise_f16;     // the eps / actions handed to the current call are binary16 (DUST_EPS_F16), set by the API entry points
   bool actions_f16;   // the kept actions were stored as binary16
   int graph_flags;
@@ -930,8 +931,11 @@ extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->cfg.kernel != DUST_KERNEL_K2_IIDMP && c->cfg.kernel != DUST_KERNEL_K2_SHARED)
     return fail(DUST_ERR_STATE, "dust_set_k2_bandwidth: the context's kernel is not iid_mp(RBF)");
-  if (bandwidth < 0.f) {
+  if (!(minimum_bw > 0.f)) return fail(DUST_ERR_INVALID, "minimum_bw must be > 0");
+  if (bandwidth < 0.f) {  // the median trick, clamped at minimum_bw (base_kernels.py:83-89)
     c->k2_fixed_h = 0.f;
+    c->k2_min_bw = minimum_bw;
+    if (c->graph_exec) graph_drop(c);
     return DUST_OK;
   }
   double h = (double)bandwidth * (double)bandwidth;
@@ -2180,6 +2184,7 @@ static K2Args k2_args(dust_ctx *c) {
   k.i0 = c->n0;
   k.n_local = c->nloc;
   k.bw_scale = c->cfg.bw_scale;
+  k.min_bw = c->k2_min_bw > 0.f ? c->k2_min_bw : 1e-5f;
   k.fixed_h = c->k2_fixed_h;
   k.theta = c->theta;
   k.thetaT = c->thetaT;

@@ -29,8 +29,6 @@ def kernel_config(kernel):
     if kernel is None or isinstance(kernel, RBFKernel) or type(kernel).__name__ == "RBFKernel":
         return dict(kernel="K1")
     if isinstance(kernel, iid_mp):
-        if kernel.base_kernel.ell < 0 and kernel.base_kernel.minimum_bw != 1e-5:
-            raise NotImplementedError("RBF(minimum_bw != 1e-5) with the median trick is not implemented on the device")
         return dict(kernel="K2" if kernel.indep_controls else "K2shared", bw_scale=kernel.base_kernel.ell_scale,
                     k2_bandwidth=kernel.base_kernel.ell, k2_minimum_bw=kernel.base_kernel.minimum_bw)
     if isinstance(kernel, IMQ):

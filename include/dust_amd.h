@@ -167,8 +167,9 @@ int dust_set_grid(dust_ctx *ctx, const float *grid, int nx, int ny, float off_x,
 
 /* particle / prior / controller state (all [N][H][da] or [N]) */
 int dust_set_theta(dust_ctx *ctx, const float *theta);                                /* SVMPC.theta svmpc.py:25 */
-/* RBF(bandwidth=, minimum_bw=) of the K2 kernels (base_kernels.py:44-92): bandwidth < 0 = median trick (default); otherwise the
- * fixed h = clip(bw_scale * bandwidth^2 / log(N + 1), minimum_bw) replaces the per-dimension medians. */
+/* RBF(bandwidth=, minimum_bw=) of the K2 kernels (base_kernels.py:44-92): bandwidth < 0 = median trick (default), every
+ * per-dimension h = max(bw_scale * median / log(N + 1), minimum_bw); otherwise the fixed h = clip(bw_scale * bandwidth^2 / log(N + 1),
+ * minimum_bw) replaces the medians.  minimum_bw > 0 (the reference's default is 1e-5). */
 int dust_set_k2_bandwidth(dust_ctx *ctx, float bandwidth, float minimum_bw);
 int dust_get_theta(dust_ctx *ctx, float *theta);
 int dust_set_prior(dust_ctx *ctx, const float *means, const float *mix_weights);      /* get_gmm svgd.py:84-89 */

@@ -27,6 +27,8 @@ def ctx_kwargs(g):
         kw["deterministic"] = bool(int(g["deterministic"]))
     if "k2_bandwidth" in g and float(g["k2_bandwidth"]) >= 0:
         kw["k2_bandwidth"] = float(g["k2_bandwidth"])  # iid_mp(RBF(bandwidth >= 0)): fixed bandwidth
+    if "k2_minimum_bw" in g:
+        kw["k2_minimum_bw"] = float(g["k2_minimum_bw"])  # RBF(minimum_bw=): the clamp of the median-trick bandwidths
     return kw
 
 

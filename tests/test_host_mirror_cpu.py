@@ -63,6 +63,9 @@ def test_kernel_config():
     assert kernel_config(iid_mp(RBF(bandwidth=-1), ctrl_dim=2, indep_controls=True))["kernel"] == "K2"
     assert kernel_config(iid_mp(RBF(bandwidth=-1), ctrl_dim=2, indep_controls=False))["kernel"] == "K2shared"
     assert kernel_config(IMQ(0.7)) == dict(kernel="IMQ", imq_ell=0.7)
+    # RBF(minimum_bw=) travels with the median trick as well as with a fixed bandwidth (base_kernels.py:44, 83-89)
+    kc = kernel_config(iid_mp(RBF(bandwidth=-1, minimum_bw=1.4), ctrl_dim=1, indep_controls=True))
+    assert kc["k2_minimum_bw"] == 1.4 and kc["k2_bandwidth"] == -1
     with pytest.raises(ValueError):
         kernel_config(RBF())
 

@@ -16,7 +16,8 @@ SVMPC_CASES = ["pend_k1", "pend_k1_close", "pend_k2", "pend_k1_params", "pend_k1
                "pend_cfg1", "part_k1_gmm", "part_k2_gmm", "part_k2shared", "part_k1_scalar", "part_k1_near_obst",
                "pend_k1_adam", "part_k1_adam", "pend_k1_f64", "pend_k1_mid_f64", "pend_k2_fixedbw", "part_k2shared_fixedbw",
                # round 5: control-channel noise (particle.py:145-148) and velocity control (particle.py:152-153)
-               "part_k1_noisy", "part_k1_velocity", "part_k2_noisy_vel", "part_k1_noisy_zero"]
+               "part_k1_noisy", "part_k1_velocity", "part_k2_noisy_vel", "part_k1_noisy_zero",
+               "pend_k2_minbw"]  # RBF(minimum_bw=1.4) under the median trick: about half of the per-dimension bandwidths are clamped
 K1_F64_CASES = ["pend_k1_f64", "pend_k1_mid_f64"]
 
 
@@ -98,8 +99,11 @@ def test_score_phi_update(golden, name):
                 phi = o.phi_k1(theta, sc, variant=0)
                 tol = k1_tolerance(theta)
             elif kind == "K2":
-                phi, _ = o.phi_k2(theta, sc, indep=True, bandwidth=float(g["k2_bandwidth"]) if "k2_bandwidth" in g else -1.0)
+                phi, hk = o.phi_k2(theta, sc, indep=True, bandwidth=float(g["k2_bandwidth"]) if "k2_bandwidth" in g else -1.0,
+                                   minimum_bw=float(g["k2_minimum_bw"]) if "k2_minimum_bw" in g else 1e-5)
                 tol = TOL
+                if "k2_minimum_bw" in g and (t, k) == (0, 0):  # the fixture must have clamped AND free dimensions
+                    assert 2 <= int((hk == np.float32(g["k2_minimum_bw"])).sum()) <= hk.size - 2
             else:
                 phi, _ = o.phi_k2(theta, sc, indep=False, bandwidth=float(g["k2_bandwidth"]) if "k2_bandwidth" in g else -1.0)
                 tol = TOL
