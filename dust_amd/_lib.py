@@ -65,6 +65,7 @@ class Config(C.Structure):
         ("target", C.c_float * 4), ("w_state", C.c_float * 4), ("w_term", C.c_float * 4), ("w_ctrl", C.c_float * 2),
         ("w_obs", C.c_float),
         ("control_type", C.c_int32), ("ctrl_noise", C.c_int32), ("dyn_std", C.c_float * 2),
+        ("full_cov", C.c_int32), ("chol_a_off", C.c_float), ("a_pre_off", C.c_float), ("chol_p", C.c_float * 3),
     ]
 
 

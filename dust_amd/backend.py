@@ -44,7 +44,9 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
                 max_speed=5.0, max_accel=10.0, can_crash=True, with_obstacle=True, cell_size=0.1,
                 target=(9.0, 9.0, 0.0, 0.0), w_state=(0.5, 0.5, 0.25, 0.25), w_term=(1e3, 1e3, 0.1, 0.1), w_ctrl=(0.2, 0.2),
                 w_obs=1e6, min_a=None, max_a=None, adam=(0.9, 0.999, 1e-8), sampling=None, control_type="acceleration",
-                deterministic=True, noise_std=(0.0, 0.0), **_ignored):
+                deterministic=True, noise_std=(0.0, 0.0), a_cov=None, p_cov=None, **_ignored):
+    """a_cov / p_cov: FULL [da, da] action / prior-component covariances (MultiDISCO(a_cov=) disco.py:91-98; get_gmm svgd.py:84-89);
+    they take precedence over sigma_a / sigma_p / chol_a / a_pre, which describe diagonal ones."""
     c = L.Config()
     c.abi_version = L.ABI_VERSION
     c.device = device
@@ -86,6 +88,24 @@ def make_config(model="pendulum", N=1, S=1, M=1, H=1, uncertain_params=None, par
     ap = (1.0 / (sa.astype(np.float32) ** 2)) if a_pre is None else np.broadcast_to(np.asarray(a_pre, np.float32), (c.dim_a,))
     for d in range(c.dim_a):
         c.sigma_a[d], c.sigma_p[d], c.chol_a[d], c.a_pre[d] = sa[d], sp[d], ch[d], ap[d]
+    if a_cov is not None or p_cov is not None:
+        import torch  # (the factorisations in fp32, as the reference's torch.linalg.cholesky / torch.inverse produce them)
+
+        ac = torch.diag(torch.as_tensor(sa.astype(np.float32)) ** 2) if a_cov is None else torch.as_tensor(np.asarray(a_cov, np.float32))
+        pc = torch.diag(torch.as_tensor(sp.astype(np.float32)) ** 2) if p_cov is None else torch.as_tensor(np.asarray(p_cov, np.float32))
+        if tuple(ac.shape) != (c.dim_a, c.dim_a) or tuple(pc.shape) != (c.dim_a, c.dim_a):
+            raise ValueError("a_cov / p_cov must be [%d, %d] matrices" % (c.dim_a, c.dim_a))
+        la, lp, pre = torch.linalg.cholesky(ac), torch.linalg.cholesky(pc), torch.inverse(ac)
+        for d in range(c.dim_a):
+            c.chol_a[d], c.a_pre[d] = float(la[d, d]), float(pre[d, d])
+            c.sigma_a[d], c.sigma_p[d] = float(ac[d, d].sqrt()), float(pc[d, d].sqrt())
+        off = c.dim_a == 2 and (float(ac[0, 1]) != 0.0 or float(ac[1, 0]) != 0.0 or float(pc[0, 1]) != 0.0 or float(pc[1, 0]) != 0.0)
+        if off:
+            c.full_cov = 1
+            c.chol_a_off, c.a_pre_off = float(la[1, 0]), float(pre[0, 1])
+            c.chol_p[0], c.chol_p[1], c.chol_p[2] = float(lp[0, 0]), float(lp[1, 0]), float(lp[1, 1])
+        elif c.dim_a > 2 or not torch.equal(ac, torch.diag(torch.diag(ac))) or not torch.equal(pc, torch.diag(torch.diag(pc))):
+            raise NotImplementedError("full covariances are implemented for dim_a = 2")
     c.bw_scale, c.imq_ell = bw_scale, imq_ell
     lo = np.broadcast_to(np.asarray((-2.0 if pend else (-0.5 if skid else -max_accel)) if min_a is None else min_a, np.float32), (c.dim_a,))
     hi = np.broadcast_to(np.asarray((2.0 if pend else (0.5 if skid else max_accel)) if max_a is None else max_a, np.float32), (c.dim_a,))

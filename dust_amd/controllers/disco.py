@@ -34,8 +34,8 @@ class MultiDISCO:
         if a_cov is None:
             a_cov = torch.eye(self.dim_a)
         a_cov = torch.as_tensor(a_cov, dtype=torch.float)
-        if not torch.equal(a_cov, torch.diag(torch.diag(a_cov))):
-            raise NotImplementedError("only diagonal a_cov has a HIP kernel (no CPU fallback)")
+        if not torch.equal(a_cov, torch.diag(torch.diag(a_cov))) and self.dim_a != 2:
+            raise NotImplementedError("a full a_cov has a HIP kernel for dim_a = 2 (no CPU fallback)")
         self.a_dist = torch.distributions.multivariate_normal.MultivariateNormal(torch.zeros(self.dim_a), a_cov)
         self.a_pre = torch.inverse(a_cov)
         self._a_seq = torch.zeros((hz_len, self.dim_a))
@@ -83,6 +83,7 @@ class MultiDISCO:
         cfg = dict(model=model.family, N=self.n_pol, S=self.n_actions, M=self._tf.pts if self._tf is not None else self.n_params, H=self.hz_len,
                    temperature=float(self.temp), ctrl_penalty=float(self._ctrl_penalty), alpha=1.0 / float(self.temp),
                    chol_a=chol.numpy(), sigma_a=sigma.numpy(), a_pre=self.a_pre.diag().numpy(),
+                   a_cov=self.a_dist.covariance_matrix.numpy(),  # (a full matrix takes the off-diagonal path: disco.py:91-98)
                    min_a=self.min_a.numpy(), max_a=self.max_a.numpy(), device=self._device, seed=self._seed, dt=model.dt,
                    params_log_space=bool(self._params_log_space), sampling=self._sampling)
         if self._sampling:

@@ -95,6 +95,7 @@ struct dust_ctx {
   float *pS;                 // Gram x score partials of the one-launch iteration (pA still holds the prior's while its Stein tiles run)
   size_t pS_cap;
   float *mw_dev;             // [M] unscented-transform weights of the dynamics samples (nullptr: mean)
+  float *theta_w, *mu_w;     // full prior covariance: whitened copies L_p^-1 x of the particles / prior means, refreshed before each prior pass
   float *cz_dev;             // recorded control-noise draws [cz_sets][H][M*S*N][da] (dust_set_ctrl_noise), consumed one set per rollout launch
   size_t cz_cap;
   int cz_sets, cz_next;
@@ -359,6 +360,10 @@ static int validate(const dust_config *g) {
     if (!(g->chol_a[d] > 0.f) || !(g->sigma_a[d] > 0.f) || !(g->sigma_p[d] > 0.f))
       return fail(DUST_ERR_INVALID, "covariance diagonals must be positive (only diagonal a_cov / prior covariances are supported)");
   if (!(g->temperature > 0.f)) return fail(DUST_ERR_INVALID, "temperature must be > 0");
+  if (g->full_cov) {
+    if (g->dim_a != 2) return fail(DUST_ERR_INVALID, "full covariances are 2 x 2: dim_a = %d", g->dim_a);
+    if (!(g->chol_p[0] > 0.f) || !(g->chol_p[2] > 0.f)) return fail(DUST_ERR_INVALID, "chol_p must be the Cholesky factor of an SPD prior covariance (positive diagonal)");
+  }
   return DUST_OK;
 }
 
@@ -367,7 +372,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev, &c->cz_dev};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -426,7 +431,10 @@ static bool particle_general(const dust_ctx *c) {
   return c->cfg.control_type == DUST_CONTROL_VELOCITY || (c->cfg.ctrl_noise && (c->cfg.dyn_std[0] != 0.f || c->cfg.dyn_std[1] != 0.f));
 }
 // families whose rollouts are a launch of their own followed by the regular kernel in its injected-costs mode: launch-per-iteration path only
-static bool two_pass_family(const dust_ctx *c) { return c->cfg.model == DUST_MODEL_SKID_STEER || particle_general(c); }
+// ... and contexts with a FULL 2 x 2 action / prior covariance (disco.py:91-98, svgd.py:84-89): the one-launch and fused forms carry the
+// diagonal arithmetic only - the launch-per-iteration kernels take the off-diagonal terms (rollout.hpp stage 1, the whitened prior pass)
+static bool full_cov(const dust_ctx *c) { return c->cfg.full_cov != 0; }
+static bool two_pass_family(const dust_ctx *c) { return c->cfg.model == DUST_MODEL_SKID_STEER || particle_general(c) || full_cov(c); }
 static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || c->env.comm_force >= 0); }
 static void comm_release(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
@@ -1048,6 +1056,7 @@ static bool pair_is_big(const dust_ctx *c) {
 }
 static bool pair_big_kernel(const dust_ctx *c) { return pair_is_big(c) && c->D <= 64 && c->nloc == c->N; }  // pairwise_big.hpp (unfused passes)
 static bool pair_fused_ok(const dust_ctx *c) {
+  if (c->cfg.full_cov) return false;  // (one distance serves prior and Stein kernel there: not with a prior metric of its own)
   if (c->env.pair_fused == 0) return false;  // development switch DUST_PAIR_FUSED: 0 keeps the two unfused passes
   return pair_is_big(c) && c->mu_aliased && (c->cfg.kernel == DUST_KERNEL_K1_RBF || c->cfg.kernel == DUST_KERNEL_IMQ);
 }
@@ -1123,6 +1132,12 @@ static PriorMerge prior_merge_args(const dust_ctx *c) {
     pm.inv_s2[d] = 1.0f / (c->cfg.sigma_p[d] * c->cfg.sigma_p[d]);
     logdet += log((double)c->cfg.sigma_p[d]);
   }
+  if (full_cov(c)) {  // the pass runs on whitened rows (prior_args): unit scale there, log det L_p in the constant
+    pm.full = 1;
+    for (int k = 0; k < 3; ++k) pm.Lp[k] = c->cfg.chol_p[k];
+    pm.inv_s2[0] = pm.inv_s2[1] = 1.0f;
+    logdet = log((double)c->cfg.chol_p[0]) + log((double)c->cfg.chol_p[2]);
+  }
   pm.log_norm = (float)(-c->H * logdet - 0.5 * c->D * log(2.0 * M_PI));
   return pm;
 }
@@ -1159,6 +1174,9 @@ static int rollout_args(dust_ctx *c, const SampleOpts &o, RolloutArgs &a, int *n
     a.sigma_a[d] = c->cfg.sigma_a[d];
     a.a_pre[d] = c->cfg.a_pre[d];
   }
+  a.full_cov = c->cfg.full_cov ? 1 : 0;
+  a.chol_off = c->cfg.full_cov ? c->cfg.chol_a_off : 0.f;
+  a.a_pre_off = c->cfg.full_cov ? c->cfg.a_pre_off : 0.f;
   a.state = c->state_dev;
   a.theta = o.base;
   a.noise = o.noise_dev;
@@ -1320,6 +1338,7 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       k.dt = (float)c->cfg.dt;
       k.chol_a[0] = a.chol_a[0];
       k.chol_a[1] = a.chol_a[1];
+      k.chol_off = a.chol_off;
       k.seed = a.seed;
       k.ctr = a.ctr;
       k.noise = a.noise;
@@ -1364,6 +1383,8 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       k.a_pre[d] = a.a_pre[d];
     }
     k.a_reg = a.a_reg;
+    k.chol_off = a.chol_off;
+    k.a_pre_off = a.a_pre_off;
     k.seed = a.seed;
     k.ctr = a.ctr;
     k.noise = a.noise;
@@ -2012,6 +2033,22 @@ static int ensure_partials(dust_ctx *c, int JS) {
 }
 
 // prior pass: writes slice partials (pA, pM, pL); combined by rollout_kernel (merge_prior) or prior_finish_kernel
+static int ensure_whitened(dust_ctx *c) {
+  const size_t nd = (size_t)c->N * c->D;
+  if (!c->theta_w) TRY(dalloc(&c->theta_w, nd));
+  if (!c->mu_w) TRY(dalloc(&c->mu_w, nd));
+  return DUST_OK;
+}
+static int launch_whiten(dust_ctx *c) {
+  TRY(ensure_whitened(c));
+  const int n_pairs = c->N * c->H;
+  const float *L = c->cfg.chol_p;
+  whiten_rows_kernel<<<(n_pairs + 255) / 256, 256, 0, c->pair_stream>>>(c->theta, c->theta_w, n_pairs, L[0], L[1], L[2]);
+  if (!c->mu_aliased) whiten_rows_kernel<<<(n_pairs + 255) / 256, 256, 0, c->pair_stream>>>(c->mu, c->mu_w, n_pairs, L[0], L[1], L[2]);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+
 static int prior_args(dust_ctx *c, PairArgs &a, int *tiles) {
   memset(&a, 0, sizeof a);
   pair_geometry(c, tiles, &a.JS, &a.slice);
@@ -2027,6 +2064,15 @@ static int prior_args(dust_ctx *c, PairArgs &a, int *tiles) {
   a.logmix = c->logmix;
   a.magicD = (uint32_t)((1ull << 32) / (uint64_t)c->D) + 1u;
   for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f / c->cfg.sigma_p[d < c->da ? d : 0];
+  if (full_cov(c)) {
+    // full prior covariance: the pass sees z = L_p^-1 x (stein.hpp whiten_rows_kernel, launched by launch_prior) at unit scale - its
+    // squared distance is the Mahalanobis distance and its weighted sum the gradient in whitened coordinates (prior_finish_kernel
+    // turns it back: L_p^-T)
+    TRY(ensure_whitened(c));
+    a.X = c->theta_w;
+    a.Y = c->mu_aliased ? c->theta_w : c->mu_w;
+    for (int d = 0; d < 4; ++d) a.inv_s[d] = 1.0f;
+  }
   a.pA = c->pA;
   a.pM = c->pM;
   a.pL = c->pL;
@@ -2040,6 +2086,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   TRY(prior_args(c, a, &tiles));
   Prof p(c, DUST_K_PRIOR_SCORE);
   c->prior_js = 0;  // (launch_pair_fused sets its own slice count)
+  if (full_cov(c)) TRY(launch_whiten(c));
   if (logp_only && pair_fused_ok(c)) {  // large aliased set
     if (c->env.logp_mfma != 0) return launch_pair_logp_mfma(c, a);  // product-form distances on the matrix cores + log-sum-exp
     return launch_pair_logp_big(c, a, tiles);                         // exact-difference distance pass + log-sum-exp
@@ -2346,8 +2393,9 @@ extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *acti
     o.noise_dev = nd;
     o.base = c->theta;
     o.costs_in = c->costs_stage;
-    o.merge_prior = 1;
+    o.merge_prior = full_cov(c) ? 0 : 1;
     TRY(launch_rollout(c, o));
+    if (full_cov(c)) TRY(launch_prior_finish(c, true, false));
   } else {
     if (!c->have_sample) return fail(DUST_ERR_STATE, "phi without costs/actions needs a prior dust_likelihood_sample");
     TRY(launch_prior_finish(c, true, false));
@@ -2403,17 +2451,16 @@ static int local_score_device(dust_ctx *c, const float *noise_dev, int param_set
   o.base = c->theta;
   o.update_a_mat = 1;
   o.bump_adam = 1;
-  o.merge_prior = overlap ? 0 : 1;
+  const bool split = overlap || full_cov(c);  // (full prior covariance: the merge epilogue of the rollout kernel has no back-substitution)
+  o.merge_prior = split ? 0 : 1;
   float *save = c->params_dev;
   if (c->params_dev) c->params_dev += (size_t)param_set * c->M * c->P;
   int s = launch_rollout(c, o);
   c->params_dev = save;
   TRY(s);
   c->have_sample = true;
-  if (overlap) {
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    TRY(launch_prior_finish(c, true, false));
-  }
+  if (overlap) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  if (split) TRY(launch_prior_finish(c, true, false));
   return DUST_OK;
 }
 

@@ -31,6 +31,7 @@ struct PartGenArgs {
   int ctrl_noise;  // Particle(deterministic=False)
   float dyn_std[2];
   float chol_a[2], a_pre[2];
+  float chol_off, a_pre_off;  // full a_cov (disco.py:91-98): L[1][0] and the off-diagonal entry of inverse(a_cov) (0: diagonal forms)
   float a_reg;
   uint64_t seed;
   const uint32_t *ctr;  // {tick, iter, ..}: Philox stream position, as the regular kernel reads it
@@ -57,13 +58,18 @@ __global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs
   const _Float16 *nzh = (a.noise && a.noise_f16) ? reinterpret_cast<const _Float16 *>(a.noise) + row : nullptr;
   const float *th = a.theta + (size_t)n * D;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
-  auto action = [&](const int j) -> float {
+  auto action = [&](const int j) -> float {  // theta + L eps (an odd column of a full L takes its partner draw too)
     const float v = nzh ? (float)nzh[j] : (nz ? nz[j] : 0.f);
     if (a.noise_mode == NOISE_ACTIONS) return v;
-    if (a.noise_mode == NOISE_EPS) return th[j] + a.chol_a[j & 1] * v;
+    const bool pair = (j & 1) && a.chol_off != 0.f;
+    if (a.noise_mode == NOISE_EPS) {
+      if (!pair) return th[j] + a.chol_a[j & 1] * v;
+      const float vp = nzh ? (float)nzh[j - 1] : nz[j - 1];
+      return th[j] + (a.chol_off * vp + a.chol_a[1] * v);
+    }
     float z[8];
     philox_normal8(a.seed, (uint32_t)(j >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
-    return th[j] + a.chol_a[j & 1] * z[j & 7];
+    return pair ? th[j] + (a.chol_off * z[(j & 7) - 1] + a.chol_a[1] * z[j & 7]) : th[j] + a.chol_a[j & 1] * z[j & 7];
   };
   const DevModel &dm = a.dm;
   const float dt = (float)dm.dt;
@@ -161,7 +167,12 @@ __global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs
     double cc = 0.0;
     for (int j = 0; j < D; ++j) {
       const float e = action(j) - a.a_seq[j];
-      cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * a.a_pre[j & 1]);
+      float ap = a.a_mat[(size_t)n * D + j] * a.a_pre[j & 1];
+      if (a.a_pre_off != 0.f) {  // (a_mat[n, t, :] @ a_pre)[d] with a full symmetric a_pre
+        const float m0 = a.a_mat[(size_t)n * D + (j & ~1)], m1 = a.a_mat[(size_t)n * D + (j | 1)];
+        ap = (j & 1) ? (m0 * a.a_pre_off + m1 * a.a_pre[1]) : (m0 * a.a_pre[0] + m1 * a.a_pre_off);
+      }
+      cc += (double)(-e) * (double)ap;
     }
     cost = cost + a.a_reg * (float)cc;
   }

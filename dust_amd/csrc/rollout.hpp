@@ -50,6 +50,9 @@ struct RolloutArgs {
   uint32_t magicD;   // floor(2^32 / D) + 1: exact division of tile indices by D
   float alpha, temp, a_reg;
   float chol_a[4], sigma_a[4], a_pre[4];
+  int full_cov;        // full 2 x 2 a_cov (disco.py:91-98): actions = theta + L eps with L[1][0] = chol_off, control cost through the full
+  float chol_off;      // a_pre (a_pre_off = its off-diagonal entry)
+  float a_pre_off;
   PriorMerge pm;
   const float *state;   // [ds] (device; refreshed by a 4-lane launch carrying the plant state as its argument before each tick)
   uint32_t *ctr;        // device counters {tick, iter, adam_step}: the Philox stream position (static under hipGraph replay)
@@ -199,8 +202,10 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
   wg_sync();
   bool nanf = tid < D && thv != thv;
   if (a.noise_mode != NOISE_PHILOX) {
-    const float thj = a.noise_mode == NOISE_EPS ? th[min(sj, D - 1)] : 0.f;
-    const float lj = a.noise_mode == NOISE_EPS ? pick_da<DA>(a.chol_a, sj) : 1.f;
+    // (full a_cov: the raw draws are staged and turned into actions by the pass below - a row of L eps needs two of them)
+    const bool eps_diag = a.noise_mode == NOISE_EPS && !(DA == 2 && a.full_cov);
+    const float thj = eps_diag ? th[min(sj, D - 1)] : 0.f;
+    const float lj = eps_diag ? pick_da<DA>(a.chol_a, sj) : 1.f;
     for (int s0 = 0; s0 < S; s0 += NB * R) {
       if (s0) {
         off0 += (uint32_t)NB * off_step;
@@ -216,6 +221,20 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           nanf |= av != av;
         }
       }
+    }
+  }
+  if (DA == 2 && a.full_cov && a.noise_mode == NOISE_EPS) {
+    // actions = theta + L eps, L lower triangular (MultivariateNormal.rsample: loc + scale_tril @ eps, likelihoods.py:85-90)
+    wg_sync();
+    for (int idx = tid; idx < S * (D >> 1); idx += nt) {
+      const int s = idx / (D >> 1), t = idx - s * (D >> 1);
+      float *p = tile + s * Dp + 2 * t;
+      const float e0 = p[0], e1 = p[1];
+      const float a0 = th[2 * t] + a.chol_a[0] * e0;
+      const float a1 = th[2 * t + 1] + (a.chol_off * e0 + a.chol_a[1] * e1);
+      p[0] = a0;
+      p[1] = a1;
+      nanf |= (a0 != a0) || (a1 != a1);
     }
   }
   if (nanf) red[40] = 1.f;
@@ -251,7 +270,9 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int j = j8 * 8 + q;
-          if (j < D) act[j] = th[j] + pick_da<DA>(a.chol_a, j) * z[q];
+          if (DA == 2 && a.full_cov && (q & 1)) {  // (an odd column's partner draw sits in the same block)
+            if (j < D) act[j] = th[j] + (a.chol_off * z[q - 1] + a.chol_a[1] * z[q]);
+          } else if (j < D) act[j] = th[j] + pick_da<DA>(a.chol_a, j) * z[q];
         }
       }
     }
@@ -267,7 +288,12 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       double cc = 0.0;
       for (int j = 0; j < D; ++j) {
         const float e = act[j] - a.a_seq[j];
-        cc += (double)(-e) * (double)(a.a_mat[(size_t)n * D + j] * pick_da<DA>(a.a_pre, j));
+        float ap = a.a_mat[(size_t)n * D + j] * pick_da<DA>(a.a_pre, j);
+        if (DA == 2 && a.full_cov) {  // (a_mat[n, t, :] @ a_pre)[d], a_pre a full symmetric 2 x 2 (disco.py:341-344)
+          const float m0 = a.a_mat[(size_t)n * D + (j & ~1)], m1 = a.a_mat[(size_t)n * D + (j | 1)];
+          ap = (j & 1) ? (m0 * a.a_pre_off + m1 * a.a_pre[1]) : (m0 * a.a_pre[0] + m1 * a.a_pre_off);
+        }
+        cc += (double)(-e) * (double)ap;
       }
       cost = cost + f_a_reg * (float)cc;
     }

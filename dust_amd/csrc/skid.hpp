@@ -31,6 +31,7 @@ struct SkidArgs {
   int log_space, interleave;
   float dt;
   float chol_a[2];
+  float chol_off;       // full a_cov: L[1][0] (0: diagonal)
   uint64_t seed;
   const uint32_t *ctr;  // {tick, iter, ..}: Philox stream position, as the regular kernel reads it
   const float *noise;   // [S][N][D] eps or actions
@@ -59,12 +60,12 @@ __global__ __launch_bounds__(256) void skid_rollout_kernel(const SkidArgs a) {
   const float *nz = a.noise ? a.noise + ((size_t)s * N + n) * D : nullptr;
   const float *th = a.theta + (size_t)n * D;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
-  auto action = [&](const int j) -> float {
+  auto action = [&](const int j) -> float {  // theta + L eps (an odd column of a full L takes its partner draw too)
     if (a.noise_mode == NOISE_ACTIONS) return nz[j];
-    if (a.noise_mode == NOISE_EPS) return th[j] + a.chol_a[j & 1] * nz[j];
+    if (a.noise_mode == NOISE_EPS) return (j & 1) && a.chol_off != 0.f ? th[j] + (a.chol_off * nz[j - 1] + a.chol_a[1] * nz[j]) : th[j] + a.chol_a[j & 1] * nz[j];
     float z[8];
     philox_normal8(a.seed, (uint32_t)(j >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
-    return th[j] + a.chol_a[j & 1] * z[j & 7];
+    return (j & 1) && a.chol_off != 0.f ? th[j] + (a.chol_off * z[(j & 7) - 1] + a.chol_a[1] * z[j & 7]) : th[j] + a.chol_a[j & 1] * z[j & 7];
   };
   if (a.actions_out)
     for (int j = 0; j < D; ++j) a.actions_out[((size_t)s * N + n) * D + j] = action(j);

@@ -517,6 +517,11 @@ struct PriorMerge {
   const float *pA, *pM, *pL;
   float inv_s2[4];
   float log_norm;  // -H sum(log sigma_p) - D/2 log(2 pi)
+  // full 2 x 2 prior covariance Sigma_p = L L^T (svgd.py:84-89): the pass ran on WHITENED rows z = L^-1 x (per time step; inv_s2 = 1,
+  // log_norm carries -H log det L), so its weighted sum g_z = sum_k r_k (z_k - z_i) is the gradient in whitened coordinates and
+  // grad_pri = L^-T g_z - what autograd returns through MultivariateNormal.log_prob's triangular solve
+  int full;
+  float Lp[3];  // l00, l10, l11
 };
 // loads are issued in batches of 8 with clamped (never predicated) indices so they overlap instead of serialising
 template <bool SC1 = false /* the partials were written (write-through) inside this launch */>
@@ -584,7 +589,14 @@ __global__ void prior_finish_kernel(const PriorFinishArgs a) {
   prior_merge_row(a.pm, il, &m, &l);
   const size_t o = (size_t)(a.i0 + il) * a.D + d;
   if (a.grad_pri || a.score) {
-    const float gp = prior_merge_col(a.pm, il, a.D, d, a.da, m, l);
+    float gp = prior_merge_col(a.pm, il, a.D, d, a.da, m, l);
+    if (a.pm.full) {  // back-substitution with L^T over the (even, odd) column pair of this time step
+      const float gq = prior_merge_col(a.pm, il, a.D, d ^ 1, a.da, m, l);
+      const float g0 = (d & 1) ? gq : gp, g1 = (d & 1) ? gp : gq;
+      const float w1 = g1 / a.pm.Lp[2];
+      const float w0 = (g0 - a.pm.Lp[1] * w1) / a.pm.Lp[0];
+      gp = (d & 1) ? w1 : w0;
+    }
     if (a.grad_pri) a.grad_pri[o] = gp;
     if (a.score) a.score[o] = a.grad_lik[o] + gp;
   }
@@ -593,6 +605,16 @@ __global__ void prior_finish_kernel(const PriorFinishArgs a) {
     a.logp[a.i0 + il] = lp;
     if (a.lw) a.lw[a.i0 + il] = a.logl[a.i0 + il] + lp;
   }
+}
+
+// z = L^-1 x per time step (forward substitution; MultivariateNormal.log_prob's _batch_mahalanobis): rows [n][H][2] -> [n][H][2]
+__global__ void whiten_rows_kernel(const float *x, float *z, const int n_pairs, const float l00, const float l10, const float l11) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const float2 v = reinterpret_cast<const float2 *>(x)[i];
+  const float z0 = v.x / l00;
+  const float z1 = (v.y - l10 * z0) / l11;
+  reinterpret_cast<float2 *>(z)[i] = make_float2(z0, z1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -26,11 +26,12 @@ class SVMPC:
         comp = prior.component_distribution.base_dist
         cov = comp.covariance_matrix
         cov = cov.reshape(-1, cov.shape[-2], cov.shape[-1])[0]
-        if not torch.equal(cov, torch.diag(torch.diag(cov))):
-            raise NotImplementedError("only diagonal prior covariances have a HIP kernel")
+        if not torch.equal(cov, torch.diag(torch.diag(cov))) and cov.shape[-1] != 2:
+            raise NotImplementedError("a full prior covariance has a HIP kernel for dim_a = 2")
         ctrl = likelihood.controller
         ctrl._svmpc_cfg.update(opt, likelihood=likelihood.kind, alpha=float(likelihood.alpha), weighted_prior=bool(weighted_prior),
-                               roll_strategy=roll_strategy, sigma_p=cov.diag().sqrt().numpy(), **kernel_config(kernel))
+                               roll_strategy=roll_strategy, sigma_p=cov.diag().sqrt().numpy(), p_cov=cov.detach().numpy().copy(),
+                               **kernel_config(kernel))
         self._theta0 = torch.as_tensor(init_particles, dtype=torch.float).detach().clone()
         self._prior0 = (comp.loc.detach().clone(), prior.mixture_distribution.probs.detach().clone())
         self._uploaded = False

@@ -115,6 +115,14 @@ typedef struct dust_config {
   int32_t control_type; /* dust_control_type */
   int32_t ctrl_noise;
   float dyn_std[2];
+  /* ABI 2: FULL 2 x 2 covariances (dim_a = 2).  MultiDISCO(a_cov=<any SPD matrix>) disco.py:91-98: policy noise actions = theta + L_a eps
+   * with L_a = cholesky(a_cov) (likelihoods.py:85-90) - chol_a[0..1] stay its diagonal, chol_a_off = L_a[1][0]; a_pre = inverse(a_cov)
+   * in the control cost (disco.py:338-346) - a_pre[0..1] stay its diagonal, a_pre_off = a_pre[0][1]; sigma_a stays sqrt(diag a_cov)
+   * (svmpc.py:107-111).  Prior components with a full covariance Sigma_p = L_p L_p^T (get_gmm svgd.py:84-89): chol_p = {L_p[0][0],
+   * L_p[1][0], L_p[1][1]}, sigma_p[0..1] stay sqrt(diag Sigma_p).  full_cov != 0 switches these on (all zero: the diagonal forms). */
+  int32_t full_cov;
+  float chol_a_off, a_pre_off;
+  float chol_p[3];
 } dust_config;
 
 /* SkidSteerRobot (dust/models/skid_steer_robot.py:19-52, step :73-122; model = DUST_MODEL_SKID_STEER, dim_s = 5: x, y, theta, v,

@@ -52,6 +52,7 @@ class _Cfg(C.Structure):
         ("target", C.c_float * 4), ("w_state", C.c_float * 4), ("w_term", C.c_float * 4), ("w_ctrl", C.c_float * 2),
         ("w_obs", C.c_float),
         ("velocity_ctrl", C.c_int), ("dyn_std", C.c_float * 2), ("ctrl_noise", C.POINTER(C.c_float)),
+        ("full_cov", C.c_int), ("chol_a_full", C.c_float * 3), ("a_pre_full", C.c_float * 3), ("chol_p_full", C.c_float * 3),
     ]
 
 
@@ -111,7 +112,7 @@ class Oracle:
                  params_log_space=False, dt=None, g=9.8, mass=1.0, length=1.0, w_cos=50.0, w_vel=1.0,
                  grid=None, cell_size=0.1, max_speed=5.0, max_accel=10.0, can_crash=True, with_obstacle=True,
                  target=(9.0, 9.0, 0.0, 0.0), w_state=(0.5, 0.5, 0.25, 0.25), w_term=(1e3, 1e3, 0.1, 0.1),
-                 w_ctrl=(0.2, 0.2), w_obs=1e6, mass_0dim=False, control_type="acceleration", noise_std=(0.0, 0.0)):
+                 w_ctrl=(0.2, 0.2), w_obs=1e6, mass_0dim=False, control_type="acceleration", noise_std=(0.0, 0.0), a_cov=None, p_cov=None):
         c = _Cfg()
         self.model = model
         c.model = MODEL_PENDULUM if model == "pendulum" else MODEL_PARTICLE
@@ -148,6 +149,16 @@ class Oracle:
         c.w_term[:] = pad4(w_term)
         c.w_ctrl[:] = w_ctrl
         c.w_obs = w_obs
+        if a_cov is not None or p_cov is not None:  # full 2 x 2 covariances (disco.py:91-98, svgd.py:84-89), fp32 as torch factors them
+            import torch
+
+            ac = torch.eye(2) if a_cov is None else torch.as_tensor(np.asarray(a_cov, np.float32))
+            pc = torch.eye(2) if p_cov is None else torch.as_tensor(np.asarray(p_cov, np.float32))
+            la, lp, ap = torch.linalg.cholesky(ac), torch.linalg.cholesky(pc), torch.inverse(ac)
+            c.full_cov = 1
+            c.chol_a_full[:] = [float(la[0, 0]), float(la[1, 0]), float(la[1, 1])]
+            c.chol_p_full[:] = [float(lp[0, 0]), float(lp[1, 0]), float(lp[1, 1])]
+            c.a_pre_full[:] = [float(ap[0, 0]), float(ap[0, 1]), float(ap[1, 1])]
         self.c = c
         self.D = H * c.da
 

@@ -200,8 +200,32 @@ void orc_sample_actions(const orc_cfg *c, const float *theta, const float *eps, 
     for (int n = 0; n < c->N; ++n)
       for (int j = 0; j < D; ++j) {
         size_t i = ((size_t)s * c->N + n) * D + j;
-        actions[i] = theta[(size_t)n * D + j] + chol_a[j % c->da] * eps[i];
+        if (c->full_cov && c->da == 2) { /* loc + L eps, row by row of the lower-triangular L (torch: _batch_mv(scale_tril, eps)) */
+          if ((j & 1) == 0) actions[i] = theta[(size_t)n * D + j] + c->chol_a_full[0] * eps[i];
+          else actions[i] = theta[(size_t)n * D + j] + (c->chol_a_full[1] * eps[i - 1] + c->chol_a_full[2] * eps[i]);
+        } else {
+          actions[i] = theta[(size_t)n * D + j] + chol_a[j % c->da] * eps[i];
+        }
       }
+}
+
+/* disco.py:338-346: a_reg * <-eps, a_mat @ a_pre> for one (s, n): only the diagonal of the [S,N,N] tensordot survives */
+static double ctrl_cost_sum(const orc_cfg *c, const float *act, const float *a_seq, const float *a_mat_n, const float *a_pre_diag) {
+  const int H = c->H, da = c->da;
+  double cc = 0.0;
+  for (int t = 0; t < H; ++t)
+    for (int d = 0; d < da; ++d) {
+      float e = act[t * da + d] - a_seq[t * da + d];
+      float ap;
+      if (c->full_cov && da == 2) { /* (a_mat[n, t, :] @ a_pre)[d] = a_mat[t,0] P[0][d] + a_mat[t,1] P[1][d] */
+        const float *P = c->a_pre_full;
+        ap = d == 0 ? (a_mat_n[t * 2] * P[0] + a_mat_n[t * 2 + 1] * P[1]) : (a_mat_n[t * 2] * P[1] + a_mat_n[t * 2 + 1] * P[2]);
+      } else {
+        ap = a_mat_n[t * da + d] * a_pre_diag[d];
+      }
+      cc += (double)(-e) * (double)ap;
+    }
+  return cc;
 }
 
 /* disco.py:139-209 (rollout), 294-346 (cost) */
@@ -238,15 +262,7 @@ void orc_rollout_cost(const orc_cfg *c, const float *state, const float *actions
       acc_m += (double)traj;
     }
     float cost = (float)(acc_m / M);
-    if (a_reg != 0.0f) { /* disco.py:338-346: only the diagonal of the [S,N,N] tensordot survives */
-      double cc = 0.0;
-      for (int t = 0; t < H; ++t)
-        for (int d = 0; d < da; ++d) {
-          float e = act[t * da + d] - a_seq[t * da + d];
-          cc += (double)(-e) * (double)(a_mat[((size_t)n * H + t) * da + d] * a_pre_diag[d]);
-        }
-      cost = cost + a_reg * (float)cc;
-    }
+    if (a_reg != 0.0f) cost = cost + a_reg * (float)ctrl_cost_sum(c, act, a_seq, a_mat + (size_t)n * H * da, a_pre_diag);
     costs[(size_t)s * N + n] = cost;
   }
 }
@@ -277,15 +293,7 @@ void orc_rollout_cost_ut(const orc_cfg *c, const float *state, const float *acti
       term_acc += (double)w[m] * (double)term_cost(c, x);
     }
     float cost = (float)inst_acc + (float)term_acc;
-    if (a_reg != 0.0f) {
-      double cc = 0.0;
-      for (int t = 0; t < H; ++t)
-        for (int d = 0; d < da; ++d) {
-          float e = act[t * da + d] - a_seq[t * da + d];
-          cc += (double)(-e) * (double)(a_mat[((size_t)n * H + t) * da + d] * a_pre_diag[d]);
-        }
-      cost = cost + a_reg * (float)cc;
-    }
+    if (a_reg != 0.0f) cost = cost + a_reg * (float)ctrl_cost_sum(c, act, a_seq, a_mat + (size_t)n * H * da, a_pre_diag);
     costs[sn] = cost;
   }
 }
@@ -349,6 +357,17 @@ void orc_log_mix(int n, const float *weights, float *logmix) {
   free(lg);
 }
 
+/* Prior component MVN(mu_k, Sigma_p) per time step (svgd.py:84-89): z = L_p^-1 (x - mu) by forward substitution, as
+ * MultivariateNormal.log_prob's _batch_mahalanobis does; w = Sigma_p^-1 (x - mu) = L_p^-T z (what autograd returns, negated). */
+static inline void whiten2(const float *L, double d0, double d1, double *z0, double *z1) {
+  *z0 = d0 / (double)L[0];
+  *z1 = (d1 - (double)L[1] * *z0) / (double)L[2];
+}
+static inline void unwhiten2(const float *L, double z0, double z1, double *w0, double *w1) {
+  *w1 = z1 / (double)L[2];
+  *w0 = (z0 - (double)L[1] * *w1) / (double)L[0];
+}
+
 /* svmpc.py:38-56 */
 void orc_score(const orc_cfg *c, const float *theta, const float *mu, const float *logmix, const float *sigma_p,
                const float *costs, const float *actions, float alpha, const float *sigma_a, float *grad_lik,
@@ -358,15 +377,47 @@ void orc_score(const orc_cfg *c, const float *theta, const float *mu, const floa
   for (int i = 0; i < N; ++i) {
     double *lg = (double *)malloc(sizeof(double) * (N > S ? N : S));
     /* prior score: grad_x log sum_k pi_k N(x; mu_k, diag sigma_p^2) = sum_k r_ik (mu_k - x)/sigma_p^2 (svmpc.py:41) */
+    const int full = c->full_cov && da == 2;
     for (int k = 0; k < N; ++k) {
       double q = 0.0;
-      for (int j = 0; j < D; ++j) {
-        double z = ((double)theta[(size_t)i * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
-        q += z * z;
+      if (full) {
+        for (int t = 0; t < D; t += 2) {
+          double z0, z1;
+          whiten2(c->chol_p_full, (double)theta[(size_t)i * D + t] - (double)mu[(size_t)k * D + t],
+                  (double)theta[(size_t)i * D + t + 1] - (double)mu[(size_t)k * D + t + 1], &z0, &z1);
+          q += z0 * z0 + z1 * z1;
+        }
+      } else {
+        for (int j = 0; j < D; ++j) {
+          double z = ((double)theta[(size_t)i * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
+          q += z * z;
+        }
       }
       lg[k] = (double)logmix[k] - 0.5 * q;
     }
     double z = lse(lg, N);
+    if (full) {
+      for (int t = 0; t < D; t += 2) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int k = 0; k < N; ++k) {
+          double z0, z1, w0, w1;
+          whiten2(c->chol_p_full, (double)mu[(size_t)k * D + t] - (double)theta[(size_t)i * D + t],
+                  (double)mu[(size_t)k * D + t + 1] - (double)theta[(size_t)i * D + t + 1], &z0, &z1);
+          unwhiten2(c->chol_p_full, z0, z1, &w0, &w1);
+          const double r = exp(lg[k] - z);
+          a0 += r * w0;
+          a1 += r * w1;
+        }
+        if (grad_pri) {
+          grad_pri[(size_t)i * D + t] = (float)a0;
+          grad_pri[(size_t)i * D + t + 1] = (float)a1;
+        }
+        if (score) {
+          score[(size_t)i * D + t] = (float)a0;
+          score[(size_t)i * D + t + 1] = (float)a1;
+        }
+      }
+    } else
     for (int j = 0; j < D; ++j) {
       double acc = 0.0, sp = (double)sigma_p[j % da];
       for (int k = 0; k < N; ++k)
@@ -569,8 +620,11 @@ void orc_forward(const orc_cfg *c, int lik_kind, float alpha, const float *costs
   double *lw = (double *)malloc(sizeof(double) * N);
   double *tmp = (double *)malloc(sizeof(double) * (N > S ? N : S));
   orc_log_mix(N, mix_weights, logmix);
+  const int full = c->full_cov && da == 2;
   double logdet = 0.0;
-  for (int d = 0; d < da; ++d) logdet += log((double)sigma_p[d]);
+  if (full) logdet = log((double)c->chol_p_full[0]) + log((double)c->chol_p_full[2]);
+  else
+    for (int d = 0; d < da; ++d) logdet += log((double)sigma_p[d]);
   for (int n = 0; n < N; ++n) {
     double ll;
     if (lik_kind == ORC_LIK_EXP_UTILITY) { /* likelihoods.py:127-135 */
@@ -583,9 +637,18 @@ void orc_forward(const orc_cfg *c, int lik_kind, float alpha, const float *costs
     }
     for (int k = 0; k < N; ++k) {
       double q = 0.0;
-      for (int j = 0; j < D; ++j) {
-        double z = ((double)theta[(size_t)n * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
-        q += z * z;
+      if (full) {
+        for (int t = 0; t < D; t += 2) {
+          double z0, z1;
+          whiten2(c->chol_p_full, (double)theta[(size_t)n * D + t] - (double)mu[(size_t)k * D + t],
+                  (double)theta[(size_t)n * D + t + 1] - (double)mu[(size_t)k * D + t + 1], &z0, &z1);
+          q += z0 * z0 + z1 * z1;
+        }
+      } else {
+        for (int j = 0; j < D; ++j) {
+          double z = ((double)theta[(size_t)n * D + j] - (double)mu[(size_t)k * D + j]) / (double)sigma_p[j % da];
+          q += z * z;
+        }
       }
       tmp[k] = (double)logmix[k] - 0.5 * q - H * logdet - 0.5 * D * log(2.0 * M_PI);
     }

@@ -61,6 +61,15 @@ typedef struct {
    * the recorded standard-normal draws [H][M*S*N][da] of one MultiDISCO._rollout (rollout r = (m*S + s)*N + n), or NULL (no noise) */
   float dyn_std[2];
   const float *ctrl_noise;
+  /* FULL 2 x 2 covariances (da = 2): MultiDISCO(a_cov=) disco.py:91-98 - policy noise actions = theta + L_a eps with L_a = cholesky(a_cov)
+   * (likelihoods.py:85-90, MultivariateNormal.rsample), control cost through a_pre = inverse(a_cov) (disco.py:338-346) - and the prior
+   * GMM's component covariance (svgd.py:84-89; MultivariateNormal.log_prob: Mahalanobis distance by a triangular solve with L_p,
+   * minus sum log diag L_p).  full_cov != 0: the diagonal arguments (chol_a / a_pre_diag / sigma_p) of the functions below are ignored
+   * in favour of these. */
+  int full_cov;
+  float chol_a_full[3]; /* l00, l10, l11 */
+  float a_pre_full[3];  /* p00, p01 (= p10), p11 */
+  float chol_p_full[3];
 } orc_cfg;
 
 /* a1  CostLikelihood.sample likelihoods.py:81-101: actions = theta + L eps (diagonal L) */

@@ -38,6 +38,8 @@ def scenario_kwargs(g):
         kw["mass_0dim"] = True
         kw["params_log_space"] = bool(int(g["params_log_space"]))
         kw["params_scalar_event"] = bool(int(g["params_scalar_event"]))
+        if "a_cov" in g:  # full 2 x 2 covariances (tests/golden/make_golden_r5.py run_svmpc_cov)
+            kw["a_cov"], kw["p_cov"] = np.asarray(g["a_cov"], np.float32), np.asarray(g["p_cov"], np.float32)
         if "control_type" in g:  # round-5 fixtures (tests/golden/make_golden_r5.py): control noise / velocity control
             kw["control_type"] = str(g["control_type"])
             kw["noise_std"] = tuple(float(v) for v in g["dyn_std"])
@@ -81,6 +83,7 @@ def tick2_ticks_expected(g, name, calls_per_tick=1):
     sp = np.atleast_1d(np.asarray(g["sigma_p"], np.float64)).reshape(-1)
     # (velocity control and non-zero control noise run on the launch-per-iteration path: csrc/particle_general.hpp)
     general = "control_type" in g and (str(g["control_type"]) == "velocity" or (not int(g["deterministic"]) and bool(np.any(g["dyn_std"] != 0))))
+    general = general or "a_cov" in g  # (full 2 x 2 covariances: launch-per-iteration kernels)
     eligible = "k2" not in name and N % 4 == 0 and D <= 32 and "ctrlpen" not in name and bool(np.all(sp == sp[0])) and not general
     return (T - 1) * calls_per_tick if eligible else 0
 

@@ -18,8 +18,9 @@ TOL = 1e-5
 
 def ctx_kwargs(g):
     kw = scenario_kwargs(g)
+    sa, sp = np.asarray(g["sigma_a"], np.float32).reshape(-1), np.asarray(g["sigma_p"], np.float32).reshape(-1)  # (a_cov / p_cov in kw win)
     kw.update(kernel=str(g["kernel_kind"]), likelihood=str(g["lik_kind"]), lr=float(g["lr"]), alpha=float(g["alpha"]),
-              temperature=float(g["temperature"]), sigma_a=float(g["sigma_a"]), sigma_p=float(g["sigma_p"]),
+              temperature=float(g["temperature"]), sigma_a=float(sa[0]) if sa.size == 1 else sa, sigma_p=float(sp[0]) if sp.size == 1 else sp,
               weighted_prior=bool(int(g["weighted_prior"])), roll_strategy=str(g["roll_strategy"]))
     a_reg, temp = float(g["a_reg"]), float(g["temperature"])
     kw["ctrl_penalty"] = 1.0 - a_reg / temp
@@ -69,7 +70,10 @@ def test_rollout_costs_vs_reference(golden, name):
             params = g["params"][t, k] if "params" in g else None
             feed_ctrl_noise(c, g, t, k)
             costs, actions = c.likelihood_sample(g["state"][t, k], g["eps"][t, k], params, want_actions=True)
-            assert np.array_equal(actions, g["actions"][t, k]), "a1 must be bit-exact"
+            if "a_cov" in g:  # (a row of L eps is a two-term sum: agrees with torch's matmul to an ulp)
+                assert elemerr(actions, g["actions"][t, k]) < 1e-6
+            else:
+                assert np.array_equal(actions, g["actions"][t, k]), "a1 must be bit-exact"
             assert elemerr(costs, g["costs"][t, k]) < TOL, (name, t, k)
             assert relerr(c.get_a_mat(), g["omega_amat"][t, k]) < 1e-4  # omega = softmax of O(1e3) logits (see module doc)
             # a_mix = softmax_n(logsumexp_s(-c/temp)): one fp32 ulp of a cost moves a logit by ulp(c)/temp, so the check is
