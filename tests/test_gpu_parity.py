@@ -1541,3 +1541,45 @@ def test_skid_steer_sharded_equals_unsharded(golden):
             assert elemerr(sh.ctx.get_theta(), rt) < 2e-6, (world, sh.rank)
             sh.ctx.close()
     ref.close()
+
+
+def test_device_noise_generator_statistics():
+    """philox_normal8 (common.hpp) - the policy-noise generator of every device path since round 4 - builds each Box-Muller pair
+    from two 16-bit uniforms: 65 536 radii up to 4.85 sigma.  What that does to the DISTRIBUTION, measured on 3.9 M draws of the product
+    shape (fetched as actions around a_mat = 0 with sigma_a = 1): moments to 5 standard errors, the tail masses beyond 3 and 4 sigma to
+    5 binomial standard deviations, the hard cut at sqrt(-2 ln 2^-17) = 4.855, and no correlation between neighbouring columns (the two
+    halves of a pair, consecutive pairs) or between samples."""
+    from math import erfc, sqrt
+
+    from dust_amd import Context
+
+    N, S, H = 1024, 128, 30
+    c = Context(model="pendulum", N=N, S=S, M=1, H=H, sigma_a=1.0, sigma_p=1.0, seed=20260101)
+    zs = []
+    for _ in range(2):  # two launches: two positions of the counter stream
+        c.set_a_mat(np.zeros((N, H, 1), np.float32))  # (forward's side effect moves a_mat: disco.py:387-392)
+        _, _, act, _ = c.disco_forward(np.array([3.0, 0.0], np.float32), None, want_actions=True)
+        zs.append(act.reshape(S, N, H).astype(np.float64))
+    c.close()
+    assert not np.array_equal(zs[0], zs[1])
+    z = np.concatenate([a.reshape(-1) for a in zs])
+    n = z.size
+    assert abs(z.mean()) < 5 / sqrt(n)
+    assert abs(z.var() - 1.0) < 5 * sqrt(2.0 / n)
+    assert abs((z ** 3).mean()) < 5 * sqrt(15.0 / n)
+    assert abs((z ** 4).mean() - 3.0) < 5 * sqrt(96.0 / n) + 2e-3  # (the tail cut takes ~1e-3 off the fourth moment)
+    for t in (3.0, 4.0):
+        p = erfc(t / sqrt(2.0))
+        k = float((np.abs(z) > t).sum())
+        assert abs(k - n * p) < 5 * sqrt(n * p) + 1, (t, k, n * p)
+    assert np.abs(z).max() <= 4.8553 + 1e-3, np.abs(z).max()
+    a = zs[0]
+    for lag in (1, 2, 8):  # neighbouring columns of a row: the sin / cos halves of one pair, consecutive pairs, consecutive Philox blocks
+        r = np.corrcoef(a[:, :, :-lag].reshape(-1), a[:, :, lag:].reshape(-1))[0, 1]
+        assert abs(r) < 5 / sqrt(a[:, :, lag:].size), (lag, r)
+    r = np.corrcoef(a[:-1].reshape(-1), a[1:].reshape(-1))[0, 1]  # consecutive samples of a particle
+    assert abs(r) < 5 / sqrt(a[1:].size)
+    r2 = np.corrcoef((a[:, :, 0::2] ** 2).reshape(-1), (a[:, :, 1::2] ** 2).reshape(-1))[0, 1]
+    # the two members of a pair share their RADIUS: z0^2 + z1^2 = r^2, so their squares are anti-correlated exactly as for true
+    # Box-Muller pairs of independent normals - i.e. not at all
+    assert abs(r2) < 5 / sqrt(a[:, :, 0::2].size), r2
