@@ -1017,6 +1017,32 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
           const float base = f->eps_base_mode ? thj : f->a_seq[j];
           const float *tp = tile_p + j;
           const float *op_ = same_w ? cst_p : omg_p;
+#ifndef T2_WSUM_PER_SAMPLE
+          // The sums run over the RAW draws and the per-column factors are applied once: sum_s w_s (a_s - theta) / sigma^2 =
+          // (L / sigma^2) sum_s w_s eps_s and sum_s omega_s (a_s - base) = (theta - base) sum_s omega_s + L sum_s omega_s eps_s, up to the
+          // rounding of a_s = fl(theta + L eps_s) that the per-sample form (below, -DT2_WSUM_PER_SAMPLE) carries through (<= 1e-6 relative per
+          // term; all parity tests unchanged): 2 instead of 6 vector instructions per sample - 94.4 -> 91.2 us per cfg2 tick (round 5)
+          {
+            float ge = 0.f, oe = 0.f, so = 0.f;
+            for (int s0 = (wave & 1) * 64; s0 < S; s0 += 128) {
+              const int s1 = min(s0 + 64, S);
+#pragma unroll 8
+              for (int s = s0 + q; s < s1; s += 2) {
+                const float e = tp[s * Dp], c = cst_p[s];
+                ge = fmaf(c, e, ge);
+                if (!same_w) {
+                  oe = fmaf(op_[s], e, oe);
+                  so += op_[s];
+                } else {
+                  so += c;
+                }
+              }
+            }
+            if (same_w) oe = ge;
+            g = ge * (lj * is2);
+            am = fmaf(thj - base, so, lj * oe);
+          }
+#else
           {
             for (int s0 = (wave & 1) * 64; s0 < S; s0 += 128) {
               const int s1 = min(s0 + 64, S);
@@ -1028,6 +1054,7 @@ __global__ __launch_bounds__(T2_NT, 4) void svmpc_tick2_kernel(const Tick2Args f
               }
             }
           }
+#endif
         }
         wpart[((rp * 2 + (wave & 1)) * 2 + q) * T2_ROW + j] = g;
         wpart[(T2_PW * 4 + (rp * 2 + (wave & 1)) * 2 + q) * T2_ROW + j] = am;
