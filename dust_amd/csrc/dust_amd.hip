@@ -27,6 +27,7 @@
 #include "rollout_states.hpp"
 #include "pairwise_fused.hpp"
 #include "pairwise_logp_mfma.hpp"
+#include "pairwise_far.hpp"
 #include "skid.hpp"
 #include "particle_general.hpp"
 #include "rollout.hpp"
@@ -114,6 +115,12 @@ struct dust_ctx {
   float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
   size_t nzf_cap;
   int nz_ld;                 // 0: the last fused pass ran dense
+  float *far_z, *far_n, *far_f;  // pairwise_far.hpp: binary16 rows, (norms, log weights), unit flags [tiles][chunks] bytes
+  size_t far_z_cap, far_n_cap, far_f_cap;
+  int far_tiles, far_chunks;  // geometry of the flags the last fused pass used (0: none)
+  float *far_g;               // the flags of the last log-p pass [groups][chunks] bytes
+  size_t far_g_cap;
+  int far_groups, far_gchunks;
   int prior_js;  // slices of the prior partials when pairwise_fused_kernel wrote them (its own split); 0 = pair_geometry's
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
@@ -169,7 +176,7 @@ struct dust_ctx {
   // Development switches and test hooks (environment variables), read ONCE when the context is created or cloned - the tick entry
   // points called getenv() several times per control tick before.  -1: unset, otherwise atoi of the value.
   struct EnvSw {
-    int comm_force, pair_big, pair_fused, states_form, dense, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
+    int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
   } env;
   struct T2Replay {
@@ -372,7 +379,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -412,6 +419,7 @@ static void env_read(dust_ctx *c) {
   c->env.pair_fused = env_int("DUST_PAIR_FUSED");
   c->env.states_form = env_int("DUST_STATES_FORM");
   c->env.dense = env_int("DUST_DENSE");
+  c->env.far = env_int("DUST_FAR");
   c->env.logp_mfma = env_int("DUST_LOGP_MFMA");
   c->env.no_fuse = env_int("DUST_NO_FUSE");
   c->env.no_persist = env_int("DUST_NO_PERSIST");
@@ -1866,6 +1874,67 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     b.nz = reinterpret_cast<unsigned char *>(c->nzf);
     b.ldnz = c->nz_ld;
   }
+  c->far_tiles = c->far_chunks = 0;
+  if (c->cfg.kernel == DUST_KERNEL_K1_RBF) {  // pairwise_far.hpp: where the running maxima start (every mode), and the far units
+    const bool flags = b.nz && c->env.far != 0;  // (DUST_FAR=0 / DUST_DENSE=1: visit all)
+    FarArgs f;
+    memset(&f, 0, sizeof f);
+    f.N = c->N;
+    f.D = a.D;
+    f.i0 = a.i0;
+    f.n_local = c->nloc;
+    f.tiles = tiles;
+    f.q_rows = tiles * fused_tq(a.D);
+    f.lscale = 1.0f;
+    f.chunks = b.chunks;
+    f.X = a.X;
+    f.logmix = a.logmix;
+    f.sg[0] = sqrtf(std::min(b.wS[0], b.wP[0]));
+    f.sg[1] = sqrtf(std::min(b.wS[1], b.wP[1]));
+    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * dpb + 1) / 2));
+    TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + b.chunks));
+    TRY(ensure(&c->far_f, &c->far_f_cap, ((size_t)tiles * b.chunks + 3) / 4));
+    f.Z = reinterpret_cast<_Float16 *>(c->far_z);
+    f.nrm = c->far_n;
+    f.lms = c->far_n + c->N;
+    f.m0 = c->far_n + 2 * (size_t)c->N;
+    f.cand = reinterpret_cast<int *>(c->far_n + 3 * (size_t)c->N);
+    {
+      const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
+      f.T = env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT;
+    }
+    f.Xp = b.Xp;
+    f.wP[0] = b.wP[0];
+    f.wP[1] = b.wP[1];
+    f.far = reinterpret_cast<unsigned char *>(c->far_f);
+    f.nz = b.nz;
+    f.ldnz = b.ldnz;
+    const int gx = (tiles + 3) / 4;
+    const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
+    f.cps = std::max(1, (b.chunks + want - 1) / want);
+    dim3 fgrid(gx, (b.chunks + f.cps - 1) / f.cps);
+    const int nq = std::min(c->N - a.i0, tiles * fused_tq(a.D));
+    far_cand_kernel<<<(b.chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);
+#define DUST_LAUNCH_FAR(DPB)                                                                         \
+  do {                                                                                               \
+    far_lb_kernel<DPB><<<(nq + 63) / 64, 256, 0, c->pair_stream>>>(f);                               \
+    if (flags) {                                                                                     \
+      far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                           \
+      far_flags_kernel<DPB, FusedGeom<DPB>::TQ><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f); \
+    }                                                                                                \
+  } while (0)
+    if (dpb == 32) DUST_LAUNCH_FAR(32);
+    else if (dpb == 64) DUST_LAUNCH_FAR(64);
+    else DUST_LAUNCH_FAR(80);
+#undef DUST_LAUNCH_FAR
+    HIP_TRY(hipGetLastError());
+    b.m0 = f.m0;
+    if (flags) {
+      b.far = f.far;
+      c->far_tiles = tiles;
+      c->far_chunks = b.chunks;
+    }
+  }
   int W, tl;
   fused_geometry(c, &tl, &W, &b.p.JS);  // (a.JS / a.slice describe the regular grid of the other kernels)
   int jsg, slg;
@@ -1936,9 +2005,58 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
   b.pM = c->pM;
   b.pL = c->pL;
   dim3 grid(tiles, b.JS);
+  // pairwise_far.hpp: (64-query group, key chunk) blocks whose terms are all negligible against the group's known max logits
+  // (DUST_FAR=0 / DUST_DENSE=1: visit all).  Base-2 logits here: log weights and the threshold scaled by log2 e.
+  const bool flags = c->env.far != 0 && c->env.dense < 0;
+  FarArgs f;
+  memset(&f, 0, sizeof f);
+  c->far_groups = c->far_gchunks = 0;
+  dim3 fgrid(1, 1);
+  if (flags) {
+    f.N = c->N;
+    f.D = a.D;
+    f.i0 = a.i0;
+    f.n_local = a.n_local;
+    f.tiles = (a.n_local + 63) / 64;
+    f.q_rows = f.tiles * 64;
+    f.lscale = 1.44269504088896340736f;
+    f.chunks = chunks;
+    f.X = a.X;
+    f.logmix = a.logmix;
+    f.sg[0] = b.sw[0];
+    f.sg[1] = b.sw[1];
+    const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
+    f.T = (env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT) * 1.44269504088896340736f;
+    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * dpb + 1) / 2));
+    TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + chunks));
+    TRY(ensure(&c->far_g, &c->far_g_cap, ((size_t)f.tiles * chunks + 3) / 4));
+    f.Z = reinterpret_cast<_Float16 *>(c->far_z);
+    f.nrm = c->far_n;
+    f.lms = c->far_n + c->N;
+    f.m0 = c->far_n + 2 * (size_t)c->N;
+    f.cand = reinterpret_cast<int *>(c->far_n + 3 * (size_t)c->N);
+    f.Xp = b.Z;  // the scaled rows: unit metric
+    f.wP[0] = f.wP[1] = 1.0f;
+    f.far = reinterpret_cast<unsigned char *>(c->far_g);
+    const int gx = (f.tiles + 3) / 4;
+    const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
+    f.cps = std::max(1, (chunks + want - 1) / want);
+    fgrid = dim3(gx, (chunks + f.cps - 1) / f.cps);
+    b.far = f.far;
+    b.groups = f.tiles;
+    b.chunks = chunks;
+    c->far_groups = f.tiles;
+    c->far_gchunks = chunks;
+  }
 #define DUST_LAUNCH_LOGPM(DPB)                                                                                                 \
   do {                                                                                                                          \
     logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                       \
+    if (flags) {                                                                                                                \
+      far_cand_kernel<<<(chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                         \
+      far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 256, 0, c->pair_stream>>>(f);                           \
+      far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                      \
+      far_flags_kernel<DPB, 64><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
+    }                                                                                                                           \
     pairwise_logp_mfma_kernel<DPB><<<grid, 256, pairwise_logp_mfma_lds_bytes<DPB>(), c->pair_stream>>>(b);                      \
   } while (0)
   if (dpb == 16) DUST_LAUNCH_LOGPM(16);
@@ -4157,6 +4275,40 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
 extern "C" int dust_debug_fused_balance(int tiles, int chunks, int slots, int *W, int *JS) {
   if (tiles < 1 || chunks < 1 || slots < 1 || !W || !JS) return DUST_ERR_INVALID;
   fused_balance(tiles, chunks, slots, W, JS);
+  return DUST_OK;
+}
+
+// (not part of include/dust_amd.h) how many (query tile, key chunk) units the last fused pairwise pass left out as exact zeros
+// (pairwise_far.hpp): out[0] = far units, out[1] = all units (0 0: the pass ran without the pre-pass).  Synchronises.
+extern "C" int dust_debug_far_units(dust_ctx *c, long long *out2) {
+  if (!c || !out2) return fail(DUST_ERR_INVALID, "null argument");
+  out2[0] = out2[1] = 0;
+  const size_t n = (size_t)c->far_tiles * c->far_chunks;
+  if (!n) return DUST_OK;
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned char> h(n);
+  HIP_TRY(hipMemcpy(h.data(), c->far_f, n, hipMemcpyDeviceToHost));
+  long long k = 0;
+  for (size_t i = 0; i < n; ++i) k += h[i] != 0;
+  out2[0] = k;
+  out2[1] = (long long)n;
+  return DUST_OK;
+}
+// the same for the last log-p pass (pairwise_logp_mfma.hpp): (64-query group, key chunk) blocks
+extern "C" int dust_debug_far_logp(dust_ctx *c, long long *out2) {
+  if (!c || !out2) return fail(DUST_ERR_INVALID, "null argument");
+  out2[0] = out2[1] = 0;
+  const size_t n = (size_t)c->far_groups * c->far_gchunks;
+  if (!n) return DUST_OK;
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<unsigned char> h(n);
+  HIP_TRY(hipMemcpy(h.data(), c->far_g, n, hipMemcpyDeviceToHost));
+  long long k = 0;
+  for (size_t i = 0; i < n; ++i) k += h[i] != 0;
+  out2[0] = k;
+  out2[1] = (long long)n;
   return DUST_OK;
 }
 

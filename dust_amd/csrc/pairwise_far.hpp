@@ -1,0 +1,264 @@
+// pairwise_far.hpp - which (query tile, key chunk) units of pairwise_fused_kernel contribute EXACTLY nothing, decided on the
+// matrix cores before the exact-difference pass runs (svmpc.py:38-41 prior gradient, 76-83 Stein kernel; K1 only).
+//
+// In H d_a = 80 dimensions a spread-out particle set has no near neighbours: the K1 value exp(-d2_S / 2) and the prior's softmax
+// term exp(log w_j - d2_P / 2 - max) underflow to exact fp32 zeros for all but a handful of pairs, and a unit whose 96 x 64 pairs
+// are all such zeros adds nothing to any output of the fused pass - yet the exact-difference distance of every pair is what that
+// pass spends its time on (2.5 of 3.8 ms at cfg4).  This pre-pass bounds the distances from below with a binary16 GEMM:
+//     G_ij = sum_k g_k (x_ik - x_jk)^2 ,   g_k = min(1 / ell^2, 1 / sigma_p,k^2)   (<= both metrics' distances)
+//          = n_i + n_j - 2 z_i . z_j ,     z = sqrt(g) (x - x_0) rounded to binary16 for the product, n = |z|^2 from the fp32 rows
+// with the product's error bounded by 2^-10 |z_i| |z_j| <= 2^-11 (n_i + n_j) (two roundings of relative size 2^-11; fp32
+// accumulation adds < 1e-5 of that).  A unit is FAR when every pair has
+//     G_ij - EB (n_i + n_j) > T + 2 max(0, log w_j - min_tile m0_i) ,        EB = 1.3e-3 ,
+// where the fused pass STARTS each query's running max at m0_i (below).  Two thresholds:
+//   T = 224 (DUST_FAR_T=224): 0.7213 d2_S > 161 (the K1 exponent in base 2: v_exp_f32 returns 0 below -150 with or without
+//     denormals) and every softmax exponent of the unit is below -161 as well: the terms are exact zeros, the running max and sum
+//     do not move, the rescale factor is exactly 1 - skipping the unit is BIT-IDENTICAL to evaluating it (the slack between 150
+//     and 161 covers the fused pass' own fp32 rounding of d2, < 1e-5 relative);
+//   T = 60 (the default): every skipped kernel value and softmax term is below e^-30 = 2^-43 of the leading term of the sum it
+//     belongs to (k_ii = 1; the term of the key that attains m0_i - a real key, visited) - at most N = 2^14 .. 2^17 of them, so
+//     each sum changes by less than 2^-26 of its leading term: under half an ulp of it.  In 80 dimensions at sigma_p = 1 the
+//     pairs of a spread-out set sit at d2 ~ 320 +- 50: beyond 60, mostly short of 224 (cfg4, bench.py).
+// Rows the bound cannot speak for (non-finite coordinates or weights, |z| beyond binary16) get n = -inf and are never far.
+// m0_i is a lower bound of query i's final max logit, known before the pass: the largest of its OWN logit log w_i (the keys are
+// the particles: distance 0) and its exact logits against one candidate key per chunk - the chunk's heaviest particle
+// (far_cand_kernel / far_lb_kernel: N x chunks exact distances, 1 / 64 of the pass).  After the first tick the mixture weights are
+// softmax(-alpha cost) - close to one-hot - and a light query's max logit is its logit against a heavy FAR particle, hundreds above
+// its own: without the candidates no unit of such a query could be proven negligible.  Any reference <= the true max + O(ulp)
+// serves the softmax equally well, so every mode of the fused pass starts from m0 (tests: DUST_FAR_T=224 against DUST_FAR=0 and
+// DUST_DENSE=1 bitwise; the default against them at 1e-6 of the largest element).
+// Cost: 2 D flops per pair on v_mfma_f32_16x16x16_f16 instead of 3 D packed fp32 lane-ops - and for a clustered set it buys nothing
+// (every unit stays, the pre-pass is ~3 % on top).  Time is data dependent, results are not.
+#pragma once
+#include "pairwise_fused.hpp"
+
+namespace dust {
+
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+#define DUST_FAR_T_EXACT 224.0f  // every skipped term is an exact fp32 zero
+#define DUST_FAR_T_DEFAULT 60.0f  // every skipped term is below e^-30 = 2^-43 of its sum's leading term
+#define DUST_FAR_EB 1.3e-3f
+
+struct FarArgs {
+  int N, D, i0, n_local, tiles, chunks, cps;  // tiles of TQ query rows (far_flags_kernel's template argument); cps: key chunks per slice (blockIdx.y)
+  int q_rows;           // tiles * TQ
+  float lscale;         // log weights enter as lscale * logmix (1: natural-log logits; log2 e: the base-2 logits of pairwise_logp_mfma.hpp)
+  const float *X;       // [N][D] particles
+  const float *logmix;  // [N] log mixture weights
+  float sg[2];          // sqrt(g) for even / odd dimensions
+  _Float16 *Z;          // [N][DPB] scaled, centred, zero-padded rows in binary16 (far_prep_kernel)
+  float *nrm;           // [N] |z|^2 (1 - EB), or -inf: the row is never far
+  float *lms;           // [N] log w (finite or -inf)
+  int *cand;            // [chunks] the heaviest particle of each key chunk (far_cand_kernel)
+  const float *Xp;      // [N][DPB] zero-padded fp32 rows (the fused pass' own copy)
+  float wP[2];          // the prior metric, 1 / sigma_p^2 for even / odd dimensions
+  float *m0;            // [N] lower bound of the query's max prior logit (far_lb_kernel): the fused pass starts its running max there
+  unsigned char *far;   // [tiles][chunks] 1 = the unit contributes exactly nothing
+  unsigned char *nz;    // the Gram-block flags of pairwise_fused.hpp: zeroed here for far units (the fused pass never visits them)
+  int ldnz;
+  float T;              // the threshold on G (DUST_FAR_T_DEFAULT; development switch DUST_FAR_T)
+};
+
+// one wave per row
+template <int DPB>
+__global__ __launch_bounds__(256) void far_prep_kernel(const FarArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.N) return;
+  float acc = 0.f;
+  bool ok = true;
+  float v[(DPB + 63) / 64];
+#pragma unroll
+  for (int u = 0; u < (DPB + 63) / 64; ++u) {
+    const int c = lane + 64 * u;
+    v[u] = 0.f;
+    if (c < a.D) v[u] = (a.X[(size_t)row * a.D + c] - a.X[c]) * a.sg[c & 1];
+    ok = ok && fabsf(v[u]) <= 60000.0f;  // (false for NaN)
+    acc = fmaf(v[u], v[u], acc);
+  }
+  acc = wave_sum(acc);
+  const float lm = a.logmix[row];
+  ok = __ballot(!ok) == 0ull && (lm < INFINITY) && acc < INFINITY;  // (lm NaN: false)
+#pragma unroll
+  for (int u = 0; u < (DPB + 63) / 64; ++u) {
+    const int c = lane + 64 * u;
+    if (c < DPB) a.Z[(size_t)row * DPB + c] = ok ? (_Float16)v[u] : (_Float16)0.f;
+  }
+  if (lane == 0) {
+    a.nrm[row] = ok ? acc * (1.0f - DUST_FAR_EB) : -INFINITY;
+    a.lms[row] = ok ? lm * a.lscale : 0.f;
+  }
+}
+
+// one wave per key chunk: its heaviest particle (first of equals; a chunk of NaN / -inf weights: its first particle)
+__global__ __launch_bounds__(256) void far_cand_kernel(const FarArgs a) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ch >= a.chunks) return;
+  const int j = ch * 64 + lane;
+  float v = j < a.N ? a.logmix[j] : -INFINITY;
+  v = v == v ? v : -INFINITY;
+  const float mx = wave_max(v);
+  const unsigned long long hit = __ballot(v == mx);
+  if (lane == 0) a.cand[ch] = min(ch * 64 + (hit ? (int)__builtin_ctzll(hit) : 0), a.N - 1);
+}
+
+// m0 (see the file comment): lane = query (row in registers), wave w of the workgroup takes candidates w, w + 4, ... through the
+// scalar path; the logit is formed as the fused pass forms it (differences first, even / odd dimensions apart, log w - pa / 2)
+template <int DPB>
+__global__ __launch_bounds__(256) void far_lb_kernel(const FarArgs a) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q_end = min(a.N, a.i0 + a.q_rows);
+  const int qi = a.i0 + blockIdx.x * 64 + lane, qc = min(qi, a.N - 1);
+  v2f x[DPB / 2];
+#pragma unroll
+  for (int p = 0; p < DPB / 4; ++p) {
+    const v4f t = *reinterpret_cast<const v4f *>(a.Xp + (size_t)qc * DPB + 4 * p);
+    x[2 * p] = v2f{t.x, t.y};
+    x[2 * p + 1] = v2f{t.z, t.w};
+  }
+  float best = -INFINITY;
+  for (int ci = wave; ci < a.chunks; ci += 4) {
+    const int c = __builtin_amdgcn_readfirstlane(a.cand[ci]);
+    typedef const v2f __attribute__((address_space(4))) * cv2;
+    const cv2 y = (cv2)(uintptr_t)(a.Xp + (size_t)c * DPB);
+    v2f d2 = {0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < DPB / 2; ++p) {
+      const v2f z = x[p] - y[p];
+      d2 = __builtin_elementwise_fma(z, z, d2);
+    }
+    const float pa = d2.x * a.wP[0] + d2.y * a.wP[1];
+    const float lg = a.logmix[c] * a.lscale - 0.5f * pa;
+    best = lg > best ? lg : best;  // (NaN: not taken)
+  }
+  red[wave][lane] = best;
+  __syncthreads();
+  if (wave == 0 && qi < q_end) {
+    const float own = a.logmix[qi] * a.lscale;
+    float m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+    m = own > m ? own : m;
+    a.m0[qi] = m;
+  }
+}
+
+template <int DPB>
+static inline size_t far_flags_lds_bytes() {
+  return 2 * ((size_t)64 * (DPB + 8) * sizeof(_Float16) + 2 * 64 * sizeof(float));
+}
+
+// Workgroup = 4 waves = 4 query tiles (TQ rows each - the consumer's tile: pairwise_fused_kernel's, or the 64 queries of a wave of
+// pairwise_logp_mfma_kernel - held in registers as B operands), the key
+// chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 8-byte LDS read.
+template <int DPB, int TQ>
+__global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
+  constexpr int JC = 64, NT = 256, QT = TQ / 16, NP = DPB / 16, ZS = DPB + 8, R8 = DPB / 8;
+  constexpr int NLD = (JC * R8 + NT - 1) / NT;
+  static_assert(TQ % 16 == 0 && DPB % 16 == 0, "whole MFMA tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr size_t BUF = (size_t)JC * ZS * sizeof(_Float16) + 2 * JC * sizeof(float);
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x * 4 + wave, N = a.N;
+  const bool live = tile < a.tiles;  // (a wave behind the last tile still stages keys)
+  const int tq = live ? tile : a.tiles - 1;
+  const int c_beg = blockIdx.y * a.cps, c_end = min(a.chunks, c_beg + a.cps);
+  if (c_beg >= c_end) return;
+
+  v4h bq[QT][NP];
+  float hq[QT];
+  float lmq = INFINITY;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qi = min(a.i0 + tq * TQ + 16 * t + r16, N - 1);  // (rows behind the set: clamped, as the fused pass clamps them)
+#pragma unroll
+    for (int s = 0; s < NP; ++s) bq[t][s] = *reinterpret_cast<const v4h *>(a.Z + (size_t)qi * DPB + 16 * s + 4 * g);
+    hq[t] = a.nrm[qi];
+    lmq = fminf(lmq, a.m0[qi]);
+  }
+  lmq = wave_min(lmq);
+
+  v8h ky[NLD];
+  float kn_next = 0.f, kl_next = 0.f;
+  auto keys_issue = [&](const int ch) {
+    const int j0 = ch * JC;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int f = tid + NT * u, row = f / R8, c8 = f - row * R8;
+      ky[u] = *reinterpret_cast<const v8h *>(a.Z + (size_t)min(j0 + row, N - 1) * DPB + 8 * c8);
+    }
+    if (tid < JC) {
+      const bool kval = j0 + tid < N;  // (keys behind the set do not exist for the fused pass: far by definition)
+      kn_next = kval ? a.nrm[j0 + tid] - a.T : 3.0e38f;
+      kl_next = kval ? a.lms[j0 + tid] : -INFINITY;
+    }
+  };
+  auto keys_commit = [&](const int buf) {
+    unsigned char *base = lds_raw + buf * BUF;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int f = tid + NT * u, row = f / R8, c8 = f - row * R8;
+      if (row < JC) *reinterpret_cast<v8h *>(base + ((size_t)row * ZS + 8 * c8) * sizeof(_Float16)) = ky[u];
+    }
+    float *kf = reinterpret_cast<float *>(base + (size_t)JC * ZS * sizeof(_Float16));
+    if (tid < JC) {
+      kf[tid] = kn_next;
+      kf[JC + tid] = kl_next;
+    }
+  };
+  keys_issue(c_beg);
+  keys_commit(0);
+  wg_sync();
+  int buf = 0;
+  for (int ch = c_beg; ch < c_end; ++ch, buf ^= 1) {
+    const bool more = ch + 1 < c_end;
+    if (more) keys_issue(ch + 1);  // in flight during the products
+    const unsigned char *base = lds_raw + buf * BUF;
+    const _Float16 *Zs = reinterpret_cast<const _Float16 *>(base);
+    const float *kf = reinterpret_cast<const float *>(base + (size_t)JC * ZS * sizeof(_Float16));
+    float mt[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) mt[t] = 3.0e38f;
+#pragma unroll 1
+    for (int kt = 0; kt < JC / 16; ++kt) {
+      v4f acc[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const v4h av = *reinterpret_cast<const v4h *>(&Zs[(16 * kt + r16) * ZS + 16 * s + 4 * g]);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bq[t][s], acc[t], 0, 0, 0);
+      }
+      // the lane holds (keys 16 kt + 4 g + r, query r16 of sub-tile t)
+      const v4f kn = *reinterpret_cast<const v4f *>(&kf[16 * kt + 4 * g]);
+      const v4f kl = *reinterpret_cast<const v4f *>(&kf[JC + 16 * kt + 4 * g]);
+      float hk[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dl = kl[r] == -INFINITY ? 0.f : fmaxf(kl[r] - lmq, 0.f);  // (a key of zero weight has no prior term at all)
+        hk[r] = fmaf(-2.0f, dl, kn[r]);
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const float m01 = fminf(fmaf(-2.0f, acc[t][0], hk[0]), fmaf(-2.0f, acc[t][1], hk[1]));
+        const float m23 = fminf(fmaf(-2.0f, acc[t][2], hk[2]), fmaf(-2.0f, acc[t][3], hk[3]));
+        mt[t] = fminf(mt[t], fminf(m01, m23));
+      }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) ok = ok && (mt[t] + hq[t] > 0.f);
+    const bool is_far = __ballot(!ok) == 0ull;  // wave-uniform
+    if (live) {
+      if (lane == 0) a.far[(size_t)tile * a.chunks + ch] = is_far ? 1 : 0;
+      if (is_far && a.nz)
+        for (int i = lane; i < TQ; i += 64) a.nz[(size_t)ch * a.ldnz + tile * TQ + i] = 0;
+    }
+    if (more) keys_commit(buf ^ 1);
+    wg_sync();
+  }
+}
+
+}  // namespace dust

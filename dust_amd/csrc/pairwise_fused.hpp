@@ -37,6 +37,8 @@ struct PairFusedArgs {
   int tiles, chunks;  // query tiles of TQ rows, key chunks of 64: the launch covers tiles * chunks units (see fused_balance)
   unsigned char *nz;  // [chunks][ldnz] 1 = the 64 Stein kernel values of (key chunk, query row) are not all exactly 0 (see below); ldnz >= rows, multiple of 64
   int ldnz;
+  const unsigned char *far;  // [tiles][chunks] 1 = the unit contributes exactly nothing and is not visited (pairwise_far.hpp), or nullptr
+  const float *m0;           // [N] where each query's running max starts (pairwise_far.hpp: a lower bound of its final max), or nullptr: -inf
 };
 
 // Exact zeros.  K1's lengthscale is fixed at ln 2 (svmpc.py:78), so k_ij = exp(-d2 / 0.96) UNDERFLOWS to exactly 0 in fp32 once
@@ -135,10 +137,31 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       accA[r][u] = accB[r][u] = v4f{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // The running max starts at a lower bound of its final value known before the pass (pairwise_far.hpp): a max known from the start
+  // is what lets the pre-pass prove that a unit's softmax terms are exact zeros.
   for (int i = tid; i < TQ; i += NT) {
-    mrow[i] = -INFINITY;
+    mrow[i] = b.m0 ? b.m0[min(ib + i, N - 1)] : -INFINITY;
     lrow[i] = 0.f;
   }
+  // live chunks of this run: 64 flags per ballot (wave-uniform; every wave reads the same bytes)
+  int fgb = ch0;
+  unsigned long long fmask = 0ull;
+  auto far_group = [&](const int base) {
+    const int cidx = base + jA;
+    const bool lv = cidx < ch1 && (b.far == nullptr || b.far[(size_t)tile * b.chunks + cidx] == 0);
+    fgb = base;
+    fmask = __ballot(lv);
+  };
+  auto next_live = [&](int from) {  // first live chunk >= from, or ch1
+    while (from < ch1) {
+      if (from >= fgb + 64) far_group(from);
+      const unsigned long long m = fmask >> (from - fgb);
+      if (m) return from + (int)__builtin_ctzll(m);
+      from = fgb + 64;
+    }
+    return ch1;
+  };
+  far_group(ch0);
 
   // Key chunks: the keys ARE the particles (prior means aliased to theta), so a chunk is rows j0 .. j0 + 63 of the padded copy -
   // one contiguous 64 * DPB float run, fetched with 16-byte loads (NLD per lane).  The NEXT chunk's loads are issued before pass B
@@ -167,9 +190,13 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       if (row < JC) *reinterpret_cast<v4f *>(&Ys[row * YS + col]) = row < jc ? ky[u] : v4f{0.f, 0.f, 0.f, 0.f};
     }
   };
-  keys_issue(jbeg);
-  keys_commit(jbeg);
-  for (int j0 = jbeg; j0 < jend; j0 += JC) {
+  int ci = next_live(ch0);
+  if (ci < ch1) {
+    keys_issue(ci * JC);
+    keys_commit(ci * JC);
+  }
+  while (ci < ch1) {
+    const int j0 = ci * JC;
     const int jc = min(JC, jend - j0);
     const float lm = lm_next;
     wg_sync();  // Ys holds this chunk
@@ -293,8 +320,9 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         for (int u = 0; u < NV; ++u) accA[r][u] *= sc;
       }
     }
-    const bool more = j0 + JC < jend;
-    if (more) keys_issue(j0 + JC);  // in flight during pass B
+    const int cn = next_live(ci + 1);
+    const bool more = cn < ch1;
+    if (more) keys_issue(cn * JC);  // in flight during pass B
     // ---- pass B: lane = 4 queries x CB columns; the difference y_j - x_i feeds the prior sum and the repulsion sum ----
     // (a chunk whose Stein kernel values are zero for the whole tile runs without the repulsion FMAs: they would add exact zeros)
     const bool tile_any = (wany[0] | wany[1] | wany[2] | wany[3]) != 0u;
@@ -325,7 +353,8 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       else pass_b(std::false_type{});
     }
     wg_sync();  // pass B is done with Ys / kv
-    if (more) keys_commit(j0 + JC);
+    if (more) keys_commit(cn * JC);
+    ci = cn;
   }
 
   // ---- partial outputs (layout of stein.hpp: [js][n_local][ldp], raw coordinates) ----
@@ -583,17 +612,21 @@ __global__ __launch_bounds__(PAIR_NT, 4) void gram_score_kernel(const GramScoreA
     }
     return nch;
   };
+  // (sparse: a row whose flag is 0 holds zeros - or, where pairwise_far.hpp kept pass 1 away from the unit, nothing at all: masked)
+  unsigned int kfl = 0xfu;
   auto k_issue = [&](const int j0, v4f (&kt)[4]) {
+    kfl = 0u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int il = min(il0 + kr + 16 * u, a.n_local - 1);
       kt[u] = *reinterpret_cast<const v4f *>(a.K + (size_t)il * a.ldK + j0 + kc);  // (ldK is a multiple of 64: in bounds; the tail is masked)
+      kfl |= (a.nz == nullptr || a.nz[(size_t)(j0 >> 6) * a.ldnz + il] != 0) ? 1u << u : 0u;
     }
   };
   auto k_commit = [&](const int jc, const v4f (&kt)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v4f t = kt[u];
+      v4f t = (kfl >> u) & 1u ? kt[u] : v4f{0.f, 0.f, 0.f, 0.f};
       t.x = kc + 0 < jc ? t.x : 0.f;
       t.y = kc + 1 < jc ? t.y : 0.f;
       t.z = kc + 2 < jc ? t.z : 0.f;

@@ -27,6 +27,8 @@ struct LogpMfmaArgs {
   float *hq;            // [N] -|z'|^2 / 2
   float *hj;            // [N] log2(w_j) - |z'_j|^2 / 2
   float *pM, *pL;       // [JS][n_local] slice partials (natural-log max, sum of exp relative to it): prior_finish_kernel merges
+  const unsigned char *far;  // [groups][chunks] 1 = every term of (64-query group, key chunk) is negligible (pairwise_far.hpp), or nullptr
+  int groups, chunks;
 };
 
 // one wave per row: scale, centre, pad; squared norm
@@ -116,16 +118,54 @@ __global__ __launch_bounds__(256, 2) void pairwise_logp_mfma_kernel(const LogpMf
     }
     if (tid < JC) hs[buf * JC + tid] = hjn;
   };
-  keys_issue(jbeg);
-  keys_commit(0);
+  // live chunks of the slice: 64 flags per ballot - wmask: some wave of the workgroup needs the chunk, omask: this wave does
+  // (a.slice is a multiple of 64: chunk c = keys 64 c ..)
+  const int c_beg = jbeg >> 6, c_end = (jend + JC - 1) >> 6;
+  int fgb = c_beg;
+  unsigned long long wmask = 0ull, omask = 0ull;
+  auto far_group = [&](const int base) {
+    const int cidx = base + lane;
+    bool any_live = cidx < c_end, own_live = any_live;
+    if (a.far && cidx < c_end) {
+      any_live = own_live = false;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int grp = tile * 4 + w;
+        const bool lv = grp < a.groups && a.far[(size_t)grp * a.chunks + cidx] == 0;
+        any_live = any_live || lv;
+        own_live = w == wave ? lv : own_live;
+      }
+    }
+    fgb = base;
+    wmask = __ballot(any_live);
+    omask = __ballot(own_live);
+  };
+  auto next_live = [&](int from) {  // first chunk >= from some wave needs, or c_end
+    while (from < c_end) {
+      if (from >= fgb + 64) far_group(from);
+      const unsigned long long mk = wmask >> (from - fgb);
+      if (mk) return from + (int)__builtin_ctzll(mk);
+      from = fgb + 64;
+    }
+    return c_end;
+  };
+  far_group(c_beg);
+  int ci = next_live(c_beg);
+  if (ci < c_end) {
+    keys_issue(ci * JC);
+    keys_commit(0);
+  }
   wg_sync();
   int buf = 0;
-  for (int j0 = jbeg; j0 < jend; j0 += JC, buf ^= 1) {
-    const bool more = j0 + JC < jend;
-    if (more) keys_issue(j0 + JC);  // in flight during the products
+  while (ci < c_end) {
+    const int j0 = ci * JC;
+    const bool own = (omask >> (ci - fgb)) & 1ull;
+    const int cn = next_live(ci + 1);
+    const bool more = cn < c_end;
+    if (more) keys_issue(cn * JC);  // in flight during the products
     const float *Yb = Ys + (size_t)buf * JC * YS;
 #pragma unroll 1
-    for (int kt = 0; kt < JC / 16; ++kt) {
+    for (int kt = 0; kt < (own ? JC / 16 : 0); ++kt) {
       v4f acc[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -159,6 +199,8 @@ __global__ __launch_bounds__(256, 2) void pairwise_logp_mfma_kernel(const LogpMf
     }
     if (more) keys_commit(buf ^ 1);
     wg_sync();
+    ci = cn;
+    buf ^= 1;
   }
   // merge the 4 lane groups of a query (lanes r16, r16 + 16, + 32, + 48), then one lane per query writes the slice partial
 #pragma unroll
