@@ -197,12 +197,13 @@ __device__ __forceinline__ float fast_cosf(float x) {
 // the final rounding - indistinguishable from the double sum at the 1e-5 the costs are held to, and small enough for the tests that
 // watch the softmax amplify cost ulps (a plain fp32 sum over H = 30 steps - the reference's own torch.sum, disco.py:325-330 - was
 // tried: -2 us per cfg2 tick instead of -1.5, but 2-3 ulp of cost error pushed two amplification-limited checks over their bounds).
-// Every Pendulum rollout kernel, and both its trig paths, sums this way: their costs still agree bit for bit.  Particle / skid-steer keep
-// the plain double sum (obstacle weights of 1e6 beside terms of 1e-2).
+// Every Pendulum rollout kernel, and both its trig paths, sums this way: their costs still agree bit for bit.  The Particle kernels'
+// packed two-sample loops carry a Kahan-compensated fp32 sum (PairKahan below: obstacle weights of 1e6 beside terms of 1e-2 want the
+// compensation); the general one-sample loop and skid-steer keep the plain double sum.
 template <int MODEL>
 struct CostSum {
   double tot = 0.0;
-  float part = 0.f;
+  float part = 0.f, comp = 0.f;  // Pendulum: the open group of four; Particle: Kahan sum / compensation (PairKahan's arithmetic, one sample)
   __device__ __forceinline__ void add(const float c, const int t) {
     if (MODEL == DUST_MODEL_PENDULUM) {
       part += c;
@@ -211,11 +212,14 @@ struct CostSum {
         part = 0.f;
       }
     } else {
-      tot += (double)c;
+      const float y = c - comp;
+      const float s = part + y;
+      comp = (s - part) - y;
+      part = s;
     }
   }
   __device__ __forceinline__ void add_weighted(const double w, const float c) { tot += w * (double)c; }  // (sigma-point rollouts: rare)
-  __device__ __forceinline__ double total() const { return MODEL == DUST_MODEL_PENDULUM ? tot + (double)part : tot; }
+  __device__ __forceinline__ double total() const { return tot + (double)part; }
 };
 
 template <int MODEL>
@@ -255,16 +259,18 @@ __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, c
     float t2 = dm.w_vel * (x[1] * x[1]);
     return t1 + t2;
   } else {
-    double sc = 0.0, cc = 0.0;
+    float tk4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float d = x[k] - dm.target[k];
-      sc += (double)((d * d) * dm.w_state[k]);
+      const float d = x[k] - dm.target[k];
+      tk4[k] = (d * d) * dm.w_state[k];
     }
+    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+    double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
     float ob = dm.with_obstacle ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
-    return ((float)sc + (float)cc) + ob;
+    return (sc + (float)cc) + ob;
   }
 }
 
@@ -279,16 +285,18 @@ __device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &
   } else {
     const bool crash = dm.can_crash && dm.with_obstacle;
     const float coll = (dm.with_obstacle || crash) ? collision(dm, x[0], x[1]) : 0.f;
-    double sc = 0.0, cc = 0.0;
+    float tk4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float d = x[k] - dm.target[k];
-      sc += (double)((d * d) * dm.w_state[k]);
+      const float d = x[k] - dm.target[k];
+      tk4[k] = (d * d) * dm.w_state[k];
     }
+    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+    double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
     const float ob = dm.with_obstacle ? dm.w_obs * coll : 0.0f;
-    const float cost = ((float)sc + (float)cc) + ob;
+    const float cost = (sc + (float)cc) + ob;
     const float dt = (float)dm.dt;
     float ax = clampf(a[0] / c.c0, -dm.max_acc, dm.max_acc);
     float ay = clampf(a[1] / c.c0, -dm.max_acc, dm.max_acc);
@@ -333,16 +341,18 @@ template <bool OBST, bool CRASH>
 __device__ __forceinline__ float particle_step_cost_fast(const DevModel &dm, const float mass, const float rmass, float *x, const float *a) {
   constexpr bool crash = CRASH;
   const float coll = OBST ? collision_bf(dm, x[0], x[1]) : 0.f;
-  double sc = 0.0, cc = 0.0;
+  float tk4[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float d = x[k] - dm.target[k];
-    sc += (double)((d * d) * dm.w_state[k]);
+    tk4[k] = (d * d) * dm.w_state[k];
   }
+  const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+  double cc = 0.0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
   const float ob = OBST ? dm.w_obs * coll : 0.0f;
-  const float cost = ((float)sc + (float)cc) + ob;
+  const float cost = (sc + (float)cc) + ob;
   const float dt = (float)dm.dt;
   const float ax = __builtin_amdgcn_fmed3f(div_by_const(a[0], mass, rmass), -dm.max_acc, dm.max_acc);
   const float ay = __builtin_amdgcn_fmed3f(div_by_const(a[1], mass, rmass), -dm.max_acc, dm.max_acc);
@@ -391,11 +401,22 @@ __device__ __forceinline__ v2f collision_pair(const DevModel &dm, const uint32_t
   c.y = (float)__builtin_amdgcn_ubfe(grid[ib >> 5], ib, 1u);
   return c;
 }
-__device__ __forceinline__ v2f round_sum4(const v2f t0, const v2f t1, const v2f t2, const v2f t3) {  // RN32 of the exact sums
-  const double sa = (((double)t0.x + (double)t1.x) + (double)t2.x) + (double)t3.x;
-  const double sb = (((double)t0.y + (double)t1.y) + (double)t2.y) + (double)t3.y;
-  return (v2f){(float)sa, (float)sb};
-}
+// The state cost's four terms, fp32 pairwise ((t0 + t1) + (t2 + t3)): 3 packed adds for both samples.  (Until round 5 this was the
+// correctly rounded exact sum - 8 v_cvt_f64_f32 + 6 v_add_f64 + 2 v_cvt_f32_f64 per step pair, 16 of the ~100 VALU instructions of a
+// Particle step and the half-rate ones; the reference's own torch fp32 `.sum(-1)` is a sum of this class, and the result stays
+// within 2 ulp of the exact one: 1e-7 against the 1e-5 bound.)
+__device__ __forceinline__ v2f sum4_pair(const v2f t0, const v2f t1, const v2f t2, const v2f t3) { return (t0 + t1) + (t2 + t3); }
+// Running sum over the time steps of both samples' step costs: Kahan-compensated in packed fp32 (4 v_pk ops per step pair instead of
+// 2 cvt + 2 v_add_f64): the total is the fp32 step costs' sum to ~1 ulp, as the double accumulator's rounded value was.
+struct PairKahan {
+  v2f sum = {0.f, 0.f}, comp = {0.f, 0.f};
+  __device__ __forceinline__ void add(const v2f c) {
+    const v2f y = c - comp;
+    const v2f t = sum + y;
+    comp = (t - sum) - y;
+    sum = t;
+  }
+};
 // the per-dimension target / state-cost weights as packed pairs (both halves equal): built once per kernel by the caller - in
 // SGPR pairs when the compiler has them to spare, in VGPR pairs (PairK::pin) when it does not (a splat of an odd-indexed SGPR
 // otherwise goes through a stack slot: a scratch load, and with it a vmcnt wait behind every store in flight, per time step)
@@ -430,7 +451,7 @@ __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const Pair
     const v2f d = x[k] - pk.target[k];
     tk[k] = (d * d) * pk.w_state[k];
   }
-  v2f cost = round_sum4(tk[0], tk[1], tk[2], tk[3]) + cc;
+  v2f cost = sum4_pair(tk[0], tk[1], tk[2], tk[3]) + cc;
   if (OBST) cost = cost + dm.w_obs * coll;  // (without obstacles the reference adds +0 to a non-negative sum: identity)
   const float dt = (float)dm.dt;
   const v2f av[2] = {{a0, a0}, {a1, a1}};
@@ -471,7 +492,7 @@ __device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint
     const v2f d = x[k] - dm.target[k];
     tk[k] = (d * d) * dm.w_term[k];
   }
-  v2f c = round_sum4(tk[0], tk[1], tk[2], tk[3]);
+  v2f c = sum4_pair(tk[0], tk[1], tk[2], tk[3]);
   if (OBST) c = c + dm.w_obs * (coll_in ? *coll_in : collision_pair(dm, grid, x[0], x[1]));
   return c;
 }
@@ -481,14 +502,15 @@ __device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
   if (MODEL == DUST_MODEL_PENDULUM) {
     return inst_cost<MODEL>(dm, x, nullptr);
   } else {
-    double sc = 0.0;
+    float tk4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float d = x[k] - dm.target[k];
-      sc += (double)((d * d) * dm.w_term[k]);
+      tk4[k] = (d * d) * dm.w_term[k];
     }
+    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);
     float ob = dm.with_obstacle ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
-    return (float)sc + ob;
+    return sc + ob;
   }
 }
 

@@ -1891,7 +1891,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.logmix = a.logmix;
     f.sg[0] = sqrtf(std::min(b.wS[0], b.wP[0]));
     f.sg[1] = sqrtf(std::min(b.wS[1], b.wP[1]));
-    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * dpb + 1) / 2));
+    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * far_zh(dpb) + 1) / 2));
     TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + b.chunks));
     TRY(ensure(&c->far_f, &c->far_f_cap, ((size_t)tiles * b.chunks + 3) / 4));
     f.Z = reinterpret_cast<_Float16 *>(c->far_z);
@@ -1917,7 +1917,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     far_cand_kernel<<<(b.chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);
 #define DUST_LAUNCH_FAR(DPB)                                                                         \
   do {                                                                                               \
-    far_lb_kernel<DPB><<<(nq + 63) / 64, 256, 0, c->pair_stream>>>(f);                               \
+    far_lb_kernel<DPB><<<(nq + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);            \
     if (flags) {                                                                                     \
       far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                           \
       far_flags_kernel<DPB, FusedGeom<DPB>::TQ><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f); \
@@ -2027,7 +2027,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     f.sg[1] = b.sw[1];
     const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
     f.T = (env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT) * 1.44269504088896340736f;
-    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * dpb + 1) / 2));
+    TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * far_zh(dpb) + 1) / 2));
     TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + chunks));
     TRY(ensure(&c->far_g, &c->far_g_cap, ((size_t)f.tiles * chunks + 3) / 4));
     f.Z = reinterpret_cast<_Float16 *>(c->far_z);
@@ -2053,7 +2053,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                       \
     if (flags) {                                                                                                                \
       far_cand_kernel<<<(chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                         \
-      far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 256, 0, c->pair_stream>>>(f);                           \
+      far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);        \
       far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                      \
       far_flags_kernel<DPB, 64><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
     }                                                                                                                           \

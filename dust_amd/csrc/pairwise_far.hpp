@@ -27,7 +27,7 @@
 // its own: without the candidates no unit of such a query could be proven negligible.  Any reference <= the true max + O(ulp)
 // serves the softmax equally well, so every mode of the fused pass starts from m0 (tests: DUST_FAR_T=224 against DUST_FAR=0 and
 // DUST_DENSE=1 bitwise; the default against them at 1e-6 of the largest element).
-// Cost: 2 D flops per pair on v_mfma_f32_16x16x16_f16 instead of 3 D packed fp32 lane-ops - and for a clustered set it buys nothing
+// Cost: 2 D flops per pair on v_mfma_f32_16x16x32_f16 instead of 3 D packed fp32 lane-ops - and for a clustered set it buys nothing
 // (every unit stays, the pre-pass is ~3 % on top).  Time is data dependent, results are not.
 #pragma once
 #include "pairwise_fused.hpp"
@@ -48,7 +48,7 @@ struct FarArgs {
   const float *X;       // [N][D] particles
   const float *logmix;  // [N] log mixture weights
   float sg[2];          // sqrt(g) for even / odd dimensions
-  _Float16 *Z;          // [N][DPB] scaled, centred, zero-padded rows in binary16 (far_prep_kernel)
+  _Float16 *Z;          // [N][far_zh(DPB)] scaled, centred, zero-padded rows in binary16 (far_prep_kernel)
   float *nrm;           // [N] |z|^2 (1 - EB), or -inf: the row is never far
   float *lms;           // [N] log w (finite or -inf)
   int *cand;            // [chunks] the heaviest particle of each key chunk (far_cand_kernel)
@@ -60,6 +60,9 @@ struct FarArgs {
   int ldnz;
   float T;              // the threshold on G (DUST_FAR_T_DEFAULT; development switch DUST_FAR_T)
 };
+
+// binary16 row length: whole K = 32 steps of v_mfma_f32_16x16x32_f16 (gfx950's full-rate shape: the 16x16x16 one runs at a quarter of it)
+static constexpr __host__ __device__ int far_zh(int dpb) { return ((dpb + 31) / 32) * 32; }
 
 // one wave per row
 template <int DPB>
@@ -80,10 +83,12 @@ __global__ __launch_bounds__(256) void far_prep_kernel(const FarArgs a) {
   acc = wave_sum(acc);
   const float lm = a.logmix[row];
   ok = __ballot(!ok) == 0ull && (lm < INFINITY) && acc < INFINITY;  // (lm NaN: false)
+  constexpr int ZH = far_zh(DPB);
 #pragma unroll
-  for (int u = 0; u < (DPB + 63) / 64; ++u) {
+  for (int u = 0; u < (ZH + 63) / 64; ++u) {
     const int c = lane + 64 * u;
-    if (c < DPB) a.Z[(size_t)row * DPB + c] = ok ? (_Float16)v[u] : (_Float16)0.f;
+    const float val = u < (DPB + 63) / 64 ? v[u < (DPB + 63) / 64 ? u : 0] : 0.f;
+    if (c < ZH) a.Z[(size_t)row * ZH + c] = ok && c < a.D ? (_Float16)val : (_Float16)0.f;
   }
   if (lane == 0) {
     a.nrm[row] = ok ? acc * (1.0f - DUST_FAR_EB) : -INFINITY;
@@ -103,11 +108,14 @@ __global__ __launch_bounds__(256) void far_cand_kernel(const FarArgs a) {
   if (lane == 0) a.cand[ch] = min(ch * 64 + (hit ? (int)__builtin_ctzll(hit) : 0), a.N - 1);
 }
 
-// m0 (see the file comment): lane = query (row in registers), wave w of the workgroup takes candidates w, w + 4, ... through the
-// scalar path; the logit is formed as the fused pass forms it (differences first, even / odd dimensions apart, log w - pa / 2)
+// m0 (see the file comment): lane = query (row in registers), the 16 waves of the workgroup share the candidates (wave w takes
+// w, w + 16, ... through the scalar path: the serial loop per wave is what bounds this launch - 57 us with 4 waves, whatever the
+// set size); the logit is formed as the fused pass forms it (differences first, even / odd dimensions apart, log w - pa / 2)
+#define DUST_FAR_LB_WAVES 16
 template <int DPB>
-__global__ __launch_bounds__(256) void far_lb_kernel(const FarArgs a) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * DUST_FAR_LB_WAVES) void far_lb_kernel(const FarArgs a) {
+  constexpr int NW = DUST_FAR_LB_WAVES;
+  __shared__ float red[NW][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q_end = min(a.N, a.i0 + a.q_rows);
   const int qi = a.i0 + blockIdx.x * 64 + lane, qc = min(qi, a.N - 1);
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void far_lb_kernel(const FarArgs a) {
     x[2 * p + 1] = v2f{t.z, t.w};
   }
   float best = -INFINITY;
-  for (int ci = wave; ci < a.chunks; ci += 4) {
+  for (int ci = wave; ci < a.chunks; ci += NW) {
     const int c = __builtin_amdgcn_readfirstlane(a.cand[ci]);
     typedef const v2f __attribute__((address_space(4))) * cv2;
     const cv2 y = (cv2)(uintptr_t)(a.Xp + (size_t)c * DPB);
@@ -136,26 +144,27 @@ __global__ __launch_bounds__(256) void far_lb_kernel(const FarArgs a) {
   red[wave][lane] = best;
   __syncthreads();
   if (wave == 0 && qi < q_end) {
-    const float own = a.logmix[qi] * a.lscale;
-    float m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
-    m = own > m ? own : m;
+    float m = a.logmix[qi] * a.lscale;  // the query's own logit
+    m = m == m ? m : -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, red[w][lane]);
     a.m0[qi] = m;
   }
 }
 
 template <int DPB>
 static inline size_t far_flags_lds_bytes() {
-  return 2 * ((size_t)64 * (DPB + 8) * sizeof(_Float16) + 2 * 64 * sizeof(float));
+  return 2 * ((size_t)64 * (far_zh(DPB) + 8) * sizeof(_Float16) + 2 * 64 * sizeof(float));
 }
 
 // Workgroup = 4 waves = 4 query tiles (TQ rows each - the consumer's tile: pairwise_fused_kernel's, or the 64 queries of a wave of
 // pairwise_logp_mfma_kernel - held in registers as B operands), the key
-// chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 8-byte LDS read.
+// chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 16-byte LDS read.
 template <int DPB, int TQ>
 __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
-  constexpr int JC = 64, NT = 256, QT = TQ / 16, NP = DPB / 16, ZS = DPB + 8, R8 = DPB / 8;
+  constexpr int JC = 64, NT = 256, QT = TQ / 16, ZH = far_zh(DPB), NP = ZH / 32, ZS = ZH + 8, R8 = ZH / 8;
   constexpr int NLD = (JC * R8 + NT - 1) / NT;
-  static_assert(TQ % 16 == 0 && DPB % 16 == 0, "whole MFMA tiles");
+  static_assert(TQ % 16 == 0, "whole MFMA tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr size_t BUF = (size_t)JC * ZS * sizeof(_Float16) + 2 * JC * sizeof(float);
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
@@ -166,14 +175,14 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
   const int c_beg = blockIdx.y * a.cps, c_end = min(a.chunks, c_beg + a.cps);
   if (c_beg >= c_end) return;
 
-  v4h bq[QT][NP];
+  v8h bq[QT][NP];
   float hq[QT];
   float lmq = INFINITY;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = min(a.i0 + tq * TQ + 16 * t + r16, N - 1);  // (rows behind the set: clamped, as the fused pass clamps them)
 #pragma unroll
-    for (int s = 0; s < NP; ++s) bq[t][s] = *reinterpret_cast<const v4h *>(a.Z + (size_t)qi * DPB + 16 * s + 4 * g);
+    for (int s = 0; s < NP; ++s) bq[t][s] = *reinterpret_cast<const v8h *>(a.Z + (size_t)qi * ZH + 32 * s + 8 * g);
     hq[t] = a.nrm[qi];
     lmq = fminf(lmq, a.m0[qi]);
   }
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int f = tid + NT * u, row = f / R8, c8 = f - row * R8;
-      ky[u] = *reinterpret_cast<const v8h *>(a.Z + (size_t)min(j0 + row, N - 1) * DPB + 8 * c8);
+      ky[u] = *reinterpret_cast<const v8h *>(a.Z + (size_t)min(j0 + row, N - 1) * ZH + 8 * c8);
     }
     if (tid < JC) {
       const bool kval = j0 + tid < N;  // (keys behind the set do not exist for the fused pass: far by definition)
@@ -227,9 +236,9 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
       for (int t = 0; t < QT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
-        const v4h av = *reinterpret_cast<const v4h *>(&Zs[(16 * kt + r16) * ZS + 16 * s + 4 * g]);
+        const v8h av = *reinterpret_cast<const v8h *>(&Zs[(16 * kt + r16) * ZS + 32 * s + 8 * g]);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bq[t][s], acc[t], 0, 0, 0);
+        for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq[t][s], acc[t], 0, 0, 0);
       }
       // the lane holds (keys 16 kt + 4 g + r, query r16 of sub-tile t)
       const v4f kn = *reinterpret_cast<const v4f *>(&kf[16 * kt + 4 * g]);

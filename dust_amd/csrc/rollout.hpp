@@ -391,7 +391,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         v2f xp[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
-        double ta = 0.0, tb = 0.0;
+        PairKahan tk2;
         float tca, tcb;
         // stored states: the two trajectories (rows G S N apart: the same alignment phase) stage side by side and their chunks
         // flush together - 2 PC LDS reads, then 2 PC stores in flight per flush
@@ -420,8 +420,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           for (int t = 0; t < H; ++t) {
             const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
             const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
-            ta += (double)c.x;
-            tb += (double)c.y;
+            tk2.add(c);
             put_pair(t + 1);
           }
           const v2f tc = particle_pair_term<OB>(a.dm, dml.grid_bits, xp);
@@ -431,8 +430,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{});
         else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{});
         else pair_loop(std::true_type{}, std::false_type{});
-        acc_m += (double)((float)ta + tca);
-        acc_m += (double)((float)tb + tcb);
+        acc_m += (double)(tk2.sum.x + tca);
+        acc_m += (double)(tk2.sum.y + tcb);
       }
       m_begin = m;
     }

@@ -101,7 +101,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
 #pragma unroll
     for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
     v4f cB[8];  // sample B's state ring (row % 8); sample A's lives in the staging area (slot = (row + pj) % 8 of the lane's line)
-    double ta = 0.0, tb = 0.0;
+    PairKahan tk2;
     // one row of both trajectories.  From row 7 on, the particle whose line completes at this row: A's line is read straight
     // from the area, B's 8 lanes dump their rings into the transient lines first; the wave stores 8 + 8 whole lines.
     auto emit = [&](const int q /* row % 8, static */, const int row) {
@@ -135,8 +135,7 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
       const int tn = min(t + 1, H - 1);
       a0 = actl[2 * tn];
       a1 = actl[2 * tn + 1];
-      ta += (double)c.x;
-      tb += (double)c.y;
+      tk2.add(c);
       emit((i + 1) & 7, t + 1);
     };
     emit(0, 0);
@@ -148,8 +147,8 @@ __device__ __forceinline__ double sg_roll_pairs(const RolloutArgs &a, const uint
         if (base + i < H) step(i, base + i);
     }
     const v2f tc = sg_pair_term<MODE>(a.dm, grid, xp, &coll);
-    acc += (double)((float)ta + tc.x);
-    acc += (double)((float)tb + tc.y);
+    acc += (double)(tk2.sum.x + tc.x);
+    acc += (double)(tk2.sum.y + tc.y);
     // ---- the 7 straddling lines of each group: tail of row j (slots 0 .. t-1) + head of row j+1 (slots t .. 7) ----
     // head rows 1..6 are rolled out AGAIN (same instructions, same operands: the same bits) rather than held in 48 registers
     // through the whole rollout
@@ -695,7 +694,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     u4 cB2[8];            // trajectory B's ring (row % 16): entries (2 v, 2 v + 1) share a register quad - half of the dumps are 16-byte writes
     u2 hA[15], hB[15];    // rows 0 .. 14 of both
-    double ta = 0.0, tb = 0.0;
+    PairKahan tk2;
     auto emit = [&](const int q /* row % 16, static */, const int row) {
       const u2 sa = pack(xp[0].x, xp[1].x, xp[2].x, xp[3].x), sbv = pack(xp[0].y, xp[1].y, xp[2].y, xp[3].y);
       *reinterpret_cast<u2 *>(my_row + (((q + pj) & 15) << 3)) = sa;
@@ -741,8 +740,7 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
       const int tn = min(t + 1, H - 1);
       a0 = actl[2 * tn];
       a1 = actl[2 * tn + 1];
-      ta += (double)c.x;
-      tb += (double)c.y;
+      tk2.add(c);
       emit((i + 1) & 15, t + 1);
     };
     emit(0, 0);
@@ -752,8 +750,8 @@ __global__ void __launch_bounds__(256, 2) particle_states_f16_kernel(const Rollo
         if (base + i < H) step(i, base + i);
     }
     const v2f tc = sg_pair_term<MODE>(a.dm, gridl, xp, &coll);
-    acc += (double)((float)ta + tc.x);
-    acc += (double)((float)tb + tc.y);
+    acc += (double)(tk2.sum.x + tc.x);
+    acc += (double)(tk2.sum.y + tc.y);
     // ---- the 15 straddling lines of each group: tail of row j (slots 0 .. t-1) + head of row j+1 (slots t .. 15) ----
     auto assemble = [&](const bool ring /* B: the tails are in the register ring */, const u2 *head, char *g0 /* + m stride, piece 0 of sample 0's group */) {
       __builtin_amdgcn_wave_barrier();
