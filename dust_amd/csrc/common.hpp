@@ -251,6 +251,12 @@ __device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, fl
   }
 }
 
+// sum_k w_k (x_k - target_k)^2 over the four state dimensions, fp32 pairwise - sum4_pair's order: every Particle path agrees bit for bit
+__device__ __forceinline__ float particle_state_cost(const float *x, const float *target, const float *w) {
+  const float d0 = x[0] - target[0], d1 = x[1] - target[1], d2 = x[2] - target[2], d3 = x[3] - target[3];
+  return ((d0 * d0) * w[0] + (d1 * d1) * w[1]) + ((d2 * d2) * w[2] + (d3 * d3) * w[3]);
+}
+
 template <int MODEL>
 __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, const float *a) {
   if (MODEL == DUST_MODEL_PENDULUM) {
@@ -259,13 +265,7 @@ __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, c
     float t2 = dm.w_vel * (x[1] * x[1]);
     return t1 + t2;
   } else {
-    float tk4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float d = x[k] - dm.target[k];
-      tk4[k] = (d * d) * dm.w_state[k];
-    }
-    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+    const float sc = particle_state_cost(x, dm.target, dm.w_state);
     double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
@@ -285,13 +285,7 @@ __device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &
   } else {
     const bool crash = dm.can_crash && dm.with_obstacle;
     const float coll = (dm.with_obstacle || crash) ? collision(dm, x[0], x[1]) : 0.f;
-    float tk4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float d = x[k] - dm.target[k];
-      tk4[k] = (d * d) * dm.w_state[k];
-    }
-    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+    const float sc = particle_state_cost(x, dm.target, dm.w_state);
     double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
@@ -341,13 +335,7 @@ template <bool OBST, bool CRASH>
 __device__ __forceinline__ float particle_step_cost_fast(const DevModel &dm, const float mass, const float rmass, float *x, const float *a) {
   constexpr bool crash = CRASH;
   const float coll = OBST ? collision_bf(dm, x[0], x[1]) : 0.f;
-  float tk4[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float d = x[k] - dm.target[k];
-    tk4[k] = (d * d) * dm.w_state[k];
-  }
-  const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);  // (sum4_pair's order: every Particle path agrees bit for bit)
+  const float sc = particle_state_cost(x, dm.target, dm.w_state);
   double cc = 0.0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) cc += (double)((a[k] * a[k]) * dm.w_ctrl[k]);
@@ -486,13 +474,9 @@ __device__ __forceinline__ float particle_ctrl_cost(const DevModel &dm, const fl
 }
 template <bool OBST>
 __device__ __forceinline__ v2f particle_pair_term(const DevModel &dm, const uint32_t *grid, const v2f *x, const v2f *coll_in = nullptr) {
-  v2f tk[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const v2f d = x[k] - dm.target[k];
-    tk[k] = (d * d) * dm.w_term[k];
-  }
-  v2f c = sum4_pair(tk[0], tk[1], tk[2], tk[3]);
+  // (once per trajectory: scalar - packed math would splat the odd-indexed SGPRs of dm.target / dm.w_term through a stack slot)
+  const float xa[4] = {x[0].x, x[1].x, x[2].x, x[3].x}, xb[4] = {x[0].y, x[1].y, x[2].y, x[3].y};
+  v2f c = {particle_state_cost(xa, dm.target, dm.w_term), particle_state_cost(xb, dm.target, dm.w_term)};
   if (OBST) c = c + dm.w_obs * (coll_in ? *coll_in : collision_pair(dm, grid, x[0], x[1]));
   return c;
 }
@@ -502,13 +486,7 @@ __device__ __forceinline__ float term_cost(const DevModel &dm, const float *x) {
   if (MODEL == DUST_MODEL_PENDULUM) {
     return inst_cost<MODEL>(dm, x, nullptr);
   } else {
-    float tk4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float d = x[k] - dm.target[k];
-      tk4[k] = (d * d) * dm.w_term[k];
-    }
-    const float sc = (tk4[0] + tk4[1]) + (tk4[2] + tk4[3]);
+    const float sc = particle_state_cost(x, dm.target, dm.w_term);
     float ob = dm.with_obstacle ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
     return sc + ob;
   }

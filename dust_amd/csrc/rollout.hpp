@@ -391,7 +391,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         v2f xp[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) xp[k] = (v2f){x0[k], x0[k]};
-        PairKahan tk2;
+        v2f ksum = {0.f, 0.f}, kcomp = {0.f, 0.f};  // PairKahan's arithmetic (plain locals: the struct, captured by the lambda below, kept a dead stack slot alive)
         float tca, tcb;
         // stored states: the two trajectories (rows G S N apart: the same alignment phase) stage side by side and their chunks
         // flush together - 2 PC LDS reads, then 2 PC stores in flight per flush
@@ -414,13 +414,19 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         };
         PairK pk;
         pk.load(a.dm);
+        pk.pin();  // (VGPR pairs: with the packed cost sums the compiler runs out of SGPR pairs and parks odd-indexed splats in a stack slot)
         auto pair_loop = [&](auto obst, auto crash) {
           constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
           put_pair(0);
           for (int t = 0; t < H; ++t) {
             const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
             const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
-            tk2.add(c);
+            {
+              const v2f ky = c - kcomp;
+              const v2f kt = ksum + ky;
+              kcomp = (kt - ksum) - ky;
+              ksum = kt;
+            }
             put_pair(t + 1);
           }
           const v2f tc = particle_pair_term<OB>(a.dm, dml.grid_bits, xp);
@@ -430,8 +436,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{});
         else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{});
         else pair_loop(std::true_type{}, std::false_type{});
-        acc_m += (double)(tk2.sum.x + tca);
-        acc_m += (double)(tk2.sum.y + tcb);
+        acc_m += (double)(ksum.x + tca);
+        acc_m += (double)(ksum.y + tcb);
       }
       m_begin = m;
     }

@@ -95,11 +95,12 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
     # (one code object per translation unit: dust_amd.hip, tick2.hip)
     notes = "".join(subprocess.run([llvm + "/llvm-readelf", "--notes", f], cwd=str(tmp_path), check=True, capture_output=True, text=True).stdout
                     for f in co)
-    kernels = {}
+    kernels, sgpr_spills = {}, {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
         blk = m.group(2)
         kernels[m.group(1)] = (int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)),
                                int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+        sgpr_spills[m.group(1)] = int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1))
     hot = [k for k in kernels if re.search(r"svgd_iter_kernel|fused_prior_rollout_kernel|stein_update_kernel|rollout_stream_kernel|"
                                            r"rollout_kernelILi\d+ELb\dELb1|pairwise_kernelILi\d+ELi[48]E|finalize_roll_kernel|"
                                            r"pairwise_big_kernelILi\d+ELi32E|"
@@ -109,6 +110,19 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
                                            r"pairwise_logp_big_kernel", k)]
     assert len(hot) >= 45, sorted(kernels)
     bad = {k: kernels[k] for k in hot if kernels[k] != (0, 0)}
+    # A kernel that spills SGPRs parks them in VGPR lanes (v_writelane / v_readlane), but the frame keeps the spill slots it no
+    # longer uses (the Particle rollout kernels since round 5: `Spill 16 + Variable 4` bytes in -Rpass-analysis=stack-frame-layout,
+    # 56-66 SGPRs in lanes): a few reserved bytes WITHOUT any scratch instruction in the code are not a spill to memory.
+    maybe = {k: v for k, v in bad.items() if v[0] == 0 and v[1] <= 32 and sgpr_spills[k] > 0}
+    if maybe:
+        for f in co:
+            dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--disassemble-symbols=" + ",".join(sorted(maybe)), f], cwd=str(tmp_path),
+                                 check=True, capture_output=True, text=True).stdout
+            for k in list(maybe):
+                body = re.search(r"<%s>:\n(.*?)(?:\n\n|\Z)" % re.escape(k), dis, re.S)
+                if body and "s_endpgm" in body.group(1) and not re.search(r"scratch_|buffer_(?:load|store)[^\n]*s\[0:3\]", body.group(1)):
+                    maybe.pop(k)
+                    bad.pop(k)
     assert not bad, "VGPR spills / scratch in hot kernels (name: (spilled VGPRs, scratch bytes)): %r" % bad
     # The one-launch tick kernels sit ON their register cap (16 / 4 resident waves per SIMD must stay) and do spill a little,
     # OUTSIDE their inner loops (tick2.hpp: the argument block is re-read per phase so that nothing is kept across the iteration
