@@ -251,7 +251,7 @@ __device__ __forceinline__ void model_step(const DevModel &dm, const Coef &c, fl
   }
 }
 
-// sum_k w_k (x_k - target_k)^2 over the four state dimensions, fp32 pairwise - sum4_pair's order: every Particle path agrees bit for bit
+// sum_k w_k (x_k - target_k)^2 over the four state dimensions - cost4_pair's sum: every Particle path agrees bit for bit
 __device__ __forceinline__ float particle_state_cost(const float *x, const float *target, const float *w) {
   const float d0 = x[0] - target[0], d1 = x[1] - target[1], d2 = x[2] - target[2], d3 = x[3] - target[3];
   return ((d0 * d0) * w[0] + (d1 * d1) * w[1]) + ((d2 * d2) * w[2] + (d3 * d3) * w[3]);
@@ -389,11 +389,18 @@ __device__ __forceinline__ v2f collision_pair(const DevModel &dm, const uint32_t
   c.y = (float)__builtin_amdgcn_ubfe(grid[ib >> 5], ib, 1u);
   return c;
 }
-// The state cost's four terms, fp32 pairwise ((t0 + t1) + (t2 + t3)): 3 packed adds for both samples.  (Until round 5 this was the
-// correctly rounded exact sum - 8 v_cvt_f64_f32 + 6 v_add_f64 + 2 v_cvt_f32_f64 per step pair, 16 of the ~100 VALU instructions of a
-// Particle step and the half-rate ones; the reference's own torch fp32 `.sum(-1)` is a sum of this class, and the result stays
-// within 2 ulp of the exact one: 1e-7 against the 1e-5 bound.)
-__device__ __forceinline__ v2f sum4_pair(const v2f t0, const v2f t1, const v2f t2, const v2f t3) { return (t0 + t1) + (t2 + t3); }
+// The state cost sum_k (d_k d_k) w_k of both samples: the reference's own fp32 products ((d * d) * w, each rounded - particle.py:180-181),
+// summed pairwise in fp32, ((t0 + t1) + (t2 + t3)): 8 packed multiplies + 3 packed adds per step pair.  (Until round 5 this was the
+// correctly rounded exact sum of the four products - 8 v_cvt_f64_f32 + 6 v_add_f64 + 2 v_cvt_f32_f64, 16 of the ~100 VALU instructions of
+// a Particle step pair and the half-rate ones.  The reference's torch fp32 `.sum(-1)` is a sum of this class; the result stays within
+// 2 ulp of the exact value: 1e-7 against the 1e-5 bound.  An FMA chain over the squares saves 3 more instructions and was tried: its
+// singly rounded terms differ from the reference's doubly rounded ones by an ulp often enough to move the softmax(-cost) of the Particle
+// goldens - costs of 6.5e5 at temperature 1, 6 % of a weight per ulp - so the terms stay the reference's.  particle_state_cost below
+// is the same sum for one sample: every Particle path agrees bit for bit.)
+__device__ __forceinline__ v2f cost4_pair(const v2f *d, const v2f *w) {
+  const v2f t0 = (d[0] * d[0]) * w[0], t1 = (d[1] * d[1]) * w[1], t2 = (d[2] * d[2]) * w[2], t3 = (d[3] * d[3]) * w[3];
+  return (t0 + t1) + (t2 + t3);
+}
 // Running sum over the time steps of both samples' step costs: Kahan-compensated in packed fp32 (4 v_pk ops per step pair instead of
 // 2 cvt + 2 v_add_f64): the total is the fp32 step costs' sum to ~1 ulp, as the double accumulator's rounded value was.
 struct PairKahan {
@@ -433,13 +440,10 @@ __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const Pair
                                                   v2f *coll_io = nullptr) {
   v2f coll = {0.f, 0.f};
   if (OBST) coll = coll_io ? *coll_io : collision_pair(dm, grid, x[0], x[1]);
-  v2f tk[4];
+  v2f dk[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const v2f d = x[k] - pk.target[k];
-    tk[k] = (d * d) * pk.w_state[k];
-  }
-  v2f cost = sum4_pair(tk[0], tk[1], tk[2], tk[3]) + cc;
+  for (int k = 0; k < 4; ++k) dk[k] = x[k] - pk.target[k];
+  v2f cost = cost4_pair(dk, pk.w_state) + cc;
   if (OBST) cost = cost + dm.w_obs * coll;  // (without obstacles the reference adds +0 to a non-negative sum: identity)
   const float dt = (float)dm.dt;
   const v2f av[2] = {{a0, a0}, {a1, a1}};

@@ -1898,7 +1898,6 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.nrm = c->far_n;
     f.lms = c->far_n + c->N;
     f.m0 = c->far_n + 2 * (size_t)c->N;
-    f.cand = reinterpret_cast<int *>(c->far_n + 3 * (size_t)c->N);
     {
       const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
       f.T = env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT;
@@ -1914,7 +1913,6 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.cps = std::max(1, (b.chunks + want - 1) / want);
     dim3 fgrid(gx, (b.chunks + f.cps - 1) / f.cps);
     const int nq = std::min(c->N - a.i0, tiles * fused_tq(a.D));
-    far_cand_kernel<<<(b.chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);
 #define DUST_LAUNCH_FAR(DPB)                                                                         \
   do {                                                                                               \
     far_lb_kernel<DPB><<<(nq + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);            \
@@ -2034,7 +2032,6 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     f.nrm = c->far_n;
     f.lms = c->far_n + c->N;
     f.m0 = c->far_n + 2 * (size_t)c->N;
-    f.cand = reinterpret_cast<int *>(c->far_n + 3 * (size_t)c->N);
     f.Xp = b.Z;  // the scaled rows: unit metric
     f.wP[0] = f.wP[1] = 1.0f;
     f.far = reinterpret_cast<unsigned char *>(c->far_g);
@@ -2050,12 +2047,12 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
   }
 #define DUST_LAUNCH_LOGPM(DPB)                                                                                                 \
   do {                                                                                                                          \
-    logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                       \
     if (flags) {                                                                                                                \
-      far_cand_kernel<<<(chunks + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                         \
+      logp_prep_far_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b, f);                                              \
       far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);        \
-      far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                                                      \
       far_flags_kernel<DPB, 64><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
+    } else {                                                                                                                    \
+      logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                     \
     }                                                                                                                           \
     pairwise_logp_mfma_kernel<DPB><<<grid, 256, pairwise_logp_mfma_lds_bytes<DPB>(), c->pair_stream>>>(b);                      \
   } while (0)

@@ -22,7 +22,7 @@
 // Rows the bound cannot speak for (non-finite coordinates or weights, |z| beyond binary16) get n = -inf and are never far.
 // m0_i is a lower bound of query i's final max logit, known before the pass: the largest of its OWN logit log w_i (the keys are
 // the particles: distance 0) and its exact logits against one candidate key per chunk - the chunk's heaviest particle
-// (far_cand_kernel / far_lb_kernel: N x chunks exact distances, 1 / 64 of the pass).  After the first tick the mixture weights are
+// (far_lb_kernel: N x chunks exact distances, 1 / 64 of the pass).  After the first tick the mixture weights are
 // softmax(-alpha cost) - close to one-hot - and a light query's max logit is its logit against a heavy FAR particle, hundreds above
 // its own: without the candidates no unit of such a query could be proven negligible.  Any reference <= the true max + O(ulp)
 // serves the softmax equally well, so every mode of the fused pass starts from m0 (tests: DUST_FAR_T=224 against DUST_FAR=0 and
@@ -31,6 +31,7 @@
 // (every unit stays, the pre-pass is ~3 % on top).  Time is data dependent, results are not.
 #pragma once
 #include "pairwise_fused.hpp"
+#include "pairwise_logp_mfma.hpp"
 
 namespace dust {
 
@@ -51,7 +52,6 @@ struct FarArgs {
   _Float16 *Z;          // [N][far_zh(DPB)] scaled, centred, zero-padded rows in binary16 (far_prep_kernel)
   float *nrm;           // [N] |z|^2 (1 - EB), or -inf: the row is never far
   float *lms;           // [N] log w (finite or -inf)
-  int *cand;            // [chunks] the heaviest particle of each key chunk (far_cand_kernel)
   const float *Xp;      // [N][DPB] zero-padded fp32 rows (the fused pass' own copy)
   float wP[2];          // the prior metric, 1 / sigma_p^2 for even / odd dimensions
   float *m0;            // [N] lower bound of the query's max prior logit (far_lb_kernel): the fused pass starts its running max there
@@ -64,11 +64,9 @@ struct FarArgs {
 // binary16 row length: whole K = 32 steps of v_mfma_f32_16x16x32_f16 (gfx950's full-rate shape: the 16x16x16 one runs at a quarter of it)
 static constexpr __host__ __device__ int far_zh(int dpb) { return ((dpb + 31) / 32) * 32; }
 
-// one wave per row
+// one wave per row (far_prep_kernel; the log-p pass runs it inside its own row kernel, logp_prep_far_kernel below)
 template <int DPB>
-__global__ __launch_bounds__(256) void far_prep_kernel(const FarArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= a.N) return;
+__device__ __forceinline__ void far_prep_row(const FarArgs &a, const int row, const int lane) {
   float acc = 0.f;
   bool ok = true;
   float v[(DPB + 63) / 64];
@@ -95,17 +93,10 @@ __global__ __launch_bounds__(256) void far_prep_kernel(const FarArgs a) {
     a.lms[row] = ok ? lm * a.lscale : 0.f;
   }
 }
-
-// one wave per key chunk: its heaviest particle (first of equals; a chunk of NaN / -inf weights: its first particle)
-__global__ __launch_bounds__(256) void far_cand_kernel(const FarArgs a) {
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (ch >= a.chunks) return;
-  const int j = ch * 64 + lane;
-  float v = j < a.N ? a.logmix[j] : -INFINITY;
-  v = v == v ? v : -INFINITY;
-  const float mx = wave_max(v);
-  const unsigned long long hit = __ballot(v == mx);
-  if (lane == 0) a.cand[ch] = min(ch * 64 + (hit ? (int)__builtin_ctzll(hit) : 0), a.N - 1);
+template <int DPB>
+__global__ __launch_bounds__(256) void far_prep_kernel(const FarArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row < a.N) far_prep_row<DPB>(a, row, lane);
 }
 
 // m0 (see the file comment): lane = query (row in registers), the 16 waves of the workgroup share the candidates (wave w takes
@@ -128,7 +119,17 @@ __global__ __launch_bounds__(64 * DUST_FAR_LB_WAVES) void far_lb_kernel(const Fa
   }
   float best = -INFINITY;
   for (int ci = wave; ci < a.chunks; ci += NW) {
-    const int c = __builtin_amdgcn_readfirstlane(a.cand[ci]);
+    // the candidate of chunk ci: its heaviest particle (first of equals; NaN weights count as -inf).  Every workgroup finds the
+    // candidates again - N log-weights out of L2 per workgroup, 1 % of its row traffic - instead of a launch of its own.
+    int c;
+    {
+      const int j = ci * 64 + lane;
+      float v = j < a.N ? a.logmix[j] : -INFINITY;
+      v = v == v ? v : -INFINITY;
+      const float mx = wave_max(v);
+      const unsigned long long hit = __ballot(v == mx);
+      c = min(ci * 64 + (hit ? (int)__builtin_ctzll(hit) : 0), a.N - 1);
+    }
     typedef const v2f __attribute__((address_space(4))) * cv2;
     const cv2 y = (cv2)(uintptr_t)(a.Xp + (size_t)c * DPB);
     v2f d2 = {0.f, 0.f};
@@ -150,6 +151,27 @@ __global__ __launch_bounds__(64 * DUST_FAR_LB_WAVES) void far_lb_kernel(const Fa
     for (int w = 0; w < NW; ++w) m = fmaxf(m, red[w][lane]);
     a.m0[qi] = m;
   }
+}
+
+// the log-p pass' row kernel and the far pre-pass' in one launch (one wave per row)
+template <int DPB>
+__global__ __launch_bounds__(256) void logp_prep_far_kernel(const LogpMfmaArgs b, const FarArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= b.N) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = lane; c < DPB; c += 64) {
+    float v = 0.f;
+    if (c < b.D) v = (b.X[(size_t)row * b.D + c] - b.X[c]) * b.sw[c & 1];
+    b.Z[(size_t)row * DPB + c] = v;
+    acc = fmaf(v, v, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    b.hq[row] = -0.5f * acc;
+    b.hj[row] = b.logmix[row] * 1.44269504088896340736f - 0.5f * acc;
+  }
+  far_prep_row<DPB>(a, row, lane);
 }
 
 template <int DPB>

@@ -418,6 +418,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         auto pair_loop = [&](auto obst, auto crash) {
           constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
           put_pair(0);
+#pragma unroll 2  // (two steps per trip: the loop-carried register copies of a single-step body - 4 v_mov of 86 instructions - go away)
           for (int t = 0; t < H; ++t) {
             const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
             const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
