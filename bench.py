@@ -59,6 +59,22 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s mea
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2  # 1024 SIMD-32 units, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
+def far_shares(ctx):
+    """Share of the pairwise units the last tick's two large-set passes left out (dust_debug_far_units / dust_debug_far_logp: debug
+    entries of the library, not part of include/dust_amd.h); None where a pass ran without the pre-pass."""
+    import ctypes as C
+    from dust_amd import _lib as L
+    lib = L.load()
+    out = {}
+    for key, fn in (("fused_prior_stein_pass", "dust_debug_far_units"), ("log_p_pass", "dust_debug_far_logp")):
+        f = getattr(lib, fn)
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        f.restype = C.c_int
+        v = (C.c_longlong * 2)()
+        out[key] = (v[0] / v[1]) if (f(ctx._h, v) == 0 and v[1]) else None
+    return out
+
+
 def synth(N, H, da, seed=0, spread=2.0):
     rng = np.random.default_rng(seed)
     mu = rng.standard_normal((N, H, da)).astype(np.float32)
@@ -451,10 +467,33 @@ def main():
             one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
         one.sync()
         e4 = time.perf_counter() - t1
+        far4 = far_shares(one)
         one.close()
+        # the same ticks with every (query tile, key chunk) unit of the pairwise passes visited (DUST_FAR=0: pairwise_far.hpp off) -
+        # what a particle set WITHOUT far pairs costs (the pre-pass then finds nothing to leave out)
+        os.environ["DUST_FAR"] = "0"
+        try:
+            allv = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
+                           uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
+        finally:
+            os.environ.pop("DUST_FAR", None)
+        allv.set_theta(theta4); allv.set_prior(mu4); allv.set_a_mat(theta4)
+        for _ in range(8):
+            allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+        allv.sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+        allv.sync()
+        e4a = (time.perf_counter() - t1) / 10
+        allv.close()
         extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
                                        n_gpus=1, ticks_per_s=n4 / e4, ms_per_tick=1e3 * e4 / n4, comm_us_per_tick=0.0, ticks=n4,
-                                       warmup_ticks_run=n4w)
+                                       warmup_ticks_run=n4w, pairwise_units_left_out=far4, ms_per_tick_all_units_visited=1e3 * e4a,
+                                       note="pairwise_units_left_out: share of the (query tile, key chunk) units of the fused prior / Stein "
+                                            "pass and of the log-p pass whose every term is below 2^-43 of its sum's leading term "
+                                            "(pairwise_far.hpp: a binary16 MFMA bound decides, the result moves by < half an ulp of that "
+                                            "term). DATA DEPENDENT: a clustered set has no such unit and runs at ms_per_tick_all_units_visited")
     else:
         c4 = CFG4
         mu, theta = synth(c4["N"], c4["H"], 2, spread=1.0)
@@ -470,7 +509,7 @@ def main():
         comm_us = sh.ctx.comm_probe(c4["n_iters"], 50) if sh.c_side else None  # the tick's all-gathers alone (collective: every rank)
         extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
                                        n_gpus=n_gpus, ticks_per_s=args.steps / el, ms_per_tick=1e3 * el / args.steps, comm_us_per_tick=comm_us,
-                                       ticks=args.steps, warmup_ticks_run=n_warm)
+                                       ticks=args.steps, warmup_ticks_run=n_warm, pairwise_units_left_out=far_shares(sh.ctx))
         workload = ("Particle N=%d total (%d per GPU), S=64, M=4, H=40, 1 SVGD iter, K1 kernel, SGD, device Philox noise inside the tick"
                     % (c4["N"], c4["N"] // n_gpus))
         par = "particles sharded x%d (strong scaling), in-place RCCL all-gathers of score and theta per SVGD iteration" % n_gpus

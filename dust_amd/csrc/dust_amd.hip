@@ -118,6 +118,12 @@ struct dust_ctx {
   float *far_z, *far_n, *far_f;  // pairwise_far.hpp: binary16 rows, (norms, log weights), unit flags [tiles][chunks] bytes
   size_t far_z_cap, far_n_cap, far_f_cap;
   int far_tiles, far_chunks;  // geometry of the flags the last fused pass used (0: none)
+  float *far_q;               // per-unit near-query masks of the fused pass [tiles][chunks][4] words
+  size_t far_q_cap;
+  size_t far_cnt_cap;
+  float *far_cnt;             // [4] device counters {far, all} of the fused pass' and the log-p pass' last pre-pass
+  unsigned int *far_cnt_host; // pinned copy (arrives a tick late at worst: it only steers whether the NEXT pre-pass is worth its launches)
+  int far_logp_skip;          // log-p pre-pass: launches left to skip before the next probe
   float *far_g;               // the flags of the last log-p pass [groups][chunks] bytes
   size_t far_g_cap;
   int far_groups, far_gchunks;
@@ -208,6 +214,10 @@ struct dust_ctx {
   // hipGraph replay of a whole tick (dust_svmpc_tick)
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
+  hipGraph_t graph_alt;          // the tick's OTHER captured variant (log-p pre-pass on / off: logp_far_decide), swapped in when the decision flips
+  hipGraphExec_t graph_exec_alt;
+  int graph_far;                 // the active capture's variant
+  bool logp_far_on, logp_far_decided;  // this tick's decision (taken once per tick on the host: a capture freezes what it saw)
   int graph_steps;
   const void *graph_eps;
   int graph_seen;     // consecutive eager ticks with the same shape (capture on the 2nd)
@@ -379,11 +389,13 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->graph_exec_alt) (void)hipGraphExecDestroy(c->graph_exec_alt);
+  if (c->graph_alt) (void)hipGraphDestroy(c->graph_alt);
   if (c->ctr_dev) (void)hipFree(c->ctr_dev);
   if (c->fused_cnt) (void)hipFree(c->fused_cnt);
   if (c->stein_cnt) (void)hipFree(c->stein_cnt);
@@ -396,6 +408,7 @@ static void free_all(dust_ctx *c) {
   if (c->t2_lwq) (void)hipFree(c->t2_lwq);
   if (c->tick1_start) (void)hipFree(c->tick1_start);
   if (c->out_pinned) (void)hipHostFree(c->out_pinned);
+  if (c->far_cnt_host) (void)hipHostFree(c->far_cnt_host);
   if (c->istar) (void)hipFree(c->istar);
   if (c->grid_bits) (void)hipFree(c->grid_bits);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -691,7 +704,7 @@ static void t2_queue_push(dust_ctx *c, const float *state4, int steps, bool fwd,
 static void handoff_ban(dust_ctx *c) {
   c->handoff_banned = true;
   c->persist_declined = 0;
-  if (c->graph_exec) graph_drop(c);  // (a captured tick replays the fused launches)
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);  // (a captured tick replays the fused launches)
 }
 // A wait of the owner-computes kernel gave up: clear the report, take the context off the spinning kernels, and tell whether the tick
 // is whole - committed by every workgroup or by none (tick2.hpp t2_commit; a tick nobody committed is replayed by t2_settle).
@@ -775,7 +788,7 @@ extern "C" int dust_set_stream(dust_ctx *c, void *s) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->t2_inflight) TRY(dust_sync(c));  // (settle one-launch ticks on the stream they were enqueued on, replays included)
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->own_stream) HIP_TRY(hipStreamDestroy(c->stream));
   c->stream = (hipStream_t)s;
@@ -852,7 +865,7 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
 extern "C" int dust_set_model_param(dust_ctx *c, const char *name, double value, int kind) {
   if (!c || !name) return fail(DUST_ERR_INVALID, "null argument");
   TRY(settle_pending(c));  // (a one-launch tick that did not start is replayed with the dynamics it was enqueued with)
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   dust_param *p = nullptr;
   if (!strcmp(name, "g")) p = &c->cfg.g;
   else if (!strcmp(name, "mass")) p = &c->cfg.mass;
@@ -868,7 +881,7 @@ extern "C" int dust_set_param_weights(dust_ctx *c, const float *w) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(settle_pending(c));  // (... and with the weights it was enqueued with)
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   if (!w) {
     if (c->mw_dev) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -887,7 +900,7 @@ extern "C" int dust_set_ctrl_noise(dust_ctx *c, const float *z, int n_sets) {
   if (c->cfg.model != DUST_MODEL_PARTICLE || !c->cfg.ctrl_noise)
     return fail(DUST_ERR_STATE, "control noise belongs to a Particle(deterministic=False) context (dust_config.ctrl_noise)");
   TRY(settle_pending(c));
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   c->cz_sets = c->cz_next = 0;
   if (!z || n_sets <= 0) return DUST_OK;
   HIP_TRY(hipSetDevice(c->cfg.device));
@@ -901,7 +914,7 @@ extern "C" int dust_set_ctrl_noise(dust_ctx *c, const float *z, int n_sets) {
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
   std::vector<uint32_t> bits(words, 0u);
   for (size_t i = 0; i < cells; ++i) {
@@ -951,7 +964,7 @@ extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum
   if (bandwidth < 0.f) {  // the median trick, clamped at minimum_bw (base_kernels.py:83-89)
     c->k2_fixed_h = 0.f;
     c->k2_min_bw = minimum_bw;
-    if (c->graph_exec) graph_drop(c);
+    if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
     return DUST_OK;
   }
   double h = (double)bandwidth * (double)bandwidth;
@@ -960,7 +973,7 @@ extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum
   if (h < (double)minimum_bw) h = (double)minimum_bw;
   c->k2_fixed_h = (float)h;
   if (!(c->k2_fixed_h > 0.f)) return fail(DUST_ERR_INVALID, "bandwidth and minimum_bw give h = 0");
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   return DUST_OK;
 }
 
@@ -970,7 +983,7 @@ extern "C" int dust_get_theta(dust_ctx *c, float *theta) {
 }
 extern "C" int dust_set_prior(dust_ctx *c, const float *means, const float *w) {
   if (!c || !means) return fail(DUST_ERR_INVALID, "null argument");
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   HIP_TRY(hipSetDevice(c->cfg.device));
   TRY(h2d(c, c->mu, means, (size_t)c->N * c->D * sizeof(float)));
   c->mu_aliased = false;
@@ -1908,6 +1921,10 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.far = reinterpret_cast<unsigned char *>(c->far_f);
     f.nz = b.nz;
     f.ldnz = b.ldnz;
+    if (flags) {
+      TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 4));
+      f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
+    }
     const int gx = (tiles + 3) / 4;
     const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
     f.cps = std::max(1, (b.chunks + want - 1) / want);
@@ -1929,6 +1946,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     b.m0 = f.m0;
     if (flags) {
       b.far = f.far;
+      b.qmask = f.qmask;
       c->far_tiles = tiles;
       c->far_chunks = b.chunks;
     }
@@ -1974,6 +1992,29 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
+// Is the log-p pass' far pre-pass (pairwise_far.hpp) worth its launches (~100 us at N = 16384)?  Only while it leaves most blocks out: a
+// set with near-duplicates scattered through it (cfg4 after ~30 ticks) has a near pair in nearly every 64 x 64 block.  The pre-pass
+// counts its far blocks on the device; the two words come back through pinned memory behind it, unsynchronised - the host reads them
+// at the NEXT decision, a tick late at worst - and a pre-pass that found under 30 % is followed by 15 log-p passes without one, then
+// probed again.  One decision per log-p pass; a graph-replayed tick takes it at its entry (dust_svmpc_tick keeps one capture per
+// variant).  DUST_FAR=2: always on.
+static bool logp_far_decide(dust_ctx *c) {
+  if (c->env.far == 0 || c->env.dense >= 0) return false;
+  if (c->env.far >= 2 || !c->far_cnt_host) return true;
+  if (c->far_logp_skip > 0) {
+    --c->far_logp_skip;
+    return false;
+  }
+  volatile unsigned int *hc = c->far_cnt_host;
+  const unsigned int fa = hc[2], al = hc[3];
+  if (al && (double)fa < 0.3 * (double)al) {
+    hc[3] = 0u;  // consumed: the next probe's result decides again
+    c->far_logp_skip = 15;
+    return false;
+  }
+  return true;
+}
+
 // log p(theta) only, large aliased sets (SVMPC.forward): product-form distances on the matrix cores + log-sum-exp
 // (pairwise_logp_mfma.hpp).  DUST_LOGP_MFMA=0 keeps the exact-difference pass of pairwise_fused.hpp (development switch).
 static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
@@ -2005,7 +2046,15 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
   dim3 grid(tiles, b.JS);
   // pairwise_far.hpp: (64-query group, key chunk) blocks whose terms are all negligible against the group's known max logits
   // (DUST_FAR=0 / DUST_DENSE=1: visit all).  Base-2 logits here: log weights and the threshold scaled by log2 e.
-  const bool flags = c->env.far != 0 && c->env.dense < 0;
+  bool flags = c->env.far != 0 && c->env.dense < 0;
+  if (flags) {
+    if (!c->far_cnt_host && !c->capturing) {
+      HIP_TRY(hipHostMalloc((void **)&c->far_cnt_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
+      memset(c->far_cnt_host, 0, 4 * sizeof(unsigned int));
+      TRY(ensure(&c->far_cnt, &c->far_cnt_cap, 8));
+    }
+    flags = c->logp_far_decided ? c->logp_far_on : logp_far_decide(c);
+  }
   FarArgs f;
   memset(&f, 0, sizeof f);
   c->far_groups = c->far_gchunks = 0;
@@ -2039,6 +2088,10 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
     f.cps = std::max(1, (chunks + want - 1) / want);
     fgrid = dim3(gx, (chunks + f.cps - 1) / f.cps);
+    if (c->far_cnt_host) {
+      f.count = reinterpret_cast<unsigned int *>(c->far_cnt) + 4;
+      f.host_count = c->far_cnt_host + 2;
+    }
     b.far = f.far;
     b.groups = f.tiles;
     b.chunks = chunks;
@@ -2063,6 +2116,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
   else DUST_LAUNCH_LOGPM(80);
 #undef DUST_LAUNCH_LOGPM
   HIP_TRY(hipGetLastError());
+
   return DUST_OK;
 }
 
@@ -2887,7 +2941,7 @@ extern "C" int dust_svmpc_roll(dust_ctx *c, int steps, int strategy, const float
   if (strategy < DUST_ROLL_REPEAT || strategy > DUST_ROLL_RESAMPLE) return fail(DUST_ERR_INVALID, "%d is an invalid roll strategy.", strategy);
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the roll is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   const float *lr = nullptr;
   if (strategy == DUST_ROLL_RESAMPLE) {
     if (!last_row) return fail(DUST_ERR_INVALID, "strategy 'resample' needs last_row [N][da]");
@@ -2914,7 +2968,7 @@ extern "C" int dust_svmpc_update_prior(dust_ctx *c, const float *weights) {
   TRY(settle_pending(c));
   if (c->nloc != c->N) return fail(DUST_ERR_STATE, "sharded context: the prior refresh is part of the sharded forward");
   HIP_TRY(hipSetDevice(c->cfg.device));
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   std::vector<float> w((size_t)c->N, 1.0f);
   if (weights && c->cfg.weighted_prior) {  // svmpc.py:162-165: mix = ones unless weighted_prior
     for (int i = 0; i < c->N; ++i) {
@@ -2955,7 +3009,7 @@ extern "C" int dust_svmpc_forward_ex(dust_ctx *c, int steps, const float *resamp
     }
   }
   TRY(settle_pending(c));  // (plain kernels from here on)
-  if (steps != -1 && c->graph_exec) graph_drop(c);
+  if (steps != -1 && (c->graph_exec || c->graph_exec_alt)) graph_drop(c);
   const float *lr = nullptr;
   TRY(resample_rows(c, resample_last_row, &lr));
   TRY(forward_device(c));
@@ -3472,7 +3526,7 @@ extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) 
     c->theta_alt = c->theta;
     c->theta = c->theta_home;
   }
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   c->theta_pinned = true;
   return DUST_OK;
 }
@@ -3748,7 +3802,7 @@ extern "C" int dust_set_skid_steer(dust_ctx *c, const dust_skid_config *g) {
     c->skid.w_state[k] = g->w_state[k];
     c->skid.w_term[k] = g->w_term[k];
   }
-  if (c->graph_exec) graph_drop(c);  // (the captured kernel arguments hold the old model)
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);  // (the captured kernel arguments hold the old model)
   return DUST_OK;
 }
 
@@ -3764,8 +3818,12 @@ extern "C" int dust_tick_stats(dust_ctx *c, long long out[4]) {
 static void graph_drop(dust_ctx *c) {
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->graph_exec_alt) (void)hipGraphExecDestroy(c->graph_exec_alt);
+  if (c->graph_alt) (void)hipGraphDestroy(c->graph_alt);
   c->graph_exec = nullptr;
   c->graph = nullptr;
+  c->graph_exec_alt = nullptr;
+  c->graph_alt = nullptr;
   c->graph_seen = 0;
 }
 
@@ -3956,13 +4014,26 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
   const bool tenants = c->cfg.device >= 0 && c->cfg.device < DUST_MAX_DEV && g_live_ctx[c->cfg.device].load() >= 2;
   const bool graphable = !no_graph && !c->prof && c->nloc == c->N && n_steps > 0 && (eps == nullptr || (flags & DUST_PTR_DEVICE)) &&
                          c->mu_aliased && c->own_stream && !tenants && c->cz_next >= c->cz_sets /* no recorded control noise pending */;
+  struct FarTick {  // this tick's log-p pre-pass decision, taken once (see logp_far_decide)
+    dust_ctx *c;
+    ~FarTick() { c->logp_far_decided = false; }
+  } far_tick{c};
+  if (graphable) {
+    c->logp_far_on = logp_far_decide(c);
+    c->logp_far_decided = true;
+  }
   if (!graphable || c->graph_steps != n_steps || c->graph_eps != (const void *)eps || c->graph_flags != flags ||
-      (c->graph_exec && c->graph_theta != c->theta)) {
-    if (c->graph_exec) graph_drop(c);
+      ((c->graph_exec || c->graph_exec_alt) && c->graph_theta != c->theta)) {
+    if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
     c->graph_steps = n_steps;
     c->graph_eps = (const void *)eps;
     c->graph_flags = flags;
     c->graph_seen = 0;
+  }
+  if (graphable && (c->graph_exec || c->graph_exec_alt) && c->graph_far != (int)c->logp_far_on) {  // the other variant: swap it in (or capture it below)
+    std::swap(c->graph, c->graph_alt);
+    std::swap(c->graph_exec, c->graph_exec_alt);
+    c->graph_far = (int)c->logp_far_on;
   }
   if (graphable && c->graph_exec) {
     if (n_steps < 0) return fail(DUST_ERR_INVALID, "n_steps < 0");
@@ -3977,6 +4048,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     TRY(upload_state_params(c, state, params, n_steps));
     c->capturing = true;
     c->graph_theta = c->theta;
+    c->graph_far = (int)c->logp_far_on;
     hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
     int st = DUST_OK;
     if (e == hipSuccess) {
@@ -4069,7 +4141,7 @@ extern "C" int dust_gather_buffers(dust_ctx *c, void **theta_all, void **score_a
     c->theta_alt = c->theta;
     c->theta = c->theta_home;
   }
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   c->theta_pinned = true;
   if (theta_all) *theta_all = c->theta;
   if (score_all) *score_all = c->score;
@@ -4139,7 +4211,7 @@ extern "C" int dust_svmpc_forward_finish(dust_ctx *c, float *a_seq, float *p_wei
 extern "C" int dust_profile_enable(dust_ctx *c, int on) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
-  if (c->graph_exec) graph_drop(c);
+  if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   c->prof = on != 0;
   return DUST_OK;
 }

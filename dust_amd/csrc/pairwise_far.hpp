@@ -59,6 +59,11 @@ struct FarArgs {
   unsigned char *nz;    // the Gram-block flags of pairwise_fused.hpp: zeroed here for far units (the fused pass never visits them)
   int ldnz;
   float T;              // the threshold on G (DUST_FAR_T_DEFAULT; development switch DUST_FAR_T)
+  unsigned int *qmask;  // [tiles][chunks][4] per unit: bit q = query q of the tile has a NEAR key in the chunk (the fused pass computes
+                        // exact distances for those queries only), or nullptr
+  unsigned int *count;  // [3] {far units, all units, workgroups done} of this launch (zeroed by the row kernel), or nullptr
+  unsigned int *host_count;  // [2] pinned host words the LAST workgroup of far_flags_kernel copies {far, all} to (no copy node, no
+                             // synchronisation: the host reads them whenever it next decides - dust_amd.hip logp_far_decide)
 };
 
 // binary16 row length: whole K = 32 steps of v_mfma_f32_16x16x32_f16 (gfx950's full-rate shape: the 16x16x16 one runs at a quarter of it)
@@ -91,6 +96,7 @@ __device__ __forceinline__ void far_prep_row(const FarArgs &a, const int row, co
   if (lane == 0) {
     a.nrm[row] = ok ? acc * (1.0f - DUST_FAR_EB) : -INFINITY;
     a.lms[row] = ok ? lm * a.lscale : 0.f;
+    if (row == 0 && a.count) a.count[0] = a.count[1] = a.count[2] = 0u;  // (far_flags_kernel, the next launch of the stream, counts into them)
   }
 }
 template <int DPB>
@@ -195,7 +201,27 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
   const bool live = tile < a.tiles;  // (a wave behind the last tile still stages keys)
   const int tq = live ? tile : a.tiles - 1;
   const int c_beg = blockIdx.y * a.cps, c_end = min(a.chunks, c_beg + a.cps);
-  if (c_beg >= c_end) return;
+  unsigned int n_far = 0u, n_all = 0u;  // wave-uniform
+  auto finish = [&]() {  // the last workgroup to get here hands the launch's counts to the host
+    if (!a.count || !a.host_count) return;
+    if (lane == 0 && n_all) {
+      atomicAdd(a.count, n_far);
+      atomicAdd(a.count + 1, n_all);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(a.count + 2, 1u) == gridDim.x * gridDim.y - 1u) {
+        const unsigned int fa = atomicAdd(a.count, 0u), al = atomicAdd(a.count + 1, 0u);
+        __hip_atomic_store(a.host_count, fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.host_count + 1, al, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  };
+  if (c_beg >= c_end) {
+    finish();
+    return;
+  }
 
   v8h bq[QT][NP];
   float hq[QT];
@@ -282,7 +308,26 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) ok = ok && (mt[t] + hq[t] > 0.f);
     const bool is_far = __ballot(!ok) == 0ull;  // wave-uniform
+    if (a.qmask) {
+      // per query: the smallest margin over the chunk's 64 keys sits in the four lanes r16, r16 + 16, + 32, + 48
+      unsigned int qm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float v = mt[t] + hq[t];
+        v = fminf(v, __shfl_xor(v, 16));
+        v = fminf(v, __shfl_xor(v, 32));
+        const unsigned int b16 = (unsigned int)(__ballot(!(v > 0.f)) & 0xffffull);  // lanes 0 .. 15: queries 16 t + r16
+        qm[t >> 1] |= b16 << (16 * (t & 1));
+      }
+      if (live && lane == 0) {
+        unsigned int *dst = a.qmask + ((size_t)tile * a.chunks + ch) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = qm[k];
+      }
+    }
     if (live) {
+      n_far += is_far ? 1u : 0u;  // (one atomic per wave at the end: 65 536 units adding to one word took 1.4 ms)
+      n_all += 1u;
       if (lane == 0) a.far[(size_t)tile * a.chunks + ch] = is_far ? 1 : 0;
       if (is_far && a.nz)
         for (int i = lane; i < TQ; i += 64) a.nz[(size_t)ch * a.ldnz + tile * TQ + i] = 0;
@@ -290,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
     if (more) keys_commit(buf ^ 1);
     wg_sync();
   }
+  finish();
 }
 
 }  // namespace dust

@@ -38,6 +38,7 @@ struct PairFusedArgs {
   unsigned char *nz;  // [chunks][ldnz] 1 = the 64 Stein kernel values of (key chunk, query row) are not all exactly 0 (see below); ldnz >= rows, multiple of 64
   int ldnz;
   const unsigned char *far;  // [tiles][chunks] 1 = the unit contributes exactly nothing and is not visited (pairwise_far.hpp), or nullptr
+  const unsigned int *qmask;  // [tiles][chunks][4] bit q = query q of the tile has a near key in the chunk (pairwise_far.hpp), or nullptr: all
   const float *m0;           // [N] where each query's running max starts (pairwise_far.hpp: a lower bound of its final max), or nullptr: -inf
 };
 
@@ -85,7 +86,7 @@ struct FusedGeom {
 template <int DPB>
 static inline size_t pairwise_fused_lds_bytes() {
   using G = FusedGeom<DPB>;
-  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 3 * (size_t)G::TQ + 4);
+  return sizeof(float) * ((size_t)PAIR_JC * G::YS + 2 * (size_t)G::TQ * G::KS + 3 * (size_t)G::TQ + 8);
 }
 
 #ifndef DUST_FUSED_WGS
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
   float *scl = mrow + TQ;           // [TQ] rescale factor of this chunk
   float *lrow = scl + TQ;           // [TQ] running sum of the softmax terms (relative to mrow)
   unsigned int *wany = reinterpret_cast<unsigned int *>(lrow + TQ);  // [4] per wave: some Stein kernel value of this chunk is non-zero
+  unsigned int *pany = wany + 4;                                     // [4] per wave: some softmax term of this chunk is non-zero
   const int tid = threadIdx.x, D = a.D, N = a.N;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), jA = tid & 63;
   const int qg = tid / LCG, cg = tid - qg * LCG, c0 = CB * cg;  // pass-B ownership: queries qg + QS r, columns c0 .. c0 + CB - 1
@@ -211,8 +213,31 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
       }
       const bool kval = jA < jc;
       bool wave_any = (MODE != PAIR_K1) || b.nz == nullptr;
-      for (int qi = 0; qi < QW; qi += 2) {
-        const int i = wave * QW + qi;  // wave-uniform
+      // the wave's queries with a NEAR key in this chunk (pairwise_far.hpp: bit q of the unit's mask; without the pre-pass: all).
+      // The others have no term here at all: logit -inf, kernel value 0, Gram row not stored (flag 0: gram_score_kernel masks it).
+      static_assert(QW <= 32, "query mask of a wave");
+      constexpr unsigned int QALL = QW == 32 ? 0xffffffffu : ((1u << QW) - 1u);
+      unsigned int near = QALL;
+      if (b.qmask) {
+        typedef const unsigned int __attribute__((address_space(4))) * cu32;  // (written by an earlier launch: scalar loads)
+        const cu32 qm = (cu32)(uintptr_t)(b.qmask + ((size_t)tile * b.chunks + ci) * 4);
+        const unsigned long long lo = (unsigned long long)qm[0] | ((unsigned long long)qm[1] << 32);
+        const unsigned long long hi = (unsigned long long)qm[2] | ((unsigned long long)qm[3] << 32);
+        const int sft = wave * QW;
+        const unsigned long long sel = sft < 64 ? ((lo >> sft) | (sft ? hi << (64 - sft) : 0ull)) : (hi >> (sft - 64));
+        near &= (unsigned int)sel;
+      }
+      for (unsigned int fq = QALL & ~near; fq; fq &= fq - 1u) {
+        const int i = wave * QW + (int)__builtin_ctz(fq);
+        kv[i * KS + jA] = v2f{-INFINITY, 0.f};
+        if (b.nz && jA == 0) b.nz[(size_t)(j0 >> 6) * b.ldnz + tile * TQ + i] = 0;
+      }
+      while (near) {  // two near queries per trip (an odd one out runs twice: the same values stored twice)
+        const int qa = (int)__builtin_ctz(near);
+        near &= near - 1u;
+        const int qb = near ? (int)__builtin_ctz(near) : qa;
+        near &= near - 1u;
+        const int i = wave * QW + qa, i2 = wave * QW + qb;  // wave-uniform
         // uniform addresses -> scalar loads.  The kernel also STORES to global memory inside this loop (the Gram rows), so a plain
         // load of Xp counts as clobberable and would become a per-lane vector load; the padded query copy is never written by
         // this kernel: address it through the constant address space, whose loads are invariant by definition.  (Scalar loads
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         // batch lands under the previous one's FMAs changed nothing - the second wave of the SIMD already covers the latency.)
         typedef const v2f __attribute__((address_space(4))) * cv2;
         const cv2 xa = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i, N - 1) * DPB);
-        const cv2 xb = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i + 1, N - 1) * DPB);
+        const cv2 xb = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i2, N - 1) * DPB);
         v2f da2 = {0.f, 0.f}, db2 = {0.f, 0.f};
 #pragma unroll
         for (int s0 = 0; s0 < DPB / 2; s0 += 16) {
@@ -255,13 +280,13 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         ka = kval ? ka : 0.f;
         kb = kval ? kb : 0.f;
         kv[i * KS + jA] = v2f{kval ? lm - 0.5f * pa : -INFINITY, ka};
-        kv[(i + 1) * KS + jA] = v2f{kval ? lm - 0.5f * pbq : -INFINITY, kb};
+        kv[i2 * KS + jA] = v2f{kval ? lm - 0.5f * pbq : -INFINITY, kb};
         // Gram matrix rows for pass 2: one 256-byte run per query and wave, streamed past the caches when pass 2 will read them
         // from HBM anyway (a 1 GB matrix at N = 16384: -7 % on this kernel).  Unconditional - no exec-mask branches inside the
         // distance loop (-6 %): K holds gridDim.x * TQ rows of ldK >= 64 ceil(N / 64) floats, so the rows behind n_local and the
         // columns behind N exist (the latter receive 0)
-        const int il = tile * TQ + i;
-        float *ka_p = &b.K[(size_t)il * b.ldK + j0 + jA], *kb_p = ka_p + b.ldK;
+        const int il = tile * TQ + i, il2 = tile * TQ + i2;
+        float *ka_p = &b.K[(size_t)il * b.ldK + j0 + jA], *kb_p = &b.K[(size_t)il2 * b.ldK + j0 + jA];
         // exact zeros (see PairFusedArgs): a row of 64 zero kernel values is flagged
         bool anya = true, anyb = true;
         if (MODE == PAIR_K1 && b.nz) {
@@ -270,9 +295,9 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
           wave_any = wave_any || anya || anyb;
         }
         if (b.nz && jA == 0) {
-          unsigned char *fz = b.nz + (size_t)(j0 >> 6) * b.ldnz + il;  // (QW is even: the two rows are adjacent bytes of one chunk row)
-          fz[0] = anya ? 1 : 0;
-          fz[1] = anyb ? 1 : 0;
+          unsigned char *fz = b.nz + (size_t)(j0 >> 6) * b.ldnz;
+          fz[il] = anya ? 1 : 0;
+          fz[il2] = anyb ? 1 : 0;
         }
         if (STREAM_K) {
           __builtin_nontemporal_store(ka, ka_p);
@@ -288,6 +313,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
     {
       // online softmax over key chunks: LQ consecutive lanes per query (DPP max, bare v_exp_f32 as in the 32 x 64 kernel)
       const int q = tid / LQ, l = tid - q * LQ;
+      bool psome = false;
       if (q < TQ) {
         float m = -INFINITY;
 #pragma unroll
@@ -305,12 +331,17 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
           sum += e;
         }
         sum = LQ == 8 ? oct_sum(sum) : (LQ == 4 ? quad_sum(sum) : pair_sum(sum));  // the chunk's mass of this query
+        psome = sum != 0.f || b.nz == nullptr;  // (DUST_DENSE: everything is evaluated)
         if (l == 0) {  // the LQ lanes of a query run in lockstep: all have read mrow[q] by now
           const float sc = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mo - mn) * 1.44269504088896340736f);
           mrow[q] = mn;
           scl[q] = sc;
           lrow[q] = lrow[q] * sc + sum;
         }
+      }
+      {
+        const bool wsome = __ballot(psome) != 0ull;
+        if (jA == 0) pany[wave] = wsome ? 1u : 0u;
       }
       wg_sync();
 #pragma unroll
@@ -325,9 +356,12 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
     if (more) keys_issue(cn * JC);  // in flight during pass B
     // ---- pass B: lane = 4 queries x CB columns; the difference y_j - x_i feeds the prior sum and the repulsion sum ----
     // (a chunk whose Stein kernel values are zero for the whole tile runs without the repulsion FMAs: they would add exact zeros)
+    // (and a chunk whose softmax terms are zero for the whole tile - after the first tick the mixture weights are one-hot: every
+    //  chunk but the heavy particle's - runs without the prior FMAs)
     const bool tile_any = (wany[0] | wany[1] | wany[2] | wany[3]) != 0u;
-    auto pass_b = [&](auto with_k) {
-      constexpr bool WK = decltype(with_k)::value;
+    const bool tile_pany = (pany[0] | pany[1] | pany[2] | pany[3]) != 0u;
+    auto pass_b = [&](auto with_p, auto with_k) {
+      constexpr bool WP = decltype(with_p)::value, WK = decltype(with_k)::value;
 #pragma unroll 2
       for (int jj = 0; jj < JC; ++jj) {
         v4f yv[NV];
@@ -342,15 +376,16 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
 #pragma unroll
           for (int u = 0; u < NV; ++u) {
             const v4f diff = yv[u] + xB[r][u];  // y_j - x_i
-            accA[r][u] = __builtin_elementwise_fma(v4f{wp, wp, wp, wp}, diff, accA[r][u]);
+            if (WP) accA[r][u] = __builtin_elementwise_fma(v4f{wp, wp, wp, wp}, diff, accA[r][u]);
             if (WK) accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
           }
         }
       }
     };
     if (pb) {
-      if (tile_any) pass_b(std::true_type{});
-      else pass_b(std::false_type{});
+      if (tile_pany && tile_any) pass_b(std::true_type{}, std::true_type{});
+      else if (tile_pany) pass_b(std::true_type{}, std::false_type{});
+      else if (tile_any) pass_b(std::false_type{}, std::true_type{});
     }
     wg_sync();  // pass B is done with Ys / kv
     if (more) keys_commit(cn * JC);

@@ -1,5 +1,6 @@
 """pairwise_far.hpp on the cfg4 workload of bench.py: per tick, the time and the share of (query tile, key chunk) units the
-pre-pass proves to be exact zeros - with the pre-pass (default) and without it (DUST_FAR=0).  python tools/far_probe.py [ticks]"""
+pre-pass proves to be exact zeros - with the pre-pass (default) and without it (DUST_FAR=0; DUST_PROBE_ONLY=1 / 0 runs one of the two).
+python tools/far_probe.py [ticks]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +12,7 @@ lib.dust_debug_far_units.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 lib.dust_debug_far_logp.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 n_ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 c4 = bench.CFG4
-for far in ("1", "0"):
+for far in ((os.environ["DUST_PROBE_ONLY"],) if os.environ.get("DUST_PROBE_ONLY") else ("1", "0")):
     os.environ["DUST_FAR"] = far
     mu4, theta4 = bench.synth(c4["N"], c4["H"], 2, spread=1.0)
     one = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
