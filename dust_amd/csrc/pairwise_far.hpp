@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * DUST_FAR_LB_WAVES) void far_lb_kernel(const Fa
     best = lg > best ? lg : best;  // (NaN: not taken)
   }
   red[wave][lane] = best;
-  __syncthreads();
+  wg_sync();
   if (wave == 0 && qi < q_end) {
     float m = a.logmix[qi] * a.lscale;  // the query's own logit
     m = m == m ? m : -INFINITY;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
       atomicAdd(a.count, n_far);
       atomicAdd(a.count + 1, n_all);
     }
-    __syncthreads();
+    wg_sync();
     if (tid == 0) {
       __threadfence();
       if (atomicAdd(a.count + 2, 1u) == gridDim.x * gridDim.y - 1u) {
