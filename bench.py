@@ -478,7 +478,7 @@ def main():
         finally:
             os.environ.pop("DUST_FAR", None)
         allv.set_theta(theta4); allv.set_prior(mu4); allv.set_a_mat(theta4)
-        for _ in range(8):
+        for _ in range(n4w + n4 - 10):  # (the same age as the timed ticks above: the set, and with it every data-dependent shortcut, evolves)
             allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
         allv.sync()
         t1 = time.perf_counter()

@@ -21,8 +21,8 @@
 //     pairs of a spread-out set sit at d2 ~ 320 +- 50: beyond 60, mostly short of 224 (cfg4, bench.py).
 // Rows the bound cannot speak for (non-finite coordinates or weights, |z| beyond binary16) get n = -inf and are never far.
 // m0_i is a lower bound of query i's final max logit, known before the pass: the largest of its OWN logit log w_i (the keys are
-// the particles: distance 0) and its exact logits against one candidate key per chunk - the chunk's heaviest particle
-// (far_lb_kernel: N x chunks exact distances, 1 / 64 of the pass).  After the first tick the mixture weights are
+// the particles: distance 0) and its exact logits against one candidate key per 256 keys - the group's heaviest particle
+// (far_lb_kernel: N x N / 256 exact distances).  After the first tick the mixture weights are
 // softmax(-alpha cost) - close to one-hot - and a light query's max logit is its logit against a heavy FAR particle, hundreds above
 // its own: without the candidates no unit of such a query could be proven negligible.  Any reference <= the true max + O(ulp)
 // serves the softmax equally well, so every mode of the fused pass starts from m0 (tests: DUST_FAR_T=224 against DUST_FAR=0 and
@@ -61,7 +61,7 @@ struct FarArgs {
   float T;              // the threshold on G (DUST_FAR_T_DEFAULT; development switch DUST_FAR_T)
   unsigned int *qmask;  // [tiles][chunks][4] per unit: bit q = query q of the tile has a NEAR key in the chunk (the fused pass computes
                         // exact distances for those queries only), or nullptr
-  unsigned int *count;  // [3] {far units, all units, workgroups done} of this launch (zeroed by the row kernel), or nullptr
+  unsigned int *count;  // [2] (8-byte aligned) {far units, all units} of this launch (zeroed by the row kernel), or nullptr
   unsigned int *host_count;  // [2] pinned host words the LAST workgroup of far_flags_kernel copies {far, all} to (no copy node, no
                              // synchronisation: the host reads them whenever it next decides - dust_amd.hip logp_far_decide)
 };
@@ -96,7 +96,7 @@ __device__ __forceinline__ void far_prep_row(const FarArgs &a, const int row, co
   if (lane == 0) {
     a.nrm[row] = ok ? acc * (1.0f - DUST_FAR_EB) : -INFINITY;
     a.lms[row] = ok ? lm * a.lscale : 0.f;
-    if (row == 0 && a.count) a.count[0] = a.count[1] = a.count[2] = 0u;  // (far_flags_kernel, the next launch of the stream, counts into them)
+    if (row == 0 && a.count) a.count[0] = a.count[1] = 0u;  // (far_flags_kernel, the next launch of the stream, counts into them)
   }
 }
 template <int DPB>
@@ -124,17 +124,29 @@ __global__ __launch_bounds__(64 * DUST_FAR_LB_WAVES) void far_lb_kernel(const Fa
     x[2 * p + 1] = v2f{t.z, t.w};
   }
   float best = -INFINITY;
-  for (int ci = wave; ci < a.chunks; ci += NW) {
-    // the candidate of chunk ci: its heaviest particle (first of equals; NaN weights count as -inf).  Every workgroup finds the
-    // candidates again - N log-weights out of L2 per workgroup, 1 % of its row traffic - instead of a launch of its own.
+  const int groups = (a.chunks + 3) / 4;
+  for (int ci = wave; ci < groups; ci += NW) {
+    // the candidate of key group ci (4 chunks = 256 keys): its heaviest particle (first of equals; NaN weights count as -inf) - the
+    // heaviest particle of the whole set is always one of them, and with softmax(-alpha cost) weights it is the one that matters.
+    // Every workgroup finds the candidates again - N log-weights out of L2 per workgroup, 1 % of its row traffic - instead of a
+    // launch of its own.  (One candidate per CHUNK - 16 per wave at N = 16384 - made this launch 29 us of serial latency.)
     int c;
     {
-      const int j = ci * 64 + lane;
-      float v = j < a.N ? a.logmix[j] : -INFINITY;
-      v = v == v ? v : -INFINITY;
-      const float mx = wave_max(v);
-      const unsigned long long hit = __ballot(v == mx);
-      c = min(ci * 64 + (hit ? (int)__builtin_ctzll(hit) : 0), a.N - 1);
+      float mx = -INFINITY;
+      int arg = ci * 256;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = ci * 256 + 64 * u + lane;
+        float v = j < a.N ? a.logmix[j] : -INFINITY;
+        v = v == v ? v : -INFINITY;
+        const float m1 = wave_max(v);
+        const unsigned long long hit = __ballot(v == m1);
+        if (m1 > mx) {  // wave-uniform
+          mx = m1;
+          arg = ci * 256 + 64 * u + (hit ? (int)__builtin_ctzll(hit) : 0);
+        }
+      }
+      c = min(arg, a.N - 1);
     }
     typedef const v2f __attribute__((address_space(4))) * cv2;
     const cv2 y = (cv2)(uintptr_t)(a.Xp + (size_t)c * DPB);
@@ -201,20 +213,26 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
   const bool live = tile < a.tiles;  // (a wave behind the last tile still stages keys)
   const int tq = live ? tile : a.tiles - 1;
   const int c_beg = blockIdx.y * a.cps, c_end = min(a.chunks, c_beg + a.cps);
-  unsigned int n_far = 0u, n_all = 0u;  // wave-uniform
-  auto finish = [&]() {  // the last workgroup to get here hands the launch's counts to the host
+  unsigned int n_far = 0u, n_all = 0u;  // wave-uniform: this wave's units
+  // One 64-bit atomic per WORKGROUP (far units in the low word, all units in the high one - per-wave 32-bit atomics on two words
+  // cost 55 us of a 60 us launch, per-unit ones 1.4 ms); the workgroup that completes the total hands the counts to the host.
+  auto finish = [&]() {
     if (!a.count || !a.host_count) return;
-    if (lane == 0 && n_all) {
-      atomicAdd(a.count, n_far);
-      atomicAdd(a.count + 1, n_all);
+    __shared__ unsigned int wcnt[4][2];
+    if (lane == 0) {
+      wcnt[wave][0] = n_far;
+      wcnt[wave][1] = n_all;
     }
     wg_sync();
     if (tid == 0) {
-      __threadfence();
-      if (atomicAdd(a.count + 2, 1u) == gridDim.x * gridDim.y - 1u) {
-        const unsigned int fa = atomicAdd(a.count, 0u), al = atomicAdd(a.count + 1, 0u);
-        __hip_atomic_store(a.host_count, fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a.host_count + 1, al, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long mine = (unsigned long long)(wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0]) |
+                                      ((unsigned long long)(wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1]) << 32);
+      if (mine) {
+        const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long *>(a.count), mine) + mine;
+        if ((unsigned int)(tot >> 32) == (unsigned int)a.tiles * (unsigned int)a.chunks) {
+          __hip_atomic_store(a.host_count, (unsigned int)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(a.host_count + 1, (unsigned int)(tot >> 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
   };

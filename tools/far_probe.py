@@ -11,7 +11,7 @@ lib = L.load()
 lib.dust_debug_far_units.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 lib.dust_debug_far_logp.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 n_ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-c4 = bench.CFG4
+c4 = dict(bench.CFG3, n_iters=1) if os.environ.get("DUST_PROBE_CFG") == "3" else bench.CFG4  # (DUST_PROBE_CFG=3: the cfg3 shape)
 for far in ((os.environ["DUST_PROBE_ONLY"],) if os.environ.get("DUST_PROBE_ONLY") else ("1", "0")):
     os.environ["DUST_FAR"] = far
     mu4, theta4 = bench.synth(c4["N"], c4["H"], 2, spread=1.0)

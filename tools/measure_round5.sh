@@ -37,6 +37,17 @@ rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq
 find $O/stats -name "*kernel_trace*" -delete
 tail -c 1500 $O/bench_driver_cmd.json; head -6 $O/stats/*/b_kernel_stats.csv 2>/dev/null | cut -c1-160 || find $O/stats -name "*kernel_stats.csv" | head
 cd $R
+# pairwise_far.hpp on cfg4: tick time and left-out shares tick by tick (fresh set -> the aged set the bench times), with and without it;
+# per-kernel durations of the LAST 10 launches of a 150-tick run (the aged state); one rank's compute with the real data flow
+timeout 200 python tools/far_probe.py 150 > $O/far_probe.txt 2>&1
+(cd /tmp && DUST_PROBE_ONLY=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_far -o b -- python3 $R/tools/far_probe.py 150 > /dev/null 2>&1)
+python tools/trace_tail.py $(find /tmp/tr_far -name "*kernel_trace.csv" | head -1) 10 > $O/far_kernels_aged.txt 2>&1
+(cd /tmp && DUST_PROBE_ONLY=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_far2 -o b -- python3 $R/tools/far_probe.py 12 > /dev/null 2>&1)
+python tools/trace_tail.py $(find /tmp/tr_far2 -name "*kernel_trace.csv" | head -1) 5 > $O/far_kernels_fresh.txt 2>&1
+timeout 200 python tools/far_granularity.py 140 > $O/far_granularity.txt 2>&1
+timeout 300 python tools/shard_emul.py 1,2,4,8 > $O/shard_emul.txt 2>&1
+DUST_FAR=0 timeout 300 python tools/shard_emul.py 1,8 > $O/shard_emul_far0.txt 2>&1
+DUST_AMD_LIB=tools/_libdust_stamps.so timeout 100 python tools/rollout_phases.py > $O/rollout_phases.txt 2>&1
 timeout 600 python tools/shard_time.py cfg4 > $O/shard_time.txt 2>&1
 timeout 300 python tools/states_probe.py > $O/states_probe.txt 2>&1
 python tools/states_hbm.py $O/states_probe.txt $O/states_hbm.json > /dev/null
