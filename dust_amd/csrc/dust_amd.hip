@@ -1922,7 +1922,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.nz = b.nz;
     f.ldnz = b.ldnz;
     if (flags) {
-      TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 4));
+      TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 8));
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
     }
     const int gx = (tiles + 3) / 4;
@@ -1935,7 +1935,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     far_lb_kernel<DPB><<<(nq + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);            \
     if (flags) {                                                                                     \
       far_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(f);                           \
-      far_flags_kernel<DPB, FusedGeom<DPB>::TQ><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f); \
+      far_flags_kernel<DPB, FusedGeom<DPB>::TQ, true><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f); \
     }                                                                                                \
   } while (0)
     if (dpb == 32) DUST_LAUNCH_FAR(32);
@@ -2103,7 +2103,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     if (flags) {                                                                                                                \
       logp_prep_far_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b, f);                                              \
       far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);        \
-      far_flags_kernel<DPB, 64><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
+      far_flags_kernel<DPB, 64, false><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
     } else {                                                                                                                    \
       logp_prep_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b);                                                     \
     }                                                                                                                           \

@@ -59,8 +59,9 @@ struct FarArgs {
   unsigned char *nz;    // the Gram-block flags of pairwise_fused.hpp: zeroed here for far units (the fused pass never visits them)
   int ldnz;
   float T;              // the threshold on G (DUST_FAR_T_DEFAULT; development switch DUST_FAR_T)
-  unsigned int *qmask;  // [tiles][chunks][4] per unit: bit q = query q of the tile has a NEAR key in the chunk (the fused pass computes
-                        // exact distances for those queries only), or nullptr
+  unsigned int *qmask;  // [tiles][chunks][8] per unit (MASKS instances): words 0-3: bit q = query q of the tile has a NEAR key in the chunk (the
+                        // fused pass computes exact distances for those queries only); words 4-5: bit k = key k of the chunk has a near
+                        // query in the tile (the others get no term at all: their weights are forced to exact zeros, pass B skips them)
   unsigned int *count;  // [2] (8-byte aligned) {far units, all units} of this launch (zeroed by the row kernel), or nullptr
   unsigned int *host_count;  // [2] pinned host words the LAST workgroup of far_flags_kernel copies {far, all} to (no copy node, no
                              // synchronisation: the host reads them whenever it next decides - dust_amd.hip logp_far_decide)
@@ -200,7 +201,7 @@ static inline size_t far_flags_lds_bytes() {
 // Workgroup = 4 waves = 4 query tiles (TQ rows each - the consumer's tile: pairwise_fused_kernel's, or the 64 queries of a wave of
 // pairwise_logp_mfma_kernel - held in registers as B operands), the key
 // chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 16-byte LDS read.
-template <int DPB, int TQ>
+template <int DPB, int TQ, bool MASKS>
 __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
   constexpr int JC = 64, NT = 256, QT = TQ / 16, ZH = far_zh(DPB), NP = ZH / 32, ZS = ZH + 8, R8 = ZH / 8;
   constexpr int NLD = (JC * R8 + NT - 1) / NT;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
     float mt[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) mt[t] = 3.0e38f;
+    unsigned long long kmask = 0ull;  // (MASKS) keys of the chunk with a near query in the tile; wave-uniform
 #pragma unroll 1
     for (int kt = 0; kt < JC / 16; ++kt) {
       v4f acc[QT];
@@ -315,18 +317,39 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
         const float dl = kl[r] == -INFINITY ? 0.f : fmaxf(kl[r] - lmq, 0.f);  // (a key of zero weight has no prior term at all)
         hk[r] = fmaf(-2.0f, dl, kn[r]);
       }
+      if (!MASKS) {
 #pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        const float m01 = fminf(fmaf(-2.0f, acc[t][0], hk[0]), fmaf(-2.0f, acc[t][1], hk[1]));
-        const float m23 = fminf(fmaf(-2.0f, acc[t][2], hk[2]), fmaf(-2.0f, acc[t][3], hk[3]));
-        mt[t] = fminf(mt[t], fminf(m01, m23));
+        for (int t = 0; t < QT; ++t) {
+          const float m01 = fminf(fmaf(-2.0f, acc[t][0], hk[0]), fmaf(-2.0f, acc[t][1], hk[1]));
+          const float m23 = fminf(fmaf(-2.0f, acc[t][2], hk[2]), fmaf(-2.0f, acc[t][3], hk[3]));
+          mt[t] = fminf(mt[t], fminf(m01, m23));
+        }
+      } else {
+        // per key as well: the smallest margin over the tile's queries (the lane's QT sub-tiles, then the 16 lanes of its row)
+        float kvm[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = fmaf(-2.0f, acc[t][r], hk[r]);
+            mt[t] = fminf(mt[t], e);
+            kvm[r] = fminf(kvm[r], e + hq[t]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kvm[r] = row16_reduce(kvm[r], 3.0e38f, [](float x, float y) { return fminf(x, y); });
+        // lane r16 < 4 of row g speaks for key 16 kt + 4 g + r16
+        const float mine = r16 == 0 ? kvm[0] : (r16 == 1 ? kvm[1] : (r16 == 2 ? kvm[2] : kvm[3]));
+        const unsigned long long bb = __ballot(r16 < 4 && !(mine > 0.f));
+        const unsigned long long k16 = (bb & 0xFull) | ((bb >> 12) & 0xF0ull) | ((bb >> 24) & 0xF00ull) | ((bb >> 36) & 0xF000ull);
+        kmask |= k16 << (16 * kt);
       }
     }
     bool ok = true;
 #pragma unroll
     for (int t = 0; t < QT; ++t) ok = ok && (mt[t] + hq[t] > 0.f);
     const bool is_far = __ballot(!ok) == 0ull;  // wave-uniform
-    if (a.qmask) {
+    if (MASKS) {
       // per query: the smallest margin over the chunk's 64 keys sits in the four lanes r16, r16 + 16, + 32, + 48
       unsigned int qm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -338,9 +361,11 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
         qm[t >> 1] |= b16 << (16 * (t & 1));
       }
       if (live && lane == 0) {
-        unsigned int *dst = a.qmask + ((size_t)tile * a.chunks + ch) * 4;
+        unsigned int *dst = a.qmask + ((size_t)tile * a.chunks + ch) * 8;
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[k] = qm[k];
+        dst[4] = (unsigned int)kmask;
+        dst[5] = (unsigned int)(kmask >> 32);
       }
     }
     if (live) {

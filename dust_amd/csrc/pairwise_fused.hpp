@@ -38,7 +38,8 @@ struct PairFusedArgs {
   unsigned char *nz;  // [chunks][ldnz] 1 = the 64 Stein kernel values of (key chunk, query row) are not all exactly 0 (see below); ldnz >= rows, multiple of 64
   int ldnz;
   const unsigned char *far;  // [tiles][chunks] 1 = the unit contributes exactly nothing and is not visited (pairwise_far.hpp), or nullptr
-  const unsigned int *qmask;  // [tiles][chunks][4] bit q = query q of the tile has a near key in the chunk (pairwise_far.hpp), or nullptr: all
+  const unsigned int *qmask;  // [tiles][chunks][8] words 0-3: bit q = query q of the tile has a near key in the chunk; words 4-5: bit k = key k of
+                              // the chunk has a near query in the tile (pairwise_far.hpp), or nullptr: all
   const float *m0;           // [N] where each query's running max starts (pairwise_far.hpp: a lower bound of its final max), or nullptr: -inf
 };
 
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
     const int j0 = ci * JC;
     const int jc = min(JC, jend - j0);
     const float lm = lm_next;
+    unsigned long long keymask = ~0ull;  // keys of this chunk that have a term at all (wave-uniform; set in pass A)
     wg_sync();  // Ys holds this chunk
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
@@ -211,16 +213,20 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
         y[2 * p] = v2f{t.x, t.y};
         y[2 * p + 1] = v2f{t.z, t.w};
       }
-      const bool kval = jA < jc;
+      // the unit's masks (pairwise_far.hpp): near queries, near keys.  A key without a near query in the tile gets NO term - logit
+      // -inf, kernel value 0 - whatever query it is paired with (exact zeros at the exact threshold, below 2^-43 at the default one)
+      typedef const unsigned int __attribute__((address_space(4))) * cu32;  // (written by an earlier launch: scalar loads)
+      const bool masks = MODE == PAIR_K1 && b.qmask != nullptr;  // (the pre-pass speaks for K1 only: IMQ's kernel values never vanish)
+      const cu32 qm = (cu32)(uintptr_t)(masks ? b.qmask + ((size_t)tile * b.chunks + ci) * 8 : nullptr);
+      keymask = masks ? ((unsigned long long)qm[4] | ((unsigned long long)qm[5] << 32)) : ~0ull;
+      const bool kval = jA < jc && ((keymask >> jA) & 1ull);
       bool wave_any = (MODE != PAIR_K1) || b.nz == nullptr;
       // the wave's queries with a NEAR key in this chunk (pairwise_far.hpp: bit q of the unit's mask; without the pre-pass: all).
       // The others have no term here at all: logit -inf, kernel value 0, Gram row not stored (flag 0: gram_score_kernel masks it).
       static_assert(QW <= 32, "query mask of a wave");
       constexpr unsigned int QALL = QW == 32 ? 0xffffffffu : ((1u << QW) - 1u);
       unsigned int near = QALL;
-      if (b.qmask) {
-        typedef const unsigned int __attribute__((address_space(4))) * cu32;  // (written by an earlier launch: scalar loads)
-        const cu32 qm = (cu32)(uintptr_t)(b.qmask + ((size_t)tile * b.chunks + ci) * 4);
+      if (masks) {
         const unsigned long long lo = (unsigned long long)qm[0] | ((unsigned long long)qm[1] << 32);
         const unsigned long long hi = (unsigned long long)qm[2] | ((unsigned long long)qm[3] << 32);
         const int sft = wave * QW;
@@ -362,8 +368,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
     const bool tile_pany = (pany[0] | pany[1] | pany[2] | pany[3]) != 0u;
     auto pass_b = [&](auto with_p, auto with_k) {
       constexpr bool WP = decltype(with_p)::value, WK = decltype(with_k)::value;
-#pragma unroll 2
-      for (int jj = 0; jj < JC; ++jj) {
+      auto one_key = [&](const int jj) {
         v4f yv[NV];
 #pragma unroll
         for (int u = 0; u < NV; ++u) yv[u] = *reinterpret_cast<const v4f *>(&Ys[jj * YS + c0 + 4 * u]);
@@ -380,7 +385,10 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_fused_kernel
             if (WK) accB[r][u] = __builtin_elementwise_fma(v4f{nk, nk, nk, nk}, diff, accB[r][u]);
           }
         }
-      }
+      };
+      // (the keys without a term carry exact zero weights: left out.  In a set with near-duplicates scattered through it nearly every
+      //  unit has a near pair, but a key has a near query among the tile's 96 only now and then - 12 % of the keys at cfg4 after 140 ticks)
+      for (unsigned long long km = keymask; km; km &= km - 1ull) one_key((int)__builtin_ctzll(km));
     };
     if (pb) {
       if (tile_pany && tile_any) pass_b(std::true_type{}, std::true_type{});
