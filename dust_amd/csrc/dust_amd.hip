@@ -1926,7 +1926,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
     }
     const int gx = (tiles + 3) / 4;
-    const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
+    const int want = std::max(1, (3 * device_cus(c) + gx - 1) / gx);  // (three resident workgroups per CU: the launch is bound by the latency of its key loads)
     f.cps = std::max(1, (b.chunks + want - 1) / want);
     dim3 fgrid(gx, (b.chunks + f.cps - 1) / f.cps);
     const int nq = std::min(c->N - a.i0, tiles * fused_tq(a.D));
@@ -2085,7 +2085,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     f.wP[0] = f.wP[1] = 1.0f;
     f.far = reinterpret_cast<unsigned char *>(c->far_g);
     const int gx = (f.tiles + 3) / 4;
-    const int want = std::max(1, (2 * device_cus(c) + gx - 1) / gx);
+    const int want = std::max(1, (3 * device_cus(c) + gx - 1) / gx);  // (three resident workgroups per CU: the launch is bound by the latency of its key loads)
     f.cps = std::max(1, (chunks + want - 1) / want);
     fgrid = dim3(gx, (chunks + f.cps - 1) / f.cps);
     if (c->far_cnt_host) {

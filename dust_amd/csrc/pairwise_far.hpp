@@ -202,7 +202,7 @@ static inline size_t far_flags_lds_bytes() {
 // pairwise_logp_mfma_kernel - held in registers as B operands), the key
 // chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 16-byte LDS read.
 template <int DPB, int TQ, bool MASKS>
-__global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
+__global__ __launch_bounds__(256, 3) void far_flags_kernel(const FarArgs a) {
   constexpr int JC = 64, NT = 256, QT = TQ / 16, ZH = far_zh(DPB), NP = ZH / 32, ZS = ZH + 8, R8 = ZH / 8;
   constexpr int NLD = (JC * R8 + NT - 1) / NT;
   static_assert(TQ % 16 == 0, "whole MFMA tiles");
@@ -243,14 +243,14 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
   }
 
   v8h bq[QT][NP];
-  float hq[QT];
+  float hqh[QT];  // -n_q (1 - EB) / 2: where the query's accumulators start (+inf: the row is never far)
   float lmq = INFINITY;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = min(a.i0 + tq * TQ + 16 * t + r16, N - 1);  // (rows behind the set: clamped, as the fused pass clamps them)
 #pragma unroll
     for (int s = 0; s < NP; ++s) bq[t][s] = *reinterpret_cast<const v8h *>(a.Z + (size_t)qi * ZH + 32 * s + 8 * g);
-    hq[t] = a.nrm[qi];
+    hqh[t] = -0.5f * a.nrm[qi];
     lmq = fminf(lmq, a.m0[qi]);
   }
   lmq = wave_min(lmq);
@@ -299,9 +299,10 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
     unsigned long long kmask = 0ull;  // (MASKS) keys of the chunk with a near query in the tile; wave-uniform
 #pragma unroll 1
     for (int kt = 0; kt < JC / 16; ++kt) {
+      // (the accumulators start at -n_q / 2: -2 acc + (key constant) is then the pair's whole margin - no add per element)
       v4f acc[QT];
 #pragma unroll
-      for (int t = 0; t < QT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < QT; ++t) acc[t] = v4f{hqh[t], hqh[t], hqh[t], hqh[t]};
 #pragma unroll
       for (int s = 0; s < NP; ++s) {
         const v8h av = *reinterpret_cast<const v8h *>(&Zs[(16 * kt + r16) * ZS + 32 * s + 8 * g]);
@@ -317,24 +318,33 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
         const float dl = kl[r] == -INFINITY ? 0.f : fmaxf(kl[r] - lmq, 0.f);  // (a key of zero weight has no prior term at all)
         hk[r] = fmaf(-2.0f, dl, kn[r]);
       }
+      const v2f hk01 = {hk[0], hk[1]}, hk23 = {hk[2], hk[3]}, m2 = {-2.0f, -2.0f};
       if (!MASKS) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          const float m01 = fminf(fmaf(-2.0f, acc[t][0], hk[0]), fmaf(-2.0f, acc[t][1], hk[1]));
-          const float m23 = fminf(fmaf(-2.0f, acc[t][2], hk[2]), fmaf(-2.0f, acc[t][3], hk[3]));
-          mt[t] = fminf(mt[t], fminf(m01, m23));
+          const v2f e01 = __builtin_elementwise_fma(m2, v2f{acc[t][0], acc[t][1]}, hk01), e23 = __builtin_elementwise_fma(m2, v2f{acc[t][2], acc[t][3]}, hk23);
+          mt[t] = fminf(fminf(mt[t], e01.x), e01.y);
+          mt[t] = fminf(fminf(mt[t], e23.x), e23.y);
         }
       } else {
         // per key as well: the smallest margin over the tile's queries (the lane's QT sub-tiles, then the 16 lanes of its row)
         float kvm[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        static_assert(QT % 2 == 0 || true, "");
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = fmaf(-2.0f, acc[t][r], hk[r]);
-            mt[t] = fminf(mt[t], e);
-            kvm[r] = fminf(kvm[r], e + hq[t]);
+        for (int t = 0; t < QT; t += 2) {  // two sub-tiles per trip: three-operand minima on the key side too
+          const int t1 = t + 1 < QT ? t + 1 : t;
+          const v2f a01 = __builtin_elementwise_fma(m2, v2f{acc[t][0], acc[t][1]}, hk01), a23 = __builtin_elementwise_fma(m2, v2f{acc[t][2], acc[t][3]}, hk23);
+          const v2f b01 = __builtin_elementwise_fma(m2, v2f{acc[t1][0], acc[t1][1]}, hk01), b23 = __builtin_elementwise_fma(m2, v2f{acc[t1][2], acc[t1][3]}, hk23);
+          mt[t] = fminf(fminf(mt[t], a01.x), a01.y);
+          mt[t] = fminf(fminf(mt[t], a23.x), a23.y);
+          if (t1 != t) {
+            mt[t1] = fminf(fminf(mt[t1], b01.x), b01.y);
+            mt[t1] = fminf(fminf(mt[t1], b23.x), b23.y);
           }
+          kvm[0] = fminf(fminf(kvm[0], a01.x), b01.x);
+          kvm[1] = fminf(fminf(kvm[1], a01.y), b01.y);
+          kvm[2] = fminf(fminf(kvm[2], a23.x), b23.x);
+          kvm[3] = fminf(fminf(kvm[3], a23.y), b23.y);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) kvm[r] = row16_reduce(kvm[r], 3.0e38f, [](float x, float y) { return fminf(x, y); });
@@ -347,14 +357,14 @@ __global__ __launch_bounds__(256, 2) void far_flags_kernel(const FarArgs a) {
     }
     bool ok = true;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) ok = ok && (mt[t] + hq[t] > 0.f);
+    for (int t = 0; t < QT; ++t) ok = ok && (mt[t] > 0.f);
     const bool is_far = __ballot(!ok) == 0ull;  // wave-uniform
     if (MASKS) {
       // per query: the smallest margin over the chunk's 64 keys sits in the four lanes r16, r16 + 16, + 32, + 48
       unsigned int qm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        float v = mt[t] + hq[t];
+        float v = mt[t];
         v = fminf(v, __shfl_xor(v, 16));
         v = fminf(v, __shfl_xor(v, 32));
         const unsigned int b16 = (unsigned int)(__ballot(!(v > 0.f)) & 0xffffull);  // lanes 0 .. 15: queries 16 t + r16

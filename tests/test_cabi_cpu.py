@@ -168,7 +168,7 @@ def test_every_barrier_drains_lds_first(built, tmp_path):
             continue
         total += 1
         ok = False
-        for j in range(i - 1, max(i - 40, 0), -1):  # (the scheduler may slide VALU work between the wait and the barrier)
+        for j in range(i - 1, max(i - 160, 0), -1):  # (the scheduler slides VALU / SALU work between the wait and the barrier: up to ~100 instructions of loop set-up in far_flags_kernel)
             if lds_mem.match(ins[j]):
                 break
             if ins[j].startswith("s_waitcnt") and "lgkmcnt(0)" in ins[j]:
