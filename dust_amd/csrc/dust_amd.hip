@@ -127,6 +127,7 @@ struct dust_ctx {
   float *far_g;               // the flags of the last log-p pass [groups][chunks] bytes
   size_t far_g_cap;
   int far_groups, far_gchunks;
+  int fused_js;  // slices of the repulsion partials of the last pairwise_fused_kernel launch (update_kernel merges them)
   int prior_js;  // slices of the prior partials when pairwise_fused_kernel wrote them (its own split); 0 = pair_geometry's
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
@@ -1924,6 +1925,15 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     if (flags) {
       TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 8));
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
+      if (!c->far_cnt_host && !c->capturing) {
+        HIP_TRY(hipHostMalloc((void **)&c->far_cnt_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
+        memset(c->far_cnt_host, 0, 4 * sizeof(unsigned int));
+        TRY(ensure(&c->far_cnt, &c->far_cnt_cap, 8));
+      }
+      if (c->far_cnt_host) {  // {far units, all units} of this pass, for the NEXT launch's work split (below)
+        f.count = reinterpret_cast<unsigned int *>(c->far_cnt);
+        f.host_count = c->far_cnt_host;
+      }
     }
     const int gx = (tiles + 3) / 4;
     const int want = std::max(1, (3 * device_cus(c) + gx - 1) / gx);  // (three resident workgroups per CU: the launch is bound by the latency of its key loads)
@@ -1953,6 +1963,16 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   }
   int W, tl;
   fused_geometry(c, &tl, &W, &b.p.JS);  // (a.JS / a.slice describe the regular grid of the other kernels)
+  // A rank of a sharded run has few query tiles (22 at cfg4 / 8) under 512 workgroups: 23 partial rows per particle for the merge
+  // kernels to read, written whether or not their workgroup found a live unit.  While the pre-pass leaves nearly everything out
+  // (its counts of the previous pass, read unsynchronised from pinned memory) two runs per tile are plenty: 60 -> ~25 us.
+  if (b.far && c->nloc < c->N && !c->capturing && c->far_cnt_host) {
+    volatile unsigned int *hc = c->far_cnt_host;
+    const unsigned int fa = hc[0], al = hc[1];
+    const int few = std::max(64, 2 * tiles);
+    if (al && (double)fa > 0.9 * (double)al && few < W) fused_balance(tiles, b.chunks, few, &W, &b.p.JS);
+  }
+  c->fused_js = b.p.JS;
   int jsg, slg;
   gram_geometry(c, &jsg, &slg);
   TRY(ensure_partials(c, std::max(std::max(a.JS, b.p.JS), jsg)));  // before anything is written: pass 2 adds its pA rows later
@@ -2534,9 +2554,8 @@ static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K
   c->kmat_valid = false;  // (theta moves below; a later Stein pass without a fresh prior pass recomputes)
   UpdateArgs u = update_args(c, apply);
   if (jsa) {  // pA from pass 2 (its own slices), pB from pairwise_fused_kernel
-    int tl, W;
     u.JSA = jsa;
-    fused_geometry(c, &tl, &W, &u.JS);
+    u.JS = c->fused_js;
   }
   Prof p(c, DUST_K_UPDATE);
   update_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(u);
