@@ -51,11 +51,6 @@ __global__ __launch_bounds__(256) void logp_prep_kernel(const LogpMfmaArgs a) {
   }
 }
 
-// rows for the far pre-pass (pairwise_far.hpp: the same scaling, binary16) and for the log-p pass in one launch
-struct FarArgs;
-template <int DPB>
-__device__ __forceinline__ void far_prep_row(const FarArgs &a, const int row, const int lane);
-
 template <int DPB>
 static inline size_t pairwise_logp_mfma_lds_bytes() {
   return sizeof(float) * (2 * (size_t)64 * (DPB + 4) + 2 * 64);
