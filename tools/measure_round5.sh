@@ -47,6 +47,7 @@ python tools/trace_tail.py $(find /tmp/tr_far2 -name "*kernel_trace.csv" | head 
 timeout 200 python tools/far_granularity.py 140 > $O/far_granularity.txt 2>&1
 timeout 300 python tools/shard_emul.py 1,2,4,8 > $O/shard_emul.txt 2>&1
 DUST_FAR=0 timeout 300 python tools/shard_emul.py 1,8 > $O/shard_emul_far0.txt 2>&1
+timeout 300 python tools/shard_emul.py 1,2,4,8 160 2>&1 | grep cfg4 > $O/shard_emul_aged.txt
 DUST_AMD_LIB=tools/_libdust_stamps.so timeout 100 python tools/rollout_phases.py > $O/rollout_phases.txt 2>&1
 timeout 600 python tools/shard_time.py cfg4 > $O/shard_time.txt 2>&1
 timeout 300 python tools/states_probe.py > $O/states_probe.txt 2>&1
