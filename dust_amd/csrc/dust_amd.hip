@@ -15,7 +15,13 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#if defined(__x86_64__) || defined(_M_X64)
 #include <emmintrin.h>
+#define DUST_CPU_PAUSE() _mm_pause()
+#else
+#define DUST_CPU_PAUSE() std::this_thread::yield()
+#include <thread>
+#endif
 
 #include "bandwidth.hpp"
 #include "common.hpp"
@@ -124,6 +130,7 @@ struct dust_ctx {
   float *far_cnt;             // [4] device counters {far, all} of the fused pass' and the log-p pass' last pre-pass
   unsigned int *far_cnt_host; // pinned copy (arrives a tick late at worst: it only steers whether the NEXT pre-pass is worth its launches)
   int far_logp_skip;          // log-p pre-pass: launches left to skip before the next probe
+  unsigned int far_logp_issued;  // counted log-p pre-passes issued so far (the report the next decision reads carries this number)
   float *far_g;               // the flags of the last log-p pass [groups][chunks] bytes
   size_t far_g_cap;
   int far_groups, far_gchunks;
@@ -185,6 +192,7 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    float far_t;  // DUST_FAR_T: the far pre-pass' threshold (pairwise_far.hpp), default DUST_FAR_T_DEFAULT
   } env;
   struct T2Replay {
     float state[4];
@@ -444,6 +452,8 @@ static void env_read(dust_ctx *c) {
   c->env.tick2_test_abort = env_int("DUST_TICK2_TEST_ABORT");
   c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
   c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
+  const char *ft = getenv("DUST_FAR_T");
+  c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
 // Particle configurations the specialised rollout kernels do not take (particle_general.hpp): velocity control, and control-channel noise
 // that is not identically zero (the reference's constructor default is deterministic=False with noise_std = zeros(2): draws are made and
@@ -499,9 +509,23 @@ static void serve_post(dust_ctx *c, unsigned int seq, unsigned int verdict, cons
     if (c->ds > 2) memcpy(&hb[0], &state[2], 4);
     if (c->ds > 3) memcpy(&hb[1], &state[3], 4);
   }
+#if defined(__x86_64__) || defined(_M_X64)
   _mm_store_si128(reinterpret_cast<__m128i *>(&m->x23[0]), _mm_load_si128(reinterpret_cast<const __m128i *>(hb)));
   std::atomic_thread_fence(std::memory_order_release);
   _mm_store_si128(reinterpret_cast<__m128i *>(&m->seq_a), _mm_load_si128(reinterpret_cast<const __m128i *>(ha)));
+#else
+  // no single-copy-atomic 16-byte store to rely on: the sequence word of each half goes LAST (the reader takes a half only when its
+  // sequence word matches, and reads the sequence word first - tick2_args.hpp T2Mbox)
+  volatile unsigned int *pb = reinterpret_cast<volatile unsigned int *>(&m->x23[0]);
+  pb[0] = hb[0]; pb[1] = hb[1]; pb[3] = hb[3];
+  std::atomic_thread_fence(std::memory_order_release);
+  pb[2] = hb[2];
+  std::atomic_thread_fence(std::memory_order_release);
+  volatile unsigned int *pa = reinterpret_cast<volatile unsigned int *>(&m->seq_a);
+  pa[1] = ha[1]; pa[2] = ha[2]; pa[3] = ha[3];
+  std::atomic_thread_fence(std::memory_order_release);
+  pa[0] = ha[0];
+#endif
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 // cancel the armed launch of `c` (caller holds g_armed_mu of its device, or is the owning thread of a context that is not registered)
@@ -846,6 +870,15 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
   c->mu_aliased = src->mu_aliased;
   c->have_sample = src->have_sample;
   c->skid = src->skid;
+  c->k2_fixed_h = src->k2_fixed_h;  // (dust_set_k2_bandwidth: RBF(bandwidth=, minimum_bw=) - a deep-copied controller keeps its kernel)
+  c->k2_min_bw = src->k2_min_bw;
+  if (src->cz_dev && src->cz_sets > 0) {  // recorded control-noise draws not consumed yet (dust_set_ctrl_noise)
+    const size_t n = (size_t)src->cz_sets * c->H * c->M * c->S * c->N * 2;
+    TRY(ensure(&c->cz_dev, &c->cz_cap, n));
+    TRY(d2d(c, c->cz_dev, src->cz_dev, n * sizeof(float)));
+    c->cz_sets = src->cz_sets;
+    c->cz_next = src->cz_next;
+  }
   if (src->grid_bits) {
     const size_t words = ((size_t)src->nx * src->ny + 31) / 32;
     TRY(dalloc(&c->grid_bits, words));
@@ -915,6 +948,7 @@ extern "C" int dust_set_ctrl_noise(dust_ctx *c, const float *z, int n_sets) {
 extern "C" int dust_set_grid(dust_ctx *c, const float *grid, int nx, int ny, float off_x, float off_y) {
   if (c) c->persist_declined = 0;  // (what the one-launch ticks declined may be eligible now - or the other way round)
   if (!c || !grid || nx < 1 || ny < 1) return fail(DUST_ERR_INVALID, "bad grid");
+  TRY(settle_pending(c));  // (before the old grid is freed: an armed launch may hold the device, a tick that did not start is replayed on the map it was enqueued with)
   if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   const size_t cells = (size_t)nx * ny, words = (cells + 31) / 32;
   std::vector<uint32_t> bits(words, 0u);
@@ -962,6 +996,7 @@ extern "C" int dust_set_k2_bandwidth(dust_ctx *c, float bandwidth, float minimum
   if (c->cfg.kernel != DUST_KERNEL_K2_IIDMP && c->cfg.kernel != DUST_KERNEL_K2_SHARED)
     return fail(DUST_ERR_STATE, "dust_set_k2_bandwidth: the context's kernel is not iid_mp(RBF)");
   if (!(minimum_bw > 0.f)) return fail(DUST_ERR_INVALID, "minimum_bw must be > 0");
+  TRY(settle_pending(c));
   if (bandwidth < 0.f) {  // the median trick, clamped at minimum_bw (base_kernels.py:83-89)
     c->k2_fixed_h = 0.f;
     c->k2_min_bw = minimum_bw;
@@ -1854,6 +1889,7 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
 
 static void gram_geometry(const dust_ctx *c, int *JS, int *slice);
 static int ensure_partials(dust_ctx *c, int JS);
+static int far_counts_alloc(dust_ctx *c);
 
 // pass 1 of the fused pair (pairwise_fused.hpp): prior partials + repulsion partials + the Gram matrix of the current theta
 static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
@@ -1912,10 +1948,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.nrm = c->far_n;
     f.lms = c->far_n + c->N;
     f.m0 = c->far_n + 2 * (size_t)c->N;
-    {
-      const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
-      f.T = env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT;
-    }
+    f.T = c->env.far_t;
     f.Xp = b.Xp;
     f.wP[0] = b.wP[0];
     f.wP[1] = b.wP[1];
@@ -1925,11 +1958,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     if (flags) {
       TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 8));
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
-      if (!c->far_cnt_host && !c->capturing) {
-        HIP_TRY(hipHostMalloc((void **)&c->far_cnt_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
-        memset(c->far_cnt_host, 0, 4 * sizeof(unsigned int));
-        TRY(ensure(&c->far_cnt, &c->far_cnt_cap, 8));
-      }
+      TRY(far_counts_alloc(c));
       if (c->far_cnt_host) {  // {far units, all units} of this pass, for the NEXT launch's work split (below)
         f.count = reinterpret_cast<unsigned int *>(c->far_cnt);
         f.host_count = c->far_cnt_host;
@@ -2014,10 +2043,21 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
 
 // Is the log-p pass' far pre-pass (pairwise_far.hpp) worth its launches (~100 us at N = 16384)?  Only while it leaves most blocks out: a
 // set with near-duplicates scattered through it (cfg4 after ~30 ticks) has a near pair in nearly every 64 x 64 block.  The pre-pass
-// counts its far blocks on the device; the two words come back through pinned memory behind it, unsynchronised - the host reads them
-// at the NEXT decision, a tick late at worst - and a pre-pass that found under 30 % is followed by 15 log-p passes without one, then
-// probed again.  One decision per log-p pass; a graph-replayed tick takes it at its entry (dust_svmpc_tick keeps one capture per
+// counts its far blocks on the device and its last workgroup reports {far, all, launch number} through pinned memory.  The decision is
+// taken from the report of exactly the LAST pre-pass the host issued (it knows their number and waits for that report: by the time the
+// next tick's log-p pass is decided, the previous tick's pre-pass is long done), so it is a function of the particle history alone -
+// a pass with the pre-pass at the default threshold and one without it differ in their last bits, and whether it runs must not
+// depend on when a counter write lands.  A pre-pass that found under 30 % is followed by 15 log-p passes without one,
+// then probed again.  One decision per log-p pass; a graph-replayed tick takes it at its entry (dust_svmpc_tick keeps one capture per
 // variant).  DUST_FAR=2: always on.
+static int far_counts_alloc(dust_ctx *c) {
+  if (c->far_cnt_host || c->capturing) return DUST_OK;
+  HIP_TRY(hipHostMalloc((void **)&c->far_cnt_host, 8 * sizeof(unsigned int), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c->far_cnt_host, 0, 8 * sizeof(unsigned int));
+  TRY(ensure(&c->far_cnt, &c->far_cnt_cap, 8));
+  HIP_TRY(hipMemsetAsync(c->far_cnt, 0, 8 * sizeof(unsigned int), c->pair_stream));
+  return DUST_OK;
+}
 static bool logp_far_decide(dust_ctx *c) {
   if (c->env.far == 0 || c->env.dense >= 0) return false;
   if (c->env.far >= 2 || !c->far_cnt_host) return true;
@@ -2025,10 +2065,17 @@ static bool logp_far_decide(dust_ctx *c) {
     --c->far_logp_skip;
     return false;
   }
-  volatile unsigned int *hc = c->far_cnt_host;
-  const unsigned int fa = hc[2], al = hc[3];
+  volatile unsigned int *hc = c->far_cnt_host + 4;
+  if (c->far_logp_issued == 0u) return true;
+  const double t0 = host_now();
+  unsigned int spins = 0u;
+  while (hc[2] != c->far_logp_issued) {  // the last pre-pass issued has not reported yet (back-to-back ticks): wait for it
+    DUST_CPU_PAUSE();
+    if ((++spins & 1023u) == 0u && host_now() - t0 > 0.05) return true;  // (device stalled or gone: the next synchronisation will say)
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const unsigned int fa = hc[0], al = hc[1];
   if (al && (double)fa < 0.3 * (double)al) {
-    hc[3] = 0u;  // consumed: the next probe's result decides again
     c->far_logp_skip = 15;
     return false;
   }
@@ -2068,11 +2115,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
   // (DUST_FAR=0 / DUST_DENSE=1: visit all).  Base-2 logits here: log weights and the threshold scaled by log2 e.
   bool flags = c->env.far != 0 && c->env.dense < 0;
   if (flags) {
-    if (!c->far_cnt_host && !c->capturing) {
-      HIP_TRY(hipHostMalloc((void **)&c->far_cnt_host, 4 * sizeof(unsigned int), hipHostMallocDefault));
-      memset(c->far_cnt_host, 0, 4 * sizeof(unsigned int));
-      TRY(ensure(&c->far_cnt, &c->far_cnt_cap, 8));
-    }
+    TRY(far_counts_alloc(c));
     flags = c->logp_far_decided ? c->logp_far_on : logp_far_decide(c);
   }
   FarArgs f;
@@ -2092,8 +2135,7 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     f.logmix = a.logmix;
     f.sg[0] = b.sw[0];
     f.sg[1] = b.sw[1];
-    const char *env_t = getenv("DUST_FAR_T");  // development switch (read per launch)
-    f.T = (env_t ? (float)atof(env_t) : DUST_FAR_T_DEFAULT) * 1.44269504088896340736f;
+    f.T = c->env.far_t * 1.44269504088896340736f;
     TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * far_zh(dpb) + 1) / 2));
     TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + chunks));
     TRY(ensure(&c->far_g, &c->far_g_cap, ((size_t)f.tiles * chunks + 3) / 4));
@@ -2110,7 +2152,8 @@ static int launch_pair_logp_mfma(dust_ctx *c, const PairArgs &a) {
     fgrid = dim3(gx, (chunks + f.cps - 1) / f.cps);
     if (c->far_cnt_host) {
       f.count = reinterpret_cast<unsigned int *>(c->far_cnt) + 4;
-      f.host_count = c->far_cnt_host + 2;
+      f.host_count = c->far_cnt_host + 4;
+      if (!c->capturing) c->far_logp_issued++;  // (a captured launch reports when its graph runs: dust_svmpc_tick counts those)
     }
     b.far = f.far;
     b.groups = f.tiles;
@@ -3802,6 +3845,7 @@ static int t2_settle(dust_ctx *c, unsigned int aborts_now, bool *replayed) {
 extern "C" int dust_set_skid_steer(dust_ctx *c, const dust_skid_config *g) {
   if (!c || !g) return fail(DUST_ERR_INVALID, "null argument");
   if (c->cfg.model != DUST_MODEL_SKID_STEER) return fail(DUST_ERR_STATE, "the context's model is not DUST_MODEL_SKID_STEER");
+  TRY(settle_pending(c));
   const dust_param *ps[3] = {&g->x_icr, &g->wheel_radius, &g->axial_distance};
   for (const dust_param *p : ps) {
     if (p->kind < 0 || p->kind > DUST_PARAM_TENSOR0D) return fail(DUST_ERR_INVALID, "bad parameter kind %d", p->kind);
@@ -3860,7 +3904,8 @@ static void graph_drop(dust_ctx *c) {
 // needs the device next (serve_cancel_device: dust_create, the dynamics filter).  A loop slower than the bound stops being armed.
 static int serve_alloc(dust_ctx *c) {
   if (c->serve_host) return DUST_OK;
-  HIP_TRY(hipHostMalloc((void **)&c->serve_host, (c->out_floats + 64) * sizeof(float), hipHostMallocDefault));
+  // (the GPU polls the mailbox and the host polls the done word: fine-grained coherent memory whatever HIP_HOST_COHERENT says - ADVICE r5)
+  HIP_TRY(hipHostMalloc((void **)&c->serve_host, (c->out_floats + 64) * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped));
   memset(c->serve_host, 0, (c->out_floats + 64) * sizeof(float));
   return DUST_OK;
 }
@@ -3934,7 +3979,7 @@ static int serve_tick(dust_ctx *c, const float *state, float *a_seq, float *p_we
       break;
     }
     if (v == (this_seq | 0x80000000u)) break;  // did not start
-    _mm_pause();
+    DUST_CPU_PAUSE();
     if ((++spins & 1023u) == 0u && host_now() - t0 > 0.25) {  // (no word: a wait inside the launch gave up - 50 ms - or the device is gone)
       slow = true;
       break;
@@ -3944,10 +3989,16 @@ static int serve_tick(dust_ctx *c, const float *state, float *a_seq, float *p_we
     std::atomic_thread_fence(std::memory_order_acquire);
     if (a_seq) memcpy(a_seq, c->serve_host, c->D * sizeof(float));
     if (p_weights) memcpy(p_weights, c->serve_host + (c->pw - c->outblk), c->N * sizeof(float));
-    // this tick is committed: it leaves the replay queue (everything in front of it committed too - the launches are ordered)
-    const size_t keep = c->armed ? 1u : 0u;
+    // this tick is committed: it leaves the replay queue (everything in front of it committed too - the launches are ordered).  The
+    // launch BEHIND it stays on record while it is armed - or was cancelled by another thread (serve_cancel_device: dust_create, the
+    // filter) while this one was spinning above: the device counts that launch as "did not start", and only dust_sync's settle takes the
+    // count and the entry off together (dropped here, the next launch aborted on a count the host had never seen).  The
+    // canceller writes these fields under the device's mutex, so the bookkeeping takes it too.
+    std::lock_guard<std::mutex> lk(g_armed_mu[dev >= 0 && dev < DUST_MAX_DEV ? dev : 0]);
+    const bool tail_pending = c->armed || c->cancel_unsettled || (!c->t2_queue->empty() && c->t2_queue->back().cancelled);
+    const size_t keep = tail_pending ? 1u : 0u;
     if (c->t2_queue->size() > keep) c->t2_queue->erase(c->t2_queue->begin(), c->t2_queue->end() - keep);
-    if (!c->armed) c->t2_inflight = false;
+    if (!tail_pending) c->t2_inflight = false;
     c->n_served++;
     if (was_armed) c->n_armed_hit++;
     return DUST_OK;
@@ -4060,6 +4111,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(upload_state_params(c, state, params, n_steps));
     HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    if (c->graph_far && c->far_cnt_host) c->far_logp_issued++;  // (the captured pre-pass reports once per replay)
   } else if (graphable && c->graph_seen >= 1) {
     // warm (every lazily sized buffer exists): capture this tick, then launch the capture
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -4093,6 +4145,7 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     TRY(st);
     if (c->graph_exec) {
       HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+      if (c->graph_far && c->far_cnt_host) c->far_logp_issued++;
     } else {  // capture unavailable: run the tick eagerly (nothing was executed during the failed capture)
       (void)hipGetLastError();
       c->graph_seen = -1000000;  // do not retry every tick

@@ -62,9 +62,11 @@ struct FarArgs {
   unsigned int *qmask;  // [tiles][chunks][8] per unit (MASKS instances): words 0-3: bit q = query q of the tile has a NEAR key in the chunk (the
                         // fused pass computes exact distances for those queries only); words 4-5: bit k = key k of the chunk has a near
                         // query in the tile (the others get no term at all: their weights are forced to exact zeros, pass B skips them)
-  unsigned int *count;  // [2] (8-byte aligned) {far units, all units} of this launch (zeroed by the row kernel), or nullptr
-  unsigned int *host_count;  // [2] pinned host words the LAST workgroup of far_flags_kernel copies {far, all} to (no copy node, no
-                             // synchronisation: the host reads them whenever it next decides - dust_amd.hip logp_far_decide)
+  unsigned int *count;  // [3] (8-byte aligned) {far units, all units} of this launch (zeroed by the row kernel) and the number of
+                        // counted launches so far (never zeroed: it numbers the reports), or nullptr
+  unsigned int *host_count;  // [3] pinned host words the LAST workgroup of far_flags_kernel copies {far, all, launch number} to (no
+                             // copy node, no stream synchronisation: the host knows how many counted launches it has issued and
+                             // reads the report of exactly the last one - dust_amd.hip logp_far_decide)
 };
 
 // binary16 row length: whole K = 32 steps of v_mfma_f32_16x16x32_f16 (gfx950's full-rate shape: the 16x16x16 one runs at a quarter of it)
@@ -231,8 +233,11 @@ __global__ __launch_bounds__(256, 3) void far_flags_kernel(const FarArgs a) {
       if (mine) {
         const unsigned long long tot = atomicAdd(reinterpret_cast<unsigned long long *>(a.count), mine) + mine;
         if ((unsigned int)(tot >> 32) == (unsigned int)a.tiles * (unsigned int)a.chunks) {
+          const unsigned int seq = a.count[2] + 1u;  // (one workgroup per launch gets here, launches of a stream are ordered)
+          a.count[2] = seq;
           __hip_atomic_store(a.host_count, (unsigned int)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(a.host_count + 1, (unsigned int)(tot >> 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(a.host_count + 1, (unsigned int)(tot >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(a.host_count + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }

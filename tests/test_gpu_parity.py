@@ -112,6 +112,31 @@ def test_phi_update_vs_reference(golden, name):
         theta = g["tick_theta_rolled"][t]
 
 
+def test_cloned_context_keeps_its_k2_bandwidth_settings(golden):
+    """the reference's drivers deep-copy the controller inside their loops (simulations.py, particle_example.py); a copy
+    must keep RBF(minimum_bw=) - host-side state set after dust_create - or it falls back to the 1e-5 clamp silently.  The clone of
+    the `pend_k2_minbw` context (about half of its bandwidths clamped at 1.4) against the reference, and bit for bit against its source."""
+    import copy
+
+    name = "pend_k2_minbw"
+    g = golden(name)
+    src = make_ctx(g, name)
+    c = copy.deepcopy(src)
+    theta = g["theta0"]
+    mu, mix = _prior_at(g, 0, theta)
+    for x in (src, c):
+        x.set_theta(theta)
+        x.set_prior(mu, mix)
+    phi0, _, _ = src.svmpc_phi(g["costs"][0, 0], g["actions"][0, 0])
+    phi1, _, gp = c.svmpc_phi(g["costs"][0, 0], g["actions"][0, 0])
+    h = c.get_bandwidths()
+    assert 2 <= int((h == np.float32(g["k2_minimum_bw"])).sum()) <= h.size - 2, "the clone lost minimum_bw"
+    assert np.array_equal(phi0, phi1)
+    assert elemerr(phi1, g["phi"][0, 0]) < k2_tolerance(theta, h, False, int(g["da"]))
+    c.close()
+    src.close()
+
+
 @pytest.mark.parametrize("name", K1_F64_CASES)
 def test_k1_phi_vs_float64_reference(golden, name):
     """The K1 branch on the HIP path against the reference's own K1 call evaluated in float64 on the recorded inputs (no fp32

@@ -217,6 +217,74 @@ def test_serving_next_to_the_dynamics_filter_and_a_second_context():
     assert sb["served"] == 7 and sb["replayed"] == 0, sb
 
 
+def test_cancel_from_another_thread_during_a_served_loop():
+    """dust_create (and the filter's calls) cancel the armed launch from WHATEVER thread they run on, while the owner thread
+    may be spinning on its tick's done word.  The cancelled launch must stay on record until dust_sync has taken the device's abort
+    count for it - otherwise the next launch aborts on a count the host never saw and the settle fails with 'n reported, n - 1 on
+    record'.  A second thread creates and destroys contexts and runs the filter as fast as it can beside 120 served ticks."""
+    import threading
+
+    from dust_amd import MpfContext
+
+    model, N, S, H, iters = "pendulum", 128, 128, 20, 2
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(0.6, 1.3, (32, 2)).astype(np.float32)
+
+    def run(serve, disturb):
+        c, _ = _make(model, N, S, H)
+        st = _state(model)
+        c.svmpc_tick(st, 1)
+        stop = threading.Event()
+        errs = []
+
+        def other():
+            try:
+                mpf = MpfContext(x0, _state(model), model="pendulum", uncertain_params=("length", "mass"), obs_std=0.1, lr=1e-3, init_bw=0.1)
+                k = 0
+                while not stop.is_set():
+                    if k % 2:
+                        d, _ = _make(model, 32, 64, 8)
+                        d.close()
+                    else:
+                        mpf.optimize(np.zeros(1, np.float32), _state(model), 0.1, 2)
+                    k += 1
+                mpf.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = threading.Thread(target=other)
+        if serve:
+            c.serve_start(iters, 5000.0)
+        if disturb:
+            th.start()
+        out = []
+        try:
+            for t in range(120):
+                r = c.svmpc_tick(st, iters)
+                out.append((r[0].copy(), r[1].copy()))
+                st = _plant(model, st, r[0][0])
+        finally:
+            stop.set()
+            if disturb:
+                th.join()
+        if serve:
+            c.serve_stop()
+        theta = c.get_theta()
+        stats = c.tick_stats()
+        c.close()
+        assert not errs, errs
+        return out, theta, stats
+
+    oa, ta, _ = run(False, False)
+    ob, tb, sb = run(True, True)
+    # a tick that did not start next to the other thread's kernels is replayed on the launch-per-iteration path (other summation order)
+    tol = 0.0 if sb["replayed"] == 0 else 2e-3
+    for t, (x, y) in enumerate(zip(oa, ob)):
+        assert np.allclose(x[0], y[0], rtol=tol, atol=tol), (t, sb)
+    assert np.allclose(ta, tb, rtol=tol, atol=tol * 10), sb
+    assert sb["served"] + sb["replayed"] >= 100, sb
+
+
 def test_serve_start_rejects_what_it_cannot_serve():
     from dust_amd import Context
     from dust_amd._lib import DustError
