@@ -34,6 +34,7 @@
 #include "pairwise_fused.hpp"
 #include "pairwise_logp_mfma.hpp"
 #include "pairwise_far.hpp"
+#include "pairwise_packed.hpp"
 #include "skid.hpp"
 #include "particle_general.hpp"
 #include "rollout.hpp"
@@ -118,9 +119,12 @@ struct dust_ctx {
   bool no_handoff;           // replay of a tick that found the device shared: plain kernels only, nothing that spins on its own grid
   unsigned long persist_declined;  // key of the (shape, state) for which the one-launch ticks last declined: no staging for it again
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
-  float *nzf;                // [chunks][nz_ld] bytes: non-zero flags of the Gram blocks (pairwise_fused.hpp), or unused (DUST_DENSE)
-  size_t nzf_cap;
-  int nz_ld;                 // 0: the last fused pass ran dense
+  // pairwise_packed.hpp: the near-key lists of the last large-set pass 1 - key indices [tiles][chunks * 64], unit offsets
+  // [tiles][chunks + 1], unit query masks [tiles][chunks][4], slice boundaries of pass 1 / pass 2, non-zero flags of the units' kernel blocks
+  float *pk_idx, *pk_uoff, *pk_uq, *pk_soff, *pk_goff, *pk_nzu;
+  size_t pk_idx_cap, pk_uoff_cap, pk_uq_cap, pk_soff_cap, pk_goff_cap, pk_nzu_cap;
+  int pk_tiles, pk_umax, pk_jsg;  // geometry of those lists
+  bool pk_masks, pk_dense;        // the units carry query masks / pass 2 visits every unit (DUST_DENSE)
   float *far_z, *far_n, *far_f;  // pairwise_far.hpp: binary16 rows, (norms, log weights), unit flags [tiles][chunks] bytes
   size_t far_z_cap, far_n_cap, far_f_cap;
   int far_tiles, far_chunks;  // geometry of the flags the last fused pass used (0: none)
@@ -134,8 +138,8 @@ struct dust_ctx {
   float *far_g;               // the flags of the last log-p pass [groups][chunks] bytes
   size_t far_g_cap;
   int far_groups, far_gchunks;
-  int fused_js;  // slices of the repulsion partials of the last pairwise_fused_kernel launch (update_kernel merges them)
-  int prior_js;  // slices of the prior partials when pairwise_fused_kernel wrote them (its own split); 0 = pair_geometry's
+  int fused_js;  // slices of the repulsion partials of the last pairwise_packed_kernel launch (update_kernel merges them)
+  int prior_js;  // slices of the prior partials when pairwise_packed_kernel wrote them (its own split); 0 = pair_geometry's
   // staging
   float *noise_stage, *actions, *states, *params_dev, *state_dev, *tmp, *costs_stage, *tile_scratch;
   size_t noise_cap, actions_cap, states_cap, params_cap, tmp_cap, tile_cap;
@@ -192,6 +196,7 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    int pack_merge;  // DUST_PACK_MERGE=0: PLAIN run lists even below the exact-zero threshold (development switch)
     float far_t;  // DUST_FAR_T: the far pre-pass' threshold (pairwise_far.hpp), default DUST_FAR_T_DEFAULT
   } env;
   struct T2Replay {
@@ -398,7 +403,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->nzf, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->pk_idx, &c->pk_uoff, &c->pk_uq, &c->pk_soff, &c->pk_goff, &c->pk_nzu, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -452,6 +457,7 @@ static void env_read(dust_ctx *c) {
   c->env.tick2_test_abort = env_int("DUST_TICK2_TEST_ABORT");
   c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
   c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
+  c->env.pack_merge = env_int("DUST_PACK_MERGE");
   const char *ft = getenv("DUST_FAR_T");
   c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
@@ -1119,22 +1125,11 @@ static bool pair_fused_ok(const dust_ctx *c) {
 }
 // key slices: `tiles` is the query-tile count of the PRIMARY kernel of the current state; a launcher whose kernel has another
 // tile size recomputes it (the partial-output layout [js][n_local][ldp] does not depend on the tile size)
-// workgroups of pairwise_fused_kernel for `units` (query tile, key chunk) units: two stay resident per CU.  Two rounds of
-// half-length workgroups run 4 % faster than one (their phases drift apart: 2 460 vs 2 565 us at cfg4) as long as a workgroup
-// keeps >= 16 chunks to amortise its tile prologue / partial rows over; below that (a rank of an 8-way sharded cfg4: 5.5 chunks)
-// one round - half the partial rows for the merge and update kernels (523 vs 536 us per iteration there)
 static int device_cus(const dust_ctx *c) {
   static int n_cu = 0;
   if (!n_cu && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) n_cu = 256;
   return n_cu;
 }
-static int fused_slots(const dust_ctx *c, long units) {
-  static const char *env = getenv("DUST_FUSED_SLOTS");  // development switch
-  if (env) return atoi(env);
-  const int n_cu = device_cus(c);
-  return units >= 16L * 4 * n_cu ? 4 * n_cu : 2 * n_cu;
-}
-
 static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   const bool fz = pair_fused_ok(c);
   const int ti = fz ? fused_tq(c->D) : (pair_big_kernel(c) ? 4096 / pair_dpb(c->D) : PAIR_TI);
@@ -1143,7 +1138,7 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   int js = (512 + *tiles - 1) / *tiles;
   js = std::max(1, std::min(js, chunks));
   if (fz) {
-    // (the regular grid of the log-p-only kernel; pairwise_fused_kernel itself splits the work by fused_geometry below)
+    // (the regular grid of the log-p-only kernel; pairwise_packed_kernel itself splits the work by fused_geometry below)
     // three workgroups per CU stay resident: pick the slice count whose grid fills whole rounds best (a small penalty per slice:
     // every slice repeats the tile prologue and adds a row of partial outputs)
     double best = -1.0;
@@ -1162,15 +1157,6 @@ static void pair_geometry(const dust_ctx *c, int *tiles, int *JS, int *slice) {
   *JS = (c->N + *slice - 1) / *slice;
 }
 
-// pairwise_fused_kernel: tiles x chunks units in equal contiguous runs, one per resident workgroup (fused_balance); JS = the
-// largest number of runs that touch one tile = partial rows per particle
-static void fused_geometry(const dust_ctx *c, int *tiles, int *W, int *JS) {
-  const int ti = fused_tq(c->D);
-  *tiles = (c->nloc + ti - 1) / ti;
-  const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
-  fused_balance(*tiles, chunks, fused_slots(c, (long)*tiles * chunks), W, JS);
-}
-
 static int cpt_for(int D) { return D <= 32 ? 4 : (D <= 64 ? 8 : (D <= 96 ? 12 : 16)); }  // pass-B columns per lane
 
 static PriorMerge prior_merge_args(const dust_ctx *c) {
@@ -1178,7 +1164,7 @@ static PriorMerge prior_merge_args(const dust_ctx *c) {
   memset(&pm, 0, sizeof pm);
   int tiles, slice;
   pair_geometry(c, &tiles, &pm.JS, &slice);
-  if (c->prior_js) pm.JS = c->prior_js;  // (the partials came from pairwise_fused_kernel: its own slice count)
+  if (c->prior_js) pm.JS = c->prior_js;  // (the partials came from pairwise_packed_kernel: its own slice count)
   pm.n_local = c->nloc;
   pm.ldp = 8 * cpt_for(c->D);
   pm.pA = c->pA;
@@ -1887,23 +1873,32 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
-static void gram_geometry(const dust_ctx *c, int *JS, int *slice);
 static int ensure_partials(dust_ctx *c, int JS);
 static int far_counts_alloc(dust_ctx *c);
 
-// pass 1 of the fused pair (pairwise_fused.hpp): prior partials + repulsion partials + the Gram matrix of the current theta
+// slices per query tile of the two run-list passes (pairwise_packed.hpp): about two resident rounds of workgroups when every
+// slice has units, at most 24 partial rows per particle for the merge kernels.  Static - a function of the shape alone: the
+// summation order does not depend on the data, and a captured tick keeps its grid.
+static int packed_slices(const dust_ctx *c, int tiles, int chunks) {
+  static const char *env = getenv("DUST_PACK_JS");  // development switch
+  if (env) return std::max(1, std::min(chunks, atoi(env)));
+  const int want = (4 * device_cus(c) + tiles - 1) / tiles;
+  return std::max(1, std::min(std::min(chunks, 24), want));
+}
+
+// pass 1 of the fused pair (pairwise_packed.hpp): prior partials + repulsion partials + the kernel blocks of the current theta
 static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
-  const int dpb = fused_dpb(a.D);
+  const int dpb = fused_dpb(a.D), tq = fused_tq(a.D);
+  const int chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
   TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb));
-  const int ldK = ((c->N + 63) / 64) * 64;
-  TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)tiles * fused_tq(a.D) * ldK));  // whole query tiles: the kernel stores rows unconditionally
+  TRY(ensure(&c->kmat, &c->kmat_cap, (size_t)tiles * chunks * tq * 64));  // [tiles][chunks][TQ][64]: touched only where units exist
   const bool whole_rows = a.D == dpb;  // (D = 80: the rows are their own padded copy - no pad_rows launch, 7 us per pass at N = 16 384)
   if (!whole_rows) {
     const int n = c->N * dpb;
     pad_rows_kernel<<<(n + 255) / 256, 256, 0, c->pair_stream>>>(a.X, c->xpad, c->N, a.D, dpb);
     HIP_TRY(hipGetLastError());
   }
-  PairFusedArgs b;
+  PairPackedArgs b;
   memset(&b, 0, sizeof b);
   b.p = a;
   b.Xp = whole_rows ? a.X : c->xpad;
@@ -1912,21 +1907,15 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   b.wP[1] = a.da == 2 ? a.inv_s[1] * a.inv_s[1] : b.wP[0];
   const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
   b.wS[0] = b.wS[1] = (1.0f / ell) * (1.0f / ell);
-  b.K = c->kmat;
-  b.ldK = ldK;
+  b.Kp = c->kmat;
   b.tiles = tiles;
-  b.chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
-  c->nz_ld = 0;
-  if (c->env.dense < 0) {  // flags of the all-zero Gram blocks (development switch: evaluate everything)
-    const int rows = std::max(tiles * fused_tq(a.D), ((c->nloc + 63) / 64) * 64);
-    c->nz_ld = ((rows + 63) / 64) * 64;
-    TRY(ensure(&c->nzf, &c->nzf_cap, ((size_t)b.chunks * c->nz_ld + 3) / 4));
-    b.nz = reinterpret_cast<unsigned char *>(c->nzf);
-    b.ldnz = c->nz_ld;
-  }
+  b.umax = chunks;
+  const bool dense = c->env.dense >= 0;  // (development switch: evaluate everything)
   c->far_tiles = c->far_chunks = 0;
+  PackArgs pk;
+  memset(&pk, 0, sizeof pk);
   if (c->cfg.kernel == DUST_KERNEL_K1_RBF) {  // pairwise_far.hpp: where the running maxima start (every mode), and the far units
-    const bool flags = b.nz && c->env.far != 0;  // (DUST_FAR=0 / DUST_DENSE=1: visit all)
+    const bool flags = !dense && c->env.far != 0;  // (DUST_FAR=0 / DUST_DENSE=1: visit all)
     FarArgs f;
     memset(&f, 0, sizeof f);
     f.N = c->N;
@@ -1934,16 +1923,16 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.i0 = a.i0;
     f.n_local = c->nloc;
     f.tiles = tiles;
-    f.q_rows = tiles * fused_tq(a.D);
+    f.q_rows = tiles * tq;
     f.lscale = 1.0f;
-    f.chunks = b.chunks;
+    f.chunks = chunks;
     f.X = a.X;
     f.logmix = a.logmix;
     f.sg[0] = sqrtf(std::min(b.wS[0], b.wP[0]));
     f.sg[1] = sqrtf(std::min(b.wS[1], b.wP[1]));
     TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * far_zh(dpb) + 1) / 2));
-    TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + b.chunks));
-    TRY(ensure(&c->far_f, &c->far_f_cap, ((size_t)tiles * b.chunks + 3) / 4));
+    TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + chunks));
+    TRY(ensure(&c->far_f, &c->far_f_cap, ((size_t)tiles * chunks + 3) / 4));
     f.Z = reinterpret_cast<_Float16 *>(c->far_z);
     f.nrm = c->far_n;
     f.lms = c->far_n + c->N;
@@ -1953,22 +1942,20 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.wP[0] = b.wP[0];
     f.wP[1] = b.wP[1];
     f.far = reinterpret_cast<unsigned char *>(c->far_f);
-    f.nz = b.nz;
-    f.ldnz = b.ldnz;
     if (flags) {
-      TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * b.chunks * 8));
+      TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * chunks * 8));
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
       TRY(far_counts_alloc(c));
-      if (c->far_cnt_host) {  // {far units, all units} of this pass, for the NEXT launch's work split (below)
+      if (c->far_cnt_host) {  // {far units, all units} of this pass (dust_debug_far_units)
         f.count = reinterpret_cast<unsigned int *>(c->far_cnt);
         f.host_count = c->far_cnt_host;
       }
     }
     const int gx = (tiles + 3) / 4;
     const int want = std::max(1, (3 * device_cus(c) + gx - 1) / gx);  // (three resident workgroups per CU: the launch is bound by the latency of its key loads)
-    f.cps = std::max(1, (b.chunks + want - 1) / want);
-    dim3 fgrid(gx, (b.chunks + f.cps - 1) / f.cps);
-    const int nq = std::min(c->N - a.i0, tiles * fused_tq(a.D));
+    f.cps = std::max(1, (chunks + want - 1) / want);
+    dim3 fgrid(gx, (chunks + f.cps - 1) / f.cps);
+    const int nq = std::min(c->N - a.i0, tiles * tq);
 #define DUST_LAUNCH_FAR(DPB)                                                                         \
   do {                                                                                               \
     far_lb_kernel<DPB><<<(nq + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);            \
@@ -1984,41 +1971,62 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     HIP_TRY(hipGetLastError());
     b.m0 = f.m0;
     if (flags) {
-      b.far = f.far;
-      b.qmask = f.qmask;
+      pk.far = f.far;
+      pk.qmask = f.qmask;
       c->far_tiles = tiles;
-      c->far_chunks = b.chunks;
+      c->far_chunks = chunks;
     }
   }
-  int W, tl;
-  fused_geometry(c, &tl, &W, &b.p.JS);  // (a.JS / a.slice describe the regular grid of the other kernels)
-  // A rank of a sharded run has few query tiles (22 at cfg4 / 8) under 512 workgroups: 23 partial rows per particle for the merge
-  // kernels to read, written whether or not their workgroup found a live unit.  While the pre-pass leaves nearly everything out
-  // (its counts of the previous pass, read unsynchronised from pinned memory) two runs per tile are plenty: 60 -> ~25 us.
-  if (b.far && c->nloc < c->N && !c->capturing && c->far_cnt_host) {
-    volatile unsigned int *hc = c->far_cnt_host;
-    const unsigned int fa = hc[0], al = hc[1];
-    const int few = std::max(64, 2 * tiles);
-    if (al && (double)fa > 0.9 * (double)al && few < W) fused_balance(tiles, b.chunks, few, &W, &b.p.JS);
-  }
-  c->fused_js = b.p.JS;
-  int jsg, slg;
-  gram_geometry(c, &jsg, &slg);
-  TRY(ensure_partials(c, std::max(std::max(a.JS, b.p.JS), jsg)));  // before anything is written: pass 2 adds its pA rows later
+  // the run lists: MERGED below the exact-zero threshold, PLAIN (bit-identical to visiting every chunk) otherwise
+  const int JS = packed_slices(c, tiles, chunks);
+  b.p.JS = JS;
+  pk.N = c->N;
+  pk.tiles = tiles;
+  pk.chunks = chunks;
+  pk.merge = (pk.qmask != nullptr && c->env.far_t < DUST_FAR_T_EXACT && c->env.pack_merge != 0) ? 1 : 0;
+  pk.JS = JS;
+  pk.JSG = JS;
+  pk.ldi = chunks * 64;
+  TRY(ensure(&c->pk_idx, &c->pk_idx_cap, (size_t)tiles * pk.ldi));
+  TRY(ensure(&c->pk_uoff, &c->pk_uoff_cap, (size_t)tiles * (chunks + 1)));
+  TRY(ensure(&c->pk_uq, &c->pk_uq_cap, (size_t)tiles * chunks * 4));
+  TRY(ensure(&c->pk_soff, &c->pk_soff_cap, (size_t)tiles * (JS + 1)));
+  TRY(ensure(&c->pk_goff, &c->pk_goff_cap, (size_t)tiles * (JS + 1)));
+  TRY(ensure(&c->pk_nzu, &c->pk_nzu_cap, ((size_t)tiles * chunks + 3) / 4));
+  pk.kidx = reinterpret_cast<int *>(c->pk_idx);
+  pk.uoff = reinterpret_cast<int *>(c->pk_uoff);
+  pk.uq = reinterpret_cast<unsigned int *>(c->pk_uq);
+  pk.soff = reinterpret_cast<int *>(c->pk_soff);
+  pk.goff = reinterpret_cast<int *>(c->pk_goff);
+  far_pack_kernel<<<tiles, 256, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);
+  HIP_TRY(hipGetLastError());
+  c->pk_tiles = tiles;
+  c->pk_umax = chunks;
+  c->pk_jsg = JS;
+  c->pk_masks = pk.qmask != nullptr;
+  c->pk_dense = dense || c->cfg.kernel != DUST_KERNEL_K1_RBF;
+  b.kidx = pk.kidx;
+  b.ldi = pk.ldi;
+  b.uoff = pk.uoff;
+  b.uq = c->pk_masks ? pk.uq : nullptr;
+  b.soff = pk.soff;
+  b.nzu = c->pk_dense ? nullptr : reinterpret_cast<unsigned char *>(c->pk_nzu);
+  c->fused_js = JS;
+  TRY(ensure_partials(c, std::max(a.JS, JS)));  // before anything is written: pass 2 adds its pA rows later
   b.p.pA = c->pA;
   b.p.pM = c->pM;
   b.p.pL = c->pL;
-  c->prior_js = b.p.JS;
-  // the Gram rows are streamed past the caches when they exceed what L2 + Infinity Cache would hand to pass 2 anyway
-  const bool stream_k = (size_t)c->nloc * ldK * sizeof(float) > ((size_t)128 << 20);
+  c->prior_js = JS;
+  // the kernel blocks are streamed past the caches when they exceed what L2 + Infinity Cache would hand to pass 2 anyway
+  const bool stream_k = !pk.merge && (size_t)c->nloc * chunks * 64 * sizeof(float) > ((size_t)128 << 20);
   b.pB = c->pB;
-  dim3 grid(W);
-#define DUST_LAUNCH_FUSED2(MODE, DPB, SK)                                                                                                     \
-  do {                                                                                                                                        \
-    const size_t lds = pairwise_fused_lds_bytes<DPB>();                                                                                       \
-    if (lds > 64 * 1024 && !c->capturing)                                                                                                     \
-      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_fused_kernel<MODE, DPB, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    pairwise_fused_kernel<MODE, DPB, SK><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                          \
+  dim3 grid(tiles, JS);
+#define DUST_LAUNCH_FUSED2(MODE, DPB, SK)                                                                                                      \
+  do {                                                                                                                                         \
+    const size_t lds = pairwise_packed_lds_bytes<DPB>();                                                                                       \
+    if (lds > 64 * 1024 && !c->capturing)                                                                                                      \
+      HIP_TRY(hipFuncSetAttribute((const void *)pairwise_packed_kernel<MODE, DPB, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    pairwise_packed_kernel<MODE, DPB, SK><<<grid, PAIR_NT, lds, c->pair_stream>>>(b);                                                          \
   } while (0)
 #define DUST_LAUNCH_FUSED(MODE, DPB)                   \
   do {                                                 \
@@ -2210,47 +2218,38 @@ static int launch_pair_logp_big(dust_ctx *c, const PairArgs &a, int tiles) {
   return DUST_OK;
 }
 
-// key slices of pass 2: its own regular grid (64-query tiles x slices), one resident round of four workgroups per CU when the
-// set allows it - the fewer slices, the fewer partial rows the update kernel has to sum
-static void gram_geometry(const dust_ctx *c, int *JS, int *slice) {
-  const int tiles = (c->nloc + 63) / 64, chunks = (c->N + PAIR_JC - 1) / PAIR_JC;
-  static const char *env = getenv("DUST_GRAM_SLOTS");  // development switch
-  const int slots = env ? atoi(env) : 8 * device_cus(c);
-  int js = std::max(1, std::min(chunks, slots / tiles));
-  const int cps = (chunks + js - 1) / js;
-  *slice = cps * PAIR_JC;
-  *JS = (c->N + *slice - 1) / *slice;
-}
-
-// pass 2: pA = K x score over key slices (matrix cores)
+// pass 2: pA = K x score over the run lists of pass 1 (matrix cores; pairwise_packed.hpp)
 static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
-  const int dpb = fused_dpb(a.D);
-  GramScoreArgs g;
+  GramPackedArgs g;
   memset(&g, 0, sizeof g);
   g.N = c->N;
   g.D = c->D;
-  g.i0 = c->n0;
   g.n_local = c->nloc;
-  gram_geometry(c, &g.JS, &g.slice);  // (the partial buffers were sized for it by launch_pair_fused)
+  g.JS = c->pk_jsg;
   *JS_out = g.JS;
   g.ldp = 8 * cpt_for(a.D);
-  g.ldK = ((c->N + 63) / 64) * 64;
-  g.K = c->kmat;
-  g.nz = c->nz_ld ? reinterpret_cast<const unsigned char *>(c->nzf) : nullptr;
-  g.ldnz = c->nz_ld;
+  g.tiles = c->pk_tiles;
+  g.umax = c->pk_umax;
+  g.Kp = c->kmat;
   g.V = c->score;
   g.pA = c->pA;
-  dim3 grid((c->nloc + 63) / 64, g.JS);
-  // (its own column padding: whole 16-column MFMA tiles, not the 32 / 64 / 80 of pass 1 - D = 40 runs 3 column tiles instead of 4)
-#define DUST_LAUNCH_GS(DPB) gram_score_kernel<DPB><<<grid, PAIR_NT, gram_score_lds_bytes<DPB>(), c->stream>>>(g)
+  g.kidx = reinterpret_cast<const int *>(c->pk_idx);
+  g.ldi = c->pk_umax * 64;
+  g.uoff = reinterpret_cast<const int *>(c->pk_uoff);
+  g.uq = c->pk_masks ? reinterpret_cast<const unsigned int *>(c->pk_uq) : nullptr;
+  g.goff = reinterpret_cast<const int *>(c->pk_goff);
+  g.nzu = c->pk_dense ? nullptr : reinterpret_cast<const unsigned char *>(c->pk_nzu);
+  dim3 grid(g.tiles, g.JS);
+  // (its own column padding: whole 16-column MFMA tiles, not the 32 / 64 / 80 of pass 1 - D = 40 runs 3 column tiles instead of 4;
+  //  the query tile is pass 1's: 128 / 112 / 96 rows at D <= 32 / 64 / 80)
+#define DUST_LAUNCH_GS(DPG, TQ) gram_packed_kernel<DPG, TQ><<<grid, GramGeom<TQ>::NT, gram_packed_lds_bytes<DPG, TQ>(), c->stream>>>(g)
   const int dpg = ((a.D + 15) / 16) * 16;
-  if (dpg == 16) DUST_LAUNCH_GS(16);
-  else if (dpg == 32) DUST_LAUNCH_GS(32);
-  else if (dpg == 48) DUST_LAUNCH_GS(48);
-  else if (dpg == 64) DUST_LAUNCH_GS(64);
-  else DUST_LAUNCH_GS(80);
+  if (dpg == 16) DUST_LAUNCH_GS(16, FusedGeom<32>::TQ);
+  else if (dpg == 32) DUST_LAUNCH_GS(32, FusedGeom<32>::TQ);
+  else if (dpg == 48) DUST_LAUNCH_GS(48, FusedGeom<64>::TQ);
+  else if (dpg == 64) DUST_LAUNCH_GS(64, FusedGeom<64>::TQ);
+  else DUST_LAUNCH_GS(80, FusedGeom<80>::TQ);
 #undef DUST_LAUNCH_GS
-  (void)dpb;
   HIP_TRY(hipGetLastError());
   return DUST_OK;
 }
@@ -2596,7 +2595,7 @@ static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K
   }
   c->kmat_valid = false;  // (theta moves below; a later Stein pass without a fresh prior pass recomputes)
   UpdateArgs u = update_args(c, apply);
-  if (jsa) {  // pA from pass 2 (its own slices), pB from pairwise_fused_kernel
+  if (jsa) {  // pA from pass 2 (its own slices), pB from pairwise_packed_kernel
     u.JSA = jsa;
     u.JS = c->fused_js;
   }
@@ -4412,15 +4411,29 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
   return DUST_OK;
 }
 
-// (not part of include/dust_amd.h) host arithmetic of pairwise_fused_kernel's work split (no device involved: callable in a CPU-only process)
-extern "C" int dust_debug_fused_balance(int tiles, int chunks, int slots, int *W, int *JS) {
-  if (tiles < 1 || chunks < 1 || slots < 1 || !W || !JS) return DUST_ERR_INVALID;
-  fused_balance(tiles, chunks, slots, W, JS);
+// The run lists of the last large-set pass 1 (pairwise_packed.hpp), one query tile: *n_units, the unit offsets [n_units + 1], the key
+// indices [uoff[n_units]], the unit query masks [n_units][4] and the slice boundaries [js + 1] of pass 1.  A test hook (not in
+// include/dust_amd.h): tests/test_gpu_parity.py checks the lists against the masks they were built from.
+extern "C" int dust_debug_pack_lists(dust_ctx *c, int tile, int *n_units, int *js, int *uoff, int *kidx, unsigned int *uq, int *soff) {
+  if (!c || !n_units || !js) return fail(DUST_ERR_INVALID, "null argument");
+  if (!c->pk_tiles || tile < 0 || tile >= c->pk_tiles) return fail(DUST_ERR_STATE, "no run lists (or no such tile)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int JS = c->pk_jsg, um = c->pk_umax;
+  std::vector<int> so((size_t)JS + 1);
+  HIP_TRY(hipMemcpy(so.data(), reinterpret_cast<int *>(c->pk_soff) + (size_t)tile * (JS + 1), so.size() * sizeof(int), hipMemcpyDeviceToHost));
+  const int U = so[JS];
+  *n_units = U;
+  *js = JS;
+  if (soff) memcpy(soff, so.data(), so.size() * sizeof(int));
+  std::vector<int> uo((size_t)U + 1);
+  HIP_TRY(hipMemcpy(uo.data(), reinterpret_cast<int *>(c->pk_uoff) + (size_t)tile * (um + 1), uo.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (uoff) memcpy(uoff, uo.data(), uo.size() * sizeof(int));
+  if (kidx && uo[U] > 0) HIP_TRY(hipMemcpy(kidx, reinterpret_cast<int *>(c->pk_idx) + (size_t)tile * um * 64, (size_t)uo[U] * sizeof(int), hipMemcpyDeviceToHost));
+  if (uq && U > 0) HIP_TRY(hipMemcpy(uq, reinterpret_cast<unsigned int *>(c->pk_uq) + (size_t)tile * um * 4, (size_t)U * 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return DUST_OK;
 }
 
-// (not part of include/dust_amd.h) how many (query tile, key chunk) units the last fused pairwise pass left out as exact zeros
-// (pairwise_far.hpp): out[0] = far units, out[1] = all units (0 0: the pass ran without the pre-pass).  Synchronises.
 extern "C" int dust_debug_far_units(dust_ctx *c, long long *out2) {
   if (!c || !out2) return fail(DUST_ERR_INVALID, "null argument");
   out2[0] = out2[1] = 0;

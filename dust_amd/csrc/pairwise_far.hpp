@@ -1,4 +1,4 @@
-// pairwise_far.hpp - which (query tile, key chunk) units of pairwise_fused_kernel contribute EXACTLY nothing, decided on the
+// pairwise_far.hpp - which (query tile, key chunk) units of pairwise_packed_kernel contribute EXACTLY nothing, decided on the
 // matrix cores before the exact-difference pass runs (svmpc.py:38-41 prior gradient, 76-83 Stein kernel; K1 only).
 //
 // In H d_a = 80 dimensions a spread-out particle set has no near neighbours: the K1 value exp(-d2_S / 2) and the prior's softmax
@@ -200,7 +200,7 @@ static inline size_t far_flags_lds_bytes() {
   return 2 * ((size_t)64 * (far_zh(DPB) + 8) * sizeof(_Float16) + 2 * 64 * sizeof(float));
 }
 
-// Workgroup = 4 waves = 4 query tiles (TQ rows each - the consumer's tile: pairwise_fused_kernel's, or the 64 queries of a wave of
+// Workgroup = 4 waves = 4 query tiles (TQ rows each - the consumer's tile: pairwise_packed_kernel's, or the 64 queries of a wave of
 // pairwise_logp_mfma_kernel - held in registers as B operands), the key
 // chunks of its slice streamed through LDS (double buffered, one barrier per chunk); a wave runs TQ / 16 MFMAs per 16-byte LDS read.
 template <int DPB, int TQ, bool MASKS>

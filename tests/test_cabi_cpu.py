@@ -106,7 +106,7 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
                                            r"pairwise_big_kernelILi\d+ELi32E|"
                                            # round 2: the stored-states kernel's fast instances (3 = the general path), the
                                            # fused large-set pairwise passes, the Gram x score GEMM, the log p pass
-                                           r"particle_states_kernelILi[012]E|pendulum_states_kernelILb0E|pairwise_fused_kernel|gram_score_kernel|"
+                                           r"particle_states_kernelILi[012]E|pendulum_states_kernelILb0E|pairwise_packed_kernel|gram_packed_kernel|"
                                            r"pairwise_logp_big_kernel", k)]
     assert len(hot) >= 45, sorted(kernels)
     bad = {k: kernels[k] for k in hot if kernels[k] != (0, 0)}
@@ -178,37 +178,3 @@ def test_every_barrier_drains_lds_first(built, tmp_path):
             bad.append(i)
     assert total > 500, total
     assert not bad, "%d of %d barriers without an LDS drain right before them (first at disassembly line %d)" % (len(bad), total, bad[0])
-
-
-def test_fused_pairwise_work_split(built):
-    """pairwise_fused.hpp fused_balance: the T = tiles x chunks units (query tile, 64-key chunk), tile-major, are cut into W equal
-    contiguous runs; a run that crosses a tile boundary flushes per tile, and the runs covering a tile are its partial slices
-    0 .. m - 1 in order.  The kernel derives a run's slice index from its workgroup number alone - s - first_wg(tile * chunks) with
-    first_wg(u) = ((u + 1) W - 1) / T - and the host sizes the partial buffers with JS = max m: both against a plain enumeration."""
-    lib = C.CDLL(built)
-    lib.dust_debug_fused_balance.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    rng = __import__("numpy").random.default_rng(4)
-    shapes = [(171, 256, 1024), (171, 256, 512), (22, 256, 512), (11, 32, 512), (16, 32, 512), (43, 64, 512), (1, 1, 512), (3, 7, 5)]
-    shapes += [(int(rng.integers(1, 200)), int(rng.integers(1, 300)), int(rng.choice([256, 512, 768, 1024]))) for _ in range(40)]
-    for tiles, chunks, slots in shapes:
-        W, JS = C.c_int(), C.c_int()
-        assert lib.dust_debug_fused_balance(tiles, chunks, slots, C.byref(W), C.byref(JS)) == 0
-        W, JS, T = W.value, JS.value, tiles * chunks
-        assert W == min(slots, T)
-        seen = {}  # tile -> list of (ordinal, first chunk, last chunk + 1)
-        covered = 0
-        for s in range(W):
-            u, u1 = s * T // W, (s + 1) * T // W
-            assert u1 - u in (T // W, T // W + 1)  # equal runs to within one chunk
-            while u < u1:
-                tile, c0 = divmod(u, chunks)
-                c1 = min(chunks, c0 + (u1 - u))
-                ordinal = s - ((tile * chunks + 1) * W - 1) // T  # the kernel's expression
-                seen.setdefault(tile, []).append((ordinal, c0, c1))
-                covered += c1 - c0
-                u += c1 - c0
-        assert covered == T and sorted(seen) == list(range(tiles))
-        for tile, segs in seen.items():
-            assert [o for o, _, _ in segs] == list(range(len(segs))), (tiles, chunks, slots, tile, segs)  # slices 0 .. m - 1, in key order
-            assert segs[0][1] == 0 and segs[-1][2] == chunks and all(a[2] == b[1] for a, b in zip(segs, segs[1:]))
-        assert JS == max(len(v) for v in seen.values())

@@ -2,7 +2,7 @@
 """Development check on the generated gfx950 code: every s_barrier must be preceded - on every fall-through path inside its basic
 block - by `s_waitcnt lgkmcnt(0)` with no LDS instruction in between.  The compiler leaves that wait out of __syncthreads() when
 it believes no LDS operation is pending (seen at a loop header whose back edge ends in ds_write_b128: round-2 race in
-pairwise_fused_kernel); s_barrier itself does not wait for LDS writes still queued in the issuing SIMD.
+pairwise_packed_kernel); s_barrier itself does not wait for LDS writes still queued in the issuing SIMD.
 
   hipcc --offload-arch=gfx950 -O3 -Iinclude -S --cuda-device-only dust_amd/csrc/dust_amd.hip -o /tmp/dust.s
   python tools/barrier_audit.py /tmp/dust.s

@@ -44,3 +44,34 @@ for q, k in ((96, 64), (64, 64), (16, 64), (2, 64), (1, 64), (16, 16), (64, 16),
     nq, nk = N // q * q, N // k * k
     blk = near[:nq, :nk].reshape(nq // q, q, nk // k, k).any(axis=(1, 3))
     print("  blocks %3d queries x %2d keys: %.4f without a near pair" % (q, k, 1.0 - blk.mean()))
+
+# --- round 6: how long are a query tile's near-key lists (pairwise_packed.hpp), and what would ordering the queries by cluster buy? ---
+def list_stats(order, name):
+    tiles = [order[t:t + 96] for t in range(0, N, 96)]
+    L = np.array([int(near[t].any(axis=0).sum()) for t in tiles])          # merged list: keys near to SOME query of the tile
+    qshare = []
+    for t in tiles[::8]:
+        keys = np.flatnonzero(near[t].any(axis=0))
+        for u0 in range(0, len(keys), 64):
+            qshare.append(float(near[np.ix_(t, keys[u0:u0 + 64])].any(axis=1).mean()))
+    units = int(np.ceil(L / 64.0).sum())
+    print("  %-34s list length per tile: mean %.0f, max %d; packed units %d; near queries per unit %.2f" % (name, L.mean(), L.max(), units, float(np.mean(qshare))))
+
+deg = near.sum(1)
+print("near keys per query: mean %.1f, median %d, p90 %d, max %d" % (deg.mean(), int(np.median(deg)), int(np.percentile(deg, 90)), int(deg.max())))
+list_stats(np.arange(N), "index order")
+first_chunk = np.array([int(np.flatnonzero(near[i])[0]) // 64 for i in range(N)])
+list_stats(np.argsort(first_chunk, kind="stable"), "by first near chunk")
+first_key = np.array([int(np.flatnonzero(near[i])[0]) for i in range(N)])
+list_stats(np.argsort(first_key, kind="stable"), "by first near key (leader)")
+# the same from the previous tick's structure is what the device could use; label propagation = connected components of the near graph
+lab = np.arange(N)
+for it in range(20):
+    new = np.array([lab[np.flatnonzero(near[i])].min() for i in range(N)])
+    if (new == lab).all():
+        break
+    lab = new
+sizes = np.bincount(lab)
+sizes = sizes[sizes > 0]
+print("connected components of the near graph: %d (largest %d, singletons %d)" % (len(sizes), sizes.max(), int((sizes == 1).sum())))
+list_stats(np.argsort(lab, kind="stable"), "by connected component")
