@@ -142,6 +142,7 @@ SYMBOLS = {
     "dust_comm_init": (C.c_int, [VP, VP, C.c_int, C.c_int]),
     "dust_comm_destroy": (C.c_int, [VP]),
     "dust_comm_probe": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "dust_comm_peer_gather": (C.c_int, [VP, C.c_int]),
     "dust_set_stream": (C.c_int, [VP, VP]),
     "dust_profile_enable": (C.c_int, [VP, C.c_int]),
     "dust_profile_get": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -194,6 +194,10 @@ class Context:
         L.check(L.load().dust_comm_probe(self._h, int(n_steps), int(reps), C.byref(us)))
         return float(us.value)
 
+    def comm_peer_gather(self, on=True):
+        """The tick's all-gathers as direct peer stores through IPC-mapped buffers (collective: every rank calls it, or none)."""
+        L.check(L.load().dust_comm_peer_gather(self._h, 1 if on else 0))
+
     def close(self):
         if self._h is not None:
             L.load().dust_destroy(self._h)

@@ -35,6 +35,7 @@
 #include "pairwise_logp_mfma.hpp"
 #include "pairwise_far.hpp"
 #include "pairwise_packed.hpp"
+#include "peer_gather.hpp"
 #include "skid.hpp"
 #include "particle_general.hpp"
 #include "rollout.hpp"
@@ -79,6 +80,16 @@ extern "C" int dust_device_count(int *count) {
 static const char *k_names[DUST_K_COUNT] = {"rollout_kernel", "pairwise_kernel<PRIOR>", "pairwise_kernel<STEIN>", "update_kernel",
                                             "forward(finalize+roll)", "bandwidth_kernel", "mpf_kernel", "states_kernel"};
 extern "C" const char *dust_kernel_name(int id) { return (id >= 0 && id < DUST_K_COUNT) ? k_names[id] : ""; }
+
+// peer_gather.hpp: the peers' buffers of the three exchanges (score rows, particles, log-weights) and arrival words, mapped through HIP IPC
+struct PeerState {
+  int world, rank;
+  float *buf[PEER_BUFS][PEER_MAX];    // [which][rank]: entry `rank` is the context's own buffer
+  unsigned int *flags[PEER_MAX];      // arrival words of every rank ([PEER_BUFS][PEER_MAX] each); entry `rank`: flags_local
+  unsigned int *flags_local;          // [PEER_ROWS][PEER_MAX], then the store kernel's workgroup counters [PEER_MAX], then the error word
+  void *opened[PEER_MAX][PEER_BUFS + 1];
+  unsigned int seq[PEER_BUFS];
+};
 
 struct dust_ctx {
   dust_config cfg;
@@ -165,6 +176,7 @@ struct dust_ctx {
   // C-side RCCL communicator of a sharded context (dust_comm_init): the sharded tick issues its all-gathers on the context's stream
   void *comm;  // ncclComm_t
   int comm_rank, comm_world;
+  struct PeerState *peer;  // direct peer-store all-gathers (peer_gather.hpp), or nullptr: the collective library's
   // tick outputs: a_seq_out | p_weights | time-out word of the persistent tick live in ONE device block, copied with ONE
   // hipMemcpyAsync into a pinned host buffer (then one stream synchronisation per tick that returns outputs)
   float *outblk;
@@ -475,6 +487,8 @@ static bool full_cov(const dust_ctx *c) { return c->cfg.full_cov != 0; }
 static bool two_pass_family(const dust_ctx *c) { return c->cfg.model == DUST_MODEL_SKID_STEER || particle_general(c) || full_cov(c); }
 static bool comm_active(const dust_ctx *c) { return c->comm && (c->comm_world > 1 || c->env.comm_force >= 0); }
 static void comm_release(dust_ctx *c);
+extern "C" int dust_comm_peer_gather(dust_ctx *c, int on);
+static int peer_check(dust_ctx *c);
 static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags);
 static bool tick2_shape_ok(dust_ctx *c, int n_steps);
 static int sharded_forward(dust_ctx *c);
@@ -806,7 +820,7 @@ extern "C" int dust_sync(dust_ctx *c) {
       return handoff_timeout(c, "persistent tick kernel: a hand-off wait timed out (results of that tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
     }
   }
-  return DUST_OK;
+  return peer_check(c);
 }
 
 extern "C" int dust_get_config(const dust_ctx *c, dust_config *out) {
@@ -3550,7 +3564,18 @@ static int check(int r, const char *what) {
 }
 }  // namespace rccl
 
+static void peer_release(dust_ctx *c) {
+  PeerState *p = c->peer;
+  if (!p) return;
+  for (int g = 0; g < PEER_MAX; ++g)
+    for (int k = 0; k <= PEER_BUFS; ++k)
+      if (p->opened[g][k]) (void)hipIpcCloseMemHandle(p->opened[g][k]);
+  if (p->flags_local) (void)hipFree(p->flags_local);
+  delete p;
+  c->peer = nullptr;
+}
 static void comm_release(dust_ctx *c) {
+  peer_release(c);
   if (c->comm && rccl::comm_destroy) (void)rccl::comm_destroy(c->comm);
   c->comm = nullptr;
 }
@@ -3589,6 +3614,9 @@ extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) 
   }
   if (c->graph_exec || c->graph_exec_alt) graph_drop(c);
   c->theta_pinned = true;
+  // DUST_PEER_GATHER=1: the tick's all-gathers as direct peer stores (peer_gather.hpp; also dust_comm_peer_gather).  Every rank of a
+  // run sees the same environment, so the set-up collective inside is entered by all of them or by none.
+  if (env_int("DUST_PEER_GATHER") > 0) TRY(dust_comm_peer_gather(c, 1));
   return DUST_OK;
 }
 
@@ -3596,6 +3624,7 @@ extern "C" int dust_comm_destroy(dust_ctx *c) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (c->comm) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    peer_release(c);
     (void)rccl::comm_destroy(c->comm);
     c->comm = nullptr;
   }
@@ -3607,6 +3636,139 @@ static int gather_inplace(dust_ctx *c, float *buf, size_t count) {
   return rccl::check(rccl::all_gather(buf + (size_t)c->comm_rank * count, buf, count, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather");
 }
 
+// ---- peer_gather.hpp: the same exchanges as direct peer stores --------------------------------------------------------------------
+enum { GATHER_SCORE = 0, GATHER_THETA = 1, GATHER_LW = 2 };
+static float *peer_own_buffer(dust_ctx *c, int which) { return which == GATHER_SCORE ? c->score : (which == GATHER_THETA ? c->theta_home : c->lw); }
+
+// Map every peer's three buffers and arrival words (collective: the IPC handles travel through one all-gather of the communicator).
+extern "C" int dust_comm_peer_gather(dust_ctx *c, int on) {
+  if (!c) return fail(DUST_ERR_INVALID, "null ctx");
+  if (!c->comm) return fail(DUST_ERR_STATE, "no communicator (dust_comm_init)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!on) {
+    peer_release(c);
+    return DUST_OK;
+  }
+  if (c->peer) return DUST_OK;
+  if (c->comm_world > PEER_MAX) return fail(DUST_ERR_UNSUPPORTED, "peer-store all-gathers take up to %d ranks (one node)", (int)PEER_MAX);
+  if (c->theta != c->theta_home) return fail(DUST_ERR_STATE, "the particles are not in their home buffer");
+  PeerState *p = new (std::nothrow) PeerState();
+  if (!p) return fail(DUST_ERR_HIP, "out of host memory");
+  memset((void *)p, 0, sizeof *p);
+  p->world = c->comm_world;
+  p->rank = c->comm_rank;
+  c->peer = p;
+  const size_t nflag = (size_t)PEER_ROWS * PEER_MAX + PEER_MAX + 1;
+  int st = DUST_OK;
+  float *hbuf = nullptr;
+  auto bail = [&](int code) {
+    if (hbuf) (void)hipFree(hbuf);
+    peer_release(c);
+    return code;
+  };
+  if (hipMalloc((void **)&p->flags_local, nflag * sizeof(unsigned int)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc (arrival words)"));
+  if (hipMemset(p->flags_local, 0, nflag * sizeof(unsigned int)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMemset (arrival words)"));
+  // my handles -> every rank
+  constexpr size_t HB = sizeof(hipIpcMemHandle_t), PER = (PEER_BUFS + 1) * HB;
+  static_assert(HB % sizeof(float) == 0, "handle size");
+  std::vector<unsigned char> host((size_t)p->world * PER, 0);
+  void *mine[PEER_BUFS + 1] = {c->score, c->theta_home, c->lw, p->flags_local};
+  for (int k = 0; k <= PEER_BUFS; ++k) {
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, mine[k]) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipIpcGetMemHandle (buffer %d): %s", k, hipGetErrorString(hipGetLastError())));
+    memcpy(&host[(size_t)p->rank * PER + k * HB], &h, HB);
+  }
+  if (hipMalloc((void **)&hbuf, host.size()) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc (handle exchange)"));
+  if (hipMemcpy(hbuf, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMemcpy (handle exchange)"));
+  st = rccl::check(rccl::all_gather(hbuf + (size_t)p->rank * (PER / sizeof(float)), hbuf, PER / sizeof(float), rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (IPC handles)");
+  if (st != DUST_OK) return bail(st);
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(host.data(), hbuf, host.size(), hipMemcpyDeviceToHost) != hipSuccess)
+    return bail(fail(DUST_ERR_HIP, "handle exchange"));
+  (void)hipFree(hbuf);
+  hbuf = nullptr;
+  for (int g = 0; g < p->world; ++g) {
+    for (int k = 0; k <= PEER_BUFS; ++k) {
+      void *ptr = mine[k];
+      if (g != p->rank) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, &host[(size_t)g * PER + k * HB], HB);
+        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+          return bail(fail(DUST_ERR_HIP, "hipIpcOpenMemHandle (rank %d, buffer %d): %s", g, k, hipGetErrorString(hipGetLastError())));
+        p->opened[g][k] = ptr;
+      }
+      if (k < PEER_BUFS) p->buf[k][g] = (float *)ptr;
+      else p->flags[g] = (unsigned int *)ptr;
+    }
+  }
+  // nobody stores before every rank has mapped (and zeroed) everything: one more collective as the barrier
+  float *bar = nullptr;
+  if (hipMalloc((void **)&bar, (size_t)p->world * sizeof(float)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc"));
+  st = rccl::check(rccl::all_gather(bar + p->rank, bar, 1, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (barrier)");
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(bar);
+  if (st != DUST_OK) return bail(st);
+  return DUST_OK;
+}
+
+static int peer_store(dust_ctx *c, int which, size_t count) {
+  PeerState *p = c->peer;
+  PeerStoreArgs a;
+  memset(&a, 0, sizeof a);
+  a.count = count;
+  a.offset = (size_t)p->rank * count;
+  a.src = peer_own_buffer(c, which) + a.offset;
+  for (int g = 0; g < p->world; ++g) {
+    a.dst[g] = p->buf[which][g];
+    a.flags[g] = p->flags[g];
+  }
+  a.done = p->flags_local + PEER_ROWS * PEER_MAX;
+  a.handshake = which == GATHER_THETA ? 1 : 0;
+  a.timeout_ticks = 200000000ull;
+  a.world = p->world;
+  a.rank = p->rank;
+  a.which = which;
+  a.seq = ++p->seq[which];
+  if (p->world < 2) return DUST_OK;
+  const int gx = (int)std::max<size_t>(1, std::min<size_t>(48, ((count >> 2) + 255) / 256));
+  peer_store_kernel<<<dim3(gx, p->world - 1), 256, 0, c->stream>>>(a);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+static int peer_wait(dust_ctx *c, int which) {
+  PeerState *p = c->peer;
+  if (p->world < 2) return DUST_OK;
+  PeerWaitArgs w;
+  w.flags = p->flags_local;
+  w.err = p->flags_local + PEER_ROWS * PEER_MAX + PEER_MAX;
+  w.world = p->world;
+  w.rank = p->rank;
+  w.which = which;
+  w.seq = p->seq[which];
+  w.timeout_ticks = 200000000ull;  // 2 s
+  peer_wait_kernel<<<1, 64, 0, c->stream>>>(w);
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
+}
+// a piece that never arrived (a rank died or fell out of step): reported at the next synchronisation, once
+static int peer_check(dust_ctx *c) {
+  if (!c->peer) return DUST_OK;
+  unsigned int e = 0u;
+  unsigned int *w = c->peer->flags_local + PEER_ROWS * PEER_MAX + PEER_MAX;
+  HIP_TRY(hipMemcpy(&e, w, sizeof e, hipMemcpyDeviceToHost));
+  if (!e) return DUST_OK;
+  HIP_TRY(hipMemset(w, 0, sizeof e));
+  return fail(DUST_ERR_HIP, "peer-store all-gather: a rank's piece did not arrive within 2 s (results of that tick are invalid)");
+}
+// the exchange `which` of the sharded tick: every rank's `count` floats, in place
+static int gather(dust_ctx *c, int which, size_t count) {
+  if (c->peer) {
+    TRY(peer_store(c, which, count));
+    return peer_wait(c, which);
+  }
+  return gather_inplace(c, peer_own_buffer(c, which), count);
+}
+
 // The collectives of one sharded control tick alone - per SVGD iteration the score and the particle all-gather, per tick the
 // log-weights - `reps` times back to back on the context's stream between one pair of HIP events: their cost when nothing
 // overlaps them (bench.py reports it as comm_us_per_tick beside the sharded rate).  A collective over all ranks.
@@ -3615,6 +3777,34 @@ extern "C" int dust_comm_probe(dust_ctx *c, int n_steps, int reps, double *us_pe
   if (!c->comm) return fail(DUST_ERR_STATE, "no communicator (dust_comm_init)");
   HIP_TRY(hipSetDevice(c->cfg.device));
   const size_t shard = (size_t)c->nloc * c->D;
+  if (c->peer) {
+    // peer stores go to the mapped buffers themselves.  Between ticks every rank holds the same rows as every other (that is what the
+    // exchanges are for), so sending them again changes nothing - the context's particles stay as they are here as well.
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int st = DUST_OK;
+    for (int w = 0; w < 2 && st == DUST_OK; ++w) st = gather(c, GATHER_SCORE, shard);
+    if (st == DUST_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) st = fail(DUST_ERR_HIP, "hipEventCreate");
+    if (st == DUST_OK) {
+      (void)hipEventRecord(e0, c->stream);
+      for (int r = 0; r < reps && st == DUST_OK; ++r) {
+        for (int k = 0; k < n_steps && st == DUST_OK; ++k) {
+          st = gather(c, GATHER_SCORE, shard);
+          if (st == DUST_OK) st = gather(c, GATHER_THETA, shard);
+        }
+        if (st == DUST_OK) st = gather(c, GATHER_LW, (size_t)c->nloc);
+      }
+      (void)hipEventRecord(e1, c->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      *us_per_tick = 1e3 * (double)ms / reps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(c->stream);
+    if (st == DUST_OK) st = peer_check(c);
+    return st;
+  }
   float *scratch = nullptr;  // gathers into scratch: the context's particles stay untouched
   TRY(dalloc(&scratch, (size_t)c->N * c->D));
   auto gather = [&](size_t count) {
@@ -3662,7 +3852,8 @@ static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const flo
   const size_t slice = ((size_t)c->S * c->N * c->D) >> ((flags & DUST_EPS_F16) ? 1 : 0);
   const size_t shard = (size_t)c->nloc * c->D;
   const bool overlap = !c->prof && c->stream2 && c->env.no_comm_overlap < 0;  // (development switch)
-  bool gather_in_flight = false;
+  // 0: none; 1: the collective library's all-gather on the side stream (ev_join follows it); 2: peer stores issued, arrival not awaited yet
+  int gather_in_flight = 0;
   for (int k = 0; k < n_steps; ++k) {
     const float *nd = nullptr;
     TRY(stage_noise(c, eps ? eps + (size_t)k * slice : nullptr, flags, &nd));
@@ -3681,36 +3872,42 @@ static int sharded_steps(dust_ctx *c, const float *state, int n_steps, const flo
       c->params_dev = save;
       TRY(st);
       c->have_sample = true;
-      HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-      gather_in_flight = false;
+      if (gather_in_flight == 2) TRY(peer_wait(c, GATHER_THETA));
+      else HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+      gather_in_flight = 0;
       TRY(launch_prior(c));
       TRY(launch_prior_finish(c, true, false));
     } else {
       TRY(local_score_device(c, nd, k));
     }
-    TRY(gather_inplace(c, c->score, shard));
+    TRY(gather(c, GATHER_SCORE, shard));
     TRY(launch_stein_update(c, 1));
-    if (overlap && k + 1 < n_steps) {
+    if (overlap && k + 1 < n_steps && c->peer) {
+      // peer stores need no stream of their own: the pieces travel while the next iteration's rollouts run, the arrival is awaited
+      // in front of the prior pass
+      TRY(peer_store(c, GATHER_THETA, shard));
+      gather_in_flight = 2;
+    } else if (overlap && k + 1 < n_steps) {
       HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
       HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       TRY(rccl::check(rccl::all_gather(c->theta + (size_t)c->comm_rank * shard, c->theta, shard, rccl::ncclFloat32, c->comm, c->stream2), "ncclAllGather"));
       HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-      gather_in_flight = true;
+      gather_in_flight = 1;
     } else {
-      TRY(gather_inplace(c, c->theta, shard));
+      TRY(gather(c, GATHER_THETA, shard));
     }
   }
   return DUST_OK;
 }
 static int sharded_forward(dust_ctx *c) {
   TRY(forward_device(c));  // rank-local log p and log-weights
-  TRY(gather_inplace(c, c->lw, (size_t)c->nloc));
+  TRY(gather(c, GATHER_LW, (size_t)c->nloc));
   // every rank holds all N particles of this tick (gathered after the last update): "repeat" / "mean" roll each row from itself,
   // so the rank rolls all of them (16 384 rows: ~10 us) and the tick ends without a third 5 MB all-gather
   const bool roll_all = c->cfg.roll_strategy != DUST_ROLL_RESAMPLE && c->theta == c->theta_home;
   TRY(forward_finish_device(c, -1, nullptr, roll_all));
   if (roll_all) return DUST_OK;
-  return gather_inplace(c, c->theta, (size_t)c->nloc * c->D);  // the other ranks' rolled rows
+  return gather(c, GATHER_THETA, (size_t)c->nloc * c->D);  // the other ranks' rolled rows
 }
 
 // the replay inputs of the one-launch tick just enqueued (t2_settle)
@@ -4044,7 +4241,10 @@ extern "C" int dust_svmpc_tick(dust_ctx *c, const float *state, int n_steps, con
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(sharded_steps(c, state, n_steps, eps, params, flags));
     TRY(sharded_forward(c));
-    if (a_seq || p_weights) TRY(tick_outputs(c, a_seq, p_weights));
+    if (a_seq || p_weights) {
+      TRY(tick_outputs(c, a_seq, p_weights));
+      TRY(peer_check(c));  // (a piece that never arrived: these outputs must not reach the plant)
+    }
     return DUST_OK;
   }
   // The FIRST tick of a context whose later ticks the owner-computes kernel will serve (tick2.hpp needs the prior means aliased to the

@@ -298,6 +298,14 @@ int dust_comm_destroy(dust_ctx *ctx);
  * back to back on the context's stream between one pair of HIP events -> microseconds per tick when nothing overlaps them.
  * Collective over all ranks; the context's particles are not touched.  (Measurement aid; no reference counterpart.) */
 int dust_comm_probe(dust_ctx *ctx, int n_steps, int reps, double *us_per_tick);
+/* The tick's all-gathers as DIRECT PEER STORES (dust_amd/csrc/peer_gather.hpp): the GPUs of a node are one xGMI hop apart, the pieces are
+ * small (a rank's score / particle rows, its log-weights), so every rank writes its piece straight into every peer's buffer - mapped once,
+ * here, through HIP IPC - and raises one arrival word per peer; a one-wave kernel in front of the first consumer waits for the words.
+ * on != 0: map the peers' buffers (COLLECTIVE: the IPC handles travel through one all-gather of the communicator - every rank calls it,
+ * or none); on == 0: back to the collective library's all-gathers.  DUST_PEER_GATHER=1 in the environment makes dust_comm_init call it.
+ * A piece that does not arrive within 2 s is reported by the next dust_sync / tick output as DUST_ERR_HIP.  (No reference counterpart:
+ * the reference is single-device.) */
+int dust_comm_peer_gather(dust_ctx *ctx, int on);
 /* run the context's kernels on an external HIP stream (hipStream_t), e.g. torch's current stream */
 int dust_set_stream(dust_ctx *ctx, void *hip_stream);
 

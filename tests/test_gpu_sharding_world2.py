@@ -42,10 +42,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("gather", ["library", "peer"])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("ci", range(len(CASES)))
-def test_c_side_sharded_tick_in_separate_processes(ci, world, overlap, fake_rccl, tmp_path):
+def test_c_side_sharded_tick_in_separate_processes(ci, world, overlap, gather, fake_rccl, tmp_path):
+    """gather = "library": the three exchanges through the collective library's all-gather; "peer": as direct peer stores into
+    IPC-mapped buffers with arrival words (dust_amd/csrc/peer_gather.hpp, DUST_PEER_GATHER=1) - the same results, bit for bit between
+    the ranks, on both stream orders (with the overlap the particle pieces travel under the next iteration's rollouts and their
+    arrival is awaited in front of the prior pass)."""
     case = CASES[ci]
     if world == 4 and ci in (1, 4):
         pytest.skip("world 4 runs on three of the cases")
@@ -61,6 +66,9 @@ def test_c_side_sharded_tick_in_separate_processes(ci, world, overlap, fake_rccl
     env.pop("DUST_NO_COMM_OVERLAP", None)
     if not overlap:
         env["DUST_NO_COMM_OVERLAP"] = "1"
+    env.pop("DUST_PEER_GATHER", None)
+    if gather == "peer":
+        env["DUST_PEER_GATHER"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(tmp_path), str(cj)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
