@@ -515,6 +515,33 @@ def main():
         par = "particles sharded x%d (strong scaling), in-place RCCL all-gathers of score and theta per SVGD iteration" % n_gpus
         value = args.steps / el
         unit = "control steps/s (joint N=16384 problem)"
+        # The same ticks with the three exchanges as DIRECT PEER STORES (dust_amd/csrc/peer_gather.hpp: every rank writes its piece into
+        # every peer's IPC-mapped buffer, one arrival word per peer).  Tried after the library run, on the same contexts; accepted only
+        # when the ranks still hold bit-identical particles afterwards (every rank keeps all N rows: a lost or stale piece shows up as a
+        # disagreement).  `value` is the better of the two accepted figures; both are reported.
+        if sh.c_side:
+            peer = dict(tried=True)
+            try:
+                sh.ctx.comm_peer_gather(True)
+                el_p, _ = timed(lambda: sh.tick(st4, c4["n_iters"], params=params), sh.sync)
+                comm_p = sh.ctx.comm_probe(c4["n_iters"], 50)
+                th = sh.ctx.get_theta()
+                sums = [None] * n_gpus
+                dist.all_gather_object(sums, (float(np.float64(th).sum()), int(np.isfinite(th).all()), __import__("zlib").crc32(th.tobytes())))
+                agree = all(x == sums[0] for x in sums) and sums[0][1] == 1
+                peer.update(ticks_per_s=args.steps / el_p, ms_per_tick=1e3 * el_p / args.steps, comm_us_per_tick=comm_p, ranks_agree=bool(agree))
+                if agree and args.steps / el_p > value:
+                    value = args.steps / el_p
+                    el = el_p
+                    par = "particles sharded x%d (strong scaling), direct peer-store all-gathers of score and theta per SVGD iteration" % n_gpus
+            except Exception as e:  # noqa: BLE001 - the library's all-gathers stay in charge
+                peer["error"] = str(e)[:300]
+                bad = [None] * n_gpus
+                try:
+                    dist.all_gather_object(bad, peer.get("error"))
+                except Exception:  # noqa: BLE001
+                    pass
+            extra["scale_workload"]["peer_gather"] = peer
         # the SAME joint problem on ONE GPU (unsharded context, rank 0, outside the timed region; the other ranks wait): the figure a
         # strong-scaling efficiency of this line has to be computed against - `python bench.py --gpus 1` runs cfg2, not this
         if rank == 0 and (n_gpus > 1 or os.environ.get("DUST_BENCH_FORCE_DIST")):
@@ -534,6 +561,40 @@ def main():
             extra["scale_workload"]["one_gpu_ticks_per_s"] = extra["one_gpu_same_workload_ticks_per_s"]
             one.close()
         dist.barrier()
+        # WEAK scaling in the particle count (north_star: "particle scaling"): 2048 particles PER GPU of the same Particle workload - at 8
+        # GPUs this is configs[3] itself - against 2048 particles on one GPU (rank 0, unsharded, outside the timed region).  The pairwise
+        # work per rank grows with the joint set (n_local x N pairs), so this is not free scaling either.
+        try:
+            n_w = 2048 * n_gpus
+            if n_w != c4["N"] or n_gpus == 1:
+                muw, thw = synth(n_w, c4["H"], 2, spread=1.0)
+                shw = ShardedSVMPC(dict(common, N=n_w), rank, n_gpus, dist)
+                shw.set_state(thw, muw)
+                elw, _ = timed(lambda: shw.tick(st4, c4["n_iters"], params=params), shw.sync)
+                tps_w = args.steps / elw
+                shw.ctx.close()
+            else:
+                tps_w = args.steps / el
+            one_w = None
+            if rank == 0:
+                mu1, th1 = synth(2048, c4["H"], 2, spread=1.0)
+                o1 = Context(**dict(common, N=2048))
+                o1.set_theta(th1); o1.set_prior(mu1); o1.set_a_mat(th1)
+                for _ in range(40):
+                    o1.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
+                o1.sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    o1.svmpc_tick(st4, c4["n_iters"], params=params, want_outputs=False)
+                o1.sync()
+                one_w = args.steps / (time.perf_counter() - t1)
+                o1.close()
+            dist.barrier()
+            extra["weak_workload"] = dict(workload="Particle, 2048 particles per GPU (N = %d), S=64, M=4, H=40, 1 SVGD iter, K1" % n_w, n_particles_total=n_w,
+                                          ticks_per_s=tps_w, one_gpu_2048_particles_ticks_per_s=one_w,
+                                          particle_throughput_vs_one_gpu=(tps_w * n_w / (one_w * 2048.0)) if one_w else None)
+        except Exception as e:  # noqa: BLE001
+            extra["weak_workload"] = dict(error=str(e)[:300])
         if args.weak:
             n_tot = w["N"] * n_gpus
             mu2, th2 = synth(n_tot, w["H"], 1)

@@ -3730,7 +3730,7 @@ static int peer_store(dust_ctx *c, int which, size_t count) {
   a.which = which;
   a.seq = ++p->seq[which];
   if (p->world < 2) return DUST_OK;
-  const int gx = (int)std::max<size_t>(1, std::min<size_t>(48, ((count >> 2) + 255) / 256));
+  const int gx = (int)std::max<size_t>(1, std::min<size_t>(16, ((count >> 2) + 255) / 256));  // (a link wants a few waves, not a full chip)
   peer_store_kernel<<<dim3(gx, p->world - 1), 256, 0, c->stream>>>(a);
   HIP_TRY(hipGetLastError());
   return DUST_OK;
@@ -4609,6 +4609,83 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (p) HIP_TRY(hipFree(p));
   return DUST_OK;
+}
+
+// The fixed cost of the sharded tick's three exchanges in their peer-store form, measured on ONE device (a test / measurement hook, not
+// in include/dust_amd.h): this context plays rank 0 of `world`, its "peers" are scratch buffers of the same device, and a one-wave
+// kernel plays the peers' arrival words and tokens.  Per exchange: the store kernel (the rank's piece copied world - 1 times, tokens,
+// fences, arrival words) + the wait kernel - everything but the time the pieces spend on the links.
+__global__ void peer_selftest_arrive_kernel(unsigned int *flags, int which, int world, unsigned int seq, int token) {
+  const int r = threadIdx.x;
+  if (r < 1 || r >= world) return;
+  if (token) __hip_atomic_store(flags + PEER_BUFS * PEER_MAX + r, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(flags + which * PEER_MAX + r, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int dust_debug_peer_selftest(dust_ctx *c, int world, int n_steps, int reps, double *us_per_tick) {
+  if (!c || !us_per_tick || world < 2 || world > PEER_MAX || reps < 1 || n_steps < 1) return fail(DUST_ERR_INVALID, "bad argument");
+  if (c->N % world) return fail(DUST_ERR_INVALID, "N %% world");
+  if (c->peer) return fail(DUST_ERR_STATE, "the context has real peers");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  PeerState *p = new (std::nothrow) PeerState();
+  if (!p) return fail(DUST_ERR_HIP, "out of host memory");
+  memset((void *)p, 0, sizeof *p);
+  p->world = world;
+  p->rank = 0;
+  const size_t nflag = (size_t)PEER_ROWS * PEER_MAX + PEER_MAX + 1, ND = (size_t)c->N * c->D;
+  float *scratch = nullptr;
+  unsigned int *sink = nullptr;
+  int st = DUST_OK;
+  if (hipMalloc((void **)&p->flags_local, nflag * 4) != hipSuccess || hipMalloc((void **)&sink, nflag * 4) != hipSuccess ||
+      hipMalloc((void **)&scratch, ND * sizeof(float)) != hipSuccess)
+    st = fail(DUST_ERR_HIP, "hipMalloc");
+  if (st == DUST_OK) {
+    (void)hipMemset(p->flags_local, 0, nflag * 4);
+    (void)hipMemset(sink, 0, nflag * 4);
+    for (int g = 0; g < world; ++g) {
+      for (int k = 0; k < PEER_BUFS; ++k) p->buf[k][g] = g == 0 ? peer_own_buffer(c, k) : scratch;  // (every "peer" takes the piece at the same offset)
+      p->flags[g] = g == 0 ? p->flags_local : sink;
+    }
+    c->peer = p;
+    const int keep_rank = c->comm_rank;
+    const size_t shard = (size_t)(c->N / world) * c->D;
+    // the peers' side, once: every arrival word and token already stands at "arrived" (sequence numbers are compared as signed differences)
+    for (int k = 0; k < PEER_ROWS; ++k) peer_selftest_arrive_kernel<<<1, 64, 0, c->stream>>>(p->flags_local, k, world, 0x3fffffffu, k == PEER_BUFS ? 1 : 0);
+    auto exchange = [&](int which, size_t count) {
+      int s2 = peer_store(c, which, count);
+      if (s2 == DUST_OK) s2 = peer_wait(c, which);
+      return s2;
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    for (int w = 0; w < 3 && st == DUST_OK; ++w) st = exchange(GATHER_SCORE, shard);
+    if (st == DUST_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) st = fail(DUST_ERR_HIP, "hipEventCreate");
+    if (st == DUST_OK) {
+      (void)hipEventRecord(e0, c->stream);
+      for (int r = 0; r < reps && st == DUST_OK; ++r) {
+        for (int k = 0; k < n_steps && st == DUST_OK; ++k) {
+          st = exchange(GATHER_SCORE, shard);
+          if (st == DUST_OK) st = exchange(GATHER_THETA, shard);
+        }
+        if (st == DUST_OK) st = exchange(GATHER_LW, (size_t)(c->N / world));
+      }
+      (void)hipEventRecord(e1, c->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      *us_per_tick = 1e3 * (double)ms / reps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(c->stream);
+    if (st == DUST_OK) st = peer_check(c);
+    (void)keep_rank;
+    c->peer = nullptr;
+  }
+  if (scratch) (void)hipFree(scratch);
+  if (sink) (void)hipFree(sink);
+  if (p->flags_local) (void)hipFree(p->flags_local);
+  delete p;
+  return st;
 }
 
 // The run lists of the last large-set pass 1 (pairwise_packed.hpp), one query tile: *n_units, the unit offsets [n_units + 1], the key

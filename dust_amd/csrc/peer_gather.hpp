@@ -59,13 +59,20 @@ __global__ __launch_bounds__(256) void peer_store_kernel(const PeerStoreArgs a) 
     }
     __syncthreads();
   }
+  // 16-byte WRITE-THROUGH stores (sc0 sc1: performed at system scope - the peer's memory - not parked in this GPU's L2), so that the
+  // wave only has to wait for its own stores (vmcnt) instead of writing the whole L2 back with a system-scope fence per wave
+  // (measured on one device at 8 ranks: 90 us per tick for the three exchanges with the fence, the L2 full of the tick's dirty lines)
   const size_t n4 = a.count >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-    reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(a.src)[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    typedef float pg_v4f __attribute__((ext_vector_type(4)));
+    const pg_v4f v = reinterpret_cast<const pg_v4f *>(a.src)[i];
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(reinterpret_cast<pg_v4f *>(dst) + i), "v"(v) : "memory");
+  }
   if (blockIdx.x == 0)
-    for (size_t i = (n4 << 2) + threadIdx.x; i < a.count; i += blockDim.x) dst[i] = a.src[i];
-  __threadfence_system();  // this lane's stores are performed at the peer before anything below
+    for (size_t i = (n4 << 2) + threadIdx.x; i < a.count; i += blockDim.x)
+      asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst + i), "v"(a.src[i]) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are performed at the peer
   __shared__ unsigned int last;
   __syncthreads();
   if (threadIdx.x == 0) {
