@@ -1459,7 +1459,14 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
     k.costsT = c->costsT;
     k.states_out = a.states_out;
     const int nthr = c->nloc * c->S;
-    particle_general_kernel<<<(nthr + 255) / 256, 256, 0, c->stream>>>(k);
+    const int pg_gw = (k.dm.with_obstacle && k.dm.grid_bits) ? (k.dm.nx * k.dm.ny + 31) / 32 : 0;
+    k.mc = c->M >= 8 ? 8 : (c->M >= 4 ? 4 : (c->M >= 2 ? 2 : 1));
+    const size_t pg_lds = particle_general_lds_bytes(c->D, pg_gw, k.mc);
+    if (pg_lds > 160 * 1024) return fail(DUST_ERR_UNSUPPORTED, "occupancy grid of %d x %d cells: the control-noise / velocity-control rollouts keep it in LDS", k.dm.nx, k.dm.ny);
+    if (pg_lds > 64 * 1024 && !c->capturing)
+      HIP_TRY(hipFuncSetAttribute((const void *)particle_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pg_lds));
+    const int pg_rows = PARTGEN_NT / k.mc;
+    particle_general_kernel<<<(nthr + pg_rows - 1) / pg_rows, PARTGEN_NT, pg_lds, c->stream>>>(k);
     HIP_TRY(hipGetLastError());
     o.want_states = false;
     o.costs_in = c->costs_stage;

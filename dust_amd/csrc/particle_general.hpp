@@ -12,10 +12,10 @@
 // under MultiDISCO._rollout / _compute_cost (disco.py:139-209, 294-346) with Particle.default_inst_cost / default_term_cost
 // (particle.py:170-225; w_state / w_term / target have dim_s entries).
 //
-// One lane = one (action sample s, policy n) pair, the M dynamics samples in sequence (the scheme of skid.hpp); costs go to a [S][N]
+// One lane = one (action sample s, policy n) pair, its action row in LDS, the M dynamics samples in sequence; costs go to a [S][N]
 // buffer that the regular rollout kernel consumes in its injected-costs mode (weights, likelihood score, a_mat update).  Control noise:
 // recorded draws `cz` [H][M*S*N][d_a] (parity runs: the reference's own torch.randn_like tensors, dust_set_ctrl_noise) or a Philox
-// stream of its own, keyed (tick, iter, r, t) - in registers, never in HBM.  A completeness row, not a tuned one: plain loads.
+// stream of its own, keyed (tick, iter, r, t / 2) - in registers, never in HBM.
 #pragma once
 #include "rollout.hpp"
 
@@ -28,6 +28,7 @@ struct PartGenArgs {
   int noise_f16;   // caller's eps / actions are binary16
   int store_f16;   // states_out is binary16
   int velocity;    // control_type == "velocity": dim_s = 2
+  int mc;          // lanes per (sample, policy) pair: a power of two <= min(M, 8); lane c runs dynamics samples c, c + mc, ...
   int ctrl_noise;  // Particle(deterministic=False)
   float dyn_std[2];
   float chol_a[2], a_pre[2];
@@ -47,38 +48,66 @@ struct PartGenArgs {
   void *states_out;     // [M][S][N][H+1][ds] or nullptr
 };
 
-__global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.n_local * a.S) return;
-  const int s = idx / a.n_local, n = a.n0 + (idx - s * a.n_local);  // (n fastest: the rows of one sample are adjacent)
-  const int D = a.D, H = a.H, N = a.N_total;
+enum { PARTGEN_NT = 128 };
+static inline size_t particle_general_lds_bytes(int D, int grid_words, int mc) { return sizeof(float) * ((size_t)(PARTGEN_NT / mc) * (D + 1) + (size_t)grid_words); }
+
+// Round 6: a (sample, policy) pair's action row is drawn ONCE, into an LDS row (the first form drew a whole
+// philox_normal8 block for every column it looked at, again for every dynamics sample: 8 M times too often - 7.5 ms per cfg3 tick
+// against 1.0 deterministic), and `mc` lanes share the pair: each runs every mc-th dynamics sample (a row per LANE left room for
+// 1.5 waves per SIMD: 5.6 ms; the dependent chain of a rollout wants many); the occupancy grid sits in LDS beside the rows; one
+// philox_normal4 serves the control noise of TWO steps; the step cost is the reference's own fp32 products summed pairwise with a
+// compensated running sum (the arithmetic of the other Particle kernels: rollout.hpp PairKahan) instead of fp64 adds.
+__global__ __launch_bounds__(PARTGEN_NT) void particle_general_kernel(const PartGenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pg_lds[];
+  const int D = a.D, H = a.H, N = a.N_total, tid = threadIdx.x;
+  const int MC = a.mc, lr = tid / MC, mc = tid - lr * MC, rows = PARTGEN_NT / MC;
+  float *arow = pg_lds + (size_t)lr * (D + 1);
+  uint32_t *gridl = reinterpret_cast<uint32_t *>(pg_lds + (size_t)rows * (D + 1));
+  DevModel dm = a.dm;
+  const int gw = (dm.with_obstacle && dm.grid_bits) ? (dm.nx * dm.ny + 31) / 32 : 0;
+  for (int w = tid; w < gw; w += PARTGEN_NT) gridl[w] = dm.grid_bits[w];
+  if (gw) dm.grid_bits = gridl;
+  const int idx = blockIdx.x * rows + lr;  // the (sample, policy) pair
+  const bool live = idx < a.n_local * a.S;
+  const int idc = live ? idx : 0;
+  const int s = idc / a.n_local, n = a.n0 + (idc - s * a.n_local);  // (n fastest: the rows of one sample are adjacent)
   const int DSm = a.velocity ? 2 : 4;
   const size_t row = ((size_t)s * N + n) * D;
-  const float *nz = (a.noise && !a.noise_f16) ? a.noise + row : nullptr;
-  const _Float16 *nzh = (a.noise && a.noise_f16) ? reinterpret_cast<const _Float16 *>(a.noise) + row : nullptr;
   const float *th = a.theta + (size_t)n * D;
   const uint32_t ctr_tick = a.ctr[0], ctr_iter = a.ctr[1];
-  auto action = [&](const int j) -> float {  // theta + L eps (an odd column of a full L takes its partner draw too)
-    const float v = nzh ? (float)nzh[j] : (nz ? nz[j] : 0.f);
-    if (a.noise_mode == NOISE_ACTIONS) return v;
-    const bool pair = (j & 1) && a.chol_off != 0.f;
-    if (a.noise_mode == NOISE_EPS) {
-      if (!pair) return th[j] + a.chol_a[j & 1] * v;
-      const float vp = nzh ? (float)nzh[j - 1] : nz[j - 1];
-      return th[j] + (a.chol_off * vp + a.chol_a[1] * v);
+  // the action row: theta + L eps (an odd column of a full L takes its partner draw too), or the caller's actions; the pair's lanes
+  // share the work
+  if (a.noise_mode == NOISE_PHILOX) {
+    for (int j0 = 8 * mc; j0 < D; j0 += 8 * MC) {
+      float z[8];
+      philox_normal8(a.seed, (uint32_t)(j0 >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = j0 + k;
+        if (j < D) {
+          const bool pair = (j & 1) && a.chol_off != 0.f;
+          arow[j] = pair ? th[j] + (a.chol_off * z[k - 1 < 0 ? 0 : k - 1] + a.chol_a[1] * z[k]) : th[j] + a.chol_a[j & 1] * z[k];
+        }
+      }
     }
-    float z[8];
-    philox_normal8(a.seed, (uint32_t)(j >> 3), (uint32_t)(s * N + n), ctr_iter, ctr_tick, z);  // (the regular kernel's stream)
-    return pair ? th[j] + (a.chol_off * z[(j & 7) - 1] + a.chol_a[1] * z[j & 7]) : th[j] + a.chol_a[j & 1] * z[j & 7];
-  };
-  const DevModel &dm = a.dm;
+  } else {
+    const float *nz = !a.noise_f16 ? a.noise + row : nullptr;
+    const _Float16 *nzh = a.noise_f16 ? reinterpret_cast<const _Float16 *>(a.noise) + row : nullptr;
+    for (int j = mc; j < D; j += MC) {
+      const float v = nzh ? (float)nzh[j] : nz[j];
+      if (a.noise_mode == NOISE_ACTIONS) arow[j] = v;
+      else if ((j & 1) && a.chol_off != 0.f) arow[j] = th[j] + (a.chol_off * (nzh ? (float)nzh[j - 1] : nz[j - 1]) + a.chol_a[1] * v);
+      else arow[j] = th[j] + a.chol_a[j & 1] * v;
+    }
+  }
+  __syncthreads();  // the grid and the rows
   const float dt = (float)dm.dt;
   const bool obst = dm.with_obstacle != 0, crash = dm.can_crash && dm.with_obstacle;
   float x0[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < DSm; ++k) x0[k] = a.state[k];
   const size_t SN = (size_t)a.S * N;
   double acc = 0.0;
-  for (int m = 0; m < a.M; ++m) {
+  for (int m = mc; m < a.M; m += MC) {
     const size_t r = (size_t)m * SN + (size_t)s * N + n;
     // scalar-event params_dist quirk (disco.py:177-179): rollout r = (m, s, n) flattened uses params[r % M]
     const int mi = dm.interleave ? (int)(r % (size_t)a.M) : m;
@@ -88,26 +117,37 @@ __global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs
     for (int k = 0; k < 4; ++k) x[k] = x0[k];
     const size_t so = r * (size_t)(H + 1) * DSm;
     auto put = [&](const int t) {
-      if (!a.states_out) return;
+      if (!a.states_out || !live) return;
       for (int k = 0; k < DSm; ++k) {
         if (a.store_f16) reinterpret_cast<_Float16 *>(a.states_out)[so + (size_t)t * DSm + k] = (_Float16)x[k];
         else reinterpret_cast<float *>(a.states_out)[so + (size_t)t * DSm + k] = x[k];
       }
     };
     put(0);
-    double tot = 0.0;
+    float tot = 0.f, comp = 0.f;  // compensated running sum of the step costs
+    float zc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < H; ++t) {
-      const float a0 = action(2 * t), a1 = action(2 * t + 1);
+      const float a0 = arow[2 * t], a1 = arow[2 * t + 1];
       // cost of the state BEFORE the action, raw action (disco.py:306; particle.py:170-198)
       const float coll = obst ? collision(dm, x[0], x[1]) : 0.f;
-      double sc = 0.0;
-      for (int k = 0; k < DSm; ++k) {
-        const float d = x[k] - dm.target[k];
-        sc += (double)((d * d) * dm.w_state[k]);
+      float sc;
+      {
+        const float d0 = x[0] - dm.target[0], d1 = x[1] - dm.target[1];
+        const float t0 = (d0 * d0) * dm.w_state[0], t1 = (d1 * d1) * dm.w_state[1];
+        sc = t0 + t1;
+        if (!a.velocity) {
+          const float d2 = x[2] - dm.target[2], d3 = x[3] - dm.target[3];
+          sc = sc + ((d2 * d2) * dm.w_state[2] + (d3 * d3) * dm.w_state[3]);
+        }
       }
-      const double cc = (double)((a0 * a0) * dm.w_ctrl[0]) + (double)((a1 * a1) * dm.w_ctrl[1]);
+      const float cc = (a0 * a0) * dm.w_ctrl[0] + (a1 * a1) * dm.w_ctrl[1];
       const float ob = obst ? dm.w_obs * coll : 0.0f;
-      tot += (double)(((float)sc + (float)cc) + ob);
+      {
+        const float term = (sc + cc) + ob;
+        const float y = term - comp, tn = tot + y;
+        comp = (tn - tot) - y;
+        tot = tn;
+      }
       // the action that drives the dynamics (particle.py:144-153)
       float u0 = a0, u1 = a1;
       if (a.ctrl_noise) {
@@ -116,11 +156,10 @@ __global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs
           const float *zp = a.cz + ((size_t)t * a.M * SN + r) * 2;
           z0 = zp[0];
           z1 = zp[1];
-        } else {  // a stream of its own: key word 0x63747264 ("ctrd") apart from the policy noise
-          float z[4];
-          philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)(r >> 32) ^ ((uint32_t)t << 8), ctr_iter, ctr_tick, z);
-          z0 = z[0];
-          z1 = z[1];
+        } else {  // a stream of its own (key word 0x63747264 "ctrd"), one block of four normals per two steps
+          if ((t & 1) == 0) philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)(r >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, zc);
+          z0 = (t & 1) ? zc[2] : zc[0];
+          z1 = (t & 1) ? zc[3] : zc[1];
         }
         u0 = u0 + a.dyn_std[0] * z0;
         u1 = u1 + a.dyn_std[1] * z1;
@@ -154,19 +193,25 @@ __global__ __launch_bounds__(256) void particle_general_kernel(const PartGenArgs
       }
       put(t + 1);
     }
-    double tc = 0.0;
-    for (int k = 0; k < DSm; ++k) {
-      const float d = x[k] - dm.target[k];
-      tc += (double)((d * d) * dm.w_term[k]);
+    float tc;
+    {
+      const float d0 = x[0] - dm.target[0], d1 = x[1] - dm.target[1];
+      tc = (d0 * d0) * dm.w_term[0] + (d1 * d1) * dm.w_term[1];
+      if (!a.velocity) {
+        const float d2 = x[2] - dm.target[2], d3 = x[3] - dm.target[3];
+        tc = tc + ((d2 * d2) * dm.w_term[2] + (d3 * d3) * dm.w_term[3]);
+      }
     }
     const float tob = obst ? dm.w_obs * collision(dm, x[0], x[1]) : 0.0f;
-    acc += (double)((float)tot + ((float)tc + tob));
+    acc += (double)(tot + (tc + tob));
   }
+  for (int o = 1; o < MC; o <<= 1) acc += __shfl_xor(acc, o);  // the pair's lanes (consecutive lanes of one wave): every lane ends with the sum
+  if (!live || mc != 0) return;
   float cost = a.M == 1 ? (float)acc : (float)(acc / a.M);
   if (a.a_reg != 0.0f) {  // disco.py:338-346, diagonal of the [S,N,N] tensordot only
     double cc = 0.0;
     for (int j = 0; j < D; ++j) {
-      const float e = action(j) - a.a_seq[j];
+      const float e = arow[j] - a.a_seq[j];
       float ap = a.a_mat[(size_t)n * D + j] * a.a_pre[j & 1];
       if (a.a_pre_off != 0.f) {  // (a_mat[n, t, :] @ a_pre)[d] with a full symmetric a_pre
         const float m0 = a.a_mat[(size_t)n * D + (j & ~1)], m1 = a.a_mat[(size_t)n * D + (j | 1)];

@@ -46,6 +46,8 @@ def run(name, ticks, warm, model, N, S, M, H, n_iters, kernel="K1", mpf=None, lr
     ctx.set_prior(mu)
     ctx.set_a_mat(th)
     state = np.array([3.0, 0.0] if pend else [-9.0, -9.0, 0.0, 0.0], np.float32)
+    if kw.get("control_type") == "velocity":
+        state = state[:2]  # (a two-state model: particle.py:41-48)
     m = None
     if mpf:
         x0 = (1.0 + 0.2 * rng.standard_normal((mpf["Mp"], 2))).astype(np.float32)
@@ -85,11 +87,23 @@ def run(name, ticks, warm, model, N, S, M, H, n_iters, kernel="K1", mpf=None, lr
 
 def main():
     out = []
+    only = os.environ.get("DUST_CONFIGS_ONLY")  # development: substring of the rows to run
+    if only:
+        global run
+        real_run = run
+
+        def run(name, *a, **k):  # noqa: F811
+            return real_run(name, *a, **k) if only in name else dict(config=name, skipped=True)
+
     out.append(run("cfg1", 300, 30, "pendulum", 32, 128, 1, 15, 1))
     out.append(run("cfg2 (bench.py)", 300, 30, "pendulum", 1024, 128, 1, 30, 5))
     out.append(run("cfg2 / K2 (iid_mp)", 100, 10, "pendulum", 1024, 128, 1, 30, 5, kernel="K2"))
     out.append(run("cfg2 / IMQ", 300, 30, "pendulum", 1024, 128, 1, 30, 5, kernel="IMQ"))
     out.append(run("cfg3", 20, 3, "particle", 4096, 64, 64, 40, 1))
+    # Particle(deterministic=False, noise_std=0.1) - the reference's constructor default with real noise - and velocity control:
+    # particle_general.hpp
+    out.append(run("cfg3 noisy (control-channel noise 0.1)", 10, 2, "particle", 4096, 64, 64, 40, 1, deterministic=False, noise_std=(0.1, 0.1)))
+    out.append(run("cfg3 velocity control", 10, 2, "particle", 4096, 64, 64, 40, 1, control_type="velocity"))
     out.append(run("cfg4 on one GPU", 20, 3, "particle", 16384, 64, 4, 40, 1))
     out.append(run("cfg5 on one GPU (K1, M=8, MPF 256 x 20)", 50, 5, "pendulum", 2048, 128, 8, 30, 5, mpf=dict(Mp=256, steps=20)))
     out.append(run("cfg5 on one GPU (IMQ, M=8, MPF 256 x 20)", 50, 5, "pendulum", 2048, 128, 8, 30, 5, kernel="IMQ", mpf=dict(Mp=256, steps=20)))
