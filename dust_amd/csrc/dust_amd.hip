@@ -28,7 +28,6 @@
 #include "forward.hpp"
 #include "fused.hpp"
 #include "pairwise_big.hpp"
-#include "persist.hpp"
 #include "tick2_args.hpp"
 #include "rollout_states.hpp"
 #include "pairwise_fused.hpp"
@@ -123,8 +122,6 @@ struct dust_ctx {
   float *kmat;               // [n_local][ldK] Stein kernel values of the current theta (pairwise_fused.hpp), valid while kmat_valid
   size_t kmat_cap;
   bool kmat_valid;
-  unsigned int *tick1_start;  // {start counter, go word} of the tiled one-launch tick's start barrier (persist.hpp)
-  unsigned int tick1_seq;     // ticks launched through it (the go word's value)
   bool t2_mu_aliased;        // the prior means aliased the particles BEFORE the last one-launch tick (its replay starts from that state)
   bool handoff_banned;       // an in-launch wait timed out once (the device is shared with another process): plain kernels from then on
   bool no_handoff;           // replay of a tick that found the device shared: plain kernels only, nothing that spins on its own grid
@@ -182,9 +179,6 @@ struct dust_ctx {
   float *outblk;
   size_t out_floats;   // a_seq (D rounded up to 32) + N + 32
   float *out_pinned;   // host, pinned: out_floats + 4 words for the hand-off flags of the launch-per-iteration paths
-  // persistent one-launch tick (persist.hpp svmpc_tick_kernel): two sets of 5 x [tiles] arrival lines, then the time-out flag
-  unsigned int *tick_cnt;
-  int tick_tiles, tick_set;
   int tick_occ;       // resident workgroups per CU of the instantiation in use (0: not queried yet)
   size_t tick_occ_lds;
   // owner-computes persistent tick (tick2.hpp): exchange buffers, two counter sets, bookkeeping of ticks that did not start
@@ -206,7 +200,7 @@ struct dust_ctx {
   // Development switches and test hooks (environment variables), read ONCE when the context is created or cloned - the tick entry
   // points called getenv() several times per control tick before.  -1: unset, otherwise atoi of the value.
   struct EnvSw {
-    int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_share, no_tick1_barrier, tick1_test_abort, no_tick2,
+    int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
     int pack_merge;  // DUST_PACK_MERGE=0: PLAIN run lists even below the exact-zero threshold (development switch)
     float far_t;  // DUST_FAR_T: the far pre-pass' threshold (pairwise_far.hpp), default DUST_FAR_T_DEFAULT
@@ -236,7 +230,7 @@ struct dust_ctx {
   long long n_served, n_armed_hit;      // sticky: ticks answered through the done word; of them, ticks that had been launched ahead
   const float *t2_params_host;  // the caller's params of the call being staged (valid inside try_persistent only)
   long long t2_replays;         // sticky: ticks replayed so far (dust_tick_stats)
-  long long n_tick2, n_tick1, n_tick_other;  // sticky: optimize / tick calls served by tick2.hpp, persist.hpp, the other paths
+  long long n_tick2, n_tick_other;  // sticky: optimize / tick calls served by tick2.hpp, the other paths
   // hipGraph replay of a whole tick (dust_svmpc_tick)
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
@@ -427,12 +421,10 @@ static void free_all(dust_ctx *c) {
   if (c->stein_cnt) (void)hipFree(c->stein_cnt);
   if (c->iter_cnt) (void)hipFree(c->iter_cnt);
   if (c->score_hs) (void)hipFree(c->score_hs);
-  if (c->tick_cnt) (void)hipFree(c->tick_cnt);
   if (c->t2_cnt) (void)hipFree(c->t2_cnt);
   if (c->t2_xq) (void)hipFree(c->t2_xq);
   if (c->t2_sq) (void)hipFree(c->t2_sq);
   if (c->t2_lwq) (void)hipFree(c->t2_lwq);
-  if (c->tick1_start) (void)hipFree(c->tick1_start);
   if (c->out_pinned) (void)hipHostFree(c->out_pinned);
   if (c->far_cnt_host) (void)hipHostFree(c->far_cnt_host);
   if (c->istar) (void)hipFree(c->istar);
@@ -462,9 +454,6 @@ static void env_read(dust_ctx *c) {
   c->env.logp_mfma = env_int("DUST_LOGP_MFMA");
   c->env.no_fuse = env_int("DUST_NO_FUSE");
   c->env.no_persist = env_int("DUST_NO_PERSIST");
-  c->env.no_share = env_int("DUST_NO_SHARE");
-  c->env.no_tick1_barrier = env_int("DUST_NO_TICK1_BARRIER");
-  c->env.tick1_test_abort = env_int("DUST_TICK1_TEST_ABORT");
   c->env.no_tick2 = env_int("DUST_NO_TICK2");
   c->env.tick2_test_abort = env_int("DUST_TICK2_TEST_ABORT");
   c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
@@ -812,7 +801,7 @@ extern "C" int dust_sync(dust_ctx *c) {
     HIP_TRY(hipMemcpy(&flag, c->iter_cnt + (size_t)2 * (2 * c->iter_tiles + c->iter_js) * CNT_STRIDE, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return handoff_timeout(c, "one-launch SVGD iteration: hand-off spin timed out (results of that tick are invalid); the device seems to be shared with another process: this context runs plain kernels from here on");
   }
-  if (c->tick_cnt || c->t2_cnt) {
+  if (c->t2_cnt) {
     unsigned int flag = flag0;
     if (!have_flag) HIP_TRY(hipMemcpy(&flag, c->outblk + c->out_floats - 32, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
@@ -3102,220 +3091,6 @@ extern "C" int dust_svmpc_forward_ex(dust_ctx *c, int steps, const float *resamp
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// One launch per control tick (persist.hpp).  *done stays false when the shape / configuration does not qualify; the caller
-// then runs the launch-per-iteration path.  eps_dev: device [n_steps][S][N][D] fp32 or nullptr (Philox).
-template <int MODEL, int MODE, int CPT>
-static int tick_occupancy(size_t lds, int *occ) {
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)svmpc_tick_kernel<MODEL, MODE, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, (const void *)svmpc_tick_kernel<MODEL, MODE, CPT>, PAIR_NT, lds));
-  return DUST_OK;
-}
-
-static int launch_tick(dust_ctx *c, const float *state, int n_steps, const float *eps_dev, bool do_forward, bool *done) {
-  *done = false;
-  if (two_pass_family(c)) return DUST_OK;  // (these families run on the launch-per-iteration path: skid.hpp, particle_general.hpp)
-  const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;  // development switches
-  if (off || c->prof || pair_is_big(c) || c->nloc != c->N || c->theta_pinned || !c->theta_alt || c->capturing) return DUST_OK;
-  if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
-  if (n_steps < 0 || (n_steps == 0 && !do_forward)) return DUST_OK;
-  if (c->cfg.roll_strategy == DUST_ROLL_RESAMPLE) return DUST_OK;  // the last row comes from a host-drawn prior sample
-  if (do_forward && !c->have_sample && n_steps == 0) return DUST_OK;
-  if (c->noise_f16 && eps_dev) return DUST_OK;
-  if (c->N > 4096) return DUST_OK;
-  const int cpt = cpt_for(c->D);
-  if (cpt > 8) return DUST_OK;
-  TickArgs f;
-  memset(&f, 0, sizeof f);
-  TRY(prior_args(c, f.prior, &f.tiles));
-  if (f.prior.JS > 16 || f.prior.slice > PAIR_JC) return DUST_OK;
-  SampleOpts o;
-  memset(&o, 0, sizeof o);
-  o.noise_mode = eps_dev ? NOISE_EPS : NOISE_PHILOX;
-  o.noise_dev = eps_dev;
-  o.base = c->theta;
-  o.update_a_mat = 1;
-  o.bump_adam = 1;
-  o.merge_prior = 1;
-  int nt;
-  size_t lds_r;
-  TRY(rollout_args(c, o, f.ra, &nt, &lds_r));
-  if (f.ra.tile_scratch || (PAIR_NT % nt) != 0 || f.ra.G > 1) return DUST_OK;
-  if (f.ra.a_reg != 0.0f || f.ra.mw || f.ra.omegaT) return DUST_OK;  // LEAN rollout body only
-  f.ra.rearm = nullptr;
-  f.ra.rearm_n = 0;
-  f.sub_nt = nt;
-  f.per_block = PAIR_NT / nt;
-  if (c->N % f.per_block || PAIR_TI % f.per_block) return DUST_OK;
-  // prior means aliasing theta + isotropic prior scale: the pair role stages once and computes the pair distances once
-  {
-    bool iso = true;
-    for (int d = 1; d < c->da; ++d) iso = iso && c->cfg.sigma_p[d] == c->cfg.sigma_p[0];
-    const bool no_share = c->env.no_share >= 0;  // development switch
-    f.share_pair = (c->mu_aliased && iso && !no_share) ? 1 : 0;
-    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
-    const float r = c->cfg.sigma_p[0] / ell;
-    f.stein_ratio = r * r;
-  }
-  const size_t lds_p = pairwise_lds_bytes(PAIR_K1, cpt) + sizeof(float) * (size_t)PAIR_TI * (PAIR_JC + 1) + sizeof(float) * PAIR_TI;  // + kvS, mrow
-  f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
-  const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
-  if (lds > 160 * 1024) return DUST_OK;
-  f.JS = f.prior.JS;
-  f.n_pair_blocks = f.tiles * f.JS;
-  f.n_own_blocks = c->N / f.per_block;
-  const int grid = f.n_pair_blocks + f.n_own_blocks;
-  HIP_TRY(hipSetDevice(c->cfg.device));
-  // every workgroup must be resident for the whole launch: check the grid against the occupancy the runtime reports
-  if (!c->tick_occ || c->tick_occ_lds != lds) {
-    int occ = 0;
-#define DUST_TICK_OCC(MODEL, MODE, CPT) TRY((tick_occupancy<MODEL, MODE, CPT>(lds, &occ)))
-#define DUST_TICK_OCC_PICK(MODEL)                            \
-  do {                                                       \
-    if (c->cfg.kernel == DUST_KERNEL_IMQ) {                  \
-      if (cpt == 4) DUST_TICK_OCC(MODEL, PAIR_IMQ, 4);       \
-      else DUST_TICK_OCC(MODEL, PAIR_IMQ, 8);                \
-    } else {                                                 \
-      if (cpt == 4) DUST_TICK_OCC(MODEL, PAIR_K1, 4);        \
-      else DUST_TICK_OCC(MODEL, PAIR_K1, 8);                 \
-    }                                                        \
-  } while (0)
-    if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_TICK_OCC_PICK(DUST_MODEL_PENDULUM);
-    else DUST_TICK_OCC_PICK(DUST_MODEL_PARTICLE);
-#undef DUST_TICK_OCC_PICK
-#undef DUST_TICK_OCC
-    c->tick_occ = occ > 0 ? occ : -1;
-    c->tick_occ_lds = lds;
-  }
-  int n_cu = 0;
-  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->cfg.device));
-  if (c->tick_occ < 1 || grid > c->tick_occ * n_cu) return DUST_OK;
-  {
-    const size_t nd = (size_t)f.JS * c->nloc * 8 * cpt;
-    TRY(ensure(&c->pS, &c->pS_cap, nd));
-  }
-  const int lines = 5 * f.tiles + 1 + 16;  // + the global log-weight line + the 16 arrival lines of the start barrier
-  if (!c->tick_cnt || c->tick_tiles != f.tiles) {
-    if (c->tick_cnt) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      HIP_TRY(hipFree(c->tick_cnt));
-    }
-    c->tick_cnt = nullptr;
-    TRY(dalloc(&c->tick_cnt, ((size_t)2 * lines + 1) * CNT_STRIDE));
-    HIP_TRY(hipMemsetAsync(c->tick_cnt, 0, ((size_t)2 * lines + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));
-    c->tick_tiles = f.tiles;
-    c->tick_set = 0;
-  }
-  if (c->cfg.dim_p > 0 && c->M >= 1 && !c->params_dev) return fail(DUST_ERR_INVALID, "params_sampling is on: pass [n_steps][M][P] parameter samples");
-  f.stein = f.prior;
-  f.stein.V = c->score;
-  f.stein.logmix = nullptr;
-  {
-    const float ell = c->cfg.kernel == DUST_KERNEL_IMQ ? c->cfg.imq_ell : 0.69314718055994531f;
-    for (int d = 0; d < 4; ++d) f.stein.inv_s[d] = 1.0f / ell;
-  }
-  f.stein.pA = c->pS;
-  f.stein.pB = c->pB;
-  f.stein.pM = nullptr;
-  f.stein.pL = nullptr;
-  f.stein.stamps = nullptr;
-  f.prior.stamps = nullptr;
-  f.ra.stamps = nullptr;
-  f.ua = update_args(c, 1);
-  f.ua.pA = c->pS;
-  f.ua.fused_cnt = nullptr;
-  f.ua.fused_tiles = 0;
-  f.pm = prior_merge_args(c);
-  f.n_iters = n_steps;
-  f.do_forward = do_forward ? 1 : 0;
-  f.mu_aliased = c->mu_aliased ? 1 : 0;
-  f.roll_strategy = c->cfg.roll_strategy;
-  f.weighted_prior = c->cfg.weighted_prior;
-  f.theta_buf0 = c->theta;
-  f.theta_buf1 = c->theta_alt;
-  f.mu = c->mu;
-  for (int k = 0; k < 4; ++k) f.x0[k] = k < c->ds ? state[k] : 0.f;
-  f.eps = eps_dev;
-  f.eps_stride = (size_t)c->S * c->N * c->D;
-  f.params = (c->cfg.dim_p > 0 && c->params_dev) ? c->params_dev : nullptr;
-  unsigned int *set = c->tick_cnt + (size_t)c->tick_set * lines * CNT_STRIDE;
-  f.cnt_theta = set;
-  f.cnt_prior = set + (size_t)1 * f.tiles * CNT_STRIDE;
-  f.cnt_score = set + (size_t)2 * f.tiles * CNT_STRIDE;
-  f.cnt_stein = set + (size_t)3 * f.tiles * CNT_STRIDE;
-  f.cnt_lw = set + (size_t)4 * f.tiles * CNT_STRIDE;
-  f.zero_base = c->tick_cnt + (size_t)(1 - c->tick_set) * lines * CNT_STRIDE;
-  f.zero_lines = lines;
-  f.timeout_flag = reinterpret_cast<unsigned int *>(c->outblk + c->out_floats - 32);
-  const bool mu_aliased_before = c->mu_aliased;
-  if (do_forward && c->env.no_tick1_barrier < 0) {  // whole ticks only: an aborted optimize-only call would leave the host's particle-buffer bookkeeping ahead of the device
-    if (!c->tick1_start) {
-      TRY(dalloc(&c->tick1_start, (size_t)CNT_STRIDE));
-      HIP_TRY(hipMemsetAsync(c->tick1_start, 0, (size_t)CNT_STRIDE * sizeof(unsigned int), c->stream));
-      c->tick1_seq = 0u;
-    }
-    c->tick1_seq = (c->tick1_seq + 1u) & 0x7fffffffu;
-    if (c->tick1_seq == 0u) c->tick1_seq = 1u;  // (the go word only has to differ from the previous tick's)
-    f.start_cnt = set + (size_t)(5 * f.tiles + 1) * CNT_STRIDE;
-    f.go = c->tick1_start;
-    f.abort_cnt = f.timeout_flag + 1;
-    f.expect_aborts = c->t2_aborts_seen;
-    f.seq = c->tick1_seq;
-    {  // test hook DUST_TICK1_TEST_ABORT, as DUST_TICK2_TEST_ABORT
-      const int every = c->env.tick1_test_abort;
-      f.test_abort = every > 0 && ((c->n_tick1 + 1) % every) == 0;
-    }
-  }
-  f.logp = c->logp;
-  f.lw = c->lw;
-  f.pw = c->pw;
-  f.a_seq_out = c->a_seq_out;
-  f.logmix = c->logmix;
-  f.mixw = c->mixw;
-  f.istar = c->istar;
-  f.tl = c->tl_dev;
-#define DUST_LAUNCH_TICK(MODEL, MODE, CPT) svmpc_tick_kernel<MODEL, MODE, CPT><<<grid, PAIR_NT, lds, c->stream>>>(f)
-#define DUST_PICK_TICK(MODEL)                                       \
-  do {                                                              \
-    if (c->cfg.kernel == DUST_KERNEL_IMQ) {                         \
-      if (cpt == 4) DUST_LAUNCH_TICK(MODEL, PAIR_IMQ, 4);           \
-      else DUST_LAUNCH_TICK(MODEL, PAIR_IMQ, 8);                    \
-    } else {                                                        \
-      if (cpt == 4) DUST_LAUNCH_TICK(MODEL, PAIR_K1, 4);            \
-      else DUST_LAUNCH_TICK(MODEL, PAIR_K1, 8);                     \
-    }                                                               \
-  } while (0)
-  {
-    PersistChain chain(c);
-    if (c->cfg.model == DUST_MODEL_PENDULUM) DUST_PICK_TICK(DUST_MODEL_PENDULUM);
-    else DUST_PICK_TICK(DUST_MODEL_PARTICLE);
-    HIP_TRY(hipGetLastError());
-  }
-#undef DUST_PICK_TICK
-#undef DUST_LAUNCH_TICK
-  c->n_tick1++;
-  c->tick_set ^= 1;
-  if (do_forward && f.start_cnt) {  // replay information (t2_settle): the state this tick started from
-    c->t2_inflight = true;
-    c->t2_transactional = false;
-    for (int k = 0; k < 4; ++k) c->t2_state[k] = k < c->ds ? state[k] : 0.f;
-    c->t2_steps = n_steps;
-    c->t2_fwd = true;
-    c->t2_replayable = eps_dev == nullptr;
-    c->t2_mu_aliased = mu_aliased_before;
-    t2_queue_push(c, c->t2_state, n_steps, true, eps_dev == nullptr, mu_aliased_before);
-  }
-  if (!do_forward && (n_steps & 1)) std::swap(c->theta, c->theta_alt);
-  if (do_forward) c->mu_aliased = true;
-  c->actions_valid = false;
-  c->have_sample = true;
-  c->fused_dirty = c->fused_dirty;  // (the launch-per-iteration paths' counters are untouched)
-  *done = true;
-  return DUST_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
 // One launch per control tick, owner-computes form (tick2.hpp): two all-to-all hand-offs per SVGD iteration instead of four.
 // *done stays false when the shape / configuration does not qualify (persist.hpp's form or the launch-per-iteration path run).
 // the static part of launch_tick2's eligibility (everything but "the prior means alias the particles")
@@ -3957,8 +3732,6 @@ static int try_persistent(dust_ctx *c, const float *state, int n_steps, const fl
     eps_dev = c->noise_stage;
   }
   TRY(launch_tick2(c, state, n_steps, eps_dev, do_forward, done));
-  if (*done) return DUST_OK;
-  TRY(launch_tick(c, state, n_steps, eps_dev, do_forward, done));
   if (!*done && !c->capturing) c->persist_declined = key;  // (a decline during graph capture says nothing about the eager call)
   return DUST_OK;
 }
@@ -4075,7 +3848,7 @@ extern "C" int dust_set_skid_steer(dust_ctx *c, const dust_skid_config *g) {
 extern "C" int dust_tick_stats(dust_ctx *c, long long out[4]) {
   if (!c || !out) return fail(DUST_ERR_INVALID, "null argument");
   out[0] = c->n_tick2;
-  out[1] = c->n_tick1;
+  out[1] = 0;  // (the tiled one-launch tick, persist.hpp: retired in round 6 - no BASELINE configuration took it)
   out[2] = c->n_served;  // (closed-loop serving: ticks answered through the pinned done word)
   out[3] = c->t2_replays;
   return DUST_OK;

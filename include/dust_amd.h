@@ -151,7 +151,7 @@ void dust_destroy(dust_ctx *ctx);
 int dust_sync(dust_ctx *ctx);
 /* Which device path served the SVMPC.optimize / forward calls so far (svmpc.py:97-200; sticky counts since creation):
  * out[0] one-launch ticks, owner-computes form (tick2.hpp) - launched-ahead ticks of closed-loop serving included, also cancelled ones;
- * out[1] one-launch ticks, tiled form (persist.hpp); out[2] ticks answered through the pinned done word of closed-loop serving;
+ * out[1] always 0 (the tiled one-launch tick of rounds 2-5 is retired); out[2] ticks answered through the pinned done word of closed-loop serving;
  * out[3] ticks whose one-launch kernel found the device shared with other work (its workgroups were not all resident) and that
  * were therefore run on the launch-per-iteration path instead - late, on unchanged state, never lost. */
 int dust_tick_stats(dust_ctx *ctx, long long out[4]);

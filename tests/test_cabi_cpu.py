@@ -128,13 +128,11 @@ def test_hot_kernels_do_not_spill(built, tmp_path):
     # OUTSIDE their inner loops (tick2.hpp: the argument block is re-read per phase so that nothing is kept across the iteration
     # loop; what is left are phase-boundary saves of the per-particle state).  The budget below is the regression guard: the
     # first tick2 build had 330 spilled registers inside the pairwise loop and ran 2.5x slower with every result correct.
-    ticks = {k: v for k, v in kernels.items() if re.search(r"svmpc_tick2?_kernel", k)}
-    assert len(ticks) >= 8, sorted(kernels)
-    # (round 4: the tiled kernel's Pendulum / 4-column instances went from 8 to 11 with the eight-normal noise draw; 141 us per cfg2 tick
-    #  with DUST_NO_TICK2=1 against 143-145 us before - the fallback kernel's budget is 12 now)
+    ticks = {k: v for k, v in kernels.items() if re.search(r"svmpc_tick2_kernel", k)}
+    assert len(ticks) >= 4, sorted(kernels)
     # (round 4: tick2.hip is built without machine LICM and its kernels spill NO vector register - the guard is 8 now; with the default
     #  pass pipeline they spill 15 and run 3 us per cfg2 tick slower, which is what this would catch if the per-unit flag were lost)
-    over = {k: v for k, v in ticks.items() if v[0] > (8 if "tick2" in k else 12) or v[1] > 128}
+    over = {k: v for k, v in ticks.items() if v[0] > 8 or v[1] > 128}
     assert not over, "tick kernels over their spill budget (name: (spilled VGPRs, scratch bytes)): %r" % over
 
 

@@ -1,5 +1,5 @@
-"""Owner-computes one-launch tick (dust_amd/csrc/tick2.hpp) against the tiled one-launch tick (persist.hpp), the
-launch-per-iteration path and the CPU oracle.  The reference path is `optimize(); forward()` of dust/utils/simulations.py:104-123
+"""Owner-computes one-launch tick (dust_amd/csrc/tick2.hpp) against the launch-per-iteration paths (DUST_NO_TICK2: the fused launch
+forms; the tiled one-launch tick of rounds 2-5, persist.hpp, is retired) and the CPU oracle.  The reference path is `optimize(); forward()` of dust/utils/simulations.py:104-123
 (SVMPC.optimize svmpc.py:97-126, SVMPC.forward svmpc.py:172-200).  tick2 takes a tick when the prior means alias the particles
 (every tick after the first forward), N % 4 == 0, N <= 1024, H * d_a <= 32; `tick_stats()` tells which path served a call."""
 import os
@@ -11,7 +11,7 @@ from helpers import elemerr
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-5  # element-wise (|a - b| / (|b| + rms b)): sums over keys / samples are taken in another order than in persist.hpp
+TOL = 2e-5  # element-wise (|a - b| / (|b| + rms b)): sums over keys / samples are taken in another order than in the tiled kernels
 
 
 def _state(model):
@@ -107,10 +107,10 @@ def _make_with_env(env, *a, **kw):
 
 @pytest.mark.parametrize("ext_noise", [True, False])
 @pytest.mark.parametrize("model,N,S,H,iters,M,kw", SHAPES)
-def test_tick2_equals_tiled_tick(model, N, S, H, iters, M, kw, ext_noise):
-    """Three ticks of two contexts side by side: tick 1 runs the tiled form on both (the prior means do not alias the particles yet),
-    ticks 2-3 run tick2.hpp in one and persist.hpp in the other.  Caller-supplied noise and the device Philox stream (same counter
-    layout in both kernels).  After every tick the tiled context takes over the owner-computes context's particles, a_mat and mixture,
+def test_tick2_equals_launch_per_iteration(model, N, S, H, iters, M, kw, ext_noise):
+    """Three ticks of two contexts side by side: tick 1 runs plain kernels on both (the prior means do not alias the particles yet),
+    ticks 2-3 run tick2.hpp in one and the launch-per-iteration forms in the other.  Caller-supplied noise and the device Philox stream (same counter
+    layout in both kernels).  After every tick the other context takes over the owner-computes context's particles, a_mat and mixture,
     so EVERY tick is a first-divergence comparison at the tolerances of one tick (round 3 let the two runs drift apart and compared
     the third tick at 2e-2, which proved little - VERDICT r3): costs at 2e-5 element-wise, what lies downstream of
     exp(-alpha cost) - one ulp of a cost of 1e3 is 1e-4 on a weight - at 5e-4."""
@@ -139,7 +139,7 @@ def test_tick2_equals_tiled_tick(model, N, S, H, iters, M, kw, ext_noise):
     a.close()
     b.close()
     assert stats_a["tick2"] == 2 and stats_a["replayed"] == 0, stats_a
-    assert stats_b["tick2"] == 0, stats_b  # (the tiled one-launch kernel, or - several lane groups per rollout - the launch-per-iteration path)
+    assert stats_b["tick2"] == 0, stats_b
 
 
 def test_tick2_optimize_only_then_forward():
@@ -176,7 +176,7 @@ def test_tick2_against_oracle_whole_tick():
     c, rng = _make("pendulum", N, S, H)
     st = _state("pendulum")
     eps0 = rng.standard_normal((1, S, N, H, 1)).astype(np.float32)
-    c.svmpc_tick(st, 1, eps=eps0)  # tick 1 (tiled form): afterwards the prior means alias the particles
+    c.svmpc_tick(st, 1, eps=eps0)  # tick 1 (plain kernels): afterwards the prior means alias the particles
     th, (mu, mix), am = c.get_theta(), c.get_prior(), c.get_a_mat()
     eps = rng.standard_normal((K, S, N, H, 1)).astype(np.float32)
     a_seq, pw = c.svmpc_tick(st, K, eps=eps)
@@ -192,7 +192,7 @@ def test_tick2_against_oracle_whole_tick():
 
 
 def test_tick2_long_run_stays_consistent():
-    """400 product ticks (device noise) through tick2 and through the tiled form from the same start: finite throughout, and the
+    """400 product ticks (device noise) through tick2 and through the launch-per-iteration forms from the same start: finite throughout, and the
     first 3 ticks - before chaos separates the two summation orders - agree."""
     N, S, H = 1024, 128, 30
     st = _state("pendulum")
@@ -390,13 +390,13 @@ def test_tick2_open_loop_queue_aborts_in_order():
     assert np.isfinite(e0).all() and abs(float(p0.sum()) - 1.0) < 1e-3
 
 
-@pytest.mark.parametrize("env", [{}, {"DUST_NO_TICK2": "1"}, {"DUST_NO_PERSIST": "1"}], ids=["tick2", "tiled-tick", "launch-per-iteration"])
+@pytest.mark.parametrize("env", [{}, {"DUST_NO_TICK2": "1"}, {"DUST_NO_PERSIST": "1"}], ids=["tick2", "fused-launches", "launch-per-iteration"])
 def test_contexts_tick_concurrently(env):
     """Three contexts on one device ticking from three host threads.  Every one-launch form spins on its own
     workgroups and needs them co-resident; with a second context on the device the library chains those launches across the
     contexts' streams (and the owner-computes tick additionally proves residency at its start and is replayed otherwise).  No
-    tick may be lost or fail: every call returns, results stay finite and normalised.  All three tick forms: the owner-computes
-    kernel, the tiled one-launch kernel (also every context's FIRST tick), the launch-per-iteration forms with in-launch hand-offs."""
+    tick may be lost or fail: every call returns, results stay finite and normalised.  All tick forms: the owner-computes kernel, the
+    fused launch-per-iteration forms with in-launch hand-offs, plain launches."""
     import threading
 
     N, S, H, T, C = 1024, 128, 30, 120, 3
@@ -434,41 +434,6 @@ def test_contexts_tick_concurrently(env):
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
-
-
-@pytest.mark.parametrize("model,N,S,H,kw", [("pendulum", 256, 128, 30, {}), ("pendulum", 512, 64, 40, {}), ("particle", 128, 64, 24, {})])
-def test_tiled_tick_aborted_ticks_are_replayed(model, N, S, H, kw):
-    """The tiled one-launch tick (persist.hpp) proves residency with the same start barrier as the owner-computes kernel: a tick
-    that does not start changes nothing and is replayed on plain kernels - including a context's FIRST tick, whose prior means do
-    not alias the particles yet.  DUST_TICK1_TEST_ABORT=2 aborts every second launch; DUST_NO_TICK2 keeps every tick on the tiled
-    kernel (shapes 2 and 3 are not the owner-computes kernel's anyway: H d_a > 32)."""
-    st = _state(model)
-    outs = []
-    for env in ({"DUST_TICK1_TEST_ABORT": "2", "DUST_NO_TICK2": "1"}, {"DUST_NO_TICK2": "1"}):
-        saved = {k: os.environ.pop(k, None) for k in ("DUST_TICK1_TEST_ABORT", "DUST_NO_TICK2")}
-        os.environ.update(env)
-        try:
-            c, _ = _make(model, N, S, H, **kw)
-            hist = []
-            for t in range(6):
-                a_seq, pw = c.svmpc_tick(st, 3)
-                hist.append((a_seq.copy(), pw.copy(), c.get_theta()))
-            outs.append((hist, c.tick_stats()))
-            c.close()
-        finally:
-            for k in ("DUST_TICK1_TEST_ABORT", "DUST_NO_TICK2"):
-                os.environ.pop(k, None)
-                if saved[k] is not None:
-                    os.environ[k] = saved[k]
-    (h0, s0), (h1, s1) = outs
-    assert s0["tick1"] == 6 and s0["replayed"] == 3 and s0["tick2"] == 0, s0
-    assert s1["tick1"] == 6 and s1["replayed"] == 0, s1
-    for t in range(3):  # (replayed ticks take the separate prior / Stein tiles: one rounding apart; later ticks amplify)
-        assert elemerr(h0[t][2], h1[t][2]) < 2e-3 * (1 + 4 * t), (t, elemerr(h0[t][2], h1[t][2]))
-        assert np.abs(h0[t][1] - h1[t][1]).max() < 5e-3 * (1 + 4 * t)
-    for t in range(6):
-        assert np.isfinite(h0[t][2]).all() and abs(float(h0[t][1].sum()) - 1.0) < 1e-3
-
 
 @pytest.mark.parametrize("model,N,S,H,iters,M,kw", [("pendulum", 2048, 16, 30, 2, 1, {}), ("pendulum", 2048, 16, 12, 2, 2, dict(kernel="IMQ")),
                                                     ("particle", 2048, 16, 16, 2, 1, {})])
