@@ -97,6 +97,8 @@ struct dust_ctx {
   bool own_stream;
   hipStream_t stream2;  // side stream: the prior pass runs beside the rollout kernel (both only read theta)
   hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_order;   // behind the side stream's query_order_kernel (pairwise_packed.hpp); order_pending: nobody has waited for it yet
+  bool order_pending;
   hipStream_t pair_stream;  // stream the next pairwise launch goes to (stream or stream2)
   // particles / prior / controller state
   float *theta, *thetaT, *mu, *muT, *logmix, *mixw;
@@ -129,8 +131,10 @@ struct dust_ctx {
   SkidModel skid;            // DUST_MODEL_SKID_STEER: model parameters and the quadratic cost (dust_set_skid_steer)
   // pairwise_packed.hpp: the near-key lists of the last large-set pass 1 - key indices [tiles][chunks * 64], unit offsets
   // [tiles][chunks + 1], unit query masks [tiles][chunks][4], slice boundaries of pass 1 / pass 2, non-zero flags of the units' kernel blocks
-  float *pk_idx, *pk_uoff, *pk_uq, *pk_soff, *pk_goff, *pk_nzu;
-  size_t pk_idx_cap, pk_uoff_cap, pk_uq_cap, pk_soff_cap, pk_goff_cap, pk_nzu_cap;
+  float *pk_idx, *pk_uoff, *pk_uq, *pk_soff, *pk_goff, *pk_nzu, *pk_perm, *pk_lead;
+  size_t pk_idx_cap, pk_uoff_cap, pk_uq_cap, pk_soff_cap, pk_goff_cap, pk_nzu_cap, pk_perm_cap, pk_lead_cap;
+  bool stagewise;                 // inside dust_svmpc_phi (a stage-wise call on caller-supplied inputs): index order - the same inputs give the same bits, call after call
+  bool pk_order;                  // pass 1 walks its queries in tile order (pk_perm) and notes their leaders (pk_lead) for the next order
   int pk_tiles, pk_umax, pk_jsg;  // geometry of those lists
   bool pk_masks, pk_dense;        // the units carry query masks / pass 2 visits every unit (DUST_DENSE)
   float *far_z, *far_n, *far_f;  // pairwise_far.hpp: binary16 rows, (norms, log weights), unit flags [tiles][chunks] bytes
@@ -202,6 +206,7 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    int pack_order;  // DUST_PACK_ORDER=0: the queries stay in index order (development switch)
     int pack_merge;  // DUST_PACK_MERGE=0: PLAIN run lists even below the exact-zero threshold (development switch)
     float far_t;  // DUST_FAR_T: the far pre-pass' threshold (pairwise_far.hpp), default DUST_FAR_T_DEFAULT
   } env;
@@ -409,7 +414,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->pk_idx, &c->pk_uoff, &c->pk_uq, &c->pk_soff, &c->pk_goff, &c->pk_nzu, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->pk_idx, &c->pk_uoff, &c->pk_uq, &c->pk_soff, &c->pk_goff, &c->pk_nzu, &c->pk_perm, &c->pk_lead, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -434,6 +439,7 @@ static void free_all(dust_ctx *c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_order) (void)hipEventDestroy(c->ev_order);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -459,6 +465,7 @@ static void env_read(dust_ctx *c) {
   c->env.tick2_test_timeout = env_int("DUST_TICK2_TEST_TIMEOUT");
   c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
   c->env.pack_merge = env_int("DUST_PACK_MERGE");
+  c->env.pack_order = env_int("DUST_PACK_ORDER");
   const char *ft = getenv("DUST_FAR_T");
   c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
@@ -574,6 +581,7 @@ extern "C" void dust_destroy(dust_ctx *c) {
   }
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   comm_release(c);
   free_all(c);
   if (c->serve_host) (void)hipHostFree(c->serve_host);
@@ -651,6 +659,7 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
   c->pair_stream = c->stream;
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
@@ -1886,6 +1895,20 @@ static int launch_pair_big(dust_ctx *c, const PairArgs &a, int tiles) {
 static int ensure_partials(dust_ctx *c, int JS);
 static int far_counts_alloc(dust_ctx *c);
 
+// the side stream's query_order_kernel (launch_gram_score) must be done before its outputs are read or its inputs rewritten
+static int order_join(dust_ctx *c) {
+  if (!c->order_pending) return DUST_OK;
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_order, 0));
+  if (c->pair_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->pair_stream, c->ev_order, 0));
+  c->order_pending = false;
+  return DUST_OK;
+}
+
+__global__ void iota_kernel(int *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
 // slices per query tile of the two run-list passes (pairwise_packed.hpp): about two resident rounds of workgroups when every
 // slice has units, at most 24 partial rows per particle for the merge kernels.  Static - a function of the shape alone: the
 // summation order does not depend on the data, and a captured tick keeps its grid.
@@ -1924,6 +1947,21 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   c->far_tiles = c->far_chunks = 0;
   PackArgs pk;
   memset(&pk, 0, sizeof pk);
+  // tile order (pairwise_packed.hpp): merged lists only - K1 behind the far pre-pass below the exact-zero threshold
+  const bool merge_mode = c->cfg.kernel == DUST_KERNEL_K1_RBF && !dense && c->env.far != 0 && c->env.far_t < DUST_FAR_T_EXACT && c->env.pack_merge != 0;
+  const bool order = merge_mode && c->env.pack_order != 0 && !c->stagewise;
+  if (order) {
+    const bool fresh = c->pk_perm_cap < (size_t)c->nloc || c->pk_lead_cap < (size_t)c->nloc;
+    if (fresh && c->capturing) return fail(DUST_ERR_STATE, "tile-order buffers must exist before a capture");
+    TRY(ensure(&c->pk_perm, &c->pk_perm_cap, (size_t)c->nloc));
+    TRY(ensure(&c->pk_lead, &c->pk_lead_cap, (size_t)c->nloc));
+    if (fresh) {  // index order, no leaders yet
+      iota_kernel<<<(c->nloc + 255) / 256, 256, 0, c->pair_stream>>>(reinterpret_cast<int *>(c->pk_perm), c->nloc);
+      HIP_TRY(hipMemsetAsync(c->pk_lead, 0x7f, (size_t)c->nloc * sizeof(int), c->pair_stream));
+    }
+  }
+  c->pk_order = order;
+  TRY(order_join(c));
   if (c->cfg.kernel == DUST_KERNEL_K1_RBF) {  // pairwise_far.hpp: where the running maxima start (every mode), and the far units
     const bool flags = !dense && c->env.far != 0;  // (DUST_FAR=0 / DUST_DENSE=1: visit all)
     FarArgs f;
@@ -1952,6 +1990,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
     f.wP[0] = b.wP[0];
     f.wP[1] = b.wP[1];
     f.far = reinterpret_cast<unsigned char *>(c->far_f);
+    f.qperm = order ? reinterpret_cast<const int *>(c->pk_perm) : nullptr;
     if (flags) {
       TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)tiles * chunks * 8));
       f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
@@ -1993,7 +2032,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   pk.N = c->N;
   pk.tiles = tiles;
   pk.chunks = chunks;
-  pk.merge = (pk.qmask != nullptr && c->env.far_t < DUST_FAR_T_EXACT && c->env.pack_merge != 0) ? 1 : 0;
+  pk.merge = (pk.qmask != nullptr && merge_mode) ? 1 : 0;
   pk.JS = JS;
   pk.JSG = JS;
   pk.ldi = chunks * 64;
@@ -2021,6 +2060,8 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   b.uq = c->pk_masks ? pk.uq : nullptr;
   b.soff = pk.soff;
   b.nzu = c->pk_dense ? nullptr : reinterpret_cast<unsigned char *>(c->pk_nzu);
+  b.qperm = order ? reinterpret_cast<const int *>(c->pk_perm) : nullptr;
+  b.lead = order ? reinterpret_cast<int *>(c->pk_lead) : nullptr;
   c->fused_js = JS;
   TRY(ensure_partials(c, std::max(a.JS, JS)));  // before anything is written: pass 2 adds its pA rows later
   b.p.pA = c->pA;
@@ -2089,7 +2130,10 @@ static bool logp_far_decide(dust_ctx *c) {
   unsigned int spins = 0u;
   while (hc[2] != c->far_logp_issued) {  // the last pre-pass issued has not reported yet (back-to-back ticks): wait for it
     DUST_CPU_PAUSE();
-    if ((++spins & 1023u) == 0u && host_now() - t0 > 0.05) return true;  // (device stalled or gone: the next synchronisation will say)
+    if ((++spins & 1023u) == 0u && host_now() - t0 > 0.05) {  // (device stalled or gone: the next synchronisation will say)
+      if (getenv("DUST_DEBUG_FAR")) fprintf(stderr, "logp_far_decide: report %u awaited, %u seen\n", c->far_logp_issued, hc[2]);
+      return true;
+    }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   const unsigned int fa = hc[0], al = hc[1];
@@ -2248,6 +2292,7 @@ static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
   g.uoff = reinterpret_cast<const int *>(c->pk_uoff);
   g.uq = c->pk_masks ? reinterpret_cast<const unsigned int *>(c->pk_uq) : nullptr;
   g.goff = reinterpret_cast<const int *>(c->pk_goff);
+  g.qperm = c->pk_order ? reinterpret_cast<const int *>(c->pk_perm) : nullptr;
   g.nzu = c->pk_dense ? nullptr : reinterpret_cast<const unsigned char *>(c->pk_nzu);
   dim3 grid(g.tiles, g.JS);
   // (its own column padding: whole 16-column MFMA tiles, not the 32 / 64 / 80 of pass 1 - D = 40 runs 3 column tiles instead of 4;
@@ -2261,6 +2306,26 @@ static int launch_gram_score(dust_ctx *c, const PairArgs &a, int *JS_out) {
   else DUST_LAUNCH_GS(80, FusedGeom<80>::TQ);
 #undef DUST_LAUNCH_GS
   HIP_TRY(hipGetLastError());
+  if (c->pk_order) {
+    // The next tick's tile order, from the leaders pass 1 noted.  One workgroup, 8 us at 2 048 rows and 42 us at 16 384, and nothing
+    // in this tick needs its result: large sets run it on the side stream beside the update and the log-p pass; the tick's last
+    // launches (forward_finish_device) - or the next pass 1, whichever comes first - wait for it.
+    const size_t lds = query_order_lds_bytes(c->nloc);
+    if (lds > 64 * 1024 && !c->capturing)
+      HIP_TRY(hipFuncSetAttribute((const void *)query_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool side = c->stream2 && !c->prof && c->nloc >= 8192;  // (below that the kernel is shorter than the two cross-stream waits: 8 us at 2 048 rows)
+    hipStream_t qs = side ? c->stream2 : c->stream;
+    if (side) {
+      HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
+    query_order_kernel<<<1, 1024, lds, qs>>>(reinterpret_cast<int *>(c->pk_lead), reinterpret_cast<int *>(c->pk_perm), c->nloc, c->n0, c->N);
+    HIP_TRY(hipGetLastError());
+    if (side) {
+      HIP_TRY(hipEventRecord(c->ev_order, c->stream2));
+      c->order_pending = true;
+    }
+  }
   return DUST_OK;
 }
 
@@ -2621,6 +2686,11 @@ extern "C" int dust_svmpc_phi(dust_ctx *c, const float *costs, const float *acti
   TRY(settle_pending(c));
   if ((costs == nullptr) != (actions == nullptr)) return fail(DUST_ERR_INVALID, "pass both costs and actions, or neither");
   HIP_TRY(hipSetDevice(c->cfg.device));
+  struct Stagewise {  // (the tile order of pairwise_packed.hpp follows the TICKS' history: a stage-wise call keeps index order)
+    dust_ctx *c;
+    ~Stagewise() { c->stagewise = false; }
+  } stagewise_guard{c};
+  c->stagewise = true;
   TRY(launch_prior(c));
   if (costs) {
     // a user-supplied log_p returned (costs, actions): only the weights / score reductions of kernel A run
@@ -2961,6 +3031,7 @@ static void roll_done(dust_ctx *c) {
 // `roll_all`: a sharded context that holds every rank's particles (just gathered) rolls ALL N rows itself instead of rolling its
 // own and gathering the others' - the roll is a pure function of the row (strategies "repeat" / "mean")
 static int forward_finish_device(dust_ctx *c, int steps = -1, const float *last_row_dev = nullptr, bool roll_all = false) {
+  TRY(order_join(c));  // (the side stream returns before the tick ends: a captured tick must see it come back)
   Prof p(c, DUST_K_FORWARD);
   const FinalizeArgs f = finalize_args(c, false);
   RollArgs r = roll_args(c, steps, c->cfg.roll_strategy, last_row_dev);

@@ -62,6 +62,7 @@ struct FarArgs {
   unsigned int *qmask;  // [tiles][chunks][8] per unit (MASKS instances): words 0-3: bit q = query q of the tile has a NEAR key in the chunk (the
                         // fused pass computes exact distances for those queries only); words 4-5: bit k = key k of the chunk has a near
                         // query in the tile (the others get no term at all: their weights are forced to exact zeros, pass B skips them)
+  const int *qperm;     // [n_local] tile order of the QUERIES (position -> local row; pairwise_packed.hpp), or nullptr: identity
   unsigned int *count;  // [3] (8-byte aligned) {far units, all units} of this launch (zeroed by the row kernel) and the number of
                         // counted launches so far (never zeroed: it numbers the reports), or nullptr
   unsigned int *host_count;  // [3] pinned host words the LAST workgroup of far_flags_kernel copies {far, all, launch number} to (no
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(256, 3) void far_flags_kernel(const FarArgs a) {
   float lmq = INFINITY;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const int qi = min(a.i0 + tq * TQ + 16 * t + r16, N - 1);  // (rows behind the set: clamped, as the fused pass clamps them)
+    // (rows behind the rank's last: clamped, as pass 1 clamps them; pass 1's tile order when it has one)
+    const int qi = a.qperm ? a.i0 + a.qperm[min(tq * TQ + 16 * t + r16, a.n_local - 1)] : min(a.i0 + tq * TQ + 16 * t + r16, N - 1);
 #pragma unroll
     for (int s = 0; s < NP; ++s) bq[t][s] = *reinterpret_cast<const v8h *>(a.Z + (size_t)qi * ZH + 32 * s + 8 * g);
     hqh[t] = -0.5f * a.nrm[qi];

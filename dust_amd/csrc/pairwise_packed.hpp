@@ -156,7 +156,18 @@ struct PairPackedArgs {
   const int *soff;
   unsigned char *nzu;  // [tiles][umax] 1 = some Stein kernel value of the unit is not exactly 0 (pass 2 skips the others), or nullptr
   const float *m0;     // [N] where each query's running max starts (pairwise_far.hpp), or nullptr: -inf
+  const int *qperm;    // [n_local] the rank's queries in TILE ORDER (position -> local row; query_order_kernel below), or nullptr: identity
+  int *lead;           // [n_local] by local row: the smallest key index with a kernel value above PACK_LEAD_K (atomicMin), or nullptr
 };
+
+// Tile order.  A tile's run list is the union of its 96 queries' near keys.  Near-duplicates are scattered over the index range, so
+// 96 consecutive particles are near 96 different groups of keys: 1 380 listed keys per tile on the aged cfg4 set, 38 % of a unit's
+// queries near one of its keys.  Tiles of queries that share their near keys need far shorter lists (host analysis of the same set,
+// tools/far_granularity.py: 355 keys per tile, 3.6x fewer units, 77 % of a unit's queries near).  So the queries are walked in the
+// order of their LEADER - the smallest key index with a non-negligible kernel value, which pass 1 notes on the way (one ballot per
+// query and unit) - sorted once per tick behind pass 2, for the NEXT tick's tiles: the particles move little between ticks and the
+// order only groups the work - every row's result is the same whatever tile it rides in, up to the regrouping of its key units.
+#define PACK_LEAD_K 1.0e-27f  // k = exp(-d2 / 0.96) above this: d2 < 60 (the far pre-pass' default threshold)
 
 template <int DPB>
 static inline size_t pairwise_packed_lds_bytes() {
@@ -188,8 +199,13 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   const bool pb = qg < TQ / 4;
   const int qgc = pb ? qg : 0;
   const int tile = blockIdx.x, js = blockIdx.y;
-  const int ib = a.i0 + tile * TQ;
   typedef const int __attribute__((address_space(4))) * ci32;  // (written by an earlier launch: scalar loads)
+  // local row of the tile's query q (positions behind the rank's last row repeat it: computed, never stored)
+  const int nl1 = a.n_local - 1;
+  const int *qpv = b.qperm;
+  const ci32 qps = (ci32)(uintptr_t)b.qperm;
+  auto row_v = [&](const int q) { const int pos = min(tile * TQ + q, nl1); return qpv ? qpv[pos] : pos; };   // per lane
+  auto row_s = [&](const int q) { const int pos = min(tile * TQ + q, nl1); return qps ? qps[pos] : pos; };   // wave-uniform
   typedef const unsigned int __attribute__((address_space(4))) * cu32;
   const ci32 soff = (ci32)(uintptr_t)(b.soff + (size_t)tile * (a.JS + 1));
   const ci32 uoff = (ci32)(uintptr_t)(b.uoff + (size_t)tile * (b.umax + 1));
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   v4f xB[4][NV] /* -x_i */, accA[4][NV], accB[4][NV];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int gi = min(ib + qgc + QS * r, N - 1);
+    const int gi = a.i0 + row_v(qgc + QS * r);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       xB[r][u] = -*reinterpret_cast<const v4f *>(b.Xp + (size_t)gi * DPB + c0 + 4 * u);
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
     }
   }
   for (int i = tid; i < TQ; i += NT) {
-    mrow[i] = b.m0 ? b.m0[min(ib + i, N - 1)] : -INFINITY;
+    mrow[i] = b.m0 ? b.m0[a.i0 + row_v(i)] : -INFINITY;
     lrow[i] = 0.f;
   }
 
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   constexpr int NLD = (JC * DPB / 4 + NT - 1) / NT;
   v4f ky[NLD];
   float lm_next = 0.f;
+  int key_next = 0;  // the lane's own key of the unit (pass A: lane = key)
   auto keys_issue = [&](const int u) {
     const int k0 = uoff[u], jc = uoff[u + 1] - k0;
     int key[NLD];
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
       ky[w] = *reinterpret_cast<const v4f *>(b.Xp + (size_t)key[w] * DPB + (f * 4 - row * DPB));
     }
     lm_next = a.logmix[kl];
+    key_next = kl;
   };
   auto keys_commit = [&](const int u) {
     const int jc = uoff[u + 1] - uoff[u];
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   for (int u = u0; u < u1; ++u) {
     const int jc = uoff[u + 1] - uoff[u];
     const float lm = lm_next;
+    const int key_cur = key_next;
     wg_sync();  // Ys holds this unit
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
@@ -284,8 +303,9 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
         near &= near - 1u;
         const int i = wave * QW + qa, i2 = wave * QW + qb;  // wave-uniform
         typedef const v2f __attribute__((address_space(4))) * cv2;  // (scalar loads: see pairwise_fused_kernel)
-        const cv2 xa = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i, N - 1) * DPB);
-        const cv2 xb = (cv2)(uintptr_t)(b.Xp + (size_t)min(ib + i2, N - 1) * DPB);
+        const int ra_ = row_s(i), rb_ = row_s(i2);
+        const cv2 xa = (cv2)(uintptr_t)(b.Xp + (size_t)(a.i0 + ra_) * DPB);
+        const cv2 xb = (cv2)(uintptr_t)(b.Xp + (size_t)(a.i0 + rb_) * DPB);
         v2f da2 = {0.f, 0.f}, db2 = {0.f, 0.f};
 #pragma unroll
         for (int s0 = 0; s0 < DPB / 2; s0 += 16) {
@@ -319,6 +339,17 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
         kv[i * KS + jA] = v2f{kval ? lm - 0.5f * pa : -INFINITY, ka};
         kv[i2 * KS + jA] = v2f{kval ? lm - 0.5f * pbq : -INFINITY, kb};
         if (MODE == PAIR_K1 && b.nzu) wave_any = wave_any || __ballot(ka != 0.f || kb != 0.f) != 0ull;
+        if (MODE == PAIR_K1 && b.lead) {  // the queries' leaders (tile order of the next tick): the unit's first key that is close
+          const unsigned long long la = __ballot(ka > PACK_LEAD_K), lb = __ballot(kb > PACK_LEAD_K);
+          if (la) {
+            const int kf = __builtin_amdgcn_readlane(key_cur, (int)__builtin_ctzll(la));
+            if (jA == 0) atomicMin(b.lead + ra_, kf);
+          }
+          if (lb && i2 != i) {
+            const int kf = __builtin_amdgcn_readlane(key_cur, (int)__builtin_ctzll(lb));
+            if (jA == 0) atomicMin(b.lead + rb_, kf);
+          }
+        }
         float *ka_p = kblk + (size_t)i * 64 + jA, *kb_p = kblk + (size_t)i2 * 64 + jA;
         if (STREAM_K) {
           __builtin_nontemporal_store(ka, ka_p);
@@ -418,8 +449,8 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
     if (qg_e < TQ / 4) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int il = tile * TQ + qg_e + QS * r;
-        if (il >= a.n_local) continue;
+        if (tile * TQ + qg_e + QS * r >= a.n_local) continue;
+        const int il = row_v(qg_e + QS * r);
         const size_t row = ((size_t)js * a.n_local + il) * b.ldp;
 #pragma unroll
         for (int w = 0; w < NV; ++w)
@@ -445,6 +476,7 @@ struct GramPackedArgs {
   const int *kidx;
   int ldi;
   const int *uoff;
+  const int *qperm;          // pass 1's tile order (position -> local row), or nullptr: identity
   const unsigned int *uq;    // rows outside a unit's mask were not written by pass 1: read as zeros (nullptr: all written)
   const int *goff;
   const unsigned char *nzu;  // units whose kernel values are all exactly 0 are skipped (nullptr: dense)
@@ -567,14 +599,96 @@ __global__ __launch_bounds__(GramGeom<TQ>::NT, 2) void gram_packed_kernel(const 
   }
   // rows from the accumulators: query = l % 16 of the row tile, columns 16 t + 4 (l / 16) ..
   {
-    const int il = tile * TQ + rt0 * 16 + r16;
-    if (il < a.n_local) {
+    const int pos = tile * TQ + rt0 * 16 + r16;
+    if (pos < a.n_local) {
+      const int il = a.qperm ? a.qperm[pos] : pos;
       const size_t row = ((size_t)js * a.n_local + il) * a.ldp;
 #pragma unroll
       for (int t = 0; t < NCT; ++t)
         if (16 * t + 4 * g < a.ldp) *reinterpret_cast<v4f *>(a.pA + row + 16 * t + 4 * g) = acc0[t];
     }
   }
+}
+
+// ---- the tile order of the NEXT tick: the rank's rows sorted by (leader, row) - a stable two-pass radix sort (7 + 7 bits, keys below
+// 16 384: validate() caps N) of at most 16 384 rows in ONE workgroup; reads the leaders pass 1 noted, re-arms them, writes qperm ------
+static inline size_t query_order_lds_bytes(int n) { return (size_t)3 * ((n + 1023) / 1024) * 1024 * sizeof(unsigned short) + (16 * 128 + 128 + 16) * sizeof(int); }
+
+__global__ __launch_bounds__(1024) void query_order_kernel(int *lead, int *qperm, const int n_local, const int i0, const int N) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short qo_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npad = ((n_local + 1023) / 1024) * 1024, seg = npad / 16;  // rows per wave: a multiple of 64
+  unsigned short *key = qo_lds;       // [npad] by row
+  unsigned short *ia = key + npad;    // [npad] rows in the current order
+  unsigned short *ib = ia + npad;     // [npad] ... and the next one
+  int *cnt = reinterpret_cast<int *>(ib + npad);  // [16][128] per wave and digit: count, then running offset
+  int *tot = cnt + 16 * 128;                      // [128] per digit
+  for (int r = tid; r < npad; r += 1024) {
+    int k = 0x3fff;  // (padding rows sort behind everything)
+    if (r < n_local) {
+      const int l = lead[r];
+      k = (l >= 0 && l < N) ? l : min(i0 + r, N - 1);  // (no close key seen - a row pass 1 masked out everywhere: its own index)
+      lead[r] = 0x7fffffff;                              // re-armed for the next pass 1
+    }
+    key[r] = (unsigned short)min(k, 0x3fff);
+    ia[r] = (unsigned short)r;
+  }
+  wg_sync();
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes below this one
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = 7 * pass;
+    const unsigned short *src = pass ? ib : ia;
+    unsigned short *dst = pass ? ia : ib;
+    for (int e = tid; e < 16 * 128; e += 1024) cnt[e] = 0;
+    wg_sync();
+    auto peers_of = [&](const int d) {  // lanes of the wave holding the same digit
+      unsigned long long m = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < 7; ++bit) {
+        const unsigned long long bb = __ballot((d >> bit) & 1);
+        m &= ((d >> bit) & 1) ? bb : ~bb;
+      }
+      return m;
+    };
+    for (int c = 0; c < seg; c += 64) {  // the wave's segment, 64 rows at a time, in order
+      const int d = (key[src[wave * seg + c + lane]] >> shift) & 127;
+      const unsigned long long m = peers_of(d);
+      if ((m & lt) == 0ull) cnt[wave * 128 + d] += (int)__builtin_popcountll(m);  // (one lane per digit: no atomic)
+    }
+    wg_sync();
+    if (tid < 128) {  // per digit: the waves' counts -> offsets inside the digit, and the digit's total
+      int run = 0;
+      for (int w = 0; w < 16; ++w) {
+        const int v = cnt[w * 128 + tid];
+        cnt[w * 128 + tid] = run;
+        run += v;
+      }
+      tot[tid] = run;
+    }
+    wg_sync();
+    if (wave == 0) {  // exclusive scan of the 128 totals
+      int a0 = tot[2 * lane], a1 = tot[2 * lane + 1];
+      int s2 = a0 + a1, ps = s2;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(ps, o);
+        if (lane >= o) ps += t;
+      }
+      const int ex = ps - s2;
+      tot[2 * lane] = ex;
+      tot[2 * lane + 1] = ex + a0;
+    }
+    wg_sync();
+    for (int c = 0; c < seg; c += 64) {
+      const unsigned short row = src[wave * seg + c + lane];
+      const int d = (key[row] >> shift) & 127;
+      const unsigned long long m = peers_of(d);
+      const int base = tot[d] + cnt[wave * 128 + d];  // (read by all peers before the first of them moves it on)
+      dst[base + (int)__builtin_popcountll(m & lt)] = row;
+      if ((m & lt) == 0ull) cnt[wave * 128 + d] += (int)__builtin_popcountll(m);
+    }
+    wg_sync();
+  }
+  for (int p = tid; p < n_local; p += 1024) qperm[p] = (int)ia[p];  // (padding rows carry the largest key and the largest rows: they sit behind)
 }
 
 }  // namespace dust

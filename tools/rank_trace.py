@@ -1,7 +1,6 @@
 """One rank's tick of the strong-scaled cfg4 run, on the AGED set, as the GPU sees it: the set is aged with all G shards in this process
-(tools/shard_emul.py's data flow), then rank 0 runs `reps` whole ticks ALONE and back to back (no host synchronisation between its
-phases; the other ranks' rows stay as the last joint tick left them - the far / near structure of the set is what prices the tick,
-and it is unchanged), timed as one block.  Under `rocprofv3 --kernel-trace` the last ticks of the trace are rank 0's and nothing
+(tools/shard_emul.py's data flow), then, `reps` times, rank 0 runs ONE whole tick alone (no host synchronisation between its
+phases), timed between two events, is put back, and a joint tick follows.  Under `rocprofv3 --kernel-trace` the last ticks of the trace are rank 0's and nothing
 else: tools/trace_seq.py prints their kernel sequence with gaps.
     python tools/rank_trace.py G [age_ticks] [reps]"""
 import os, sys, time
@@ -40,15 +39,43 @@ for k in range(age):
 for sh in shards:
     sh.sync()
 r0 = shards[0]
+import torch
+
+
+def joint_tick():
+    for it in range(c4["n_iters"]):
+        for sh in shards:
+            sh.local_score(st, None, params[it])
+        comm.all_gather_inplace(shards, "score_all", E)
+        for sh in shards:
+            sh.apply_phi()
+        comm.all_gather_inplace(shards, "theta_all", E)
+    for sh in shards:
+        sh.forward_local()
+    comm.all_gather_inplace(shards, "lw_all", shards[0].n_loc)
+    for sh in shards:
+        sh.forward_finish(False)
+
+
+# Rank 0's tick ALONE, timed between two events on its stream, from the state the JOINT run is in: its particles are put back afterwards
+# and a joint tick follows, so the set keeps evolving as in the G-GPU run (a rank that ticks alone for long drifts away from the frozen
+# rows of the others, and its run lists with it: 10 ticks alone at G = 2 took 4.3 ms each against 0.8 in step with the others).
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for rep in range(3):
-    r0.sync()
-    t0 = time.perf_counter()
+    ts = []
     for k in range(reps):
+        joint_tick()
+        keep = r0.theta_all.clone()
+        r0.sync()
+        e0.record()
         for it in range(c4["n_iters"]):
             r0.local_score(st, None, params[it])
             r0.apply_phi()
         r0.forward_local()
         r0.forward_finish(False)
-    r0.sync()
-    print("cfg4 G=%d n_local=%d aged %d ticks: rank 0 alone, %d ticks back to back: %.1f us per tick" %
-          (G, c4["N"] // G, age, reps, (time.perf_counter() - t0) / reps * 1e6), flush=True)
+        e1.record()
+        r0.sync()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+        r0.theta_all.copy_(keep)
+    print("cfg4 G=%d n_local=%d aged %d ticks: rank 0's tick alone (GPU time between two events, %d ticks in step with the joint run): median %.1f us, min %.1f, max %.1f" %
+          (G, c4["N"] // G, age + rep * reps, reps, float(np.median(ts)), min(ts), max(ts)), flush=True)
