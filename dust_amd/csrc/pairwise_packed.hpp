@@ -233,7 +233,6 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   constexpr int NLD = (JC * DPB / 4 + NT - 1) / NT;
   v4f ky[NLD];
   float lm_next = 0.f;
-  int key_next = 0;  // the lane's own key of the unit (pass A: lane = key)
   auto keys_issue = [&](const int u) {
     const int k0 = uoff[u], jc = uoff[u + 1] - k0;
     int key[NLD];
@@ -249,7 +248,6 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
       ky[w] = *reinterpret_cast<const v4f *>(b.Xp + (size_t)key[w] * DPB + (f * 4 - row * DPB));
     }
     lm_next = a.logmix[kl];
-    key_next = kl;
   };
   auto keys_commit = [&](const int u) {
     const int jc = uoff[u + 1] - uoff[u];
@@ -267,7 +265,6 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
   for (int u = u0; u < u1; ++u) {
     const int jc = uoff[u + 1] - uoff[u];
     const float lm = lm_next;
-    const int key_cur = key_next;
     wg_sync();  // Ys holds this unit
     // ---- pass A: lane = key jA (row in registers), wave = QW queries, query rows through the scalar path ----
     {
@@ -341,14 +338,9 @@ __global__ __launch_bounds__(PAIR_NT, DUST_FUSED_WGS) void pairwise_packed_kerne
         if (MODE == PAIR_K1 && b.nzu) wave_any = wave_any || __ballot(ka != 0.f || kb != 0.f) != 0ull;
         if (MODE == PAIR_K1 && b.lead) {  // the queries' leaders (tile order of the next tick): the unit's first key that is close
           const unsigned long long la = __ballot(ka > PACK_LEAD_K), lb = __ballot(kb > PACK_LEAD_K);
-          if (la) {
-            const int kf = __builtin_amdgcn_readlane(key_cur, (int)__builtin_ctzll(la));
-            if (jA == 0) atomicMin(b.lead + ra_, kf);
-          }
-          if (lb && i2 != i) {
-            const int kf = __builtin_amdgcn_readlane(key_cur, (int)__builtin_ctzll(lb));
-            if (jA == 0) atomicMin(b.lead + rb_, kf);
-          }
+          const int k0u = uoff[u];  // (the key of list slot k0u + lane: looked up by the one lane that reports it)
+          if (la && jA == 0) atomicMin(b.lead + ra_, kidx[k0u + (int)__builtin_ctzll(la)]);
+          if (lb && i2 != i && jA == 0) atomicMin(b.lead + rb_, kidx[k0u + (int)__builtin_ctzll(lb)]);
         }
         float *ka_p = kblk + (size_t)i * 64 + jA, *kb_p = kblk + (size_t)i2 * 64 + jA;
         if (STREAM_K) {
