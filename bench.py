@@ -72,6 +72,13 @@ def far_shares(ctx):
         f.restype = C.c_int
         v = (C.c_longlong * 2)()
         out[key] = (v[0] / v[1]) if (f(ctx._h, v) == 0 and v[1]) else None
+    # the run lists of pairwise_packed.hpp: packed units walked by the last pass 1 over the (query tile, key chunk) units of the set
+    IP = C.POINTER(C.c_int)
+    lib.dust_debug_pack_lists.argtypes = [C.c_void_p, C.c_int, IP, IP, IP, IP, C.POINTER(C.c_uint), IP]
+    lib.dust_debug_pack_lists.restype = C.c_int
+    nu, al = C.c_int(), C.c_int()
+    if lib.dust_debug_pack_lists(ctx._h, -1, C.byref(nu), C.byref(al), None, None, None, None) == 0 and al.value:
+        out["run_list_units_over_all_units"] = nu.value / al.value
     return out
 
 
@@ -103,9 +110,9 @@ def pendulum_plant(state, u, dt=0.05, g=9.8, m=1.0, l=1.0):
 
 
 def profile_json(name, family=None):
-    """Newest committed summary profiles/round<k>_<name>.json (k = 5, 4); with `family`, only if its source stamp matches the kernel
+    """Newest committed summary profiles/round<k>_<name>.json (k = 6, 5, 4); with `family`, only if its source stamp matches the kernel
     sources of this checkout (tools/srcstamp.py) - a summary measured on other sources is not this kernel's: (None, why)."""
-    for rnd in (5, 4):
+    for rnd in (6, 5, 4):
         pth = os.path.join(ROOT, "profiles", "round%d_%s.json" % (rnd, name))
         if not os.path.exists(pth):
             continue
@@ -312,6 +319,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--open-loop-only", action="store_true",
+                    help="N=1: the timed open-loop leg and nothing else on the GPU (no cfg4 leg, no roofline legs, no closed loops, no CPU baseline): "
+                         "under rocprofv3 the svmpc_tick2_kernel row is then the timed kernel alone (VERDICT r5 item 3)")
     ap.add_argument("--weak", action="store_true", help="N>1: also time the weak-scaled cfg2 form (1024 Pendulum particles per GPU)")
     args = ap.parse_args()
 
@@ -329,11 +339,10 @@ def main():
 
     if rank == 0:  # (before anything initialises the GPU in this process: a stale library would compile in a child process)
         entry.build()
-    # the CPU baseline runs FIRST: the GPU phases then sit together at the end of the run (a driver that samples device activity a few
-    # times over the run saw an idle GPU while 10 s of host arithmetic closed it - VERDICT r4)
+    # Order of the single-GPU run: the cfg4 leg and the roofline legs (GPU, seconds), THEN the CPU baseline (host, ~10 s),
+    # and the timed cfg2 leg and its closed loops LAST - a driver that samples device activity a few times over the run finds the GPU at
+    # work at both ends instead of idle behind (r4) or in front of (r5) ten seconds of host arithmetic
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
     import torch
 
     # torch initialises its HIP context lazily, at the first torch.cuda call - which would otherwise be the synchronize() in front of
@@ -397,7 +406,59 @@ def main():
     w = WORKLOAD
     state = np.array([3.0, 0.0], np.float32)
     extra = {}
+    rk_early = None
+    if args.open_loop_only:
+        args.no_roofline = args.no_cpu_baseline = True
     if dist is None:
+        # the multi-GPU workload on this one GPU: the N = 1 point of the scaling curve
+        if not args.open_loop_only:
+            c4 = CFG4
+            mu4, theta4 = synth(c4["N"], c4["H"], 2, spread=1.0)
+            one = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
+                          uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
+            one.set_theta(theta4); one.set_prior(mu4); one.set_a_mat(theta4)
+            p4 = (1.0 + 0.1 * np.random.default_rng(5).standard_normal((c4["n_iters"], c4["M"], 1))).astype(np.float32)
+            st4 = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+            n4w = warm(lambda: one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False), one.sync, 3)
+            n4 = 20
+            t1 = time.perf_counter()
+            for _ in range(n4):
+                one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+            one.sync()
+            e4 = time.perf_counter() - t1
+            far4 = far_shares(one)
+            one.close()
+            # the same ticks with every (query tile, key chunk) unit of the pairwise passes visited (DUST_FAR=0: pairwise_far.hpp off) -
+            # what a particle set WITHOUT far pairs costs (the pre-pass then finds nothing to leave out)
+            os.environ["DUST_FAR"] = "0"
+            try:
+                allv = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
+                               uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
+            finally:
+                os.environ.pop("DUST_FAR", None)
+            allv.set_theta(theta4); allv.set_prior(mu4); allv.set_a_mat(theta4)
+            for _ in range(n4w + n4 - 10):  # (the same age as the timed ticks above: the set, and with it every data-dependent shortcut, evolves)
+                allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+            allv.sync()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
+            allv.sync()
+            e4a = (time.perf_counter() - t1) / 10
+            allv.close()
+            extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
+                                           n_gpus=1, ticks_per_s=n4 / e4, ms_per_tick=1e3 * e4 / n4, comm_us_per_tick=0.0, ticks=n4,
+                                           warmup_ticks_run=n4w, pairwise_units_left_out=far4, ms_per_tick_all_units_visited=1e3 * e4a,
+                                           note="pairwise_units_left_out: share of the (query tile, key chunk) units of the fused prior / Stein "
+                                                "pass and of the log-p pass whose every term is below 2^-43 of its sum's leading term "
+                                                "(pairwise_far.hpp: a binary16 MFMA bound decides, the result moves by < half an ulp of that "
+                                                "term); run_list_units_over_all_units: 64-key units pass 1 actually walks (the near keys of a "
+                                                "query tile packed, tiles in leader order: pairwise_packed.hpp) over the units of the set. "
+                                                "DATA DEPENDENT: a clustered set has no far pair and runs at ms_per_tick_all_units_visited")
+        if rank == 0 and not args.no_roofline:
+            rk_early = roofline_section(local, state)
+        if rank == 0 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
         mu, theta = synth(w["N"], w["H"], 1)
         ctx = Context(model=w["model"], N=w["N"], S=w["S"], M=1, H=w["H"], kernel=w["kernel"], lr=w["lr"], alpha=w["alpha"],
                       sigma_a=w["sigma_a"], sigma_p=w["sigma_p"], device=local, seed=1234)
@@ -437,63 +498,22 @@ def main():
             return dict(ticks_per_s=n_cl / el_cl, us_per_tick=1e6 * el_cl / n_cl, ticks=n_cl, warmup_ticks_run=n_wcl,
                         served=s1["served"] - s0["served"], replayed=s1["replayed"] - s0["replayed"])
 
-        cl_plain = closed_loop(False)
-        cl_served = closed_loop(True)
-        extra["closed_loop_ticks_per_s"] = cl_served["ticks_per_s"]
-        extra["closed_loop"] = dict(
-            served=cl_served, unserved=cl_plain,
-            note="every tick returns its chosen sequence to the host, whose first action steps a host pendulum plant; the new state feeds the "
-                 "next tick.  served: dust_svmpc_serve_start - the outputs arrive through pinned host memory (no device-to-host copy, no stream "
-                 "synchronisation) and the next tick is launched ahead of its plant state (bit-identical results: tests/test_gpu_serve.py); "
-                 "unserved: one pinned device-to-host copy + one stream synchronisation per tick")
+        if not args.open_loop_only:
+            cl_plain = closed_loop(False)
+            cl_served = closed_loop(True)
+            extra["closed_loop_ticks_per_s"] = cl_served["ticks_per_s"]
+            extra["closed_loop"] = dict(
+                served=cl_served, unserved=cl_plain,
+                note="every tick returns its chosen sequence to the host, whose first action steps a host pendulum plant; the new state feeds the "
+                     "next tick.  served: dust_svmpc_serve_start - the outputs arrive through pinned host memory (no device-to-host copy, no stream "
+                     "synchronisation) and the next tick is launched ahead of its plant state (bit-identical results: tests/test_gpu_serve.py); "
+                     "unserved: one pinned device-to-host copy + one stream synchronisation per tick")
         ctx.close()
         workload = ("Pendulum N=%d, S=128, M=1, H=30, 5 SVGD iters, K1 (gpytorch-RBF) kernel, SGD, device Philox noise inside the tick; "
                     "one persistent kernel launch per tick" % w["N"])
         par = "single GPU"
         value = args.steps / el
         unit = "control steps/s"
-        # the multi-GPU workload on this one GPU: the N = 1 point of the scaling curve
-        c4 = CFG4
-        mu4, theta4 = synth(c4["N"], c4["H"], 2, spread=1.0)
-        one = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
-                      uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
-        one.set_theta(theta4); one.set_prior(mu4); one.set_a_mat(theta4)
-        p4 = (1.0 + 0.1 * np.random.default_rng(5).standard_normal((c4["n_iters"], c4["M"], 1))).astype(np.float32)
-        st4 = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
-        n4w = warm(lambda: one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False), one.sync, 3)
-        n4 = 20
-        t1 = time.perf_counter()
-        for _ in range(n4):
-            one.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
-        one.sync()
-        e4 = time.perf_counter() - t1
-        far4 = far_shares(one)
-        one.close()
-        # the same ticks with every (query tile, key chunk) unit of the pairwise passes visited (DUST_FAR=0: pairwise_far.hpp off) -
-        # what a particle set WITHOUT far pairs costs (the pre-pass then finds nothing to leave out)
-        os.environ["DUST_FAR"] = "0"
-        try:
-            allv = Context(model="particle", N=c4["N"], S=c4["S"], M=c4["M"], H=c4["H"], kernel="K1", lr=100.0, alpha=1.0, sigma_a=1.0, sigma_p=1.0,
-                           uncertain_params=("mass",), grid=particle_grid(), device=local, seed=1234)
-        finally:
-            os.environ.pop("DUST_FAR", None)
-        allv.set_theta(theta4); allv.set_prior(mu4); allv.set_a_mat(theta4)
-        for _ in range(n4w + n4 - 10):  # (the same age as the timed ticks above: the set, and with it every data-dependent shortcut, evolves)
-            allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
-        allv.sync()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            allv.svmpc_tick(st4, c4["n_iters"], params=p4, want_outputs=False)
-        allv.sync()
-        e4a = (time.perf_counter() - t1) / 10
-        allv.close()
-        extra["scale_workload"] = dict(workload="Particle N=16384, S=64, M=4, H=40, 1 SVGD iter, K1, SGD, device Philox noise (BASELINE configs[3])",
-                                       n_gpus=1, ticks_per_s=n4 / e4, ms_per_tick=1e3 * e4 / n4, comm_us_per_tick=0.0, ticks=n4,
-                                       warmup_ticks_run=n4w, pairwise_units_left_out=far4, ms_per_tick_all_units_visited=1e3 * e4a,
-                                       note="pairwise_units_left_out: share of the (query tile, key chunk) units of the fused prior / Stein "
-                                            "pass and of the log-p pass whose every term is below 2^-43 of its sum's leading term "
-                                            "(pairwise_far.hpp: a binary16 MFMA bound decides, the result moves by < half an ulp of that "
-                                            "term). DATA DEPENDENT: a clustered set has no such unit and runs at ms_per_tick_all_units_visited")
     else:
         c4 = CFG4
         mu, theta = synth(c4["N"], c4["H"], 2, spread=1.0)
@@ -608,7 +628,7 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline and dist is None:
-        rk = roofline_section(local, state)
+        rk = rk_early
         # The TIMED kernel on top: one launch of svmpc_tick2_kernel = one control tick = n_iters SVGD iterations + forward.
         # Algorithmic bytes per SURVEY 8d: B_roll per iteration (4 [S N D + N D + S N] + grad_lik out; the noise term counts although the
         # product draws it in registers: it is the traffic the contract's figure is defined over) + the epilogue 4 (S N + 4 N D).
@@ -639,6 +659,8 @@ def main():
         roofline["forms"] = forms
 
     if rank == 0:
+        # short keys first (a reader that keeps the head of the line keeps the figures); the long notes follow
+        rkk = (roofline or {}).get("rollout_kernel") or {}
         out = {
             "metric": "MPC control steps/sec (SVGD-MPC tick: SVGD iterations + forward)",
             "value": value,
@@ -655,15 +677,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "parallelism": par,
-                       "other_configs": "BASELINE configs[4] (cfg5) is run with M = 8 dynamics samples per rollout (the yaml's params_samples), drawn from "
-                                        "the 256-particle MPF: 1 635 ticks/s on one GPU (profiles/round4_configs.json).  SURVEY 8d's alternative, M = 256 "
-                                        "(every dynamics particle once), is accepted by the launch-per-iteration rollout kernels (any M; parity 9e-8 vs the "
-                                        "oracle) but not by the one-launch tick (T2_MAXM = 64): 114 ticks/s (tools/cfg5_m256.py)"},
+            "closed_loop_ticks_per_s": extra.get("closed_loop_ticks_per_s"),
+            "rollout_kernel_hbm_frac": rkk.get("frac"),
+            "rollout_kernel_achieved_gbs": rkk.get("achieved"),
+            "rollout_kernel_avg_launch_us": rkk.get("avg_launch_us"),
+            "rollout_kernel_traffic_bytes": rkk.get("traffic"),
+            "cfg4_one_gpu_ms_per_tick": (extra.get("scale_workload") or {}).get("ms_per_tick"),
+            "config": {"workload": workload, "parallelism": par},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         out.update(extra)
+        out["config"]["other_configs"] = ("BASELINE configs[4] (cfg5) is run with M = 8 dynamics samples per rollout (the yaml's params_samples), drawn from "
+                                          "the 256-particle MPF (tools/configs_bench.py -> profiles/round6_configs.json).  SURVEY 8d's alternative, M = 256 "
+                                          "(every dynamics particle once), is accepted by the launch-per-iteration rollout kernels (any M; parity 9e-8 vs the "
+                                          "oracle) but not by the one-launch tick (T2_MAXM = 64): 114 ticks/s (tools/cfg5_m256.py)")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

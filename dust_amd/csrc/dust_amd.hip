@@ -4544,10 +4544,19 @@ extern "C" int dust_debug_peer_selftest(dust_ctx *c, int world, int n_steps, int
 // include/dust_amd.h): tests/test_gpu_parity.py checks the lists against the masks they were built from.
 extern "C" int dust_debug_pack_lists(dust_ctx *c, int tile, int *n_units, int *js, int *uoff, int *kidx, unsigned int *uq, int *soff) {
   if (!c || !n_units || !js) return fail(DUST_ERR_INVALID, "null argument");
-  if (!c->pk_tiles || tile < 0 || tile >= c->pk_tiles) return fail(DUST_ERR_STATE, "no run lists (or no such tile)");
+  if (!c->pk_tiles || tile < -1 || tile >= c->pk_tiles) return fail(DUST_ERR_STATE, "no run lists (or no such tile)");
   HIP_TRY(hipSetDevice(c->cfg.device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const int JS = c->pk_jsg, um = c->pk_umax;
+  if (tile == -1) {  // totals: *n_units = the units of all tiles, *js = tiles x chunks (what visiting every unit would walk)
+    std::vector<int> all((size_t)c->pk_tiles * (JS + 1));
+    HIP_TRY(hipMemcpy(all.data(), c->pk_soff, all.size() * sizeof(int), hipMemcpyDeviceToHost));
+    long tot = 0;
+    for (int t = 0; t < c->pk_tiles; ++t) tot += all[(size_t)t * (JS + 1) + JS];
+    *n_units = (int)tot;
+    *js = c->pk_tiles * um;
+    return DUST_OK;
+  }
   std::vector<int> so((size_t)JS + 1);
   HIP_TRY(hipMemcpy(so.data(), reinterpret_cast<int *>(c->pk_soff) + (size_t)tile * (JS + 1), so.size() * sizeof(int), hipMemcpyDeviceToHost));
   const int U = so[JS];

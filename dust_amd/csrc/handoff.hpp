@@ -129,6 +129,41 @@ __device__ __forceinline__ void pendulum_trig(float th, float *sin_tp, float *co
   *cos_th = cs;
 }
 
+// pendulum_trig for TWO angles in packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, two per lane-op) -
+// the two dynamics samples a rollout lane carries side by side (rollout.hpp, round 6).  Operation for operation the scalar function.
+__device__ __forceinline__ void pendulum_trig2(const v2f th, v2f *sin_tp, v2f *cos_th, const TrigConsts K = trig_consts()) {
+  auto sp = [](const float v) { return v2f{v, v}; };
+  const v2f magic = sp(K.magic);
+  const v2f t = __builtin_elementwise_fma(th, sp(0.318309886183790671538f), magic);
+  const v2f kf = t - magic;
+  const unsigned int sg0 = __float_as_uint(t.x) << 31, sg1 = __float_as_uint(t.y) << 31;
+  v2f r = __builtin_elementwise_fma(kf, sp(-(2.0f * 1.57079601e+00f)), th);
+  r = __builtin_elementwise_fma(kf, sp(-(2.0f * 3.13916473e-07f)), r);
+  const v2f s = r * r;
+  v2f p = sp(2.596175364e-06f);
+  p = __builtin_elementwise_fma(p, s, sp(K.s1));
+  p = __builtin_elementwise_fma(p, s, sp(8.332992904e-03f));
+  p = __builtin_elementwise_fma(p, s, sp(-1.666665673e-01f));
+  v2f sn = __builtin_elementwise_fma(p, r * s, r);
+  v2f q = sp(-2.604016061e-07f);
+  q = __builtin_elementwise_fma(q, s, sp(K.c1));
+  q = __builtin_elementwise_fma(q, s, sp(-1.388836536e-03f));
+  q = __builtin_elementwise_fma(q, s, sp(4.166663811e-02f));
+  q = __builtin_elementwise_fma(q, s, sp(-5.000000000e-01f));
+  v2f cs = __builtin_elementwise_fma(q, s, sp(1.0f));
+  sn.x = __uint_as_float(__float_as_uint(sn.x) ^ sg0);
+  sn.y = __uint_as_float(__float_as_uint(sn.y) ^ sg1);
+  cs.x = __uint_as_float(__float_as_uint(cs.x) ^ sg0);
+  cs.y = __uint_as_float(__float_as_uint(cs.y) ^ sg1);
+  const v2f pif = sp(K.pif);
+  const v2f tp = th + pif;
+  const v2f bb = tp - th;
+  const v2f err = (th - (tp - bb)) + (pif - bb);  // exact: th + PI_F = tp + err
+  const v2f e = sp(8.742278000372485e-8f) - err;  // pi_f - pi
+  *sin_tp = -__builtin_elementwise_fma(e, cs, sn);
+  *cos_th = cs;
+}
+
 // Workgroup barrier that orders LDS only: global loads issued before it stay in flight across it (wg_sync()
 // drains vmcnt as well, which would serialise the prefetches of the tail behind every reduction step).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

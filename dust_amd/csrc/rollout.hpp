@@ -442,6 +442,47 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
       }
       m_begin = m;
     }
+    if (MODEL == DUST_MODEL_PENDULUM && fast_trig) {
+      // Round 6: TWO of the lane's dynamics samples side by side in packed fp32 (cfg5: M = 8) - the step is nearly all FMAs, and a
+      // packed FMA is one lane-op for two of them: 45 -> ~30 instructions per sample and step.  The same operations in the same order
+      // as the one-sample loop below, and the samples' trajectory costs join acc_m in its order: bit-identical results.
+      const float dt = (float)a.dm.dt, mt = a.dm.max_torque, ms = a.dm.max_speed_pend;
+      const float *actl = lds + s * Dp;
+      int m = m_begin;
+      for (; m + G < a.M; m += 2 * G) {
+        const long rA = (long)m * SN + (long)s * N + n, rB = rA + (long)G * SN;
+        const int pa = a.dm.interleave ? (int)(rA % a.M) : m, pb = a.dm.interleave ? (int)(rB % a.M) : m + G;
+        const v2f c0 = {coefs[2 * pa], coefs[2 * pb]}, c1 = {coefs[2 * pa + 1], coefs[2 * pb + 1]};
+        if (!(fabsf(c0.x) <= 3.0e38f && fabsf(c0.y) <= 3.0e38f && fabsf(c1.x) <= 3.0e38f && fabsf(c1.y) <= 3.0e38f)) break;  // (the general loop)
+        v2f th = {x0[0], x0[0]}, thd = {x0[1], x0[1]};
+        const v2f wc = {a.dm.w_cos, a.dm.w_cos}, wv = {a.dm.w_vel, a.dm.w_vel}, dt2 = {dt, dt}, one = {1.0f, 1.0f};
+        double totA = 0.0, totB = 0.0;
+        v2f part = {0.f, 0.f};
+        v2f sn, cs;
+#pragma unroll 4
+        for (int t = 0; t < H; ++t) {
+          pendulum_trig2(th, &sn, &cs);
+          const v2f cm = cs - one;
+          part += wc * (cm * cm) + wv * (thd * thd);  // (q = W (q q); q.x + q.y of the one-sample loop, per sample)
+          if ((t & 3) == 3) {  // CostSum<PENDULUM>: groups of four steps, then double
+            totA += (double)part.x;
+            totB += (double)part.y;
+            part = v2f{0.f, 0.f};
+          }
+          const float u = __builtin_amdgcn_fmed3f(actl[t], -mt, mt);
+          thd = thd + dt2 * (c0 * sn + c1 * v2f{u, u});
+          thd.x = __builtin_amdgcn_fmed3f(thd.x, -ms, ms);
+          thd.y = __builtin_amdgcn_fmed3f(thd.y, -ms, ms);
+          th = th + thd * dt2;
+        }
+        pendulum_trig2(th, &sn, &cs);
+        const v2f cm = cs - one;
+        const v2f tq = wc * (cm * cm) + wv * (thd * thd);
+        acc_m += (double)((float)(totA + (double)part.x) + tq.x);
+        acc_m += (double)((float)(totB + (double)part.y) + tq.y);
+      }
+      m_begin = m;
+    }
     for (int m = m_begin; m < a.M; m += G) {
       const long r = (long)m * SN + (long)s * N + n;
       const int pidx = a.dm.interleave ? (int)(r % a.M) : m;

@@ -58,7 +58,7 @@ from dust.inference.mpf import MPF  # noqa: E402
 from dust.inference.svgd import get_gmm  # noqa: E402
 from dust.inference.svmpc import SVMPC  # noqa: E402
 
-REC = dict(eps=[], params=[], theta_opt=[], theta_fwd=[], p_weights=[], a_seq=[], mpf_x=[], mpf_gn=[], state_in=[])
+REC = dict(eps=[], params=[], theta_opt=[], theta_fwd=[], p_weights=[], a_seq=[], mpf_x=[], mpf_gn=[], state_in=[], mpf_bw_used=[])
 
 
 class RecSVMPC(SVMPC):
@@ -86,6 +86,7 @@ class RecMPF(MPF):
         g, bw = super().optimize(action, new_obs, *a, **k)
         REC["mpf_x"].append(mg.npf(self.x))
         REC["mpf_gn"].append(mg.npf(g))
+        REC["mpf_bw_used"].append(np.float32(bw))
         return g, bw
 
 
@@ -103,6 +104,12 @@ if __name__ == "__main__":
     torch.manual_seed(31)
     N, H, S, M, Mp = 6, 8, 8, 4, 10
     MPF_STEPS, MPF_BW, STEPS, WARM = 5, 0.2, 3, 1
+    # `python tests/golden/make_golden_driver.py bwnull`: demo/pendulum_config.yaml's own setting, `mpf_bandwidth: null` - the filter's first
+    # prior from bw_silverman of its particles (mpf.py:31-36) and every mpf.optimize with bw = silvermans_rule of the pooled particles
+    # (mpf.py:68-73; KDEpy restated in oracle/ref_shim.py: third-party, parity unpinned) -> driver_pend_dual_bwnull.npz
+    BWNULL = len(sys.argv) > 1 and sys.argv[1] == "bwnull"
+    if BWNULL:
+        MPF_BW = None
     env_model = PendulumModel()
     init_state = torch.tensor([3.0, 0.0])
     policies_prior = get_gmm(torch.randn(N, H, 1), torch.ones(N), 2.0 ** 2 * torch.eye(1))
@@ -131,10 +138,11 @@ if __name__ == "__main__":
     finally:
         dist.MixtureSameFamily.sample = _orig_mix_sample
     assert len(REC["eps"]) == STEPS and len(REC["params"]) == STEPS and len(REC["mpf_x"]) == STEPS and len(REC["a_seq"]) == STEPS - WARM
-    g = dict(N=N, H=H, S=S, M=M, Mp=Mp, mpf_steps=MPF_STEPS, mpf_bw=MPF_BW, steps=STEPS, warm_up=WARM, sigma=2.0, lr=2.0, mpf_lr=1e-3,
+    g = dict(N=N, H=H, S=S, M=M, Mp=Mp, mpf_steps=MPF_STEPS, mpf_bw=(-1.0 if MPF_BW is None else MPF_BW), steps=STEPS, warm_up=WARM, sigma=2.0, lr=2.0, mpf_lr=1e-3,
              obs_std=0.1, init_state=mg.npf(init_state), mu0=mg.npf(policies_prior.component_distribution.base_dist.loc),
              init_policies=mg.npf(init_policies0), mpf_init=mg.npf(mpf_init), true_length=0.9, true_mass=1.1)
     for k, v in REC.items():
         g[k] = np.stack(v)
-    np.savez_compressed(os.path.join(mg.OUT, "driver_pend_dual.npz"), **g)
-    print("wrote driver_pend_dual", {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim > 1})
+    name = "driver_pend_dual_bwnull" if BWNULL else "driver_pend_dual"
+    np.savez_compressed(os.path.join(mg.OUT, name + ".npz"), **g)
+    print("wrote", name, {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim > 1})

@@ -594,8 +594,12 @@ def test_mpf_control_noise_through_the_class_api(golden):
     assert elemerr(mpf.x.numpy(), g["x_final2"]) < 1e-5
 
 
-def test_dual_svmpc_facade_vs_reference_driver(golden):
-    """BASELINE north_star's named surface, `DualSVMPC` with step() / forward() (the reference composes the two inferences by hand:
+@pytest.mark.parametrize("fixture", ["driver_pend_dual", "driver_pend_dual_bwnull"])
+def test_dual_svmpc_facade_vs_reference_driver(golden, fixture):
+    """(`driver_pend_dual_bwnull`: demo/pendulum_config.yaml's own `mpf_bandwidth: null` - the filter's first prior from bw_silverman
+    of its particles, every filter update with bw = silvermans_rule of the pooled particles, mpf.py:31-36, 68-73 - the bandwidths
+    the reference used are part of the fixture.)
+    BASELINE north_star's named surface, `DualSVMPC` with step() / forward() (the reference composes the two inferences by hand:
     dust/utils/simulations.py:104-138), held to the golden of the reference's OWN dual loop (`driver_pend_dual`): forward(state) =
     optimize + forward (zero plan while warming up), step(action, new_state) = the filter update; tick() = forward, plant, step.
     A deep copy continues identically (the loop deep-copies controller and filter per episode, simulations.py:62,78)."""
@@ -606,7 +610,8 @@ def test_dual_svmpc_facade_vs_reference_driver(golden):
     from dust_amd.kernels import RBFKernel
     from dust_amd.models import PendulumModel
 
-    g = golden("driver_pend_dual")
+    g = golden(fixture)
+    bw_arg = None if float(g["mpf_bw"]) < 0 else float(g["mpf_bw"])
     N, H, S, M = (int(g[k]) for k in ("N", "H", "S", "M"))
     steps, warm = int(g["steps"]), int(g["warm_up"])
     env_model = PendulumModel()
@@ -622,12 +627,12 @@ def test_dual_svmpc_facade_vs_reference_driver(golden):
     mpf_model = PendulumModel(uncertain_params=("length", "mass"))
     mpf = MPF(init_particles=torch.tensor(g["mpf_init"]), likelihood=GaussianLikelihood(initial_obs=init_state, obs_std=float(g["obs_std"]),
                                                                                          model=mpf_model, log_space=False),
-              optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]), bw=float(g["mpf_bw"]), bw_scale=1.0)
+              optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]), bw=bw_arg, bw_scale=1.0)
     # the model the controller rolls out: the filter prior's mean parameters (use_exact_model=False, simulations.py:45-47)
     model = PendulumModel(length=mpf.prior.mean[0], mass=mpf.prior.mean[1], uncertain_params=("length", "mass"))
     sv = SVMPC(likelihood=ExponentiatedUtility(alpha=1.0, n_samples=S, controller=ctrl, model=model), init_particles=init_policies, prior=prior,
                kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]))
-    dual = DualSVMPC(sv, mpf, mpf_bw=float(g["mpf_bw"]), mpf_steps=int(g["mpf_steps"]), warm_up=warm)
+    dual = DualSVMPC(sv, mpf, mpf_bw=bw_arg, mpf_steps=int(g["mpf_steps"]), warm_up=warm)
     assert dual.dyn_dist is mpf.prior and dual.controller is ctrl
     plant_model = PendulumModel(g=10.0, length=float(g["true_length"]), mass=float(g["true_mass"]))  # the driver's gym stand-in
 
@@ -642,6 +647,8 @@ def test_dual_svmpc_facade_vs_reference_driver(golden):
             twin_state = state.clone()
         assert relerr(state.numpy().reshape(-1), g["state_in"][t]) < 1e-4, t
         action, state, pw = dual.tick(state, plant)
+        if "mpf_bw_used" in g:  # the bandwidth each filter update ran with (Silverman's rule of the particles when none is given)
+            assert abs(float(dual.last_bw) - float(g["mpf_bw_used"][t])) < (1e-6 if bw_arg is not None else 1e-5 * (1 + 50 * t)) * float(g["mpf_bw_used"][t]) + 1e-9, t
         assert relerr(dual.dyn_particles.numpy(), g["mpf_x"][t]) < (1e-5 if t == 0 else 1e-3), t
         if t < warm:
             assert pw is None and float(action.abs().max()) == 0.0
