@@ -170,6 +170,8 @@ SYMBOLS = {
     "dust_mpf_stats": (C.c_int, [VP, C.POINTER(C.c_longlong)]),
     "dust_mpf_prior_sample": (C.c_int, [VP, C.c_int, C.c_uint64, FP]),
     "dust_mpf_prior_log_prob": (C.c_int, [VP, C.c_int, FP, FP]),
+    "dust_mpf_silverman": (C.c_int, [VP, FP]),
+    "dust_dual_tick": (C.c_int, [VP, VP, FP, FP, C.c_int, C.c_int, C.c_float, C.c_uint64, FP, FP, FP]),
 }
 
 _lib = None

@@ -194,6 +194,19 @@ class Context:
         L.check(L.load().dust_comm_probe(self._h, int(n_steps), int(reps), C.byref(us)))
         return float(us.value)
 
+    def dual_tick(self, mpf, state, action_prev, n_steps, mpf_steps=20, mpf_bw=None, seed=0, want_outputs=True):
+        """One control period of the dual loop in one C call (dust_dual_tick): filter update for (action_prev, state) - skipped when
+        action_prev is None -, the controller's dynamics samples drawn from the filter's refreshed prior on the device, the control
+        tick.  mpf_bw None: Silverman's rule of the filter's particles, on the device.  Returns (a_seq, p_weights, bw_used)."""
+        st = _f(state, (self.ds,))
+        ap = None if action_prev is None else _f(action_prev).reshape(-1)
+        a_seq = np.empty((self.H, self.da), np.float32) if want_outputs else None
+        pw = np.empty(self.N, np.float32) if want_outputs else None
+        bw = C.c_float(0.0)
+        L.check(L.load().dust_dual_tick(self._h, mpf._h, _p(st), _p(ap), int(n_steps), int(mpf_steps), float(-1.0 if mpf_bw is None else mpf_bw),
+                                        int(seed), _p(a_seq), _p(pw), C.cast(C.byref(bw), L.FP)))
+        return a_seq, pw, float(bw.value)
+
     def comm_peer_gather(self, on=True):
         """The tick's all-gathers as direct peer stores through IPC-mapped buffers (collective: every rank calls it, or none)."""
         L.check(L.load().dust_comm_peer_gather(self._h, 1 if on else 0))
@@ -550,6 +563,12 @@ class MpfContext:
             self.close()
         except Exception:
             pass
+
+    def silverman(self):
+        """silvermans_rule of the pooled particles times bw_scale, on the device (dust_mpf_silverman)."""
+        bw = C.c_float(0.0)
+        L.check(L.load().dust_mpf_silverman(self._h, C.cast(C.byref(bw), L.FP)))
+        return float(bw.value)
 
     def clone(self):
         h = L.VP()

@@ -133,6 +133,7 @@ struct dust_ctx {
   // [tiles][chunks + 1], unit query masks [tiles][chunks][4], slice boundaries of pass 1 / pass 2, non-zero flags of the units' kernel blocks
   float *pk_idx, *pk_uoff, *pk_uq, *pk_soff, *pk_goff, *pk_nzu, *pk_perm, *pk_lead;
   size_t pk_idx_cap, pk_uoff_cap, pk_uq_cap, pk_soff_cap, pk_goff_cap, pk_nzu_cap, pk_perm_cap, pk_lead_cap;
+  bool params_staged;             // inside dust_dual_tick: the tick's dynamics samples already sit in params_dev (drawn there by the filter's kernel)
   bool stagewise;                 // inside dust_svmpc_phi (a stage-wise call on caller-supplied inputs): index order - the same inputs give the same bits, call after call
   bool pk_order;                  // pass 1 walks its queries in tile order (pk_perm) and notes their leaders (pk_lead) for the next order
   int pk_tiles, pk_umax, pk_jsg;  // geometry of those lists
@@ -1617,6 +1618,7 @@ __global__ void set_state_params_kernel(float *dst, float *pdst, const StatePara
 }
 
 static int upload_state_params(dust_ctx *c, const float *state, const float *params, int n_sets) {
+  if (c->params_staged) params = nullptr;  // (dust_dual_tick: the samples are in params_dev already)
   const size_t np = (c->cfg.dim_p > 0 && c->M >= 1 && params) ? (size_t)n_sets * c->M * c->P : 0;
   if (np > 0 && np <= 240) {
     TRY(ensure(&c->params_dev, &c->params_cap, np));
@@ -3780,7 +3782,7 @@ static void t2_queue_push(dust_ctx *c, const float *state4, int steps, bool fwd,
 static int try_persistent(dust_ctx *c, const float *state, int n_steps, const float *eps, const float *params, int flags, bool do_forward,
                           bool *done) {
   *done = false;
-  const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0;
+  const bool off = c->env.no_fuse >= 0 || c->env.no_persist >= 0 || c->params_staged;
   if (off || c->no_handoff || c->handoff_banned || c->prof || c->nloc != c->N || c->theta_pinned || n_steps < 0 || (flags & DUST_EPS_F16)) return DUST_OK;
   if (c->cfg.kernel != DUST_KERNEL_K1_RBF && c->cfg.kernel != DUST_KERNEL_IMQ) return DUST_OK;
   if (c->N > 4096 || c->D > 64 || pair_is_big(c) || two_pass_family(c)) return DUST_OK;

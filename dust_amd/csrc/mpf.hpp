@@ -811,6 +811,69 @@ __global__ void mpf_sample_kernel(const float *means, int K, int P, const MpfBw 
   for (int p = 0; p < P; ++p) out[i * P + p] = means[k * P + p] + bw.v[p] * z[p];
 }
 
+// KDEpy 1.1.0 `silvermans_rule` of the pooled particle values (mpf.py:68-73: `silvermans_rule(self.x.view(-1, 1))`; restated in
+// oracle/ref_shim.py - third party, parity unpinned) on the device: sigma = min(std(ddof = 1), IQR / 1.349) (the positive one when one
+// of them is 0), bw = sigma (3 n / 4)^(-1/5), times bw_scale; 1 when n = 1 or both spreads are 0.  float64 throughout, as the host rule
+// (numpy on the float64 copy): mean and squared deviations in two passes, the quartiles by numpy's linear interpolation
+// (`a + (b - a) t`, from the upper end when t >= 1/2) between the order statistics around q (n - 1), which are found by RANK (every lane
+// counts the values below its own: n <= 4096 values, n^2 comparisons - 0.26 M at 256 particles x 2 parameters).  One workgroup.
+__global__ __launch_bounds__(1024) void mpf_silverman_kernel(const float *x, const int n, const float bw_scale, float *out) {
+  extern __shared__ float sv_x[];  // [n]
+  __shared__ double red[16];
+  __shared__ double quart[4];      // order statistics floor / ceil of the two quartile positions
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 1024) sv_x[i] = x[i];
+  __syncthreads();
+  auto block_sum = [&](double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < 16; ++w) r += red[w];
+    return r;
+  };
+  double acc = 0.0;
+  for (int i = tid; i < n; i += 1024) acc += (double)sv_x[i];
+  const double mean = block_sum(acc) / (double)n;
+  acc = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double d = (double)sv_x[i] - mean;
+    acc += d * d;
+  }
+  const double ss = block_sum(acc);
+  const double p25 = 0.25 * (double)(n - 1), p75 = 0.75 * (double)(n - 1);
+  const int k[4] = {(int)floor(p25), min(n - 1, (int)floor(p25) + 1), (int)floor(p75), min(n - 1, (int)floor(p75) + 1)};
+  for (int i = tid; i < n; i += 1024) {
+    const float v = sv_x[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float u = sv_x[j];
+      rank += (u < v || (u == v && j < i)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (rank == k[q]) quart[q] = (double)v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float bw = 1.0f;
+    if (n > 1) {
+      const double sd = sqrt(ss / (double)(n - 1));
+      auto lerp = [](const double a, const double b, const double t) { return t >= 0.5 ? b - (b - a) * (1.0 - t) : a + (b - a) * t; };
+      const double q25 = lerp(quart[0], quart[1], p25 - floor(p25)), q75 = lerp(quart[2], quart[3], p75 - floor(p75));
+      const double iqr = (q75 - q25) / 1.3489795003921634;
+      double sigma = fmin(sd, iqr);
+      if (!(sigma > 0.0)) sigma = fmax(sd, iqr);
+      if (sigma > 0.0) bw = (float)(sigma * pow((double)n * 3.0 / 4.0, -0.2) * (double)bw_scale);
+      else bw = (float)(1.0 * (double)bw_scale);
+    } else {
+      bw = (float)(1.0 * (double)bw_scale);
+    }
+    out[0] = bw;
+  }
+}
+
 }  // namespace dust
 
 struct dust_mpf {
@@ -1309,4 +1372,54 @@ extern "C" int dust_mpf_prior_log_prob(dust_mpf *m, int n, const float *x, float
   HIP_TRY(hipMemcpyAsync(log_prob, m->tmp + (size_t)n * m->P, n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return DUST_OK;
+}
+
+// MPF.optimize's `bw = silvermans_rule(self.x.view(-1, 1)) * self.bw_scale` (mpf.py:68-73) on the device: one launch and a 4-byte read-back
+// instead of a copy of the particles and a host percentile.
+extern "C" int dust_mpf_silverman(dust_mpf *m, float *bw) {
+  if (!m || !bw) return fail(DUST_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->cfg.device));
+  const int n = m->Mp * m->P;
+  if (n > 4096) return fail(DUST_ERR_UNSUPPORTED, "Silverman's rule on the device takes up to 4096 pooled values (%d particles x %d parameters)", m->Mp, m->P);
+  if (!m->hpin) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->hpin), (4096 + 8) * sizeof(float), hipHostMallocDefault));
+  TRY(ensure(&m->tmp, &m->tmp_cap, 4));
+  mpf_silverman_kernel<<<1, 1024, (size_t)n * sizeof(float), m->stream>>>(m->x, n, m->cfg.bw_scale, m->tmp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(m->hpin + 4096 + 4, m->tmp, sizeof(float), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  *bw = m->hpin[4096 + 4];
+  if (!(*bw > 0.f)) return fail(DUST_ERR_HIP, "Silverman's rule gave a bandwidth of %g", (double)*bw);
+  return DUST_OK;
+}
+
+// One control period of the DUAL loop (simulations.py:104-138) in one call: the filter update for the action just applied and the state
+// it led to (mpf.optimize(action, state, bw, n_steps): skipped when action_prev is NULL - the first period), then the controller's
+// dynamics samples drawn from the filter's refreshed prior ON THE DEVICE, straight into the controller's parameter buffer (n_steps
+// draws of [M][P]: disco.py:171, one per SVGD iteration), then the control tick (optimize + forward).  mpf_bw <= 0: Silverman's rule of
+// the filter's particles (mpf.py:68-73), evaluated on the device.  Host round trips: the 4-byte bandwidth and the filter's status words
+// (the stream is idle there: the caller has just used the previous tick's outputs), then the tick's outputs.  seed: the Philox key of
+// this period's draws (dust_mpf_prior_sample's stream).  *bw_used: the bandwidth the filter update ran with (0: no update).
+extern "C" int dust_dual_tick(dust_ctx *c, dust_mpf *m, const float *state, const float *action_prev, int n_steps, int mpf_steps, float bw_in,
+                              uint64_t seed, float *a_seq, float *p_weights, float *bw_used) {
+  if (!c || !m || !state) return fail(DUST_ERR_INVALID, "null argument");
+  if (n_steps < 1 || mpf_steps < 0) return fail(DUST_ERR_INVALID, "bad step counts");
+  if (c->cfg.dim_p != m->P) return fail(DUST_ERR_INVALID, "the controller samples dim_p = %d dynamics parameters, the filter carries P = %d", c->cfg.dim_p, m->P);
+  if (c->cfg.device != m->cfg.device) return fail(DUST_ERR_INVALID, "controller and filter live on different devices");
+  if (comm_active(c)) return fail(DUST_ERR_UNSUPPORTED, "the dual tick runs on an unsharded controller (the filter is replicated: tick it per rank)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  float bw = bw_in;
+  if (action_prev) {
+    if (!(bw > 0.f)) TRY(dust_mpf_silverman(m, &bw));
+    TRY(dust_mpf_optimize(m, action_prev, state, bw, mpf_steps, nullptr));  // (synchronises the filter's stream: its particles are final)
+  }
+  if (bw_used) *bw_used = action_prev ? bw : 0.f;
+  TRY(settle_pending(c));
+  const int n = n_steps * c->M;
+  TRY(ensure(&c->params_dev, &c->params_cap, (size_t)n * c->P));
+  dust::mpf_sample_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(m->x, m->Mp, m->P, mpf_bw(m), seed, n, c->params_dev);
+  HIP_TRY(hipGetLastError());
+  c->params_staged = true;  // (dust_svmpc_tick finds its dynamics samples in place: no host copy, no one-launch tick - its replay record keeps host samples)
+  const int st = dust_svmpc_tick(c, state, n_steps, nullptr, c->params_dev, 0, a_seq, p_weights);
+  c->params_staged = false;
+  return st;
 }

@@ -376,6 +376,17 @@ int dust_mpf_stats(dust_mpf *mpf, long long out[2]);
 /* mpf.prior.sample([n]) / .log_prob(x): the controller draws its dynamics samples here (disco.py:171-172) */
 int dust_mpf_prior_sample(dust_mpf *mpf, int n, uint64_t seed, float *samples);
 int dust_mpf_prior_log_prob(dust_mpf *mpf, int n, const float *x, float *log_prob);
+/* MPF.optimize's default bandwidth, `silvermans_rule(self.x.view(-1, 1)) * self.bw_scale` (mpf.py:68-73; KDEpy 1.1.0, third party: parity
+ * unpinned), evaluated on the device (float64, numpy's linear-interpolation quartiles): one launch + a 4-byte read-back. */
+int dust_mpf_silverman(dust_mpf *mpf, float *bw);
+/* One control period of the dual loop (simulations.py:104-138; BASELINE north_star "DualSVMPC step() / forward()") in ONE call:
+ * mpf.optimize(action_prev, state, bw, mpf_steps) (skipped when action_prev is NULL: the first period; mpf_bw <= 0: Silverman's rule of
+ * the filter's particles, on the device) -> the controller's n_steps x [M][P] dynamics samples drawn from the filter's refreshed prior on
+ * the device, into the controller's parameter buffer (dyn_dist = mpf.prior: simulations.py:79, disco.py:171) -> svmpc.optimize(n_steps) +
+ * svmpc.forward().  a_seq [H][da], p_weights [N] or NULL; *bw_used (or NULL): the bandwidth of the filter update.  seed: Philox key of the
+ * period's draws (the stream of dust_mpf_prior_sample). */
+int dust_dual_tick(dust_ctx *ctx, dust_mpf *mpf, const float *state, const float *action_prev, int n_steps, int mpf_steps, float mpf_bw,
+                   uint64_t seed, float *a_seq, float *p_weights, float *bw_used);
 
 #ifdef __cplusplus
 }

@@ -710,3 +710,121 @@ def test_full_covariances_through_the_class_api(golden, name):
         a_seq, pw = sv.forward(state, pdist)
         assert int(pw.argmax()) == int(np.argmax(g["tick_p_weights"][t]))
         sv.theta = torch.tensor(g["tick_theta_rolled"][t])
+
+
+@pytest.mark.parametrize("Mp,P,kind", [(256, 2, "normal"), (10, 2, "normal"), (64, 1, "ties"), (33, 2, "tight_iqr"), (1024, 2, "normal"), (2, 1, "normal")])
+def test_device_silverman_rule_matches_the_host_rule(Mp, P, kind):
+    """dust_mpf_silverman: MPF.optimize's default bandwidth (mpf.py:68-73, `silvermans_rule(self.x.view(-1, 1)) * bw_scale`) evaluated on
+    the device - float64, numpy's linear-interpolation quartiles - against the host restatement of KDEpy's rule
+    (dust_amd/inference/mpf.py; third party, parity unpinned): equal to fp32 rounding, for ties, a zero IQR and two values as well."""
+    from dust_amd import MpfContext
+    from dust_amd.inference.mpf import silvermans_rule
+
+    rng = np.random.default_rng(Mp + P)
+    x = (1.0 + 0.2 * rng.standard_normal((Mp, P))).astype(np.float32)
+    if kind == "ties":
+        x = np.round(x * 8) / 8
+    elif kind == "tight_iqr":  # more than half of the values identical: IQR = 0, the rule falls back to the standard deviation
+        x[: (3 * Mp) // 4] = 1.0
+    state = np.array([3.0, 0.0], np.float32)
+    for scale in (1.0, 0.5):
+        m = MpfContext(x, state, model="pendulum", uncertain_params=("length", "mass")[:P], obs_std=0.1, lr=1e-3, init_bw=0.1, bw_scale=scale)
+        want = silvermans_rule(x.astype(np.float64).reshape(-1, 1)) * scale
+        got = m.silverman()
+        assert abs(got - np.float32(want)) <= 2e-7 * abs(want), (got, want)
+        m.close()
+
+
+def test_fused_dual_tick_equals_its_pieces(monkeypatch):
+    """(Both sides on the launch-per-iteration kernels - DUST_NO_TICK2: the dual tick's staged samples keep the controller off the
+    one-launch tick, whose sums run in another order.)
+    dust_dual_tick (DualSVMPC(fused=True)): the filter update with Silverman's bandwidth on the device, the controller's dynamics samples
+    drawn from the refreshed filter prior on the device, the control tick - ONE call - against the same pieces called one by one through the
+    C ABI with the same Philox key (dust_mpf_silverman, dust_mpf_optimize, dust_mpf_prior_sample -> host -> dust_svmpc_tick): bit-identical
+    action sequences, weights, particles and filter particles over five control periods."""
+    from dust_amd import Context, MpfContext
+
+    monkeypatch.setenv("DUST_NO_TICK2", "1")
+    N, S, M, H, K, Mp = 64, 32, 4, 12, 2, 48
+    rng = np.random.default_rng(9)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    th = (mu + rng.standard_normal((N, H, 1))).astype(np.float32)
+    x0 = rng.uniform(0.6, 1.3, (Mp, 2)).astype(np.float32)
+
+    def make():
+        c = Context(model="pendulum", N=N, S=S, M=M, H=H, kernel="K1", lr=0.5, sigma_a=2.0, sigma_p=2.0, uncertain_params=("length", "mass"), seed=5)
+        c.set_theta(th); c.set_prior(mu); c.set_a_mat(th)
+        m = MpfContext(x0, np.array([3.0, 0.0], np.float32), model="pendulum", uncertain_params=("length", "mass"), obs_std=0.1, lr=1e-3, init_bw=0.1)
+        return c, m
+
+    def plant(st, a):
+        thd = np.float32(np.clip(st[1] + 0.05 * (14.7 * np.sin(st[0]) + 3.0 * np.clip(a, -2, 2)), -8, 8))
+        return np.array([st[0] + thd * 0.05, thd], np.float32)
+
+    ca, ma = make()
+    cb, mb = make()
+    sa = sb = np.array([3.0, 0.0], np.float32)
+    prev = None
+    for t in range(5):
+        a1, p1, bw1 = ca.dual_tick(ma, sa, prev, K, mpf_steps=6, mpf_bw=None, seed=100 + t)
+        if prev is not None:
+            bw2 = mb.silverman()
+            mb.optimize(prev, sb, bw2, 6)
+            assert bw1 == bw2
+        params = mb.prior_sample(K * M, 100 + t).reshape(K, M, 2)
+        a2, p2 = cb.svmpc_tick(sb, K, None, params)
+        assert np.array_equal(a1, a2) and np.array_equal(p1, p2), t
+        assert np.array_equal(ma.get_particles(), mb.get_particles()), t
+        prev = a1[0].copy()
+        sa = sb = plant(sa, float(a1[0, 0]))
+    assert np.array_equal(ca.get_theta(), cb.get_theta())
+    for o in (ca, cb, ma, mb):
+        o.close()
+
+
+def test_dual_svmpc_fused_runs_the_reference_loop_shape(golden):
+    """DualSVMPC(fused=True) on the shapes of the reference's dual driver (`driver_pend_dual_bwnull`: mpf_bandwidth null), own draws: the
+    filter update noted by step() is carried out by the next forward(); bandwidths are Silverman's rule of the particles that update
+    started from; every output finite and normalised; reading the filter between step() and forward() carries the update out first."""
+    from dust_amd.controllers import DualSVMPC, MultiDISCO
+    from dust_amd.inference import MPF, SVMPC, ExponentiatedUtility, GaussianLikelihood, get_gmm
+    from dust_amd.inference.mpf import silvermans_rule
+    from dust_amd.kernels import RBFKernel
+    from dust_amd.models import PendulumModel
+
+    g = golden("driver_pend_dual_bwnull")
+    N, H, S, M = (int(g[k]) for k in ("N", "H", "S", "M"))
+    env_model = PendulumModel()
+    init_state = torch.tensor(g["init_state"])
+    init_policies = torch.tensor(g["init_policies"])
+    prior = get_gmm(torch.tensor(g["mu0"]), torch.ones(N), float(g["sigma"]) ** 2 * torch.eye(1))
+    ctrl = MultiDISCO(observation_space=env_model.observation_space, action_space=env_model.action_space, hz_len=H, action_samples=S,
+                      params_samples=M, temperature=1.0, a_cov=float(g["sigma"]) ** 2 * torch.eye(1), inst_cost_fn=inst_cost,
+                      term_cost_fn=term_cost, params_sampling=True, n_policies=N, params_log_space=False)
+    ctrl.a_mat = init_policies.clone()
+    ctrl.return_rollouts = False
+    mpf = MPF(init_particles=torch.tensor(g["mpf_init"]), likelihood=GaussianLikelihood(initial_obs=init_state, obs_std=float(g["obs_std"]),
+                                                                                         model=PendulumModel(uncertain_params=("length", "mass")), log_space=False),
+              optimizer_class=torch.optim.SGD, lr=float(g["mpf_lr"]), bw=None, bw_scale=1.0)
+    model = PendulumModel(length=mpf.prior.mean[0], mass=mpf.prior.mean[1], uncertain_params=("length", "mass"))
+    sv = SVMPC(likelihood=ExponentiatedUtility(alpha=1.0, n_samples=S, controller=ctrl, model=model), init_particles=init_policies, prior=prior,
+               kernel=RBFKernel(), n_particles=N, bw_scale=1.0, n_steps=1, optimizer_class=torch.optim.SGD, lr=float(g["lr"]))
+    dual = DualSVMPC(sv, mpf, mpf_bw=None, mpf_steps=int(g["mpf_steps"]), warm_up=1, fused=True, seed=3)
+    plant_model = PendulumModel(g=10.0, length=float(g["true_length"]), mass=float(g["true_mass"]))
+
+    def plant(state, action):
+        return plant_model.step(state, torch.as_tensor(action, dtype=torch.float).clamp(-2.0, 2.0).reshape(1, -1)).reshape(1, -1)
+
+    state = init_state.reshape(1, -1)
+    for t in range(6):
+        x_before = mpf.x.numpy().copy() if t >= 1 else None  # (the filter is current here: the previous forward() ran its update)
+        action, state, pw = dual.tick(state, plant)
+        if t == 0:
+            assert pw is None and float(action.abs().max()) == 0.0  # warming up: zero action, unfused
+            continue
+        assert torch.isfinite(action).all() and abs(float(pw.sum()) - 1.0) < 1e-4, t
+        if t >= 2:  # this forward() carried out the update step() noted at t - 1, with Silverman's rule of the particles it started from
+            assert dual.last_bw is not None and abs(dual.last_bw - silvermans_rule(x_before.reshape(-1, 1))) < 1e-6 * dual.last_bw, t
+    assert dual._pending is not None
+    x_now = dual.dyn_particles  # reading the filter carries the noted update out
+    assert dual._pending is None and torch.isfinite(x_now).all()
