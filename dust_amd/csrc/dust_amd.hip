@@ -907,6 +907,15 @@ extern "C" int dust_clone(const dust_ctx *src, dust_ctx **out) {
     c->off_x = src->off_x;
     c->off_y = src->off_y;
   }
+  if (src->pk_perm && src->pk_lead && src->pk_perm_cap >= (size_t)c->nloc && src->pk_lead_cap >= (size_t)c->nloc) {
+    // the tile order of the large-set passes and the leaders noted for the next one (pairwise_packed.hpp): a copy continues with the
+    // same run lists - the same grouping of every sum - as its source
+    if (src->stream2) HIP_TRY(hipStreamSynchronize(src->stream2));  // (the side stream's query_order_kernel)
+    TRY(ensure(&c->pk_perm, &c->pk_perm_cap, (size_t)c->nloc));
+    TRY(ensure(&c->pk_lead, &c->pk_lead_cap, (size_t)c->nloc));
+    TRY(d2d(c, c->pk_perm, src->pk_perm, (size_t)c->nloc * sizeof(int)));
+    TRY(d2d(c, c->pk_lead, src->pk_lead, (size_t)c->nloc * sizeof(int)));
+  }
   if (src->mw_dev) {
     TRY(dalloc(&c->mw_dev, (size_t)c->M));
     TRY(d2d(c, c->mw_dev, src->mw_dev, (size_t)c->M * sizeof(float)));
