@@ -133,6 +133,8 @@ struct dust_ctx {
   // [tiles][chunks + 1], unit query masks [tiles][chunks][4], slice boundaries of pass 1 / pass 2, non-zero flags of the units' kernel blocks
   float *pk_idx, *pk_uoff, *pk_uq, *pk_soff, *pk_goff, *pk_nzu, *pk_perm, *pk_lead;
   size_t pk_idx_cap, pk_uoff_cap, pk_uq_cap, pk_soff_cap, pk_goff_cap, pk_nzu_cap, pk_perm_cap, pk_lead_cap;
+  float *lp_idx, *lp_uoff, *lp_uq, *lp_soff, *lp_goff;  // the log-p pass' own run lists (64-query groups of the UPDATED particles)
+  size_t lp_idx_cap, lp_uoff_cap, lp_uq_cap, lp_soff_cap, lp_goff_cap;
   bool params_staged;             // inside dust_dual_tick: the tick's dynamics samples already sit in params_dev (drawn there by the filter's kernel)
   bool stagewise;                 // inside dust_svmpc_phi (a stage-wise call on caller-supplied inputs): index order - the same inputs give the same bits, call after call
   bool pk_order;                  // pass 1 walks its queries in tile order (pk_perm) and notes their leaders (pk_lead) for the next order
@@ -207,6 +209,7 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    int logp_pack;   // DUST_LOGP_PACK=0 / 1: the log-p pass never / always walks run lists (default: from 8 192 local rows on)
     int pack_order;  // DUST_PACK_ORDER=0: the queries stay in index order (development switch)
     int pack_merge;  // DUST_PACK_MERGE=0: PLAIN run lists even below the exact-zero threshold (development switch)
     float far_t;  // DUST_FAR_T: the far pre-pass' threshold (pairwise_far.hpp), default DUST_FAR_T_DEFAULT
@@ -415,7 +418,7 @@ static void free_all(dust_ctx *c) {
   float **fp[] = {&c->theta, &c->theta_alt, &c->thetaT, &c->thetaT_alt, &c->mu, &c->muT, &c->logmix, &c->mixw, &c->a_mat, &c->a_seq, &c->a_mix, &c->eta,
                   &c->costsT, &c->omegaT, &c->grad_lik, &c->grad_pri, &c->score, &c->phi, &c->logl, &c->logp, &c->lw,
                   &c->outblk, &c->bw, &c->adam_m, &c->adam_v, &c->noise_stage, &c->actions, &c->states, &c->params_dev,
-                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->pk_idx, &c->pk_uoff, &c->pk_uq, &c->pk_soff, &c->pk_goff, &c->pk_nzu, &c->pk_perm, &c->pk_lead, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
+                  &c->state_dev, &c->tmp, &c->costs_stage, &c->tile_scratch, &c->wg_flags, &c->pA, &c->pB, &c->pM, &c->pL, &c->pS, &c->xpad, &c->kmat, &c->pk_idx, &c->pk_uoff, &c->pk_uq, &c->pk_soff, &c->pk_goff, &c->pk_nzu, &c->pk_perm, &c->pk_lead, &c->lp_idx, &c->lp_uoff, &c->lp_uq, &c->lp_soff, &c->lp_goff, &c->far_z, &c->far_n, &c->far_f, &c->far_g, &c->far_q, &c->far_cnt, &c->mw_dev, &c->cz_dev, &c->theta_w, &c->mu_w};
   for (auto p : fp)
     if (*p) (void)hipFree(*p);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -467,6 +470,7 @@ static void env_read(dust_ctx *c) {
   c->env.no_comm_overlap = env_int("DUST_NO_COMM_OVERLAP");
   c->env.pack_merge = env_int("DUST_PACK_MERGE");
   c->env.pack_order = env_int("DUST_PACK_ORDER");
+  c->env.logp_pack = env_int("DUST_LOGP_PACK");
   const char *ft = getenv("DUST_FAR_T");
   c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
@@ -2128,8 +2132,10 @@ static int far_counts_alloc(dust_ctx *c) {
   HIP_TRY(hipMemsetAsync(c->far_cnt, 0, 8 * sizeof(unsigned int), c->pair_stream));
   return DUST_OK;
 }
+static bool logp_pack_ok(const dust_ctx *c);
 static bool logp_far_decide(dust_ctx *c) {
   if (c->env.far == 0 || c->env.dense >= 0) return false;
+  if (logp_pack_ok(c)) return true;  // (run lists: the pre-pass always pays there)
   if (c->env.far >= 2 || !c->far_cnt_host) return true;
   if (c->far_logp_skip > 0) {
     --c->far_logp_skip;
@@ -2153,6 +2159,126 @@ static bool logp_far_decide(dust_ctx *c) {
     return false;
   }
   return true;
+}
+
+// log p(theta) over run lists (pairwise_packed.hpp pairwise_logp_packed_kernel): the far pre-pass on the updated particles with key masks
+// (64-query groups in pass 1's tile order), one list of near keys per group, the product-form log-sum-exp over the listed keys only.
+// Large sets only: a rank's 2 048 rows cost 52 us dense and the pre-pass alone 45.
+static bool logp_pack_ok(const dust_ctx *c) {
+  if (c->env.far == 0 || c->env.dense >= 0 || c->env.pack_merge == 0 || !(c->env.far_t < DUST_FAR_T_EXACT)) return false;
+  if (c->env.logp_pack >= 0) return c->env.logp_pack != 0;
+  return c->nloc >= 8192;
+}
+static int launch_pair_logp_packed(dust_ctx *c, const PairArgs &a) {
+  const int dpb = std::max(16, ((a.D + 15) / 16) * 16);
+  TRY(ensure(&c->xpad, &c->xpad_cap, (size_t)c->N * dpb + 2 * (size_t)c->N));
+  const int groups = (a.n_local + 63) / 64, chunks = (c->N + 63) / 64;
+  LogpPackedArgs p;
+  memset(&p, 0, sizeof p);
+  LogpMfmaArgs &b = p.a;
+  b.N = c->N;
+  b.D = a.D;
+  b.i0 = a.i0;
+  b.n_local = a.n_local;
+  const int JS = std::max(1, std::min(std::min(chunks, 8), (2 * device_cus(c) + groups - 1) / groups));
+  b.JS = JS;
+  TRY(ensure_partials(c, JS));
+  c->prior_js = JS;
+  b.X = a.X;
+  b.logmix = a.logmix;
+  b.sw[0] = a.inv_s[0] * 1.2011224087864498f;  // sqrt(log2 e) / sigma_p
+  b.sw[1] = a.da == 2 ? a.inv_s[1] * 1.2011224087864498f : b.sw[0];
+  b.Z = c->xpad;
+  b.hq = c->xpad + (size_t)c->N * dpb;
+  b.hj = b.hq + c->N;
+  b.pM = c->pM;
+  b.pL = c->pL;
+  FarArgs f;
+  memset(&f, 0, sizeof f);
+  f.N = c->N;
+  f.D = a.D;
+  f.i0 = a.i0;
+  f.n_local = a.n_local;
+  f.tiles = groups;
+  f.q_rows = groups * 64;
+  f.lscale = 1.44269504088896340736f;
+  f.chunks = chunks;
+  f.X = a.X;
+  f.logmix = a.logmix;
+  f.sg[0] = b.sw[0];
+  f.sg[1] = b.sw[1];
+  f.T = c->env.far_t * 1.44269504088896340736f;
+  TRY(ensure(&c->far_z, &c->far_z_cap, ((size_t)c->N * far_zh(dpb) + 1) / 2));
+  TRY(ensure(&c->far_n, &c->far_n_cap, 3 * (size_t)c->N + chunks));
+  TRY(ensure(&c->far_g, &c->far_g_cap, ((size_t)groups * chunks + 3) / 4));
+  TRY(ensure(&c->far_q, &c->far_q_cap, (size_t)groups * chunks * 8));
+  f.Z = reinterpret_cast<_Float16 *>(c->far_z);
+  f.nrm = c->far_n;
+  f.lms = c->far_n + c->N;
+  f.m0 = c->far_n + 2 * (size_t)c->N;
+  f.Xp = b.Z;  // the scaled rows: unit metric
+  f.wP[0] = f.wP[1] = 1.0f;
+  f.far = reinterpret_cast<unsigned char *>(c->far_g);
+  f.qmask = reinterpret_cast<unsigned int *>(c->far_q);
+  const bool order = c->pk_order && c->pk_perm && !c->stagewise;  // pass 1's tile order (the one in force this tick)
+  f.qperm = order ? reinterpret_cast<const int *>(c->pk_perm) : nullptr;
+  TRY(far_counts_alloc(c));
+  if (c->far_cnt_host) {
+    f.count = reinterpret_cast<unsigned int *>(c->far_cnt) + 4;
+    f.host_count = c->far_cnt_host + 4;
+    if (!c->capturing) c->far_logp_issued++;
+  }
+  const int gx = (groups + 3) / 4;
+  const int want = std::max(1, (3 * device_cus(c) + gx - 1) / gx);
+  f.cps = std::max(1, (chunks + want - 1) / want);
+  dim3 fgrid(gx, (chunks + f.cps - 1) / f.cps);
+  c->far_groups = groups;
+  c->far_gchunks = chunks;
+  PackArgs pk;
+  memset(&pk, 0, sizeof pk);
+  pk.N = c->N;
+  pk.tiles = groups;
+  pk.chunks = chunks;
+  pk.merge = 1;
+  pk.JS = JS;
+  pk.JSG = JS;
+  pk.far = f.far;
+  pk.qmask = f.qmask;
+  pk.ldi = chunks * 64;
+  TRY(ensure(&c->lp_idx, &c->lp_idx_cap, (size_t)groups * pk.ldi));
+  TRY(ensure(&c->lp_uoff, &c->lp_uoff_cap, (size_t)groups * (chunks + 1)));
+  TRY(ensure(&c->lp_uq, &c->lp_uq_cap, (size_t)groups * chunks * 4));
+  TRY(ensure(&c->lp_soff, &c->lp_soff_cap, (size_t)groups * (JS + 1)));
+  TRY(ensure(&c->lp_goff, &c->lp_goff_cap, (size_t)groups * (JS + 1)));
+  pk.kidx = reinterpret_cast<int *>(c->lp_idx);
+  pk.uoff = reinterpret_cast<int *>(c->lp_uoff);
+  pk.uq = reinterpret_cast<unsigned int *>(c->lp_uq);
+  pk.soff = reinterpret_cast<int *>(c->lp_soff);
+  pk.goff = reinterpret_cast<int *>(c->lp_goff);
+  p.kidx = pk.kidx;
+  p.ldi = pk.ldi;
+  p.umax = chunks;
+  p.uoff = pk.uoff;
+  p.uq = pk.uq;
+  p.soff = pk.soff;
+  p.qperm = f.qperm;
+  dim3 grid(groups, JS);
+#define DUST_LAUNCH_LOGPP(DPB)                                                                                                       \
+  do {                                                                                                                              \
+    logp_prep_far_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b, f);                                                    \
+    far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);              \
+    far_flags_kernel<DPB, 64, true><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
+    far_pack_kernel<<<groups, 256, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);                                               \
+    pairwise_logp_packed_kernel<DPB><<<grid, 256, pairwise_logp_packed_lds_bytes<DPB>(), c->pair_stream>>>(p);                      \
+  } while (0)
+  if (dpb == 16) DUST_LAUNCH_LOGPP(16);
+  else if (dpb == 32) DUST_LAUNCH_LOGPP(32);
+  else if (dpb == 48) DUST_LAUNCH_LOGPP(48);
+  else if (dpb == 64) DUST_LAUNCH_LOGPP(64);
+  else DUST_LAUNCH_LOGPP(80);
+#undef DUST_LAUNCH_LOGPP
+  HIP_TRY(hipGetLastError());
+  return DUST_OK;
 }
 
 // log p(theta) only, large aliased sets (SVMPC.forward): product-form distances on the matrix cores + log-sum-exp
@@ -2405,6 +2531,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   c->prior_js = 0;  // (launch_pair_fused sets its own slice count)
   if (full_cov(c)) TRY(launch_whiten(c));
   if (logp_only && pair_fused_ok(c)) {  // large aliased set
+    if (c->env.logp_mfma != 0 && logp_pack_ok(c)) return launch_pair_logp_packed(c, a);  // ... over run lists of near keys (large sets)
     if (c->env.logp_mfma != 0) return launch_pair_logp_mfma(c, a);  // product-form distances on the matrix cores + log-sum-exp
     return launch_pair_logp_big(c, a, tiles);                         // exact-difference distance pass + log-sum-exp
   }

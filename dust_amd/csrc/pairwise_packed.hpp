@@ -22,6 +22,7 @@
 // those of visiting every chunk, minus the chunks whose terms are exact zeros: the three modes stay bit-identical to one another.
 #pragma once
 #include "pairwise_fused.hpp"
+#include "pairwise_logp_mfma.hpp"
 
 namespace dust {
 
@@ -599,6 +600,141 @@ __global__ __launch_bounds__(GramGeom<TQ>::NT, 2) void gram_packed_kernel(const 
       for (int t = 0; t < NCT; ++t)
         if (16 * t + 4 * g < a.ldp) *reinterpret_cast<v4f *>(a.pA + row + 16 * t + 4 * g) = acc0[t];
     }
+  }
+}
+
+// ---- forward's log p over run lists (round 6): pairwise_logp_mfma.hpp's product-form log-sum-exp, walking the near keys of a 64-query
+// group instead of every key.  The dense pass is 372 us at cfg4 (0.79 of the fp32 MFMA peak) for sums whose terms are all but 0.1 %
+// below 2^-43 of their leader; its pre-pass (pairwise_far.hpp on the UPDATED particles, 64-query groups, with key masks) + the lists
+// cost less than half of that once the set is large.  Workgroup = one group: 4 waves x 16 queries (one MFMA column tile per wave, the
+// query rows in registers as B operands), the group's listed keys gathered through LDS in units of 64 (double buffered); 4 MFMAs per
+// 16-byte LDS read.  The query's own term is put in exactly (pairwise_logp_mfma.hpp), found by key index.
+struct LogpPackedArgs {
+  LogpMfmaArgs a;      // Z / hq / hj rows, pM / pL, JS = slices per group
+  const int *kidx;     // [groups][ldi]
+  int ldi, umax;
+  const int *uoff;     // [groups][umax + 1]
+  const unsigned int *uq;  // [groups][umax][4] (words 0-1: the group's 64 queries)
+  const int *soff;     // [groups][JS + 1]
+  const int *qperm;    // tile order (position -> local row), or nullptr
+};
+
+template <int DPB>
+static inline size_t pairwise_logp_packed_lds_bytes() {
+  return sizeof(float) * (2 * (size_t)64 * (DPB + 4) + 4 * 64);
+}
+
+template <int DPB>
+__global__ __launch_bounds__(256, 2) void pairwise_logp_packed_kernel(const LogpPackedArgs b) {
+  constexpr int JC = 64, NT = 256, YS = DPB + 4, NP = DPB / 16, R4 = DPB / 4;
+  static_assert(DPB % 16 == 0, "whole 16-column pieces");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const LogpMfmaArgs &a = b.a;
+  float *Ys = lds;                // [2][JC][YS] key rows
+  float *hs = lds + 2 * JC * YS;  // [2][JC] key constants (slots behind the unit's last key: -inf)
+  int *ks = reinterpret_cast<int *>(hs + 2 * JC);  // [2][JC] key indices
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.x, js = blockIdx.y;
+  typedef const int __attribute__((address_space(4))) * ci32;
+  typedef const unsigned int __attribute__((address_space(4))) * cu32;
+  const ci32 soff = (ci32)(uintptr_t)(b.soff + (size_t)grp * (a.JS + 1));
+  const ci32 uoff = (ci32)(uintptr_t)(b.uoff + (size_t)grp * (b.umax + 1));
+  const int *kidx = b.kidx + (size_t)grp * b.ldi;
+  const int u0 = soff[js], u1 = soff[js + 1];
+  const int pos = grp * 64 + 16 * wave + r16;  // the lane's query: position in tile order
+  const int posc = min(pos, a.n_local - 1);
+  const int row = b.qperm ? b.qperm[posc] : posc, gq = a.i0 + row;
+  v4f bq[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) bq[s] = *reinterpret_cast<const v4f *>(a.Z + (size_t)gq * DPB + 16 * s + 4 * g);
+  float m = -3.0e38f, sm = 0.f;
+  const float hq2 = 2.0f * a.hq[gq];
+  v4f ky[NP];
+  float hjn = 0.f;
+  int kin = 0;
+  auto keys_issue = [&](const int u) {
+    const int k0 = uoff[u], jc = uoff[u + 1] - k0;
+    int key[NP];
+#pragma unroll
+    for (int w = 0; w < NP; ++w) key[w] = kidx[k0 + min((tid + NT * w) / R4, jc - 1)];
+    const int kl = kidx[k0 + min(tid & 63, jc - 1)];
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const int f = tid + NT * w, rr = f / R4, c4 = f - rr * R4;
+      ky[w] = *reinterpret_cast<const v4f *>(a.Z + (size_t)key[w] * DPB + 4 * c4);
+    }
+    if (tid < JC) {
+      hjn = tid < jc ? a.hj[kl] : -INFINITY;
+      kin = tid < jc ? kl : -1;
+    }
+  };
+  auto keys_commit = [&](const int buf) {
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
+      const int f = tid + NT * w, rr = f / R4, c4 = f - rr * R4;
+      *reinterpret_cast<v4f *>(&Ys[(buf * JC + rr) * YS + 4 * c4]) = ky[w];
+    }
+    if (tid < JC) {
+      hs[buf * JC + tid] = hjn;
+      ks[buf * JC + tid] = kin;
+    }
+  };
+  if (u0 < u1) {
+    keys_issue(u0);
+    keys_commit(0);
+  }
+  wg_sync();
+  int buf = 0;
+  for (int u = u0; u < u1; ++u, buf ^= 1) {
+    // does one of the wave's 16 queries have a near key in this unit?
+    bool own = true;
+    if (b.uq) {
+      const cu32 qm = (cu32)(uintptr_t)(b.uq + ((size_t)grp * b.umax + u) * 4);
+      const unsigned int w32 = qm[wave >> 1];
+      own = ((w32 >> (16 * (wave & 1))) & 0xffffu) != 0u;
+    }
+    const bool more = u + 1 < u1;
+    if (more) keys_issue(u + 1);  // in flight during the products
+    const float *Yb = Ys + (size_t)buf * JC * YS;
+#pragma unroll 1
+    for (int kt = 0; kt < (own ? JC / 16 : 0); ++kt) {
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const v4f av = *reinterpret_cast<const v4f *>(&Yb[(16 * kt + r16) * YS + 16 * s + 4 * g]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bq[s][c], acc, 0, 0, 0);
+      }
+      // the lane holds (keys 16 kt + 4 g + r, query r16): online log-sum-exp in base 2
+      const v4f h = *reinterpret_cast<const v4f *>(&hs[buf * JC + 16 * kt + 4 * g]);
+      const int4 kid = *reinterpret_cast<const int4 *>(&ks[buf * JC + 16 * kt + 4 * g]);
+      v4f x = acc + h;
+      x.x = kid.x == gq ? h.x - hq2 : x.x;  // the query's OWN term, exact (distance 0: logit = log w_i)
+      x.y = kid.y == gq ? h.y - hq2 : x.y;
+      x.z = kid.z == gq ? h.z - hq2 : x.z;
+      x.w = kid.w == gq ? h.w - hq2 : x.w;
+      const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+      const float mn = fmaxf(m, mx);
+      const float e = (__builtin_amdgcn_exp2f(x.x - mn) + __builtin_amdgcn_exp2f(x.y - mn)) +
+                      (__builtin_amdgcn_exp2f(x.z - mn) + __builtin_amdgcn_exp2f(x.w - mn));
+      sm = fmaf(sm, __builtin_amdgcn_exp2f(m - mn), e);
+      m = mn;
+    }
+    if (more) keys_commit(buf ^ 1);
+    wg_sync();
+  }
+  // merge the 4 lane groups of a query (lanes r16, r16 + 16, + 32, + 48), then one lane per query writes the slice partial
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o), so = __shfl_xor(sm, o);
+    const float mn = fmaxf(m, mo);
+    sm = sm * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
+    m = mn;
+  }
+  if (g == 0 && pos < a.n_local) {
+    a.pM[(size_t)js * a.n_local + row] = sm > 0.f ? (m + a.hq[gq]) * 0.69314718055994531f : -INFINITY;
+    a.pL[(size_t)js * a.n_local + row] = sm;
   }
 }
 
