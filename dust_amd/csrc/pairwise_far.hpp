@@ -300,13 +300,17 @@ __global__ __launch_bounds__(256, 3) void far_flags_kernel(const FarArgs a) {
     const unsigned char *base = lds_raw + buf * BUF;
     const _Float16 *Zs = reinterpret_cast<const _Float16 *>(base);
     const float *kf = reinterpret_cast<const float *>(base + (size_t)JC * ZS * sizeof(_Float16));
-    float mt[QT];
+    // Round 6: the margins are never formed.  margin = key constant - 2 acc > 0  <=>  acc < key constant / 2: ONE compare per accumulator
+    // component, its lane mask straight into scalar registers - and the per-query / per-key minima of round 5 (2 packed FMAs, 6-14
+    // three-operand minima and 16 DPP steps per 16 x 16 tile, on the vector pipe the MFMAs share) become ORs on the scalar pipe.
+    // A NaN accumulator compares "not below": near, as before.
+    unsigned long long qacc[QT];  // lane (g, r16): query r16 of sub-tile t has a near key among the chunk's keys 16 kt + 4 g + r
 #pragma unroll
-    for (int t = 0; t < QT; ++t) mt[t] = 3.0e38f;
+    for (int t = 0; t < QT; ++t) qacc[t] = 0ull;
     unsigned long long kmask = 0ull;  // (MASKS) keys of the chunk with a near query in the tile; wave-uniform
 #pragma unroll 1
     for (int kt = 0; kt < JC / 16; ++kt) {
-      // (the accumulators start at -n_q / 2: -2 acc + (key constant) is then the pair's whole margin - no add per element)
+      // (the accumulators start at -n_q / 2: acc = z_q . z_k - n_q / 2, and the pair is far when acc < (n_k - T - 2 dl) / 2)
       v4f acc[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) acc[t] = v4f{hqh[t], hqh[t], hqh[t], hqh[t]};
@@ -319,62 +323,45 @@ __global__ __launch_bounds__(256, 3) void far_flags_kernel(const FarArgs a) {
       // the lane holds (keys 16 kt + 4 g + r, query r16 of sub-tile t)
       const v4f kn = *reinterpret_cast<const v4f *>(&kf[16 * kt + 4 * g]);
       const v4f kl = *reinterpret_cast<const v4f *>(&kf[JC + 16 * kt + 4 * g]);
-      float hk[4];
+      float thr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float dl = kl[r] == -INFINITY ? 0.f : fmaxf(kl[r] - lmq, 0.f);  // (a key of zero weight has no prior term at all)
-        hk[r] = fmaf(-2.0f, dl, kn[r]);
+        thr[r] = 0.5f * fmaf(-2.0f, dl, kn[r]);
       }
-      const v2f hk01 = {hk[0], hk[1]}, hk23 = {hk[2], hk[3]}, m2 = {-2.0f, -2.0f};
-      if (!MASKS) {
+      unsigned long long kr[4] = {0ull, 0ull, 0ull, 0ull};  // component r: lanes whose key 16 kt + 4 g + r is near SOME sub-tile's query r16
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          const v2f e01 = __builtin_elementwise_fma(m2, v2f{acc[t][0], acc[t][1]}, hk01), e23 = __builtin_elementwise_fma(m2, v2f{acc[t][2], acc[t][3]}, hk23);
-          mt[t] = fminf(fminf(mt[t], e01.x), e01.y);
-          mt[t] = fminf(fminf(mt[t], e23.x), e23.y);
+      for (int t = 0; t < QT; ++t) {
+        const unsigned long long b0 = __ballot(!(acc[t][0] < thr[0])), b1 = __ballot(!(acc[t][1] < thr[1]));
+        const unsigned long long b2 = __ballot(!(acc[t][2] < thr[2])), b3 = __ballot(!(acc[t][3] < thr[3]));
+        qacc[t] |= (b0 | b1) | (b2 | b3);
+        if (MASKS) {
+          kr[0] |= b0;
+          kr[1] |= b1;
+          kr[2] |= b2;
+          kr[3] |= b3;
         }
-      } else {
-        // per key as well: the smallest margin over the tile's queries (the lane's QT sub-tiles, then the 16 lanes of its row)
-        float kvm[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-        static_assert(QT % 2 == 0 || true, "");
+      }
+      if (MASKS) {
+        unsigned long long k16 = 0ull;  // bit 4 g + r: some lane of row g (its 16 queries) flagged key 16 kt + 4 g + r
 #pragma unroll
-        for (int t = 0; t < QT; t += 2) {  // two sub-tiles per trip: three-operand minima on the key side too
-          const int t1 = t + 1 < QT ? t + 1 : t;
-          const v2f a01 = __builtin_elementwise_fma(m2, v2f{acc[t][0], acc[t][1]}, hk01), a23 = __builtin_elementwise_fma(m2, v2f{acc[t][2], acc[t][3]}, hk23);
-          const v2f b01 = __builtin_elementwise_fma(m2, v2f{acc[t1][0], acc[t1][1]}, hk01), b23 = __builtin_elementwise_fma(m2, v2f{acc[t1][2], acc[t1][3]}, hk23);
-          mt[t] = fminf(fminf(mt[t], a01.x), a01.y);
-          mt[t] = fminf(fminf(mt[t], a23.x), a23.y);
-          if (t1 != t) {
-            mt[t1] = fminf(fminf(mt[t1], b01.x), b01.y);
-            mt[t1] = fminf(fminf(mt[t1], b23.x), b23.y);
-          }
-          kvm[0] = fminf(fminf(kvm[0], a01.x), b01.x);
-          kvm[1] = fminf(fminf(kvm[1], a01.y), b01.y);
-          kvm[2] = fminf(fminf(kvm[2], a23.x), b23.x);
-          kvm[3] = fminf(fminf(kvm[3], a23.y), b23.y);
-        }
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kvm[r] = row16_reduce(kvm[r], 3.0e38f, [](float x, float y) { return fminf(x, y); });
-        // lane r16 < 4 of row g speaks for key 16 kt + 4 g + r16
-        const float mine = r16 == 0 ? kvm[0] : (r16 == 1 ? kvm[1] : (r16 == 2 ? kvm[2] : kvm[3]));
-        const unsigned long long bb = __ballot(r16 < 4 && !(mine > 0.f));
-        const unsigned long long k16 = (bb & 0xFull) | ((bb >> 12) & 0xF0ull) | ((bb >> 24) & 0xF00ull) | ((bb >> 36) & 0xF000ull);
+          for (int gg = 0; gg < 4; ++gg) k16 |= ((kr[r] >> (16 * gg)) & 0xffffull) ? (1ull << (4 * gg + r)) : 0ull;
         kmask |= k16 << (16 * kt);
       }
     }
-    bool ok = true;
+    bool any_near = false;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) ok = ok && (mt[t] > 0.f);
-    const bool is_far = __ballot(!ok) == 0ull;  // wave-uniform
+    for (int t = 0; t < QT; ++t) any_near = any_near || qacc[t] != 0ull;
+    const bool is_far = !any_near;  // wave-uniform
     if (MASKS) {
-      // per query: the smallest margin over the chunk's 64 keys sits in the four lanes r16, r16 + 16, + 32, + 48
+      // per query: near when one of its four lanes (r16, r16 + 16, + 32, + 48) saw a near key
       unsigned int qm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        float v = mt[t];
-        v = fminf(v, __shfl_xor(v, 16));
-        v = fminf(v, __shfl_xor(v, 32));
-        const unsigned int b16 = (unsigned int)(__ballot(!(v > 0.f)) & 0xffffull);  // lanes 0 .. 15: queries 16 t + r16
+        const unsigned long long q = qacc[t];
+        const unsigned int b16 = (unsigned int)((q | (q >> 16) | (q >> 32) | (q >> 48)) & 0xffffull);  // queries 16 t + r16
         qm[t >> 1] |= b16 << (16 * (t & 1));
       }
       if (live && lane == 0) {
