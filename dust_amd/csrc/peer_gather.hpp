@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void peer_store_kernel(const PeerStoreArgs a) 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     typedef float pg_v4f __attribute__((ext_vector_type(4)));
     const pg_v4f v = reinterpret_cast<const pg_v4f *>(a.src)[i];
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(reinterpret_cast<pg_v4f *>(dst) + i), "v"(v) : "memory");
+    // (s_nop behind the store: a > 8-byte VMEM store reads its data registers late - stein.hpp store16)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(reinterpret_cast<pg_v4f *>(dst) + i), "v"(v) : "memory");
   }
   if (blockIdx.x == 0)
     for (size_t i = (n4 << 2) + threadIdx.x; i < a.count; i += blockDim.x)
