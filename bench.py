@@ -540,25 +540,45 @@ def main():
         # when the ranks still hold bit-identical particles afterwards (every rank keeps all N rows: a lost or stale piece shows up as a
         # disagreement).  `value` is the better of the two accepted figures; both are reported.
         if sh.c_side:
+            # Every rank takes every branch below together: the set-up's verdict is collective (dust_comm_peer_gather), the two
+            # validation ticks have no collective inside (peer stores with bounded waits: a rank whose pieces do not arrive raises
+            # within seconds, it cannot hang the others), and the ranks AGREE (all_gather_object) before anything is timed.
+            import zlib
+
             peer = dict(tried=True)
+            err = None
             try:
                 sh.ctx.comm_peer_gather(True)
+            except Exception as e:  # noqa: BLE001 - collective outcome: every rank is here, or none
+                err = "set-up: " + str(e)[:300]
+            crc = None
+            if err is None:
+                try:
+                    for _ in range(2):
+                        sh.tick(st4, c4["n_iters"], params=params)
+                    sh.sync()
+                    th = sh.ctx.get_theta()
+                    crc = (zlib.crc32(th.tobytes()), bool(np.isfinite(th).all()))
+                except Exception as e:  # noqa: BLE001
+                    err = "validation ticks: " + str(e)[:300]
+            verdicts = [None] * n_gpus
+            dist.all_gather_object(verdicts, (err, crc))
+            errs = [v[0] for v in verdicts if v[0]]
+            agree = not errs and all(v[1] == verdicts[0][1] for v in verdicts) and bool(verdicts[0][1][1])
+            peer["ranks_agree"] = bool(agree)
+            if errs:
+                peer["error"] = errs[0]
+            if agree:
                 el_p, _ = timed(lambda: sh.tick(st4, c4["n_iters"], params=params), sh.sync)
                 comm_p = sh.ctx.comm_probe(c4["n_iters"], 50)
-                th = sh.ctx.get_theta()
-                sums = [None] * n_gpus
-                dist.all_gather_object(sums, (float(np.float64(th).sum()), int(np.isfinite(th).all()), __import__("zlib").crc32(th.tobytes())))
-                agree = all(x == sums[0] for x in sums) and sums[0][1] == 1
-                peer.update(ticks_per_s=args.steps / el_p, ms_per_tick=1e3 * el_p / args.steps, comm_us_per_tick=comm_p, ranks_agree=bool(agree))
-                if agree and args.steps / el_p > value:
+                peer.update(ticks_per_s=args.steps / el_p, ms_per_tick=1e3 * el_p / args.steps, comm_us_per_tick=comm_p)
+                if args.steps / el_p > value:
                     value = args.steps / el_p
                     el = el_p
                     par = "particles sharded x%d (strong scaling), direct peer-store all-gathers of score and theta per SVGD iteration" % n_gpus
-            except Exception as e:  # noqa: BLE001 - the library's all-gathers stay in charge
-                peer["error"] = str(e)[:300]
-                bad = [None] * n_gpus
+            elif err is None or not err.startswith("set-up"):
                 try:
-                    dist.all_gather_object(bad, peer.get("error"))
+                    sh.ctx.comm_peer_gather(False)  # back to the collective library for the legs below
                 except Exception:  # noqa: BLE001
                     pass
             extra["scale_workload"]["peer_gather"] = peer

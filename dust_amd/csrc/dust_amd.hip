@@ -3609,7 +3609,10 @@ extern "C" int dust_comm_init(dust_ctx *c, const void *id, int rank, int world) 
   c->theta_pinned = true;
   // DUST_PEER_GATHER=1: the tick's all-gathers as direct peer stores (peer_gather.hpp; also dust_comm_peer_gather).  Every rank of a
   // run sees the same environment, so the set-up collective inside is entered by all of them or by none.
-  if (env_int("DUST_PEER_GATHER") > 0) TRY(dust_comm_peer_gather(c, 1));
+  if (env_int("DUST_PEER_GATHER") > 0) {  // (best effort: where the devices cannot map each other EVERY rank is told so and keeps the library's all-gathers)
+    const int st = dust_comm_peer_gather(c, 1);
+    if (st != DUST_OK && st != DUST_ERR_UNSUPPORTED) return st;
+  }
   return DUST_OK;
 }
 
@@ -3634,6 +3637,9 @@ enum { GATHER_SCORE = 0, GATHER_THETA = 1, GATHER_LW = 2 };
 static float *peer_own_buffer(dust_ctx *c, int which) { return which == GATHER_SCORE ? c->score : (which == GATHER_THETA ? c->theta_home : c->lw); }
 
 // Map every peer's three buffers and arrival words (collective: the IPC handles travel through one all-gather of the communicator).
+// The OUTCOME is collective too: a rank whose local step fails (no handle for a buffer, a peer's handle that does not open) still takes
+// part in both all-gathers and says so in its status word, and every rank returns the same verdict - either all of them store to
+// their peers from here on or none does.  (A rank that left before the second all-gather would leave the others hanging inside it.)
 extern "C" int dust_comm_peer_gather(dust_ctx *c, int on) {
   if (!c) return fail(DUST_ERR_INVALID, "null ctx");
   if (!c->comm) return fail(DUST_ERR_STATE, "no communicator (dust_comm_init)");
@@ -3646,6 +3652,7 @@ extern "C" int dust_comm_peer_gather(dust_ctx *c, int on) {
   if (c->peer) return DUST_OK;
   if (c->comm_world > PEER_MAX) return fail(DUST_ERR_UNSUPPORTED, "peer-store all-gathers take up to %d ranks (one node)", (int)PEER_MAX);
   if (c->theta != c->theta_home) return fail(DUST_ERR_STATE, "the particles are not in their home buffer");
+  // (the checks above depend on the shape and the call history alone: every rank of a run takes them the same way)
   PeerState *p = new (std::nothrow) PeerState();
   if (!p) return fail(DUST_ERR_HIP, "out of host memory");
   memset((void *)p, 0, sizeof *p);
@@ -3653,54 +3660,87 @@ extern "C" int dust_comm_peer_gather(dust_ctx *c, int on) {
   p->rank = c->comm_rank;
   c->peer = p;
   const size_t nflag = (size_t)PEER_ROWS * PEER_MAX + PEER_MAX + 1;
-  int st = DUST_OK;
+  constexpr size_t HB = sizeof(hipIpcMemHandle_t), PER = (PEER_BUFS + 1) * HB + 64;  // four handles + a status word (padded)
+  static_assert(HB % sizeof(float) == 0 && PER % sizeof(float) == 0, "handle block size");
+  std::string why;  // this rank's first local failure
+  auto note = [&](const char *what) {
+    if (why.empty()) why = std::string(what) + ": " + hipGetErrorString(hipGetLastError());
+  };
+  std::vector<unsigned char> host((size_t)p->world * PER, 0);
+  void *mine[PEER_BUFS + 1] = {c->score, c->theta_home, c->lw, nullptr};
+  if (hipMalloc((void **)&p->flags_local, nflag * sizeof(unsigned int)) != hipSuccess) {
+    p->flags_local = nullptr;
+    note("hipMalloc (arrival words)");
+  } else if (hipMemset(p->flags_local, 0, nflag * sizeof(unsigned int)) != hipSuccess) {
+    note("hipMemset (arrival words)");
+  }
+  mine[PEER_BUFS] = p->flags_local;
+  for (int k = 0; k <= PEER_BUFS && why.empty(); ++k) {
+    hipIpcMemHandle_t h;
+    if (!mine[k] || hipIpcGetMemHandle(&h, mine[k]) != hipSuccess) note("hipIpcGetMemHandle");
+    else memcpy(&host[(size_t)p->rank * PER + k * HB], &h, HB);
+  }
+  unsigned int ok_word = why.empty() ? 1u : 0u;
+  memcpy(&host[(size_t)p->rank * PER + (PEER_BUFS + 1) * HB], &ok_word, sizeof ok_word);
+  // all-gather 1: handles + status.  (The staging buffer and the copies around a collective are unlikely to fail; if one does, the
+  // communicator itself is in doubt and the error is returned as it is.)
   float *hbuf = nullptr;
   auto bail = [&](int code) {
     if (hbuf) (void)hipFree(hbuf);
     peer_release(c);
     return code;
   };
-  if (hipMalloc((void **)&p->flags_local, nflag * sizeof(unsigned int)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc (arrival words)"));
-  if (hipMemset(p->flags_local, 0, nflag * sizeof(unsigned int)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMemset (arrival words)"));
-  // my handles -> every rank
-  constexpr size_t HB = sizeof(hipIpcMemHandle_t), PER = (PEER_BUFS + 1) * HB;
-  static_assert(HB % sizeof(float) == 0, "handle size");
-  std::vector<unsigned char> host((size_t)p->world * PER, 0);
-  void *mine[PEER_BUFS + 1] = {c->score, c->theta_home, c->lw, p->flags_local};
-  for (int k = 0; k <= PEER_BUFS; ++k) {
-    hipIpcMemHandle_t h;
-    if (hipIpcGetMemHandle(&h, mine[k]) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipIpcGetMemHandle (buffer %d): %s", k, hipGetErrorString(hipGetLastError())));
-    memcpy(&host[(size_t)p->rank * PER + k * HB], &h, HB);
-  }
   if (hipMalloc((void **)&hbuf, host.size()) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc (handle exchange)"));
   if (hipMemcpy(hbuf, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMemcpy (handle exchange)"));
-  st = rccl::check(rccl::all_gather(hbuf + (size_t)p->rank * (PER / sizeof(float)), hbuf, PER / sizeof(float), rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (IPC handles)");
+  int st = rccl::check(rccl::all_gather(hbuf + (size_t)p->rank * (PER / sizeof(float)), hbuf, PER / sizeof(float), rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (IPC handles)");
   if (st != DUST_OK) return bail(st);
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(host.data(), hbuf, host.size(), hipMemcpyDeviceToHost) != hipSuccess)
     return bail(fail(DUST_ERR_HIP, "handle exchange"));
-  (void)hipFree(hbuf);
-  hbuf = nullptr;
+  bool all_ok = true;
   for (int g = 0; g < p->world; ++g) {
-    for (int k = 0; k <= PEER_BUFS; ++k) {
-      void *ptr = mine[k];
-      if (g != p->rank) {
-        hipIpcMemHandle_t h;
-        memcpy(&h, &host[(size_t)g * PER + k * HB], HB);
-        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
-          return bail(fail(DUST_ERR_HIP, "hipIpcOpenMemHandle (rank %d, buffer %d): %s", g, k, hipGetErrorString(hipGetLastError())));
-        p->opened[g][k] = ptr;
+    unsigned int w = 0u;
+    memcpy(&w, &host[(size_t)g * PER + (PEER_BUFS + 1) * HB], sizeof w);
+    all_ok = all_ok && w == 1u;
+  }
+  if (env_int("DUST_PEER_TEST_FAIL") == p->rank) why = "test hook DUST_PEER_TEST_FAIL: this rank acts as if a peer's handle had not opened";
+  // open the peers' handles (only when every rank published valid ones)
+  if (all_ok) {
+    for (int g = 0; g < p->world && why.empty(); ++g) {
+      for (int k = 0; k <= PEER_BUFS && why.empty(); ++k) {
+        void *ptr = mine[k];
+        if (g != p->rank) {
+          hipIpcMemHandle_t h;
+          memcpy(&h, &host[(size_t)g * PER + k * HB], HB);
+          if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            note("hipIpcOpenMemHandle");
+            break;
+          }
+          p->opened[g][k] = ptr;
+        }
+        if (k < PEER_BUFS) p->buf[k][g] = (float *)ptr;
+        else p->flags[g] = (unsigned int *)ptr;
       }
-      if (k < PEER_BUFS) p->buf[k][g] = (float *)ptr;
-      else p->flags[g] = (unsigned int *)ptr;
     }
   }
-  // nobody stores before every rank has mapped (and zeroed) everything: one more collective as the barrier
-  float *bar = nullptr;
-  if (hipMalloc((void **)&bar, (size_t)p->world * sizeof(float)) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMalloc"));
-  st = rccl::check(rccl::all_gather(bar + p->rank, bar, 1, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (barrier)");
-  (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(bar);
+  // all-gather 2: the verdicts - and the barrier: nobody stores before every rank has mapped (and zeroed) everything
+  ok_word = (all_ok && why.empty()) ? 1u : 0u;
+  std::vector<float> verdict((size_t)p->world, 0.f);
+  verdict[(size_t)p->rank] = ok_word ? 1.0f : 0.0f;
+  if (hipMemcpy(hbuf, verdict.data(), verdict.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(DUST_ERR_HIP, "hipMemcpy (verdicts)"));
+  st = rccl::check(rccl::all_gather(hbuf + p->rank, hbuf, 1, rccl::ncclFloat32, c->comm, c->stream), "ncclAllGather (verdicts)");
   if (st != DUST_OK) return bail(st);
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(verdict.data(), hbuf, verdict.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    return bail(fail(DUST_ERR_HIP, "verdict exchange"));
+  int bad_rank = -1;
+  for (int g = 0; g < p->world; ++g)
+    if (verdict[(size_t)g] != 1.0f && bad_rank < 0) bad_rank = g;
+  if (bad_rank >= 0) {
+    const std::string mine_why = why;
+    (void)bail(DUST_OK);
+    return fail(DUST_ERR_UNSUPPORTED, "peer-store all-gathers are not available: rank %d could not map its peers%s%s (every rank keeps the collective library's all-gathers)",
+                bad_rank, mine_why.empty() ? "" : " - this rank: ", mine_why.c_str());
+  }
+  (void)hipFree(hbuf);
   return DUST_OK;
 }
 
@@ -3717,7 +3757,7 @@ static int peer_store(dust_ctx *c, int which, size_t count) {
   }
   a.done = p->flags_local + PEER_ROWS * PEER_MAX;
   a.handshake = which == GATHER_THETA ? 1 : 0;
-  a.timeout_ticks = 200000000ull;
+  a.timeout_ticks = 100000000ull;
   a.world = p->world;
   a.rank = p->rank;
   a.which = which;
@@ -3738,7 +3778,7 @@ static int peer_wait(dust_ctx *c, int which) {
   w.rank = p->rank;
   w.which = which;
   w.seq = p->seq[which];
-  w.timeout_ticks = 200000000ull;  // 2 s
+  w.timeout_ticks = 100000000ull;  // 1 s
   peer_wait_kernel<<<1, 64, 0, c->stream>>>(w);
   HIP_TRY(hipGetLastError());
   return DUST_OK;
@@ -3751,7 +3791,7 @@ static int peer_check(dust_ctx *c) {
   HIP_TRY(hipMemcpy(&e, w, sizeof e, hipMemcpyDeviceToHost));
   if (!e) return DUST_OK;
   HIP_TRY(hipMemset(w, 0, sizeof e));
-  return fail(DUST_ERR_HIP, "peer-store all-gather: a rank's piece did not arrive within 2 s (results of that tick are invalid)");
+  return fail(DUST_ERR_HIP, "peer-store all-gather: a rank's piece did not arrive within 1 s (results of that tick are invalid)");
 }
 // the exchange `which` of the sharded tick: every rank's `count` floats, in place
 static int gather(dust_ctx *c, int which, size_t count) {

@@ -303,7 +303,8 @@ int dust_comm_probe(dust_ctx *ctx, int n_steps, int reps, double *us_per_tick);
  * here, through HIP IPC - and raises one arrival word per peer; a one-wave kernel in front of the first consumer waits for the words.
  * on != 0: map the peers' buffers (COLLECTIVE: the IPC handles travel through one all-gather of the communicator - every rank calls it,
  * or none); on == 0: back to the collective library's all-gathers.  DUST_PEER_GATHER=1 in the environment makes dust_comm_init call it.
- * A piece that does not arrive within 2 s is reported by the next dust_sync / tick output as DUST_ERR_HIP.  (No reference counterpart:
+ * Its outcome is collective as well: if ANY rank cannot map its peers (no IPC between the devices), every rank returns DUST_ERR_UNSUPPORTED and
+ * keeps the collective library's all-gathers.  A piece that does not arrive within 1 s is reported by the next dust_sync / tick output as DUST_ERR_HIP.  (No reference counterpart:
  * the reference is single-device.) */
 int dust_comm_peer_gather(dust_ctx *ctx, int on);
 /* run the context's kernels on an external HIP stream (hipStream_t), e.g. torch's current stream */

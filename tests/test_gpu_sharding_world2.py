@@ -42,7 +42,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("gather", ["library", "peer"])
+@pytest.mark.parametrize("gather", ["library", "peer", "peer-refused"])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("ci", range(len(CASES)))
@@ -54,6 +54,8 @@ def test_c_side_sharded_tick_in_separate_processes(ci, world, overlap, gather, f
     case = CASES[ci]
     if world == 4 and ci in (1, 4):
         pytest.skip("world 4 runs on three of the cases")
+    if gather == "peer-refused" and (ci, world, overlap) != (0, 2, True):
+        pytest.skip("one case: a rank that cannot map its peers (test hook) - EVERY rank must fall back to the library's all-gathers, none may hang")
     sys.path.insert(0, HERE)
     from sharded_worker import case_inputs
 
@@ -67,8 +69,11 @@ def test_c_side_sharded_tick_in_separate_processes(ci, world, overlap, gather, f
     if not overlap:
         env["DUST_NO_COMM_OVERLAP"] = "1"
     env.pop("DUST_PEER_GATHER", None)
-    if gather == "peer":
+    env.pop("DUST_PEER_TEST_FAIL", None)
+    if gather in ("peer", "peer-refused"):
         env["DUST_PEER_GATHER"] = "1"
+    if gather == "peer-refused":
+        env["DUST_PEER_TEST_FAIL"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(tmp_path), str(cj)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
