@@ -2064,7 +2064,7 @@ static int launch_pair_fused(dust_ctx *c, const PairArgs &a, int tiles) {
   pk.uq = reinterpret_cast<unsigned int *>(c->pk_uq);
   pk.soff = reinterpret_cast<int *>(c->pk_soff);
   pk.goff = reinterpret_cast<int *>(c->pk_goff);
-  far_pack_kernel<<<tiles, 256, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);
+  far_pack_kernel<<<tiles, 1024, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);
   HIP_TRY(hipGetLastError());
   c->pk_tiles = tiles;
   c->pk_umax = chunks;
@@ -2270,7 +2270,7 @@ static int launch_pair_logp_packed(dust_ctx *c, const PairArgs &a) {
     logp_prep_far_kernel<DPB><<<(c->N + 3) / 4, 256, 0, c->pair_stream>>>(b, f);                                                    \
     far_lb_kernel<DPB><<<(std::min(c->N - a.i0, f.q_rows) + 63) / 64, 64 * DUST_FAR_LB_WAVES, 0, c->pair_stream>>>(f);              \
     far_flags_kernel<DPB, 64, true><<<fgrid, 256, far_flags_lds_bytes<DPB>(), c->pair_stream>>>(f);                                 \
-    far_pack_kernel<<<groups, 256, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);                                               \
+    far_pack_kernel<<<groups, 1024, far_pack_lds_bytes(chunks), c->pair_stream>>>(pk);                                               \
     pairwise_logp_packed_kernel<DPB><<<grid, 256, pairwise_logp_packed_lds_bytes<DPB>(), c->pair_stream>>>(p);                      \
   } while (0)
   if (dpb == 16) DUST_LAUNCH_LOGPP(16);
