@@ -4642,6 +4642,19 @@ extern "C" int dust_device_free(dust_ctx *c, void *p) {
   return DUST_OK;
 }
 
+// The tile order of the large-set passes (pairwise_packed.hpp query_order_kernel): position -> local row, n_local entries.  A test hook
+// (not in include/dust_amd.h): the order must be a permutation of the rank's rows - a row that is listed twice leaves another one out of
+// both passes.  Returns DUST_ERR_STATE when the context walks its queries in index order.
+extern "C" int dust_debug_tile_order(dust_ctx *c, int *perm) {
+  if (!c || !perm) return fail(DUST_ERR_INVALID, "null argument");
+  if (!c->pk_order || !c->pk_perm) return fail(DUST_ERR_STATE, "no tile order (index order)");
+  HIP_TRY(hipSetDevice(c->cfg.device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+  HIP_TRY(hipMemcpy(perm, c->pk_perm, (size_t)c->nloc * sizeof(int), hipMemcpyDeviceToHost));
+  return DUST_OK;
+}
+
 // The fixed cost of the sharded tick's three exchanges in their peer-store form, measured on ONE device (a test / measurement hook, not
 // in include/dust_amd.h): this context plays rank 0 of `world`, its "peers" are scratch buffers of the same device, and a one-wave
 // kernel plays the peers' arrival words and tokens.  Per exchange: the store kernel (the rank's piece copied world - 1 times, tokens,

@@ -1372,6 +1372,59 @@ def _pack_lists(ctx, tile):
     return U, uoff[:U + 1].copy(), kidx[:uoff[U]].copy(), uq[:4 * U].reshape(U, 4).copy(), soff[:JS + 1].copy()
 
 
+@pytest.mark.parametrize("N,shard", [(2100, None), (4096, None), (4096, (1024, 2048))])
+def test_tile_order_is_a_permutation_and_changes_nothing_but_rounding(N, shard, monkeypatch):
+    """pairwise_packed.hpp query_order_kernel: from the second tick on the large-set passes walk the queries in the order of their
+    leader (the smallest close key index, noted by pass 1; one workgroup's stable radix sort).  The order must be a PERMUTATION of the
+    rank's rows (ragged row counts, a shard in the middle of the set) - a row listed twice leaves another out of both passes - and it only
+    groups work: five ticks with the order and five with index order (DUST_PACK_ORDER=0) agree to the tolerance of a regrouped sum."""
+    import ctypes as C
+
+    monkeypatch.setenv("DUST_PAIR_BIG", "1")
+    from dust_amd import Context
+    from dust_amd import _lib as L
+    from oracle import grid_4x4_map
+
+    H, S = 40, 8
+    rng = np.random.default_rng(N)
+    theta = (3.0 * rng.standard_normal((N, H, 2))).astype(np.float32)
+    theta[::5] = theta[2] + (0.4 * rng.standard_normal((len(theta[::5]), H, 2))).astype(np.float32)   # scattered near-duplicates
+    theta[300:700] = theta[300] + (0.5 * rng.standard_normal((400, H, 2))).astype(np.float32)
+    state = np.array([-9.0, -9.0, 0.0, 0.0], np.float32)
+    kw = dict(model="particle", N=N, S=S, M=1, H=H, kernel="K1", lr=0.5, alpha=1e-4, sigma_a=2.0, sigma_p=1.0, grid=grid_4x4_map(), seed=3)
+    if shard:
+        kw.update(shard_offset=shard[0], shard_size=shard[1])
+    out = {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("DUST_PACK_ORDER", order)
+        c = Context(**kw)
+        c.set_theta(theta); c.set_prior(theta); c.set_a_mat(theta)
+        if shard:  # a rank alone (the other rows stay as they are): local score + Stein step + forward, the rank's kernels
+            lib = L.load()
+            for _ in range(5):
+                L.check(lib.dust_svmpc_local_score(c._h, state.ctypes.data_as(L.FP), None, None, 0))
+                L.check(lib.dust_svmpc_apply_phi(c._h))
+                lw, nb = L.VP(), C.c_size_t(0)
+                L.check(lib.dust_svmpc_forward_local(c._h, C.byref(lw), C.byref(nb)))
+                L.check(lib.dust_svmpc_forward_finish(c._h, None, None))
+        else:
+            for _ in range(5):
+                c.svmpc_tick(state, 1)
+        if order == "1":
+            lib = L.load()
+            lib.dust_debug_tile_order.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            lib.dust_debug_tile_order.restype = C.c_int
+            n_loc = shard[1] if shard else N
+            perm = np.zeros(n_loc, np.int32)
+            assert lib.dust_debug_tile_order(c._h, perm.ctypes.data_as(C.POINTER(C.c_int))) == 0
+            assert np.array_equal(np.sort(perm), np.arange(n_loc)), "the tile order is not a permutation of the rank's rows"
+            assert not np.array_equal(perm, np.arange(n_loc)), "leaders were noted: the order should differ from index order on this set"
+        out[order] = c.get_theta()
+        c.close()
+    rows = slice(shard[0], shard[0] + shard[1]) if shard else slice(None)
+    assert elemerr(out["1"][rows], out["0"][rows]) < 2e-5, elemerr(out["1"][rows], out["0"][rows])
+
+
 @pytest.mark.parametrize("mode", ["merged", "plain"])
 def test_run_lists_cover_every_near_pair(mode, monkeypatch):
     """pairwise_packed.hpp far_pack_kernel: a query tile's run list must hold EVERY key with a near query in the tile (the pre-pass'
