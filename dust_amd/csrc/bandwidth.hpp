@@ -30,6 +30,8 @@ struct K2Args {
   const float *thetaT;  // [D][N]
   const float *score;   // [N][D]
   float *h;             // [G] bandwidths out (G = D, or H when shared)
+  float log_n1;         // (float)log((double)N + 1.0), formed on the host (k2_bandwidth256)
+  const float *h_prev;  // [G] the bandwidths of the previous call (warm start of the sorted kernels); may be h itself
   float *phi;           // [N][D]
   // optimiser step folded into k2_phi_kernel (apply != 0): what update_from_phi_kernel does in a launch of its own otherwise.  The phi
   // kernel reads the particles through the TRANSPOSED copy only, so the row-major theta may be updated in place while other
@@ -39,6 +41,11 @@ struct K2Args {
   float *theta_rw;      // [N][D] row-major particles (updated in place)
   float *thetaT_out;    // [D][N] or nullptr: the updated particles, transposed, for the NEXT iteration's bandwidth and phi kernels (a second
                         // buffer: this launch's other workgroups still read the current transposed copy) - no transpose launch between iterations
+  // k2_phi2_kernel without a transposed copy (round 6, unsharded ping-pong of the particle buffers): x_rows != nullptr - the coordinates
+  // are read from these ROW-MAJOR particles (strided, like the scores) and the updated particles go to theta_out (the OTHER buffer:
+  // other workgroups still read x_rows); theta_out == nullptr: theta_rw is updated in place as described above
+  const float *x_rows;
+  float *theta_out;
   float *adam_m, *adam_v;
   uint32_t *ctr;        // {tick, iter, adam_step}
   unsigned int *fused_cnt;
@@ -60,18 +67,17 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // (several candidate thresholds per bisection round were measured at N = 1024 and lost: 1 -> 43 us, 2 -> 50, 3 -> 54, 7 -> 77; again in round 4
 //  behind the warm start: 282 / 291 / 297 us per cfg2 tick)
 
-// one workgroup per independent scalar dimension c
-__global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args a, int npow2) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [npow2]
-  __shared__ unsigned redc[16 * 8];  // [3][8] rotating count slots, [24] the gathered answer
-  const int tid = threadIdx.x, nt = blockDim.x, N = a.N, c = blockIdx.x;
+// The bandwidth of scalar dimension c, computed by ONE 1024-lane workgroup (every lane returns it): `v` is lane tid's coordinate
+// x_{tid,c} (INFINITY past N), xs = 2 npow2 floats of LDS.
+__device__ __forceinline__ float k2_sorted_bandwidth(const K2Args &a, const int npow2, const int c, float *const xs, float v) {
+  __shared__ unsigned redc[16 * 8];  // [3][8] rotating count slots, [24] the gathered answer, [25] the bandwidth
+  const int tid = threadIdx.x, N = a.N;
   // bitonic sort, one element per lane (npow2 <= 1024 = blockDim): partners inside a wave (j < 64) are exchanged with a lane
   // shuffle - no barrier - and only the 10 stages with j >= 64 go through LDS (55 barrier-separated LDS passes before: ~30 of 76 us)
   // (round 4: the partner at distance 1 / 2 / 8 comes through one DPP move, at distance 4 through two - 34 of the 45 in-wave stages - and
   //  the LDS stages alternate between two buffers, so one barrier per stage suffices: a wave that passes the barrier of stage s has seen
   //  every wave finish its reads of stage s - 1, whose buffer stage s + 1 writes.  8.5 -> 5 us of the kernel's 20.)
   {
-    float v = tid < N ? a.thetaT[(size_t)c * N + tid] : INFINITY;
     float *const xs2 = xs + npow2;  // (the host allocates 2 npow2 floats)
     int pp = 0;
     auto cmpx = [&](const int k, const int j, const float other) {
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
   // starts from 2^17 bit patterns instead of 2^31 (17 rounds instead of 31; the median moves 0.2-0.8 % per iteration at cfg2: +-2^-9 misses too often, +-2^-5 costs two more rounds); if
   // not (first call, a jump), nothing is lost but the two probes.  The answer is the same exact order statistic either way.
   {
-    const float hp = a.h[c];
+    const float hp = a.h_prev[c];
     const float vp = hp > a.min_bw && a.bw_scale > 0.f ?  /* (a clamped bandwidth says nothing about the median) */ (hp / a.bw_scale) * (float)log((double)N + 1.0) : 0.f;
     if (vp > 0.f && vp < span * span) {  // (wave-uniform: one value per workgroup)
       const unsigned plo = __float_as_uint(vp * (1.0f - 0.0078125f)), phi_ = __float_as_uint(vp * (1.0f + 0.0078125f));
@@ -293,8 +299,357 @@ __global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args 
     float h = __uint_as_float(lo);
     h = h / (float)log((double)N + 1.0);  // base_kernels.py:77
     h = a.bw_scale * h;
+    redc[25] = __float_as_uint(fmaxf(h, a.min_bw));
+  }
+  wg_sync();
+  return __uint_as_float(redc[25]);
+}
+
+// one workgroup per independent scalar dimension c
+__global__ __launch_bounds__(1024) void k2_bandwidth_sorted_kernel(const K2Args a, int npow2) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [2 npow2]
+  const int tid = threadIdx.x, N = a.N, c = blockIdx.x;
+  const float h = k2_sorted_bandwidth(a, npow2, c, xs, tid < N ? a.thetaT[(size_t)c * N + tid] : INFINITY);
+  if (tid == 0) a.h[c] = h;
+}
+
+// The same order statistic by a 256-LANE workgroup, four sorted positions per lane (round 6).  It exists so that the bandwidths can ride
+// in the prior + rollout launch (fused.hpp: fused_prior_rollout_kernel's workgroups are 256 lanes): they read the particles only, and
+// as a launch of their own behind the rollouts they were 16 of the 43 us of a cfg2 / K2 iteration.  Element e = 4 tid + r of the
+// bitonic network: the distance-1 / -2 stages are register exchanges, distances 4-128 cross lanes (DPP, two shuffles), only the three
+// stages at distance 256 / 512 cross waves through LDS.  Selection as above, a lane searching for its four positions at once (four
+// independent chains of LDS reads in flight).  Reads the ROW-MAJOR particles (a.theta): no transposed copy is needed in front of it.
+// lds: K2_BW256_LDS floats.  Writes a.h[c] (a.h_prev may be the same buffer: one workgroup per dimension).
+enum { K2_BW256_LDS = 3072 + 128 };
+#ifdef K2_STAMPS  // (tools/k2_bw_probe.hip: where the role's time goes)
+__device__ unsigned long long k2_stamps[64 * 16];
+#define K2_STAMP(k)                                                                                                   \
+  do {                                                                                                                \
+    if (threadIdx.x == 0) k2_stamps[blockIdx.x * 16 + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define K2_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+__device__ __forceinline__ void k2_bandwidth256(const K2Args &a, const int c, float *const lds) {
+  // (no static LDS: 388 bytes of it in the prior + rollout kernel took that launch from 6 to 5 resident workgroups per CU - every
+  //  workgroup of the cfg2 grid resident at once before, two rounds after: 17 -> 42 us)
+  unsigned *const redq = (unsigned *)(lds + 3072);  // [3][8] rotating count slots (two counts x four waves), [24] the gathered answer
+  float *const candq = lds + 3072 + 32;             // [64]
+  unsigned &ncandq = *(unsigned *)(lds + 3072 + 96);
+  const int tid = threadIdx.x, N = a.N, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float v[4];
+  K2_STAMP(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = 4 * tid + r;
+    v[r] = e < N ? a.theta[(size_t)e * a.D + c] : INFINITY;
+  }
+  if (tid == 0) ncandq = 0u;
+  if (v[0] == 12345.f) K2_STAMP(15);  // (waits for the loads)
+  K2_STAMP(1);
+  {
+    auto pair = [](float &x, float &y, const bool up) {  // (x, y) ascending when up
+      const float lo_ = fminf(x, y), hi_ = fmaxf(x, y);
+      x = up ? lo_ : hi_;
+      y = up ? hi_ : lo_;
+    };
+    int pp = 0;
+#pragma unroll
+    for (int k = 2; k <= 1024; k <<= 1) {
+      const bool up = (tid & (k >> 2)) == 0;  // (k >= 4; k = 2 is the register stage below alone)
+      auto cross = [&](const int m, const float (&o)[4]) {
+        const bool keep_min = ((tid & m) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = keep_min ? fminf(v[r], o[r]) : fmaxf(v[r], o[r]);
+      };
+      auto lds_stage = [&](const int m) {
+        float *const buf = lds + (pp ? 1024 : 0);
+        pp ^= 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[r * 256 + tid] = v[r];
+        wg_sync();
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = buf[r * 256 + (tid ^ m)];
+        cross(m, o);
+      };
+      if (k >= 1024) lds_stage(128);
+      if (k >= 512) lds_stage(64);
+      if (k >= 256) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], 32, 64);
+        cross(32, o);
+      }
+      if (k >= 128) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], 16, 64);
+        cross(16, o);
+      }
+      if (k >= 64) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[r]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+        cross(8, o);
+      }
+      if (k >= 32) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[r]), 0x104 /* row_shl:4 */, 0xf, 0x5, false);  // banks 0 / 2: the lane 4 up
+          t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, v[r]), 0x114 /* row_shr:4 */, 0xf, 0xa, false);      // banks 1 / 3: the lane 4 down
+          o[r] = __builtin_bit_cast(float, t);
+        }
+        cross(4, o);
+      }
+      if (k >= 16) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[r]), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+        cross(2, o);
+      }
+      if (k >= 8) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[r]), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+        cross(1, o);
+      }
+      if (k >= 4) {  // distance 2 inside the lane
+        pair(v[0], v[2], up);
+        pair(v[1], v[3], up);
+        pair(v[0], v[1], up);
+        pair(v[2], v[3], up);
+      } else {  // k = 2: (0, 1) ascending, (2, 3) descending
+        pair(v[0], v[1], true);
+        pair(v[2], v[3], false);
+      }
+    }
+  }
+  K2_STAMP(2);
+  float *const xs = lds + 2048;
+  *(v4f *)(xs + 4 * tid) = v4f{v[0], v[1], v[2], v[3]};
+  wg_sync();
+  const unsigned long long want = ((unsigned long long)N * N - 1ull) / 2ull + 1ull;  // rank (lower middle) + 1
+  const float span = xs[N - 1] - xs[0];
+  unsigned lo = 0u, hi = __float_as_uint(span * span);
+  bool has[4];
+  int bl[4], br[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    has[r] = 4 * tid + r < N;
+    bl[r] = 4 * tid + r;
+    br[r] = has[r] ? N - 1 : 4 * tid + r;
+  }
+  // b_v(i) = largest j >= i with (x_j - x_i)^2 <= thr, searched inside [l, rr] for the lane's four positions at once
+  auto search = [&](const float thr, int (&l)[4], const int (&r0)[4]) {
+    // Branch-free steps: the four LDS reads of a step are issued together (with a branch per position each read waited for its own
+    // compare).  l is always a position where the predicate holds (it starts at the position itself: distance 0), so a finished
+    // search (l == rr: m == l) re-reads its own answer and changes nothing; padded positions (e >= N: INFINITY - INFINITY is NaN, the
+    // predicate fails) start finished and only ever lower their private rr.
+    int rr[4] = {r0[0], r0[1], r0[2], r0[3]};
+    bool any;
+    do {
+      int m[4];
+      float x[4];
+      any = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        any |= l[r] < rr[r];
+        m[r] = (l[r] + rr[r] + 1) >> 1;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = xs[m[r]];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dlt = x[r] - v[r];
+        const bool ok = dlt * dlt <= thr;
+        l[r] = ok ? m[r] : l[r];
+        rr[r] = ok ? rr[r] : m[r] - 1;
+      }
+    } while (any);
+  };
+  auto count_of = [&](const int (&l)[4]) {
+    unsigned n = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) n += (unsigned)(l[r] - (4 * tid + r));  // (padded positions: l stays at the position)
+    return n;
+  };
+  int round = 0;
+  // block sums of up to two per-lane counts (< 2^12 each: the wave sums are exact in fp32); one barrier per call - the slot sets rotate
+  auto block_counts = [&](const unsigned n0, const unsigned n1, unsigned &s0, unsigned &s1) {
+    unsigned *const slot = redq + (round % 3) * 8;
+    const unsigned w0 = (unsigned)wave_sum((float)n0), w1 = (unsigned)wave_sum((float)n1);
+    if (lane == 0) {
+      slot[w] = w0;
+      slot[4 + w] = w1;
+    }
+    wg_sync();
+    ++round;
+    s0 = slot[0] + slot[1] + slot[2] + slot[3];
+    s1 = slot[4] + slot[5] + slot[6] + slot[7];
+  };
+  auto block_count = [&](const unsigned n0) {
+    unsigned *const slot = redq + (round % 3) * 8;
+    const unsigned w0 = (unsigned)wave_sum((float)n0);
+    if (lane == 0) slot[w] = w0;
+    wg_sync();
+    ++round;
+    const uint4 q = *(const uint4 *)slot;
+    return q.x + q.y + q.z + q.w;
+  };
+  const unsigned Wc = (unsigned)((want - (unsigned long long)N + 1ull) / 2ull);
+  unsigned Clo = 0u, Chi = (unsigned)(((unsigned long long)N * (N - 1)) / 2ull);
+  {  // warm start from the previous bandwidth (see k2_sorted_bandwidth)
+    const float hp = a.h_prev[c];
+    const float vp = hp > a.min_bw && a.bw_scale > 0.f ? (hp / a.bw_scale) * a.log_n1 : 0.f;
+    if (vp > 0.f && vp < span * span) {
+      const unsigned plo = __float_as_uint(vp * (1.0f - 0.0078125f)), phi_ = __float_as_uint(vp * (1.0f + 0.0078125f));
+      int b0[4] = {bl[0], bl[1], bl[2], bl[3]};
+      search(__uint_as_float(plo), b0, br);
+      // the second threshold is 1.6 % above the first: its answers lie a few positions above the first one's - a 4-step search in
+      // [b0, b0 + 15], and only a lane that ends on that range's last position goes on to the rest
+      int b1[4] = {b0[0], b0[1], b0[2], b0[3]};
+      {
+        int cap[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cap[r] = min(b0[r] + 15, br[r]);
+        search(__uint_as_float(phi_), b1, cap);
+        bool more = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) more |= b1[r] == cap[r] && cap[r] < br[r];
+        if (__builtin_amdgcn_ballot_w64(more) != 0ull) search(__uint_as_float(phi_), b1, br);
+      }
+      unsigned c_lo, c_hi;
+      block_counts(count_of(b0), count_of(b1), c_lo, c_hi);
+      const bool lo_below = 2ull * c_lo + (unsigned long long)N < want, hi_reaches = !(2ull * c_hi + (unsigned long long)N < want);
+      if (plo < phi_ && phi_ <= hi) {
+        if (lo_below) {
+          lo = plo + 1u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bl[r] = b0[r];
+          Clo = c_lo;
+        }
+        if (hi_reaches) {
+          hi = phi_;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) br[r] = b1[r];
+          Chi = c_hi;
+        } else {  // the answer lies above both probes
+          lo = phi_ + 1u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bl[r] = b1[r];
+          Clo = c_hi;
+        }
+        if (!lo_below) {  // ... or below both
+          hi = plo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) br[r] = b0[r];
+          Chi = c_lo;
+        }
+        const bool open_hi = !hi_reaches, open_lo = !lo_below;
+        if (open_hi || open_lo) {
+#pragma unroll 1
+          for (int e = 4; e >= 2; e -= 2) {
+            const float wv = open_hi ? vp * (1.0f + 1.0f / (float)(1 << e)) : vp * (1.0f - 1.0f / (float)(1 << e));
+            const unsigned pv = __float_as_uint(wv);
+            if (!(pv >= lo && pv < hi)) break;  // (workgroup-uniform)
+            int l[4] = {bl[0], bl[1], bl[2], bl[3]};
+            search(wv, l, br);
+            const unsigned cw = block_count(count_of(l));
+            if (cw >= Wc) {
+              hi = pv;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) br[r] = l[r];
+              Chi = cw;
+              if (open_hi) break;  // closed
+            } else {
+              lo = pv + 1u;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bl[r] = l[r];
+              Clo = cw;
+              if (open_lo) break;  // closed
+            }
+          }
+        }
+      }
+    }
+  }
+  K2_STAMP(3);
+  bool interp = true;
+  int nrounds = 0;
+  while (lo < hi) {  // narrowing: interpolated thresholds while they pay, bit-pattern midpoints otherwise (see k2_sorted_bandwidth)
+    const unsigned K = Chi - Clo;
+    if (K <= 64u) break;
+    unsigned mid = lo + ((hi - lo) >> 1);
+    if (interp) {
+      const float vlo = lo ? __uint_as_float(lo - 1u) : 0.f, vhi = __uint_as_float(hi);
+      const float fr = ((float)(Wc - Clo) - 0.5f) * __builtin_amdgcn_rcpf((float)K);  // (any threshold inside the bracket is a legal probe)
+      const unsigned mi = __float_as_uint(fmaf(vhi - vlo, fr, vlo));
+      mid = min(max(mi, lo), hi - 1u);
+    }
+    int l[4] = {bl[0], bl[1], bl[2], bl[3]};
+    ++nrounds;
+    search(__uint_as_float(mid), l, br);
+    const unsigned cnt = block_count(count_of(l));
+    if (cnt >= Wc) {  // the answer is <= mid
+      interp = (cnt - Clo) * 2u <= K;
+      hi = mid;
+      Chi = cnt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) br[r] = l[r];
+    } else {
+      interp = (Chi - cnt) * 2u <= K;
+      lo = mid + 1u;
+      Clo = cnt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bl[r] = l[r];
+    }
+  }
+  K2_STAMP(4);
+#ifdef K2_STAMPS
+  if (tid == 0) k2_stamps[blockIdx.x * 16 + 8] = nrounds;
+#endif
+  if (lo < hi) {  // <= 64 candidates: position i's are the pairs (i, j), bl < j <= br
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (has[r])
+        for (int j = bl[r] + 1; j <= br[r]; ++j) {
+          const float dlt = xs[j] - v[r];
+          candq[atomicAdd(&ncandq, 1u)] = dlt * dlt;
+        }
+    wg_sync();
+    if (tid < 64) {
+      float x = tid < (int)ncandq ? candq[tid] : INFINITY;
+      for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const float o = __shfl_xor(x, j, 64);
+          const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+          x = (lower == up) ? fminf(x, o) : fmaxf(x, o);
+        }
+      const float ans = __shfl(x, (int)(Wc - Clo) - 1, 64);
+      if (tid == 0) redq[24] = __float_as_uint(ans);
+    }
+    wg_sync();
+    lo = redq[24];
+  }
+  if (tid == 0) {
+    float h = __uint_as_float(lo);
+    h = h / a.log_n1;  // base_kernels.py:77 ((float)log(N + 1) formed on the host)
+    h = a.bw_scale * h;
     a.h[c] = fmaxf(h, a.min_bw);
   }
+  K2_STAMP(5);
+  (void)nrounds;
+}
+
+// (the role as a launch of its own - DUST_K2_FORM=3, a measuring aid: its duration in a kernel trace is the role's time without the
+//  rollout waves around it)
+__global__ __launch_bounds__(256) void k2_bandwidth256_kernel(const K2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds256[];
+  k2_bandwidth256(a, (int)blockIdx.x, lds256);
 }
 
 // N > 1024 (several particles per lane): plain bisection, a full binary search per particle and round
@@ -507,13 +862,14 @@ __global__ __launch_bounds__(256) void k2_phi2_kernel(const K2Args a) {
   const float h = a.h[g];
   const float ce = -1.44269504088896340736f / h;
   const v2f ce2 = {ce, ce};
-  const v2f xi = {a.thetaT[(size_t)g * N + ia], a.thetaT[(size_t)g * N + ib]};
+  const float *const xr = a.x_rows;  // (uniform)
+  const v2f xi = xr ? v2f{xr[(size_t)ia * D + g], xr[(size_t)ib * D + g]} : v2f{a.thetaT[(size_t)g * N + ia], a.thetaT[(size_t)g * N + ib]};
   v2f g1 = {0.f, 0.f}, g2 = {0.f, 0.f};
   for (int jb = 0; jb < N; jb += K2_JT) {
     const int jn = min(K2_JT, N - jb);
     wg_sync();
     for (int j = threadIdx.x; j < jn; j += 256) {
-      xcol[j] = a.thetaT[(size_t)g * N + jb + j];
+      xcol[j] = xr ? xr[(size_t)(jb + j) * D + g] : a.thetaT[(size_t)g * N + jb + j];
       scol[j] = a.score[(size_t)(jb + j) * D + g];
     }
     wg_sync();
@@ -556,7 +912,7 @@ __global__ __launch_bounds__(256) void k2_phi2_kernel(const K2Args a) {
           a.adam_m[o] = m;
           a.adam_v[o] = v;
         }
-        a.theta_rw[o] = th;
+        (a.theta_out ? a.theta_out : a.theta_rw)[o] = th;
         if (a.thetaT_out) a.thetaT_out[(size_t)g * N + i] = th;
       }
     }
@@ -585,7 +941,9 @@ static inline int launch_k2_bandwidth(hipStream_t stream, const K2Args &a) {
   } else {
     int np = 1;
     while (np < a.N) np <<= 1;
-    if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)2 * np * sizeof(float), stream>>>(a, np);  // (two buffers: the sort's LDS stages alternate)
+    static const bool alone256 = getenv("DUST_K2_FORM") && atoi(getenv("DUST_K2_FORM")) == 3;
+    if (a.N <= 1024 && alone256) k2_bandwidth256_kernel<<<G, 256, (size_t)K2_BW256_LDS * sizeof(float), stream>>>(a);
+    else if (a.N <= 1024) k2_bandwidth_sorted_kernel<<<G, 1024, (size_t)2 * np * sizeof(float), stream>>>(a, np);  // (two buffers: the sort's LDS stages alternate)
     else k2_bandwidth_sorted_big_kernel<<<G, 1024, (size_t)np * sizeof(float), stream>>>(a, np);
   }
   return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
@@ -598,7 +956,7 @@ static inline int launch_k2_phi(hipStream_t stream, const K2Args &a) {
     k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
   } else {
     static const bool one_q = getenv("DUST_K2_PHI1") != nullptr;  // development switch: one query per lane (k2_phi_kernel<1>)
-    if (one_q) k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
+    if (one_q && !a.x_rows) k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
     else k2_phi2_kernel<<<dim3((a.n_local + 127) / 128, G), 256, 0, stream>>>(a);
   }
   return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;

@@ -209,6 +209,8 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    int k2_form;     // DUST_K2_FORM=0 (development switch): K2's bandwidth launch stays behind the prior + rollout launch (rounds 1-5);
+                     // default: the bandwidths ride in that launch, phi reads the row-major particles (round 6)
     int logp_pack;   // DUST_LOGP_PACK=0 / 1: the log-p pass never / always walks run lists (default: from 8 192 local rows on)
     int pack_order;  // DUST_PACK_ORDER=0: the queries stay in index order (development switch)
     int pack_merge;  // DUST_PACK_MERGE=0: PLAIN run lists even below the exact-zero threshold (development switch)
@@ -253,6 +255,8 @@ struct dust_ctx {
   bool capturing;
   bool have_sample, actions_valid;
   bool states_valid, states_f16;  // the last rollout launch left states [M][S][N][H+1][ds] in `states` (binary16 when states_f16)
+  bool k2_inline_want;  // K2, set by step_device around its score launch: the prior + rollout launch may carry the bandwidth role
+  bool k2_bw_inline;    // K2: ... and did (the bandwidths of the current theta are in c->bw; no transposed copy was made)
   bool k2_bw_ahead;   // K2: transpose + bandwidths of the current theta are already in flight on the side stream
   float k2_fixed_h;   // > 0: fixed-bandwidth RBF (dust_set_k2_bandwidth), else the median trick
   float k2_min_bw;    // RBF(minimum_bw=): clamp of the median-trick bandwidths (0: the reference's default 1e-5)
@@ -471,6 +475,7 @@ static void env_read(dust_ctx *c) {
   c->env.pack_merge = env_int("DUST_PACK_MERGE");
   c->env.pack_order = env_int("DUST_PACK_ORDER");
   c->env.logp_pack = env_int("DUST_LOGP_PACK");
+  c->env.k2_form = env_int("DUST_K2_FORM");
   const char *ft = getenv("DUST_FAR_T");
   c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
@@ -693,6 +698,7 @@ static int create_impl(const dust_config *cfg, dust_ctx **out) {
     HIP_TRY(hipHostMalloc((void **)&c->out_pinned, (c->out_floats + 4) * sizeof(float), hipHostMallocDefault));
   }
   TRY(dalloc(&c->bw, (size_t)c->D));
+  HIP_TRY(hipMemsetAsync(c->bw, 0, c->D * sizeof(float), c->stream));  // (no previous bandwidth: the sorted kernels' warm start stands down)
   HIP_TRY(hipMemsetAsync(c->a_seq, 0, c->D * sizeof(float), c->stream));
   TRY(dalloc(&c->costsT, SN));
   TRY(dalloc(&c->omegaT, SN));
@@ -2542,6 +2548,7 @@ static int launch_prior(dust_ctx *c, bool logp_only = false) {
   return launch_pair<PAIR_PRIOR>(c, a, tiles);
 }
 
+static K2Args k2_args(dust_ctx *c);
 // Fused prior pass + rollout kernel (fused.hpp).  Returns DUST_OK with *done = false when the shape does not qualify.
 static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   *done = false;
@@ -2567,8 +2574,14 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   if (cpt > 8) return DUST_OK;  // D > 64: separate launches
   const size_t lds_p = pairwise_lds_bytes(PAIR_PRIOR, cpt);
   f.lds_roll_floats = (int)((lds_r / sizeof(float) + 3) & ~(size_t)3);
-  const size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
+  size_t lds = std::max(lds_p, (size_t)f.per_block * f.lds_roll_floats * sizeof(float));
   if (lds > 72 * 1024) return DUST_OK;  // keep >= 2 workgroups per CU co-resident
+  const bool k2_role = c->k2_inline_want;  // K2: the per-dimension bandwidths of THIS theta as a third role of the launch (bandwidth.hpp k2_bandwidth256)
+  if (k2_role) {
+    f.k2 = k2_args(c);
+    f.n_k2_blocks = (c->D + 7) & ~7;
+    lds = std::max(lds, (size_t)K2_BW256_LDS * sizeof(float));
+  }
   if (!c->fused_cnt || c->fused_tiles != f.tiles) {
     if (c->capturing) return DUST_OK;
     if (c->fused_cnt) HIP_TRY(hipFree(c->fused_cnt));
@@ -2583,7 +2596,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   f.n_pair_blocks = f.tiles * f.pa.JS;
   f.cnt = c->fused_cnt;
   f.timeout_flag = c->fused_cnt + (size_t)f.tiles * CNT_STRIDE;
-  const int grid = f.n_pair_blocks + c->nloc / f.per_block;
+  const int grid = f.n_k2_blocks + f.n_pair_blocks + c->nloc / f.per_block;
 #define DUST_LAUNCH_FUSED2(MODEL, CPT, GR)                                                                                                \
   do {                                                                                                                                  \
     if (lds > 64 * 1024 && !c->capturing)                                                                                               \
@@ -2609,6 +2622,7 @@ static int launch_fused(dust_ctx *c, const SampleOpts &o, bool *done) {
   c->fused_dirty = true;
   c->stein_dirty = false;
   c->actions_valid = false;
+  if (k2_role) c->k2_bw_ahead = c->k2_bw_inline = true;
   *done = true;
   return DUST_OK;
 }
@@ -2683,6 +2697,8 @@ static K2Args k2_args(dust_ctx *c) {
   k.thetaT = c->thetaT;
   k.score = c->score;
   k.h = c->bw;
+  k.h_prev = c->bw;
+  k.log_n1 = (float)log((double)c->N + 1.0);
   k.phi = c->phi;
   return k;
 }
@@ -2695,11 +2711,17 @@ static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K
     {
       Prof p(c, DUST_K_BANDWIDTH);
       const K2Args k = k2_args(c);
-      if (!c->k2_bw_ahead) {  // (else: the bandwidths of this theta were computed beside the rollouts, step_device's forked form)
+      // the bandwidths came with the prior + rollout launch (k2_inline_want): phi needs no transposed copy either when the update can go
+      // to the other particle buffer (unsharded contexts: nobody else holds theta's address)
+      const bool inline_bw = c->k2_bw_ahead && c->k2_bw_inline;
+      const bool rows = inline_bw && apply && c->nloc == c->N && !c->theta_pinned && c->theta_alt && !k.shared;
+      if (!c->k2_bw_ahead) {  // (else: the bandwidths of this theta were computed beside the rollouts - in their launch, or step_device's forked form)
         if (!(in_loop && c->k2_thetaT_fresh)) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));  // (fresh: the last update launch wrote it)
         TRY(launch_k2_bandwidth(c->stream, k));
+      } else if (inline_bw && !rows) {
+        if (!(in_loop && c->k2_thetaT_fresh)) TRY(launch_transpose(c, c->theta, c->thetaT, c->N, c->D));
       }
-      c->k2_bw_ahead = false;
+      c->k2_bw_ahead = c->k2_bw_inline = false;
       K2Args kp = k;
       if (apply) {  // the optimiser step rides in the phi kernel (no update_from_phi launch)
         const UpdateArgs u = update_args(c, 1);
@@ -2715,12 +2737,16 @@ static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K
         kp.ctr = u.ctr;
         kp.fused_cnt = u.fused_cnt;
         kp.fused_tiles = u.fused_tiles;
-        if (c->nloc == c->N && c->k2_fixed_h <= 0.f) {  // (unsharded: every column of the transposed copy is written here)
+        if (rows) {
+          kp.x_rows = c->theta;
+          kp.theta_out = c->theta_alt;
+        } else if (c->nloc == c->N && c->k2_fixed_h <= 0.f) {  // (unsharded: every column of the transposed copy is written here)
           kp.thetaT_out = c->thetaT_alt;  // (allocated with the context for the K2 kernels: nothing may be allocated inside a graph capture)
         }
       }
       TRY(launch_k2_phi(c->stream, kp));
       c->k2_thetaT_fresh = false;
+      if (rows) std::swap(c->theta, c->theta_alt);
       if (kp.thetaT_out) {
         std::swap(c->thetaT, c->thetaT_alt);
         c->k2_thetaT_fresh = true;
@@ -3066,7 +3092,12 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
     c->k2_bw_ahead = true;
     return launch_stein_update(c, 1, true);
   }
-  TRY(local_score_device(c, noise_dev, param_set));
+  // K2, one dimension per kernel (every demo), N <= 1024: the bandwidths as a role of the prior + rollout launch (when that launch is taken)
+  c->k2_inline_want = c->cfg.kernel == DUST_KERNEL_K2_IIDMP && c->env.k2_form != 0 && c->env.k2_form != 3 && !c->prof && c->N <= 1024 &&
+                      c->k2_fixed_h <= 0.f && c->da <= 2;
+  int sl = local_score_device(c, noise_dev, param_set);
+  c->k2_inline_want = false;
+  TRY(sl);
   TRY(launch_stein_update(c, 1, true));
   return DUST_OK;
 }

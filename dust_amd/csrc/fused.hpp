@@ -16,6 +16,7 @@
 // prior workgroups have the LOWER block indices and never wait on anything, so the rollout workgroups can only wait on
 // work that has already been dispatched (and the spin is bounded).
 #pragma once
+#include "bandwidth.hpp"
 #include "rollout.hpp"
 #include "stein.hpp"
 
@@ -29,20 +30,33 @@ struct FusedArgs {
   int lds_roll_floats;       // LDS floats per particle sub-block
   unsigned int *cnt;         // [tiles][CNT_STRIDE] arrival counters, one per 128-byte line
   unsigned int *timeout_flag;
+  // kernel branch K2 (round 6): the per-dimension median bandwidths read the particles only, like the two roles above - workgroups
+  // [0, n_k2_blocks) of the launch (the lowest indices: latency-bound chains of ~10 us, dispatched first; a multiple of 8, so that the
+  // other roles keep their XCD mapping; workgroup c < k2.D finds h_c, the rest return at once).  0: no such role.
+  int n_k2_blocks;
+  K2Args k2;
 };
 
 template <int MODEL, int CPT, bool GROUPS>
 __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollout_kernel(const FusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x < f.n_pair_blocks) {
-    const int tile_x = (int)blockIdx.x % f.tiles, js = (int)blockIdx.x / f.tiles;
+  if ((int)blockIdx.x < f.n_k2_blocks) {
+    if ((int)blockIdx.x < f.k2.D) {
+      __builtin_amdgcn_s_setprio(3);  // (a chain of dependent steps, one wave per SIMD: it goes first whenever it can issue)
+      k2_bandwidth256(f.k2, (int)blockIdx.x, lds);
+    }
+    return;
+  }
+  const int bx = (int)blockIdx.x - f.n_k2_blocks;
+  if (bx < f.n_pair_blocks) {
+    const int tile_x = bx % f.tiles, js = bx / f.tiles;
     pairwise_body<PAIR_PRIOR, CPT>(f.pa, lds, tile_x, js, /*write_through=*/true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores ...
     wg_sync();                                    // ... before the one lane that signals for the workgroup
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.cnt + tile_x * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    const int nb = (int)gridDim.x - f.n_pair_blocks;
-    const int b = (f.n_pair_blocks & 7) ? (int)blockIdx.x - f.n_pair_blocks : xcd_contiguous((int)blockIdx.x - f.n_pair_blocks, nb);
+    const int nb = (int)gridDim.x - f.n_k2_blocks - f.n_pair_blocks;
+    const int b = (f.n_pair_blocks & 7) ? bx - f.n_pair_blocks : xcd_contiguous(bx - f.n_pair_blocks, nb);
     const int sub = (int)threadIdx.x / f.sub_nt, tid = (int)threadIdx.x - sub * f.sub_nt;
     const FusedWait fw{f.cnt, (unsigned int)f.pa.JS, f.timeout_flag, nullptr, 1, 0, nullptr, nullptr};
     rollout_body<MODEL, 12, GROUPS, true>(f.ra, lds + (size_t)sub * f.lds_roll_floats, tid, f.sub_nt, b * f.per_block + sub, &fw);

@@ -734,6 +734,37 @@ def test_imq_phi_vs_oracle(N, H, ell):
     c.close()
 
 
+@pytest.mark.parametrize("N,optimizer", [(1024, "SGD"), (1000, "Adam"), (200, "SGD"), (70, "Adam")])
+def test_k2_launch_forms_agree(N, optimizer, monkeypatch):
+    """Round 6, bandwidth.hpp: by default the per-dimension bandwidths ride in the prior + rollout launch as a 256-lane role
+    (k2_bandwidth256) and phi reads the row-major particles, updating into the other particle buffer - no transposed copy;
+    DUST_K2_FORM=0 keeps the launches of rounds 1-5 (transpose, 1024-lane bandwidth kernel, phi in place).  The bandwidths are exact order
+    statistics either way (test_k2_bandwidth_is_the_exact_order_statistic runs on the default) and phi is the same kernel on the same
+    values: the particles are BIT-IDENTICAL over ticks of several iterations - ragged particle counts, both optimisers, odd and even
+    iteration counts (the particle buffers ping-pong in the default form)."""
+    from dust_amd import Context
+
+    H, S = 7, 16
+    rng = np.random.default_rng(N)
+    mu = rng.standard_normal((N, H, 1)).astype(np.float32)
+    theta = (mu + 1.5 * rng.standard_normal((N, H, 1))).astype(np.float32)
+    state = np.array([3.0, 0.0], np.float32)
+    out = {}
+    for form in ("0", "2"):
+        monkeypatch.setenv("DUST_K2_FORM", form)
+        c = Context(model="pendulum", N=N, S=S, M=1, H=H, kernel="K2", lr=0.5 if optimizer == "SGD" else 0.05, sigma_a=1.0, sigma_p=1.0,
+                    optimizer=optimizer, seed=11)
+        c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+        hs = []
+        for it in (3, 3, 3, 3, 2, 2, 2):  # (the third tick of a shape on is a replayed capture)
+            c.svmpc_tick(state, it)
+            hs.append(c.get_bandwidths().copy())
+        out[form] = (c.get_theta(), np.array(hs))
+        c.close()
+    assert np.array_equal(out["2"][1], out["0"][1]), "bandwidths differ"
+    assert np.array_equal(out["2"][0], out["0"][0]), elemerr(out["2"][0], out["0"][0])
+
+
 @pytest.mark.parametrize("N", [1000, 1024, 2048, 3000])
 def test_k2_bandwidth_is_the_exact_order_statistic(N):
     """h_c = median(pairwise squared distances) / log(N+1) with torch.median's lower-middle rule over all N^2 entries
