@@ -41,10 +41,7 @@ template <int MODEL, int CPT, bool GROUPS>
 __global__ __launch_bounds__(PAIR_NT, (CPT <= 4 ? 4 : 2)) void fused_prior_rollout_kernel(const FusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x < f.n_k2_blocks) {
-    if ((int)blockIdx.x < f.k2.D) {
-      __builtin_amdgcn_s_setprio(3);  // (a chain of dependent steps, one wave per SIMD: it goes first whenever it can issue)
-      k2_bandwidth256(f.k2, (int)blockIdx.x, lds);
-    }
+    if ((int)blockIdx.x < f.k2.D) k2_bandwidth256(f.k2, (int)blockIdx.x, lds);  // (s_setprio(3) around it: no change, 186 us per cfg2 / K2 tick either way)
     return;
   }
   const int bx = (int)blockIdx.x - f.n_k2_blocks;
