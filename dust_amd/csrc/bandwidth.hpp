@@ -923,6 +923,81 @@ __global__ __launch_bounds__(256) void k2_phi2_kernel(const K2Args a) {
   }
 }
 
+// k2_phi2_kernel's arithmetic on 1024 lanes (round 6; N <= K2_P3_N): 128 queries per workgroup (two per lane, packed fp32), the 16 waves
+// take 16 key slices, the slice partials are summed in slice order.  The 256-lane launch was 10.9 us per cfg2 iteration of pure
+// latency (a lane walked 256 keys); here a lane walks 64.  Sharded and unsharded contexts take the same kernel: the slices cut the key
+// range [0, N), whoever owns the queries - the ranks of a sharded run stay bit-identical to the unsharded one.
+enum { K2_P3_Q = 128, K2_P3_N = 2048 };
+__global__ __launch_bounds__(1024) void k2_phi3_kernel(const K2Args a) {
+  __shared__ float xcol[K2_P3_N], scol[K2_P3_N];
+  __shared__ float part[16][K2_P3_Q][2];
+  const int N = a.N, D = a.D, g = blockIdx.y, tid = threadIdx.x;
+  const int ii = tid & 63, js = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ila = blockIdx.x * K2_P3_Q + ii, ilb = ila + 64;
+  const bool ona = ila < a.n_local, onb = ilb < a.n_local;
+  const int ia = a.i0 + (ona ? ila : 0), ib = a.i0 + (onb ? ilb : 0);
+  const float *const xr = a.x_rows;  // (uniform)
+  for (int j = tid; j < N; j += 1024) {
+    xcol[j] = xr ? xr[(size_t)j * D + g] : a.thetaT[(size_t)g * N + j];
+    scol[j] = a.score[(size_t)j * D + g];
+  }
+  const float h = a.h[g];
+  const float ce = -1.44269504088896340736f / h;
+  const v2f ce2 = {ce, ce};
+  wg_sync();
+  const v2f xi = {xcol[ia], xcol[ib]};
+  v2f g1 = {0.f, 0.f}, g2 = {0.f, 0.f};
+  {
+    const int per = (N + 15) >> 4, j0 = js * per, j1 = min(N, j0 + per);
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      const float xc = xcol[j], sc = scol[j];
+      const v2f df = xi - v2f{xc, xc};
+      const v2f arg = (df * df) * ce2;
+      const v2f k = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+      g1 = __builtin_elementwise_fma(k, v2f{sc, sc}, g1);
+      g2 = __builtin_elementwise_fma(k, df, g2);
+    }
+  }
+  part[js][ii][0] = g1.x;
+  part[js][ii][1] = g2.x;
+  part[js][ii + 64][0] = g1.y;
+  part[js][ii + 64][1] = g2.y;
+  wg_sync();
+  if (tid < K2_P3_Q) {
+    const int q = tid, il = blockIdx.x * K2_P3_Q + q;
+    if (il < a.n_local) {
+      const int i = a.i0 + il;
+      float s1 = part[0][q][0], s2 = part[0][q][1];
+      for (int r = 1; r < 16; ++r) {
+        s1 += part[r][q][0];
+        s2 += part[r][q][1];
+      }
+      const size_t o = (size_t)i * D + g;
+      const float phi = s1 / (float)N + ((s2 * 2.0f) / h) / (float)N;
+      a.phi[o] = phi;
+      if (a.apply) {  // (update_from_phi_kernel's element)
+        float th = a.theta_rw[o];
+        const float gr = -phi;
+        if (a.optimizer == DUST_OPT_SGD) {
+          th = fmaf(-a.lr, gr, th);
+        } else {
+          float m = a.adam_m[o], v = a.adam_v[o];
+          th = adam_step(th, gr, m, v, a.lr, a.beta1, a.beta2, a.eps, (float)a.ctr[2]);
+          a.adam_m[o] = m;
+          a.adam_v[o] = v;
+        }
+        (a.theta_out ? a.theta_out : a.theta_rw)[o] = th;
+        if (a.thetaT_out) a.thetaT_out[(size_t)g * N + i] = th;
+      }
+    }
+  }
+  if (a.apply && blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int t = tid; t < a.fused_tiles; t += 1024) a.fused_cnt[t * 32] = 0u;
+    if (tid == 0) a.ctr[1] += 1u;
+  }
+}
+
 __global__ void k2_bandwidth_fixed_kernel(float *h, int G, float v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < G) h[i] = v;
@@ -956,7 +1031,9 @@ static inline int launch_k2_phi(hipStream_t stream, const K2Args &a) {
     k2_phi_kernel<2><<<grid, 256, 0, stream>>>(a);
   } else {
     static const bool one_q = getenv("DUST_K2_PHI1") != nullptr;  // development switch: one query per lane (k2_phi_kernel<1>)
+    static const bool two_q = getenv("DUST_K2_PHI2") != nullptr;  // development switch: the 256-lane launch at every size
     if (one_q && !a.x_rows) k2_phi_kernel<1><<<grid, 256, 0, stream>>>(a);
+    else if (a.N <= K2_P3_N && !two_q) k2_phi3_kernel<<<dim3((a.n_local + K2_P3_Q - 1) / K2_P3_Q, G), 1024, 0, stream>>>(a);
     else k2_phi2_kernel<<<dim3((a.n_local + 127) / 128, G), 256, 0, stream>>>(a);
   }
   return hipGetLastError() != hipSuccess ? DUST_ERR_HIP : DUST_OK;
