@@ -3,7 +3,7 @@
 # run), derived summaries stamped with the kernel sources they were measured on (tools/srcstamp.py).  Results land in gpurun_out/r6m/ ;
 # the summaries to be judged are copied to profiles/round6_* afterwards.
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6m; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6f; mkdir -p $O
 cd $R
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
@@ -48,6 +48,12 @@ python tools/trace_seq.py $(find /tmp/tr1 -name "*kernel_trace.csv" | head -1) 2
 timeout 300 python tools/shard_emul.py 1,2,4,8 160 2>&1 | grep cfg4 > $O/shard_emul_aged.txt
 timeout 300 python tools/peer_probe.py 2,4 > $O/peer_probe.txt 2>&1
 bash tools/path_survey.sh > $O/path_survey.txt 2>&1
+# cfg2 / K2: rate of the default form and of the launches apart, the steady-state launch sequence, the bandwidth role's own timeline
+(python tools/k2_seq.py 300; python tools/k2_seq.py 300; DUST_K2_FORM=0 python tools/k2_seq.py 300) > $O/k2_sequence.txt 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trk2 -o b -- python3 $R/tools/k2_seq.py 60 > /dev/null 2>&1)
+python tools/trace_seq.py $(find /tmp/trk2 -name "*kernel_trace.csv" | head -1) 16 >> $O/k2_sequence.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -DK2_STAMPS -Iinclude -Idust_amd/csrc tools/k2_bw_probe.hip -o /tmp/k2_bw_probe 2>/dev/null && /tmp/k2_bw_probe >> $O/k2_sequence.txt 2>&1
+(python tools/cfg5_seq.py 100; cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trc5 -o b -- python3 $R/tools/cfg5_seq.py 30 > /dev/null 2>&1; cd $R; python tools/trace_seq.py $(find /tmp/trc5 -name "*kernel_trace.csv" | head -1) 14) > $O/cfg5_control_sequence.txt 2>&1
 timeout 300 python tools/states_probe.py > $O/states_probe.txt 2>&1
 python tools/states_hbm.py $O/states_probe.txt $O/states_hbm.json > /dev/null
 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 DUST_BENCH_FORCE_DIST=1 timeout 400 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline > $O/sharded_world1_bench.json 2> $O/sharded_world1_bench.err
