@@ -55,7 +55,7 @@ static inline size_t particle_general_lds_bytes(int D, int grid_words, int mc) {
 // philox_normal8 block for every column it looked at, again for every dynamics sample: 8 M times too often - 7.5 ms per cfg3 tick
 // against 1.0 deterministic), and `mc` lanes share the pair: each runs every mc-th dynamics sample (a row per LANE left room for
 // 1.5 waves per SIMD: 5.6 ms; the dependent chain of a rollout wants many); the occupancy grid sits in LDS beside the rows; one
-// philox_normal4 serves the control noise of TWO steps; the step cost is the reference's own fp32 products summed pairwise with a
+// philox_normal8 serves the control noise of FOUR steps; the step cost is the reference's own fp32 products summed pairwise with a
 // compensated running sum (the arithmetic of the other Particle kernels: rollout.hpp PairKahan) instead of fp64 adds.
 __global__ __launch_bounds__(PARTGEN_NT) void particle_general_kernel(const PartGenArgs a) {
   extern __shared__ __attribute__((aligned(16))) float pg_lds[];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(PARTGEN_NT) void particle_general_kernel(const Part
     };
     put(0);
     float tot = 0.f, comp = 0.f;  // compensated running sum of the step costs
-    float zc[4] = {0.f, 0.f, 0.f, 0.f};
+    float zc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < H; ++t) {
       const float a0 = arow[2 * t], a1 = arow[2 * t + 1];
       // cost of the state BEFORE the action, raw action (disco.py:306; particle.py:170-198)
@@ -156,10 +156,12 @@ __global__ __launch_bounds__(PARTGEN_NT) void particle_general_kernel(const Part
           const float *zp = a.cz + ((size_t)t * a.M * SN + r) * 2;
           z0 = zp[0];
           z1 = zp[1];
-        } else {  // a stream of its own (key word 0x63747264 "ctrd"), one block of four normals per two steps
-          if ((t & 1) == 0) philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)(r >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, zc);
-          z0 = (t & 1) ? zc[2] : zc[0];
-          z1 = (t & 1) ? zc[3] : zc[1];
+        } else {  // a stream of its own (key word 0x63747264 "ctrd"), one block of EIGHT normals per four steps (philox_normal8: the policy
+                  // noise's generator - half the Philox rounds per normal of the four-normal block this loop drew from before)
+          if ((t & 3) == 0) philox_normal8(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)(r >> 32) ^ ((uint32_t)(t >> 2) << 8), ctr_iter, ctr_tick, zc);
+          const int q = t & 3;
+          z0 = q == 0 ? zc[0] : (q == 1 ? zc[2] : (q == 2 ? zc[4] : zc[6]));
+          z1 = q == 0 ? zc[1] : (q == 1 ? zc[3] : (q == 2 ? zc[5] : zc[7]));
         }
         u0 = u0 + a.dyn_std[0] * z0;
         u1 = u1 + a.dyn_std[1] * z1;

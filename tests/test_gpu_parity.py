@@ -750,19 +750,26 @@ def test_k2_launch_forms_agree(N, optimizer, monkeypatch):
     theta = (mu + 1.5 * rng.standard_normal((N, H, 1))).astype(np.float32)
     state = np.array([3.0, 0.0], np.float32)
     out = {}
-    for form in ("0", "2"):
-        monkeypatch.setenv("DUST_K2_FORM", form)
+    for form in ("0", "2", "pinned"):
+        monkeypatch.setenv("DUST_K2_FORM", "2" if form == "pinned" else form)
         c = Context(model="pendulum", N=N, S=S, M=1, H=H, kernel="K2", lr=0.5 if optimizer == "SGD" else 0.05, sigma_a=1.0, sigma_p=1.0,
                     optimizer=optimizer, seed=11)
         c.set_theta(theta); c.set_prior(mu); c.set_a_mat(theta)
+        if form == "pinned":  # the particles' address handed out (in-place collectives): one buffer, phi through a transposed copy again
+            import ctypes as C
+            from dust_amd import _lib as L
+
+            th, sc, nb = L.VP(), L.VP(), C.c_size_t(0)
+            L.check(L.load().dust_gather_buffers(c._h, C.byref(th), C.byref(sc), C.byref(nb)))
         hs = []
         for it in (3, 3, 3, 3, 2, 2, 2):  # (the third tick of a shape on is a replayed capture)
             c.svmpc_tick(state, it)
             hs.append(c.get_bandwidths().copy())
         out[form] = (c.get_theta(), np.array(hs))
         c.close()
-    assert np.array_equal(out["2"][1], out["0"][1]), "bandwidths differ"
-    assert np.array_equal(out["2"][0], out["0"][0]), elemerr(out["2"][0], out["0"][0])
+    for form in ("2", "pinned"):
+        assert np.array_equal(out[form][1], out["0"][1]), "bandwidths differ (%s)" % form
+        assert np.array_equal(out[form][0], out["0"][0]), (form, elemerr(out[form][0], out["0"][0]))
 
 
 @pytest.mark.parametrize("N", [1000, 1024, 2048, 3000])
