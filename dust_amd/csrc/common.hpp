@@ -277,7 +277,8 @@ __device__ __forceinline__ float inst_cost(const DevModel &dm, const float *x, c
 // inst_cost of the state BEFORE the action, then the step: the Particle model looks the same cell up for the obstacle
 // cost and for the crash mask - one lookup serves both.
 template <int MODEL>
-__device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &c, float *x, const float *a) {
+__device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &c, float *x, const float *a,
+                                                const float *un = nullptr /* Particle with control noise: the action that drives the dynamics */) {
   if (MODEL == DUST_MODEL_PENDULUM) {
     const float cost = inst_cost<MODEL>(dm, x, a);
     model_step<MODEL>(dm, c, x, a);
@@ -292,8 +293,9 @@ __device__ __forceinline__ float step_with_cost(const DevModel &dm, const Coef &
     const float ob = dm.with_obstacle ? dm.w_obs * coll : 0.0f;
     const float cost = (sc + (float)cc) + ob;
     const float dt = (float)dm.dt;
-    float ax = clampf(a[0] / c.c0, -dm.max_acc, dm.max_acc);
-    float ay = clampf(a[1] / c.c0, -dm.max_acc, dm.max_acc);
+    const float *ad = un ? un : a;
+    float ax = clampf(ad[0] / c.c0, -dm.max_acc, dm.max_acc);
+    float ay = clampf(ad[1] / c.c0, -dm.max_acc, dm.max_acc);
     float xd[4] = {x[2], x[3], ax, ay};
     if (crash) {
       float om = 1.0f - coll;
@@ -437,7 +439,9 @@ struct PairK {
 template <bool OBST, bool CRASH>
 __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const PairK &pk, const uint32_t *grid, const v2f mass, const v2f rmass, v2f *x, const float a0,
                                                   const float a1, const float cc /* control cost of (a0, a1), shared by both samples */,
-                                                  v2f *coll_io = nullptr) {
+                                                  v2f *coll_io = nullptr,
+                                                  const v2f *un = nullptr /* [2] the actions that DRIVE the two samples when the model adds control noise
+                                                                             (particle.py:144-153: the cost sees the raw action) */) {
   v2f coll = {0.f, 0.f};
   if (OBST) coll = coll_io ? *coll_io : collision_pair(dm, grid, x[0], x[1]);
   v2f dk[4];
@@ -446,7 +450,7 @@ __device__ __forceinline__ v2f particle_pair_step(const DevModel &dm, const Pair
   v2f cost = cost4_pair(dk, pk.w_state) + cc;
   if (OBST) cost = cost + dm.w_obs * coll;  // (without obstacles the reference adds +0 to a non-negative sum: identity)
   const float dt = (float)dm.dt;
-  const v2f av[2] = {{a0, a0}, {a1, a1}};
+  const v2f av[2] = {un ? un[0] : v2f{a0, a0}, un ? un[1] : v2f{a1, a1}};
   v2f acc[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {

@@ -209,6 +209,7 @@ struct dust_ctx {
   struct EnvSw {
     int comm_force, pair_big, pair_fused, states_form, dense, far, logp_mfma, no_fuse, no_persist, no_tick2,
         tick2_test_abort, tick2_test_timeout, no_comm_overlap;
+    int noise_general;  // DUST_NOISE_GENERAL=1 (development switch): control-channel noise always through particle_general.hpp's first pass
     int k2_form;     // DUST_K2_FORM=0 (development switch): K2's bandwidth launch stays behind the prior + rollout launch (rounds 1-5);
                      // default: the bandwidths ride in that launch, phi reads the row-major particles (round 6)
     int logp_pack;   // DUST_LOGP_PACK=0 / 1: the log-p pass never / always walks run lists (default: from 8 192 local rows on)
@@ -476,6 +477,7 @@ static void env_read(dust_ctx *c) {
   c->env.pack_order = env_int("DUST_PACK_ORDER");
   c->env.logp_pack = env_int("DUST_LOGP_PACK");
   c->env.k2_form = env_int("DUST_K2_FORM");
+  c->env.noise_general = env_int("DUST_NOISE_GENERAL");
   const char *ft = getenv("DUST_FAR_T");
   c->env.far_t = (ft && *ft) ? (float)atof(ft) : DUST_FAR_T_DEFAULT;
 }
@@ -1432,7 +1434,18 @@ static int launch_rollout(dust_ctx *c, const SampleOpts &o_in) {
       TRY(rollout_args(c, o, a, &nt, &lds));
     }
   }
-  if (particle_general(c) && o.costs_in == nullptr) {
+  // Control-channel noise with acceleration control, drawn on the device, nothing but costs wanted: the regular kernel draws it inside
+  // its own rollout loops (rollout.hpp, round 6: the packed pair path keeps its 40 instructions per step and sample and adds one
+  // eight-normal Philox block per two steps of a pair) - no first pass.  Recorded draws (the goldens), stored states, velocity control:
+  // particle_general.hpp below.
+  const bool noise_inline = particle_general(c) && o.costs_in == nullptr && c->cfg.control_type != DUST_CONTROL_VELOCITY && !o.want_states &&
+                            !a.mw && !(c->cz_dev && c->cz_next < c->cz_sets) && c->env.noise_general <= 0;
+  if (noise_inline) {
+    a.ctrl_noise = 1;
+    a.dyn_std[0] = c->cfg.dyn_std[0];
+    a.dyn_std[1] = c->cfg.dyn_std[1];
+  }
+  if (particle_general(c) && o.costs_in == nullptr && !noise_inline) {
     // pass 1 (particle_general.hpp): rollouts with control noise / velocity control + costs (+ states); pass 2: the regular kernel in
     // its injected-costs mode
     if (a.mw) return fail(DUST_ERR_UNSUPPORTED, "sigma-point weights are not implemented for Particle rollouts with control noise / velocity control");

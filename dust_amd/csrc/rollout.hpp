@@ -64,6 +64,11 @@ struct RolloutArgs {
                         // (one wait per time step): with the map in LDS the stores of the staged-states form overlap the loop
   int coef_given;       // no sampled parameters: the model coefficients were evaluated once on the host
   float coef_host[2];
+  // Particle(deterministic=False, noise_std != 0), acceleration control (particle.py:144-148: every step of every rollout draws
+  // acts = action + noise_std z, and the step cost sees the raw action): drawn inside the rollout loops (round 6) - a Philox stream
+  // of its own per rollout; recorded draws (tests) and velocity control keep particle_general.hpp
+  int ctrl_noise;
+  float dyn_std[2];
   const float *theta;   // [N_total][D] base of the noise (theta, or a_mat for MultiDISCO's own sampling)
   const float *noise;   // eps or actions [S][N_total][D] (device), or nullptr for Philox
   const float *params;  // [M][P] raw samples or nullptr
@@ -415,28 +420,56 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
         PairK pk;
         pk.load(a.dm);
         pk.pin();  // (VGPR pairs: with the packed cost sums the compiler runs out of SGPR pairs and parks odd-indexed splats in a stack slot)
-        auto pair_loop = [&](auto obst, auto crash) {
-          constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value;
+        auto pair_loop = [&](auto obst, auto crash, auto noisy) {
+          constexpr bool OB = decltype(obst)::value, CR = decltype(crash)::value, NZ = decltype(noisy)::value;
           put_pair(0);
-#pragma unroll 2  // (two steps per trip: the loop-carried register copies of a single-step body - 4 v_mov of 86 instructions - go away)
-          for (int t = 0; t < H; ++t) {
-            const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
-            const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
-            {
-              const v2f ky = c - kcomp;
-              const v2f kt = ksum + ky;
-              kcomp = (kt - ksum) - ky;
-              ksum = kt;
+          if constexpr (NZ) {
+            // control noise: ONE block of eight normals serves two steps of the lane's two rollouts (two channels each); the block is
+            // keyed by the first rollout of the pair (key word "ctrp"), the step pair, the iteration and the tick
+            const long rN = (long)m * SN + (long)s * N + n;
+            const v2f sd0 = {a.dyn_std[0], a.dyn_std[0]}, sd1 = {a.dyn_std[1], a.dyn_std[1]};
+            for (int t = 0; t < H; t += 2) {
+              float z[8];
+              philox_normal8(a.seed ^ 0x6374727000000000ull, (uint32_t)rN, (uint32_t)((unsigned long long)rN >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, z);
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                if (t + q < H) {
+                  const float a0 = actl[2 * (t + q)], a1 = actl[2 * (t + q) + 1];
+                  const v2f un[2] = {v2f{a0, a0} + sd0 * v2f{z[4 * q], z[4 * q + 2]}, v2f{a1, a1} + sd1 * v2f{z[4 * q + 1], z[4 * q + 3]}};
+                  const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1), nullptr, un);
+                  const v2f ky = c - kcomp;
+                  const v2f kt = ksum + ky;
+                  kcomp = (kt - ksum) - ky;
+                  ksum = kt;
+                  put_pair(t + q + 1);
+                }
+              }
             }
-            put_pair(t + 1);
+          } else {
+#pragma unroll 2  // (two steps per trip: the loop-carried register copies of a single-step body - 4 v_mov of 86 instructions - go away)
+            for (int t = 0; t < H; ++t) {
+              const float a0 = actl[2 * t], a1 = actl[2 * t + 1];
+              const v2f c = particle_pair_step<OB, CR>(a.dm, pk, dml.grid_bits, m2, r2, xp, a0, a1, particle_ctrl_cost(a.dm, a0, a1));
+              {
+                const v2f ky = c - kcomp;
+                const v2f kt = ksum + ky;
+                kcomp = (kt - ksum) - ky;
+                ksum = kt;
+              }
+              put_pair(t + 1);
+            }
           }
           const v2f tc = particle_pair_term<OB>(a.dm, dml.grid_bits, xp);
           tca = tc.x;
           tcb = tc.y;
         };
-        if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{});
-        else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{});
-        else pair_loop(std::true_type{}, std::false_type{});
+        if (a.ctrl_noise) {
+          if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{}, std::true_type{});
+          else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{}, std::true_type{});
+          else pair_loop(std::true_type{}, std::false_type{}, std::true_type{});
+        } else if (!dml.with_obstacle) pair_loop(std::false_type{}, std::false_type{}, std::false_type{});
+        else if (dml.can_crash) pair_loop(std::true_type{}, std::true_type{}, std::false_type{});
+        else pair_loop(std::true_type{}, std::false_type{}, std::false_type{});
         acc_m += (double)(ksum.x + tca);
         acc_m += (double)(ksum.y + tcb);
       }
@@ -536,11 +569,20 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           else if (row == H) flush(endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
         };
         if (so) put_and_flush(0);
+        float zc[4] = {0.f, 0.f, 0.f, 0.f};  // control noise of this rollout (key word "ctrd": one block of four normals per two steps)
         for (int t = 0; t < H; ++t) {
           float at[DA];
 #pragma unroll
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
-          const float ci = step_with_cost<MODEL>(dml, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
+          float ci;
+          if (MODEL == DUST_MODEL_PARTICLE && a.ctrl_noise) {
+            if ((t & 1) == 0) philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)((unsigned long long)r >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, zc);
+            float un[DA];
+#pragma unroll
+            for (int k = 0; k < DA; ++k) un[k] = at[k] + (k < 2 ? a.dyn_std[k & 1] * ((t & 1) ? zc[2 + (k & 1)] : zc[k & 1]) : 0.f);
+            ci = step_with_cost<MODEL>(dml, cf, x, at, un);
+          } else
+          ci = step_with_cost<MODEL>(dml, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
           // sigma-point rollouts: the reference pairs entry (m, t) of its flat [sigma][step] block with w[(m H + t) mod M]
           if (f_mw) tot.add_weighted((double)f_mw[((long)m * H + t) % a.M], ci);
           else tot.add(ci, t);

@@ -383,6 +383,49 @@ def test_particle_control_noise_philox_statistics():
     assert abs(np.corrcoef(vm[0], vm[1])[0, 1]) < 5 / np.sqrt(vm.shape[1])
 
 
+@pytest.mark.parametrize("M,obst", [(4, True), (2, False), (3, True)])
+def test_particle_control_noise_inside_the_rollout_kernel(M, obst, monkeypatch):
+    """Round 6: with acceleration control, device-drawn control noise and nothing but costs asked for, the regular rollout kernel draws
+    the noise inside its own loops (the packed pair path: one eight-normal block per two steps of a pair; the one-sample loop: four normals
+    per two steps) instead of running particle_general.hpp as a first pass (DUST_NOISE_GENERAL=1 - the path the goldens with recorded
+    draws pin).  The generators' streams differ, the law does not: the costs of both paths - policy noise zero, so control noise is the
+    only randomness - agree in mean and spread to sampling error, on the lean kernel (likelihood sample: pair path; M = 3 leaves a third
+    sample to the one-sample loop) and on the full one (omega wanted: one-sample loop); launches draw fresh noise; without noise the
+    kernel is the deterministic one."""
+    from dust_amd import Context
+    from oracle import grid_4x4_map
+
+    N, S, H, std = 96, 64, 24, (0.6, 0.4)
+    theta = np.full((N, H, 2), 0.4, np.float32)
+    theta[:, ::3, 1] = -0.7
+    st = np.array([-9.0, -9.0, 0.3, -0.2], np.float32)
+    params = (2.0 + 0.05 * np.arange(M, dtype=np.float32)).reshape(M, 1)
+    kw = dict(model="particle", N=N, S=S, M=M, H=H, uncertain_params=("mass",), sampling=True, with_obstacle=obst, can_crash=obst,
+              grid=grid_4x4_map() if obst else None, deterministic=False, noise_std=std, sigma_a=1.0, mass=2.0, dt=0.05, seed=5)
+    zeros = np.zeros((S, N, H, 2), np.float32)
+    acts = np.broadcast_to(theta, (S, N, H, 2)).copy()
+    out = {}
+    for general in ("0", "1"):
+        monkeypatch.setenv("DUST_NOISE_GENERAL", general)
+        c = Context(**kw)
+        c.set_theta(theta); c.set_a_mat(theta)
+        lean = [c.likelihood_sample(st, zeros, params).astype(np.float64) for _ in range(6)]
+        full = [c.disco_forward(st, acts, params)[0].astype(np.float64) for _ in range(6)]
+        assert not np.array_equal(lean[0], lean[1]) and not np.array_equal(full[0], full[1]), "every launch draws fresh control noise"
+        out[general] = (np.concatenate([x.ravel() for x in lean]), np.concatenate([x.ravel() for x in full]))
+        c.close()
+    for k, name in ((0, "lean kernel"), (1, "full kernel")):
+        a_, b_ = out["0"][k], out["1"][k]
+        n = a_.size
+        assert np.isfinite(a_).all() and a_.std() > 0
+        se = np.sqrt(a_.var() / n + b_.var() / n)
+        assert abs(a_.mean() - b_.mean()) < 5 * se, (name, a_.mean(), b_.mean(), se)
+        assert abs(a_.std() / b_.std() - 1.0) < 0.06, (name, a_.std(), b_.std())
+    # lean and full kernel of the inline path against each other (different loops, different streams, one law)
+    a_, b_ = out["0"]
+    assert abs(a_.mean() - b_.mean()) < 5 * np.sqrt(a_.var() / a_.size + b_.var() / b_.size)
+
+
 @pytest.mark.parametrize("name", ["mpf_pend_adam", "mpf_part_log_adam"])
 def test_mpf_adam(golden, name):
     """MPF with the reference's class-default optimiser (torch.optim.Adam): two filter updates from the reference's own run; the
