@@ -569,17 +569,26 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a, float *lds, c
           else if (row == H) flush(endb / CHB, endb < CHB ? ph : 0, endb & (CHB - 1));
         };
         if (so) put_and_flush(0);
-        float zc[4] = {0.f, 0.f, 0.f, 0.f};  // control noise of this rollout (key word "ctrd": one block of four normals per two steps)
+        float zc0 = 0.f, zc1 = 0.f, zc2 = 0.f, zc3 = 0.f;  // control noise of this rollout (key word "ctrd": one block of four normals per two steps;
+                                                            // four scalars - an array read with (t & 1) became a scratch slot with a dynamic index)
         for (int t = 0; t < H; ++t) {
           float at[DA];
 #pragma unroll
           for (int k = 0; k < DA; ++k) at[k] = act[t * DA + k];
           float ci;
           if (MODEL == DUST_MODEL_PARTICLE && a.ctrl_noise) {
-            if ((t & 1) == 0) philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)((unsigned long long)r >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, zc);
+            if ((t & 1) == 0) {
+              float zn[4];
+              philox_normal4(a.seed ^ 0x6374726400000000ull, (uint32_t)r, (uint32_t)((unsigned long long)r >> 32) ^ ((uint32_t)(t >> 1) << 8), ctr_iter, ctr_tick, zn);
+              zc0 = zn[0];
+              zc1 = zn[1];
+              zc2 = zn[2];
+              zc3 = zn[3];
+            }
+            const float zq[2] = {(t & 1) ? zc2 : zc0, (t & 1) ? zc3 : zc1};
             float un[DA];
 #pragma unroll
-            for (int k = 0; k < DA; ++k) un[k] = at[k] + (k < 2 ? a.dyn_std[k & 1] * ((t & 1) ? zc[2 + (k & 1)] : zc[k & 1]) : 0.f);
+            for (int k = 0; k < DA; ++k) un[k] = at[k] + (k < 2 ? a.dyn_std[k & 1] * zq[k & 1] : 0.f);
             ci = step_with_cost<MODEL>(dml, cf, x, at, un);
           } else
           ci = step_with_cost<MODEL>(dml, cf, x, at);  // cost of the state BEFORE the action (disco.py:306)
