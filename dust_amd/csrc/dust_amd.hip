@@ -3110,6 +3110,7 @@ static int step_device(dust_ctx *c, const float *noise_dev, int param_set) {
                       c->k2_fixed_h <= 0.f && c->da <= 2;
   int sl = local_score_device(c, noise_dev, param_set);
   c->k2_inline_want = false;
+  if (sl != DUST_OK) c->k2_bw_ahead = c->k2_bw_inline = false;  // (no phi launch will consume the bandwidths of this theta)
   TRY(sl);
   TRY(launch_stein_update(c, 1, true));
   return DUST_OK;
