@@ -815,7 +815,7 @@ def test_k2_launch_forms_agree(N, optimizer, monkeypatch):
         assert np.array_equal(out[form][0], out["0"][0]), (form, elemerr(out[form][0], out["0"][0]))
 
 
-@pytest.mark.parametrize("N", [1000, 1024, 2048, 3000])
+@pytest.mark.parametrize("N", [8, 64, 260, 1000, 1024, 2048, 3000])
 def test_k2_bandwidth_is_the_exact_order_statistic(N):
     """h_c = median(pairwise squared distances) / log(N+1) with torch.median's lower-middle rule over all N^2 entries
     (base_kernels.py:53-77): the GPU selects it by bisection on the float's bit pattern - it must be the exact value, for
@@ -827,6 +827,8 @@ def test_k2_bandwidth_is_the_exact_order_statistic(N):
     mu = rng.standard_normal((N, H, 1)).astype(np.float32)
     theta = (mu + rng.standard_normal((N, H, 1))).astype(np.float32)
     theta[: N // 7, 1, 0] = theta[0, 1, 0]  # ties and zero distances in one dimension
+    if N == 260:
+        theta[:, 2, 0] = 1.25  # a constant column: every distance is zero, the bandwidth is the clamp
     c = Context(model="pendulum", N=N, S=8, M=1, H=H, kernel="K2", lr=0.0, sigma_a=1.0, sigma_p=1.0)
     c.set_theta(theta)
     c.set_prior(mu)
