@@ -93,18 +93,21 @@ def main():
         real_run = run
         # a single row is timed right after process start: 10 ticks on cold clocks read 20-30 % low (round 6: an A/B of the noisy cfg3 row
         # came out backwards that way) - half a second of cfg2 ticks first
-        wc = Context(model="pendulum", N=1024, S=128, M=1, H=30, kernel="K1", lr=2.0, sigma_a=2.0, sigma_p=2.0, seed=1)
-        w0 = np.zeros((1024, 30, 1), np.float32)
-        wc.set_theta(w0); wc.set_prior(w0); wc.set_a_mat(w0)
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < 0.5:
-            for _ in range(50):
-                wc.svmpc_tick(np.array([3.0, 0.0], np.float32), 5, want_outputs=False)
-            wc.sync()
-        wc.close()
+        wc = None if os.environ.get("DUST_CONFIGS_NO_WARM") else Context(model="pendulum", N=1024, S=128, M=1, H=30, kernel="K1", lr=2.0, sigma_a=2.0, sigma_p=2.0, seed=1)
+        if wc is not None:
+            w0 = np.zeros((1024, 30, 1), np.float32)
+            wc.set_theta(w0); wc.set_prior(w0); wc.set_a_mat(w0)
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.5:
+                for _ in range(50):
+                    wc.svmpc_tick(np.array([3.0, 0.0], np.float32), 5, want_outputs=False)
+                wc.sync()
+            wc.close()
+
+        exact = os.environ.get("DUST_CONFIGS_EXACT")  # the row's whole name ("cfg3" alone also names the noisy / velocity rows)
 
         def run(name, *a, **k):  # noqa: F811
-            return real_run(name, *a, **k) if only in name else dict(config=name, skipped=True)
+            return real_run(name, *a, **k) if (name == only if exact else only in name) else dict(config=name, skipped=True)
 
     out.append(run("cfg1", 300, 30, "pendulum", 32, 128, 1, 15, 1))
     out.append(run("cfg2 (bench.py)", 300, 30, "pendulum", 1024, 128, 1, 30, 5))
