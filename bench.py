@@ -496,7 +496,7 @@ def main():
             while n_wcl < args.warmup or time.perf_counter() - t0 < MIN_WARM_S:  # the same warm-up rule, by time
                 a_seq, _ = ctx.svmpc_tick(st, w["n_iters"], want_outputs="action")
                 n_wcl += 1
-            n_cl = max(args.steps, 200)  # (a loop of 20 ticks is 2 ms: at least 200)
+            n_cl = max(args.steps, 1000)  # (a loop of 20 ticks is 2 ms; 200 ticks - 19 ms - read 9 770 once where five other runs read 10.4-10.65 k: 1 000)
             s0 = ctx.tick_stats()
             t0 = time.perf_counter()
             for _ in range(n_cl):
