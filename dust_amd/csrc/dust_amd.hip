@@ -2807,10 +2807,30 @@ static int launch_stein_update(dust_ctx *c, int apply, bool in_loop = false /* K
     if (fuse) {
       // Stein tiles + update role in ONE launch (fused.hpp): the update launch and its ramp disappear
       if (c->stein_dirty) HIP_TRY(hipMemsetAsync(c->stein_cnt, 0, ((size_t)tiles + 1) * CNT_STRIDE * sizeof(unsigned int), c->stream));  // (not the time-out word)
+      // More key slices for the Stein tiles than for the prior tiles (which share their launch with the rollouts and are better off
+      // few): a Stein workgroup is a chain of dependent chunk passes, and at ~500 of them the chip holds 2 waves per SIMD - cfg5
+      // (64 tiles x 8 slices of 4 chunks): 26.5 us; 16 slices of 2: 24.7 (round 6).  The update role sums the slices this launch wrote.
+      static const bool stein_fine = getenv("DUST_STEIN_JS") == nullptr || atoi(getenv("DUST_STEIN_JS")) != 0;  // development switch
+      if (stein_fine) {
+        int js2 = a.JS, sl2 = a.slice;
+        while (tiles * js2 < 1024 && js2 * 2 <= 16 && sl2 >= 2 * PAIR_JC && (sl2 / 2) % PAIR_JC == 0) {
+          sl2 /= 2;
+          js2 = (c->N + sl2 - 1) / sl2;
+        }
+        const size_t need = (size_t)js2 * c->nloc * 8 * cpt;
+        if (js2 != a.JS && js2 <= 16 && (!c->capturing || (c->pA_cap >= need && c->pB_cap >= need))) {
+          TRY(ensure_partials(c, js2));
+          a.JS = js2;
+          a.slice = sl2;
+          a.pA = c->pA;
+          a.pB = c->pB;
+        }
+      }
       SteinUpdateArgs f;
       memset(&f, 0, sizeof f);
       f.pa = a;
       f.ua = update_args(c, 1);
+      f.ua.JS = a.JS;
       // unsharded: the update writes the OTHER theta buffer, so its role may start per query tile while other Stein tiles
       // still read the current one; sharded contexts expose theta's address to the collectives and keep one buffer
       const bool pingpong = c->nloc == c->N && !c->theta_pinned;
